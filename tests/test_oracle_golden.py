@@ -1,0 +1,111 @@
+"""Pin the CPU oracle (oracle/ba_oracle.py) against vectors produced by the real reference."""
+import numpy as np
+import pytest
+from scipy import sparse
+
+from oracle import ba_oracle as orc
+from golden_util import CASES, load_case
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_pack_matches_reference_x0(name):
+    scene, g = load_case(name)
+    prob, x0 = orc.problem_from_scene(scene)
+    assert x0.shape == g['x0'].shape
+    np.testing.assert_allclose(x0, g['x0'], rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_residual_matches_reference(name):
+    scene, g = load_case(name)
+    prob, _ = orc.problem_from_scene(scene)
+    f0 = orc.residual(prob, g['x0'])
+    assert f0.shape == g['f_x0'].shape
+    np.testing.assert_allclose(f0, g['f_x0'], rtol=0, atol=1e-9)
+    f1 = orc.residual(prob, g['x0'] + g['delta'])
+    np.testing.assert_allclose(f1, g['f_x0_delta'], rtol=0, atol=1e-9)
+    # the zero pattern (non-visible detections) is integer information: exact
+    assert np.array_equal(f0 == 0, g['f_x0'] == 0)
+    assert np.array_equal(f1 == 0, g['f_x0_delta'] == 0)
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_pattern_matches_reference_bit_exact(name):
+    scene, g = load_case(name)
+    prob, _ = orc.problem_from_scene(scene)
+    A = orc.jac_pattern(prob, g['x0']).tocoo()
+    assert tuple(A.shape) == tuple(g['pattern_shape'])
+    order = np.lexsort((A.col, A.row))
+    assert np.array_equal(A.row[order], g['pattern_rows'])
+    cols = A.col[order]
+    if not np.array_equal(cols, g['pattern_cols']):
+        # the only legal difference: a tie between the two coincident end knots broken the
+        # other way by numpy's unstable argsort (see oracle.jac_pattern) -> neighbouring column
+        diff = np.nonzero(cols != g['pattern_cols'])[0]
+        assert diff.size < 0.02 * cols.size
+        assert np.all(np.abs(cols[diff].astype(np.int64) - g['pattern_cols'][diff]) == 1)
+
+
+# The reference estimates the Jacobian by forward differences with h ~ 1.5e-8 (scipy '2-point'),
+# which amplifies last-bit differences of the residual (4.5e-13 px between this restatement and
+# the reference) to ~1e-5 relative noise in J.  Its 10-evaluation, unconverged iterate is
+# therefore only reproducible to ~1e-4 relative in cost (measured: +-7e-4 px RMSE (pinhole case) to +-1e-2 px (calib+KE+bounds case) under a
+# 1e-15 relative perturbation of the residual, see DESIGN.md "parity").  Tolerances below are
+# that noise floor, not a property of this restatement.
+SOLVE_COST_RTOL = 5e-3
+SOLVE_RMSE_ATOL = 2.5e-2
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_solve_matches_reference(name):
+    scene, g = load_case(name)
+    prob, _ = orc.problem_from_scene(scene)
+    res = orc.solve(prob, g['x0'], max_iter=10)
+    assert res.nfev == int(g['ba10_nfev'])
+    assert res.status == int(g['ba10_status'])
+    np.testing.assert_allclose(res.cost, float(g['ba10_cost']), rtol=SOLVE_COST_RTOL)
+    np.testing.assert_allclose(orc.reprojection_rmse(prob, res.x), float(g['ba10_rmse']), rtol=0,
+                               atol=SOLVE_RMSE_ATOL)
+    # the golden iterate itself evaluates to the golden cost through the oracle residual
+    f = orc.residual(prob, g['ba10_x'])
+    np.testing.assert_allclose(0.5 * f @ f, float(g['ba10_cost']), rtol=1e-10)
+    np.testing.assert_allclose(f, g['ba10_fun'], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(orc.reprojection_rmse(prob, g['ba10_x']), float(g['ba10_rmse']), rtol=0, atol=1e-9)
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_outlier_mask_bit_exact(name):
+    scene, g = load_case(name)
+    prob, _ = orc.problem_from_scene(scene)
+    keep = np.concatenate(orc.outlier_keep_mask(prob, g['ba10_x'], float(g['thres_outlier'])))
+    assert np.array_equal(keep.astype(np.uint8), g['outlier_keep'])
+
+
+def test_splev3_matches_scipy():
+    from scipy.interpolate import splev
+    rng = np.random.default_rng(0)
+    for n_int in (0, 1, 5, 40):
+        inner = np.sort(rng.uniform(3.0, 97.0, n_int))
+        t = np.concatenate(([2.5] * 4, inner, [98.25] * 4))
+        c = [rng.normal(size=t.size - 4) for _ in range(3)]
+        x = np.concatenate((rng.uniform(2.5, 98.25, 500), [2.5, 98.25], inner))
+        got = orc.splev3(x, [t, c, 3])
+        ref = np.asarray(splev(x, [t, c, 3]))
+        np.testing.assert_allclose(got, ref, rtol=0, atol=1e-12)
+
+
+def test_rodrigues_roundtrip():
+    rng = np.random.default_rng(1)
+    for _ in range(50):
+        r = rng.normal(size=3)
+        r *= rng.uniform(0, 3.1) / np.linalg.norm(r)
+        R = orc.rodrigues(r)
+        np.testing.assert_allclose(R @ R.T, np.eye(3), atol=1e-14)
+        np.testing.assert_allclose(orc.rotation_to_rvec(R), r, atol=1e-9)
+    np.testing.assert_array_equal(orc.rodrigues(np.zeros(3)), np.eye(3))
+
+
+def test_sampling_half_open():
+    interval = np.array([[0.0, 20.0], [10.0, 30.0]])
+    ts = np.array([-1.0, 0.0, 5.0, 10.0, 15.0, 20.0, 29.999, 30.0])
+    assert orc.sampling_idx(ts, interval).tolist() == [0, 1, 1, 0, 0, 2, 2, 0]
