@@ -1,0 +1,177 @@
+/* mvus_ba.h -- C ABI of libmvusba.so, the MI355X (gfx950) bundle-adjustment core.
+ *
+ * The reference (CenekAlbl/mvus) has no FFI on this path: the boundary is the Python call
+ *
+ *     res = least_squares(fn, model, jac_sparsity=A, tr_solver='lsmr', xtol=1e-12,
+ *                         max_nfev=max_iter, verbose=0, bounds=bounds_rs)
+ *                                   (multiviewunsynch/reconstruction/common.py:670)
+ *
+ * inside Scene.BA (common.py:441-697) with fn = error_BA (common.py:448-487) and A = jac_BA()
+ * (common.py:490-610), plus Scene.remove_outliers (common.py:700-717).  The entry points below are
+ * what a ctypes binding placed at that call site needs; each one cites the reference code it
+ * replaces.  INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative MVUS_E_* code; nothing throws across the ABI;
+ *     mvus_last_error() gives the message of the last failure on the handle (or, with NULL, of the
+ *     last failed mvus_ba_create on this thread);
+ *   - all `const double*` / `double*` arguments are HOST pointers unless the name ends in `_dev`;
+ *     the caller owns every buffer it passes; the handle owns all device memory;
+ *   - the parameter vector x has the reference layout (common.py:615-650):
+ *       [alpha(C) beta(C) rs(C) cam_0(P) .. cam_{C-1}(P) spline_0: cx(n_0) cy(n_0) cz(n_0) spline_1 ..]
+ *     P = 6 (rvec,t) or 15 (fx,fy,cx,cy,rvec,t,k1,k2,p1,p2,k3) when opt_calib (common.py:1113-1124);
+ *   - the residual vector f has the reference row order (common.py:476-485): per camera
+ *     [|ex|(M_c) |ey|(M_c)], then the motion-regulariser rows (T);
+ *   - one handle per (host thread, GPU, stream); calls on one handle must not overlap.
+ *   - there is NO CPU fallback: without a HIP device mvus_ba_create fails with MVUS_E_HIP.
+ */
+#ifndef MVUS_BA_H
+#define MVUS_BA_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MVUS_OK 0
+#define MVUS_E_INVALID (-1)  /* bad argument / inconsistent problem description */
+#define MVUS_E_HIP (-2)      /* HIP runtime error (no device, allocation, launch) */
+#define MVUS_E_NUMERIC (-3)  /* non-finite residuals at x0, x0 outside bounds (scipy raises ValueError) */
+#define MVUS_E_COMM (-4)     /* the all-reduce callback reported a failure */
+
+#define MVUS_MOTION_F 0  /* constant-force prior       common.py:984-998 */
+#define MVUS_MOTION_KE 1 /* constant-kinetic-energy    common.py:976-981 */
+
+/* Jacobian used by mvus_ba_solve */
+#define MVUS_JAC_ANALYTIC 0 /* full analytic block-sparse Jacobian */
+#define MVUS_JAC_PATTERN 1  /* analytic, masked to the reference sparsity pattern jac_BA builds at x0
+                               (3 nearest knots per row, common.py:559-563,573-585) */
+
+/* Solver used by mvus_ba_solve */
+#define MVUS_SOLVER_TRF_LSMR 0 /* restatement of scipy trf + lsmr (the reference's optimiser), J kept as operator */
+#define MVUS_SOLVER_LM_SCHUR 1 /* Levenberg-Marquardt on device-assembled normal equations, spline block
+                                  eliminated by a block-banded Cholesky, dense reduced camera system */
+
+typedef struct mvus_ba mvus_ba; /* opaque */
+
+/* The Scene state Scene.BA closes over (common.py:441-697), cameras in sequence[:numCam] order. */
+typedef struct mvus_problem {
+  int32_t num_cam;       /* C = numCam */
+  int32_t opt_calib;     /* settings['opt_calib']      common.py:621 */
+  int32_t undist_points; /* settings['undist_points']  common.py:126 */
+  int32_t rs_free;       /* `rs` argument of Scene.BA: rolling-shutter column in the pattern, common.py:518 */
+  int32_t rs_bounds;     /* `rs_bounds`: 0 <= rs <= 1   common.py:655-662 */
+  int32_t motion_reg;    /* `motion_reg`                common.py:483-485 */
+  int32_t motion_type;   /* MVUS_MOTION_*  settings['motion_type'] common.py:416-420 */
+  double motion_weight;  /* `motion_weights`            common.py:413 */
+  const int64_t* det_offsets; /* [C+1] detections of camera c are [det_offsets[c], det_offsets[c+1]) */
+  const double* frame;        /* [M] detections[c][0]  (np.loadtxt usecols=(2,0,1), common.py:1190) */
+  const double* u_raw;        /* [M] detections[c][1] */
+  const double* v_raw;        /* [M] detections[c][2] */
+  const double* img_height;   /* [C] cameras[c].resolution[1]  common.py:125 */
+  const double* K;            /* [C*4] fx fy cx cy, used when !opt_calib */
+  const double* dist;         /* [C*5] k1 k2 p1 p2 k3, used when !opt_calib */
+  int32_t num_splines;        /* S = spline['int'].shape[1] */
+  const double* interval;     /* [2*S] row-major spline['int']: S starts then S ends */
+  const int64_t* knot_offsets; /* [S+1] */
+  const double* knots;        /* concatenated spline['tck'][s][0] */
+  int32_t device;             /* HIP device ordinal */
+  void* stream;               /* hipStream_t to run on, or NULL for a stream owned by the handle */
+} mvus_problem;
+
+typedef struct mvus_solve_opts {
+  int32_t solver;    /* MVUS_SOLVER_* */
+  int32_t jac_mode;  /* MVUS_JAC_* */
+  int32_t max_nfev;  /* max_iter of Scene.BA (10)           common.py:441,670 */
+  double ftol;       /* 1e-8  scipy default                  */
+  double xtol;       /* 1e-12 as passed at common.py:670     */
+  double gtol;       /* 1e-8  scipy default                  */
+  double lsmr_atol;  /* 1e-6  scipy lsmr default             */
+  double lsmr_btol;  /* 1e-6                                 */
+  double lsmr_conlim; /* 1e8                                 */
+  int32_t lsmr_maxiter; /* 0 -> min(m, n)                    */
+  int32_t verbose;
+} mvus_solve_opts;
+
+/* scipy.optimize.OptimizeResult fields Scene.BA returns (common.py:670,697) */
+typedef struct mvus_result {
+  double cost;        /* 0.5*|f|^2 */
+  double optimality;  /* |g|_inf (scaled by the Coleman-Li vector when bounded) */
+  int32_t nfev, njev;
+  int32_t status;     /* 0 max_nfev, 1 gtol, 2 ftol, 3 xtol, 4 ftol&xtol (scipy codes) */
+  int32_t lin_iters;  /* total LSMR iterations / Cholesky solves */
+  double solve_ms;    /* wall time of the call */
+  double initial_cost;
+} mvus_result;
+
+/* sum-all-reduce of `count` doubles at device address `buf_dev`, issued on `stream`; returns 0 on success.
+ * Called by the solver once per normal-equation assembly / J^T u product when observations are sharded. */
+typedef int (*mvus_allreduce_fn)(void* user, void* buf_dev, size_t count, void* stream);
+
+void mvus_default_opts(mvus_solve_opts* opts);
+
+/* Copies the problem to the GPU, undistorts observations once when calibration is fixed
+ * (detection_to_global, common.py:126).  */
+int mvus_ba_create(const mvus_problem* p, mvus_ba** out);
+void mvus_ba_destroy(mvus_ba* h);
+const char* mvus_last_error(const mvus_ba* h);
+
+int64_t mvus_ba_num_params(const mvus_ba* h);      /* n = 3C + C*P + 3*sum(n_s)            common.py:652 */
+int64_t mvus_ba_num_residuals(const mvus_ba* h);   /* m = 2M + T                                          */
+int64_t mvus_ba_num_motion_rows(const mvus_ba* h); /* T = len(spline_to_traj()[0]) when motion_reg else 0 */
+int32_t mvus_ba_num_slots(const mvus_ba* h);       /* NS = 3 + P + 12 Jacobian slots per residual row     */
+
+/* error_BA(x): f[m]  (common.py:448-487) */
+int mvus_ba_residual(mvus_ba* h, const double* x, double* f);
+
+/* Residual plus block-sparse Jacobian of the 2M detection rows (analytic; replaces the 2-point finite
+ * differences scipy takes over jac_BA's pattern).  Outputs (any may be NULL):
+ *   f[m];  J[2*NS*M]: J[(a*NS + k)*M + i] = d|e_a(i)| / d slot k, a = 0 (x) / 1 (y), observation i in
+ *   camera-segmented order; slots: 0 alpha, 1 beta, 2 rs, 3..3+P camera params, 3+P+3q+d control point
+ *   ctrl[i]+q coordinate d;  ctrl[M]: global index of the first active control point, -1 if not visible. */
+int mvus_ba_residual_jacobian(mvus_ba* h, const double* x, int32_t jac_mode, double* f, double* J, int32_t* ctrl);
+
+/* Motion-regulariser rows and their Jacobian: mf[T], mJ[36*T] (mJ[k*T + j], k = 12*sample + 3*q + d for the
+ * samples j-1, j, j+1), mctrl[3*T] first control point of each of the three samples (-1 = unused). */
+int mvus_ba_motion_rows(mvus_ba* h, const double* x, int32_t jac_mode, double* mf, double* mJ, int32_t* mctrl);
+
+/* Fix the reference sparsity pattern at x0 (jac_BA + compute_visibility, common.py:427-438,490-610):
+ * pat[M] = global index of the first of the three in-pattern control points, -1 for all-zero rows. */
+int mvus_ba_set_pattern(mvus_ba* h, const double* x0, int32_t* pat_out);
+
+/* y[m] = J v (v[n]);  z[n] = J^T u (u[m]) with the Jacobian currently held by the handle
+ * (after mvus_ba_residual_jacobian / inside solve).  Test and integration hooks for the operator. */
+int mvus_ba_jv(mvus_ba* h, const double* v, double* y);
+int mvus_ba_jtu(mvus_ba* h, const double* u, double* z);
+
+/* Gauss-Newton normal equations of the current Jacobian: dense copies for inspection.
+ *   g[n] = J^T f;  JtJ_cam[C*B*B] camera diagonal blocks, B = 3+P (row-major);
+ *   band: block-banded spline part, band[((g*W + w)*3 + a)*3 + b] = (J^T J)[3g+a, 3(g+w)+b], w < W;
+ *   cross[C*B*3N]: cross[(c*B + k)*3N + 3g + d].  Any output may be NULL; *W_out receives W. */
+int mvus_ba_normal_equations(mvus_ba* h, double* g, double* JtJ_cam, double* band, double* cross, int32_t* W_out);
+
+/* The least_squares call of Scene.BA (common.py:670) -- x is read and overwritten with res.x.
+ * lb/ub come from opts of the problem (rs_bounds).  f_out[m] may be NULL. */
+int mvus_ba_solve(mvus_ba* h, double* x, const mvus_solve_opts* opts, mvus_result* res, double* f_out);
+
+/* Scene.remove_outliers (common.py:700-717): keep[i] = sqrt(ex^2 + ey^2) < thres, camera-segmented order. */
+int mvus_ba_outlier_mask(mvus_ba* h, const double* x, double thres, uint8_t* keep);
+
+/* Multi-GPU: observations sharded across ranks, this handle holds one shard.  `is_root` ranks add the
+ * replicated terms (motion rows, damping) exactly once. */
+int mvus_ba_set_allreduce(mvus_ba* h, mvus_allreduce_fn fn, void* user, int32_t is_root);
+
+/* Measurement hook for bench.py: runs `launches` back-to-back launches of one kernel on the handle's
+ * stream between two hipEvents and returns the average duration in milliseconds.
+ *   which: 0 residual, 1 residual+Jacobian, 2 J v, 3 J^T u, 4 normal-equation assembly */
+int mvus_ba_time_kernel(mvus_ba* h, int32_t which, int32_t launches, double* avg_ms);
+
+/* Upload x to the handle without evaluating anything (used with mvus_ba_time_kernel). */
+int mvus_ba_set_x(mvus_ba* h, const double* x);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MVUS_BA_H */

@@ -1,0 +1,133 @@
+// Host-side preparation of one BA problem: validation of the mvus_problem description and the
+// derived tables the kernels index with (launch chunks, control-point -> x index maps, the
+// parameter-independent motion-regulariser samples).  Pure host C++ (no HIP), shared by the HIP
+// backend (which uploads these arrays once) and by the test-only host backend.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/mvus_ba.h"
+#include "ba_math.h"
+
+namespace mvus {
+
+constexpr int kChunk = 256;  // observations per workgroup; a chunk never straddles two cameras
+
+struct HostProblem {
+  int C = 0, P = 6, NS = 21, S = 0;
+  int calib = 0, undist = 1, rs_free = 0, rs_bounds = 0, motion_reg = 0, motion_type = 0;
+  double w = 1.0;
+  int64_t M = 0, n = 0, m = 0;
+  int T = 0, N = 0;
+  std::vector<int64_t> det_off;
+  std::vector<double> frame, u_raw, v_raw, H, K, dist, istart, iend, knots;
+  std::vector<int32_t> knot_off, ctrl_off, xoff, ctrl_x0, ctrl_stride;
+  std::vector<int32_t> chunk_cam, chunk_count;
+  std::vector<int64_t> chunk_start;
+  std::vector<double> ms_t, ms_basis;
+  std::vector<int32_t> ms_ctrl, ms_part, ms_pat;
+
+  SplineView spline_view() const {
+    return SplineView{S, istart.data(), iend.data(), knots.data(), knot_off.data(), ctrl_off.data(), xoff.data()};
+  }
+  MotionView motion_view() const {
+    return MotionView{T, motion_type, w, ms_t.data(), ms_basis.data(), ms_ctrl.data(), ms_part.data(), ms_pat.data(),
+                      ctrl_x0.data(), ctrl_stride.data()};
+  }
+
+  // returns "" on success, otherwise what is wrong with the description
+  std::string build(const mvus_problem* p) {
+    if (!p) return "problem is NULL";
+    C = p->num_cam;
+    if (C < 1) return "num_cam must be >= 1";
+    calib = p->opt_calib != 0; undist = p->undist_points != 0; rs_free = p->rs_free != 0;
+    rs_bounds = p->rs_bounds != 0; motion_reg = p->motion_reg != 0; motion_type = p->motion_type;
+    if (motion_reg && motion_type != MVUS_MOTION_F && motion_type != MVUS_MOTION_KE)
+      return "Motion type must be either F or KE";          // common.py:416
+    w = p->motion_weight;
+    P = calib ? 15 : 6;
+    NS = 3 + P + 12;
+    if (!p->det_offsets || !p->img_height || !p->interval || !p->knot_offsets || !p->knots) return "NULL array in problem";
+    det_off.assign(p->det_offsets, p->det_offsets + C + 1);
+    if (det_off[0] != 0) return "det_offsets[0] must be 0";
+    for (int c = 0; c < C; ++c) if (det_off[c + 1] < det_off[c]) return "det_offsets must be non-decreasing";
+    M = det_off[C];
+    if (M > 0 && (!p->frame || !p->u_raw || !p->v_raw)) return "NULL detection array";
+    frame.assign(p->frame, p->frame + M); u_raw.assign(p->u_raw, p->u_raw + M); v_raw.assign(p->v_raw, p->v_raw + M);
+    H.assign(p->img_height, p->img_height + C);
+    K.assign(4 * C, 0.0); dist.assign(5 * C, 0.0);
+    if (!calib) {
+      if (!p->K || !p->dist) return "K and dist are required when opt_calib is off";
+      K.assign(p->K, p->K + 4 * C); dist.assign(p->dist, p->dist + 5 * C);
+    } else if (p->K && p->dist) {
+      K.assign(p->K, p->K + 4 * C); dist.assign(p->dist, p->dist + 5 * C);
+    }
+    S = p->num_splines;
+    if (S < 1) return "num_splines must be >= 1";
+    istart.assign(p->interval, p->interval + S);
+    iend.assign(p->interval + S, p->interval + 2 * S);
+    for (int s = 0; s < S; ++s) {
+      if (!(iend[s] > istart[s])) return "spline interval with end <= start";
+      if (s > 0 && !(istart[s] > iend[s - 1])) return "spline intervals must be sorted and disjoint";   // util.py:82
+    }
+    knot_off.resize(S + 1); ctrl_off.resize(S + 1); xoff.resize(S);
+    ctrl_off[0] = 0;
+    for (int s = 0; s <= S; ++s) knot_off[s] = (int32_t)p->knot_offsets[s];
+    if (knot_off[0] != 0) return "knot_offsets[0] must be 0";
+    knots.assign(p->knots, p->knots + knot_off[S]);
+    int64_t xo = (int64_t)C * (3 + P);
+    for (int s = 0; s < S; ++s) {
+      const int nk = knot_off[s + 1] - knot_off[s];
+      if (nk < 8) return "a cubic spline needs at least 8 knots";
+      const int ns = nk - 4;
+      const double* t = knots.data() + knot_off[s];
+      for (int k = 1; k < nk; ++k) if (t[k] < t[k - 1]) return "knot vector must be non-decreasing";
+      for (int k = 3; k < ns; ++k) if (!(t[k + 1] > t[k])) return "interior knots must be distinct";
+      ctrl_off[s + 1] = ctrl_off[s] + ns;
+      xoff[s] = (int32_t)xo;
+      xo += 3 * (int64_t)ns;
+    }
+    N = ctrl_off[S];
+    n = xo;
+    ctrl_x0.resize(N); ctrl_stride.resize(N);
+    for (int s = 0; s < S; ++s)
+      for (int g = ctrl_off[s]; g < ctrl_off[s + 1]; ++g) { ctrl_x0[g] = xoff[s] + (g - ctrl_off[s]); ctrl_stride[g] = ctrl_off[s + 1] - ctrl_off[s]; }
+    // launch chunks
+    chunk_cam.clear(); chunk_start.clear(); chunk_count.clear();
+    for (int c = 0; c < C; ++c)
+      for (int64_t a = det_off[c]; a < det_off[c + 1]; a += kChunk) {
+        chunk_cam.push_back(c); chunk_start.push_back(a);
+        chunk_count.push_back((int32_t)std::min<int64_t>(kChunk, det_off[c + 1] - a));
+      }
+    // motion samples: ts = arange(int[0,0], int[1,-1], 1) kept where start <= ts <= end (common.py:289-292)
+    ms_t.clear(); ms_basis.clear(); ms_ctrl.clear(); ms_part.clear(); ms_pat.clear();
+    T = 0;
+    if (motion_reg) {
+      const double a0 = istart[0], b0 = iend[S - 1];
+      const int64_t len = (b0 > a0) ? (int64_t)std::ceil(b0 - a0) : 0;
+      for (int s = 0; s < S; ++s) {
+        const double* t = knots.data() + knot_off[s];
+        const int ns = ctrl_off[s + 1] - ctrl_off[s];
+        for (int64_t k = 0; k < len; ++k) {
+          const double ts = a0 + (double)k;
+          if (!(ts >= istart[s] && ts <= iend[s])) continue;
+          const int l = find_span(t, ns, ts);
+          double h[4], dh[4];
+          bspline_basis<false>(t, l, ts, h, dh);
+          ms_t.push_back(ts);
+          for (int q = 0; q < 4; ++q) ms_basis.push_back(h[q]);
+          ms_ctrl.push_back(ctrl_off[s] + l - 3);
+          ms_part.push_back(find_interval(istart.data(), iend.data(), S, ts));   // half-open: util.py:105
+          ms_pat.push_back(pattern_first_kept(t, l, ts));
+        }
+      }
+      T = (int)ms_t.size();
+    }
+    m = 2 * M + T;
+    return "";
+  }
+};
+
+}  // namespace mvus

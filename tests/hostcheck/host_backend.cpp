@@ -1,0 +1,252 @@
+// TEST-ONLY plain-C++ backend for the templated optimiser (mvus_amd/csrc/ba_solver.h).
+//
+// It evaluates residuals / Jacobians with the same ba_math.h functions the HIP kernels call and
+// stores J in the same slot layout, so the CPU test-suite can check the restated scipy optimiser,
+// the block-sparse J v / J^T u operators, the pattern mask and the normal-equation algebra against
+// the oracle without a GPU.  It is compiled into tests/hostcheck/libhostcheck.so only -- the
+// product library libmvusba.so has no CPU path.
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../mvus_amd/csrc/ba_problem.h"
+#include "../../mvus_amd/csrc/ba_solver.h"
+#ifdef MVUS_WITH_SCHUR
+#include "../../mvus_amd/csrc/ba_schur.h"
+#endif
+
+using namespace mvus;
+
+namespace {
+
+struct HostBackend {
+  HostProblem hp;
+  std::vector<double> J, mJ, u_obs, v_obs;
+  std::vector<int32_t> span, pat0, mctrl;
+  bool has_pattern = false;
+
+  int64_t n() const { return hp.n; }
+  int64_t m_local() const { return hp.m; }
+  int64_t m_global() const { return hp.m; }
+  double* alloc(int64_t len) { return new double[len > 0 ? len : 1](); }
+  void release(double* p) { delete[] p; }
+  void upload(double* d, const double* s, int64_t len) { std::memcpy(d, s, sizeof(double) * len); }
+  void download(double* d, const double* s, int64_t len) { std::memcpy(d, s, sizeof(double) * len); }
+  void copy(double* d, const double* s, int64_t len) { std::memcpy(d, s, sizeof(double) * len); }
+  void fill(double* d, double v, int64_t len) { for (int64_t i = 0; i < len; ++i) d[i] = v; }
+  void axpby(int64_t len, double a, const double* x, double b, const double* y, double* out) {
+    for (int64_t i = 0; i < len; ++i) out[i] = a * x[i] + b * y[i];
+  }
+  void mul(int64_t len, const double* x, const double* y, double* out) { for (int64_t i = 0; i < len; ++i) out[i] = x[i] * y[i]; }
+  double dot_n(const double* a, const double* b, int64_t len) { double s = 0; for (int64_t i = 0; i < len; ++i) s += a[i] * b[i]; return s; }
+  double dot_m(const double* a, const double* b) { return dot_n(a, b, hp.m); }
+
+  void init() {
+    J.assign((size_t)2 * hp.NS * hp.M, 0.0); span.assign(hp.M, -1); pat0.assign(hp.M, -1);
+    mJ.assign((size_t)36 * hp.T, 0.0); mctrl.assign((size_t)3 * hp.T, -1);
+    u_obs = hp.u_raw; v_obs = hp.v_raw;
+    if (!hp.calib && hp.undist)
+      for (int c = 0; c < hp.C; ++c) {
+        const double fx = hp.K[4 * c], fy = hp.K[4 * c + 1], cx = hp.K[4 * c + 2], cy = hp.K[4 * c + 3];
+        for (int64_t i = hp.det_off[c]; i < hp.det_off[c + 1]; ++i) {
+          double xn, yn;
+          undistort5<false>((hp.u_raw[i] - cx) / fx, (hp.v_raw[i] - cy) / fy, &hp.dist[5 * c], xn, yn, nullptr, nullptr);
+          u_obs[i] = fx * xn + cx; v_obs[i] = fy * yn + cy;
+        }
+      }
+  }
+
+  template <bool JAC>
+  void eval(const double* x, double* f, int jac_mode) {
+    const SplineView sp = hp.spline_view();
+    const int NS = hp.NS;
+    std::vector<double> jx(NS), jy(NS);
+    for (int c = 0; c < hp.C; ++c) {
+      CamState cam;
+      load_cam_state(x, hp.C, c, hp.calib, hp.K.data(), hp.dist.data(), hp.H[c], cam);
+      const int64_t a = hp.det_off[c], Mc = hp.det_off[c + 1] - a;
+      for (int64_t i = a; i < a + Mc; ++i) {
+        ObsResult r = hp.calib ? eval_observation<true, JAC>(cam, sp, x, hp.undist, hp.rs_free, hp.frame[i], hp.u_raw[i], hp.v_raw[i], u_obs[i], v_obs[i], jx.data(), jy.data())
+                               : eval_observation<false, JAC>(cam, sp, x, hp.undist, hp.rs_free, hp.frame[i], hp.u_raw[i], hp.v_raw[i], u_obs[i], v_obs[i], jx.data(), jy.data());
+        f[2 * a + (i - a)] = r.ex;
+        f[2 * a + Mc + (i - a)] = r.ey;
+        if (JAC) {
+          int32_t ctrl = r.ctrl;
+          if (jac_mode == MVUS_JAC_PATTERN && ctrl >= 0) {
+            if (pat0[i] < 0) ctrl = -1;
+            else mask_to_pattern(jx.data(), jy.data(), 3 + hp.P, ctrl, pat0[i]);
+          }
+          span[i] = ctrl;
+          for (int k = 0; k < NS; ++k) {
+            J[(size_t)k * hp.M + i] = ctrl >= 0 ? jx[k] : 0.0;
+            J[(size_t)(NS + k) * hp.M + i] = ctrl >= 0 ? jy[k] : 0.0;
+          }
+        }
+      }
+    }
+    const MotionView mv = hp.motion_view();
+    for (int j = 0; j < hp.T; ++j) {
+      double jrow[36]; int32_t cidx[3];
+      f[2 * hp.M + j] = eval_motion_row<JAC>(mv, x, j, jac_mode == MVUS_JAC_PATTERN, jrow, cidx);
+      if (JAC) {
+        for (int k = 0; k < 36; ++k) mJ[(size_t)k * hp.T + j] = jrow[k];
+        for (int k = 0; k < 3; ++k) mctrl[(size_t)k * hp.T + j] = cidx[k];
+      }
+    }
+  }
+  void residual(const double* x, double* f) { eval<false>(x, f, 0); }
+  void jacobian(const double* x, double* f, int jac_mode) { eval<true>(x, f, jac_mode); }
+
+  void set_pattern(const double* x0) {
+    const SplineView sp = hp.spline_view();
+    for (int c = 0; c < hp.C; ++c) {
+      CamState cam;
+      load_cam_state(x0, hp.C, c, hp.calib, hp.K.data(), hp.dist.data(), hp.H[c], cam);
+      for (int64_t i = hp.det_off[c]; i < hp.det_off[c + 1]; ++i)
+        pat0[i] = observation_pattern(cam, sp, hp.frame[i], hp.v_raw[i]);
+    }
+    has_pattern = true;
+  }
+
+  int col_of(int c, int k) const { return k < 3 ? k * hp.C + c : 3 * hp.C + c * hp.P + (k - 3); }
+
+  void jv(const double* v, double* y) {
+    const int NS = hp.NS, B = 3 + hp.P;
+    for (int c = 0; c < hp.C; ++c) {
+      const int64_t a = hp.det_off[c], Mc = hp.det_off[c + 1] - a;
+      for (int64_t i = a; i < a + Mc; ++i) {
+        double sx = 0, sy = 0;
+        const int g = span[i];
+        if (g >= 0) {
+          for (int k = 0; k < B; ++k) { const double vv = v[col_of(c, k)]; sx += J[(size_t)k * hp.M + i] * vv; sy += J[(size_t)(NS + k) * hp.M + i] * vv; }
+          const int x0 = hp.ctrl_x0[g], st = hp.ctrl_stride[g];
+          for (int q = 0; q < 4; ++q)
+            for (int d = 0; d < 3; ++d) {
+              const double vv = v[x0 + q + d * st];
+              sx += J[(size_t)(B + 3 * q + d) * hp.M + i] * vv; sy += J[(size_t)(NS + B + 3 * q + d) * hp.M + i] * vv;
+            }
+        }
+        y[2 * a + (i - a)] = sx; y[2 * a + Mc + (i - a)] = sy;
+      }
+    }
+    for (int j = 0; j < hp.T; ++j) {
+      double s = 0;
+      for (int k = 0; k < 3; ++k) {
+        const int g = mctrl[(size_t)k * hp.T + j];
+        if (g < 0) continue;
+        const int x0 = hp.ctrl_x0[g], st = hp.ctrl_stride[g];
+        for (int q = 0; q < 4; ++q) for (int d = 0; d < 3; ++d) s += mJ[(size_t)(12 * k + 3 * q + d) * hp.T + j] * v[x0 + q + d * st];
+      }
+      y[2 * hp.M + j] = s;
+    }
+  }
+
+  void jtu(const double* u, double* z) {
+    const int NS = hp.NS, B = 3 + hp.P;
+    for (int64_t i = 0; i < hp.n; ++i) z[i] = 0;
+    for (int c = 0; c < hp.C; ++c) {
+      const int64_t a = hp.det_off[c], Mc = hp.det_off[c + 1] - a;
+      for (int64_t i = a; i < a + Mc; ++i) {
+        const int g = span[i];
+        if (g < 0) continue;
+        const double ux = u[2 * a + (i - a)], uy = u[2 * a + Mc + (i - a)];
+        for (int k = 0; k < B; ++k) z[col_of(c, k)] += J[(size_t)k * hp.M + i] * ux + J[(size_t)(NS + k) * hp.M + i] * uy;
+        const int x0 = hp.ctrl_x0[g], st = hp.ctrl_stride[g];
+        for (int q = 0; q < 4; ++q)
+          for (int d = 0; d < 3; ++d)
+            z[x0 + q + d * st] += J[(size_t)(B + 3 * q + d) * hp.M + i] * ux + J[(size_t)(NS + B + 3 * q + d) * hp.M + i] * uy;
+      }
+    }
+    for (int j = 0; j < hp.T; ++j)
+      for (int k = 0; k < 3; ++k) {
+        const int g = mctrl[(size_t)k * hp.T + j];
+        if (g < 0) continue;
+        const int x0 = hp.ctrl_x0[g], st = hp.ctrl_stride[g];
+        for (int q = 0; q < 4; ++q) for (int d = 0; d < 3; ++d) z[x0 + q + d * st] += mJ[(size_t)(12 * k + 3 * q + d) * hp.T + j] * u[2 * hp.M + j];
+      }
+  }
+};
+
+thread_local std::string g_err;
+
+}  // namespace
+
+extern "C" {
+
+const char* hostcheck_error() { return g_err.c_str(); }
+
+void* hostcheck_create(const mvus_problem* p) {
+  HostBackend* be = new HostBackend();
+  g_err = be->hp.build(p);
+  if (!g_err.empty()) { delete be; return nullptr; }
+  be->init();
+  return be;
+}
+void hostcheck_destroy(void* h) { delete static_cast<HostBackend*>(h); }
+int64_t hostcheck_n(void* h) { return static_cast<HostBackend*>(h)->hp.n; }
+int64_t hostcheck_m(void* h) { return static_cast<HostBackend*>(h)->hp.m; }
+int hostcheck_T(void* h) { return static_cast<HostBackend*>(h)->hp.T; }
+
+int hostcheck_residual(void* h, const double* x, double* f) { static_cast<HostBackend*>(h)->residual(x, f); return 0; }
+
+int hostcheck_set_pattern(void* h, const double* x0, int32_t* pat) {
+  HostBackend* be = static_cast<HostBackend*>(h);
+  be->set_pattern(x0);
+  if (pat) std::memcpy(pat, be->pat0.data(), sizeof(int32_t) * be->hp.M);
+  return 0;
+}
+
+// dense Jacobian (m x n, row-major) of the current mode, for comparison with scipy / finite differences
+int hostcheck_dense_jacobian(void* h, const double* x, int jac_mode, double* f, double* Jd) {
+  HostBackend* be = static_cast<HostBackend*>(h);
+  be->jacobian(x, f, jac_mode);
+  const int64_t n = be->hp.n, m = be->hp.m;
+  std::vector<double> e(n, 0.0), col(m);
+  for (int64_t j = 0; j < n; ++j) {
+    e[j] = 1.0;
+    be->jv(e.data(), col.data());
+    e[j] = 0.0;
+    for (int64_t i = 0; i < m; ++i) Jd[i * n + j] = col[i];
+  }
+  return 0;
+}
+
+int hostcheck_jtu(void* h, const double* u, double* z) { static_cast<HostBackend*>(h)->jtu(u, z); return 0; }
+
+int hostcheck_solve(void* h, double* x, const mvus_solve_opts* o, mvus_result* r, double* f_out) {
+  HostBackend* be = static_cast<HostBackend*>(h);
+  const int64_t n = be->hp.n;
+  std::vector<double> xv(x, x + n), lb(n, -INFINITY), ub(n, INFINITY);
+  if (be->hp.rs_bounds) for (int c = 0; c < be->hp.C; ++c) { lb[2 * be->hp.C + c] = 0.0; ub[2 * be->hp.C + c] = 1.0; }
+  SolveOptions so;
+  so.jac_mode = o->jac_mode; so.max_nfev = o->max_nfev; so.ftol = o->ftol; so.xtol = o->xtol; so.gtol = o->gtol;
+  so.lsmr_atol = o->lsmr_atol; so.lsmr_btol = o->lsmr_btol; so.lsmr_conlim = o->lsmr_conlim; so.lsmr_maxiter = o->lsmr_maxiter; so.verbose = o->verbose;
+  if (so.jac_mode == MVUS_JAC_PATTERN) be->set_pattern(x);
+  std::vector<double> f(be->hp.m);
+  SolveResult sr;
+#ifdef MVUS_WITH_SCHUR
+  if (o->solver == MVUS_SOLVER_LM_SCHUR) sr = lm_schur<HostBackend, HostSchur>(*be, xv, lb, ub, so, f.data());
+  else
+#endif
+    sr = trf_lsmr(*be, xv, lb, ub, so, f.data());
+  if (sr.error) { g_err = "non-finite residuals at x0 or x0 outside bounds"; return sr.error; }
+  std::memcpy(x, xv.data(), sizeof(double) * n);
+  if (f_out) std::memcpy(f_out, f.data(), sizeof(double) * be->hp.m);
+  r->cost = sr.cost; r->optimality = sr.optimality; r->nfev = sr.nfev; r->njev = sr.njev; r->status = sr.status;
+  r->lin_iters = sr.lin_iters; r->initial_cost = sr.initial_cost; r->solve_ms = 0;
+  return 0;
+}
+
+}  // extern "C"
+
+// LSMR on the Jacobian currently held (after hostcheck_dense_jacobian): min |J x - b|^2 + damp^2 |x|^2
+extern "C" int hostcheck_lsmr(void* h, const double* b, double damp, double atol, double btol, double conlim,
+                              int maxiter, double* x_out, int* itn) {
+  HostBackend* be = static_cast<HostBackend*>(h);
+  Lsmr<HostBackend> l(*be);
+  return l.run(nullptr, nullptr, b, damp, atol, btol, conlim, maxiter > 0 ? maxiter : std::min(be->hp.m, be->hp.n), x_out, itn);
+}
+
+extern "C" void hostcheck_tr2d(const double* B, const double* g, double Delta, double* p) {
+  mvus::detail::solve_trust_region_2d(B, g, Delta, p);
+}

@@ -1,0 +1,36 @@
+// TEST-ONLY host build of the per-observation device math (mvus_amd/csrc/ba_math.h).
+// Lets the CPU test-suite check the arithmetic the HIP kernels run (residual, analytic Jacobian)
+// against the oracle without a GPU.  Never linked into libmvusba.so.
+#include "../../mvus_amd/csrc/ba_math.h"
+
+using namespace mvus;
+
+extern "C" int hostcheck_eval(int C, int calib, int undist, int rs_free, const int64_t* det_off,
+                              const double* frame, const double* u_raw, const double* v_raw, const double* H,
+                              const double* Kfix, const double* dfix, int S, const double* istart,
+                              const double* iend, const double* knots, const int32_t* knot_off,
+                              const int32_t* ctrl_off, const int32_t* xoff, const double* x, double* ex,
+                              double* ey, int32_t* ctrl, double* J) {
+  SplineView sp{S, istart, iend, knots, knot_off, ctrl_off, xoff};
+  const int NS = num_slots(calib != 0);
+  for (int c = 0; c < C; ++c) {
+    CamState cam;
+    load_cam_state(x, C, c, calib != 0, Kfix, dfix, H[c], cam);
+    for (int64_t i = det_off[c]; i < det_off[c + 1]; ++i) {
+      double uo = u_raw[i], vo = v_raw[i];
+      if (!calib && undist) {
+        double xn, yn;
+        undistort5<false>((u_raw[i] - cam.cx) / cam.fx, (v_raw[i] - cam.cy) / cam.fy, cam.d, xn, yn, nullptr, nullptr);
+        uo = cam.fx * xn + cam.cx;
+        vo = cam.fy * yn + cam.cy;
+      }
+      double* jx = J + (2 * i) * NS;
+      double* jy = J + (2 * i + 1) * NS;
+      for (int k = 0; k < 2 * NS; ++k) jx[k] = 0.0;
+      ObsResult r = calib ? eval_observation<true, true>(cam, sp, x, undist != 0, rs_free != 0, frame[i], u_raw[i], v_raw[i], uo, vo, jx, jy)
+                          : eval_observation<false, true>(cam, sp, x, undist != 0, rs_free != 0, frame[i], u_raw[i], v_raw[i], uo, vo, jx, jy);
+      ex[i] = r.ex; ey[i] = r.ey; ctrl[i] = r.ctrl;
+    }
+  }
+  return 0;
+}

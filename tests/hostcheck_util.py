@@ -1,0 +1,101 @@
+"""Build/load the TEST-ONLY host build of the device math + optimiser (tests/hostcheck)."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+from mvus_amd import _lib
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+SRC = [os.path.join(HERE, 'hostcheck', f) for f in ('hostcheck.cpp', 'host_backend.cpp')]
+DEPS = SRC + [os.path.join(ROOT, 'mvus_amd', 'csrc', f) for f in ('ba_math.h', 'ba_solver.h', 'ba_problem.h', 'ba_schur.h')] \
+    + [os.path.join(ROOT, 'include', 'mvus_ba.h')]
+SO = os.path.join(HERE, 'hostcheck', 'libhostcheck.so')
+
+_cached = None
+
+
+def load():
+    global _cached
+    if _cached is not None:
+        return _cached
+    deps = [d for d in DEPS if os.path.exists(d)]
+    if (not os.path.exists(SO)) or os.path.getmtime(SO) < max(os.path.getmtime(d) for d in deps):
+        flags = ['-DMVUS_WITH_SCHUR'] if os.path.exists(os.path.join(ROOT, 'mvus_amd', 'csrc', 'ba_schur.h')) else []
+        subprocess.check_call(['g++', '-O2', '-std=c++17', '-shared', '-fPIC'] + flags + ['-o', SO] + SRC)
+    lib = ctypes.CDLL(SO)
+    lib.hostcheck_create.restype = ctypes.c_void_p
+    lib.hostcheck_create.argtypes = [ctypes.POINTER(_lib.MvusProblem)]
+    lib.hostcheck_destroy.argtypes = [ctypes.c_void_p]
+    lib.hostcheck_error.restype = ctypes.c_char_p
+    for name in ('hostcheck_n', 'hostcheck_m'):
+        getattr(lib, name).restype = ctypes.c_int64
+        getattr(lib, name).argtypes = [ctypes.c_void_p]
+    lib.hostcheck_T.argtypes = [ctypes.c_void_p]
+    lib.hostcheck_residual.argtypes = [ctypes.c_void_p, _lib.c_double_p, _lib.c_double_p]
+    lib.hostcheck_set_pattern.argtypes = [ctypes.c_void_p, _lib.c_double_p, _lib.c_int32_p]
+    lib.hostcheck_dense_jacobian.argtypes = [ctypes.c_void_p, _lib.c_double_p, ctypes.c_int, _lib.c_double_p, _lib.c_double_p]
+    lib.hostcheck_jtu.argtypes = [ctypes.c_void_p, _lib.c_double_p, _lib.c_double_p]
+    lib.hostcheck_solve.argtypes = [ctypes.c_void_p, _lib.c_double_p, ctypes.POINTER(_lib.MvusSolveOpts),
+                                    ctypes.POINTER(_lib.MvusResult), _lib.c_double_p]
+    _cached = lib
+    return lib
+
+
+class HostHandle:
+    """Thin object wrapper over the hostcheck_* functions (mirrors mvus_amd.ba.BAHandle's methods)."""
+
+    def __init__(self, prob):
+        self.lib = load()
+        self.prob = prob
+        self._struct, self._keep = _lib.make_problem_struct(prob)
+        self.h = self.lib.hostcheck_create(ctypes.byref(self._struct))
+        if not self.h:
+            raise ValueError(self.lib.hostcheck_error().decode())
+        self.n = self.lib.hostcheck_n(self.h)
+        self.m = self.lib.hostcheck_m(self.h)
+        self.T = self.lib.hostcheck_T(self.h)
+
+    def close(self):
+        if self.h:
+            self.lib.hostcheck_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def residual(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        f = np.zeros(self.m)
+        self.lib.hostcheck_residual(self.h, _lib.dptr(x), _lib.dptr(f))
+        return f
+
+    def set_pattern(self, x0):
+        x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        pat = np.zeros(self.prob.M, dtype=np.int32)
+        self.lib.hostcheck_set_pattern(self.h, _lib.dptr(x0), pat.ctypes.data_as(_lib.c_int32_p))
+        return pat
+
+    def dense_jacobian(self, x, jac_mode):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        f = np.zeros(self.m)
+        J = np.zeros((self.m, self.n))
+        self.lib.hostcheck_dense_jacobian(self.h, _lib.dptr(x), jac_mode, _lib.dptr(f), _lib.dptr(J))
+        return f, J
+
+    def jtu(self, u):
+        u = np.ascontiguousarray(u, dtype=np.float64)
+        z = np.zeros(self.n)
+        self.lib.hostcheck_jtu(self.h, _lib.dptr(u), _lib.dptr(z))
+        return z
+
+    def solve(self, x0, opts):
+        x = np.array(x0, dtype=np.float64)
+        res = _lib.MvusResult()
+        f = np.zeros(self.m)
+        rc = self.lib.hostcheck_solve(self.h, _lib.dptr(x), ctypes.byref(opts), ctypes.byref(res), _lib.dptr(f))
+        if rc != 0:
+            raise ValueError(self.lib.hostcheck_error().decode())
+        return x, res, f
