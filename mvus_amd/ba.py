@@ -1,0 +1,171 @@
+"""Python face of the C ABI (include/mvus_ba.h): one ``BAHandle`` per BA problem, GPU and stream.
+
+``BAHandle.solve`` stands where the reference calls ``scipy.optimize.least_squares``
+(``reconstruction/common.py:670``); ``residual`` is ``error_BA`` (``common.py:448-487``);
+``outlier_mask`` is the test of ``Scene.remove_outliers`` (``common.py:709-713``).
+Everything is computed by libmvusba.so on the GPU; there is no CPU fallback.
+"""
+import ctypes
+from types import SimpleNamespace
+
+import numpy as np
+
+from . import _lib
+from ._lib import JAC_ANALYTIC, JAC_PATTERN, SOLVER_LM_SCHUR, SOLVER_TRF_LSMR  # noqa: F401 (re-exported)
+
+_ERRORS = {_lib.MVUS_E_INVALID: ValueError, _lib.MVUS_E_NUMERIC: ValueError, _lib.MVUS_E_HIP: RuntimeError,
+           _lib.MVUS_E_COMM: RuntimeError}
+
+
+class BAHandle:
+    def __init__(self, prob, device=0, stream=None):
+        self.lib = _lib.load()
+        self.prob = prob
+        self._struct, self._keep = _lib.make_problem_struct(prob, device=device, stream=stream)
+        h = ctypes.c_void_p()
+        rc = self.lib.mvus_ba_create(ctypes.byref(self._struct), ctypes.byref(h))
+        if rc != 0:
+            raise _ERRORS.get(rc, RuntimeError)('mvus_ba_create: ' + self.lib.mvus_last_error(None).decode())
+        self.h = h
+        self.n = int(self.lib.mvus_ba_num_params(h))
+        self.m = int(self.lib.mvus_ba_num_residuals(h))
+        self.T = int(self.lib.mvus_ba_num_motion_rows(h))
+        self.NS = int(self.lib.mvus_ba_num_slots(h))
+        self.M = prob.M
+        self._cb = None
+
+    def close(self):
+        if getattr(self, 'h', None):
+            self.lib.mvus_ba_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise _ERRORS.get(rc, RuntimeError)('%s: %s' % (what, self.lib.mvus_last_error(self.h).decode()))
+
+    @staticmethod
+    def _x(x, n):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        if x.shape != (n,):
+            raise ValueError('x has shape %s, expected (%d,)' % (x.shape, n))
+        return x
+
+    def residual(self, x):
+        x = self._x(x, self.n)
+        f = np.empty(self.m)
+        self._check(self.lib.mvus_ba_residual(self.h, _lib.dptr(x), _lib.dptr(f)), 'mvus_ba_residual')
+        return f
+
+    def residual_jacobian(self, x, jac_mode=JAC_ANALYTIC):
+        """f[m], J[2, NS, M] (slot layout of include/mvus_ba.h), ctrl[M]."""
+        x = self._x(x, self.n)
+        f = np.empty(self.m)
+        J = np.empty((2, self.NS, self.M))
+        ctrl = np.empty(self.M, dtype=np.int32)
+        self._check(self.lib.mvus_ba_residual_jacobian(self.h, _lib.dptr(x), jac_mode, _lib.dptr(f), _lib.dptr(J),
+                                                       ctrl.ctypes.data_as(_lib.c_int32_p)), 'mvus_ba_residual_jacobian')
+        return f, J, ctrl
+
+    def motion_rows(self, x, jac_mode=JAC_ANALYTIC):
+        x = self._x(x, self.n)
+        mf = np.zeros(self.T)
+        mJ = np.zeros((36, self.T))
+        mctrl = np.full((3, self.T), -1, dtype=np.int32)
+        self._check(self.lib.mvus_ba_motion_rows(self.h, _lib.dptr(x), jac_mode, _lib.dptr(mf), _lib.dptr(mJ),
+                                                 mctrl.ctypes.data_as(_lib.c_int32_p)), 'mvus_ba_motion_rows')
+        return mf, mJ, mctrl
+
+    def set_pattern(self, x0):
+        x0 = self._x(x0, self.n)
+        pat = np.empty(self.M, dtype=np.int32)
+        self._check(self.lib.mvus_ba_set_pattern(self.h, _lib.dptr(x0), pat.ctypes.data_as(_lib.c_int32_p)), 'mvus_ba_set_pattern')
+        return pat
+
+    def jv(self, v):
+        v = self._x(v, self.n)
+        y = np.empty(self.m)
+        self._check(self.lib.mvus_ba_jv(self.h, _lib.dptr(v), _lib.dptr(y)), 'mvus_ba_jv')
+        return y
+
+    def jtu(self, u):
+        u = self._x(u, self.m)
+        z = np.empty(self.n)
+        self._check(self.lib.mvus_ba_jtu(self.h, _lib.dptr(u), _lib.dptr(z)), 'mvus_ba_jtu')
+        return z
+
+    def normal_equations(self):
+        """g[n], JtJ_cam[C,B,B], band[N,W,3,3], cross[C,B,3N] of the Jacobian currently held."""
+        C, B, N = self.prob.C, 3 + self.prob.P, int(self.prob.n_coef.sum())
+        W = ctypes.c_int32(0)
+        self._check(self.lib.mvus_ba_normal_equations(self.h, None, None, None, None, ctypes.byref(W)), 'mvus_ba_normal_equations')
+        g = np.empty(self.n)
+        cam = np.empty((C, B, B))
+        band = np.empty((N, W.value, 3, 3))
+        cross = np.empty((C, B, 3 * N))
+        self._check(self.lib.mvus_ba_normal_equations(self.h, _lib.dptr(g), _lib.dptr(cam), _lib.dptr(band), _lib.dptr(cross),
+                                                      ctypes.byref(W)), 'mvus_ba_normal_equations')
+        return g, cam, band, cross
+
+    def solve(self, x0, solver=SOLVER_TRF_LSMR, jac_mode=JAC_PATTERN, max_nfev=10, opts=None, return_fun=True):
+        """The least_squares call of Scene.BA.  Returns an OptimizeResult-like namespace
+        (x, cost, fun, nfev, njev, status, optimality, ...)."""
+        x = np.array(self._x(x0, self.n))
+        o = opts if opts is not None else _lib.default_opts(solver, jac_mode, max_nfev)
+        res = _lib.MvusResult()
+        f = np.empty(self.m) if return_fun else None
+        self._check(self.lib.mvus_ba_solve(self.h, _lib.dptr(x), ctypes.byref(o), ctypes.byref(res),
+                                           _lib.dptr(f) if return_fun else None), 'mvus_ba_solve')
+        return SimpleNamespace(x=x, cost=res.cost, fun=f, nfev=res.nfev, njev=res.njev, status=res.status,
+                               optimality=res.optimality, lin_iters=res.lin_iters, solve_ms=res.solve_ms,
+                               initial_cost=res.initial_cost, success=res.status > 0,
+                               active_mask=np.zeros(self.n), grad=None, jac=None)
+
+    def outlier_mask(self, x, thres):
+        """Per-detection ``error < thres`` (camera-segmented order), dtype bool."""
+        x = self._x(x, self.n)
+        keep = np.empty(self.M, dtype=np.uint8)
+        self._check(self.lib.mvus_ba_outlier_mask(self.h, _lib.dptr(x), float(thres), keep.ctypes.data_as(_lib.c_uint8_p)),
+                    'mvus_ba_outlier_mask')
+        return keep.astype(bool)
+
+    def set_x(self, x):
+        x = self._x(x, self.n)
+        self._check(self.lib.mvus_ba_set_x(self.h, _lib.dptr(x)), 'mvus_ba_set_x')
+
+    def time_kernel(self, which, launches=20):
+        """Average duration (ms) of ``launches`` back-to-back launches, HIP events on the handle's stream."""
+        ms = ctypes.c_double(0.0)
+        self._check(self.lib.mvus_ba_time_kernel(self.h, which, launches, ctypes.byref(ms)), 'mvus_ba_time_kernel')
+        return ms.value
+
+    def set_allreduce(self, fn, is_root=True):
+        """fn(buf_dev_ptr:int, count:int, stream:int) -> None sums ``count`` doubles in place across ranks."""
+        if fn is None:
+            self._cb = _lib.ALLREDUCE_FN(0)
+        else:
+            def tramp(user, buf, count, stream):
+                try:
+                    fn(int(buf), int(count), int(stream or 0))
+                    return 0
+                except Exception:      # never let an exception cross the C boundary
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            self._cb = _lib.ALLREDUCE_FN(tramp)
+        self._check(self.lib.mvus_ba_set_allreduce(self.h, self._cb, None, int(bool(is_root))), 'mvus_ba_set_allreduce')
+
+
+# kernel ids of mvus_ba_time_kernel
+KERNEL_RESIDUAL, KERNEL_RESIDUAL_JACOBIAN, KERNEL_JV, KERNEL_JTU, KERNEL_ASSEMBLY = 0, 1, 2, 3, 4

@@ -1,0 +1,476 @@
+// libmvusba.so: HIP backend of the templated optimiser + the C ABI of include/mvus_ba.h.
+// There is no CPU compute path in this library: every entry point that evaluates anything
+// launches HIP kernels, and mvus_ba_create fails with MVUS_E_HIP when no device is usable.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "ba_kernels.hip.h"
+#include "ba_problem.h"
+#include "ba_solver.h"
+#include "ba_schur_hip.hip.h"
+
+namespace mvus {
+
+struct HipError { std::string msg; };
+
+#define MVUS_HIP(expr)                                                                              \
+  do {                                                                                              \
+    hipError_t e_ = (expr);                                                                         \
+    if (e_ != hipSuccess) throw HipError{std::string(#expr) + ": " + hipGetErrorString(e_)};        \
+  } while (0)
+
+static inline int grid_for(long long len) { return (int)std::min<long long>(2048, std::max<long long>(1, (len + kThreads - 1) / kThreads)); }
+
+struct HipBackend {
+  HostProblem hp;
+  DevProblem dp{};
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  int device = 0;
+  std::vector<void*> owned;
+  // evaluation state
+  CamState* cams = nullptr;
+  double *J = nullptr, *mJ = nullptr, *x_cur = nullptr, *f_cur = nullptr;
+  int32_t *span = nullptr, *pat0 = nullptr, *mctrl = nullptr;
+  bool has_pattern = false, has_jacobian = false;
+  // reductions
+  double *partials = nullptr, *scal_dev = nullptr, *scal_host = nullptr;
+  // multi-GPU
+  mvus_allreduce_fn allreduce = nullptr;
+  void* allreduce_user = nullptr;
+  int is_root = 1;
+  int64_t m_glob = 0;
+  std::string err;
+
+  template <class T>
+  T* dalloc(size_t count) {
+    void* p = nullptr;
+    MVUS_HIP(hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T)));
+    owned.push_back(p);
+    return static_cast<T*>(p);
+  }
+  template <class T>
+  T* dupload(const std::vector<T>& v) {
+    T* p = dalloc<T>(v.size());
+    if (!v.empty()) MVUS_HIP(hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, stream));
+    return p;
+  }
+
+  void init(const mvus_problem* p) {
+    device = p->device;
+    MVUS_HIP(hipSetDevice(device));
+    if (p->stream) stream = static_cast<hipStream_t>(p->stream);
+    else { MVUS_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking)); own_stream = true; }
+    dp.C = hp.C; dp.P = hp.P; dp.NS = hp.NS; dp.S = hp.S; dp.calib = hp.calib; dp.undist = hp.undist;
+    dp.rs_free = hp.rs_free; dp.T = hp.T; dp.M = hp.M;
+    dp.frame = dupload(hp.frame); dp.u_raw = dupload(hp.u_raw); dp.v_raw = dupload(hp.v_raw);
+    dp.H = dupload(hp.H); dp.Kfix = dupload(hp.K); dp.dfix = dupload(hp.dist);
+    dp.sp.S = hp.S; dp.sp.istart = dupload(hp.istart); dp.sp.iend = dupload(hp.iend); dp.sp.knots = dupload(hp.knots);
+    dp.sp.knot_off = dupload(hp.knot_off); dp.sp.ctrl_off = dupload(hp.ctrl_off); dp.sp.xoff = dupload(hp.xoff);
+    dp.mv.T = hp.T; dp.mv.type = hp.motion_type; dp.mv.w = hp.w;
+    dp.mv.t = dupload(hp.ms_t); dp.mv.basis = dupload(hp.ms_basis); dp.mv.ctrl = dupload(hp.ms_ctrl);
+    dp.mv.part = dupload(hp.ms_part); dp.mv.pat = dupload(hp.ms_pat);
+    dp.mv.ctrl_x0 = dupload(hp.ctrl_x0); dp.mv.ctrl_stride = dupload(hp.ctrl_stride);
+    dp.chunk_cam = dupload(hp.chunk_cam); dp.chunk_count = dupload(hp.chunk_count);
+    std::vector<long long> cs(hp.chunk_start.begin(), hp.chunk_start.end()), doff(hp.det_off.begin(), hp.det_off.end());
+    dp.chunk_start = dupload(cs); dp.det_off = dupload(doff);
+    dp.n_chunks = (int)hp.chunk_cam.size();
+    double* uo = dalloc<double>(hp.M); double* vo = dalloc<double>(hp.M);
+    dp.u_obs = uo; dp.v_obs = vo;
+    cams = dalloc<CamState>(hp.C);
+    J = dalloc<double>((size_t)2 * hp.NS * hp.M);
+    span = dalloc<int32_t>(hp.M); pat0 = dalloc<int32_t>(hp.M);
+    mJ = dalloc<double>((size_t)36 * hp.T); mctrl = dalloc<int32_t>((size_t)3 * hp.T);
+    x_cur = dalloc<double>(hp.n); f_cur = dalloc<double>(hp.m);
+    partials = dalloc<double>(2048); scal_dev = dalloc<double>(16);
+    MVUS_HIP(hipHostMalloc(reinterpret_cast<void**>(&scal_host), 16 * sizeof(double), hipHostMallocDefault));
+    MVUS_HIP(hipMemsetAsync(span, 0xff, sizeof(int32_t) * std::max<int64_t>(hp.M, 1), stream));
+    MVUS_HIP(hipMemsetAsync(pat0, 0xff, sizeof(int32_t) * std::max<int64_t>(hp.M, 1), stream));
+    MVUS_HIP(hipMemsetAsync(mctrl, 0xff, sizeof(int32_t) * std::max<int64_t>(3 * hp.T, 1), stream));
+    if (dp.n_chunks > 0) {
+      if (!hp.calib && hp.undist) hipLaunchKernelGGL(k_undistort_fixed, dim3(dp.n_chunks), dim3(kThreads), 0, stream, dp, uo, vo);
+      else {
+        MVUS_HIP(hipMemcpyAsync(uo, dp.u_raw, sizeof(double) * hp.M, hipMemcpyDeviceToDevice, stream));
+        MVUS_HIP(hipMemcpyAsync(vo, dp.v_raw, sizeof(double) * hp.M, hipMemcpyDeviceToDevice, stream));
+      }
+    }
+    MVUS_HIP(hipGetLastError());
+    MVUS_HIP(hipStreamSynchronize(stream));
+    m_glob = hp.m;
+  }
+
+  ~HipBackend() {
+    (void)hipSetDevice(device);
+    if (stream) (void)hipStreamSynchronize(stream);
+    for (void* p : owned) (void)hipFree(p);
+    if (scal_host) (void)hipHostFree(scal_host);
+    if (own_stream && stream) (void)hipStreamDestroy(stream);
+  }
+
+  // ---- Backend concept -------------------------------------------------------------------------
+  int64_t n() const { return hp.n; }
+  int64_t m_local() const { return hp.m; }
+  int64_t m_global() const { return m_glob; }
+  double* alloc(int64_t len) {
+    void* p = nullptr;
+    MVUS_HIP(hipMalloc(&p, std::max<int64_t>(len, 1) * sizeof(double)));
+    return static_cast<double*>(p);
+  }
+  void release(double* p) { if (p) { (void)hipStreamSynchronize(stream); (void)hipFree(p); } }
+  void upload(double* d, const double* s, int64_t len) {
+    MVUS_HIP(hipMemcpyAsync(d, s, len * sizeof(double), hipMemcpyHostToDevice, stream));
+    MVUS_HIP(hipStreamSynchronize(stream));   // the host buffer may be reused right away
+  }
+  void download(double* d, const double* s, int64_t len) {
+    MVUS_HIP(hipMemcpyAsync(d, s, len * sizeof(double), hipMemcpyDeviceToHost, stream));
+    MVUS_HIP(hipStreamSynchronize(stream));
+  }
+  void copy(double* d, const double* s, int64_t len) { if (d != s) MVUS_HIP(hipMemcpyAsync(d, s, len * sizeof(double), hipMemcpyDeviceToDevice, stream)); }
+  void fill(double* d, double v, int64_t len) { if (len > 0) hipLaunchKernelGGL(k_fill, dim3(grid_for(len)), dim3(kThreads), 0, stream, (long long)len, v, d); }
+  void axpby(int64_t len, double a, const double* x, double b, const double* y, double* out) {
+    if (len > 0) hipLaunchKernelGGL(k_axpby, dim3(grid_for(len)), dim3(kThreads), 0, stream, (long long)len, a, x, b, y, out);
+  }
+  void mul(int64_t len, const double* x, const double* y, double* out) {
+    if (len > 0) hipLaunchKernelGGL(k_mul, dim3(grid_for(len)), dim3(kThreads), 0, stream, (long long)len, x, y, out);
+  }
+  void dot_to_slot(const double* a, const double* b, int64_t len, int slot) {
+    const int nb = grid_for(len);
+    if (len > 0) {
+      hipLaunchKernelGGL(k_dot_partial, dim3(nb), dim3(kThreads), 0, stream, (long long)len, a, b, partials);
+      hipLaunchKernelGGL(k_dot_final, dim3(1), dim3(kThreads), 0, stream, nb, partials, scal_dev + slot);
+    } else {
+      MVUS_HIP(hipMemsetAsync(scal_dev + slot, 0, sizeof(double), stream));
+    }
+  }
+  double read_slot(int slot) {
+    MVUS_HIP(hipMemcpyAsync(scal_host + slot, scal_dev + slot, sizeof(double), hipMemcpyDeviceToHost, stream));
+    MVUS_HIP(hipStreamSynchronize(stream));
+    return scal_host[slot];
+  }
+  void reduce(double* buf, size_t count) {
+    if (!allreduce) return;
+    if (allreduce(allreduce_user, buf, count, stream) != 0) throw HipError{"all-reduce callback failed"};
+  }
+  double dot_n(const double* a, const double* b, int64_t len) { dot_to_slot(a, b, len, 0); return read_slot(0); }
+  double dot_m(const double* a, const double* b) { dot_to_slot(a, b, hp.m, 1); reduce(scal_dev + 1, 1); return read_slot(1); }
+
+  void eval(const double* x, double* f, bool jac, int jac_mode) {
+    const bool masked = jac && jac_mode == MVUS_JAC_PATTERN;
+    if (masked && !has_pattern) throw HipError{"MVUS_JAC_PATTERN needs mvus_ba_set_pattern (or solve) first"};
+    hipLaunchKernelGGL(k_cam_states, dim3((hp.C + 63) / 64), dim3(64), 0, stream, dp, x, cams);
+    if (dp.n_chunks > 0) {
+      const dim3 g(dp.n_chunks), b(kThreads);
+      if (hp.calib) {
+        if (jac) hipLaunchKernelGGL((k_observations<true, true>), g, b, 0, stream, dp, cams, x, f, J, span, pat0, (int)masked);
+        else hipLaunchKernelGGL((k_observations<true, false>), g, b, 0, stream, dp, cams, x, f, J, span, pat0, 0);
+      } else {
+        if (jac) hipLaunchKernelGGL((k_observations<false, true>), g, b, 0, stream, dp, cams, x, f, J, span, pat0, (int)masked);
+        else hipLaunchKernelGGL((k_observations<false, false>), g, b, 0, stream, dp, cams, x, f, J, span, pat0, 0);
+      }
+    }
+    if (hp.T > 0) {
+      const dim3 g((hp.T + kThreads - 1) / kThreads), b(kThreads);
+      if (jac) hipLaunchKernelGGL(k_motion<true>, g, b, 0, stream, dp, x, f + 2 * hp.M, mJ, mctrl, (int)masked);
+      else hipLaunchKernelGGL(k_motion<false>, g, b, 0, stream, dp, x, f + 2 * hp.M, mJ, mctrl, 0);
+    }
+    MVUS_HIP(hipGetLastError());
+    if (jac) has_jacobian = true;
+  }
+  void residual(const double* x, double* f) { eval(x, f, false, 0); }
+  void jacobian(const double* x, double* f, int jac_mode) { eval(x, f, true, jac_mode); }
+
+  void set_pattern(const double* x0_dev) {
+    hipLaunchKernelGGL(k_cam_states, dim3((hp.C + 63) / 64), dim3(64), 0, stream, dp, x0_dev, cams);
+    if (dp.n_chunks > 0) hipLaunchKernelGGL(k_pattern, dim3(dp.n_chunks), dim3(kThreads), 0, stream, dp, cams, pat0);
+    MVUS_HIP(hipGetLastError());
+    has_pattern = true;
+  }
+
+  void jv(const double* v, double* y) {
+    if (dp.n_chunks > 0) {
+      if (hp.calib) hipLaunchKernelGGL(k_jv<30>, dim3(dp.n_chunks), dim3(kThreads), 0, stream, dp, J, span, v, y);
+      else hipLaunchKernelGGL(k_jv<21>, dim3(dp.n_chunks), dim3(kThreads), 0, stream, dp, J, span, v, y);
+    }
+    if (hp.T > 0) hipLaunchKernelGGL(k_motion_jv, dim3((hp.T + kThreads - 1) / kThreads), dim3(kThreads), 0, stream, dp, mJ, mctrl, v, y + 2 * hp.M);
+    MVUS_HIP(hipGetLastError());
+  }
+  void jtu_local(const double* u, double* z) {
+    MVUS_HIP(hipMemsetAsync(z, 0, sizeof(double) * hp.n, stream));
+    if (dp.n_chunks > 0) {
+      if (hp.calib) hipLaunchKernelGGL(k_jtu<30>, dim3(dp.n_chunks), dim3(kThreads), 0, stream, dp, J, span, u, z);
+      else hipLaunchKernelGGL(k_jtu<21>, dim3(dp.n_chunks), dim3(kThreads), 0, stream, dp, J, span, u, z);
+    }
+    if (hp.T > 0) hipLaunchKernelGGL(k_motion_jtu, dim3((hp.T + kThreads - 1) / kThreads), dim3(kThreads), 0, stream, dp, mJ, mctrl, u + 2 * hp.M, z);
+    MVUS_HIP(hipGetLastError());
+  }
+  void jtu(const double* u, double* z) { jtu_local(u, z); reduce(z, (size_t)hp.n); }
+};
+
+}  // namespace mvus
+
+using namespace mvus;
+
+struct mvus_ba {
+  HipBackend be;
+};
+
+static thread_local std::string g_create_error;
+
+template <class F>
+static int guarded(mvus_ba* h, F&& fn) {
+  if (!h) return MVUS_E_INVALID;
+  try {
+    (void)hipSetDevice(h->be.device);
+    return fn();
+  } catch (const HipError& e) {
+    h->be.err = e.msg;
+    return e.msg.find("all-reduce") != std::string::npos ? MVUS_E_COMM : MVUS_E_HIP;
+  } catch (const std::exception& e) {
+    h->be.err = e.what();
+    return MVUS_E_INVALID;
+  }
+}
+
+extern "C" {
+
+void mvus_default_opts(mvus_solve_opts* o) {
+  if (!o) return;
+  o->solver = MVUS_SOLVER_TRF_LSMR; o->jac_mode = MVUS_JAC_PATTERN; o->max_nfev = 10;
+  o->ftol = 1e-8; o->xtol = 1e-12; o->gtol = 1e-8;
+  o->lsmr_atol = 1e-6; o->lsmr_btol = 1e-6; o->lsmr_conlim = 1e8; o->lsmr_maxiter = 0; o->verbose = 0;
+}
+
+int mvus_ba_create(const mvus_problem* p, mvus_ba** out) {
+  if (!out) return MVUS_E_INVALID;
+  *out = nullptr;
+  mvus_ba* h = new mvus_ba();
+  std::string msg = h->be.hp.build(p);
+  if (!msg.empty()) { g_create_error = msg; delete h; return MVUS_E_INVALID; }
+  try {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= p->device)
+      throw HipError{"no usable HIP device (libmvusba has no CPU fallback)"};
+    h->be.init(p);
+  } catch (const HipError& e) {
+    g_create_error = e.msg;
+    delete h;
+    return MVUS_E_HIP;
+  }
+  *out = h;
+  return MVUS_OK;
+}
+
+void mvus_ba_destroy(mvus_ba* h) { delete h; }
+
+const char* mvus_last_error(const mvus_ba* h) { return h ? h->be.err.c_str() : g_create_error.c_str(); }
+
+int64_t mvus_ba_num_params(const mvus_ba* h) { return h ? h->be.hp.n : -1; }
+int64_t mvus_ba_num_residuals(const mvus_ba* h) { return h ? h->be.hp.m : -1; }
+int64_t mvus_ba_num_motion_rows(const mvus_ba* h) { return h ? h->be.hp.T : -1; }
+int32_t mvus_ba_num_slots(const mvus_ba* h) { return h ? h->be.hp.NS : -1; }
+
+int mvus_ba_set_x(mvus_ba* h, const double* x) {
+  return guarded(h, [&] { h->be.upload(h->be.x_cur, x, h->be.hp.n); return MVUS_OK; });
+}
+
+int mvus_ba_residual(mvus_ba* h, const double* x, double* f) {
+  return guarded(h, [&] {
+    HipBackend& be = h->be;
+    be.upload(be.x_cur, x, be.hp.n);
+    be.residual(be.x_cur, be.f_cur);
+    if (f) be.download(f, be.f_cur, be.hp.m);
+    return MVUS_OK;
+  });
+}
+
+int mvus_ba_residual_jacobian(mvus_ba* h, const double* x, int32_t jac_mode, double* f, double* J, int32_t* ctrl) {
+  return guarded(h, [&] {
+    HipBackend& be = h->be;
+    be.upload(be.x_cur, x, be.hp.n);
+    // rows that stay invisible are never written by the kernel: clear so the host copy is well defined
+    if (J) MVUS_HIP(hipMemsetAsync(be.J, 0, sizeof(double) * 2 * be.hp.NS * be.hp.M, be.stream));
+    be.jacobian(be.x_cur, be.f_cur, jac_mode);
+    if (f) be.download(f, be.f_cur, be.hp.m);
+    if (J) be.download(J, be.J, (int64_t)2 * be.hp.NS * be.hp.M);
+    if (ctrl) {
+      MVUS_HIP(hipMemcpyAsync(ctrl, be.span, sizeof(int32_t) * be.hp.M, hipMemcpyDeviceToHost, be.stream));
+      MVUS_HIP(hipStreamSynchronize(be.stream));
+    }
+    return MVUS_OK;
+  });
+}
+
+int mvus_ba_motion_rows(mvus_ba* h, const double* x, int32_t jac_mode, double* mf, double* mJ, int32_t* mctrl) {
+  return guarded(h, [&] {
+    HipBackend& be = h->be;
+    be.upload(be.x_cur, x, be.hp.n);
+    be.jacobian(be.x_cur, be.f_cur, jac_mode);
+    const int T = be.hp.T;
+    if (mf && T) be.download(mf, be.f_cur + 2 * be.hp.M, T);
+    if (mJ && T) be.download(mJ, be.mJ, (int64_t)36 * T);
+    if (mctrl && T) {
+      MVUS_HIP(hipMemcpyAsync(mctrl, be.mctrl, sizeof(int32_t) * 3 * T, hipMemcpyDeviceToHost, be.stream));
+      MVUS_HIP(hipStreamSynchronize(be.stream));
+    }
+    return MVUS_OK;
+  });
+}
+
+int mvus_ba_set_pattern(mvus_ba* h, const double* x0, int32_t* pat_out) {
+  return guarded(h, [&] {
+    HipBackend& be = h->be;
+    be.upload(be.x_cur, x0, be.hp.n);
+    be.set_pattern(be.x_cur);
+    if (pat_out) {
+      MVUS_HIP(hipMemcpyAsync(pat_out, be.pat0, sizeof(int32_t) * be.hp.M, hipMemcpyDeviceToHost, be.stream));
+      MVUS_HIP(hipStreamSynchronize(be.stream));
+    }
+    return MVUS_OK;
+  });
+}
+
+int mvus_ba_jv(mvus_ba* h, const double* v, double* y) {
+  return guarded(h, [&] {
+    HipBackend& be = h->be;
+    if (!be.has_jacobian) { be.err = "no Jacobian held: call mvus_ba_residual_jacobian first"; return MVUS_E_INVALID; }
+    double* vd = be.alloc(be.hp.n); double* yd = be.alloc(be.hp.m);
+    be.upload(vd, v, be.hp.n);
+    be.jv(vd, yd);
+    be.download(y, yd, be.hp.m);
+    be.release(vd); be.release(yd);
+    return MVUS_OK;
+  });
+}
+
+int mvus_ba_jtu(mvus_ba* h, const double* u, double* z) {
+  return guarded(h, [&] {
+    HipBackend& be = h->be;
+    if (!be.has_jacobian) { be.err = "no Jacobian held: call mvus_ba_residual_jacobian first"; return MVUS_E_INVALID; }
+    double* ud = be.alloc(be.hp.m); double* zd = be.alloc(be.hp.n);
+    be.upload(ud, u, be.hp.m);
+    be.jtu(ud, zd);
+    be.download(z, zd, be.hp.n);
+    be.release(ud); be.release(zd);
+    return MVUS_OK;
+  });
+}
+
+int mvus_ba_normal_equations(mvus_ba* h, double* g, double* JtJ_cam, double* band, double* cross, int32_t* W_out) {
+  return guarded(h, [&] { return schur_export(h->be, g, JtJ_cam, band, cross, W_out); });
+}
+
+int mvus_ba_solve(mvus_ba* h, double* x, const mvus_solve_opts* opts, mvus_result* res, double* f_out) {
+  return guarded(h, [&] {
+    HipBackend& be = h->be;
+    if (!x || !opts || !res) { be.err = "NULL argument"; return MVUS_E_INVALID; }
+    const auto t0 = std::chrono::steady_clock::now();
+    const int64_t n = be.hp.n;
+    std::vector<double> xv(x, x + n), lb(n, -INFINITY), ub(n, INFINITY);
+    if (be.hp.rs_bounds) for (int c = 0; c < be.hp.C; ++c) { lb[2 * be.hp.C + c] = 0.0; ub[2 * be.hp.C + c] = 1.0; }
+    SolveOptions so;
+    so.jac_mode = opts->jac_mode; so.max_nfev = opts->max_nfev; so.ftol = opts->ftol; so.xtol = opts->xtol; so.gtol = opts->gtol;
+    so.lsmr_atol = opts->lsmr_atol; so.lsmr_btol = opts->lsmr_btol; so.lsmr_conlim = opts->lsmr_conlim;
+    so.lsmr_maxiter = opts->lsmr_maxiter; so.verbose = opts->verbose;
+    if (so.jac_mode == MVUS_JAC_PATTERN) {
+      be.upload(be.x_cur, xv.data(), n);
+      be.set_pattern(be.x_cur);
+    }
+    SolveResult sr;
+    if (opts->solver == MVUS_SOLVER_LM_SCHUR) sr = lm_schur_hip(be, xv, lb, ub, so, be.f_cur);
+    else sr = trf_lsmr(be, xv, lb, ub, so, be.f_cur);
+    if (sr.error) { be.err = "residuals are not finite in the initial point, or x0 is outside of the bounds"; return MVUS_E_NUMERIC; }
+    std::memcpy(x, xv.data(), sizeof(double) * n);
+    if (f_out) be.download(f_out, be.f_cur, be.hp.m);
+    MVUS_HIP(hipStreamSynchronize(be.stream));
+    res->cost = sr.cost; res->optimality = sr.optimality; res->nfev = sr.nfev; res->njev = sr.njev; res->status = sr.status;
+    res->lin_iters = sr.lin_iters; res->initial_cost = sr.initial_cost;
+    res->solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return MVUS_OK;
+  });
+}
+
+int mvus_ba_outlier_mask(mvus_ba* h, const double* x, double thres, uint8_t* keep) {
+  return guarded(h, [&] {
+    HipBackend& be = h->be;
+    be.upload(be.x_cur, x, be.hp.n);
+    be.residual(be.x_cur, be.f_cur);
+    uint8_t* kd = nullptr;
+    MVUS_HIP(hipMalloc(reinterpret_cast<void**>(&kd), std::max<int64_t>(be.hp.M, 1)));
+    if (be.dp.n_chunks > 0) hipLaunchKernelGGL(k_outlier_mask, dim3(be.dp.n_chunks), dim3(kThreads), 0, be.stream, be.dp, be.f_cur, thres, kd);
+    hipError_t e = hipMemcpyAsync(keep, kd, be.hp.M, hipMemcpyDeviceToHost, be.stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(be.stream);
+    (void)hipFree(kd);
+    MVUS_HIP(e);
+    return MVUS_OK;
+  });
+}
+
+int mvus_ba_set_allreduce(mvus_ba* h, mvus_allreduce_fn fn, void* user, int32_t is_root) {
+  return guarded(h, [&] {
+    HipBackend& be = h->be;
+    be.allreduce = fn; be.allreduce_user = user; be.is_root = is_root;
+    be.m_glob = be.hp.m;
+    if (fn) {   // global row count = sum of the shards' rows
+      be.scal_host[2] = (double)be.hp.m;
+      MVUS_HIP(hipMemcpyAsync(be.scal_dev + 2, be.scal_host + 2, sizeof(double), hipMemcpyHostToDevice, be.stream));
+      be.reduce(be.scal_dev + 2, 1);
+      be.m_glob = (int64_t)(be.read_slot(2) + 0.5);
+    }
+    return MVUS_OK;
+  });
+}
+
+int mvus_ba_time_kernel(mvus_ba* h, int32_t which, int32_t launches, double* avg_ms) {
+  return guarded(h, [&] {
+    HipBackend& be = h->be;
+    if (launches < 1 || !avg_ms) { be.err = "bad arguments"; return MVUS_E_INVALID; }
+    hipEvent_t e0, e1;
+    MVUS_HIP(hipEventCreate(&e0)); MVUS_HIP(hipEventCreate(&e1));
+    double* vn = be.alloc(be.hp.n); double* um = be.alloc(be.hp.m); double* zn = be.alloc(be.hp.n); double* ym = be.alloc(be.hp.m);
+    be.fill(vn, 1e-3, be.hp.n); be.fill(um, 1e-3, be.hp.m);
+    hipLaunchKernelGGL(k_cam_states, dim3((be.hp.C + 63) / 64), dim3(64), 0, be.stream, be.dp, be.x_cur, be.cams);
+    if (which >= 2 && !be.has_jacobian) be.jacobian(be.x_cur, be.f_cur, MVUS_JAC_ANALYTIC);
+    const dim3 g(std::max(be.dp.n_chunks, 1)), b(kThreads);
+    auto launch = [&]() {
+      switch (which) {
+        case 0:
+          if (be.hp.calib) hipLaunchKernelGGL((k_observations<true, false>), g, b, 0, be.stream, be.dp, be.cams, be.x_cur, be.f_cur, be.J, be.span, be.pat0, 0);
+          else hipLaunchKernelGGL((k_observations<false, false>), g, b, 0, be.stream, be.dp, be.cams, be.x_cur, be.f_cur, be.J, be.span, be.pat0, 0);
+          break;
+        case 1:
+          if (be.hp.calib) hipLaunchKernelGGL((k_observations<true, true>), g, b, 0, be.stream, be.dp, be.cams, be.x_cur, be.f_cur, be.J, be.span, be.pat0, 0);
+          else hipLaunchKernelGGL((k_observations<false, true>), g, b, 0, be.stream, be.dp, be.cams, be.x_cur, be.f_cur, be.J, be.span, be.pat0, 0);
+          break;
+        case 2:
+          if (be.hp.calib) hipLaunchKernelGGL(k_jv<30>, g, b, 0, be.stream, be.dp, be.J, be.span, vn, ym);
+          else hipLaunchKernelGGL(k_jv<21>, g, b, 0, be.stream, be.dp, be.J, be.span, vn, ym);
+          break;
+        case 3:
+          if (be.hp.calib) hipLaunchKernelGGL(k_jtu<30>, g, b, 0, be.stream, be.dp, be.J, be.span, um, zn);
+          else hipLaunchKernelGGL(k_jtu<21>, g, b, 0, be.stream, be.dp, be.J, be.span, um, zn);
+          break;
+        default:
+          schur_time_assembly(be);
+      }
+    };
+    if (be.dp.n_chunks == 0) { *avg_ms = 0; return MVUS_OK; }
+    launch();
+    MVUS_HIP(hipEventRecord(e0, be.stream));
+    for (int i = 0; i < launches; ++i) launch();
+    MVUS_HIP(hipEventRecord(e1, be.stream));
+    MVUS_HIP(hipEventSynchronize(e1));
+    float ms = 0;
+    MVUS_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *avg_ms = (double)ms / launches;
+    be.release(vn); be.release(um); be.release(zn); be.release(ym);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    be.has_jacobian = which >= 1 ? true : be.has_jacobian;
+    return MVUS_OK;
+  });
+}
+
+}  // extern "C"

@@ -1,0 +1,310 @@
+// HIP kernels of the BA hot path for gfx950 (MI355X, CDNA4).  fp64 throughout.
+//
+// Data layout in HBM (all SoA, camera-segmented, detections of one camera in frame order):
+//   frame[M] u_raw[M] v_raw[M]            raw detections (common.py:1190)
+//   u_obs[M] v_obs[M]                     observed pixel after the one-time undistortion (fixed calibration)
+//   f[m]                                  residuals in the reference row order (common.py:476-485)
+//   J[(a*NS + k)*M + i]                   Jacobian slot k of row a (0:x, 1:y) of observation i -> every one of
+//                                         the 2*NS stores / loads of a wavefront is one contiguous 512-B segment
+//   span[M]                               first active control point (global index), -1 = row is zero
+// Work decomposition: one 256-thread workgroup (4 wavefronts of 64) per chunk of <=256 consecutive
+// detections of ONE camera, so the camera's decoded parameters (R, t, K, d, alpha, beta, rs and the
+// rotation-derivative matrix W) are staged once per workgroup in LDS and every lane reads them as LDS
+// broadcasts; consecutive lanes hold consecutive frames, i.e. neighbouring timestamps, so their knot-span
+// searches and control-point gathers hit the same L1/L2 lines.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "ba_math.h"
+
+namespace mvus {
+
+constexpr int kThreads = 256;
+
+struct DevProblem {  // trivially copyable: passed to kernels by value
+  int C, P, NS, S, calib, undist, rs_free, T;
+  long long M;
+  const double *frame, *u_raw, *v_raw, *u_obs, *v_obs, *H, *Kfix, *dfix;
+  SplineView sp;
+  MotionView mv;
+  const int32_t *chunk_cam, *chunk_count;
+  const long long *chunk_start, *det_off;
+  int n_chunks;
+};
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// Decode every camera's parameters once per evaluation (C threads): Rodrigues + derivative matrix.
+__global__ void k_cam_states(DevProblem dp, const double* __restrict__ x, CamState* __restrict__ cams) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= dp.C) return;
+  CamState s;
+  load_cam_state(x, dp.C, c, dp.calib != 0, dp.Kfix, dp.dfix, dp.H[c], s);
+  cams[c] = s;
+}
+
+// Stage one camera state into LDS with the first sizeof(CamState)/8 lanes.
+__device__ __forceinline__ void stage_cam(const CamState* __restrict__ cams, int c, CamState& lds_cam) {
+  constexpr int kWords = sizeof(CamState) / sizeof(double);
+  const double* src = reinterpret_cast<const double*>(cams + c);
+  double* dst = reinterpret_cast<double*>(&lds_cam);
+  if (threadIdx.x < kWords) dst[threadIdx.x] = src[threadIdx.x];
+  __syncthreads();
+}
+
+// One-time undistortion of the observations when calibration is fixed (detection_to_global, common.py:126).
+__global__ void k_undistort_fixed(DevProblem dp, double* __restrict__ u_obs, double* __restrict__ v_obs) {
+  const int chunk = blockIdx.x;
+  const int c = dp.chunk_cam[chunk];
+  if ((int)threadIdx.x >= dp.chunk_count[chunk]) return;
+  const long long i = dp.chunk_start[chunk] + threadIdx.x;
+  const double fx = dp.Kfix[4 * c], fy = dp.Kfix[4 * c + 1], cx = dp.Kfix[4 * c + 2], cy = dp.Kfix[4 * c + 3];
+  double xn, yn;
+  undistort5<false>((dp.u_raw[i] - cx) / fx, (dp.v_raw[i] - cy) / fy, dp.dfix + 5 * c, xn, yn, nullptr, nullptr);
+  u_obs[i] = fx * xn + cx;
+  v_obs[i] = fy * yn + cy;
+}
+
+// Fused per-observation kernel: timestamp -> interval/span search -> de Boor -> R,t -> K -> |residual|
+// and (JAC) the 2 x NS analytic Jacobian block.  masked != 0 keeps only the reference pattern (pat0).
+template <bool CALIB, bool JAC>
+__global__ __launch_bounds__(kThreads) void k_observations(DevProblem dp, const CamState* __restrict__ cams,
+                                                           const double* __restrict__ x, double* __restrict__ f,
+                                                           double* __restrict__ J, int32_t* __restrict__ span,
+                                                           const int32_t* __restrict__ pat0, int masked) {
+  __shared__ CamState cam;
+  constexpr int NS = 3 + (CALIB ? 15 : 6) + 12;
+  const int chunk = blockIdx.x;
+  const int c = dp.chunk_cam[chunk];
+  stage_cam(cams, c, cam);
+  if ((int)threadIdx.x >= dp.chunk_count[chunk]) return;
+  const long long i = dp.chunk_start[chunk] + threadIdx.x;
+  const long long a = dp.det_off[c], Mc = dp.det_off[c + 1] - a;
+  double jx[NS], jy[NS];
+  const double uo = CALIB ? 0.0 : dp.u_obs[i], vo = CALIB ? 0.0 : dp.v_obs[i];
+  const double ur = CALIB ? dp.u_raw[i] : 0.0;
+  ObsResult r = eval_observation<CALIB, JAC>(cam, dp.sp, x, dp.undist != 0, dp.rs_free != 0, dp.frame[i], ur, dp.v_raw[i],
+                                             uo, vo, jx, jy);
+  f[2 * a + (i - a)] = r.ex;
+  f[2 * a + Mc + (i - a)] = r.ey;
+  if (JAC) {
+    int32_t ctrl = r.ctrl;
+    if (masked && ctrl >= 0) {
+      const int32_t p = pat0[i];
+      if (p < 0) ctrl = -1;
+      else mask_to_pattern(jx, jy, NS - 12, ctrl, p);
+    }
+    span[i] = ctrl;
+    if (ctrl >= 0) {
+#pragma unroll
+      for (int k = 0; k < NS; ++k) {
+        J[(long long)k * dp.M + i] = jx[k];
+        J[(long long)(NS + k) * dp.M + i] = jy[k];
+      }
+    }
+  }
+}
+
+// Reference sparsity pattern of the detection rows at x0 (jac_BA + compute_visibility).
+__global__ __launch_bounds__(kThreads) void k_pattern(DevProblem dp, const CamState* __restrict__ cams, int32_t* __restrict__ pat0) {
+  __shared__ CamState cam;
+  const int chunk = blockIdx.x;
+  const int c = dp.chunk_cam[chunk];
+  stage_cam(cams, c, cam);
+  if ((int)threadIdx.x >= dp.chunk_count[chunk]) return;
+  const long long i = dp.chunk_start[chunk] + threadIdx.x;
+  pat0[i] = observation_pattern(cam, dp.sp, dp.frame[i], dp.v_raw[i]);
+}
+
+// Motion-regulariser rows (error_motion / motion_prior): one thread per sample.
+template <bool JAC>
+__global__ __launch_bounds__(kThreads) void k_motion(DevProblem dp, const double* __restrict__ x, double* __restrict__ fm,
+                                                     double* __restrict__ mJ, int32_t* __restrict__ mctrl, int masked) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= dp.T) return;
+  double jrow[36];
+  int32_t cidx[3];
+  fm[j] = eval_motion_row<JAC>(dp.mv, x, j, masked != 0, jrow, cidx);
+  if (JAC) {
+#pragma unroll
+    for (int k = 0; k < 36; ++k) mJ[(long long)k * dp.T + j] = jrow[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) mctrl[(long long)k * dp.T + j] = cidx[k];
+  }
+}
+
+__device__ __forceinline__ int cam_col(int C, int P, int c, int k) { return k < 3 ? k * C + c : 3 * C + c * P + (k - 3); }
+
+// y = J v on the detection rows.  Camera/sync entries of v are staged in LDS once per workgroup.
+template <int NS>
+__global__ __launch_bounds__(kThreads) void k_jv(DevProblem dp, const double* __restrict__ J, const int32_t* __restrict__ span,
+                                                 const double* __restrict__ v, double* __restrict__ y) {
+  constexpr int B = NS - 12;
+  __shared__ double vc[B];
+  const int chunk = blockIdx.x;
+  const int c = dp.chunk_cam[chunk];
+  if (threadIdx.x < B) vc[threadIdx.x] = v[cam_col(dp.C, dp.P, c, threadIdx.x)];
+  __syncthreads();
+  if ((int)threadIdx.x >= dp.chunk_count[chunk]) return;
+  const long long i = dp.chunk_start[chunk] + threadIdx.x;
+  const long long a = dp.det_off[c], Mc = dp.det_off[c + 1] - a;
+  const int g = span[i];
+  double sx = 0.0, sy = 0.0;
+  if (g >= 0) {
+#pragma unroll
+    for (int k = 0; k < B; ++k) {
+      sx += J[(long long)k * dp.M + i] * vc[k];
+      sy += J[(long long)(NS + k) * dp.M + i] * vc[k];
+    }
+    const int x0 = dp.mv.ctrl_x0[g], st = dp.mv.ctrl_stride[g];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        const double vv = v[x0 + q + d * st];
+        sx += J[(long long)(B + 3 * q + d) * dp.M + i] * vv;
+        sy += J[(long long)(NS + B + 3 * q + d) * dp.M + i] * vv;
+      }
+  }
+  y[2 * a + (i - a)] = sx;
+  y[2 * a + Mc + (i - a)] = sy;
+}
+
+// z += J^T u on the detection rows.  The camera/sync slots of a workgroup all hit the same B columns:
+// wavefront shuffle reduction, then LDS across the 4 wavefronts, then one fp64 atomic per column.
+template <int NS>
+__global__ __launch_bounds__(kThreads) void k_jtu(DevProblem dp, const double* __restrict__ J, const int32_t* __restrict__ span,
+                                                  const double* __restrict__ u, double* __restrict__ z) {
+  constexpr int B = NS - 12;
+  __shared__ double part[kThreads / 64][B];
+  const int chunk = blockIdx.x;
+  const int c = dp.chunk_cam[chunk];
+  const bool active = (int)threadIdx.x < dp.chunk_count[chunk];
+  const long long i = dp.chunk_start[chunk] + (active ? threadIdx.x : 0);
+  const long long a = dp.det_off[c], Mc = dp.det_off[c + 1] - a;
+  const int g = active ? span[i] : -1;
+  const double ux = g >= 0 ? u[2 * a + (i - a)] : 0.0;
+  const double uy = g >= 0 ? u[2 * a + Mc + (i - a)] : 0.0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < B; ++k) {
+    double val = 0.0;
+    if (g >= 0) val = J[(long long)k * dp.M + i] * ux + J[(long long)(NS + k) * dp.M + i] * uy;
+    val = wave_sum(val);
+    if (lane == 0) part[wave][k] = val;
+  }
+  if (g >= 0) {
+    const int x0 = dp.mv.ctrl_x0[g], st = dp.mv.ctrl_stride[g];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        const double val = J[(long long)(B + 3 * q + d) * dp.M + i] * ux + J[(long long)(NS + B + 3 * q + d) * dp.M + i] * uy;
+        unsafeAtomicAdd(&z[x0 + q + d * st], val);
+      }
+  }
+  __syncthreads();
+  if (threadIdx.x < B) {
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < kThreads / 64; ++w) s += part[w][threadIdx.x];
+    unsafeAtomicAdd(&z[cam_col(dp.C, dp.P, c, threadIdx.x)], s);
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void k_motion_jv(DevProblem dp, const double* __restrict__ mJ, const int32_t* __restrict__ mctrl,
+                                                        const double* __restrict__ v, double* __restrict__ ym) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= dp.T) return;
+  double s = 0.0;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int g = mctrl[(long long)k * dp.T + j];
+    if (g < 0) continue;
+    const int x0 = dp.mv.ctrl_x0[g], st = dp.mv.ctrl_stride[g];
+    for (int q = 0; q < 4; ++q)
+      for (int d = 0; d < 3; ++d) s += mJ[(long long)(12 * k + 3 * q + d) * dp.T + j] * v[x0 + q + d * st];
+  }
+  ym[j] = s;
+}
+
+__global__ __launch_bounds__(kThreads) void k_motion_jtu(DevProblem dp, const double* __restrict__ mJ, const int32_t* __restrict__ mctrl,
+                                                         const double* __restrict__ um, double* __restrict__ z) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= dp.T) return;
+  const double uj = um[j];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int g = mctrl[(long long)k * dp.T + j];
+    if (g < 0) continue;
+    const int x0 = dp.mv.ctrl_x0[g], st = dp.mv.ctrl_stride[g];
+    for (int q = 0; q < 4; ++q)
+      for (int d = 0; d < 3; ++d) {
+        const double val = mJ[(long long)(12 * k + 3 * q + d) * dp.T + j] * uj;
+        if (val != 0.0) unsafeAtomicAdd(&z[x0 + q + d * st], val);
+      }
+  }
+}
+
+// Scene.remove_outliers (common.py:709-713): keep = sqrt(ex^2 + ey^2) < thres.  Explicit round-to-nearest
+// multiplies/adds (no FMA contraction) so the integer result is the one numpy computes from the same ex, ey.
+__global__ __launch_bounds__(kThreads) void k_outlier_mask(DevProblem dp, const double* __restrict__ f, double thres,
+                                                           uint8_t* __restrict__ keep) {
+  const int chunk = blockIdx.x;
+  const int c = dp.chunk_cam[chunk];
+  if ((int)threadIdx.x >= dp.chunk_count[chunk]) return;
+  const long long i = dp.chunk_start[chunk] + threadIdx.x;
+  const long long a = dp.det_off[c], Mc = dp.det_off[c + 1] - a;
+  const double ex = f[2 * a + (i - a)], ey = f[2 * a + Mc + (i - a)];
+  const double e = __dsqrt_rn(__dadd_rn(__dmul_rn(ex, ex), __dmul_rn(ey, ey)));
+  keep[i] = e < thres ? 1 : 0;
+}
+
+// ---- small vector kernels (n- and m-sized) -------------------------------------------------------
+__global__ void k_axpby(long long len, double a, const double* x, double b, const double* y, double* out) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < len; i += (long long)gridDim.x * blockDim.x)
+    out[i] = a * x[i] + b * y[i];
+}
+__global__ void k_mul(long long len, const double* x, const double* y, double* out) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < len; i += (long long)gridDim.x * blockDim.x)
+    out[i] = x[i] * y[i];
+}
+__global__ void k_fill(long long len, double v, double* out) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < len; i += (long long)gridDim.x * blockDim.x)
+    out[i] = v;
+}
+// deterministic two-stage dot product: per-workgroup partials, then one workgroup sums them
+__global__ __launch_bounds__(kThreads) void k_dot_partial(long long len, const double* __restrict__ a, const double* __restrict__ b,
+                                                          double* __restrict__ partials) {
+  __shared__ double red[kThreads / 64];
+  double s = 0.0;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < len; i += (long long)gridDim.x * blockDim.x)
+    s += a[i] * b[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int w = 0; w < kThreads / 64; ++w) t += red[w];
+    partials[blockIdx.x] = t;
+  }
+}
+__global__ __launch_bounds__(kThreads) void k_dot_final(int nb, const double* __restrict__ partials, double* __restrict__ out) {
+  __shared__ double red[kThreads / 64];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nb; i += blockDim.x) s += partials[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int w = 0; w < kThreads / 64; ++w) t += red[w];
+    *out = t;
+  }
+}
+
+}  // namespace mvus

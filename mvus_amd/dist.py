@@ -1,0 +1,61 @@
+"""One-process-per-GPU plumbing: observation shards + the all-reduce hook of the C ABI.
+
+PyTorch is used here for exactly two things: ``torch.distributed`` (backend ``nccl`` = RCCL over
+xGMI on ROCm) and the HIP stream the kernels and the collective are ordered on.  The device
+buffers the library asks to reduce are aliased as torch tensors through
+``__cuda_array_interface__`` -- no staging copy.
+"""
+import numpy as np
+
+from . import sharding
+from .ba import BAHandle
+
+
+class _DeviceDoubles:
+    """Zero-copy view of ``count`` float64 at a raw device pointer."""
+
+    def __init__(self, ptr, count):
+        self.__cuda_array_interface__ = {'shape': (int(count),), 'typestr': '<f8', 'data': (int(ptr), False),
+                                         'version': 2, 'strides': None}
+
+
+def make_gpu_allreduce(device_index, group=None):
+    """Returns fn(ptr, count, stream) summing the buffer across ranks with torch.distributed (RCCL)."""
+    import torch
+    import torch.distributed as dist
+    stats = {'calls': 0, 'doubles': 0}
+
+    def fn(ptr, count, stream):
+        t = torch.as_tensor(_DeviceDoubles(ptr, count), device='cuda:%d' % device_index)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        stats['calls'] += 1
+        stats['doubles'] += count
+
+    fn.stats = stats
+    return fn
+
+
+def sharded_handle(prob, rank, world, device_index, group=None):
+    """BAHandle over observation shard ``rank`` of ``world`` on ``cuda:device_index``.
+
+    The handle runs on torch's current stream of that device so that its kernels and the collective are
+    ordered without extra events.  Motion-regulariser rows are replicated inputs but must be counted
+    once: rank 0 keeps them, the other shards drop them."""
+    import torch
+    torch.cuda.set_device(device_index)
+    shard, keep = prob.shard(rank, world)
+    if rank != 0:
+        shard.motion_reg = False
+    stream = torch.cuda.current_stream(device_index).cuda_stream
+    h = BAHandle(shard, device=device_index, stream=stream)
+    if world > 1 or group is not None:
+        cb = make_gpu_allreduce(device_index, group)
+        h.set_allreduce(cb, is_root=(rank == 0))
+        h.allreduce_stats = cb.stats
+    return h, keep
+
+
+def shard_sizes(prob, world):
+    return [sum(sharding.shard_offsets(int(prob.det_offsets[c + 1] - prob.det_offsets[c]), r, world)[1]
+                - sharding.shard_offsets(int(prob.det_offsets[c + 1] - prob.det_offsets[c]), r, world)[0]
+                for c in range(prob.C)) for r in range(world)]

@@ -1,0 +1,239 @@
+"""GPU parity tests: the HIP path (through the C ABI, mvus_amd.ba.BAHandle) against the oracle, the
+golden vectors captured from the reference, and the host build of the same device math."""
+import numpy as np
+import pytest
+
+from oracle import ba_oracle as orc
+from golden_util import CASES, load_case
+from mvus_amd import _lib
+from mvus_amd import problem as mp
+
+pytestmark = pytest.mark.gpu
+
+RESIDUAL_ATOL = 1e-9        # px, fp64 residuals vs the reference's values
+JAC_RTOL = 1e-10            # GPU vs host build of the same analytic formulas (relative to column scale)
+
+
+@pytest.fixture(scope='module')
+def BAHandle():
+    from mvus_amd.ba import BAHandle as H
+    return H
+
+
+def _host(prob):
+    from hostcheck_util import HostHandle
+    return HostHandle(prob)
+
+
+def slots_to_dense(prob, J, ctrl, mJ=None, mctrl=None):
+    """Scatter the slot Jacobian into a dense (m, n) matrix in the reference row order."""
+    C, P = prob.C, prob.P
+    n = prob.n_params
+    T = 0 if mJ is None else mJ.shape[1]
+    D = np.zeros((2 * prob.M + T, n))
+    coff = prob.ctrl_offsets
+    for c in range(C):
+        a, b = int(prob.det_offsets[c]), int(prob.det_offsets[c + 1])
+        Mc = b - a
+        cam_cols = [c, C + c, 2 * C + c] + list(range(3 * C + c * P, 3 * C + (c + 1) * P))
+        for i in range(a, b):
+            g = int(ctrl[i])
+            if g < 0:
+                continue
+            s = int(np.searchsorted(coff, g, side='right') - 1)
+            ns, j = int(prob.n_coef[s]), g - int(coff[s])
+            cols = cam_cols + [int(prob.spline_x_offsets[s]) + d * ns + j + q for q in range(4) for d in range(3)]
+            D[2 * a + (i - a), cols] = J[0, :, i]
+            D[2 * a + Mc + (i - a), cols] = J[1, :, i]
+    for jrow in range(T):
+        for k in range(3):
+            g = int(mctrl[k, jrow])
+            if g < 0:
+                continue
+            s = int(np.searchsorted(coff, g, side='right') - 1)
+            ns, j = int(prob.n_coef[s]), g - int(coff[s])
+            for q in range(4):
+                for d in range(3):
+                    D[2 * prob.M + jrow, int(prob.spline_x_offsets[s]) + d * ns + j + q] += mJ[12 * k + 3 * q + d, jrow]
+    return D
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_residual_vs_reference_golden(BAHandle, name):
+    scene, g = load_case(name)
+    prob, x0 = mp.problem_from_scene(scene)
+    np.testing.assert_allclose(x0, g['x0'], rtol=0, atol=1e-12)
+    oprob, _ = orc.problem_from_scene(scene)
+    with BAHandle(prob) as h:
+        assert h.n == g['x0'].size and h.m == g['f_x0'].size
+        for x, fref in ((g['x0'], g['f_x0']), (g['x0'] + g['delta'], g['f_x0_delta']), (g['ba10_x'], g['ba10_fun'])):
+            f = h.residual(x)
+            scale = np.maximum(1.0, np.abs(fref))
+            assert np.max(np.abs(f - fref) / scale) < RESIDUAL_ATOL
+            assert np.array_equal(f == 0, fref == 0)          # visibility: integer information, exact
+            fo = orc.residual(oprob, x)
+            assert np.max(np.abs(f - fo) / scale) < RESIDUAL_ATOL
+
+
+@pytest.mark.parametrize('name', CASES)
+@pytest.mark.parametrize('mode', [_lib.JAC_ANALYTIC, _lib.JAC_PATTERN])
+def test_jacobian_operator_vs_host_build(BAHandle, name, mode):
+    scene, g = load_case(name)
+    prob, _ = mp.problem_from_scene(scene)
+    hh = _host(prob)
+    x = g['x0'] + g['delta']
+    pat_host = hh.set_pattern(g['x0'])
+    f_ref, D_ref = hh.dense_jacobian(x, mode)
+    with BAHandle(prob) as h:
+        pat = h.set_pattern(g['x0'])
+        assert np.array_equal(pat, pat_host)
+        f, J, ctrl = h.residual_jacobian(x, mode)
+        mf, mJ, mctrl = h.motion_rows(x, mode)
+        D = slots_to_dense(prob, J, ctrl, mJ if h.T else None, mctrl if h.T else None)
+        scale = np.maximum(np.abs(D_ref).max(axis=0), 1e-12)
+        assert np.max(np.abs(D - D_ref) / scale) < JAC_RTOL
+        np.testing.assert_allclose(f, f_ref, rtol=0, atol=1e-9)
+        rng = np.random.default_rng(0)
+        v, u = rng.normal(size=h.n), rng.normal(size=h.m)
+        yref, zref = D_ref @ v, D_ref.T @ u
+        np.testing.assert_allclose(h.jv(v), yref, rtol=1e-10, atol=1e-10 * np.abs(yref).max())
+        np.testing.assert_allclose(h.jtu(u), zref, rtol=1e-10, atol=1e-10 * np.abs(zref).max())
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_analytic_jacobian_vs_oracle_central_differences(BAHandle, name):
+    scene, g = load_case(name)
+    prob, _ = mp.problem_from_scene(scene)
+    oprob, _ = orc.problem_from_scene(scene)
+    oprob.motion_reg = False
+    x = g['x0'] + g['delta']
+    with BAHandle(prob) as h:
+        f, J, ctrl = h.residual_jacobian(x, _lib.JAC_ANALYTIC)
+    D = slots_to_dense(prob, J, ctrl)
+    Jfd = orc.numeric_jacobian(oprob, x, rel=1e-6)
+    if not prob.rs_free:
+        Jfd[:, 2 * prob.C:3 * prob.C] = 0.0
+    fo = orc.residual(oprob, x)
+    ok = np.abs(fo) > 0.05
+    alpha, beta, rs, cams, tck = orc.unpack_x(oprob, x)
+    near = []
+    for c in range(prob.C):
+        tau = orc.detection_to_global(oprob, c, alpha, beta, rs, cams[c])[0]
+        ne = (np.abs(tau[:, None] - oprob.interval.reshape(1, -1)) < 0.05).any(axis=1)
+        near += [ne, ne]
+    ok &= ~np.concatenate(near)
+    scale = np.maximum(np.abs(Jfd[ok]).max(axis=0), 1e-12)
+    assert np.max(np.abs(D[ok] - Jfd[ok]) / scale) < 2e-5
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_outlier_mask_bit_exact(BAHandle, name):
+    scene, g = load_case(name)
+    prob, _ = mp.problem_from_scene(scene)
+    with BAHandle(prob) as h:
+        keep = h.outlier_mask(g['ba10_x'], float(g['thres_outlier']))
+    assert np.array_equal(keep.astype(np.uint8), g['outlier_keep'])
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_trf_lsmr_gpu_matches_host_backend(BAHandle, name):
+    """Same templated optimiser, HIP backend vs plain-C++ backend, LSMR capped where rounding cannot fork it."""
+    scene, g = load_case(name)
+    prob, _ = mp.problem_from_scene(scene)
+    opts = _lib.default_opts(_lib.SOLVER_TRF_LSMR, _lib.JAC_PATTERN, 15)
+    opts.lsmr_maxiter = 4
+    xh, rh, fh = _host(prob).solve(g['x0'], opts)
+    with BAHandle(prob) as h:
+        r = h.solve(g['x0'], opts=opts)
+    assert (r.nfev, r.njev, r.status) == (rh.nfev, rh.njev, rh.status)
+    np.testing.assert_allclose(r.cost, rh.cost, rtol=1e-9)
+    np.testing.assert_allclose(r.x, xh, rtol=0, atol=1e-7)
+    np.testing.assert_allclose(r.fun, fh, rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_ba_vs_reference_result(BAHandle, name):
+    """Scene.BA's 10-evaluation result: never worse than the reference beyond its own reproducibility."""
+    scene, g = load_case(name)
+    prob, _ = mp.problem_from_scene(scene)
+    oprob, _ = orc.problem_from_scene(scene)
+    with BAHandle(prob) as h:
+        r = h.solve(g['x0'], solver=_lib.SOLVER_TRF_LSMR, jac_mode=_lib.JAC_PATTERN, max_nfev=10)
+        keep = h.outlier_mask(r.x, float(g['thres_outlier']))
+    assert r.nfev == int(g['ba10_nfev'])
+    assert r.cost < float(g['ba10_cost']) * (1 + 5e-3)
+    assert orc.reprojection_rmse(oprob, r.x) < float(g['ba10_rmse']) + 2.5e-2
+    assert np.mean(keep.astype(np.uint8) == g['outlier_keep']) > 0.95
+
+
+def test_error_paths(BAHandle):
+    scene, g = load_case('calib_KE_bounds_3cam')
+    prob, x0 = mp.problem_from_scene(scene)
+    with BAHandle(prob) as h:
+        bad = x0.copy()
+        bad[2 * prob.C] = 1.5                         # outside 0 <= rs <= 1: scipy raises ValueError
+        with pytest.raises(ValueError):
+            h.solve(bad)
+        nanx = x0.copy()
+        nanx[0] = np.nan
+        with pytest.raises(ValueError):
+            h.solve(nanx)
+        with pytest.raises(ValueError):
+            h.residual(x0[:-1])
+    broken = mp.problem_from_scene(scene)[0]
+    broken.interval = broken.interval[::-1].copy()    # end < start
+    with pytest.raises(ValueError):
+        BAHandle(broken)
+
+
+def test_empty_and_ragged_cameras(BAHandle):
+    """A camera without detections and a camera whose detections all fall outside the spline."""
+    from mvus_amd import synth
+    sc = synth.make_scene(3, 900, seed=9, rolling_shutter=True, knot_spacing=14.0)
+    sc.detections[1] = sc.detections[1][:, :0]
+    sc.detections[2] = sc.detections[2].copy()
+    sc.detections[2][0] += 1e6
+    prob, x0 = mp.problem_from_scene(sc)
+    oprob, _ = orc.problem_from_scene(sc)
+    with BAHandle(prob) as h:
+        f = h.residual(x0)
+        fo = orc.residual(oprob, x0)
+        np.testing.assert_allclose(f, fo, rtol=0, atol=1e-9)
+        assert not f[2 * prob.det_offsets[2]:].any()
+        r = h.solve(x0, jac_mode=_lib.JAC_ANALYTIC, max_nfev=5)
+        assert np.isfinite(r.cost) and r.cost <= r.initial_cost
+
+
+def test_full_size_properties(BAHandle):
+    """BASELINE config 3 (32 cams x 500k obs): size-independent properties of the operator pair."""
+    from mvus_amd import synth
+    sc = synth.baseline_scene(2)
+    prob, x0 = mp.problem_from_scene(sc)
+    assert prob.C == 32 and abs(prob.M - 500_000) < 25_000
+    rng = np.random.default_rng(0)
+    with BAHandle(prob) as h:
+        f1 = h.residual(x0)
+        f2, J, ctrl = h.residual_jacobian(x0, _lib.JAC_ANALYTIC)
+        assert np.array_equal(f1, f2)                              # idempotent, and both kernels agree bit for bit
+        assert (ctrl >= 0).mean() > 0.9
+        del J
+        v1, v2, u = rng.normal(size=h.n), rng.normal(size=h.n), rng.normal(size=h.m)
+        y1, y2, y12 = h.jv(v1), h.jv(v2), h.jv(v1 + 2.0 * v2)
+        np.testing.assert_allclose(y12, y1 + 2.0 * y2, rtol=1e-9, atol=1e-9 * np.abs(y12).max())   # linearity
+        z = h.jtu(u)
+        lhs, rhs = float(y1 @ u), float(v1 @ z)
+        assert abs(lhs - rhs) <= 1e-9 * np.linalg.norm(y1) * np.linalg.norm(u)                       # adjoint pair
+        # directional derivative: |r| is smooth away from r = 0
+        d = rng.normal(size=h.n) * 1e-3
+        eps = 1e-4
+        fp, fm = h.residual(x0 + eps * d), h.residual(x0 - eps * d)
+        jd = h.jv(d)
+        ok = (np.abs(f1) > 0.5) & (fp != 0) & (fm != 0)
+        err = np.abs((fp - fm)[ok] / (2 * eps) - jd[ok])
+        assert np.quantile(err / (np.abs(jd[ok]) + 1e-3), 0.999) < 1e-3
+        # outlier mask == threshold on the residual pairs, bit for bit
+        keep = h.outlier_mask(x0, 10.0)
+        off = prob.det_offsets
+        ex = np.concatenate([f1[2 * a:2 * a + (b - a)] for a, b in zip(off[:-1], off[1:])])
+        ey = np.concatenate([f1[2 * a + (b - a):2 * b] for a, b in zip(off[:-1], off[1:])])
+        assert np.array_equal(keep, np.sqrt(ex ** 2 + ey ** 2) < 10.0)
