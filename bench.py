@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""bench.py -- BA iterations on synthetic N-camera x M-observation scenes, 1..8 MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config I] [--solver trf|lm]
+
+A *step* is one bundle-adjustment iteration = one trust-region trial of ``Scene.BA``:
+residual + Jacobian at x, one linear solve for the step, residual at the trial point
+(``mvus_ba_solve`` with ``max_nfev = 2``; comparable to one scipy ``nfev``).  ``value`` is the whole-job
+throughput in residuals/s -- one residual = one observation's (x, y) pair going through one BA
+iteration -- with every input already resident in HBM (the handle is created before the timed region;
+per step only the n-vector x crosses PCIe).  BA iterations/s is reported beside it.
+
+Workload at N=1: BASELINE.json configs[2] ("synthetic 32 cams x 500k obs, RS on, ~5k spline knots"), the
+configuration the north star quotes its HBM target on; configs[1] (7 cams x 100k) via ``--config 1``.
+For N>1 the observation count grows with N (weak scaling: ~500k observations per GPU, cameras and
+spline fixed) and observations are sharded over the ranks with one RCCL all-reduce per J^T u / dot product.
+
+The JSON line also carries the roofline of the dominant kernel (residual+Jacobian), measured with
+HIP events on the kernel's own stream, and a CPU baseline (the oracle's restatement of the scipy path,
+one core) on a bounded sample, on rank 0 at N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def algorithmic_bytes(prob):
+    """per observation read frame,v_raw,u_obs,v_obs (32 B; 24 B + in-kernel undistortion with
+    opt_calib), write 2 residuals (16 B), 2*NS Jacobian slots and one int32 span; once per launch the
+    parameter vector, the knots and the per-camera constants."""
+    NS = 3 + prob.P + 12
+    per_obs = (24 if prob.opt_calib else 32) + 16 + 2 * NS * 8 + 4
+    once = (prob.n_params + prob.knots.size + 10 * prob.C) * 8
+    return per_obs, once
+
+
+def cpu_baseline(config_index):
+    """The reference's CPU path restated (oracle: numpy residual + scipy least_squares with the sparsity
+    pattern, exactly the call of common.py:670), single core, on a 1/32-scale sample of the workload."""
+    import numpy as np
+    from mvus_amd import synth
+    from oracle import ba_oracle as orc
+    kw = dict(synth.BASELINE_CONFIGS[config_index])
+    scale = 32 if kw['total_obs'] >= 200_000 else 8
+    kw['total_obs'] = max(kw['total_obs'] // scale, 2000)
+    if kw.get('num_knots'):
+        kw['num_knots'] = max(kw['num_knots'] // scale, 16)
+    sc = synth.make_scene(**kw)
+    oprob, x0 = orc.problem_from_scene(sc)
+    t0 = time.perf_counter()
+    res = orc.solve(oprob, x0, max_iter=8)
+    dt = time.perf_counter() - t0
+    M = sum(d.shape[1] for d in oprob.detections)
+    iters = max(res.nfev - 1, 1)
+    return {'value': M * iters / dt, 'unit': 'residuals/s', 'cores': 1, 'kind': 'port',
+            'ba_iters_per_s': iters / dt,
+            'sample': '%d cams x %d obs (%d params), 1/%d-scale sample of the workload from the same generator; '
+                      'oracle restatement of Scene.BA: scipy least_squares(jac_sparsity, lsmr, 2-point FD), '
+                      '%d trial steps in %.1f s' % (oprob.C, M, x0.size, scale, iters, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--config', type=int, default=2, help='index into BASELINE.json configs (2 = 32 cams x 500k obs)')
+    ap.add_argument('--solver', choices=['trf', 'lm'], default=os.environ.get('MVUS_BENCH_SOLVER', 'trf'))
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d' % (args.gpus, args.gpus))
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU (the BA hot path has no CPU fallback)')
+    torch.cuda.set_device(local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+
+    from mvus_amd import problem as mp, synth
+    from mvus_amd import ba
+    from mvus_amd.dist import sharded_handle
+
+    kw = dict(synth.BASELINE_CONFIGS[args.config])
+    per_gpu_obs = kw['total_obs']
+    kw['total_obs'] = per_gpu_obs * world                      # weak scaling: fixed work per GPU
+    if kw.get('num_knots'):
+        kw['num_knots'] = kw['num_knots'] * world              # keep observations per knot fixed
+    scene = synth.make_scene(**kw)
+    prob, x0 = mp.problem_from_scene(scene)
+    handle, _ = sharded_handle(prob, rank, world, local_rank) if world > 1 else (ba.BAHandle(prob, device=local_rank), None)
+    solver = ba.SOLVER_LM_SCHUR if args.solver == 'lm' else ba.SOLVER_TRF_LSMR
+    jac_mode = ba.JAC_ANALYTIC if args.solver == 'lm' else ba.JAC_PATTERN
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    x = x0.copy()
+    lin_iters = 0
+    for _ in range(args.warmup):
+        r = handle.solve(x, solver=solver, jac_mode=jac_mode, max_nfev=2, return_fun=False)
+        x = r.x
+    barrier()
+    t0 = time.perf_counter()
+    cost0 = None
+    for _ in range(args.steps):
+        r = handle.solve(x, solver=solver, jac_mode=jac_mode, max_nfev=2, return_fun=False)
+        x = r.x
+        lin_iters += r.lin_iters
+        cost0 = r.initial_cost if cost0 is None else cost0
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    # roofline of the dominant kernel: residual + Jacobian, HIP events on the kernel's own stream
+    handle.set_x(x)
+    t_rj = handle.time_kernel(ba.KERNEL_RESIDUAL_JACOBIAN, 50)
+    t_r = handle.time_kernel(ba.KERNEL_RESIDUAL, 50)
+    t_jv = handle.time_kernel(ba.KERNEL_JV, 50)
+    t_jtu = handle.time_kernel(ba.KERNEL_JTU, 50)
+    per_obs, once = algorithmic_bytes(handle.prob)
+    bytes_launch = handle.prob.M * per_obs + once
+    achieved = bytes_launch / (t_rj * 1e-3) / 1e9
+
+    if rank == 0:
+        M_total = prob.M
+        out = {
+            'metric': 'residuals/sec', 'value': M_total * args.steps / dt, 'unit': 'residuals/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'ba_iters_per_sec': args.steps / dt,
+            'config': {'workload': 'BASELINE configs[%d]: %d cams x %d obs (%d per GPU), rolling shutter %s, %d spline '
+                                   'control points, %d params, %d residual rows; step = 1 trust-region trial '
+                                   '(residual+Jacobian, %s, trial residual)'
+                                   % (args.config, prob.C, M_total, handle.prob.M, 'on' if prob.rs_free else 'off',
+                                      int(prob.n_coef.sum()), prob.n_params, prob.n_residuals,
+                                      'LM normal equations + Schur solve' if args.solver == 'lm'
+                                      else 'scipy-TRF restatement with LSMR on the block-sparse J (%.0f LSMR its/step)' % (lin_iters / max(args.steps, 1))),
+                       'solver': args.solver, 'parallelism': 'obs-shard x%d' % world,
+                       'cost_first': cost0, 'cost_last': r.cost},
+            'roofline': {'bound': 'hbm', 'kernel': 'k_observations<calib=%s,jac=true>' % ('true' if prob.opt_calib else 'false'),
+                         'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+                         'traffic': None, 'bytes_per_launch': bytes_launch, 'avg_launch_ms': t_rj,
+                         'bytes_per_obs': per_obs, 'obs_per_launch': handle.prob.M},
+            'kernels_ms': {'residual': t_r, 'residual_jacobian': t_rj, 'jv': t_jv, 'jtu': t_jtu},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(args.config)
+        print(json.dumps(out))
+    handle.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,408 @@
+"""``Scene`` / ``Camera`` / ``create_scene`` with the reference's names, attributes and config surface
+(reference ``multiviewunsynch/reconstruction/common.py``), with the bundle-adjustment hot path --
+``Scene.BA`` (common.py:441-697), ``Scene.remove_outliers`` (:700-717), ``Scene.error_cam`` (:304-359) --
+running on the GPU through libmvusba.so.  There is no CPU fallback for those three.
+
+Kept from the reference: the ``Scene`` attribute set that ends up in the output pickle (README "Output"),
+method names and signatures, the ``config.json`` schema (``create_scene``), the parameter-vector layout and the
+side effects of ``BA`` on ``alpha/beta/rs/cameras/spline/detections_global``.
+
+Out of scope: trajectory initialisation, PnP, triangulation, synchronisation search,
+plotting, and the dead ``motion_prior=True`` branch -- those methods raise ``NotImplementedError``.
+
+Extra ``settings`` keys (all optional): ``ba_solver`` ('trf' = scipy TRF+LSMR restated, default; 'lm' = LM with
+Schur complement), ``ba_jacobian`` ('pattern' = analytic masked to the reference sparsity pattern, default with
+'trf'; 'analytic'), ``device`` (HIP device ordinal).
+"""
+import json
+
+import numpy as np
+
+from ..tools import util
+from .. import problem as _problem
+from ..synth import rodrigues as _rodrigues, rotation_to_rvec as _rotation_to_rvec
+
+
+def _undistort_normalized(points, K, d):
+    """cv2.undistortPoints(src, K, d): 5 fixed-point iterations of the 5-coefficient model (host copy of
+    ``undistort5`` in csrc/ba_math.h; used outside the BA loop only)."""
+    k1, k2, p1, p2, k3 = [float(v) for v in np.asarray(d, dtype=np.float64).reshape(-1)[:5]]
+    x0 = (points[0] - K[0, 2]) / K[0, 0]
+    y0 = (points[1] - K[1, 2]) / K[1, 1]
+    x, y = x0.copy(), y0.copy()
+    for _ in range(5):
+        r2 = x * x + y * y
+        icd = 1.0 / (1.0 + ((k3 * r2 + k2) * r2 + k1) * r2)
+        dx = 2.0 * p1 * x * y + p2 * (r2 + 2.0 * x * x)
+        dy = p1 * (r2 + 2.0 * y * y) + 2.0 * p2 * x * y
+        x, y = (x0 - dx) * icd, (y0 - dy) * icd
+    return np.vstack((x, y))
+
+
+class Camera:
+    """K, R, t, d, P container (reference common.py:1040-1168)."""
+
+    def __init__(self, **kwargs):
+        self.P = kwargs.get('P')
+        self.K = kwargs.get('K')
+        self.R = kwargs.get('R')
+        self.t = kwargs.get('t')
+        self.d = kwargs.get('d')
+        self.c = kwargs.get('c')
+        self.fps = kwargs.get('fps')
+        self.resolution = kwargs.get('resolution')
+
+    def projectPoint(self, X):
+        assert self.P is not None, 'The projection matrix P has not been calculated yet'
+        if X.shape[0] == 3:
+            X = util.homogeneous(X)
+        x = self.P @ X
+        return x / x[2]
+
+    def compose(self):
+        self.P = self.K @ np.hstack((self.R, np.asarray(self.t, dtype=np.float64).reshape(3, 1)))
+
+    def decompose(self):
+        M = self.P[:, :3]
+        Rinv, Kinv = np.linalg.qr(np.linalg.inv(M))
+        R, K = np.linalg.inv(Rinv), np.linalg.inv(Kinv)
+        T = np.diag(np.sign(np.diag(K)))
+        if np.linalg.det(T) < 0:
+            T[1, 1] *= -1
+        self.K, self.R = K @ T, T @ R
+        self.t = np.linalg.inv(self.K) @ self.P[:, 3]
+        self.K = self.K / self.K[-1, -1]
+        return self.K, self.R, self.t
+
+    def center(self):
+        if self.c is None:
+            self.decompose()
+            self.c = -self.R.T @ self.t
+        return self.c
+
+    def P2vector(self, calib=False):
+        r = _rotation_to_rvec(self.R)
+        if calib:
+            return np.concatenate(([self.K[0, 0], self.K[1, 1], self.K[0, 2], self.K[1, 2]], r, self.t, self.d))
+        return np.concatenate((r, self.t))
+
+    def vector2P(self, vector, calib=False):
+        vector = np.asarray(vector, dtype=np.float64)
+        if calib:
+            self.K = np.diag((1.0, 1.0, 1.0))
+            self.K[0, 0], self.K[1, 1] = vector[0], vector[1]
+            self.K[:2, -1] = vector[2:4]
+            self.R = _rodrigues(vector[4:7])
+            self.t = vector[7:10].copy()
+            self.d = vector[10:].copy()
+        else:
+            self.R = _rodrigues(vector[:3])
+            self.t = vector[3:6].copy()
+        self.compose()
+        return self.P
+
+    def undist_point(self, points):
+        assert points.shape[0] == 2, 'Input must be a 2D array'
+        return (self.K @ util.homogeneous(_undistort_normalized(points, self.K, self.d)))[:2]
+
+    def info(self):
+        for name in ('P', 'K', 'R', 't'):
+            print('\n %s:' % name)
+            print(getattr(self, name))
+
+
+class Scene:
+    """Everything known about the scene (reference common.py:22-61)."""
+
+    def __init__(self):
+        self.numCam = 0
+        self.cameras = []
+        self.detections = []
+        self.detections_raw = []
+        self.detections_global = []
+        self.alpha = []
+        self.beta = []
+        self.beta_after_Fbeta = []
+        self.cf = []
+        self.traj = []
+        self.traj_len = []
+        self.sequence = []
+        self.visible = []
+        self.settings = []
+        self.gt = []
+        self.out = {}
+        self.spline = {'tck': [], 'int': []}
+        self.rs = []
+        self.ref_cam = 0
+        self.find_order = True
+
+    # ---- bookkeeping --------------------------------------------------------------------------
+    def addCamera(self, *camera):
+        for c in camera:
+            assert type(c) is Camera, 'camera is not an instance of Camera'
+            self.cameras.append(c)
+
+    def addDetection(self, *detection):
+        for d in detection:
+            assert d.shape[0] == 3, 'Detection must in form of (x,y,frameId)*N'
+            self.detections.append(d)
+
+    def init_alpha(self, *prior):
+        if len(prior):
+            assert len(prior) == self.numCam, 'Number of input must be the same as the number of cameras'
+            self.alpha = prior
+        else:
+            fps_ref = self.cameras[self.ref_cam].fps
+            self.alpha = np.array([fps_ref / self.cameras[i].fps for i in range(self.numCam)], dtype=np.float64)
+
+    def time_shift(self, iter=False):
+        assert len(self.cf) == self.numCam, 'The number of frame indices should equal to the number of cameras'
+        if self.settings['cf_exact']:
+            self.beta = self.cf[self.ref_cam] - self.alpha * self.cf
+            print('The given corresponding frames are directly exploited as temporal synchronization\n')
+        else:
+            raise NotImplementedError('synchronisation search (sync_iter / sync_bf) is outside the BA hot path')
+
+    def detection_to_global(self, *cam, motion_prior=False):
+        """Frame indices -> global timeline, and the observed pixel (common.py:105-127)."""
+        assert len(self.alpha) == self.numCam and len(self.beta) == self.numCam, 'The Number of alpha and beta is wrong'
+        if motion_prior:
+            raise NotImplementedError('motion_prior branch is dead in the reference pipeline')
+        if len(cam):
+            cams = cam if isinstance(cam[0], (int, np.integer)) else cam[0]
+        else:
+            cams = range(self.numCam)
+            self.detections_global = [[] for _ in cams]
+        for i in cams:
+            det = self.detections[i]
+            ts = self.alpha[i] * (det[0] + self.rs[i] * det[2] / self.cameras[i].resolution[1]) + self.beta[i]
+            obs = self.cameras[i].undist_point(det[1:]) if self.settings['undist_points'] else det[1:]
+            self.detections_global[i] = np.vstack((ts, obs))
+
+    def cut_detection(self, second=1):
+        if not second:
+            return
+        for i in range(self.numCam):
+            det = self.detections[i]
+            interval = util.find_intervals(det[0])
+            cut = int(self.cameras[i].fps * second)
+            keep = interval[:, interval[1] - interval[0] > cut * 2]
+            keep[0] += cut
+            keep[1] -= cut
+            assert (keep[1] - keep[0] >= 0).all()
+            self.detections[i], _ = util.sampling(det, keep)
+
+    # ---- spline <-> trajectory (host, outside the BA loop; SURVEY 8f "next") -----------------------
+    def traj_to_spline(self, smooth_factor):
+        """One smoothing cubic spline per contiguous part of ``self.traj`` (FITPACK ``splprep`` with the
+        reference's knot-density loop, common.py:224-270)."""
+        from scipy import interpolate
+        assert len(smooth_factor) == 2, 'Smoothness should be defined by two parameters (min, max)'
+        interval, idx = util.find_intervals(self.traj[0], idx=True)
+        lo, hi = min(smooth_factor), max(smooth_factor)
+        tck = []
+        for i in range(interval.shape[1]):
+            part = self.traj[:, idx[0, i]:idx[1, i] + 1]
+            measure = part[0, -1] - part[0, 0]
+            s = (1e-3) ** 2 * measure
+            prev, direction = 0, 0
+            try:
+                while True:
+                    fit, _ = interpolate.splprep(part[1:], u=part[0], s=s, k=3)
+                    n = len(fit[0]) - 4
+                    if n == prev and n == 4 and direction == 2:
+                        break
+                    prev = n
+                    if measure / n > hi:
+                        s, direction = s / 1.5, 1
+                    elif measure / n < lo:
+                        s, direction = s * 2, 2
+                    else:
+                        break
+            except Exception:
+                fit, _ = interpolate.splprep(part[1:], u=part[0], s=s, k=1)
+            tck.append(fit)
+        self.spline['tck'], self.spline['int'] = tck, interval
+        return self.spline
+
+    def spline_to_traj(self, sampling_rate=1, t=None):
+        from scipy import interpolate
+        tck, interval = self.spline['tck'], self.spline['int']
+        if t is not None:
+            assert len(t.shape) == 1, 'Input timestamps must be a 1D array'
+            ts = t
+        else:
+            ts = np.arange(interval[0, 0], interval[1, -1], sampling_rate)
+        parts = [np.empty([4, 0])]
+        for i in range(interval.shape[1]):
+            tp = ts[(ts >= interval[0, i]) & (ts <= interval[1, i])]
+            if tp.size:
+                parts.append(np.vstack((tp, np.asarray(interpolate.splev(tp, tck[i])))))
+        self.traj = np.hstack(parts)
+        assert (self.traj[0, 1:] >= self.traj[0, :-1]).all()
+        return self.traj
+
+    def all_detect_to_traj(self, *cam):
+        """Attributes the reference refreshes while regularising (common.py:887-947); they do not enter the
+        residual, so they are computed once after BA instead of on every evaluation."""
+        cams = list(cam[0]) if len(cam) else list(range(self.numCam))
+        for i in cams:
+            self.detection_to_global(i)
+        ts = np.concatenate([self.detections_global[i][0] for i in cams])
+        frames = np.concatenate([self.detections[i][0] for i in cams])
+        ids = np.concatenate([np.full(self.detections[i].shape[1], float(i)) for i in cams])
+        self.frame_id_all = frames
+        self.global_time_stamps_all = ts
+        self.spline_to_traj(t=np.sort(ts))
+        self.global_detections = np.vstack((ids, frames, ts))
+        ordered = self.global_detections[:, np.argsort(ts)]
+        ordered = ordered[:, np.isin(ordered[2], self.traj[0])]
+        self.global_traj = np.vstack((np.arange(ordered.shape[1]), ordered, self.traj[1:]))
+        assert (self.global_traj[3][1:] >= self.global_traj[3][:-1]).all(), 'timestamps are not in ascending order'
+
+    # ---- the hot path --------------------------------------------------------------------------
+    def _ba_problem(self, cams, rs=False, motion_reg=False, motion_weights=1, rs_bounds=False):
+        st = self.settings
+        return _problem.problem_from_arrays(
+            [self.detections[i] for i in cams], [self.cameras[i] for i in cams], self.spline['tck'], self.spline['int'],
+            opt_calib=st['opt_calib'], undist_points=st['undist_points'], rs=rs, rs_bounds=rs_bounds,
+            motion_reg=motion_reg, motion_type=st.get('motion_type', 'F'), motion_weights=motion_weights)
+
+    def _pack(self, prob, cams):
+        return _problem.pack_x(prob, np.asarray(self.alpha)[cams], np.asarray(self.beta)[cams], np.asarray(self.rs)[cams],
+                               [self.cameras[i] for i in cams], self.spline['tck'])
+
+    def _handle(self, prob):
+        from ..ba import BAHandle          # raises if libmvusba.so is missing: no CPU fallback
+        return BAHandle(prob, device=int(self.settings.get('device', 0)) if isinstance(self.settings, dict) else 0)
+
+    def error_cam(self, cam_id, mode='dist', motion_prior=False, norm=False):
+        """Reprojection errors of one camera (common.py:304-359), evaluated by the HIP residual kernel."""
+        if motion_prior or norm:
+            raise NotImplementedError('motion_prior / norm variants are not on the BA hot path')
+        self.detection_to_global(cam_id)
+        prob = self._ba_problem([cam_id])
+        with self._handle(prob) as h:
+            f = h.residual(self._pack(prob, [cam_id]))
+        M = self.detections[cam_id].shape[1]
+        ex, ey = f[:M], f[M:2 * M]
+        if mode == 'each':
+            return np.concatenate((ex, ey))
+        _, ids = util.sampling(self.detections_global[cam_id], self.spline['int'], belong=True)
+        order = np.concatenate([np.nonzero(ids == s + 1)[0] for s in range(self.spline['int'].shape[1])]).astype(int)
+        if mode == 'dist':
+            return np.sqrt(ex[order] ** 2 + ey[order] ** 2)
+        if mode == 'xy_1D':
+            return np.concatenate((ex[order], ey[order]))
+        if mode == 'xy_2D':
+            return np.vstack((ex[order], ey[order]))
+        raise ValueError('unknown mode %r' % (mode,))
+
+    def compute_visibility(self):
+        self.visible = []
+        self.detection_to_global()
+        for cam_id in range(self.numCam):
+            _, vis = util.sampling(self.detections_global[cam_id], self.spline['int'], belong=True)
+            self.visible.append(vis)
+
+    def BA(self, numCam, max_iter=10, rs=False, motion_prior=False, motion_reg=False, motion_weights=1, norm=False,
+           rs_bounds=False):
+        """Bundle adjustment over ``self.sequence[:numCam]`` (common.py:441-697): same arguments, same side effects,
+        the optimisation itself runs in ``mvus_ba_solve`` on the GPU."""
+        if motion_prior:
+            raise NotImplementedError('motion_prior=True is dead code in the reference pipeline (SURVEY.md section 2)')
+        from .. import ba as _ba
+        cams = list(self.sequence[:numCam])
+        self.alpha, self.beta, self.rs = (np.asarray(v, dtype=np.float64) for v in (self.alpha, self.beta, self.rs))
+        prob = self._ba_problem(cams, rs=rs, motion_reg=motion_reg, motion_weights=motion_weights, rs_bounds=rs_bounds)
+        model = self._pack(prob, cams)
+        print('Number of BA parameters is {}'.format(len(model)))
+        print('Doing BA with {} cameras...\n'.format(numCam))
+        st = self.settings
+        solver = _ba.SOLVER_LM_SCHUR if st.get('ba_solver', 'trf') == 'lm' else _ba.SOLVER_TRF_LSMR
+        default_jac = 'analytic' if solver == _ba.SOLVER_LM_SCHUR else 'pattern'
+        jac_mode = _ba.JAC_ANALYTIC if st.get('ba_jacobian', default_jac) == 'analytic' else _ba.JAC_PATTERN
+        with self._handle(prob) as h:
+            res = h.solve(model, solver=solver, jac_mode=jac_mode, max_nfev=max_iter)
+        alpha, beta, rs_new, cam_states, coefs = _problem.unpack_x(prob, res.x)
+        self.alpha[cams], self.beta[cams], self.rs[cams] = alpha, beta, rs_new
+        for k, i in enumerate(cams):
+            c = self.cameras[i]
+            if st['opt_calib']:
+                c.K, c.d = cam_states[k]['K'], cam_states[k]['d']
+            c.R, c.t = cam_states[k]['R'], cam_states[k]['t']
+            c.compose()
+        for s, c in enumerate(coefs):
+            self.spline['tck'][s][1] = c
+        self.detection_to_global()
+        if motion_reg:
+            self.all_detect_to_traj(cams)
+            self.spline_to_traj()
+        return res
+
+    def remove_outliers(self, cams, thres=30, verbose=False):
+        """Drop detections whose reprojection error is >= thres (common.py:700-717); the mask is computed by
+        ``mvus_ba_outlier_mask``."""
+        if not thres:
+            return
+        cams = list(cams)
+        for i in cams:
+            self.detection_to_global(i)
+        prob = self._ba_problem(cams)
+        with self._handle(prob) as h:
+            keep = h.outlier_mask(self._pack(prob, cams), thres)
+            f = h.residual(self._pack(prob, cams)) if verbose else None
+        for k, i in enumerate(cams):
+            a, b = int(prob.det_offsets[k]), int(prob.det_offsets[k + 1])
+            if verbose:
+                ex, ey = f[2 * a:2 * a + (b - a)], f[2 * a + (b - a):2 * b]
+                print('{} out of {} detections are removed for camera {}'.format(int((~keep[a:b]).sum()),
+                                                                                  int(((ex != 0) | (ey != 0)).sum()), i))
+            self.detections[i] = self.detections[i][:, keep[a:b]]
+            self.detection_to_global(i)
+
+    # ---- outside the hot path -----------------------------------------------------------------------
+    def _out_of_scope(self, *a, **k):
+        raise NotImplementedError('outside the BA hot path this package accelerates (SURVEY.md section 2); '
+                                  'use the reference implementation for initialisation / PnP / triangulation')
+
+    init_traj = get_camera_pose = triangulate = select_most_overlap = plot_reprojection = error_motion = _out_of_scope
+
+
+def create_scene(path_input):
+    """Build a Scene from the reference's JSON config (common.py:1171-1230): sections
+    'necessary inputs', 'optional inputs', 'settings'."""
+    with open(path_input, 'r') as fh:
+        config = json.load(fh)
+    flight = Scene()
+    flight.settings = config['settings']
+    paths = config['necessary inputs']['path_detections']
+    flight.numCam = len(paths)
+    for p in paths:
+        det = np.loadtxt(p, usecols=(2, 0, 1))[:flight.settings['num_detections']].T
+        flight.addDetection(det)
+    for p in config['necessary inputs']['path_cameras']:
+        try:
+            with open(p, 'r') as fh:
+                cam = json.load(fh)
+        except Exception:
+            raise Exception('Wrong input of camera')
+        d = list(cam['distCoeff'])
+        if len(d) == 4:
+            d.append(0)
+        flight.addCamera(Camera(K=np.asarray(cam['K-matrix'], dtype=np.float64), d=np.asarray(d, dtype=np.float64),
+                                fps=cam['fps'], resolution=cam['resolution']))
+    flight.ref_cam = config['settings']['ref_cam']
+    flight.sequence = config['settings']['camera_sequence']
+    flight.find_order = False if len(flight.sequence) else True
+    flight.cf = np.asarray(config['necessary inputs']['corresponding_frames'], dtype=np.float64)
+    init_rs = config['settings']['init_rs'] if config['settings']['rolling_shutter'] else 0
+    if isinstance(init_rs, list):
+        assert len(init_rs) == flight.numCam, 'the number of initial rolling shutter values must equal the number of cameras'
+        flight.rs = np.asarray(init_rs, dtype=np.float64)
+    else:
+        flight.rs = np.full(flight.numCam, float(init_rs))
+    if 'optional inputs' in config and 'ground_truth' in config['optional inputs']:
+        flight.gt = config['optional inputs']['ground_truth']
+    print('Input data are loaded successfully, a scene is created.\n')
+    return flight

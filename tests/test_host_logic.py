@@ -1,0 +1,147 @@
+"""Host-side logic that surrounds the GPU path: interval helpers, parameter codec, Scene/Camera surface,
+config parsing, observation sharding (no GPU needed)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import ba_oracle as orc
+from golden_util import CASES, load_case
+from mvus_amd import problem as mp, sharding, synth
+from mvus_amd.reconstruction import common
+from mvus_amd.tools import util
+
+
+def test_find_intervals_and_sampling_match_oracle():
+    rng = np.random.default_rng(0)
+    for trial in range(50):
+        x = np.sort(rng.choice(np.arange(0, 400), size=rng.integers(2, 200), replace=False)).astype(float)
+        a, ia = util.find_intervals(x, idx=True)
+        b, ib = orc.find_intervals(x, idx=True)
+        assert np.array_equal(a, b) and np.array_equal(ia, ib)
+        if a.shape[1]:
+            ts = rng.uniform(-5, 405, 300)
+            ts[:a.shape[1]] = a[0]          # exactly on a start (inside)
+            ts[a.shape[1]:2 * a.shape[1]] = a[1]   # exactly on an end (outside: half-open)
+            _, ids = util.sampling(ts, a, belong=True)
+            assert np.array_equal(ids, orc.sampling_idx(ts, a))
+            picked, mask = util.sampling(np.vstack((ts, ts, ts)), a)
+            assert mask.dtype == bool and picked.shape[1] == mask.sum()
+    assert util.find_intervals(np.array([1.0, 2.0, 3.0])).shape == (2, 0)      # shorter than the gap: dropped
+    with pytest.raises(AssertionError):
+        util.find_intervals(np.array([2.0, 1.0]))
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_pack_unpack_roundtrip(name):
+    scene, g = load_case(name)
+    prob, x0 = mp.problem_from_scene(scene)
+    np.testing.assert_allclose(x0, g['x0'], rtol=0, atol=1e-12)
+    assert prob.n_params == x0.size and prob.n_residuals == g['f_x0'].size
+    alpha, beta, rs, cams, coefs = mp.unpack_x(prob, x0)
+    x1 = mp.pack_x(prob, alpha, beta, rs, cams, [[None, c, 3] for c in coefs])
+    np.testing.assert_allclose(x1, x0, rtol=0, atol=1e-12)
+    lb, ub = prob.bounds()
+    assert np.isinf(lb).all() != prob.rs_bounds
+
+
+def test_camera_codec_and_projection():
+    rng = np.random.default_rng(1)
+    K = np.array([[1000.0, 0, 960], [0, 1010.0, 540], [0, 0, 1]])
+    R = synth.rodrigues(rng.normal(size=3))
+    cam = common.Camera(K=K, d=np.array([0.1, -0.02, 1e-4, -1e-4, 0.0]), R=R, t=rng.normal(size=3), fps=30, resolution=[1920, 1080])
+    cam.compose()
+    v6, v15 = cam.P2vector(), cam.P2vector(calib=True)
+    assert v6.size == 6 and v15.size == 15
+    cam2 = common.Camera(K=K.copy(), d=cam.d.copy(), fps=30, resolution=[1920, 1080])
+    cam2.vector2P(v15, calib=True)
+    np.testing.assert_allclose(cam2.P, cam.P, atol=1e-9)
+    X = rng.normal(size=(3, 5)) + np.array([[0], [0], [30.0]])
+    x = cam.projectPoint(X)
+    np.testing.assert_allclose(x[2], 1.0)
+    K2, R2, t2 = cam2.decompose()
+    np.testing.assert_allclose(K2, K, atol=1e-6)
+    np.testing.assert_allclose(R2, R, atol=1e-9)
+    # undistortion is the inverse of the forward lens model
+    xn = rng.uniform(-0.3, 0.3, (2, 20))
+    xd, yd = synth.distort(xn[0], xn[1], cam.d)
+    raw = np.vstack((K[0, 0] * xd + K[0, 2], K[1, 1] * yd + K[1, 2]))
+    und = cam.undist_point(raw)
+    np.testing.assert_allclose(und, np.vstack((K[0, 0] * xn[0] + K[0, 2], K[1, 1] * xn[1] + K[1, 2])), atol=2e-3)
+    np.testing.assert_allclose(und, orc.undist_point(raw, K, cam.d), atol=1e-12)
+
+
+def test_create_scene_reads_reference_config(tmp_path):
+    rng = np.random.default_rng(2)
+    dets, cams = [], []
+    for i in range(2):
+        d = np.column_stack((rng.uniform(0, 1920, 30), rng.uniform(0, 1080, 30), np.arange(30) + 5))   # x y frame
+        p = tmp_path / ('det%d.txt' % i)
+        np.savetxt(p, d)
+        dets.append(str(p))
+        c = tmp_path / ('cam%d.json' % i)
+        c.write_text(json.dumps({'K-matrix': [[1000, 0, 960], [0, 1000, 540], [0, 0, 1]], 'distCoeff': [0.1, 0.01, 0, 0],
+                                 'fps': 30 - 5 * i, 'resolution': [1920, 1080]}))
+        cams.append(str(c))
+    cfg = {'necessary inputs': {'path_detections': dets, 'path_cameras': cams, 'corresponding_frames': [10, 20]},
+           'optional inputs': {'ground_truth': {'filepath': 'gt.txt', 'frequency': 5}},
+           'settings': {'num_detections': 20, 'opt_calib': False, 'cf_exact': True, 'undist_points': True,
+                        'rolling_shutter': True, 'init_rs': [0.5, 0.6], 'rs_bounds': False, 'motion_reg': False,
+                        'motion_weights': 100, 'camera_sequence': [], 'ref_cam': 0}}
+    path = tmp_path / 'config.json'
+    path.write_text(json.dumps(cfg))
+    flight = common.create_scene(str(path))
+    assert flight.numCam == 2 and flight.find_order
+    assert flight.detections[0].shape == (3, 20)
+    np.testing.assert_array_equal(flight.detections[0][0], np.arange(20) + 5)        # row 0 = frame id
+    assert flight.cameras[0].d.size == 5 and flight.cameras[0].d[4] == 0            # 4 coefficients are zero-padded
+    np.testing.assert_array_equal(flight.rs, [0.5, 0.6])
+    flight.init_alpha()
+    np.testing.assert_allclose(flight.alpha, [1.0, 30 / 25])
+    flight.time_shift()
+    np.testing.assert_allclose(flight.beta, 10 - flight.alpha * np.array([10.0, 20.0]))
+    flight.detection_to_global()
+    assert flight.detections_global[1].shape == (3, 20)
+    assert flight.gt['frequency'] == 5
+
+
+def test_out_of_scope_methods_say_so():
+    s = common.Scene()
+    for name in ('init_traj', 'get_camera_pose', 'triangulate', 'select_most_overlap'):
+        with pytest.raises(NotImplementedError):
+            getattr(s, name)()
+
+
+def test_shard_offsets_partition():
+    for count in (0, 1, 7, 64, 1001):
+        for world in (1, 2, 3, 8):
+            pieces = [sharding.shard_offsets(count, r, world) for r in range(world)]
+            assert pieces[0][0] == 0 and pieces[-1][1] == count
+            assert all(a[1] == b[0] for a, b in zip(pieces[:-1], pieces[1:]))
+            sizes = [hi - lo for lo, hi in pieces]
+            assert max(sizes) - min(sizes) <= 1
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_problem_shards_cover_every_observation_once(world):
+    scene, g = load_case('rs_F_2int_3cam')
+    prob, x0 = mp.problem_from_scene(scene)
+    seen = np.zeros(prob.M, dtype=int)
+    for r in range(world):
+        shard, keep = prob.shard(r, world)
+        seen[keep] += 1
+        assert shard.M == keep.size and shard.n_params == prob.n_params
+        assert np.array_equal(shard.frame, prob.frame[keep])
+    assert (seen == 1).all()
+
+
+def test_motion_sample_times_match_oracle():
+    scene, g = load_case('rs_F_2int_3cam')
+    prob, x0 = mp.problem_from_scene(scene)
+    oprob, _ = orc.problem_from_scene(scene)
+    _, _, _, _, tck = orc.unpack_x(oprob, x0)
+    traj = orc.spline_to_traj(oprob, tck)
+    ts, sid = prob.motion_sample_times()
+    np.testing.assert_array_equal(ts, traj[0])
+    assert prob.num_motion_rows == traj.shape[1]
