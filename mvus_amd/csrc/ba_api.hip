@@ -5,6 +5,7 @@
 
 #include <chrono>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -14,14 +15,6 @@
 #include "ba_schur_hip.hip.h"
 
 namespace mvus {
-
-struct HipError { std::string msg; };
-
-#define MVUS_HIP(expr)                                                                              \
-  do {                                                                                              \
-    hipError_t e_ = (expr);                                                                         \
-    if (e_ != hipSuccess) throw HipError{std::string(#expr) + ": " + hipGetErrorString(e_)};        \
-  } while (0)
 
 static inline int grid_for(long long len) { return (int)std::min<long long>(2048, std::max<long long>(1, (len + kThreads - 1) / kThreads)); }
 
@@ -435,6 +428,8 @@ int mvus_ba_time_kernel(mvus_ba* h, int32_t which, int32_t launches, double* avg
     hipLaunchKernelGGL(k_cam_states, dim3((be.hp.C + 63) / 64), dim3(64), 0, be.stream, be.dp, be.x_cur, be.cams);
     if (which >= 2 && !be.has_jacobian) be.jacobian(be.x_cur, be.f_cur, MVUS_JAC_ANALYTIC);
     const dim3 g(std::max(be.dp.n_chunks, 1)), b(kThreads);
+    std::unique_ptr<HipSchur<HipBackend>> schur;
+    if (which >= 4) schur.reset(new HipSchur<HipBackend>(be));
     auto launch = [&]() {
       switch (which) {
         case 0:
@@ -454,7 +449,7 @@ int mvus_ba_time_kernel(mvus_ba* h, int32_t which, int32_t launches, double* avg
           else hipLaunchKernelGGL(k_jtu<21>, g, b, 0, be.stream, be.dp, be.J, be.span, um, zn);
           break;
         default:
-          schur_time_assembly(be);
+          schur->assemble_local(be.f_cur);
       }
     };
     if (be.dp.n_chunks == 0) { *avg_ms = 0; return MVUS_OK; }

@@ -15,11 +15,21 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <string>
+
 #include "ba_math.h"
 
 namespace mvus {
 
 constexpr int kThreads = 256;
+
+struct HipError { std::string msg; };
+
+#define MVUS_HIP(expr)                                                                              \
+  do {                                                                                              \
+    hipError_t e_ = (expr);                                                                         \
+    if (e_ != hipSuccess) throw ::mvus::HipError{std::string(#expr) + ": " + hipGetErrorString(e_)}; \
+  } while (0)
 
 struct DevProblem {  // trivially copyable: passed to kernels by value
   int C, P, NS, S, calib, undist, rs_free, T;

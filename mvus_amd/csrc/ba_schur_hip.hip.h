@@ -1,10 +1,514 @@
-// Normal-equation assembly + Schur-complement LM solver on the HIP backend (placeholder until ba_schur lands).
+// HIP implementation of the `Schur` concept of ba_schur.h: on-device assembly of the normal equations
+// (camera blocks, block-banded spline block, cross block, gradient) from the slot Jacobian, and the
+// damped solve by elimination of the spline block.
+//
+// Layout (one packed buffer `NE`, so that a single all-reduce sums every shard's contribution):
+//   A  [C][B][B]        camera diagonal blocks, B = 3+P (alpha, beta, rs, camera params)
+//   gc [C][B]           camera part of g = J^T f
+//   Cb [N][W][3][3]     Cb[g][w] = H[3g.., 3(g+w)..]: upper block band of the spline block, W >= 4
+//   gs [3N]             spline part of g, internal order 3*ctrl + xyz
+//   Et [3N][C*B]        E^T: row = spline unknown, column = camera unknown  (the many right-hand sides)
 #pragma once
-#include "ba_solver.h"
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "ba_kernels.hip.h"
+#include "ba_schur.h"
+
 namespace mvus {
-struct HipBackend;
-template <class BE> int schur_export(BE& be, double*, double*, double*, double*, int32_t*) { be.err = "normal equations: not built in this revision"; return MVUS_E_INVALID; }
-template <class BE> SolveResult lm_schur_hip(BE& be, std::vector<double>&, const std::vector<double>&, const std::vector<double>&, const SolveOptions&, double*) {
-  SolveResult r; r.error = -1; be.err = "LM_SCHUR: not built in this revision"; return r; }
-template <class BE> void schur_time_assembly(BE&) {}
+
+constexpr int kNWin = 64;   // control points covered by a workgroup's LDS accumulation window
+
+struct NEView {
+  double *A, *gc, *Cb, *gs, *Et;
+  int C, B, CB, N, N3, W;
+};
+
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_down(v, off, 64));
+  return v;
+}
+
+// ---- assembly of the detection rows ------------------------------------------------------------------
+// One workgroup per chunk of <=256 detections of one camera.  Camera block: wavefront shuffle reduction.
+// Spline / cross terms: fp64 LDS atomics into a window of kNWin control points starting at the chunk's
+// smallest span (neighbouring lanes = neighbouring timestamps = same few control points), flushed once with
+// global atomics; lanes outside the window (sparse detections) fall back to global atomics.
+template <int NS>
+__global__ __launch_bounds__(kThreads) void k_assemble(DevProblem dp, const double* __restrict__ J, const int32_t* __restrict__ span,
+                                                       const double* __restrict__ f, NEView ne) {
+  constexpr int B = NS - 12;
+  __shared__ double Aw[B * B];
+  __shared__ double gcw[B];
+  __shared__ double Ew[kNWin * 3 * B];
+  __shared__ double Cw[kNWin * 4 * 9];
+  __shared__ double gsw[kNWin * 3];
+  __shared__ int gmin_s[kThreads / 64];
+  const int chunk = blockIdx.x;
+  const int c = dp.chunk_cam[chunk];
+  const bool active = (int)threadIdx.x < dp.chunk_count[chunk];
+  const long long i = dp.chunk_start[chunk] + (active ? threadIdx.x : 0);
+  const long long a0 = dp.det_off[c], Mc = dp.det_off[c + 1] - a0;
+  const int g = active ? span[i] : -1;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int k = threadIdx.x; k < B * B; k += kThreads) Aw[k] = 0.0;
+  for (int k = threadIdx.x; k < B; k += kThreads) gcw[k] = 0.0;
+  for (int k = threadIdx.x; k < kNWin * 3 * B; k += kThreads) Ew[k] = 0.0;
+  for (int k = threadIdx.x; k < kNWin * 36; k += kThreads) Cw[k] = 0.0;
+  for (int k = threadIdx.x; k < kNWin * 3; k += kThreads) gsw[k] = 0.0;
+  int gm = wave_min_i(g >= 0 ? g : 0x7fffffff);
+  if (lane == 0) gmin_s[wave] = gm;
+  __syncthreads();
+  int g0 = gmin_s[0];
+#pragma unroll
+  for (int w = 1; w < kThreads / 64; ++w) g0 = min(g0, gmin_s[w]);
+  if (g0 == 0x7fffffff) return;   // nothing visible in this chunk (uniform)
+
+  double jx[NS], jy[NS];
+  double fx = 0.0, fy = 0.0;
+  if (g >= 0) {
+#pragma unroll
+    for (int k = 0; k < NS; ++k) { jx[k] = J[(long long)k * dp.M + i]; jy[k] = J[(long long)(NS + k) * dp.M + i]; }
+    fx = f[2 * a0 + (i - a0)];
+    fy = f[2 * a0 + Mc + (i - a0)];
+  } else {
+#pragma unroll
+    for (int k = 0; k < NS; ++k) { jx[k] = 0.0; jy[k] = 0.0; }
+  }
+  // camera block (lower triangle incl. diagonal, mirrored at flush) and camera gradient
+#pragma unroll
+  for (int a = 0; a < B; ++a) {
+    double v = wave_sum(jx[a] * fx + jy[a] * fy);
+    if (lane == 0) unsafeAtomicAdd(&gcw[a], v);
+#pragma unroll
+    for (int b = 0; b <= a; ++b) {
+      v = wave_sum(jx[a] * jx[b] + jy[a] * jy[b]);
+      if (lane == 0) unsafeAtomicAdd(&Aw[a * B + b], v);
+    }
+  }
+  if (g >= 0) {
+    const int l = g - g0;
+    const bool inwin = l + 3 < kNWin;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        const int sq = B + 3 * q + d;
+        const double vx = jx[sq], vy = jy[sq];
+        const double gval = vx * fx + vy * fy;
+        if (inwin) unsafeAtomicAdd(&gsw[3 * (l + q) + d], gval);
+        else unsafeAtomicAdd(&ne.gs[3 * (g + q) + d], gval);
+#pragma unroll
+        for (int k = 0; k < B; ++k) {
+          const double ev = jx[k] * vx + jy[k] * vy;
+          if (inwin) unsafeAtomicAdd(&Ew[(3 * (l + q) + d) * B + k], ev);
+          else unsafeAtomicAdd(&ne.Et[(long long)(3 * (g + q) + d) * ne.CB + c * B + k], ev);
+        }
+#pragma unroll
+        for (int q2 = q; q2 < 4; ++q2) {
+#pragma unroll
+          for (int d2 = 0; d2 < 3; ++d2) {
+            const int s2 = B + 3 * q2 + d2;
+            const double cv = vx * jx[s2] + vy * jy[s2];
+            if (inwin) unsafeAtomicAdd(&Cw[((l + q) * 4 + (q2 - q)) * 9 + 3 * d + d2], cv);
+            else unsafeAtomicAdd(&ne.Cb[((long long)(g + q) * ne.W + (q2 - q)) * 9 + 3 * d + d2], cv);
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < B * B; k += kThreads) {
+    const int a = k / B, b = k % B;
+    const double v = a >= b ? Aw[a * B + b] : Aw[b * B + a];
+    if (v != 0.0) unsafeAtomicAdd(&ne.A[((long long)c * B + a) * B + b], v);
+  }
+  for (int k = threadIdx.x; k < B; k += kThreads) if (gcw[k] != 0.0) unsafeAtomicAdd(&ne.gc[c * B + k], gcw[k]);
+  for (int k = threadIdx.x; k < kNWin * 3; k += kThreads) {
+    const int r = 3 * g0 + k;
+    if (r < ne.N3 && gsw[k] != 0.0) unsafeAtomicAdd(&ne.gs[r], gsw[k]);
+  }
+  for (int k = threadIdx.x; k < kNWin * 3 * B; k += kThreads) {
+    const int r = 3 * g0 + k / B;
+    const double v = Ew[k];
+    if (r < ne.N3 && v != 0.0) unsafeAtomicAdd(&ne.Et[(long long)r * ne.CB + c * B + (k % B)], v);
+  }
+  for (int k = threadIdx.x; k < kNWin * 36; k += kThreads) {
+    const int gg = g0 + k / 36, w = (k / 9) % 4;
+    const double v = Cw[k];
+    if (gg < ne.N && v != 0.0) unsafeAtomicAdd(&ne.Cb[((long long)gg * ne.W + w) * 9 + (k % 9)], v);
+  }
+}
+
+// motion-regulariser rows: spline block and gradient only (the rows do not depend on camera parameters)
+__global__ __launch_bounds__(kThreads) void k_assemble_motion(DevProblem dp, const double* __restrict__ mJ, const int32_t* __restrict__ mctrl,
+                                                              const double* __restrict__ fm, NEView ne) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= dp.T) return;
+  const double fj = fm[j];
+  for (int e1 = 0; e1 < 36; ++e1) {
+    const int k1 = e1 / 12, g1 = mctrl[(long long)k1 * dp.T + j];
+    if (g1 < 0) continue;
+    const double v1 = mJ[(long long)e1 * dp.T + j];
+    if (v1 == 0.0) continue;
+    const int c1 = g1 + (e1 % 12) / 3, d1 = e1 % 3;
+    unsafeAtomicAdd(&ne.gs[3 * c1 + d1], v1 * fj);
+    for (int e2 = 0; e2 < 36; ++e2) {
+      const int k2 = e2 / 12, g2 = mctrl[(long long)k2 * dp.T + j];
+      if (g2 < 0) continue;
+      const int c2 = g2 + (e2 % 12) / 3, d2 = e2 % 3;
+      if (c2 < c1) continue;
+      const double v2 = mJ[(long long)e2 * dp.T + j];
+      if (v2 == 0.0) continue;
+      unsafeAtomicAdd(&ne.Cb[((long long)c1 * ne.W + (c2 - c1)) * 9 + 3 * d1 + d2], v1 * v2);
+    }
+  }
+}
+
+// D = diag(H) in x order (0 -> 1 so that unused columns stay put), and g in x order
+__global__ void k_ne_diag_grad(DevProblem dp, NEView ne, double* __restrict__ D, double* __restrict__ gx) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < ne.CB) {
+    const int c = idx / ne.B, k = idx % ne.B;
+    const double h = ne.A[((long long)c * ne.B + k) * ne.B + k];
+    const int col = cam_col(dp.C, dp.P, c, k);
+    D[col] = h > 0.0 ? h : 1.0;
+    gx[col] = ne.gc[idx];
+  } else if (idx < ne.CB + ne.N3) {
+    const int r = idx - ne.CB, g = r / 3, d = r % 3;
+    const double h = ne.Cb[((long long)g * ne.W) * 9 + 4 * d];
+    const int col = dp.mv.ctrl_x0[g] + d * dp.mv.ctrl_stride[g];
+    D[col] = h > 0.0 ? h : 1.0;
+    gx[col] = ne.gs[r];
+  }
+}
+
+// scalar lower band of (C + lambda D_s): Lb[i][j] = (C + lambda D)(i, i-j), j = 0..BW
+__global__ void k_band_pack(NEView ne, double lambda, int BW, double* __restrict__ Lb) {
+  const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  const long long total = (long long)ne.N3 * (BW + 1);
+  if (idx >= total) return;
+  const int i = (int)(idx / (BW + 1)), j = (int)(idx % (BW + 1));
+  const int cidx = i - j;
+  double v = 0.0;
+  if (cidx >= 0) {
+    const int gi = i / 3, ai = i % 3, gc_ = cidx / 3, ac = cidx % 3;
+    const int w = gi - gc_;
+    if (w < ne.W) v = ne.Cb[((long long)gc_ * ne.W + w) * 9 + 3 * ac + ai];
+    if (j == 0) { const double h = v; v = h + lambda * (h > 0.0 ? h : 1.0); }
+  }
+  Lb[idx] = v;
+}
+
+// In-place banded Cholesky (right-looking) by ONE wavefront, staged through LDS in tiles of kTile columns.
+// fail[0] is set when a pivot is not positive.  After the call Lb[i][0] holds 1 / L(i,i).
+constexpr int kTile = 384;
+template <int BW>
+__global__ __launch_bounds__(64) void k_band_cholesky(int n3, double* __restrict__ Lb, int* __restrict__ fail) {
+  constexpr int R = BW + 1;
+  __shared__ double T[(kTile + BW) * R];
+  const int lane = threadIdx.x;
+  for (int k0 = 0; k0 < n3; k0 += kTile) {
+    const int rows = min(kTile + BW, n3 - k0);
+    for (int e = lane; e < rows * R; e += 64) T[e] = Lb[(long long)k0 * R + e];
+    __syncthreads();
+    const int cols = min(kTile, n3 - k0);
+    for (int k = 0; k < cols; ++k) {
+      double piv = T[k * R];
+      if (!(piv > 0.0)) { if (lane == 0) fail[0] = 1; piv = 1.0; }
+      const double d = sqrt(piv), inv = 1.0 / d;
+      const int nb = min(BW, rows - 1 - k);          // rows below k inside the band and the tile
+      // scale column k: L(k+r, k) = A(k+r, k) / d, r = 1..nb   (stored at T[(k+r)*R + r])
+      if (lane >= 1 && lane <= nb) T[(k + lane) * R + lane] *= inv;
+      __syncthreads();
+      // trailing update: A(k+r, k+s) -= L(k+r,k) L(k+s,k), 1 <= s <= r <= nb
+      const int npairs = nb * (nb + 1) / 2;
+      for (int e = lane; e < npairs; e += 64) {
+        int r = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
+        while ((r + 1) * (r + 2) / 2 <= e) ++r;
+        while (r * (r + 1) / 2 > e) --r;
+        const int s = e - r * (r + 1) / 2;           // 0 <= s <= r
+        const int rr = r + 1, ss = s + 1;
+        T[(k + rr) * R + (rr - ss)] -= T[(k + rr) * R + rr] * T[(k + ss) * R + ss];
+      }
+      if (lane == 0) T[k * R] = inv;
+      __syncthreads();
+    }
+    // rows [k0, k0+cols) are final; the next BW rows carry partial updates and are reloaded by the next tile
+    for (int e = lane; e < rows * R; e += 64) Lb[(long long)k0 * R + e] = T[e];
+    __syncthreads();
+  }
+}
+
+// Z[3N][ncols] = [E^T | gs]
+__global__ void k_build_rhs(NEView ne, int ncols, double* __restrict__ Z) {
+  const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (idx >= (long long)ne.N3 * ncols) return;
+  const int r = (int)(idx / ncols), cidx = (int)(idx % ncols);
+  Z[idx] = cidx < ne.CB ? ne.Et[(long long)r * ne.CB + cidx] : ne.gs[r];
+}
+
+// Z <- (L L^T)^-1 Z, one thread per right-hand-side column, forward then backward substitution.
+template <int BW>
+__global__ __launch_bounds__(64) void k_band_solve(int n3, int ncols, const double* __restrict__ Lb, double* __restrict__ Z) {
+  constexpr int R = BW + 1;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= ncols) return;
+  double yw[BW];
+#pragma unroll
+  for (int j = 0; j < BW; ++j) yw[j] = 0.0;
+  for (int i = 0; i < n3; ++i) {
+    const double* Lr = Lb + (long long)i * R;
+    double acc = Z[(long long)i * ncols + t];
+#pragma unroll
+    for (int j = 1; j <= BW; ++j) acc -= Lr[j] * yw[j - 1];      // L(i, i-j) y(i-j); zero outside the matrix
+    const double y = acc * Lr[0];
+    Z[(long long)i * ncols + t] = y;
+#pragma unroll
+    for (int j = BW - 1; j >= 1; --j) yw[j] = yw[j - 1];
+    yw[0] = y;
+  }
+#pragma unroll
+  for (int j = 0; j < BW; ++j) yw[j] = 0.0;
+  for (int i = n3 - 1; i >= 0; --i) {
+    double acc = Z[(long long)i * ncols + t];
+#pragma unroll
+    for (int j = 1; j <= BW; ++j) {
+      const double l = (i + j < n3) ? Lb[(long long)(i + j) * R + j] : 0.0;   // L(i+j, i)
+      acc -= l * yw[j - 1];
+    }
+    const double xv = acc * Lb[(long long)i * R];
+    Z[(long long)i * ncols + t] = xv;
+#pragma unroll
+    for (int j = BW - 1; j >= 1; --j) yw[j] = yw[j - 1];
+    yw[0] = xv;
+  }
+}
+
+// G[CB][ncols] += Et^T Z over a slice of rows (16x16 output tile, 128-row slices staged in LDS)
+constexpr int kGemmK = 128;
+__global__ __launch_bounds__(256) void k_schur_gemm(NEView ne, int ncols, const double* __restrict__ Z, double* __restrict__ G) {
+  __shared__ double Es[kGemmK][17];
+  __shared__ double Zs[kGemmK][17];
+  const int a0 = blockIdx.x * 16, b0 = blockIdx.y * 16, k0 = blockIdx.z * kGemmK;
+  const int ta = threadIdx.x / 16, tb = threadIdx.x % 16;
+  for (int e = threadIdx.x; e < kGemmK * 16; e += 256) {
+    const int kk = e / 16, cc = e % 16, r = k0 + kk;
+    Es[kk][cc] = (r < ne.N3 && a0 + cc < ne.CB) ? ne.Et[(long long)r * ne.CB + a0 + cc] : 0.0;
+    Zs[kk][cc] = (r < ne.N3 && b0 + cc < ncols) ? Z[(long long)r * ncols + b0 + cc] : 0.0;
+  }
+  __syncthreads();
+  double acc = 0.0;
+#pragma unroll 8
+  for (int kk = 0; kk < kGemmK; ++kk) acc += Es[kk][ta] * Zs[kk][tb];
+  if (a0 + ta < ne.CB && b0 + tb < ncols && acc != 0.0) unsafeAtomicAdd(&G[(long long)(a0 + ta) * ncols + b0 + tb], acc);
+}
+
+// S = (A + lambda D_c) - G[:, :CB] (dense CB x CB), rhs = gc - G[:, CB]
+__global__ void k_schur_finish(NEView ne, int ncols, double lambda, const double* __restrict__ G, double* __restrict__ S, double* __restrict__ rhs) {
+  const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (idx >= (long long)ne.CB * ne.CB) return;
+  const int a = (int)(idx / ne.CB), b = (int)(idx % ne.CB);
+  double v = -G[(long long)a * ncols + b];
+  if (a / ne.B == b / ne.B) {
+    const int c = a / ne.B;
+    double h = ne.A[((long long)c * ne.B + a % ne.B) * ne.B + b % ne.B];
+    if (a == b) h += lambda * (h > 0.0 ? h : 1.0);
+    v += h;
+  }
+  S[idx] = v;
+  if (b == 0) rhs[a] = ne.gc[a] - G[(long long)a * ncols + ne.CB];
+}
+
+// Dense Cholesky + solve of the reduced camera system by one workgroup (right-looking, in global memory;
+// CB <= 1152 so S stays in L2).  pc = -S^-1 rhs.
+__global__ __launch_bounds__(1024) void k_dense_chol_solve(int nn, double* __restrict__ S, double* __restrict__ rhs, double* __restrict__ pc,
+                                                           int* __restrict__ fail) {
+  __shared__ double col[1152];
+  __shared__ double piv_s;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  for (int k = 0; k < nn; ++k) {
+    if (tid == 0) {
+      double p = S[(long long)k * nn + k];
+      if (!(p > 0.0)) { fail[0] = 2; p = 1.0; }
+      piv_s = sqrt(p);
+    }
+    __syncthreads();
+    const double d = piv_s;
+    for (int i = k + tid; i < nn; i += nt) {
+      const double v = (i == k) ? d : S[(long long)i * nn + k] / d;
+      col[i] = v;
+      S[(long long)i * nn + k] = v;
+    }
+    __syncthreads();
+    const int rem = nn - k - 1;
+    for (long long e = tid; e < (long long)rem * rem; e += nt) {
+      const int i = k + 1 + (int)(e / rem), j = k + 1 + (int)(e % rem);
+      if (j <= i) S[(long long)i * nn + j] -= col[i] * col[j];
+    }
+    __syncthreads();
+  }
+  // forward / backward substitution (single wavefront worth of work; nn is small)
+  for (int i = 0; i < nn; ++i) {
+    if (tid == 0) rhs[i] = rhs[i] / S[(long long)i * nn + i];
+    __syncthreads();
+    const double yi = rhs[i];
+    for (int r = i + 1 + tid; r < nn; r += nt) rhs[r] -= S[(long long)r * nn + i] * yi;
+    __syncthreads();
+  }
+  for (int i = nn - 1; i >= 0; --i) {
+    if (tid == 0) rhs[i] = rhs[i] / S[(long long)i * nn + i];
+    __syncthreads();
+    const double xi = rhs[i];
+    for (int r = tid; r < i; r += nt) rhs[r] -= S[(long long)i * nn + r] * xi;
+    __syncthreads();
+  }
+  for (int i = tid; i < nn; i += nt) pc[i] = -rhs[i];
+}
+
+// p (x order) from p_c and p_s = -(z_g + Z_E p_c)
+__global__ __launch_bounds__(kThreads) void k_back_substitute(DevProblem dp, NEView ne, int ncols, const double* __restrict__ Z,
+                                                              const double* __restrict__ pc, double* __restrict__ px) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < ne.CB) {
+    px[cam_col(dp.C, dp.P, idx / ne.B, idx % ne.B)] = pc[idx];
+  } else if (idx < ne.CB + ne.N3) {
+    const int r = idx - ne.CB;
+    const double* zr = Z + (long long)r * ncols;
+    double acc = zr[ne.CB];
+    for (int k = 0; k < ne.CB; ++k) acc += zr[k] * pc[k];
+    const int g = r / 3, d = r % 3;
+    px[dp.mv.ctrl_x0[g] + d * dp.mv.ctrl_stride[g]] = -acc;
+  }
+}
+
+template <class BE>
+struct HipSchur {
+  BE& be;
+  NEView ne{};
+  int ncols = 0, BW = 0;
+  size_t ne_count = 0;
+  double *NE = nullptr, *Lb = nullptr, *Z = nullptr, *G = nullptr, *S = nullptr, *rhs = nullptr, *pc = nullptr, *D = nullptr, *gx = nullptr, *px = nullptr;
+  int* fail = nullptr;
+  int* fail_host = nullptr;
+
+  explicit HipSchur(BE& b) : be(b) {
+    const HostProblem& hp = be.hp;
+    ne.C = hp.C; ne.B = 3 + hp.P; ne.CB = ne.C * ne.B; ne.N = hp.N; ne.N3 = 3 * hp.N;
+    int W = 4;
+    for (int j = 1; j + 1 < hp.T; ++j) {
+      if (hp.ms_part[j] < 0 || hp.ms_part[j - 1] != hp.ms_part[j]) continue;
+      int lo = std::min(hp.ms_ctrl[j - 1], hp.ms_ctrl[j]), hi = std::max(hp.ms_ctrl[j - 1], hp.ms_ctrl[j]);
+      if (hp.motion_type == MVUS_MOTION_F && hp.ms_part[j + 1] == hp.ms_part[j]) { lo = std::min(lo, hp.ms_ctrl[j + 1]); hi = std::max(hi, hp.ms_ctrl[j + 1]); }
+      W = std::max(W, hi + 3 - lo + 1);
+    }
+    if (W > 6) throw HipError{"LM_SCHUR: motion rows couple control points more than 6 apart (knot spacing below one frame) - unsupported band width"};
+    W = W <= 4 ? 4 : 6;
+    ne.W = W;
+    BW = 3 * W - 1;
+    ncols = ne.CB + 1;
+    const size_t nA = (size_t)ne.C * ne.B * ne.B, ngc = ne.CB, nCb = (size_t)ne.N * W * 9, ngs = ne.N3, nEt = (size_t)ne.N3 * ne.CB;
+    ne_count = nA + ngc + nCb + ngs + nEt;
+    NE = be.alloc(ne_count);
+    ne.A = NE; ne.gc = ne.A + nA; ne.Cb = ne.gc + ngc; ne.gs = ne.Cb + nCb; ne.Et = ne.gs + ngs;
+    Lb = be.alloc((size_t)ne.N3 * (BW + 1));
+    Z = be.alloc((size_t)ne.N3 * ncols);
+    G = be.alloc((size_t)ne.CB * ncols);
+    S = be.alloc((size_t)ne.CB * ne.CB);
+    rhs = be.alloc(ne.CB); pc = be.alloc(ne.CB);
+    D = be.alloc(hp.n); gx = be.alloc(hp.n); px = be.alloc(hp.n);
+    MVUS_HIP(hipMalloc(reinterpret_cast<void**>(&fail), sizeof(int)));
+    MVUS_HIP(hipHostMalloc(reinterpret_cast<void**>(&fail_host), sizeof(int), hipHostMallocDefault));
+  }
+  ~HipSchur() {
+    for (double* p : {NE, Lb, Z, G, S, rhs, pc, D, gx, px}) be.release(p);
+    if (fail) (void)hipFree(fail);
+    if (fail_host) (void)hipHostFree(fail_host);
+  }
+
+  void assemble_local(const double* f_dev) {
+    MVUS_HIP(hipMemsetAsync(NE, 0, ne_count * sizeof(double), be.stream));
+    if (be.dp.n_chunks > 0) {
+      if (be.hp.calib) hipLaunchKernelGGL(k_assemble<30>, dim3(be.dp.n_chunks), dim3(kThreads), 0, be.stream, be.dp, be.J, be.span, f_dev, ne);
+      else hipLaunchKernelGGL(k_assemble<21>, dim3(be.dp.n_chunks), dim3(kThreads), 0, be.stream, be.dp, be.J, be.span, f_dev, ne);
+    }
+    if (be.hp.T > 0)
+      hipLaunchKernelGGL(k_assemble_motion, dim3((be.hp.T + kThreads - 1) / kThreads), dim3(kThreads), 0, be.stream, be.dp, be.mJ, be.mctrl,
+                         f_dev + 2 * be.hp.M, ne);
+    MVUS_HIP(hipGetLastError());
+  }
+  void assemble(BE&, const double* f_dev) {
+    assemble_local(f_dev);
+    be.reduce(NE, ne_count);          // one sum-all-reduce of the packed normal-equation blocks per iteration
+    const int tot = ne.CB + ne.N3;
+    MVUS_HIP(hipMemsetAsync(D, 0, be.hp.n * sizeof(double), be.stream));
+    be.fill(D, 1.0, be.hp.n);
+    MVUS_HIP(hipMemsetAsync(gx, 0, be.hp.n * sizeof(double), be.stream));
+    hipLaunchKernelGGL(k_ne_diag_grad, dim3((tot + 255) / 256), dim3(256), 0, be.stream, be.dp, ne, D, gx);
+    MVUS_HIP(hipGetLastError());
+  }
+  void gradient(std::vector<double>& g) { g.resize(be.hp.n); be.download(g.data(), gx, be.hp.n); }
+  void diagonal(std::vector<double>& d) { d.resize(be.hp.n); be.download(d.data(), D, be.hp.n); }
+
+  bool solve(double lambda, std::vector<double>& p) {
+    const long long nLb = (long long)ne.N3 * (BW + 1);
+    MVUS_HIP(hipMemsetAsync(fail, 0, sizeof(int), be.stream));
+    hipLaunchKernelGGL(k_band_pack, dim3((unsigned)((nLb + 255) / 256)), dim3(256), 0, be.stream, ne, lambda, BW, Lb);
+    if (BW == 11) hipLaunchKernelGGL(k_band_cholesky<11>, dim3(1), dim3(64), 0, be.stream, ne.N3, Lb, fail);
+    else hipLaunchKernelGGL(k_band_cholesky<17>, dim3(1), dim3(64), 0, be.stream, ne.N3, Lb, fail);
+    const long long nZ = (long long)ne.N3 * ncols;
+    hipLaunchKernelGGL(k_build_rhs, dim3((unsigned)((nZ + 255) / 256)), dim3(256), 0, be.stream, ne, ncols, Z);
+    if (BW == 11) hipLaunchKernelGGL(k_band_solve<11>, dim3((ncols + 63) / 64), dim3(64), 0, be.stream, ne.N3, ncols, Lb, Z);
+    else hipLaunchKernelGGL(k_band_solve<17>, dim3((ncols + 63) / 64), dim3(64), 0, be.stream, ne.N3, ncols, Lb, Z);
+    MVUS_HIP(hipMemsetAsync(G, 0, (size_t)ne.CB * ncols * sizeof(double), be.stream));
+    hipLaunchKernelGGL(k_schur_gemm, dim3((ne.CB + 15) / 16, (ncols + 15) / 16, (ne.N3 + kGemmK - 1) / kGemmK), dim3(256), 0, be.stream, ne, ncols, Z, G);
+    const long long nS = (long long)ne.CB * ne.CB;
+    hipLaunchKernelGGL(k_schur_finish, dim3((unsigned)((nS + 255) / 256)), dim3(256), 0, be.stream, ne, ncols, lambda, G, S, rhs);
+    hipLaunchKernelGGL(k_dense_chol_solve, dim3(1), dim3(1024), 0, be.stream, ne.CB, S, rhs, pc, fail);
+    MVUS_HIP(hipMemsetAsync(px, 0, be.hp.n * sizeof(double), be.stream));
+    const int tot = ne.CB + ne.N3;
+    hipLaunchKernelGGL(k_back_substitute, dim3((tot + kThreads - 1) / kThreads), dim3(kThreads), 0, be.stream, be.dp, ne, ncols, Z, pc, px);
+    MVUS_HIP(hipGetLastError());
+    MVUS_HIP(hipMemcpyAsync(fail_host, fail, sizeof(int), hipMemcpyDeviceToHost, be.stream));
+    p.resize(be.hp.n);
+    be.download(p.data(), px, be.hp.n);
+    if (*fail_host != 0) return false;
+    for (double v : p) if (!std::isfinite(v)) return false;
+    return true;
+  }
+};
+
+template <class BE>
+SolveResult lm_schur_hip(BE& be, std::vector<double>& x, const std::vector<double>& lb, const std::vector<double>& ub,
+                         const SolveOptions& opt, double* f_dev) {
+  if (be.hp.C * (3 + be.hp.P) > 1152) throw HipError{"LM_SCHUR: reduced camera system larger than 1152 unknowns"};
+  HipSchur<BE> sc(be);
+  return lm_schur(be, sc, x, lb, ub, opt, f_dev);
+}
+
+// Gauss-Newton normal equations of the Jacobian currently held, copied out for inspection (mvus_ba_normal_equations)
+template <class BE>
+int schur_export(BE& be, double* g, double* JtJ_cam, double* band, double* cross, int32_t* W_out) {
+  if (!be.has_jacobian) { be.err = "no Jacobian held: call mvus_ba_residual_jacobian first"; return MVUS_E_INVALID; }
+  HipSchur<BE> sc(be);
+  if (W_out) *W_out = sc.ne.W;
+  if (!g && !JtJ_cam && !band && !cross) return MVUS_OK;
+  sc.assemble(be, be.f_cur);
+  const NEView& ne = sc.ne;
+  if (g) be.download(g, sc.gx, be.hp.n);
+  if (JtJ_cam) be.download(JtJ_cam, ne.A, (int64_t)ne.C * ne.B * ne.B);
+  if (band) be.download(band, ne.Cb, (int64_t)ne.N * ne.W * 9);
+  if (cross) {
+    std::vector<double> Et((size_t)ne.N3 * ne.CB);
+    be.download(Et.data(), ne.Et, (int64_t)Et.size());
+    for (int r = 0; r < ne.N3; ++r)
+      for (int cidx = 0; cidx < ne.CB; ++cidx) cross[(size_t)cidx * ne.N3 + r] = Et[(size_t)r * ne.CB + cidx];
+  }
+  return MVUS_OK;
+}
+
 }  // namespace mvus

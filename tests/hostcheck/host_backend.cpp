@@ -225,7 +225,7 @@ int hostcheck_solve(void* h, double* x, const mvus_solve_opts* o, mvus_result* r
   std::vector<double> f(be->hp.m);
   SolveResult sr;
 #ifdef MVUS_WITH_SCHUR
-  if (o->solver == MVUS_SOLVER_LM_SCHUR) sr = lm_schur<HostBackend, HostSchur>(*be, xv, lb, ub, so, f.data());
+  if (o->solver == MVUS_SOLVER_LM_SCHUR) { HostSchur sc; sr = lm_schur(*be, sc, xv, lb, ub, so, f.data()); }
   else
 #endif
     sr = trf_lsmr(*be, xv, lb, ub, so, f.data());

@@ -1,0 +1,90 @@
+"""GPU tests of the normal-equation assembly and the LM + Schur solver against dense host algebra."""
+import numpy as np
+import pytest
+
+from oracle import ba_oracle as orc
+from golden_util import CASES, load_case
+from mvus_amd import _lib
+from mvus_amd import problem as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _host(prob):
+    from hostcheck_util import HostHandle
+    return HostHandle(prob)
+
+
+def internal_index(prob):
+    """x index of every unknown in the solver's internal order: camera blocks (alpha,beta,rs,params), then 3*ctrl+xyz."""
+    C, P = prob.C, prob.P
+    cam = [[c, C + c, 2 * C + c] + list(range(3 * C + c * P, 3 * C + (c + 1) * P)) for c in range(C)]
+    spl = []
+    for s, n in enumerate(prob.n_coef):
+        for j in range(int(n)):
+            spl += [int(prob.spline_x_offsets[s]) + d * int(n) + j for d in range(3)]
+    return np.array(cam), np.array(spl)
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_normal_equations_match_dense(name):
+    from mvus_amd.ba import BAHandle
+    scene, g = load_case(name)
+    prob, _ = mp.problem_from_scene(scene)
+    x = g['x0'] + g['delta']
+    f, D = _host(prob).dense_jacobian(x, _lib.JAC_ANALYTIC)
+    H, grad = D.T @ D, D.T @ f
+    cam_idx, spl_idx = internal_index(prob)
+    with BAHandle(prob) as h:
+        h.residual_jacobian(x, _lib.JAC_ANALYTIC)
+        gg, A, band, cross = h.normal_equations()
+    scale = np.abs(H).max()
+    np.testing.assert_allclose(gg, grad, rtol=0, atol=1e-11 * np.abs(grad).max())
+    for c in range(prob.C):
+        np.testing.assert_allclose(A[c], H[np.ix_(cam_idx[c], cam_idx[c])], rtol=0, atol=1e-12 * scale)
+    Hs = H[np.ix_(spl_idx, spl_idx)]
+    N, W = band.shape[0], band.shape[1]
+    covered = np.zeros_like(Hs, dtype=bool)
+    for gi in range(N):
+        for w in range(W):
+            if gi + w < N:
+                blk = Hs[3 * gi:3 * gi + 3, 3 * (gi + w):3 * (gi + w) + 3]
+                np.testing.assert_allclose(band[gi, w], blk, rtol=0, atol=1e-12 * scale)
+                covered[3 * gi:3 * gi + 3, 3 * (gi + w):3 * (gi + w) + 3] = True
+                covered[3 * (gi + w):3 * (gi + w) + 3, 3 * gi:3 * gi + 3] = True
+    assert not Hs[~covered].any()                                   # nothing outside the band
+    E = H[np.ix_(cam_idx.ravel(), spl_idx)]
+    np.testing.assert_allclose(cross.reshape(E.shape), E, rtol=0, atol=1e-12 * scale)
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_lm_schur_gpu_matches_host_dense_lm(name):
+    from mvus_amd.ba import BAHandle
+    scene, g = load_case(name)
+    prob, _ = mp.problem_from_scene(scene)
+    opts = _lib.default_opts(_lib.SOLVER_LM_SCHUR, _lib.JAC_ANALYTIC, 8)
+    xh, rh, fh = _host(prob).solve(g['x0'], opts)
+    with BAHandle(prob) as h:
+        r = h.solve(g['x0'], opts=opts)
+    assert (r.nfev, r.njev, r.status) == (rh.nfev, rh.njev, rh.status)
+    np.testing.assert_allclose(r.cost, rh.cost, rtol=1e-7)
+    np.testing.assert_allclose(r.x, xh, rtol=0, atol=1e-5 * max(1.0, np.abs(xh).max()))
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_lm_schur_final_fit_not_worse_than_reference(name):
+    """Second BA of main.py:59 (inliers only): LM with the exact Jacobian must reach at least the reference's cost."""
+    from mvus_amd.ba import BAHandle
+    scene, g = load_case(name)
+    keep, off = g['outlier_keep'].astype(bool), g['det_offsets']
+    for i in range(scene.num_cam):
+        scene.detections[i] = scene.detections[i][:, keep[off[i]:off[i + 1]]]
+    prob, _ = mp.problem_from_scene(scene)
+    oprob, _ = orc.problem_from_scene(scene)
+    with BAHandle(prob) as h:
+        r = h.solve(g['ba2_10_x0'], solver=_lib.SOLVER_LM_SCHUR, jac_mode=_lib.JAC_ANALYTIC, max_nfev=40)
+        np.testing.assert_allclose(0.5 * np.sum(orc.residual(oprob, r.x) ** 2), r.cost, rtol=1e-9)
+    assert r.cost < float(g['ba2_10_cost'])
+    if prob.rs_bounds:
+        rs = r.x[2 * prob.C:3 * prob.C]
+        assert np.all((rs >= 0) & (rs <= 1))
