@@ -141,6 +141,7 @@ def main():
     t_r = handle.time_kernel(ba.KERNEL_RESIDUAL, 50)
     t_jv = handle.time_kernel(ba.KERNEL_JV, 50)
     t_jtu = handle.time_kernel(ba.KERNEL_JTU, 50)
+    t_asm = handle.time_kernel(ba.KERNEL_ASSEMBLY, 20)
     per_obs, once = algorithmic_bytes(handle.prob)
     bytes_launch = handle.prob.M * per_obs + once
     achieved = bytes_launch / (t_rj * 1e-3) / 1e9
@@ -165,7 +166,7 @@ def main():
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': None, 'bytes_per_launch': bytes_launch, 'avg_launch_ms': t_rj,
                          'bytes_per_obs': per_obs, 'obs_per_launch': handle.prob.M},
-            'kernels_ms': {'residual': t_r, 'residual_jacobian': t_rj, 'jv': t_jv, 'jtu': t_jtu},
+            'kernels_ms': {'residual': t_r, 'residual_jacobian': t_rj, 'jv': t_jv, 'jtu': t_jtu, 'normal_eq_assembly': t_asm},
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.config)

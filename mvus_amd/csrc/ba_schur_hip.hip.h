@@ -244,6 +244,268 @@ __global__ __launch_bounds__(64) void k_band_cholesky(int n3, double* __restrict
   }
 }
 
+// ---- partitioned (separator-based) parallel solve of the banded spline system ---------------------------
+// The chain of control points is cut into P interiors of kPartL control points separated by separators of
+// W-1 control points (= the block half-bandwidth, so two interiors never couple directly):
+//     I_0 S_0 I_1 S_1 ... I_{P-1}
+// A) every interior is factorised and solved independently (one wavefront per interior; one thread per
+//    right-hand side, plus the 2*(W-1)*3 coupling columns V_p = B_p^-1 H[I_p,S_{p-1}], W_p = B_p^-1 H[I_p,S_p]);
+// B) the separator system (block tridiagonal, blocks of 3(W-1)) is formed from short dot products;
+// C) it is solved sequentially by one workgroup (P-1 small steps, all right-hand sides in parallel);
+// D) the interiors are corrected: X_I = Y - V X_{S_{p-1}} - W X_{S_p}.
+constexpr int kPartL = 32;
+constexpr int kPartRowsMax = 3 * (kPartL + 6);
+
+struct PartView {
+  int P;                 // interiors
+  int s3;                // separator size in scalars, 3*(W-1)
+  const int* i0;         // [P]  first scalar row of interior p
+  const int* i1;         // [P]  one past the last scalar row of interior p
+  const int* s0;         // [P-1] first scalar row of separator q
+  double* VW;            // [P][kPartRowsMax][2*s3]
+  double* T;             // [P-1][s3][s3] diagonal blocks of the separator system
+  double* U;             // [P-1][s3][s3] U[q] = T(q, q+1)
+};
+
+// original (damped) matrix entry H(i, c) read from the lower band; valid for separator rows/columns and for
+// interior-separator couplings, which the interior factorisation never overwrites
+template <int BW>
+__device__ __forceinline__ double band_entry(const double* __restrict__ Lb, int i, int c) {
+  const int hi = i > c ? i : c, d = i > c ? i - c : c - i;
+  return d <= BW ? Lb[(long long)hi * (BW + 1) + d] : 0.0;
+}
+
+template <int BW>
+__global__ __launch_bounds__(64) void k_part_cholesky(PartView pv, double* __restrict__ Lb, int* __restrict__ fail) {
+  constexpr int R = BW + 1;
+  __shared__ double T[kPartRowsMax * R];
+  const int p = blockIdx.x, lane = threadIdx.x;
+  const int r0 = pv.i0[p], n = pv.i1[p] - r0;
+  for (int e = lane; e < n * R; e += 64) T[e] = Lb[(long long)r0 * R + e];
+  __syncthreads();
+  for (int k = 0; k < n; ++k) {
+    double piv = T[k * R];
+    if (!(piv > 0.0)) { if (lane == 0) fail[0] = 1; piv = 1.0; }
+    const double inv = 1.0 / sqrt(piv);
+    const int nb = min(BW, n - 1 - k);
+    if (lane >= 1 && lane <= nb) T[(k + lane) * R + lane] *= inv;
+    __syncthreads();
+    const int npairs = nb * (nb + 1) / 2;
+    for (int e = lane; e < npairs; e += 64) {
+      int r = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
+      while ((r + 1) * (r + 2) / 2 <= e) ++r;
+      while (r * (r + 1) / 2 > e) --r;
+      const int rr = r + 1, ss = e - r * (r + 1) / 2 + 1;
+      T[(k + rr) * R + (rr - ss)] -= T[(k + rr) * R + rr] * T[(k + ss) * R + ss];
+    }
+    if (lane == 0) T[k * R] = inv;      // reciprocal of L(k,k)
+    __syncthreads();
+  }
+  // write back only entries whose column lies inside the interior (j <= row - r0); couplings stay original
+  for (int e = lane; e < n * R; e += 64) {
+    const int row = e / R, j = e % R;
+    if (j <= row) Lb[(long long)r0 * R + e] = T[e];
+  }
+}
+
+// interior solves: thread t < ncols -> right-hand side column of Z (in place); t >= ncols -> coupling column
+template <int BW>
+__global__ __launch_bounds__(64) void k_part_solve(PartView pv, int ncols, const double* __restrict__ Lb, double* __restrict__ Z) {
+  constexpr int R = BW + 1;
+  const int p = blockIdx.x;
+  const int t = blockIdx.y * blockDim.x + threadIdx.x;
+  const int s3 = pv.s3;
+  if (t >= ncols + 2 * s3) return;
+  const int r0 = pv.i0[p], r1 = pv.i1[p];
+  int kind = 0, ccol = 0;                    // 0: rhs, 1: left coupling, 2: right coupling
+  if (t >= ncols) {
+    const int k = t - ncols;
+    if (k < s3) { if (p == 0) return; kind = 1; ccol = pv.s0[p - 1] + k; }
+    else { if (p == pv.P - 1) return; kind = 2; ccol = pv.s0[p] + (k - s3); }
+  }
+  double* out = kind == 0 ? nullptr : pv.VW + ((long long)p * kPartRowsMax) * (2 * s3) + (t - ncols);
+  const int ostride = 2 * s3;
+  double yw[BW];
+#pragma unroll
+  for (int j = 0; j < BW; ++j) yw[j] = 0.0;
+  for (int i = r0; i < r1; ++i) {
+    const double* Lr = Lb + (long long)i * R;
+    double acc = kind == 0 ? Z[(long long)i * ncols + t] : band_entry<BW>(Lb, i, ccol);
+#pragma unroll
+    for (int j = 1; j <= BW; ++j) acc -= (i - j >= r0 ? Lr[j] : 0.0) * yw[j - 1];
+    const double y = acc * Lr[0];
+    if (kind == 0) Z[(long long)i * ncols + t] = y; else out[(long long)(i - r0) * ostride] = y;
+#pragma unroll
+    for (int j = BW - 1; j >= 1; --j) yw[j] = yw[j - 1];
+    yw[0] = y;
+  }
+#pragma unroll
+  for (int j = 0; j < BW; ++j) yw[j] = 0.0;
+  for (int i = r1 - 1; i >= r0; --i) {
+    double acc = kind == 0 ? Z[(long long)i * ncols + t] : out[(long long)(i - r0) * ostride];
+#pragma unroll
+    for (int j = 1; j <= BW; ++j) {
+      const double l = (i + j < r1) ? Lb[(long long)(i + j) * R + j] : 0.0;
+      acc -= l * yw[j - 1];
+    }
+    const double xv = acc * Lb[(long long)i * R];
+    if (kind == 0) Z[(long long)i * ncols + t] = xv; else out[(long long)(i - r0) * ostride] = xv;
+#pragma unroll
+    for (int j = BW - 1; j >= 1; --j) yw[j] = yw[j - 1];
+    yw[0] = xv;
+  }
+}
+
+// separator system: T(q,q), T(q,q+1) and the reduced right-hand sides (in place in the separator rows of Z)
+template <int BW>
+__global__ __launch_bounds__(256) void k_part_reduce(PartView pv, int ncols, const double* __restrict__ Lb, double* __restrict__ Z) {
+  const int q = blockIdx.x, s3 = pv.s3, st = 2 * s3;
+  const int c0 = pv.s0[q];
+  const int a0 = pv.i0[q], a1 = pv.i1[q];             // interior before the separator
+  const int b0 = pv.i0[q + 1], b1 = pv.i1[q + 1];     // interior after it
+  const int alo = max(a0, a1 - BW), bhi = min(b1, b0 + BW);   // rows that can couple to the separator
+  const double* VWa = pv.VW + ((long long)q * kPartRowsMax) * st;
+  const double* VWb = pv.VW + ((long long)(q + 1) * kPartRowsMax) * st;
+  for (int e = threadIdx.x; e < s3 * s3; e += blockDim.x) {
+    const int a = e / s3, b = e % s3;
+    double t = band_entry<BW>(Lb, c0 + a, c0 + b), u = 0.0;
+    for (int i = alo; i < a1; ++i) t -= band_entry<BW>(Lb, i, c0 + a) * VWa[(long long)(i - a0) * st + s3 + b];     // F_right(q)^T W_q
+    for (int i = b0; i < bhi; ++i) {
+      const double fl = band_entry<BW>(Lb, i, c0 + a);
+      t -= fl * VWb[(long long)(i - b0) * st + b];                                                                  // F_left(q+1)^T V_{q+1}
+      u -= fl * VWb[(long long)(i - b0) * st + s3 + b];                                                             // F_left(q+1)^T W_{q+1}
+    }
+    pv.T[((long long)q * s3 + a) * s3 + b] = t;
+    pv.U[((long long)q * s3 + a) * s3 + b] = (q + 1 < pv.P - 1) ? u : 0.0;
+  }
+  for (int e = threadIdx.x; e < s3 * ncols; e += blockDim.x) {
+    const int a = e / ncols, col = e % ncols;
+    double r = Z[(long long)(c0 + a) * ncols + col];
+    for (int i = alo; i < a1; ++i) r -= band_entry<BW>(Lb, i, c0 + a) * Z[(long long)i * ncols + col];
+    for (int i = b0; i < bhi; ++i) r -= band_entry<BW>(Lb, i, c0 + a) * Z[(long long)i * ncols + col];
+    Z[(long long)(c0 + a) * ncols + col] = r;
+  }
+}
+
+// block-tridiagonal Cholesky of the separator system + all right-hand sides, by one workgroup
+template <int S3>
+__global__ __launch_bounds__(256) void k_sep_solve(PartView pv, int ncols, double* __restrict__ Z, int* __restrict__ fail) {
+  __shared__ double Cq[S3 * S3];      // Cholesky factor of the current diagonal block (lower)
+  __shared__ double Lq[S3 * S3];      // L(q, q-1) = U_{q-1}^T C_{q-1}^-T
+  const int nq = pv.P - 1, tid = threadIdx.x;
+  // forward: factorisation; L blocks are stored back into U (U[q-1] <- L(q,q-1)), factors into T
+  for (int q = 0; q < nq; ++q) {
+    double* Tq = pv.T + (long long)q * S3 * S3;
+    for (int e = tid; e < S3 * S3; e += blockDim.x) {
+      const int a = e / S3, b = e % S3;
+      double v = Tq[e];
+      if (q > 0) for (int k = 0; k < S3; ++k) v -= Lq[a * S3 + k] * Lq[b * S3 + k];
+      Cq[e] = v;
+    }
+    __syncthreads();
+    if (tid == 0) {                    // small dense Cholesky (S3 <= 15)
+      for (int k = 0; k < S3; ++k) {
+        double d = Cq[k * S3 + k];
+        for (int j = 0; j < k; ++j) d -= Cq[k * S3 + j] * Cq[k * S3 + j];
+        if (!(d > 0.0)) { fail[0] = 3; d = 1.0; }
+        d = sqrt(d);
+        Cq[k * S3 + k] = d;
+        for (int i = k + 1; i < S3; ++i) {
+          double sacc = Cq[i * S3 + k];
+          for (int j = 0; j < k; ++j) sacc -= Cq[i * S3 + j] * Cq[k * S3 + j];
+          Cq[i * S3 + k] = sacc / d;
+        }
+      }
+    }
+    __syncthreads();
+    // right-hand sides: r_q <- C_q^-1 (r_q - L(q,q-1) r_{q-1})
+    for (int col = tid; col < ncols; col += blockDim.x) {
+      double rv[S3];
+#pragma unroll
+      for (int a = 0; a < S3; ++a) rv[a] = Z[(long long)(pv.s0[q] + a) * ncols + col];
+      if (q > 0) {
+#pragma unroll
+        for (int k = 0; k < S3; ++k) {
+          const double pk = Z[(long long)(pv.s0[q - 1] + k) * ncols + col];
+#pragma unroll
+          for (int a = 0; a < S3; ++a) rv[a] -= Lq[a * S3 + k] * pk;
+        }
+      }
+#pragma unroll
+      for (int a = 0; a < S3; ++a) {
+        double sacc = rv[a];
+#pragma unroll
+        for (int j = 0; j < S3; ++j) if (j < a) sacc -= Cq[a * S3 + j] * rv[j];
+        rv[a] = sacc / Cq[a * S3 + a];
+      }
+#pragma unroll
+      for (int a = 0; a < S3; ++a) Z[(long long)(pv.s0[q] + a) * ncols + col] = rv[a];
+    }
+    for (int e = tid; e < S3 * S3; e += blockDim.x) Tq[e] = Cq[e];
+    __syncthreads();
+    if (q + 1 < nq) {
+      // L(q+1, q) = U_q^T C_q^-T : row a of L solves  C_q l_a = U_q[:, a]
+      double* Uq = pv.U + (long long)q * S3 * S3;
+      if (tid < S3) {
+        const int a = tid;
+        double l[S3];
+        for (int k = 0; k < S3; ++k) {
+          double sacc = Uq[k * S3 + a];
+          for (int j = 0; j < k; ++j) sacc -= Cq[k * S3 + j] * l[j];
+          l[k] = sacc / Cq[k * S3 + k];
+        }
+        for (int k = 0; k < S3; ++k) Lq[a * S3 + k] = l[k];
+      }
+      __syncthreads();
+      for (int e = tid; e < S3 * S3; e += blockDim.x) Uq[e] = Lq[e];
+      __syncthreads();
+    }
+  }
+  // backward: x_q = C_q^-T (y_q - L(q+1,q)^T x_{q+1})
+  for (int q = nq - 1; q >= 0; --q) {
+    const double* Tq = pv.T + (long long)q * S3 * S3;
+    for (int e = tid; e < S3 * S3; e += blockDim.x) { Cq[e] = Tq[e]; if (q + 1 < nq) Lq[e] = pv.U[(long long)q * S3 * S3 + e]; }
+    __syncthreads();
+    for (int col = tid; col < ncols; col += blockDim.x) {
+      double rv[S3];
+#pragma unroll
+      for (int a = 0; a < S3; ++a) rv[a] = Z[(long long)(pv.s0[q] + a) * ncols + col];
+      if (q + 1 < nq) {
+#pragma unroll
+        for (int k = 0; k < S3; ++k) {
+          const double xk = Z[(long long)(pv.s0[q + 1] + k) * ncols + col];
+#pragma unroll
+          for (int a = 0; a < S3; ++a) rv[a] -= Lq[k * S3 + a] * xk;
+        }
+      }
+#pragma unroll
+      for (int a = S3 - 1; a >= 0; --a) {
+        double sacc = rv[a];
+#pragma unroll
+        for (int j = 0; j < S3; ++j) if (j > a) sacc -= Cq[j * S3 + a] * rv[j];
+        rv[a] = sacc / Cq[a * S3 + a];
+      }
+#pragma unroll
+      for (int a = 0; a < S3; ++a) Z[(long long)(pv.s0[q] + a) * ncols + col] = rv[a];
+    }
+    __syncthreads();
+  }
+}
+
+// interiors: X = Y - V X_{S_{p-1}} - W X_{S_p}
+__global__ __launch_bounds__(256) void k_part_back(PartView pv, int ncols, double* __restrict__ Z) {
+  const int p = blockIdx.x, s3 = pv.s3, st = 2 * s3;
+  const int r0 = pv.i0[p], n = pv.i1[p] - r0;
+  const double* VWp = pv.VW + ((long long)p * kPartRowsMax) * st;
+  for (int e = blockIdx.y * blockDim.x + threadIdx.x; e < n * ncols; e += gridDim.y * blockDim.x) {
+    const int i = e / ncols, col = e % ncols;
+    double v = Z[(long long)(r0 + i) * ncols + col];
+    if (p > 0) for (int a = 0; a < s3; ++a) v -= VWp[(long long)i * st + a] * Z[(long long)(pv.s0[p - 1] + a) * ncols + col];
+    if (p < pv.P - 1) for (int a = 0; a < s3; ++a) v -= VWp[(long long)i * st + s3 + a] * Z[(long long)(pv.s0[p] + a) * ncols + col];
+    Z[(long long)(r0 + i) * ncols + col] = v;
+  }
+}
+
 // Z[3N][ncols] = [E^T | gs]
 __global__ void k_build_rhs(NEView ne, int ncols, double* __restrict__ Z) {
   const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
@@ -395,6 +657,8 @@ struct HipSchur {
   double *NE = nullptr, *Lb = nullptr, *Z = nullptr, *G = nullptr, *S = nullptr, *rhs = nullptr, *pc = nullptr, *D = nullptr, *gx = nullptr, *px = nullptr;
   int* fail = nullptr;
   int* fail_host = nullptr;
+  PartView pv{};
+  int* part_tables = nullptr;
 
   explicit HipSchur(BE& b) : be(b) {
     const HostProblem& hp = be.hp;
@@ -423,9 +687,33 @@ struct HipSchur {
     D = be.alloc(hp.n); gx = be.alloc(hp.n); px = be.alloc(hp.n);
     MVUS_HIP(hipMalloc(reinterpret_cast<void**>(&fail), sizeof(int)));
     MVUS_HIP(hipHostMalloc(reinterpret_cast<void**>(&fail_host), sizeof(int), hipHostMallocDefault));
+    // partition of the control-point chain: interiors of kPartL control points, separators of W-1
+    const int sctrl = W - 1;
+    std::vector<int> i0, i1, s0;
+    for (int g = 0; g < ne.N;) {
+      int e = std::min(g + kPartL, ne.N);
+      i0.push_back(3 * g); i1.push_back(3 * e); g = e;
+      if (g < ne.N) {
+        const int e2 = std::min(g + sctrl, ne.N);
+        if (ne.N - e2 < 1) { i1.back() = 3 * ne.N; g = ne.N; }      // tail too short for another interior: merge
+        else { s0.push_back(3 * g); g = e2; }
+      }
+    }
+    pv.P = (int)i0.size(); pv.s3 = 3 * sctrl;
+    std::vector<int> tab;
+    tab.insert(tab.end(), i0.begin(), i0.end()); tab.insert(tab.end(), i1.begin(), i1.end()); tab.insert(tab.end(), s0.begin(), s0.end());
+    tab.push_back(0);
+    MVUS_HIP(hipMalloc(reinterpret_cast<void**>(&part_tables), tab.size() * sizeof(int)));
+    MVUS_HIP(hipMemcpyAsync(part_tables, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice, be.stream));
+    MVUS_HIP(hipStreamSynchronize(be.stream));
+    pv.i0 = part_tables; pv.i1 = part_tables + pv.P; pv.s0 = part_tables + 2 * pv.P;
+    pv.VW = be.alloc((size_t)pv.P * kPartRowsMax * 2 * pv.s3);
+    pv.T = be.alloc((size_t)std::max(pv.P - 1, 1) * pv.s3 * pv.s3);
+    pv.U = be.alloc((size_t)std::max(pv.P - 1, 1) * pv.s3 * pv.s3);
   }
   ~HipSchur() {
-    for (double* p : {NE, Lb, Z, G, S, rhs, pc, D, gx, px}) be.release(p);
+    for (double* p : {NE, Lb, Z, G, S, rhs, pc, D, gx, px, pv.VW, pv.T, pv.U}) be.release(p);
+    if (part_tables) (void)hipFree(part_tables);
     if (fail) (void)hipFree(fail);
     if (fail_host) (void)hipHostFree(fail_host);
   }
@@ -458,12 +746,25 @@ struct HipSchur {
     const long long nLb = (long long)ne.N3 * (BW + 1);
     MVUS_HIP(hipMemsetAsync(fail, 0, sizeof(int), be.stream));
     hipLaunchKernelGGL(k_band_pack, dim3((unsigned)((nLb + 255) / 256)), dim3(256), 0, be.stream, ne, lambda, BW, Lb);
-    if (BW == 11) hipLaunchKernelGGL(k_band_cholesky<11>, dim3(1), dim3(64), 0, be.stream, ne.N3, Lb, fail);
-    else hipLaunchKernelGGL(k_band_cholesky<17>, dim3(1), dim3(64), 0, be.stream, ne.N3, Lb, fail);
     const long long nZ = (long long)ne.N3 * ncols;
     hipLaunchKernelGGL(k_build_rhs, dim3((unsigned)((nZ + 255) / 256)), dim3(256), 0, be.stream, ne, ncols, Z);
-    if (BW == 11) hipLaunchKernelGGL(k_band_solve<11>, dim3((ncols + 63) / 64), dim3(64), 0, be.stream, ne.N3, ncols, Lb, Z);
-    else hipLaunchKernelGGL(k_band_solve<17>, dim3((ncols + 63) / 64), dim3(64), 0, be.stream, ne.N3, ncols, Lb, Z);
+    const dim3 gsolve(pv.P, (ncols + 2 * pv.s3 + 63) / 64);
+    if (BW == 11) {
+      hipLaunchKernelGGL(k_part_cholesky<11>, dim3(pv.P), dim3(64), 0, be.stream, pv, Lb, fail);
+      hipLaunchKernelGGL(k_part_solve<11>, gsolve, dim3(64), 0, be.stream, pv, ncols, Lb, Z);
+      if (pv.P > 1) {
+        hipLaunchKernelGGL(k_part_reduce<11>, dim3(pv.P - 1), dim3(256), 0, be.stream, pv, ncols, Lb, Z);
+        hipLaunchKernelGGL(k_sep_solve<9>, dim3(1), dim3(256), 0, be.stream, pv, ncols, Z, fail);
+      }
+    } else {
+      hipLaunchKernelGGL(k_part_cholesky<17>, dim3(pv.P), dim3(64), 0, be.stream, pv, Lb, fail);
+      hipLaunchKernelGGL(k_part_solve<17>, gsolve, dim3(64), 0, be.stream, pv, ncols, Lb, Z);
+      if (pv.P > 1) {
+        hipLaunchKernelGGL(k_part_reduce<17>, dim3(pv.P - 1), dim3(256), 0, be.stream, pv, ncols, Lb, Z);
+        hipLaunchKernelGGL(k_sep_solve<15>, dim3(1), dim3(256), 0, be.stream, pv, ncols, Z, fail);
+      }
+    }
+    if (pv.P > 1) hipLaunchKernelGGL(k_part_back, dim3(pv.P, 8), dim3(256), 0, be.stream, pv, ncols, Z);
     MVUS_HIP(hipMemsetAsync(G, 0, (size_t)ne.CB * ncols * sizeof(double), be.stream));
     hipLaunchKernelGGL(k_schur_gemm, dim3((ne.CB + 15) / 16, (ncols + 15) / 16, (ne.N3 + kGemmK - 1) / kGemmK), dim3(256), 0, be.stream, ne, ncols, Z, G);
     const long long nS = (long long)ne.CB * ne.CB;

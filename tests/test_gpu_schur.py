@@ -88,3 +88,21 @@ def test_lm_schur_final_fit_not_worse_than_reference(name):
     if prob.rs_bounds:
         rs = r.x[2 * prob.C:3 * prob.C]
         assert np.all((rs >= 0) & (rs <= 1))
+
+
+@pytest.mark.parametrize('motion', [False, True])
+def test_partitioned_band_solver_many_partitions(motion):
+    """~300 control points -> ~9 interiors + separators; LM steps must equal the dense host LM."""
+    from mvus_amd import synth
+    from mvus_amd.ba import BAHandle
+    sc = synth.make_scene(3, 4000, seed=17, rolling_shutter=True, num_knots=300, motion_reg=motion, motion_type='F',
+                          motion_weights=50.0)
+    prob, x0 = mp.problem_from_scene(sc)
+    assert int(prob.n_coef.sum()) > 250
+    opts = _lib.default_opts(_lib.SOLVER_LM_SCHUR, _lib.JAC_ANALYTIC, 4)
+    xh, rh, fh = _host(prob).solve(x0, opts)
+    with BAHandle(prob) as h:
+        r = h.solve(x0, opts=opts)
+    assert (r.nfev, r.njev, r.status) == (rh.nfev, rh.njev, rh.status)
+    np.testing.assert_allclose(r.cost, rh.cost, rtol=1e-7)
+    np.testing.assert_allclose(r.x, xh, rtol=0, atol=1e-5 * max(1.0, np.abs(xh).max()))
