@@ -387,108 +387,107 @@ __global__ __launch_bounds__(256) void k_part_reduce(PartView pv, int ncols, con
   }
 }
 
-// block-tridiagonal Cholesky of the separator system + all right-hand sides, by one workgroup
+// block-tridiagonal Cholesky of the separator system by ONE wavefront (no workgroup barriers needed between
+// the tiny dependent steps): T[q] <- C_q (lower factor of the q-th pivot block), U[q] <- L(q+1,q) = U_q^T C_q^-T
 template <int S3>
-__global__ __launch_bounds__(256) void k_sep_solve(PartView pv, int ncols, double* __restrict__ Z, int* __restrict__ fail) {
-  __shared__ double Cq[S3 * S3];      // Cholesky factor of the current diagonal block (lower)
-  __shared__ double Lq[S3 * S3];      // L(q, q-1) = U_{q-1}^T C_{q-1}^-T
-  const int nq = pv.P - 1, tid = threadIdx.x;
-  // forward: factorisation; L blocks are stored back into U (U[q-1] <- L(q,q-1)), factors into T
+__global__ __launch_bounds__(64) void k_sep_factor(PartView pv, int* __restrict__ fail) {
+  __shared__ double Cq[S3 * S3];
+  __shared__ double Lq[S3 * S3];
+  __shared__ double Uq[S3 * S3];
+  const int nq = pv.P - 1, lane = threadIdx.x;
   for (int q = 0; q < nq; ++q) {
     double* Tq = pv.T + (long long)q * S3 * S3;
-    for (int e = tid; e < S3 * S3; e += blockDim.x) {
+    double* Ug = pv.U + (long long)q * S3 * S3;
+    for (int e = lane; e < S3 * S3; e += 64) {
       const int a = e / S3, b = e % S3;
       double v = Tq[e];
       if (q > 0) for (int k = 0; k < S3; ++k) v -= Lq[a * S3 + k] * Lq[b * S3 + k];
       Cq[e] = v;
+      Uq[e] = Ug[e];
     }
     __syncthreads();
-    if (tid == 0) {                    // small dense Cholesky (S3 <= 15)
-      for (int k = 0; k < S3; ++k) {
-        double d = Cq[k * S3 + k];
-        for (int j = 0; j < k; ++j) d -= Cq[k * S3 + j] * Cq[k * S3 + j];
-        if (!(d > 0.0)) { fail[0] = 3; d = 1.0; }
-        d = sqrt(d);
-        Cq[k * S3 + k] = d;
-        for (int i = k + 1; i < S3; ++i) {
-          double sacc = Cq[i * S3 + k];
-          for (int j = 0; j < k; ++j) sacc -= Cq[i * S3 + j] * Cq[k * S3 + j];
-          Cq[i * S3 + k] = sacc / d;
-        }
+    // right-looking Cholesky of the S3 x S3 block, lanes over the trailing entries
+    for (int k = 0; k < S3; ++k) {
+      double d = Cq[k * S3 + k];
+      if (!(d > 0.0)) { if (lane == 0) fail[0] = 3; d = 1.0; }
+      d = sqrt(d);
+      __syncthreads();
+      if (lane == 0) Cq[k * S3 + k] = d;
+      if (lane > k && lane < S3) Cq[lane * S3 + k] /= d;
+      __syncthreads();
+      for (int e = lane; e < S3 * S3; e += 64) {
+        const int a = e / S3, b = e % S3;
+        if (a > k && b > k && b <= a) Cq[e] -= Cq[a * S3 + k] * Cq[b * S3 + k];
       }
+      __syncthreads();
     }
-    __syncthreads();
-    // right-hand sides: r_q <- C_q^-1 (r_q - L(q,q-1) r_{q-1})
-    for (int col = tid; col < ncols; col += blockDim.x) {
-      double rv[S3];
-#pragma unroll
-      for (int a = 0; a < S3; ++a) rv[a] = Z[(long long)(pv.s0[q] + a) * ncols + col];
-      if (q > 0) {
-#pragma unroll
-        for (int k = 0; k < S3; ++k) {
-          const double pk = Z[(long long)(pv.s0[q - 1] + k) * ncols + col];
-#pragma unroll
-          for (int a = 0; a < S3; ++a) rv[a] -= Lq[a * S3 + k] * pk;
-        }
-      }
-#pragma unroll
-      for (int a = 0; a < S3; ++a) {
-        double sacc = rv[a];
-#pragma unroll
-        for (int j = 0; j < S3; ++j) if (j < a) sacc -= Cq[a * S3 + j] * rv[j];
-        rv[a] = sacc / Cq[a * S3 + a];
-      }
-#pragma unroll
-      for (int a = 0; a < S3; ++a) Z[(long long)(pv.s0[q] + a) * ncols + col] = rv[a];
-    }
-    for (int e = tid; e < S3 * S3; e += blockDim.x) Tq[e] = Cq[e];
-    __syncthreads();
+    for (int e = lane; e < S3 * S3; e += 64) Tq[e] = Cq[e];
     if (q + 1 < nq) {
-      // L(q+1, q) = U_q^T C_q^-T : row a of L solves  C_q l_a = U_q[:, a]
-      double* Uq = pv.U + (long long)q * S3 * S3;
-      if (tid < S3) {
-        const int a = tid;
+      if (lane < S3) {                       // row `lane` of L(q+1,q): solve C_q l = U_q[:, lane]
         double l[S3];
         for (int k = 0; k < S3; ++k) {
-          double sacc = Uq[k * S3 + a];
-          for (int j = 0; j < k; ++j) sacc -= Cq[k * S3 + j] * l[j];
+          double sacc = Uq[k * S3 + lane];
+          for (int jj = 0; jj < k; ++jj) sacc -= Cq[k * S3 + jj] * l[jj];
           l[k] = sacc / Cq[k * S3 + k];
         }
-        for (int k = 0; k < S3; ++k) Lq[a * S3 + k] = l[k];
+        for (int k = 0; k < S3; ++k) Lq[lane * S3 + k] = l[k];
       }
       __syncthreads();
-      for (int e = tid; e < S3 * S3; e += blockDim.x) Uq[e] = Lq[e];
-      __syncthreads();
+      for (int e = lane; e < S3 * S3; e += 64) Ug[e] = Lq[e];
     }
+    __syncthreads();
   }
-  // backward: x_q = C_q^-T (y_q - L(q+1,q)^T x_{q+1})
-  for (int q = nq - 1; q >= 0; --q) {
-    const double* Tq = pv.T + (long long)q * S3 * S3;
-    for (int e = tid; e < S3 * S3; e += blockDim.x) { Cq[e] = Tq[e]; if (q + 1 < nq) Lq[e] = pv.U[(long long)q * S3 * S3 + e]; }
-    __syncthreads();
-    for (int col = tid; col < ncols; col += blockDim.x) {
-      double rv[S3];
+}
+
+// forward / backward substitution of every right-hand side through the factored separator system:
+// one thread per column, no synchronisation (the factors are read-only, broadcast through the caches)
+template <int S3>
+__global__ __launch_bounds__(64) void k_sep_rhs(PartView pv, int ncols, double* __restrict__ Z) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= ncols) return;
+  const int nq = pv.P - 1;
+  double prev[S3], rv[S3];
+  for (int q = 0; q < nq; ++q) {
+    const double* __restrict__ Cq = pv.T + (long long)q * S3 * S3;
+    const double* __restrict__ Lq = pv.U + (long long)(q - 1) * S3 * S3;     // L(q, q-1)
 #pragma unroll
-      for (int a = 0; a < S3; ++a) rv[a] = Z[(long long)(pv.s0[q] + a) * ncols + col];
-      if (q + 1 < nq) {
+    for (int a = 0; a < S3; ++a) rv[a] = Z[(long long)(pv.s0[q] + a) * ncols + col];
+    if (q > 0) {
 #pragma unroll
-        for (int k = 0; k < S3; ++k) {
-          const double xk = Z[(long long)(pv.s0[q + 1] + k) * ncols + col];
+      for (int a = 0; a < S3; ++a)
 #pragma unroll
-          for (int a = 0; a < S3; ++a) rv[a] -= Lq[k * S3 + a] * xk;
-        }
-      }
-#pragma unroll
-      for (int a = S3 - 1; a >= 0; --a) {
-        double sacc = rv[a];
-#pragma unroll
-        for (int j = 0; j < S3; ++j) if (j > a) sacc -= Cq[j * S3 + a] * rv[j];
-        rv[a] = sacc / Cq[a * S3 + a];
-      }
-#pragma unroll
-      for (int a = 0; a < S3; ++a) Z[(long long)(pv.s0[q] + a) * ncols + col] = rv[a];
+        for (int k = 0; k < S3; ++k) rv[a] -= Lq[a * S3 + k] * prev[k];
     }
-    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < S3; ++a) {
+      double sacc = rv[a];
+#pragma unroll
+      for (int jj = 0; jj < S3; ++jj) if (jj < a) sacc -= Cq[a * S3 + jj] * rv[jj];
+      rv[a] = sacc / Cq[a * S3 + a];
+    }
+#pragma unroll
+    for (int a = 0; a < S3; ++a) { prev[a] = rv[a]; Z[(long long)(pv.s0[q] + a) * ncols + col] = rv[a]; }
+  }
+  for (int q = nq - 1; q >= 0; --q) {
+    const double* __restrict__ Cq = pv.T + (long long)q * S3 * S3;
+    const double* __restrict__ Ln = pv.U + (long long)q * S3 * S3;           // L(q+1, q)
+#pragma unroll
+    for (int a = 0; a < S3; ++a) rv[a] = Z[(long long)(pv.s0[q] + a) * ncols + col];
+    if (q + 1 < nq) {
+#pragma unroll
+      for (int k = 0; k < S3; ++k)
+#pragma unroll
+        for (int a = 0; a < S3; ++a) rv[a] -= Ln[k * S3 + a] * prev[k];
+    }
+#pragma unroll
+    for (int a = S3 - 1; a >= 0; --a) {
+      double sacc = rv[a];
+#pragma unroll
+      for (int jj = 0; jj < S3; ++jj) if (jj > a) sacc -= Cq[jj * S3 + a] * rv[jj];
+      rv[a] = sacc / Cq[a * S3 + a];
+    }
+#pragma unroll
+    for (int a = 0; a < S3; ++a) { prev[a] = rv[a]; Z[(long long)(pv.s0[q] + a) * ncols + col] = rv[a]; }
   }
 }
 
@@ -583,53 +582,107 @@ __global__ void k_schur_finish(NEView ne, int ncols, double lambda, const double
     v += h;
   }
   S[idx] = v;
-  if (b == 0) rhs[a] = ne.gc[a] - G[(long long)a * ncols + ne.CB];
+  if (b == 0) S[(long long)ne.CB * ne.CB + a] = ne.gc[a] - G[(long long)a * ncols + ne.CB];   // rhs rides as row CB
 }
 
-// Dense Cholesky + solve of the reduced camera system by one workgroup (right-looking, in global memory;
-// CB <= 1152 so S stays in L2).  pc = -S^-1 rhs.
-__global__ __launch_bounds__(1024) void k_dense_chol_solve(int nn, double* __restrict__ S, double* __restrict__ rhs, double* __restrict__ pc,
-                                                           int* __restrict__ fail) {
-  __shared__ double col[1152];
-  __shared__ double piv_s;
-  const int tid = threadIdx.x, nt = blockDim.x;
-  for (int k = 0; k < nn; ++k) {
-    if (tid == 0) {
-      double p = S[(long long)k * nn + k];
-      if (!(p > 0.0)) { fail[0] = 2; p = 1.0; }
-      piv_s = sqrt(p);
-    }
+// Dense Cholesky + solve of the reduced camera system (nn <= 1152), blocked with panels of kNB columns.
+// The right-hand side rides along as row nn of the (nn+1) x nn array `Sa` (Sa[nn][:] = rhs), so the panel
+// triangular solve performs the forward substitution; the backward substitution runs panel by panel.
+constexpr int kNB = 32;
+
+__global__ __launch_bounds__(1024) void k_potrf_diag(int nn, int kb, double* __restrict__ Sa, int* __restrict__ fail) {
+  __shared__ double D[kNB][kNB + 1];
+  const int nb = min(kNB, nn - kb);
+  const int r = threadIdx.x / kNB, c = threadIdx.x % kNB;
+  D[r][c] = (r < nb && c < nb) ? Sa[(long long)(kb + r) * nn + kb + c] : (r == c ? 1.0 : 0.0);
+  __syncthreads();
+  for (int k = 0; k < nb; ++k) {
+    double d = D[k][k];
+    if (!(d > 0.0)) { if (threadIdx.x == 0) fail[0] = 2; d = 1.0; }
+    d = sqrt(d);
     __syncthreads();
-    const double d = piv_s;
-    for (int i = k + tid; i < nn; i += nt) {
-      const double v = (i == k) ? d : S[(long long)i * nn + k] / d;
-      col[i] = v;
-      S[(long long)i * nn + k] = v;
-    }
+    if (r == k && c == k) D[k][k] = d;
+    if (c == k && r > k) D[r][k] /= d;
     __syncthreads();
-    const int rem = nn - k - 1;
-    for (long long e = tid; e < (long long)rem * rem; e += nt) {
-      const int i = k + 1 + (int)(e / rem), j = k + 1 + (int)(e % rem);
-      if (j <= i) S[(long long)i * nn + j] -= col[i] * col[j];
-    }
+    if (r > k && c > k && c <= r) D[r][c] -= D[r][k] * D[c][k];
     __syncthreads();
   }
-  // forward / backward substitution (single wavefront worth of work; nn is small)
-  for (int i = 0; i < nn; ++i) {
-    if (tid == 0) rhs[i] = rhs[i] / S[(long long)i * nn + i];
-    __syncthreads();
-    const double yi = rhs[i];
-    for (int r = i + 1 + tid; r < nn; r += nt) rhs[r] -= S[(long long)r * nn + i] * yi;
-    __syncthreads();
+  if (r < nb && c < nb) Sa[(long long)(kb + r) * nn + kb + c] = (c <= r) ? D[r][c] : 0.0;
+}
+
+// rows below the panel (and the rhs row): X <- X L11^-T.  One thread per row; the row's panel entries live in
+// LDS (column-major over threads, conflict free) so nothing is spilled.
+constexpr int kTrsmThreads = 128;
+__global__ __launch_bounds__(kTrsmThreads) void k_trsm_panel(int nn, int kb, double* __restrict__ Sa) {
+  __shared__ double L11[kNB][kNB + 1];
+  __shared__ double xs[kNB][kTrsmThreads];
+  const int nb = min(kNB, nn - kb), tid = threadIdx.x;
+  for (int e = tid; e < kNB * kNB; e += blockDim.x) {
+    const int r = e / kNB, c = e % kNB;
+    L11[r][c] = (r < nb && c < nb) ? Sa[(long long)(kb + r) * nn + kb + c] : (r == c ? 1.0 : 0.0);
   }
-  for (int i = nn - 1; i >= 0; --i) {
-    if (tid == 0) rhs[i] = rhs[i] / S[(long long)i * nn + i];
-    __syncthreads();
-    const double xi = rhs[i];
-    for (int r = tid; r < i; r += nt) rhs[r] -= S[(long long)i * nn + r] * xi;
-    __syncthreads();
+  __syncthreads();
+  const int i = kb + nb + blockIdx.x * blockDim.x + tid;     // rows kb+nb .. nn (row nn = rhs)
+  const bool valid = i <= nn;
+  for (int c = 0; c < nb; ++c) xs[c][tid] = valid ? Sa[(long long)i * nn + kb + c] : 0.0;
+  for (int c = 0; c < nb; ++c) {
+    double sacc = xs[c][tid];
+    for (int jj = 0; jj < c; ++jj) sacc -= xs[jj][tid] * L11[c][jj];
+    xs[c][tid] = sacc / L11[c][c];
   }
-  for (int i = tid; i < nn; i += nt) pc[i] = -rhs[i];
+  if (valid) for (int c = 0; c < nb; ++c) Sa[(long long)i * nn + kb + c] = xs[c][tid];
+}
+
+// trailing update: Sa[i][j] -= sum_c P[i][c] P[j][c] for kb+nb <= j <= i <= nn (tiles of 32x32, lower part)
+__global__ __launch_bounds__(1024) void k_syrk_update(int nn, int kb, double* __restrict__ Sa) {
+  if (blockIdx.y > blockIdx.x) return;
+  __shared__ double Pi[kNB][kNB + 1];
+  __shared__ double Pj[kNB][kNB + 1];
+  const int nb = min(kNB, nn - kb);
+  const int i0 = kb + nb + blockIdx.x * kNB, j0 = kb + nb + blockIdx.y * kNB;
+  const int r = threadIdx.x / kNB, c = threadIdx.x % kNB;
+  Pi[r][c] = (i0 + r <= nn && c < nb) ? Sa[(long long)(i0 + r) * nn + kb + c] : 0.0;
+  Pj[r][c] = (j0 + r < nn && c < nb) ? Sa[(long long)(j0 + r) * nn + kb + c] : 0.0;
+  __syncthreads();
+  const int i = i0 + r, jcol = j0 + c;
+  if (i > nn || jcol >= nn || jcol > i) return;
+  double acc = 0.0;
+#pragma unroll
+  for (int k = 0; k < kNB; ++k) acc += Pi[r][k] * Pj[c][k];
+  Sa[(long long)i * nn + jcol] -= acc;
+}
+
+// backward substitution L^T x = y, one panel per launch (from the last panel to the first); y = row nn of Sa
+__global__ __launch_bounds__(256) void k_backsub_panel(int nn, int kb, double* __restrict__ Sa) {
+  __shared__ double L11[kNB][kNB + 1];
+  __shared__ double xs[kNB];
+  const int nb = min(kNB, nn - kb);
+  double* y = Sa + (long long)nn * nn;
+  for (int e = threadIdx.x; e < kNB * kNB; e += blockDim.x) {
+    const int r = e / kNB, c = e % kNB;
+    L11[r][c] = (r < nb && c < nb) ? Sa[(long long)(kb + r) * nn + kb + c] : 0.0;
+  }
+  if (threadIdx.x < kNB) xs[threadIdx.x] = threadIdx.x < nb ? y[kb + threadIdx.x] : 0.0;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = nb - 1; k >= 0; --k) {
+      double v = xs[k];
+      for (int jj = k + 1; jj < nb; ++jj) v -= L11[jj][k] * xs[jj];
+      xs[k] = v / L11[k][k];
+    }
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < nb; k += blockDim.x) y[kb + k] = xs[k];
+  for (int i = threadIdx.x; i < kb; i += blockDim.x) {
+    double v = y[i];
+    for (int c = 0; c < nb; ++c) v -= Sa[(long long)(kb + c) * nn + i] * xs[c];
+    y[i] = v;
+  }
+}
+
+__global__ void k_negate_copy(int nn, const double* __restrict__ src, double* __restrict__ dst) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nn) dst[i] = -src[i];
 }
 
 // p (x order) from p_c and p_s = -(z_g + Z_E p_c)
@@ -682,7 +735,7 @@ struct HipSchur {
     Lb = be.alloc((size_t)ne.N3 * (BW + 1));
     Z = be.alloc((size_t)ne.N3 * ncols);
     G = be.alloc((size_t)ne.CB * ncols);
-    S = be.alloc((size_t)ne.CB * ne.CB);
+    S = be.alloc((size_t)(ne.CB + 1) * ne.CB);
     rhs = be.alloc(ne.CB); pc = be.alloc(ne.CB);
     D = be.alloc(hp.n); gx = be.alloc(hp.n); px = be.alloc(hp.n);
     MVUS_HIP(hipMalloc(reinterpret_cast<void**>(&fail), sizeof(int)));
@@ -754,14 +807,16 @@ struct HipSchur {
       hipLaunchKernelGGL(k_part_solve<11>, gsolve, dim3(64), 0, be.stream, pv, ncols, Lb, Z);
       if (pv.P > 1) {
         hipLaunchKernelGGL(k_part_reduce<11>, dim3(pv.P - 1), dim3(256), 0, be.stream, pv, ncols, Lb, Z);
-        hipLaunchKernelGGL(k_sep_solve<9>, dim3(1), dim3(256), 0, be.stream, pv, ncols, Z, fail);
+        hipLaunchKernelGGL(k_sep_factor<9>, dim3(1), dim3(64), 0, be.stream, pv, fail);
+        hipLaunchKernelGGL(k_sep_rhs<9>, dim3((ncols + 63) / 64), dim3(64), 0, be.stream, pv, ncols, Z);
       }
     } else {
       hipLaunchKernelGGL(k_part_cholesky<17>, dim3(pv.P), dim3(64), 0, be.stream, pv, Lb, fail);
       hipLaunchKernelGGL(k_part_solve<17>, gsolve, dim3(64), 0, be.stream, pv, ncols, Lb, Z);
       if (pv.P > 1) {
         hipLaunchKernelGGL(k_part_reduce<17>, dim3(pv.P - 1), dim3(256), 0, be.stream, pv, ncols, Lb, Z);
-        hipLaunchKernelGGL(k_sep_solve<15>, dim3(1), dim3(256), 0, be.stream, pv, ncols, Z, fail);
+        hipLaunchKernelGGL(k_sep_factor<15>, dim3(1), dim3(64), 0, be.stream, pv, fail);
+        hipLaunchKernelGGL(k_sep_rhs<15>, dim3((ncols + 63) / 64), dim3(64), 0, be.stream, pv, ncols, Z);
       }
     }
     if (pv.P > 1) hipLaunchKernelGGL(k_part_back, dim3(pv.P, 8), dim3(256), 0, be.stream, pv, ncols, Z);
@@ -769,7 +824,19 @@ struct HipSchur {
     hipLaunchKernelGGL(k_schur_gemm, dim3((ne.CB + 15) / 16, (ncols + 15) / 16, (ne.N3 + kGemmK - 1) / kGemmK), dim3(256), 0, be.stream, ne, ncols, Z, G);
     const long long nS = (long long)ne.CB * ne.CB;
     hipLaunchKernelGGL(k_schur_finish, dim3((unsigned)((nS + 255) / 256)), dim3(256), 0, be.stream, ne, ncols, lambda, G, S, rhs);
-    hipLaunchKernelGGL(k_dense_chol_solve, dim3(1), dim3(1024), 0, be.stream, ne.CB, S, rhs, pc, fail);
+    {
+      const int nn = ne.CB;
+      for (int kb = 0; kb < nn; kb += kNB) {
+        const int nb = std::min(kNB, nn - kb), below = nn + 1 - (kb + nb);       // rows under the panel incl. the rhs row
+        hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(kNB * kNB), 0, be.stream, nn, kb, S, fail);
+        hipLaunchKernelGGL(k_trsm_panel, dim3((below + kTrsmThreads - 1) / kTrsmThreads), dim3(kTrsmThreads), 0, be.stream, nn, kb, S);
+        const int tiles = (below + kNB - 1) / kNB;
+        hipLaunchKernelGGL(k_syrk_update, dim3(tiles, tiles), dim3(kNB * kNB), 0, be.stream, nn, kb, S);
+      }
+      for (int kb = ((nn - 1) / kNB) * kNB; kb >= 0; kb -= kNB)
+        hipLaunchKernelGGL(k_backsub_panel, dim3(1), dim3(256), 0, be.stream, nn, kb, S);
+      hipLaunchKernelGGL(k_negate_copy, dim3((nn + 255) / 256), dim3(256), 0, be.stream, nn, S + (size_t)nn * nn, pc);
+    }
     MVUS_HIP(hipMemsetAsync(px, 0, be.hp.n * sizeof(double), be.stream));
     const int tot = ne.CB + ne.N3;
     hipLaunchKernelGGL(k_back_substitute, dim3((tot + kThreads - 1) / kThreads), dim3(kThreads), 0, be.stream, be.dp, ne, ncols, Z, pc, px);
@@ -777,7 +844,7 @@ struct HipSchur {
     MVUS_HIP(hipMemcpyAsync(fail_host, fail, sizeof(int), hipMemcpyDeviceToHost, be.stream));
     p.resize(be.hp.n);
     be.download(p.data(), px, be.hp.n);
-    if (*fail_host != 0) return false;
+    if (*fail_host != 0) { if (std::getenv("MVUS_DEBUG")) std::fprintf(stderr, "schur solve: fail code %d at lambda %.3e\n", *fail_host, lambda); return false; }
     for (double v : p) if (!std::isfinite(v)) return false;
     return true;
   }
