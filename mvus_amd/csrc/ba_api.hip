@@ -37,6 +37,7 @@ struct HipBackend {
   void* allreduce_user = nullptr;
   int is_root = 1;
   int64_t m_glob = 0;
+  double lm_lambda = 0;   // LM damping carried from one solve on this handle to the next
   std::string err;
 
   template <class T>
@@ -209,6 +210,8 @@ using namespace mvus;
 
 struct mvus_ba {
   HipBackend be;
+  std::unique_ptr<HipSchur<HipBackend>> schur;   // normal-equation workspace, built on first use
+  ~mvus_ba() { schur.reset(); }
 };
 
 static thread_local std::string g_create_error;
@@ -353,7 +356,10 @@ int mvus_ba_jtu(mvus_ba* h, const double* u, double* z) {
 }
 
 int mvus_ba_normal_equations(mvus_ba* h, double* g, double* JtJ_cam, double* band, double* cross, int32_t* W_out) {
-  return guarded(h, [&] { return schur_export(h->be, g, JtJ_cam, band, cross, W_out); });
+  return guarded(h, [&] {
+    if (!h->schur) h->schur.reset(new HipSchur<HipBackend>(h->be));
+    return schur_export(h->be, *h->schur, g, JtJ_cam, band, cross, W_out);
+  });
 }
 
 int mvus_ba_solve(mvus_ba* h, double* x, const mvus_solve_opts* opts, mvus_result* res, double* f_out) {
@@ -373,7 +379,13 @@ int mvus_ba_solve(mvus_ba* h, double* x, const mvus_solve_opts* opts, mvus_resul
       be.set_pattern(be.x_cur);
     }
     SolveResult sr;
-    if (opts->solver == MVUS_SOLVER_LM_SCHUR) sr = lm_schur_hip(be, xv, lb, ub, so, be.f_cur);
+    if (opts->solver == MVUS_SOLVER_LM_SCHUR) {
+      if (be.hp.C * (3 + be.hp.P) > 1152) throw HipError{"LM_SCHUR: reduced camera system larger than 1152 unknowns"};
+      if (!h->schur) h->schur.reset(new HipSchur<HipBackend>(be));
+      so.lm_lambda0 = be.lm_lambda;
+      sr = lm_schur(be, *h->schur, xv, lb, ub, so, be.f_cur);
+      if (!sr.error) be.lm_lambda = std::min(std::max(sr.lm_lambda, 1e-12), 1e6);
+    }
     else sr = trf_lsmr(be, xv, lb, ub, so, be.f_cur);
     if (sr.error) { be.err = "residuals are not finite in the initial point, or x0 is outside of the bounds"; return MVUS_E_NUMERIC; }
     std::memcpy(x, xv.data(), sizeof(double) * n);
@@ -428,8 +440,8 @@ int mvus_ba_time_kernel(mvus_ba* h, int32_t which, int32_t launches, double* avg
     hipLaunchKernelGGL(k_cam_states, dim3((be.hp.C + 63) / 64), dim3(64), 0, be.stream, be.dp, be.x_cur, be.cams);
     if (which >= 2 && !be.has_jacobian) be.jacobian(be.x_cur, be.f_cur, MVUS_JAC_ANALYTIC);
     const dim3 g(std::max(be.dp.n_chunks, 1)), b(kThreads);
-    std::unique_ptr<HipSchur<HipBackend>> schur;
-    if (which >= 4) schur.reset(new HipSchur<HipBackend>(be));
+    if (which >= 4 && !h->schur) h->schur.reset(new HipSchur<HipBackend>(be));
+    HipSchur<HipBackend>* schur = h->schur.get();
     auto launch = [&]() {
       switch (which) {
         case 0:

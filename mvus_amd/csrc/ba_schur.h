@@ -51,7 +51,7 @@ SolveResult lm_schur(B& be, Schur& sc, std::vector<double>& x, const std::vector
   sc.gradient(g);
   sc.diagonal(D);
 
-  double lambda = 1e-4, nu = 2.0;
+  double lambda = opt.lm_lambda0 > 0 ? opt.lm_lambda0 : 1e-4, nu = 2.0;
   int status = -1;
   double g_norm = 0;
   while (true) {
@@ -116,6 +116,7 @@ SolveResult lm_schur(B& be, Schur& sc, std::vector<double>& x, const std::vector
   res.status = status;
   res.cost = cost;
   res.optimality = g_norm;
+  res.lm_lambda = lambda;
   cleanup();
   return res;
 }

@@ -253,7 +253,7 @@ __global__ __launch_bounds__(64) void k_band_cholesky(int n3, double* __restrict
 // B) the separator system (block tridiagonal, blocks of 3(W-1)) is formed from short dot products;
 // C) it is solved sequentially by one workgroup (P-1 small steps, all right-hand sides in parallel);
 // D) the interiors are corrected: X_I = Y - V X_{S_{p-1}} - W X_{S_p}.
-constexpr int kPartL = 32;
+constexpr int kPartL = 64;
 constexpr int kPartRowsMax = 3 * (kPartL + 6);
 
 struct PartView {
@@ -850,19 +850,10 @@ struct HipSchur {
   }
 };
 
-template <class BE>
-SolveResult lm_schur_hip(BE& be, std::vector<double>& x, const std::vector<double>& lb, const std::vector<double>& ub,
-                         const SolveOptions& opt, double* f_dev) {
-  if (be.hp.C * (3 + be.hp.P) > 1152) throw HipError{"LM_SCHUR: reduced camera system larger than 1152 unknowns"};
-  HipSchur<BE> sc(be);
-  return lm_schur(be, sc, x, lb, ub, opt, f_dev);
-}
-
 // Gauss-Newton normal equations of the Jacobian currently held, copied out for inspection (mvus_ba_normal_equations)
 template <class BE>
-int schur_export(BE& be, double* g, double* JtJ_cam, double* band, double* cross, int32_t* W_out) {
+int schur_export(BE& be, HipSchur<BE>& sc, double* g, double* JtJ_cam, double* band, double* cross, int32_t* W_out) {
   if (!be.has_jacobian) { be.err = "no Jacobian held: call mvus_ba_residual_jacobian first"; return MVUS_E_INVALID; }
-  HipSchur<BE> sc(be);
   if (W_out) *W_out = sc.ne.W;
   if (!g && !JtJ_cam && !band && !cross) return MVUS_OK;
   sc.assemble(be, be.f_cur);

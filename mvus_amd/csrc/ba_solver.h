@@ -44,12 +44,14 @@ struct SolveOptions {
   double lsmr_atol = 1e-6, lsmr_btol = 1e-6, lsmr_conlim = 1e8;
   int lsmr_maxiter = 0;
   int verbose = 0;
+  double lm_lambda0 = 0;   // > 0: initial LM damping (a handle carries it over from its previous solve)
 };
 
 struct SolveResult {
   double cost = 0, optimality = 0, initial_cost = 0;
   int nfev = 0, njev = 0, status = 0, lin_iters = 0;
   int error = 0;  // 0 ok, -3 numeric (non-finite f0 / infeasible x0)
+  double lm_lambda = 0;  // final LM damping
 };
 
 namespace detail {
