@@ -167,9 +167,15 @@ struct HipBackend {
       }
     }
     if (hp.T > 0) {
-      const dim3 g((hp.T + kThreads - 1) / kThreads), b(kThreads);
-      if (jac) hipLaunchKernelGGL(k_motion<true>, g, b, 0, stream, dp, x, f + 2 * hp.M, mJ, mctrl, (int)masked);
-      else hipLaunchKernelGGL(k_motion<false>, g, b, 0, stream, dp, x, f + 2 * hp.M, mJ, mctrl, 0);
+      if (is_root) {
+        const dim3 g((hp.T + kThreads - 1) / kThreads), b(kThreads);
+        if (jac) hipLaunchKernelGGL(k_motion<true>, g, b, 0, stream, dp, x, f + 2 * hp.M, mJ, mctrl, (int)masked);
+        else hipLaunchKernelGGL(k_motion<false>, g, b, 0, stream, dp, x, f + 2 * hp.M, mJ, mctrl, 0);
+      } else {
+        // sharded run: the (replicated) motion rows are owned by the root rank; here they are rows of zeros
+        // (mctrl stays -1 from initialisation, so they contribute nothing to J v, J^T u or the normal equations)
+        MVUS_HIP(hipMemsetAsync(f + 2 * hp.M, 0, sizeof(double) * hp.T, stream));
+      }
     }
     MVUS_HIP(hipGetLastError());
     if (jac) has_jacobian = true;
@@ -419,8 +425,8 @@ int mvus_ba_set_allreduce(mvus_ba* h, mvus_allreduce_fn fn, void* user, int32_t 
     HipBackend& be = h->be;
     be.allreduce = fn; be.allreduce_user = user; be.is_root = is_root;
     be.m_glob = be.hp.m;
-    if (fn) {   // global row count = sum of the shards' rows
-      be.scal_host[2] = (double)be.hp.m;
+    if (fn) {   // global row count = sum of the shards' detection rows + the motion rows once
+      be.scal_host[2] = (double)(2 * be.hp.M + (is_root ? be.hp.T : 0));
       MVUS_HIP(hipMemcpyAsync(be.scal_dev + 2, be.scal_host + 2, sizeof(double), hipMemcpyHostToDevice, be.stream));
       be.reduce(be.scal_dev + 2, 1);
       be.m_glob = (int64_t)(be.read_slot(2) + 0.5);

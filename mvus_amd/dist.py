@@ -40,12 +40,11 @@ def sharded_handle(prob, rank, world, device_index, group=None):
 
     The handle runs on torch's current stream of that device so that its kernels and the collective are
     ordered without extra events.  Motion-regulariser rows are replicated inputs but must be counted
-    once: rank 0 keeps them, the other shards drop them."""
+    once: every shard keeps the same layout and `is_root` tells the library which rank evaluates them."""
     import torch
     torch.cuda.set_device(device_index)
-    shard, keep = prob.shard(rank, world)
-    if rank != 0:
-        shard.motion_reg = False
+    shard, keep = prob.shard(rank, world)       # motion samples stay in every shard (same layout on all ranks);
+                                                # the library evaluates them on the root rank only (is_root)
     stream = torch.cuda.current_stream(device_index).cuda_stream
     h = BAHandle(shard, device=device_index, stream=stream)
     if world > 1 or group is not None:

@@ -37,3 +37,64 @@ def test_allreduce_hook_with_rccl_world1():
         h.close()
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('solver', ['trf', 'lm'])
+@pytest.mark.parametrize('case', ['rs_F_2int_3cam', 'calib_KE_bounds_3cam'])
+def test_two_shards_on_one_gpu_match_unsharded(solver, case):
+    """Two observation shards (rank 0 = root owning the motion rows, rank 1) driven by two host threads on the
+    one test GPU, with an in-process sum standing in for RCCL: the sharded solve must reproduce the unsharded one."""
+    import threading
+    import torch
+    from mvus_amd.ba import BAHandle
+    from mvus_amd.dist import _DeviceDoubles
+    scene, g = load_case(case)
+    prob, x0 = mp.problem_from_scene(scene)
+    if solver == 'trf':
+        opts = _lib.default_opts(_lib.SOLVER_TRF_LSMR, _lib.JAC_PATTERN, 6)
+        opts.lsmr_maxiter = 4
+    else:
+        opts = _lib.default_opts(_lib.SOLVER_LM_SCHUR, _lib.JAC_ANALYTIC, 5)
+    with BAHandle(prob) as h0:
+        ref = h0.solve(g['x0'], opts=opts)
+
+    world = 2
+    barrier = threading.Barrier(world)
+    bufs, total, results, errors = [None] * world, [None], [None] * world, []
+
+    def make_cb(rank):
+        def cb(ptr, count, stream):
+            t = torch.as_tensor(_DeviceDoubles(ptr, count), device='cuda:0')
+            torch.cuda.synchronize()
+            bufs[rank] = t
+            barrier.wait()
+            if rank == 0:
+                total[0] = bufs[0] + bufs[1]
+                torch.cuda.synchronize()
+            barrier.wait()
+            t.copy_(total[0])
+            torch.cuda.synchronize()
+            barrier.wait()
+        return cb
+
+    def run(rank):
+        try:
+            shard, keep = prob.shard(rank, world)
+            h = BAHandle(shard, device=0)
+            h.set_allreduce(make_cb(rank), is_root=(rank == 0))
+            results[rank] = h.solve(g['x0'], opts=opts)
+            h.close()
+        except Exception as e:                      # pragma: no cover
+            errors.append(e)
+            barrier.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in threads]
+    [t.join(120) for t in threads]
+    assert not errors, errors
+    for r in range(world):
+        res = results[r]
+        assert (res.nfev, res.njev, res.status) == (ref.nfev, ref.njev, ref.status)
+        np.testing.assert_allclose(res.cost, ref.cost, rtol=1e-9)
+        np.testing.assert_allclose(res.x, ref.x, rtol=0, atol=1e-7 * max(1.0, np.abs(ref.x).max()))
+    np.testing.assert_array_equal(results[0].x, results[1].x)        # ranks stay in lockstep bit for bit
