@@ -73,8 +73,9 @@ def main():
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--config', type=int, default=2, help='index into BASELINE.json configs (2 = 32 cams x 500k obs)')
-    ap.add_argument('--solver', choices=['trf', 'lm'], default=os.environ.get('MVUS_BENCH_SOLVER', 'trf'))
+    ap.add_argument('--solver', choices=['trf', 'lm'], default=os.environ.get('MVUS_BENCH_SOLVER', 'lm'))
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-parity-solver', action='store_true', help='skip the extra timing of the scipy-TRF+LSMR restatement')
     args = ap.parse_args()
 
     import numpy as np
@@ -146,6 +147,29 @@ def main():
     bytes_launch = handle.prob.M * per_obs + once
     achieved = bytes_launch / (t_rj * 1e-3) / 1e9
 
+    # the reference-faithful solver (scipy TRF + LSMR restated) on the same workload, a few steps, for the record
+    parity = None
+    if not args.no_parity_solver and args.solver == 'lm':
+        xs = x0.copy()
+        handle.solve(xs, solver=ba.SOLVER_TRF_LSMR, jac_mode=ba.JAC_PATTERN, max_nfev=2, return_fun=False)
+        barrier()
+        tp = time.perf_counter()
+        nsteps, its = 3, 0
+        for _ in range(nsteps):
+            rp = handle.solve(xs, solver=ba.SOLVER_TRF_LSMR, jac_mode=ba.JAC_PATTERN, max_nfev=2, return_fun=False)
+            xs = rp.x
+            its += rp.lin_iters
+        barrier()
+        dtp = time.perf_counter() - tp
+        parity = {'solver': 'trf_lsmr (scipy restatement, pattern-masked J)', 'ms_per_step': 1e3 * dtp / nsteps,
+                  'ba_iters_per_sec': nsteps / dtp, 'residuals_per_sec': prob.M * nsteps / dtp, 'lsmr_its_per_step': its / nsteps}
+
+    traffic = None
+    tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    if os.path.exists(tpath):
+        key = 'config%d_calib%d' % (args.config, int(prob.opt_calib))
+        traffic = json.load(open(tpath)).get(key, {}).get('bytes_per_launch')
+
     if rank == 0:
         M_total = prob.M
         out = {
@@ -164,8 +188,9 @@ def main():
                        'cost_first': cost0, 'cost_last': r.cost},
             'roofline': {'bound': 'hbm', 'kernel': 'k_observations<calib=%s,jac=true>' % ('true' if prob.opt_calib else 'false'),
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': None, 'bytes_per_launch': bytes_launch, 'avg_launch_ms': t_rj,
+                         'traffic': traffic, 'bytes_per_launch': bytes_launch, 'avg_launch_ms': t_rj,
                          'bytes_per_obs': per_obs, 'obs_per_launch': handle.prob.M},
+            'parity_solver': parity,
             'kernels_ms': {'residual': t_r, 'residual_jacobian': t_rj, 'jv': t_jv, 'jtu': t_jtu, 'normal_eq_assembly': t_asm},
         }
         if world == 1 and not args.no_cpu_baseline:
