@@ -48,6 +48,9 @@ extern "C" {
 #define MVUS_JAC_ANALYTIC 0 /* full analytic block-sparse Jacobian */
 #define MVUS_JAC_PATTERN 1  /* analytic, masked to the reference sparsity pattern jac_BA builds at x0
                                (3 nearest knots per row, common.py:559-563,573-585) */
+#define MVUS_JAC_FD 2       /* scipy's own estimate: sparse 2-point forward differences over that pattern, columns
+                               perturbed group-wise (scipy/optimize/_numdiff.py:628-700), one residual launch per
+                               group.  Needs mvus_ba_set_fd_groups. */
 
 /* Solver used by mvus_ba_solve */
 #define MVUS_SOLVER_TRF_LSMR 0 /* restatement of scipy trf + lsmr (the reference's optimiser), J kept as operator */
@@ -140,6 +143,10 @@ int mvus_ba_motion_rows(mvus_ba* h, const double* x, int32_t jac_mode, double* m
 /* Fix the reference sparsity pattern at x0 (jac_BA + compute_visibility, common.py:427-438,490-610):
  * pat[M] = global index of the first of the three in-pattern control points, -1 for all-zero rows. */
 int mvus_ba_set_pattern(mvus_ba* h, const double* x0, int32_t* pat_out);
+
+/* Column groups for MVUS_JAC_FD: groups[n] in [0, num_groups), two columns share a group only if no row of the
+ * reference pattern contains both (scipy.optimize._numdiff.group_columns on jac_BA's matrix). */
+int mvus_ba_set_fd_groups(mvus_ba* h, const int32_t* groups, int32_t num_groups);
 
 /* y[m] = J v (v[n]);  z[n] = J^T u (u[m]) with the Jacobian currently held by the handle
  * (after mvus_ba_residual_jacobian / inside solve).  Test and integration hooks for the operator. */

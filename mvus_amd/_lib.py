@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, 'csrc', 'libmvusba.so')
 
 MVUS_OK = 0
 MVUS_E_INVALID, MVUS_E_HIP, MVUS_E_NUMERIC, MVUS_E_COMM = -1, -2, -3, -4
-JAC_ANALYTIC, JAC_PATTERN = 0, 1
+JAC_ANALYTIC, JAC_PATTERN, JAC_FD = 0, 1, 2
 SOLVER_TRF_LSMR, SOLVER_LM_SCHUR = 0, 1
 
 c_double_p = ctypes.POINTER(ctypes.c_double)
@@ -67,6 +67,7 @@ API = [
     ('mvus_ba_residual_jacobian', ctypes.c_int, [ctypes.c_void_p, c_double_p, ctypes.c_int32, c_double_p, c_double_p, c_int32_p]),
     ('mvus_ba_motion_rows', ctypes.c_int, [ctypes.c_void_p, c_double_p, ctypes.c_int32, c_double_p, c_double_p, c_int32_p]),
     ('mvus_ba_set_pattern', ctypes.c_int, [ctypes.c_void_p, c_double_p, c_int32_p]),
+    ('mvus_ba_set_fd_groups', ctypes.c_int, [ctypes.c_void_p, c_int32_p, ctypes.c_int32]),
     ('mvus_ba_jv', ctypes.c_int, [ctypes.c_void_p, c_double_p, c_double_p]),
     ('mvus_ba_jtu', ctypes.c_int, [ctypes.c_void_p, c_double_p, c_double_p]),
     ('mvus_ba_normal_equations', ctypes.c_int, [ctypes.c_void_p, c_double_p, c_double_p, c_double_p, c_double_p, c_int32_p]),

@@ -11,7 +11,7 @@ from types import SimpleNamespace
 import numpy as np
 
 from . import _lib
-from ._lib import JAC_ANALYTIC, JAC_PATTERN, SOLVER_LM_SCHUR, SOLVER_TRF_LSMR  # noqa: F401 (re-exported)
+from ._lib import JAC_ANALYTIC, JAC_FD, JAC_PATTERN, SOLVER_LM_SCHUR, SOLVER_TRF_LSMR  # noqa: F401 (re-exported)
 
 _ERRORS = {_lib.MVUS_E_INVALID: ValueError, _lib.MVUS_E_NUMERIC: ValueError, _lib.MVUS_E_HIP: RuntimeError,
            _lib.MVUS_E_COMM: RuntimeError}
@@ -93,6 +93,21 @@ class BAHandle:
         self._check(self.lib.mvus_ba_set_pattern(self.h, _lib.dptr(x0), pat.ctypes.data_as(_lib.c_int32_p)), 'mvus_ba_set_pattern')
         return pat
 
+    def set_fd_groups(self, groups, num_groups):
+        groups = np.ascontiguousarray(groups, dtype=np.int32)
+        if groups.shape != (self.n,):
+            raise ValueError('groups has shape %s, expected (%d,)' % (groups.shape, self.n))
+        self._check(self.lib.mvus_ba_set_fd_groups(self.h, groups.ctypes.data_as(_lib.c_int32_p), int(num_groups)),
+                    'mvus_ba_set_fd_groups')
+
+    def prepare_fd(self, x0):
+        """Set-up for JAC_FD at x0: the reference pattern on the GPU, scipy's column grouping on the host."""
+        from . import pattern
+        pat = self.set_pattern(x0)
+        groups, ng = pattern.fd_groups(self.prob, pat)
+        self.set_fd_groups(groups, ng)
+        return ng
+
     def jv(self, v):
         v = self._x(v, self.n)
         y = np.empty(self.m)
@@ -123,6 +138,8 @@ class BAHandle:
         (x, cost, fun, nfev, njev, status, optimality, ...)."""
         x = np.array(self._x(x0, self.n))
         o = opts if opts is not None else _lib.default_opts(solver, jac_mode, max_nfev)
+        if o.jac_mode == JAC_FD:
+            self.prepare_fd(x)
         res = _lib.MvusResult()
         f = np.empty(self.m) if return_fun else None
         self._check(self.lib.mvus_ba_solve(self.h, _lib.dptr(x), ctypes.byref(o), ctypes.byref(res),

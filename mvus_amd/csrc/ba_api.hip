@@ -38,6 +38,10 @@ struct HipBackend {
   int is_root = 1;
   int64_t m_glob = 0;
   double lm_lambda = 0;   // LM damping carried from one solve on this handle to the next
+  // MVUS_JAC_FD
+  int32_t* fd_groups = nullptr;
+  int fd_ngroups = 0;
+  double *fd_F = nullptr, *fd_h = nullptr, *fd_dx = nullptr, *fd_xg = nullptr;
   std::string err;
 
   template <class T>
@@ -60,7 +64,7 @@ struct HipBackend {
     if (p->stream) stream = static_cast<hipStream_t>(p->stream);
     else { MVUS_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking)); own_stream = true; }
     dp.C = hp.C; dp.P = hp.P; dp.NS = hp.NS; dp.S = hp.S; dp.calib = hp.calib; dp.undist = hp.undist;
-    dp.rs_free = hp.rs_free; dp.T = hp.T; dp.M = hp.M;
+    dp.rs_free = hp.rs_free; dp.T = hp.T; dp.M = hp.M; dp.N = hp.N;
     dp.frame = dupload(hp.frame); dp.u_raw = dupload(hp.u_raw); dp.v_raw = dupload(hp.v_raw);
     dp.H = dupload(hp.H); dp.Kfix = dupload(hp.K); dp.dfix = dupload(hp.dist);
     dp.sp.S = hp.S; dp.sp.istart = dupload(hp.istart); dp.sp.iend = dupload(hp.iend); dp.sp.knots = dupload(hp.knots);
@@ -181,7 +185,37 @@ struct HipBackend {
     if (jac) has_jacobian = true;
   }
   void residual(const double* x, double* f) { eval(x, f, false, 0); }
-  void jacobian(const double* x, double* f, int jac_mode) { eval(x, f, true, jac_mode); }
+  void jacobian(const double* x, double* f, int jac_mode) {
+    if (jac_mode == MVUS_JAC_FD) jacobian_fd(x, f); else eval(x, f, true, jac_mode);
+  }
+
+  void set_fd_groups(const int32_t* groups, int ngroups) {
+    if (!fd_groups) { fd_groups = dalloc<int32_t>(hp.n); fd_h = dalloc<double>(hp.n); fd_dx = dalloc<double>(hp.n); fd_xg = dalloc<double>(hp.n); }
+    MVUS_HIP(hipMemcpyAsync(fd_groups, groups, sizeof(int32_t) * hp.n, hipMemcpyHostToDevice, stream));
+    MVUS_HIP(hipStreamSynchronize(stream));
+    if (ngroups > fd_ngroups || !fd_F) { fd_F = dalloc<double>((size_t)ngroups * hp.m); }
+    fd_ngroups = ngroups;
+  }
+  // scipy's approx_derivative(..., method='2-point', sparsity=(pattern, groups)): one residual per column group
+  void jacobian_fd(const double* x, double* f) {
+    if (!has_pattern || fd_ngroups <= 0) throw HipError{"MVUS_JAC_FD needs mvus_ba_set_pattern and mvus_ba_set_fd_groups first"};
+    const int n = (int)hp.n;
+    eval(x, f, false, 0);
+    hipLaunchKernelGGL(k_fd_steps, dim3((n + 255) / 256), dim3(256), 0, stream, n, hp.C, hp.rs_bounds, x, fd_h, fd_dx);
+    for (int g = 0; g < fd_ngroups; ++g) {
+      hipLaunchKernelGGL(k_fd_perturb, dim3((n + 255) / 256), dim3(256), 0, stream, n, g, x, fd_h, fd_groups, fd_xg);
+      eval(fd_xg, fd_F + (size_t)g * hp.m, false, 0);
+    }
+    if (dp.n_chunks > 0) {
+      if (hp.calib) hipLaunchKernelGGL(k_fd_fill<30>, dim3(dp.n_chunks), dim3(kThreads), 0, stream, dp, (long long)hp.m, f, fd_F, fd_dx, fd_groups, pat0, J, span);
+      else hipLaunchKernelGGL(k_fd_fill<21>, dim3(dp.n_chunks), dim3(kThreads), 0, stream, dp, (long long)hp.m, f, fd_F, fd_dx, fd_groups, pat0, J, span);
+    }
+    if (hp.T > 0) {
+      if (is_root) hipLaunchKernelGGL(k_fd_fill_motion, dim3((hp.T + kThreads - 1) / kThreads), dim3(kThreads), 0, stream, dp, (long long)hp.m, f, fd_F, fd_dx, fd_groups, mJ, mctrl);
+    }
+    MVUS_HIP(hipGetLastError());
+    has_jacobian = true;
+  }
 
   void set_pattern(const double* x0_dev) {
     hipLaunchKernelGGL(k_cam_states, dim3((hp.C + 63) / 64), dim3(64), 0, stream, dp, x0_dev, cams);
@@ -335,6 +369,15 @@ int mvus_ba_set_pattern(mvus_ba* h, const double* x0, int32_t* pat_out) {
   });
 }
 
+int mvus_ba_set_fd_groups(mvus_ba* h, const int32_t* groups, int32_t num_groups) {
+  return guarded(h, [&] {
+    if (!groups || num_groups < 1) { h->be.err = "bad arguments"; return MVUS_E_INVALID; }
+    for (int64_t j = 0; j < h->be.hp.n; ++j) if (groups[j] < 0 || groups[j] >= num_groups) { h->be.err = "group index out of range"; return MVUS_E_INVALID; }
+    h->be.set_fd_groups(groups, num_groups);
+    return MVUS_OK;
+  });
+}
+
 int mvus_ba_jv(mvus_ba* h, const double* v, double* y) {
   return guarded(h, [&] {
     HipBackend& be = h->be;
@@ -383,6 +426,10 @@ int mvus_ba_solve(mvus_ba* h, double* x, const mvus_solve_opts* opts, mvus_resul
     if (so.jac_mode == MVUS_JAC_PATTERN) {
       be.upload(be.x_cur, xv.data(), n);
       be.set_pattern(be.x_cur);
+    }
+    if (so.jac_mode == MVUS_JAC_FD && (!be.has_pattern || be.fd_ngroups <= 0)) {
+      be.err = "MVUS_JAC_FD: call mvus_ba_set_pattern(x0) and mvus_ba_set_fd_groups first";
+      return MVUS_E_INVALID;
     }
     SolveResult sr;
     if (opts->solver == MVUS_SOLVER_LM_SCHUR) {

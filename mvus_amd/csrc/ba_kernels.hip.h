@@ -32,7 +32,7 @@ struct HipError { std::string msg; };
   } while (0)
 
 struct DevProblem {  // trivially copyable: passed to kernels by value
-  int C, P, NS, S, calib, undist, rs_free, T;
+  int C, P, NS, S, calib, undist, rs_free, T, N;
   long long M;
   const double *frame, *u_raw, *v_raw, *u_obs, *v_obs, *H, *Kfix, *dfix;
   SplineView sp;
@@ -315,6 +315,78 @@ __global__ __launch_bounds__(kThreads) void k_dot_final(int nb, const double* __
     for (int w = 0; w < kThreads / 64; ++w) t += red[w];
     *out = t;
   }
+}
+
+// ---- MVUS_JAC_FD: scipy's sparse 2-point differences (scipy/optimize/_numdiff.py:628-700) ----------------
+// steps: h_j and dx_j = (x_j + h_j) - x_j ; bounds are [0,1] on the rs block when rs_bounds, else infinite
+__global__ void k_fd_steps(int n, int C, int rs_bounds, const double* __restrict__ x, double* __restrict__ h, double* __restrict__ dx) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const bool bounded = rs_bounds && j >= 2 * C && j < 3 * C;
+  const double hj = fd_step(x[j], bounded ? 0.0 : -INFINITY, bounded ? 1.0 : INFINITY);
+  h[j] = hj;
+  dx[j] = (x[j] + hj) - x[j];
+}
+__global__ void k_fd_perturb(int n, int g, const double* __restrict__ x, const double* __restrict__ h, const int32_t* __restrict__ groups,
+                             double* __restrict__ xg) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < n) xg[j] = groups[j] == g ? x[j] + h[j] : x[j];
+}
+// J[i, j] = (f(x + h_group(j))[i] - f(x)[i]) / dx_j for (i, j) in the reference pattern; F[g*m + row]
+template <int NS>
+__global__ __launch_bounds__(kThreads) void k_fd_fill(DevProblem dp, long long m, const double* __restrict__ f0, const double* __restrict__ F,
+                                                      const double* __restrict__ dx, const int32_t* __restrict__ groups,
+                                                      const int32_t* __restrict__ pat0, double* __restrict__ J, int32_t* __restrict__ span) {
+  constexpr int B = NS - 12;
+  const int chunk = blockIdx.x;
+  const int c = dp.chunk_cam[chunk];
+  if ((int)threadIdx.x >= dp.chunk_count[chunk]) return;
+  const long long i = dp.chunk_start[chunk] + threadIdx.x;
+  const long long a = dp.det_off[c], Mc = dp.det_off[c + 1] - a;
+  const long long rx = 2 * a + (i - a), ry = rx + Mc;
+  const int p = pat0[i];
+  span[i] = p;
+  if (p < 0) return;
+  const double fx = f0[rx], fy = f0[ry];
+  // the row stores 4 consecutive control points base..base+3; the pattern triple p..p+2 sits at offset p-base
+  // (base = p unless the triple ends the spline, where a 4th point p+3 does not exist)
+  const bool room = (p + 3 < dp.N) && (dp.mv.ctrl_x0[p + 3] == dp.mv.ctrl_x0[p] + 3);
+  const int base = room ? p : p - 1, off = p - base;
+  span[i] = base;
+  const int x0 = dp.mv.ctrl_x0[base], st = dp.mv.ctrl_stride[base];
+  for (int k = 0; k < NS; ++k) {
+    int col = -1;
+    if (k < B) { if (!(k == 2 && !dp.rs_free)) col = cam_col(dp.C, dp.P, c, k); }
+    else { const int q = (k - B) / 3, d = (k - B) % 3; if (q >= off && q < off + 3) col = x0 + q + d * st; }
+    double jx = 0.0, jy = 0.0;
+    if (col >= 0) {
+      const double* Fg = F + (long long)groups[col] * m;
+      jx = (Fg[rx] - fx) / dx[col];
+      jy = (Fg[ry] - fy) / dx[col];
+    }
+    J[(long long)k * dp.M + i] = jx;
+    J[(long long)(NS + k) * dp.M + i] = jy;
+  }
+}
+__global__ __launch_bounds__(kThreads) void k_fd_fill_motion(DevProblem dp, long long m, const double* __restrict__ f0, const double* __restrict__ F,
+                                                             const double* __restrict__ dx, const int32_t* __restrict__ groups,
+                                                             double* __restrict__ mJ, int32_t* __restrict__ mctrl) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= dp.T) return;
+  for (int k = 0; k < 36; ++k) mJ[(long long)k * dp.T + j] = 0.0;
+  mctrl[j] = -1; mctrl[(long long)2 * dp.T + j] = -1;
+  if (dp.mv.part[j] < 0) { mctrl[(long long)dp.T + j] = -1; return; }     // row is identically zero
+  const int pc = dp.mv.ctrl[j] + dp.mv.pat[j];
+  const bool room = (pc + 3 < dp.N) && (dp.mv.ctrl_x0[pc + 3] == dp.mv.ctrl_x0[pc] + 3);
+  const int base = room ? pc : pc - 1, off = pc - base;
+  mctrl[(long long)dp.T + j] = base;
+  const long long row = 2 * dp.M + j;
+  const int x0 = dp.mv.ctrl_x0[base], st = dp.mv.ctrl_stride[base];
+  for (int q = off; q < off + 3; ++q)
+    for (int d = 0; d < 3; ++d) {
+      const int col = x0 + q + d * st;
+      mJ[(long long)(12 + 3 * q + d) * dp.T + j] = (F[(long long)groups[col] * m + row] - f0[row]) / dx[col];
+    }
 }
 
 }  // namespace mvus

@@ -448,4 +448,18 @@ MVUS_HD double eval_motion_row(const MotionView& mv, const double* x, int j, boo
   return row;
 }
 
+// scipy 2-point step for one variable (scipy/optimize/_numdiff.py:146-192, :13-90 with scheme '1-sided', num_steps 1):
+// h = sqrt(eps) * sign(x) * max(1, |x|), flipped / shrunk so that x + h stays inside [lb, ub].
+MVUS_HD double fd_step(double x, double lb, double ub) {
+  const double rstep = 1.4901161193847656e-08;   // sqrt(2.220446049250313e-16)
+  double h = rstep * (x >= 0.0 ? 1.0 : -1.0) * fmax(1.0, fabs(x));
+  if (lb == -INFINITY && ub == INFINITY) return h;
+  const double lower = x - lb, upper = ub - x, xn = x + h;
+  const bool violated = (xn < lb) || (xn > ub);
+  const bool fitting = fabs(h) <= fmax(lower, upper);
+  if (violated && fitting) h = -h;
+  if (!fitting) h = (upper >= lower) ? upper : -lower;
+  return h;
+}
+
 }  // namespace mvus

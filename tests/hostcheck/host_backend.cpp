@@ -24,6 +24,8 @@ struct HostBackend {
   std::vector<double> J, mJ, u_obs, v_obs;
   std::vector<int32_t> span, pat0, mctrl;
   bool has_pattern = false;
+  std::vector<int32_t> fd_groups;
+  int fd_ngroups = 0;
 
   int64_t n() const { return hp.n; }
   int64_t m_local() const { return hp.m; }
@@ -95,7 +97,61 @@ struct HostBackend {
     }
   }
   void residual(const double* x, double* f) { eval<false>(x, f, 0); }
-  void jacobian(const double* x, double* f, int jac_mode) { eval<true>(x, f, jac_mode); }
+  void jacobian(const double* x, double* f, int jac_mode) {
+    if (jac_mode == MVUS_JAC_FD) jacobian_fd(x, f); else eval<true>(x, f, jac_mode);
+  }
+  void jacobian_fd(const double* x, double* f) {
+    const int64_t n = hp.n, m = hp.m;
+    const int NS = hp.NS, B = 3 + hp.P;
+    eval<false>(x, f, 0);
+    std::vector<double> h(n), dx(n), xg(n), F((size_t)fd_ngroups * m);
+    for (int64_t j = 0; j < n; ++j) {
+      const bool bounded = hp.rs_bounds && j >= 2 * hp.C && j < 3 * hp.C;
+      h[j] = fd_step(x[j], bounded ? 0.0 : -INFINITY, bounded ? 1.0 : INFINITY);
+      dx[j] = (x[j] + h[j]) - x[j];
+    }
+    for (int g = 0; g < fd_ngroups; ++g) {
+      for (int64_t j = 0; j < n; ++j) xg[j] = fd_groups[j] == g ? x[j] + h[j] : x[j];
+      eval<false>(xg.data(), &F[(size_t)g * m], 0);
+    }
+    for (int c = 0; c < hp.C; ++c) {
+      const int64_t a = hp.det_off[c], Mc = hp.det_off[c + 1] - a;
+      for (int64_t i = a; i < a + Mc; ++i) {
+        const int p = pat0[i];
+        int base = p, off = 0;
+        if (p >= 0) {
+          const bool room = (p + 3 < hp.N) && (hp.ctrl_x0[p + 3] == hp.ctrl_x0[p] + 3);
+          base = room ? p : p - 1; off = p - base;
+        }
+        span[i] = base;
+        const int64_t rx = 2 * a + (i - a), ry = rx + Mc;
+        for (int k = 0; k < NS; ++k) {
+          int col = -1;
+          if (p >= 0) {
+            if (k < B) { if (!(k == 2 && !hp.rs_free)) col = col_of(c, k); }
+            else { const int q = (k - B) / 3, d = (k - B) % 3; if (q >= off && q < off + 3) col = hp.ctrl_x0[base] + q + d * hp.ctrl_stride[base]; }
+          }
+          J[(size_t)k * hp.M + i] = col >= 0 ? (F[(size_t)fd_groups[col] * m + rx] - f[rx]) / dx[col] : 0.0;
+          J[(size_t)(NS + k) * hp.M + i] = col >= 0 ? (F[(size_t)fd_groups[col] * m + ry] - f[ry]) / dx[col] : 0.0;
+        }
+      }
+    }
+    for (int j = 0; j < hp.T; ++j) {
+      for (int k = 0; k < 36; ++k) mJ[(size_t)k * hp.T + j] = 0.0;
+      mctrl[j] = -1; mctrl[(size_t)2 * hp.T + j] = -1; mctrl[(size_t)hp.T + j] = -1;
+      if (hp.ms_part[j] < 0) continue;
+      const int pc = hp.ms_ctrl[j] + hp.ms_pat[j];
+      const bool room = (pc + 3 < hp.N) && (hp.ctrl_x0[pc + 3] == hp.ctrl_x0[pc] + 3);
+      const int base = room ? pc : pc - 1, off = pc - base;
+      mctrl[(size_t)hp.T + j] = base;
+      const int64_t row = 2 * hp.M + j;
+      for (int q = off; q < off + 3; ++q)
+        for (int d = 0; d < 3; ++d) {
+          const int col = hp.ctrl_x0[base] + q + d * hp.ctrl_stride[base];
+          mJ[(size_t)(12 + 3 * q + d) * hp.T + j] = (F[(size_t)fd_groups[col] * m + row] - f[row]) / dx[col];
+        }
+    }
+  }
 
   void set_pattern(const double* x0) {
     const SplineView sp = hp.spline_view();
@@ -208,6 +264,13 @@ int hostcheck_dense_jacobian(void* h, const double* x, int jac_mode, double* f, 
     e[j] = 0.0;
     for (int64_t i = 0; i < m; ++i) Jd[i * n + j] = col[i];
   }
+  return 0;
+}
+
+int hostcheck_set_fd_groups(void* h, const int32_t* groups, int ngroups) {
+  HostBackend* be = static_cast<HostBackend*>(h);
+  be->fd_groups.assign(groups, groups + be->hp.n);
+  be->fd_ngroups = ngroups;
   return 0;
 }
 

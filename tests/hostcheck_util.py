@@ -37,6 +37,7 @@ def load():
     lib.hostcheck_residual.argtypes = [ctypes.c_void_p, _lib.c_double_p, _lib.c_double_p]
     lib.hostcheck_set_pattern.argtypes = [ctypes.c_void_p, _lib.c_double_p, _lib.c_int32_p]
     lib.hostcheck_dense_jacobian.argtypes = [ctypes.c_void_p, _lib.c_double_p, ctypes.c_int, _lib.c_double_p, _lib.c_double_p]
+    lib.hostcheck_set_fd_groups.argtypes = [ctypes.c_void_p, _lib.c_int32_p, ctypes.c_int]
     lib.hostcheck_jtu.argtypes = [ctypes.c_void_p, _lib.c_double_p, _lib.c_double_p]
     lib.hostcheck_solve.argtypes = [ctypes.c_void_p, _lib.c_double_p, ctypes.POINTER(_lib.MvusSolveOpts),
                                     ctypes.POINTER(_lib.MvusResult), _lib.c_double_p]
@@ -78,6 +79,14 @@ class HostHandle:
         self.lib.hostcheck_set_pattern(self.h, _lib.dptr(x0), pat.ctypes.data_as(_lib.c_int32_p))
         return pat
 
+    def prepare_fd(self, x0):
+        from mvus_amd import pattern
+        pat = self.set_pattern(x0)
+        groups, ng = pattern.fd_groups(self.prob, pat)
+        self._groups = np.ascontiguousarray(groups, dtype=np.int32)
+        self.lib.hostcheck_set_fd_groups(self.h, self._groups.ctypes.data_as(_lib.c_int32_p), ng)
+        return pat, self._groups, ng
+
     def dense_jacobian(self, x, jac_mode):
         x = np.ascontiguousarray(x, dtype=np.float64)
         f = np.zeros(self.m)
@@ -93,6 +102,8 @@ class HostHandle:
 
     def solve(self, x0, opts):
         x = np.array(x0, dtype=np.float64)
+        if opts.jac_mode == _lib.JAC_FD:
+            self.prepare_fd(x)
         res = _lib.MvusResult()
         f = np.zeros(self.m)
         rc = self.lib.hostcheck_solve(self.h, _lib.dptr(x), ctypes.byref(opts), ctypes.byref(res), _lib.dptr(f))

@@ -237,3 +237,45 @@ def test_full_size_properties(BAHandle):
         ex = np.concatenate([f1[2 * a:2 * a + (b - a)] for a, b in zip(off[:-1], off[1:])])
         ey = np.concatenate([f1[2 * a + (b - a):2 * b] for a, b in zip(off[:-1], off[1:])])
         assert np.array_equal(keep, np.sqrt(ex ** 2 + ey ** 2) < 10.0)
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_fd_jacobian_gpu_vs_host_and_scipy(BAHandle, name):
+    """MVUS_JAC_FD: grouped forward differences on the GPU = the host build = scipy's approx_derivative."""
+    from mvus_amd import pattern
+    scene, g = load_case(name)
+    prob, _ = mp.problem_from_scene(scene)
+    hh = _host(prob)
+    pat, groups, ng = hh.prepare_fd(g['x0'])
+    x = g['x0'] + g['delta']
+    if prob.rs_bounds:
+        x[2 * prob.C:3 * prob.C] = np.clip(x[2 * prob.C:3 * prob.C], 0.0, 1.0)
+    f_ref, D_ref = hh.dense_jacobian(x, _lib.JAC_FD)
+    with BAHandle(prob) as h:
+        assert h.prepare_fd(g['x0']) == ng
+        f, J, ctrl = h.residual_jacobian(x, _lib.JAC_FD)
+        mf, mJ, mctrl = h.motion_rows(x, _lib.JAC_FD)
+    D = slots_to_dense(prob, J, ctrl, mJ if prob.motion_reg else None, mctrl if prob.motion_reg else None)
+    scale = np.maximum(np.abs(D_ref).max(axis=0), 1e-12)
+    # both divide differences of residuals that agree to ~1e-13 px by h ~ 1.5e-8: the quotient agrees to ~1e-5
+    # (per column the noise floor is ~1e-13 px / 1.5e-8 = 1e-5 absolute; weak columns such as k3 have small scale)
+    assert np.max(np.abs(D - D_ref) / np.maximum(scale, 1e-2 * np.abs(D_ref).max())) < 1e-3
+    assert np.quantile(np.abs(D - D_ref) / scale, 0.999) < 1e-2
+    A = pattern.reference_pattern(prob, pat)
+    assert not D[A.toarray() == 0].any()                      # nothing outside the reference pattern
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_fd_mode_ba_vs_reference_result(BAHandle, name):
+    """The reference's own algorithm end to end on the GPU (scipy TRF + LSMR + grouped 2-point differences)."""
+    scene, g = load_case(name)
+    prob, _ = mp.problem_from_scene(scene)
+    oprob, _ = orc.problem_from_scene(scene)
+    with BAHandle(prob) as h:
+        r = h.solve(g['x0'], solver=_lib.SOLVER_TRF_LSMR, jac_mode=_lib.JAC_FD, max_nfev=10)
+        keep = h.outlier_mask(r.x, float(g['thres_outlier']))
+    assert r.nfev == int(g['ba10_nfev'])
+    assert r.cost < float(g['ba10_cost']) * (1 + 5e-3)
+    assert abs(r.cost - float(g['ba10_cost'])) < 5e-2 * float(g['ba10_cost'])
+    assert abs(orc.reprojection_rmse(oprob, r.x) - float(g['ba10_rmse'])) < 0.2
+    assert np.mean(keep.astype(np.uint8) == g['outlier_keep']) >= 0.96
