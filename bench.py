@@ -12,8 +12,8 @@ per step only the n-vector x crosses PCIe).  BA iterations/s is r
 
 Workload at N=1: BASELINE.json configs[2] ("synthetic 32 cams x 500k obs, RS on, ~5k spline knots"), the
 configuration the north star quotes its HBM target on; configs[1] (7 cams x 100k) via ``--config 1``.
-For N>1 the observation count grows with N (weak scaling: ~500k observations per GPU, cameras and
-spline fixed) and observations are sharded over the ranks with one RCCL all-reduce per J^T u / dot product.
+For N>1 the observation count grows with N (weak scaling: ~500k observations per GPU; cameras and
+spline knots fixed, so the timeline gets denser) and observations are sharded over the ranks with one RCCL all-reduce per J^T u / dot product.
 
 The JSON line also carries the roofline of the dominant kernel (residual+Jacobian), measured with
 HIP events on the kernel's own stream, and a CPU baseline (the oracle's restatement of the scipy path,
@@ -101,9 +101,8 @@ def main():
 
     kw = dict(synth.BASELINE_CONFIGS[args.config])
     per_gpu_obs = kw['total_obs']
-    kw['total_obs'] = per_gpu_obs * world                      # weak scaling: fixed work per GPU
-    if kw.get('num_knots'):
-        kw['num_knots'] = kw['num_knots'] * world              # keep observations per knot fixed
+    kw['total_obs'] = per_gpu_obs * world                      # weak scaling: fixed observations per GPU;
+                                                               # cameras and the spline (knots) stay as configured
     scene = synth.make_scene(**kw)
     prob, x0 = mp.problem_from_scene(scene)
     handle, _ = sharded_handle(prob, rank, world, local_rank) if world > 1 else (ba.BAHandle(prob, device=local_rank), None)

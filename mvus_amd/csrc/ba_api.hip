@@ -5,6 +5,7 @@
 
 #include <chrono>
 #include <cstring>
+#include <map>
 #include <memory>
 #include <string>
 #include <vector>
@@ -105,6 +106,7 @@ struct HipBackend {
     (void)hipSetDevice(device);
     if (stream) (void)hipStreamSynchronize(stream);
     for (void* p : owned) (void)hipFree(p);
+    for (auto& kv : pool_size) (void)hipFree(kv.first);
     if (scal_host) (void)hipHostFree(scal_host);
     if (own_stream && stream) (void)hipStreamDestroy(stream);
   }
@@ -113,12 +115,20 @@ struct HipBackend {
   int64_t n() const { return hp.n; }
   int64_t m_local() const { return hp.m; }
   int64_t m_global() const { return m_glob; }
+  // work vectors come from a size-keyed free list: the solvers allocate and release the same handful of n- and
+  // m-sized buffers on every call, and hipMalloc/hipFree cost far more than the kernels they feed
+  std::map<size_t, std::vector<double*>> pool_free;
+  std::map<double*, size_t> pool_size;
   double* alloc(int64_t len) {
+    const size_t bytes = (size_t)std::max<int64_t>(len, 1) * sizeof(double);
+    auto it = pool_free.find(bytes);
+    if (it != pool_free.end() && !it->second.empty()) { double* p = it->second.back(); it->second.pop_back(); return p; }
     void* p = nullptr;
-    MVUS_HIP(hipMalloc(&p, std::max<int64_t>(len, 1) * sizeof(double)));
+    MVUS_HIP(hipMalloc(&p, bytes));
+    pool_size[static_cast<double*>(p)] = bytes;
     return static_cast<double*>(p);
   }
-  void release(double* p) { if (p) { (void)hipStreamSynchronize(stream); (void)hipFree(p); } }
+  void release(double* p) { if (p) pool_free[pool_size[p]].push_back(p); }   // stream-ordered reuse: one stream per handle
   void upload(double* d, const double* s, int64_t len) {
     MVUS_HIP(hipMemcpyAsync(d, s, len * sizeof(double), hipMemcpyHostToDevice, stream));
     MVUS_HIP(hipStreamSynchronize(stream));   // the host buffer may be reused right away

@@ -12,7 +12,8 @@ plotting, and the dead ``motion_prior=True`` branch -- those methods raise ``Not
 
 Extra ``settings`` keys (all optional): ``ba_solver`` ('trf' = scipy TRF+LSMR restated, default; 'lm' = LM with
 Schur complement), ``ba_jacobian`` ('pattern' = analytic masked to the reference sparsity pattern, default with
-'trf'; 'analytic'), ``device`` (HIP device ordinal).
+'trf'; 'analytic' = full analytic, default with 'lm'; 'fd' = scipy's grouped 2-point differences on the GPU, the
+reference's own estimate), ``device`` (HIP device ordinal).
 """
 import json
 
@@ -321,7 +322,7 @@ class Scene:
         st = self.settings
         solver = _ba.SOLVER_LM_SCHUR if st.get('ba_solver', 'trf') == 'lm' else _ba.SOLVER_TRF_LSMR
         default_jac = 'analytic' if solver == _ba.SOLVER_LM_SCHUR else 'pattern'
-        jac_mode = _ba.JAC_ANALYTIC if st.get('ba_jacobian', default_jac) == 'analytic' else _ba.JAC_PATTERN
+        jac_mode = {'analytic': _ba.JAC_ANALYTIC, 'pattern': _ba.JAC_PATTERN, 'fd': _ba.JAC_FD}[st.get('ba_jacobian', default_jac)]
         with self._handle(prob) as h:
             res = h.solve(model, solver=solver, jac_mode=jac_mode, max_nfev=max_iter)
         alpha, beta, rs_new, cam_states, coefs = _problem.unpack_x(prob, res.x)
