@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libmvusba.so')
+LIB_PATH = os.environ.get('MVUS_LIB_PATH') or os.path.join(_HERE, 'csrc', 'libmvusba.so')   # override: kernel experiments
 
 MVUS_OK = 0
 MVUS_E_INVALID, MVUS_E_HIP, MVUS_E_NUMERIC, MVUS_E_COMM = -1, -2, -3, -4

@@ -7,7 +7,9 @@
 //   gc [C][B]           camera part of g = J^T f
 //   Cb [N][W][3][3]     Cb[g][w] = H[3g.., 3(g+w)..]: upper block band of the spline block, W >= 4
 //   gs [3N]             spline part of g, internal order 3*ctrl + xyz
-//   Et [3N][C*B]        E^T: row = spline unknown, column = camera unknown  (the many right-hand sides)
+//   Ec [C][3N][B]       cross block, camera-major: the window a workgroup accumulates for one camera is one
+//                       contiguous run of 3*nwin*B doubles, so its flush is fully coalesced; k_build_rhs transposes
+//                       it into the row-major [3N][C*B] right-hand-side / GEMM operand
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -90,7 +92,27 @@ __global__ __launch_bounds__(kThreads) void k_assemble(DevProblem dp, const doub
       if (lane == 0) unsafeAtomicAdd(&Aw[a * B + b], v);
     }
   }
-  if (g >= 0) {
+  // Spline / cross terms.  Neighbouring lanes hold neighbouring timestamps, i.e. runs of lanes share the same four
+  // control points; same-address fp64 LDS atomics serialise badly (measured: 1.08 of 1.16 ms), so every quantity is
+  // first summed over its run with a wavefront segmented scan and only the run's last lane adds it -- all lanes
+  // of one ds_add_f64 then hit distinct addresses.
+  {
+    const int gprev = __shfl_up(g, 1, 64), gnext = __shfl_down(g, 1, 64);
+    const bool head = lane == 0 || gprev != g;
+    const bool tail = (lane == 63 || gnext != g) && g >= 0;
+    int start = head ? lane : 0;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int s2 = __shfl_up(start, off, 64); if (lane >= off) start = max(start, s2); }
+    // scan depth: runs are short (a few detections per knot span), so stop after ceil(log2(longest run)) steps
+    int runlen = lane - start + 1;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) runlen = max(runlen, __shfl_xor(runlen, off, 64));
+    const int maxrun = __builtin_amdgcn_readfirstlane(runlen);
+    auto seg = [&](double v) {
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) { if (off >= maxrun) break; const double u = __shfl_up(v, off, 64); if (lane - off >= start) v += u; }
+      return v;
+    };
     const int l = g - g0;
     const bool inwin = l + 3 < kNWin;
 #pragma unroll
@@ -99,23 +121,29 @@ __global__ __launch_bounds__(kThreads) void k_assemble(DevProblem dp, const doub
       for (int d = 0; d < 3; ++d) {
         const int sq = B + 3 * q + d;
         const double vx = jx[sq], vy = jy[sq];
-        const double gval = vx * fx + vy * fy;
-        if (inwin) unsafeAtomicAdd(&gsw[3 * (l + q) + d], gval);
-        else unsafeAtomicAdd(&ne.gs[3 * (g + q) + d], gval);
+        const double gval = seg(vx * fx + vy * fy);
+        if (tail) {
+          if (inwin) unsafeAtomicAdd(&gsw[3 * (l + q) + d], gval);
+          else unsafeAtomicAdd(&ne.gs[3 * (g + q) + d], gval);
+        }
 #pragma unroll
         for (int k = 0; k < B; ++k) {
-          const double ev = jx[k] * vx + jy[k] * vy;
-          if (inwin) unsafeAtomicAdd(&Ew[(3 * (l + q) + d) * B + k], ev);
-          else unsafeAtomicAdd(&ne.Et[(long long)(3 * (g + q) + d) * ne.CB + c * B + k], ev);
+          const double ev = seg(jx[k] * vx + jy[k] * vy);
+          if (tail) {
+            if (inwin) unsafeAtomicAdd(&Ew[(3 * (l + q) + d) * B + k], ev);
+            else unsafeAtomicAdd(&ne.Et[((long long)c * ne.N3 + 3 * (g + q) + d) * B + k], ev);
+          }
         }
 #pragma unroll
         for (int q2 = q; q2 < 4; ++q2) {
 #pragma unroll
           for (int d2 = 0; d2 < 3; ++d2) {
             const int s2 = B + 3 * q2 + d2;
-            const double cv = vx * jx[s2] + vy * jy[s2];
-            if (inwin) unsafeAtomicAdd(&Cw[((l + q) * 4 + (q2 - q)) * 9 + 3 * d + d2], cv);
-            else unsafeAtomicAdd(&ne.Cb[((long long)(g + q) * ne.W + (q2 - q)) * 9 + 3 * d + d2], cv);
+            const double cv = seg(vx * jx[s2] + vy * jy[s2]);
+            if (tail) {
+              if (inwin) unsafeAtomicAdd(&Cw[((l + q) * 4 + (q2 - q)) * 9 + 3 * d + d2], cv);
+              else unsafeAtomicAdd(&ne.Cb[((long long)(g + q) * ne.W + (q2 - q)) * 9 + 3 * d + d2], cv);
+            }
           }
         }
       }
@@ -132,10 +160,13 @@ __global__ __launch_bounds__(kThreads) void k_assemble(DevProblem dp, const doub
     const int r = 3 * g0 + k;
     if (r < ne.N3 && gsw[k] != 0.0) unsafeAtomicAdd(&ne.gs[r], gsw[k]);
   }
-  for (int k = threadIdx.x; k < kNWin * 3 * B; k += kThreads) {
-    const int r = 3 * g0 + k / B;
-    const double v = Ew[k];
-    if (r < ne.N3 && v != 0.0) unsafeAtomicAdd(&ne.Et[(long long)r * ne.CB + c * B + (k % B)], v);
+  {
+    double* Ecam = ne.Et + ((long long)c * ne.N3 + 3 * g0) * B;       // contiguous window of this camera
+    const int lim = min(kNWin * 3, ne.N3 - 3 * g0) * B;
+    for (int k = threadIdx.x; k < lim; k += kThreads) {
+      const double v = Ew[k];
+      if (v != 0.0) unsafeAtomicAdd(&Ecam[k], v);
+    }
   }
   for (int k = threadIdx.x; k < kNWin * 36; k += kThreads) {
     const int gg = g0 + k / 36, w = (k / 9) % 4;
@@ -144,28 +175,85 @@ __global__ __launch_bounds__(kThreads) void k_assemble(DevProblem dp, const doub
   }
 }
 
-// motion-regulariser rows: spline block and gradient only (the rows do not depend on camera parameters)
+// motion-regulariser rows: spline block and gradient only (the rows do not depend on camera parameters).
+// 256 consecutive rows (= consecutive sample times) per workgroup; each row is first compacted to the <= 6
+// distinct control points it touches, then accumulated into an LDS window like the detection rows.
+constexpr int kMotW = 6;
 __global__ __launch_bounds__(kThreads) void k_assemble_motion(DevProblem dp, const double* __restrict__ mJ, const int32_t* __restrict__ mctrl,
                                                               const double* __restrict__ fm, NEView ne) {
+  __shared__ double Cw[kNWin * kMotW * 9];
+  __shared__ double gsw[kNWin * 3];
+  __shared__ int gmin_s[kThreads / 64];
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= dp.T) return;
-  const double fj = fm[j];
-  for (int e1 = 0; e1 < 36; ++e1) {
-    const int k1 = e1 / 12, g1 = mctrl[(long long)k1 * dp.T + j];
-    if (g1 < 0) continue;
-    const double v1 = mJ[(long long)e1 * dp.T + j];
-    if (v1 == 0.0) continue;
-    const int c1 = g1 + (e1 % 12) / 3, d1 = e1 % 3;
-    unsafeAtomicAdd(&ne.gs[3 * c1 + d1], v1 * fj);
-    for (int e2 = 0; e2 < 36; ++e2) {
-      const int k2 = e2 / 12, g2 = mctrl[(long long)k2 * dp.T + j];
-      if (g2 < 0) continue;
-      const int c2 = g2 + (e2 % 12) / 3, d2 = e2 % 3;
-      if (c2 < c1) continue;
-      const double v2 = mJ[(long long)e2 * dp.T + j];
-      if (v2 == 0.0) continue;
-      unsafeAtomicAdd(&ne.Cb[((long long)c1 * ne.W + (c2 - c1)) * 9 + 3 * d1 + d2], v1 * v2);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int k = threadIdx.x; k < kNWin * kMotW * 9; k += kThreads) Cw[k] = 0.0;
+  for (int k = threadIdx.x; k < kNWin * 3; k += kThreads) gsw[k] = 0.0;
+  // compact the row: control points lo .. lo+kMotW-1, 3 coordinates each
+  int lo = 0x7fffffff, hi = -1;
+  int cid[3] = {-1, -1, -1};
+  if (j < dp.T)
+    for (int k = 0; k < 3; ++k) {
+      cid[k] = mctrl[(long long)k * dp.T + j];
+      if (cid[k] >= 0) { lo = min(lo, cid[k]); hi = max(hi, cid[k] + 3); }
     }
+  double rv[kMotW * 3];
+#pragma unroll
+  for (int e = 0; e < kMotW * 3; ++e) rv[e] = 0.0;
+  const bool live = hi >= 0 && hi - lo < kMotW;      // the band width W (<= 6) guarantees this for valid rows
+  if (live)
+    for (int k = 0; k < 3; ++k) {
+      if (cid[k] < 0) continue;
+      const int o = cid[k] - lo;
+      for (int q = 0; q < 4; ++q)
+        for (int d = 0; d < 3; ++d) {
+          const double v = mJ[(long long)(12 * k + 3 * q + d) * dp.T + j];
+          // static indexing of rv: select by comparison
+#pragma unroll
+          for (int e = 0; e < kMotW * 3; ++e) if (e == 3 * (o + q) + d) rv[e] += v;
+        }
+    }
+  int gm = wave_min_i(live ? lo : 0x7fffffff);
+  if (lane == 0) gmin_s[wave] = gm;
+  __syncthreads();
+  int g0 = gmin_s[0];
+#pragma unroll
+  for (int w = 1; w < kThreads / 64; ++w) g0 = min(g0, gmin_s[w]);
+  if (g0 == 0x7fffffff) return;
+  if (live) {
+    const double fj = fm[j];
+    const int l = lo - g0;
+    const bool inwin = l + kMotW <= kNWin;
+#pragma unroll
+    for (int a = 0; a < kMotW; ++a) {
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        const double va = rv[3 * a + d];
+        if (va == 0.0) continue;
+        if (inwin) unsafeAtomicAdd(&gsw[3 * (l + a) + d], va * fj);
+        else unsafeAtomicAdd(&ne.gs[3 * (lo + a) + d], va * fj);
+#pragma unroll
+        for (int b = a; b < kMotW; ++b) {
+          if (b - a >= ne.W) continue;
+#pragma unroll
+          for (int d2 = 0; d2 < 3; ++d2) {
+            const double vb = rv[3 * b + d2];
+            if (vb == 0.0) continue;
+            if (inwin) unsafeAtomicAdd(&Cw[((l + a) * kMotW + (b - a)) * 9 + 3 * d + d2], va * vb);
+            else unsafeAtomicAdd(&ne.Cb[((long long)(lo + a) * ne.W + (b - a)) * 9 + 3 * d + d2], va * vb);
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < kNWin * 3; k += kThreads) {
+    const int r = 3 * g0 + k;
+    if (r < ne.N3 && gsw[k] != 0.0) unsafeAtomicAdd(&ne.gs[r], gsw[k]);
+  }
+  for (int k = threadIdx.x; k < kNWin * kMotW * 9; k += kThreads) {
+    const int gg = g0 + k / (kMotW * 9), w = (k / 9) % kMotW;
+    const double v = Cw[k];
+    if (gg < ne.N && w < ne.W && v != 0.0) unsafeAtomicAdd(&ne.Cb[((long long)gg * ne.W + w) * 9 + (k % 9)], v);
   }
 }
 
@@ -505,12 +593,19 @@ __global__ __launch_bounds__(256) void k_part_back(PartView pv, int ncols, doubl
   }
 }
 
-// Z[3N][ncols] = [E^T | gs]
-__global__ void k_build_rhs(NEView ne, int ncols, double* __restrict__ Z) {
+// Z[3N][ncols] = [E^T | gs] and Erm[3N][CB] = E^T (row-major copies of the camera-major cross block)
+__global__ void k_build_rhs(NEView ne, int ncols, double* __restrict__ Z, double* __restrict__ Erm) {
   const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (idx >= (long long)ne.N3 * ncols) return;
   const int r = (int)(idx / ncols), cidx = (int)(idx % ncols);
-  Z[idx] = cidx < ne.CB ? ne.Et[(long long)r * ne.CB + cidx] : ne.gs[r];
+  if (cidx < ne.CB) {
+    const int c = cidx / ne.B, k = cidx % ne.B;
+    const double v = ne.Et[((long long)c * ne.N3 + r) * ne.B + k];
+    Z[idx] = v;
+    Erm[(long long)r * ne.CB + cidx] = v;
+  } else {
+    Z[idx] = ne.gs[r];
+  }
 }
 
 // Z <- (L L^T)^-1 Z, one thread per right-hand-side column, forward then backward substitution.
@@ -550,23 +645,46 @@ __global__ __launch_bounds__(64) void k_band_solve(int n3, int ncols, const doub
   }
 }
 
-// G[CB][ncols] += Et^T Z over a slice of rows (16x16 output tile, 128-row slices staged in LDS)
-constexpr int kGemmK = 128;
-__global__ __launch_bounds__(256) void k_schur_gemm(NEView ne, int ncols, const double* __restrict__ Z, double* __restrict__ G) {
-  __shared__ double Es[kGemmK][17];
-  __shared__ double Zs[kGemmK][17];
-  const int a0 = blockIdx.x * 16, b0 = blockIdx.y * 16, k0 = blockIdx.z * kGemmK;
-  const int ta = threadIdx.x / 16, tb = threadIdx.x % 16;
-  for (int e = threadIdx.x; e < kGemmK * 16; e += 256) {
-    const int kk = e / 16, cc = e % 16, r = k0 + kk;
-    Es[kk][cc] = (r < ne.N3 && a0 + cc < ne.CB) ? ne.Et[(long long)r * ne.CB + a0 + cc] : 0.0;
-    Zs[kk][cc] = (r < ne.N3 && b0 + cc < ncols) ? Z[(long long)r * ncols + b0 + cc] : 0.0;
+// G[CB][ncols] += Et^T Z : the one dense contraction of the solve (2 * CB^2 * 3N flops).  64x64 output tile per
+// workgroup, 4x4 outputs per thread held in registers, 32-row slices of both operands staged in LDS, split over the
+// long K (= 3N) dimension with one fp64 atomic per output element and K-slab.
+constexpr int kGemmT = 64, kGemmKs = 32, kGemmSlab = 1024;
+__global__ __launch_bounds__(256) void k_schur_gemm(NEView ne, int ncols, const double* __restrict__ Erm, const double* __restrict__ Z, double* __restrict__ G) {
+  __shared__ double Es[kGemmKs][kGemmT + 1];
+  __shared__ double Zs[kGemmKs][kGemmT + 1];
+  const int a0 = blockIdx.x * kGemmT, b0 = blockIdx.y * kGemmT;
+  const int kbeg = blockIdx.z * kGemmSlab, kend = min(kbeg + kGemmSlab, ne.N3);
+  const int ta = (threadIdx.x / 16) * 4, tb = (threadIdx.x % 16) * 4;
+  double acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) acc[i][jj] = 0.0;
+  for (int k0 = kbeg; k0 < kend; k0 += kGemmKs) {
+    for (int e = threadIdx.x; e < kGemmKs * kGemmT; e += 256) {
+      const int kk = e / kGemmT, cc = e % kGemmT, r = k0 + kk;
+      Es[kk][cc] = (r < kend && a0 + cc < ne.CB) ? Erm[(long long)r * ne.CB + a0 + cc] : 0.0;
+      Zs[kk][cc] = (r < kend && b0 + cc < ncols) ? Z[(long long)r * ncols + b0 + cc] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int kk = 0; kk < kGemmKs; ++kk) {
+      double ea[4], zb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { ea[i] = Es[kk][ta + i]; zb[i] = Zs[kk][tb + i]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) acc[i][jj] += ea[i] * zb[jj];
+    }
+    __syncthreads();
   }
-  __syncthreads();
-  double acc = 0.0;
-#pragma unroll 8
-  for (int kk = 0; kk < kGemmK; ++kk) acc += Es[kk][ta] * Zs[kk][tb];
-  if (a0 + ta < ne.CB && b0 + tb < ncols && acc != 0.0) unsafeAtomicAdd(&G[(long long)(a0 + ta) * ncols + b0 + tb], acc);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+      if (a0 + ta + i < ne.CB && b0 + tb + jj < ncols && acc[i][jj] != 0.0)
+        unsafeAtomicAdd(&G[(long long)(a0 + ta + i) * ncols + b0 + tb + jj], acc[i][jj]);
 }
 
 // S = (A + lambda D_c) - G[:, :CB] (dense CB x CB), rhs = gc - G[:, CB]
@@ -590,24 +708,34 @@ __global__ void k_schur_finish(NEView ne, int ncols, double lambda, const double
 // triangular solve performs the forward substitution; the backward substitution runs panel by panel.
 constexpr int kNB = 32;
 
-__global__ __launch_bounds__(1024) void k_potrf_diag(int nn, int kb, double* __restrict__ Sa, int* __restrict__ fail) {
+// Cholesky of the kNB x kNB diagonal block by ONE wavefront in LDS (no workgroup barriers across 16 wavefronts)
+__global__ __launch_bounds__(64) void k_potrf_diag(int nn, int kb, double* __restrict__ Sa, int* __restrict__ fail) {
   __shared__ double D[kNB][kNB + 1];
-  const int nb = min(kNB, nn - kb);
-  const int r = threadIdx.x / kNB, c = threadIdx.x % kNB;
-  D[r][c] = (r < nb && c < nb) ? Sa[(long long)(kb + r) * nn + kb + c] : (r == c ? 1.0 : 0.0);
+  const int nb = min(kNB, nn - kb), lane = threadIdx.x;
+  for (int e = lane; e < kNB * kNB; e += 64) {
+    const int r = e / kNB, c = e % kNB;
+    D[r][c] = (r < nb && c < nb) ? Sa[(long long)(kb + r) * nn + kb + c] : (r == c ? 1.0 : 0.0);
+  }
   __syncthreads();
   for (int k = 0; k < nb; ++k) {
     double d = D[k][k];
-    if (!(d > 0.0)) { if (threadIdx.x == 0) fail[0] = 2; d = 1.0; }
+    if (!(d > 0.0)) { if (lane == 0) fail[0] = 2; d = 1.0; }
     d = sqrt(d);
     __syncthreads();
-    if (r == k && c == k) D[k][k] = d;
-    if (c == k && r > k) D[r][k] /= d;
+    if (lane == k) D[k][k] = d;
+    if (lane > k && lane < nb) D[lane][k] /= d;
     __syncthreads();
-    if (r > k && c > k && c <= r) D[r][c] -= D[r][k] * D[c][k];
+    const int rem = nb - k - 1;                      // trailing lower triangle, rem*(rem+1)/2 entries
+    for (int e = lane; e < rem * rem; e += 64) {
+      const int r = k + 1 + e / rem, c = k + 1 + e % rem;
+      if (c <= r) D[r][c] -= D[r][k] * D[c][k];
+    }
     __syncthreads();
   }
-  if (r < nb && c < nb) Sa[(long long)(kb + r) * nn + kb + c] = (c <= r) ? D[r][c] : 0.0;
+  for (int e = lane; e < kNB * kNB; e += 64) {
+    const int r = e / kNB, c = e % kNB;
+    if (r < nb && c < nb) Sa[(long long)(kb + r) * nn + kb + c] = (c <= r) ? D[r][c] : 0.0;
+  }
 }
 
 // rows below the panel (and the rhs row): X <- X L11^-T.  One thread per row; the row's panel entries live in
@@ -664,11 +792,15 @@ __global__ __launch_bounds__(256) void k_backsub_panel(int nn, int kb, double* _
   }
   if (threadIdx.x < kNB) xs[threadIdx.x] = threadIdx.x < nb ? y[kb + threadIdx.x] : 0.0;
   __syncthreads();
-  if (threadIdx.x == 0) {
+  if (threadIdx.x < 64) {                     // column-oriented back substitution by the first wavefront
+    const int lane = threadIdx.x;
     for (int k = nb - 1; k >= 0; --k) {
-      double v = xs[k];
-      for (int jj = k + 1; jj < nb; ++jj) v -= L11[jj][k] * xs[jj];
-      xs[k] = v / L11[k][k];
+      const double xk = xs[k] / L11[k][k];
+      __builtin_amdgcn_wave_barrier();
+      if (lane == k) xs[k] = xk;
+      if (lane < k) xs[lane] -= L11[k][lane] * xk;
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
   }
   __syncthreads();
@@ -707,6 +839,7 @@ struct HipSchur {
   NEView ne{};
   int ncols = 0, BW = 0;
   size_t ne_count = 0;
+  double *Erm = nullptr;
   double *NE = nullptr, *Lb = nullptr, *Z = nullptr, *G = nullptr, *S = nullptr, *rhs = nullptr, *pc = nullptr, *D = nullptr, *gx = nullptr, *px = nullptr;
   int* fail = nullptr;
   int* fail_host = nullptr;
@@ -734,6 +867,7 @@ struct HipSchur {
     ne.A = NE; ne.gc = ne.A + nA; ne.Cb = ne.gc + ngc; ne.gs = ne.Cb + nCb; ne.Et = ne.gs + ngs;
     Lb = be.alloc((size_t)ne.N3 * (BW + 1));
     Z = be.alloc((size_t)ne.N3 * ncols);
+    Erm = be.alloc((size_t)ne.N3 * ne.CB);
     G = be.alloc((size_t)ne.CB * ncols);
     S = be.alloc((size_t)(ne.CB + 1) * ne.CB);
     rhs = be.alloc(ne.CB); pc = be.alloc(ne.CB);
@@ -765,7 +899,7 @@ struct HipSchur {
     pv.U = be.alloc((size_t)std::max(pv.P - 1, 1) * pv.s3 * pv.s3);
   }
   ~HipSchur() {
-    for (double* p : {NE, Lb, Z, G, S, rhs, pc, D, gx, px, pv.VW, pv.T, pv.U}) be.release(p);
+    for (double* p : {Erm, NE, Lb, Z, G, S, rhs, pc, D, gx, px, pv.VW, pv.T, pv.U}) be.release(p);
     if (part_tables) (void)hipFree(part_tables);
     if (fail) (void)hipFree(fail);
     if (fail_host) (void)hipHostFree(fail_host);
@@ -800,7 +934,7 @@ struct HipSchur {
     MVUS_HIP(hipMemsetAsync(fail, 0, sizeof(int), be.stream));
     hipLaunchKernelGGL(k_band_pack, dim3((unsigned)((nLb + 255) / 256)), dim3(256), 0, be.stream, ne, lambda, BW, Lb);
     const long long nZ = (long long)ne.N3 * ncols;
-    hipLaunchKernelGGL(k_build_rhs, dim3((unsigned)((nZ + 255) / 256)), dim3(256), 0, be.stream, ne, ncols, Z);
+    hipLaunchKernelGGL(k_build_rhs, dim3((unsigned)((nZ + 255) / 256)), dim3(256), 0, be.stream, ne, ncols, Z, Erm);
     const dim3 gsolve(pv.P, (ncols + 2 * pv.s3 + 63) / 64);
     if (BW == 11) {
       hipLaunchKernelGGL(k_part_cholesky<11>, dim3(pv.P), dim3(64), 0, be.stream, pv, Lb, fail);
@@ -821,14 +955,14 @@ struct HipSchur {
     }
     if (pv.P > 1) hipLaunchKernelGGL(k_part_back, dim3(pv.P, 8), dim3(256), 0, be.stream, pv, ncols, Z);
     MVUS_HIP(hipMemsetAsync(G, 0, (size_t)ne.CB * ncols * sizeof(double), be.stream));
-    hipLaunchKernelGGL(k_schur_gemm, dim3((ne.CB + 15) / 16, (ncols + 15) / 16, (ne.N3 + kGemmK - 1) / kGemmK), dim3(256), 0, be.stream, ne, ncols, Z, G);
+    hipLaunchKernelGGL(k_schur_gemm, dim3((ne.CB + kGemmT - 1) / kGemmT, (ncols + kGemmT - 1) / kGemmT, (ne.N3 + kGemmSlab - 1) / kGemmSlab), dim3(256), 0, be.stream, ne, ncols, Erm, Z, G);
     const long long nS = (long long)ne.CB * ne.CB;
     hipLaunchKernelGGL(k_schur_finish, dim3((unsigned)((nS + 255) / 256)), dim3(256), 0, be.stream, ne, ncols, lambda, G, S, rhs);
     {
       const int nn = ne.CB;
       for (int kb = 0; kb < nn; kb += kNB) {
         const int nb = std::min(kNB, nn - kb), below = nn + 1 - (kb + nb);       // rows under the panel incl. the rhs row
-        hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(kNB * kNB), 0, be.stream, nn, kb, S, fail);
+        hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(64), 0, be.stream, nn, kb, S, fail);
         hipLaunchKernelGGL(k_trsm_panel, dim3((below + kTrsmThreads - 1) / kTrsmThreads), dim3(kTrsmThreads), 0, be.stream, nn, kb, S);
         const int tiles = (below + kNB - 1) / kNB;
         hipLaunchKernelGGL(k_syrk_update, dim3(tiles, tiles), dim3(kNB * kNB), 0, be.stream, nn, kb, S);
@@ -862,10 +996,11 @@ int schur_export(BE& be, HipSchur<BE>& sc, double* g, double* JtJ_cam, double* b
   if (JtJ_cam) be.download(JtJ_cam, ne.A, (int64_t)ne.C * ne.B * ne.B);
   if (band) be.download(band, ne.Cb, (int64_t)ne.N * ne.W * 9);
   if (cross) {
-    std::vector<double> Et((size_t)ne.N3 * ne.CB);
-    be.download(Et.data(), ne.Et, (int64_t)Et.size());
-    for (int r = 0; r < ne.N3; ++r)
-      for (int cidx = 0; cidx < ne.CB; ++cidx) cross[(size_t)cidx * ne.N3 + r] = Et[(size_t)r * ne.CB + cidx];
+    std::vector<double> Ec((size_t)ne.N3 * ne.CB);
+    be.download(Ec.data(), ne.Et, (int64_t)Ec.size());
+    for (int c = 0; c < ne.C; ++c)
+      for (int r = 0; r < ne.N3; ++r)
+        for (int k = 0; k < ne.B; ++k) cross[((size_t)c * ne.B + k) * ne.N3 + r] = Ec[((size_t)c * ne.N3 + r) * ne.B + k];
   }
   return MVUS_OK;
 }
