@@ -245,8 +245,8 @@ struct HipBackend {
   void jtu_local(const double* u, double* z) {
     MVUS_HIP(hipMemsetAsync(z, 0, sizeof(double) * hp.n, stream));
     if (dp.n_chunks > 0) {
-      if (hp.calib) hipLaunchKernelGGL(k_jtu<30>, dim3(dp.n_chunks), dim3(kThreads), 0, stream, dp, J, span, u, z);
-      else hipLaunchKernelGGL(k_jtu<21>, dim3(dp.n_chunks), dim3(kThreads), 0, stream, dp, J, span, u, z);
+      if (hp.calib) hipLaunchKernelGGL(k_jtu_gather<30>, dim3(dp.n_chunks), dim3(kThreads), 0, stream, dp, J, span, u, z);
+      else hipLaunchKernelGGL(k_jtu_gather<21>, dim3(dp.n_chunks), dim3(kThreads), 0, stream, dp, J, span, u, z);
     }
     if (hp.T > 0) hipLaunchKernelGGL(k_motion_jtu, dim3((hp.T + kThreads - 1) / kThreads), dim3(kThreads), 0, stream, dp, mJ, mctrl, u + 2 * hp.M, z);
     MVUS_HIP(hipGetLastError());
@@ -520,8 +520,8 @@ int mvus_ba_time_kernel(mvus_ba* h, int32_t which, int32_t launches, double* avg
           else hipLaunchKernelGGL(k_jv<21>, g, b, 0, be.stream, be.dp, be.J, be.span, vn, ym);
           break;
         case 3:
-          if (be.hp.calib) hipLaunchKernelGGL(k_jtu<30>, g, b, 0, be.stream, be.dp, be.J, be.span, um, zn);
-          else hipLaunchKernelGGL(k_jtu<21>, g, b, 0, be.stream, be.dp, be.J, be.span, um, zn);
+          if (be.hp.calib) hipLaunchKernelGGL(k_jtu_gather<30>, g, b, 0, be.stream, be.dp, be.J, be.span, um, zn);
+          else hipLaunchKernelGGL(k_jtu_gather<21>, g, b, 0, be.stream, be.dp, be.J, be.span, um, zn);
           break;
         default:
           schur->assemble_local(be.f_cur);

@@ -226,6 +226,103 @@ __global__ __launch_bounds__(kThreads) void k_jtu(DevProblem dp, const double* _
   }
 }
 
+// z += J^T u, gather form.  The products p[q][d][i] = Jx[q,d](i) ux(i) + Jy[q,d](i) uy(i) of the chunk are staged in
+// LDS; the detections of one knot span form one contiguous index range (frames are time ordered), so output
+// (control point l, coordinate d) is owned by one thread that sums the <= 4 spans touching it: no LDS atomics, one
+// global atomic per output and chunk instead of 12 per detection.  Chunks whose spans are not sorted, or that
+// do not fit the window, take the atomic path of k_jtu (flagged per chunk).
+constexpr int kJtWin = 144;     // control points per chunk window
+template <int NS>
+__global__ __launch_bounds__(kThreads) void k_jtu_gather(DevProblem dp, const double* __restrict__ J, const int32_t* __restrict__ span,
+                                                         const double* __restrict__ u, double* __restrict__ z) {
+  constexpr int B = NS - 12;
+  constexpr int PS = kThreads + 1;                     // padded row stride of the staged products
+  __shared__ double part[kThreads / 64][B];
+  __shared__ double prod[12 * PS];
+  __shared__ int lo[kJtWin], hi[kJtWin];
+  __shared__ int gmin_s[kThreads / 64];
+  __shared__ int bad_s;
+  const int chunk = blockIdx.x;
+  const int c = dp.chunk_cam[chunk];
+  const int cnt = dp.chunk_count[chunk];
+  const bool active = (int)threadIdx.x < cnt;
+  const long long i = dp.chunk_start[chunk] + (active ? threadIdx.x : 0);
+  const long long a = dp.det_off[c], Mc = dp.det_off[c + 1] - a;
+  const int g = active ? span[i] : -1;
+  const double ux = g >= 0 ? u[2 * a + (i - a)] : 0.0;
+  const double uy = g >= 0 ? u[2 * a + Mc + (i - a)] : 0.0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int k = threadIdx.x; k < kJtWin; k += kThreads) { lo[k] = 0x7fffffff; hi[k] = 0; }
+  if (threadIdx.x == 0) bad_s = 0;
+  int gm = g >= 0 ? g : 0x7fffffff;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) gm = min(gm, __shfl_xor(gm, off, 64));
+  if (lane == 0) gmin_s[wave] = gm;
+  // camera / sync columns: wavefront reduction as in k_jtu
+#pragma unroll
+  for (int k = 0; k < B; ++k) {
+    double val = 0.0;
+    if (g >= 0) val = J[(long long)k * dp.M + i] * ux + J[(long long)(NS + k) * dp.M + i] * uy;
+    val = wave_sum(val);
+    if (lane == 0) part[wave][k] = val;
+  }
+  __syncthreads();
+  int g0 = gmin_s[0];
+#pragma unroll
+  for (int w = 1; w < kThreads / 64; ++w) g0 = min(g0, gmin_s[w]);
+  if (threadIdx.x < B) {
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < kThreads / 64; ++w) s += part[w][threadIdx.x];
+    if (s != 0.0) unsafeAtomicAdd(&z[cam_col(dp.C, dp.P, c, threadIdx.x)], s);
+  }
+  if (g0 == 0x7fffffff) return;                       // nothing visible (uniform)
+  const int l = g - g0;
+  double pv[12];
+#pragma unroll
+  for (int e = 0; e < 12; ++e) {
+    pv[e] = g >= 0 ? J[(long long)(B + e) * dp.M + i] * ux + J[(long long)(NS + B + e) * dp.M + i] * uy : 0.0;
+    prod[e * PS + threadIdx.x] = pv[e];
+  }
+  if (g >= 0) {
+    if (l + 3 >= kJtWin) atomicOr(&bad_s, 1);
+    else { atomicMin(&lo[l], (int)threadIdx.x); atomicMax(&hi[l], (int)threadIdx.x + 1); }
+  }
+  __syncthreads();
+  // ranges of different spans must not interleave (they cannot when timestamps increase with the frame number)
+  if (threadIdx.x < kJtWin && hi[threadIdx.x] > 0) {
+    for (int t = threadIdx.x + 1; t < kJtWin; ++t)
+      if (hi[t] > 0) { if (lo[t] < hi[threadIdx.x]) atomicOr(&bad_s, 1); break; }
+  }
+  __syncthreads();
+  if (bad_s) {                                         // fallback: per-detection atomics
+    if (g >= 0) {
+      const int x0 = dp.mv.ctrl_x0[g], st = dp.mv.ctrl_stride[g];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) unsafeAtomicAdd(&z[x0 + q + d * st], pv[3 * q + d]);
+    }
+    return;
+  }
+  for (int o = threadIdx.x; o < 3 * kJtWin; o += kThreads) {
+    const int lc = o / 3, d = o % 3;                   // local control point, coordinate
+    double acc = 0.0;
+    bool any = false;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int s = lc - q;
+      if (s < 0) continue;
+      const int b = lo[s], e = hi[s];
+      for (int t = b; t < e; ++t) { acc += prod[(3 * q + d) * PS + t]; any = true; }
+    }
+    if (any && acc != 0.0) {
+      const int gg = g0 + lc;
+      unsafeAtomicAdd(&z[dp.mv.ctrl_x0[gg] + d * dp.mv.ctrl_stride[gg]], acc);
+    }
+  }
+}
+
 __global__ __launch_bounds__(kThreads) void k_motion_jv(DevProblem dp, const double* __restrict__ mJ, const int32_t* __restrict__ mctrl,
                                                         const double* __restrict__ v, double* __restrict__ ym) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
