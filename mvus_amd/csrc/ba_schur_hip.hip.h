@@ -42,7 +42,7 @@ __device__ __forceinline__ int wave_min_i(int v) {
 // global atomics; lanes outside the window (sparse detections) fall back to global atomics.
 template <int NS>
 __global__ __launch_bounds__(kThreads) void k_assemble(DevProblem dp, const double* __restrict__ J, const int32_t* __restrict__ span,
-                                                       const double* __restrict__ f, NEView ne) {
+                                                       const double* __restrict__ f, NEView ne, const int* __restrict__ redo) {
   constexpr int B = NS - 12;
   __shared__ double Aw[B * B];
   __shared__ double gcw[B];
@@ -51,8 +51,10 @@ __global__ __launch_bounds__(kThreads) void k_assemble(DevProblem dp, const doub
   __shared__ double gsw[kNWin * 3];
   __shared__ int gmin_s[kThreads / 64];
   const int chunk = blockIdx.x;
+  const int r0 = redo[2 * chunk], r1 = redo[2 * chunk + 1];     // halves the gather kernel could not take
+  if (!r0 && !r1) return;
   const int c = dp.chunk_cam[chunk];
-  const bool active = (int)threadIdx.x < dp.chunk_count[chunk];
+  const bool active = (int)threadIdx.x < dp.chunk_count[chunk] && (threadIdx.x < kThreads / 2 ? r0 : r1);
   const long long i = dp.chunk_start[chunk] + (active ? threadIdx.x : 0);
   const long long a0 = dp.det_off[c], Mc = dp.det_off[c + 1] - a0;
   const int g = active ? span[i] : -1;
@@ -172,6 +174,118 @@ __global__ __launch_bounds__(kThreads) void k_assemble(DevProblem dp, const doub
     const int gg = g0 + k / 36, w = (k / 9) % 4;
     const double v = Cw[k];
     if (gg < ne.N && v != 0.0) unsafeAtomicAdd(&ne.Cb[((long long)gg * ne.W + w) * 9 + (k % 9)], v);
+  }
+}
+
+// ---- assembly of the detection rows, gather form --------------------------------------------------------
+// One workgroup per HALF chunk (<=128 consecutive detections of one camera).  The 2*NS Jacobian slots and the two
+// residuals of those detections are staged in LDS (row stride padded to 129 doubles: bank-conflict free);
+// detections of one knot span occupy one contiguous index range, so every output entry -- camera block, gradient,
+// cross block E, spline band C -- is owned by exactly one thread, which sums the (at most four) span ranges that
+// touch it and issues ONE global fp64 atomic.  No LDS atomics (fp64 ds_add measured at ~8 cycles per lane), no
+// shuffles.  Chunks whose spans interleave or overflow the window are handled by k_assemble (atomic form).
+constexpr int kGaObs = 128, kGaWin = 96, kGaStride = kGaObs + 1;
+template <int NS>
+__global__ __launch_bounds__(kThreads) void k_assemble_gather(DevProblem dp, const double* __restrict__ J, const int32_t* __restrict__ span,
+                                                              const double* __restrict__ f, NEView ne, int* __restrict__ redo) {
+  constexpr int B = NS - 12;
+  __shared__ double Js[(2 * NS + 2) * kGaStride];     // rows 0..NS-1: x-row slots, NS..2NS-1: y-row slots, then fx, fy
+  __shared__ int lo[kGaWin], hi[kGaWin];
+  __shared__ int g0_s, bad_s, lmax_s;
+  const int chunk = blockIdx.x >> 1, half = blockIdx.x & 1;
+  const int c = dp.chunk_cam[chunk];
+  const int cnt = min(kGaObs, dp.chunk_count[chunk] - half * kGaObs);
+  if (cnt <= 0) return;
+  const long long i0 = dp.chunk_start[chunk] + half * kGaObs;
+  const long long a0 = dp.det_off[c], Mc = dp.det_off[c + 1] - a0;
+  const int tid = threadIdx.x;
+  if (tid == 0) { g0_s = 0x7fffffff; bad_s = 0; lmax_s = -1; }
+  for (int k = tid; k < kGaWin; k += kThreads) { lo[k] = 0x7fffffff; hi[k] = 0; }
+  __syncthreads();
+  const int t = tid & (kGaObs - 1);                    // detection handled while staging
+  const int g = t < cnt ? span[i0 + t] : -1;
+  if (tid < kGaObs && g >= 0) atomicMin(&g0_s, g);
+  // stage: thread (tid) loads rows tid/128, tid/128+2, ... for detection t
+  for (int r = tid >> 7; r < 2 * NS + 2; r += 2) {
+    double v = 0.0;
+    if (g >= 0) {
+      if (r < 2 * NS) v = J[(long long)r * dp.M + i0 + t];
+      else v = f[2 * a0 + (r - 2 * NS) * Mc + (i0 + t - a0)];
+    }
+    Js[r * kGaStride + t] = v;
+  }
+  __syncthreads();
+  const int g0 = g0_s;
+  if (g0 == 0x7fffffff) return;                        // nothing visible (uniform)
+  if (tid < kGaObs && g >= 0) {
+    const int l = g - g0;
+    if (l + 3 >= kGaWin) atomicOr(&bad_s, 1);
+    else { atomicMin(&lo[l], t); atomicMax(&hi[l], t + 1); atomicMax(&lmax_s, l); }
+  }
+  __syncthreads();
+  if (tid < kGaWin && hi[tid] > 0)
+    for (int u = tid + 1; u < kGaWin; ++u)
+      if (hi[u] > 0) { if (lo[u] < hi[tid]) atomicOr(&bad_s, 1); break; }
+  __syncthreads();
+  if (bad_s) { if (tid == 0) redo[blockIdx.x] = 1; return; }
+  const int nctrl = lmax_s + 4;                        // local control points 0 .. lmax+3
+  const double* fxs = Js + (2 * NS) * kGaStride;
+  const double* fys = fxs + kGaStride;
+  // camera block (lower triangle) and camera gradient: full-range sums
+  for (int o = tid; o < B * (B + 1) / 2 + B; o += kThreads) {
+    double acc = 0.0;
+    if (o < B) {
+      const double* jxa = Js + o * kGaStride; const double* jya = Js + (NS + o) * kGaStride;
+      for (int u = 0; u < cnt; ++u) acc += jxa[u] * fxs[u] + jya[u] * fys[u];
+      if (acc != 0.0) unsafeAtomicAdd(&ne.gc[c * B + o], acc);
+    } else {
+      int e = o - B, ra = 0;
+      while ((ra + 1) * (ra + 2) / 2 <= e) ++ra;
+      const int rb = e - ra * (ra + 1) / 2;
+      const double* jxa = Js + ra * kGaStride; const double* jya = Js + (NS + ra) * kGaStride;
+      const double* jxb = Js + rb * kGaStride; const double* jyb = Js + (NS + rb) * kGaStride;
+      for (int u = 0; u < cnt; ++u) acc += jxa[u] * jxb[u] + jya[u] * jyb[u];
+      if (acc != 0.0) {
+        unsafeAtomicAdd(&ne.A[((long long)c * B + ra) * B + rb], acc);
+        if (ra != rb) unsafeAtomicAdd(&ne.A[((long long)c * B + rb) * B + ra], acc);
+      }
+    }
+  }
+  // spline gradient + cross block: output (lc, d, k), k = B means the gradient entry
+  const int nE = nctrl * 3 * (B + 1);
+  for (int o = tid; o < nE; o += kThreads) {
+    const int k = o % (B + 1), ld = o / (B + 1), d = ld % 3, lc = ld / 3;
+    const double* cx = k < B ? Js + k * kGaStride : fxs;
+    const double* cy = k < B ? Js + (NS + k) * kGaStride : fys;
+    double acc = 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int s_ = lc - q;
+      if (s_ < 0 || s_ >= kGaWin) continue;
+      const int b = lo[s_], e = hi[s_];
+      const double* sx = Js + (B + 3 * q + d) * kGaStride; const double* sy = Js + (NS + B + 3 * q + d) * kGaStride;
+      for (int u = b; u < e; ++u) acc += cx[u] * sx[u] + cy[u] * sy[u];
+    }
+    if (acc != 0.0) {
+      const int r = 3 * (g0 + lc) + d;
+      if (k < B) unsafeAtomicAdd(&ne.Et[((long long)c * ne.N3 + r) * B + k], acc);
+      else unsafeAtomicAdd(&ne.gs[r], acc);
+    }
+  }
+  // spline band: output (lc, w, d, d2) = block (ctrl lc, ctrl lc+w)
+  const int nC = nctrl * 36;
+  for (int o = tid; o < nC; o += kThreads) {
+    const int d2 = o % 3, d = (o / 3) % 3, w = (o / 9) % 4, lc = o / 36;
+    double acc = 0.0;
+    for (int q = 0; q + w < 4; ++q) {
+      const int s_ = lc - q;
+      if (s_ < 0 || s_ >= kGaWin) continue;
+      const int b = lo[s_], e = hi[s_];
+      const double* ax = Js + (B + 3 * q + d) * kGaStride; const double* ay = Js + (NS + B + 3 * q + d) * kGaStride;
+      const double* bx = Js + (B + 3 * (q + w) + d2) * kGaStride; const double* by = Js + (NS + B + 3 * (q + w) + d2) * kGaStride;
+      for (int u = b; u < e; ++u) acc += ax[u] * bx[u] + ay[u] * by[u];
+    }
+    if (acc != 0.0) unsafeAtomicAdd(&ne.Cb[((long long)(g0 + lc) * ne.W + w) * 9 + 3 * d + d2], acc);
   }
 }
 
@@ -845,6 +959,7 @@ struct HipSchur {
   int* fail_host = nullptr;
   PartView pv{};
   int* part_tables = nullptr;
+  int* redo = nullptr;      // per half chunk: 1 = the gather assembly deferred it to the atomic kernel
 
   explicit HipSchur(BE& b) : be(b) {
     const HostProblem& hp = be.hp;
@@ -874,6 +989,7 @@ struct HipSchur {
     D = be.alloc(hp.n); gx = be.alloc(hp.n); px = be.alloc(hp.n);
     MVUS_HIP(hipMalloc(reinterpret_cast<void**>(&fail), sizeof(int)));
     MVUS_HIP(hipHostMalloc(reinterpret_cast<void**>(&fail_host), sizeof(int), hipHostMallocDefault));
+    MVUS_HIP(hipMalloc(reinterpret_cast<void**>(&redo), sizeof(int) * 2 * std::max(be.dp.n_chunks, 1)));
     // partition of the control-point chain: interiors of kPartL control points, separators of W-1
     const int sctrl = W - 1;
     std::vector<int> i0, i1, s0;
@@ -901,6 +1017,7 @@ struct HipSchur {
   ~HipSchur() {
     for (double* p : {Erm, NE, Lb, Z, G, S, rhs, pc, D, gx, px, pv.VW, pv.T, pv.U}) be.release(p);
     if (part_tables) (void)hipFree(part_tables);
+    if (redo) (void)hipFree(redo);
     if (fail) (void)hipFree(fail);
     if (fail_host) (void)hipHostFree(fail_host);
   }
@@ -908,8 +1025,15 @@ struct HipSchur {
   void assemble_local(const double* f_dev) {
     MVUS_HIP(hipMemsetAsync(NE, 0, ne_count * sizeof(double), be.stream));
     if (be.dp.n_chunks > 0) {
-      if (be.hp.calib) hipLaunchKernelGGL(k_assemble<30>, dim3(be.dp.n_chunks), dim3(kThreads), 0, be.stream, be.dp, be.J, be.span, f_dev, ne);
-      else hipLaunchKernelGGL(k_assemble<21>, dim3(be.dp.n_chunks), dim3(kThreads), 0, be.stream, be.dp, be.J, be.span, f_dev, ne);
+      const int nc = be.dp.n_chunks;
+      MVUS_HIP(hipMemsetAsync(redo, 0, sizeof(int) * 2 * nc, be.stream));
+      if (be.hp.calib) {
+        hipLaunchKernelGGL(k_assemble_gather<30>, dim3(2 * nc), dim3(kThreads), 0, be.stream, be.dp, be.J, be.span, f_dev, ne, redo);
+        hipLaunchKernelGGL(k_assemble<30>, dim3(nc), dim3(kThreads), 0, be.stream, be.dp, be.J, be.span, f_dev, ne, redo);
+      } else {
+        hipLaunchKernelGGL(k_assemble_gather<21>, dim3(2 * nc), dim3(kThreads), 0, be.stream, be.dp, be.J, be.span, f_dev, ne, redo);
+        hipLaunchKernelGGL(k_assemble<21>, dim3(nc), dim3(kThreads), 0, be.stream, be.dp, be.J, be.span, f_dev, ne, redo);
+      }
     }
     if (be.hp.T > 0)
       hipLaunchKernelGGL(k_assemble_motion, dim3((be.hp.T + kThreads - 1) / kThreads), dim3(kThreads), 0, be.stream, be.dp, be.mJ, be.mctrl,
