@@ -35,146 +35,49 @@ __device__ __forceinline__ int wave_min_i(int v) {
   return v;
 }
 
-// ---- assembly of the detection rows ------------------------------------------------------------------
-// One workgroup per chunk of <=256 detections of one camera.  Camera block: wavefront shuffle reduction.
-// Spline / cross terms: fp64 LDS atomics into a window of kNWin control points starting at the chunk's
-// smallest span (neighbouring lanes = neighbouring timestamps = same few control points), flushed once with
-// global atomics; lanes outside the window (sparse detections) fall back to global atomics.
+// ---- assembly of the detection rows, atomic form (fallback) ---------------------------------------------------
+// Only for the half chunks the gather kernel below defers (`redo` flag: knot spans that interleave in index order, or
+// more spans than the window holds -- sparse or badly ordered detections): one thread per detection adds its
+// contributions straight into the global blocks with fp64 atomics.  Rare, so simplicity beats speed here.
 template <int NS>
 __global__ __launch_bounds__(kThreads) void k_assemble(DevProblem dp, const double* __restrict__ J, const int32_t* __restrict__ span,
                                                        const double* __restrict__ f, NEView ne, const int* __restrict__ redo) {
   constexpr int B = NS - 12;
-  __shared__ double Aw[B * B];
-  __shared__ double gcw[B];
-  __shared__ double Ew[kNWin * 3 * B];
-  __shared__ double Cw[kNWin * 4 * 9];
-  __shared__ double gsw[kNWin * 3];
-  __shared__ int gmin_s[kThreads / 64];
   const int chunk = blockIdx.x;
-  const int r0 = redo[2 * chunk], r1 = redo[2 * chunk + 1];     // halves the gather kernel could not take
+  const int r0 = redo[2 * chunk], r1 = redo[2 * chunk + 1];
   if (!r0 && !r1) return;
   const int c = dp.chunk_cam[chunk];
-  const bool active = (int)threadIdx.x < dp.chunk_count[chunk] && (threadIdx.x < kThreads / 2 ? r0 : r1);
-  const long long i = dp.chunk_start[chunk] + (active ? threadIdx.x : 0);
+  if ((int)threadIdx.x >= dp.chunk_count[chunk] || !(threadIdx.x < kThreads / 2 ? r0 : r1)) return;
+  const long long i = dp.chunk_start[chunk] + threadIdx.x;
   const long long a0 = dp.det_off[c], Mc = dp.det_off[c + 1] - a0;
-  const int g = active ? span[i] : -1;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int k = threadIdx.x; k < B * B; k += kThreads) Aw[k] = 0.0;
-  for (int k = threadIdx.x; k < B; k += kThreads) gcw[k] = 0.0;
-  for (int k = threadIdx.x; k < kNWin * 3 * B; k += kThreads) Ew[k] = 0.0;
-  for (int k = threadIdx.x; k < kNWin * 36; k += kThreads) Cw[k] = 0.0;
-  for (int k = threadIdx.x; k < kNWin * 3; k += kThreads) gsw[k] = 0.0;
-  int gm = wave_min_i(g >= 0 ? g : 0x7fffffff);
-  if (lane == 0) gmin_s[wave] = gm;
-  __syncthreads();
-  int g0 = gmin_s[0];
-#pragma unroll
-  for (int w = 1; w < kThreads / 64; ++w) g0 = min(g0, gmin_s[w]);
-  if (g0 == 0x7fffffff) return;   // nothing visible in this chunk (uniform)
-
+  const int g = span[i];
+  if (g < 0) return;
   double jx[NS], jy[NS];
-  double fx = 0.0, fy = 0.0;
-  if (g >= 0) {
 #pragma unroll
-    for (int k = 0; k < NS; ++k) { jx[k] = J[(long long)k * dp.M + i]; jy[k] = J[(long long)(NS + k) * dp.M + i]; }
-    fx = f[2 * a0 + (i - a0)];
-    fy = f[2 * a0 + Mc + (i - a0)];
-  } else {
-#pragma unroll
-    for (int k = 0; k < NS; ++k) { jx[k] = 0.0; jy[k] = 0.0; }
-  }
-  // camera block (lower triangle incl. diagonal, mirrored at flush) and camera gradient
+  for (int k = 0; k < NS; ++k) { jx[k] = J[(long long)k * dp.M + i]; jy[k] = J[(long long)(NS + k) * dp.M + i]; }
+  const double fx = f[2 * a0 + (i - a0)], fy = f[2 * a0 + Mc + (i - a0)];
 #pragma unroll
   for (int a = 0; a < B; ++a) {
-    double v = wave_sum(jx[a] * fx + jy[a] * fy);
-    if (lane == 0) unsafeAtomicAdd(&gcw[a], v);
+    unsafeAtomicAdd(&ne.gc[c * B + a], jx[a] * fx + jy[a] * fy);
 #pragma unroll
-    for (int b = 0; b <= a; ++b) {
-      v = wave_sum(jx[a] * jx[b] + jy[a] * jy[b]);
-      if (lane == 0) unsafeAtomicAdd(&Aw[a * B + b], v);
+    for (int b = 0; b < B; ++b) unsafeAtomicAdd(&ne.A[((long long)c * B + a) * B + b], jx[a] * jx[b] + jy[a] * jy[b]);
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const int sq = B + 3 * q + d;
+      const double vx = jx[sq], vy = jy[sq];
+      const long long r = 3 * (g + q) + d;
+      unsafeAtomicAdd(&ne.gs[r], vx * fx + vy * fy);
+#pragma unroll
+      for (int k = 0; k < B; ++k) unsafeAtomicAdd(&ne.Et[((long long)c * ne.N3 + r) * B + k], jx[k] * vx + jy[k] * vy);
+#pragma unroll
+      for (int q2 = q; q2 < 4; ++q2)
+#pragma unroll
+        for (int d2 = 0; d2 < 3; ++d2)
+          unsafeAtomicAdd(&ne.Cb[((long long)(g + q) * ne.W + (q2 - q)) * 9 + 3 * d + d2], vx * jx[B + 3 * q2 + d2] + vy * jy[B + 3 * q2 + d2]);
     }
-  }
-  // Spline / cross terms.  Neighbouring lanes hold neighbouring timestamps, i.e. runs of lanes share the same four
-  // control points; same-address fp64 LDS atomics serialise badly (measured: 1.08 of 1.16 ms), so every quantity is
-  // first summed over its run with a wavefront segmented scan and only the run's last lane adds it -- all lanes
-  // of one ds_add_f64 then hit distinct addresses.
-  {
-    const int gprev = __shfl_up(g, 1, 64), gnext = __shfl_down(g, 1, 64);
-    const bool head = lane == 0 || gprev != g;
-    const bool tail = (lane == 63 || gnext != g) && g >= 0;
-    int start = head ? lane : 0;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) { const int s2 = __shfl_up(start, off, 64); if (lane >= off) start = max(start, s2); }
-    // scan depth: runs are short (a few detections per knot span), so stop after ceil(log2(longest run)) steps
-    int runlen = lane - start + 1;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) runlen = max(runlen, __shfl_xor(runlen, off, 64));
-    const int maxrun = __builtin_amdgcn_readfirstlane(runlen);
-    auto seg = [&](double v) {
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) { if (off >= maxrun) break; const double u = __shfl_up(v, off, 64); if (lane - off >= start) v += u; }
-      return v;
-    };
-    const int l = g - g0;
-    const bool inwin = l + 3 < kNWin;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-#pragma unroll
-      for (int d = 0; d < 3; ++d) {
-        const int sq = B + 3 * q + d;
-        const double vx = jx[sq], vy = jy[sq];
-        const double gval = seg(vx * fx + vy * fy);
-        if (tail) {
-          if (inwin) unsafeAtomicAdd(&gsw[3 * (l + q) + d], gval);
-          else unsafeAtomicAdd(&ne.gs[3 * (g + q) + d], gval);
-        }
-#pragma unroll
-        for (int k = 0; k < B; ++k) {
-          const double ev = seg(jx[k] * vx + jy[k] * vy);
-          if (tail) {
-            if (inwin) unsafeAtomicAdd(&Ew[(3 * (l + q) + d) * B + k], ev);
-            else unsafeAtomicAdd(&ne.Et[((long long)c * ne.N3 + 3 * (g + q) + d) * B + k], ev);
-          }
-        }
-#pragma unroll
-        for (int q2 = q; q2 < 4; ++q2) {
-#pragma unroll
-          for (int d2 = 0; d2 < 3; ++d2) {
-            const int s2 = B + 3 * q2 + d2;
-            const double cv = seg(vx * jx[s2] + vy * jy[s2]);
-            if (tail) {
-              if (inwin) unsafeAtomicAdd(&Cw[((l + q) * 4 + (q2 - q)) * 9 + 3 * d + d2], cv);
-              else unsafeAtomicAdd(&ne.Cb[((long long)(g + q) * ne.W + (q2 - q)) * 9 + 3 * d + d2], cv);
-            }
-          }
-        }
-      }
-    }
-  }
-  __syncthreads();
-  for (int k = threadIdx.x; k < B * B; k += kThreads) {
-    const int a = k / B, b = k % B;
-    const double v = a >= b ? Aw[a * B + b] : Aw[b * B + a];
-    if (v != 0.0) unsafeAtomicAdd(&ne.A[((long long)c * B + a) * B + b], v);
-  }
-  for (int k = threadIdx.x; k < B; k += kThreads) if (gcw[k] != 0.0) unsafeAtomicAdd(&ne.gc[c * B + k], gcw[k]);
-  for (int k = threadIdx.x; k < kNWin * 3; k += kThreads) {
-    const int r = 3 * g0 + k;
-    if (r < ne.N3 && gsw[k] != 0.0) unsafeAtomicAdd(&ne.gs[r], gsw[k]);
-  }
-  {
-    double* Ecam = ne.Et + ((long long)c * ne.N3 + 3 * g0) * B;       // contiguous window of this camera
-    const int lim = min(kNWin * 3, ne.N3 - 3 * g0) * B;
-    for (int k = threadIdx.x; k < lim; k += kThreads) {
-      const double v = Ew[k];
-      if (v != 0.0) unsafeAtomicAdd(&Ecam[k], v);
-    }
-  }
-  for (int k = threadIdx.x; k < kNWin * 36; k += kThreads) {
-    const int gg = g0 + k / 36, w = (k / 9) % 4;
-    const double v = Cw[k];
-    if (gg < ne.N && v != 0.0) unsafeAtomicAdd(&ne.Cb[((long long)gg * ne.W + w) * 9 + (k % 9)], v);
-  }
 }
 
 // ---- assembly of the detection rows, gather form --------------------------------------------------------
