@@ -526,7 +526,7 @@ __global__ __launch_bounds__(64) void k_sep_factor(PartView pv, int* __restrict_
       }
       __syncthreads();
     }
-    for (int e = lane; e < S3 * S3; e += 64) Tq[e] = Cq[e];
+    for (int e = lane; e < S3 * S3; e += 64) Tq[e] = (e / S3 == e % S3) ? 1.0 / Cq[e] : Cq[e];      // diagonal inverted for k_sep_rhs
     if (q + 1 < nq) {
       if (lane < S3) {                       // row `lane` of L(q+1,q): solve C_q l = U_q[:, lane]
         double l[S3];
@@ -544,19 +544,27 @@ __global__ __launch_bounds__(64) void k_sep_factor(PartView pv, int* __restrict_
   }
 }
 
-// forward / backward substitution of every right-hand side through the factored separator system:
-// one thread per column, no synchronisation (the factors are read-only, broadcast through the caches)
+// forward / backward substitution of every right-hand side through the factored separator system: one thread per
+// column, no synchronisation (the factors are read-only and identical for all lanes, so they are fetched as
+// broadcasts through the caches); the next step's right-hand-side rows are fetched before the current step's
+// dependent chain, and the diagonal of C_q is stored inverted (k_sep_factor) so the chain has no divisions.
 template <int S3>
 __global__ __launch_bounds__(64) void k_sep_rhs(PartView pv, int ncols, double* __restrict__ Z) {
   const int col = blockIdx.x * blockDim.x + threadIdx.x;
   if (col >= ncols) return;
   const int nq = pv.P - 1;
-  double prev[S3], rv[S3];
+  double prev[S3], rv[S3], nx[S3];
+#pragma unroll
+  for (int a = 0; a < S3; ++a) { prev[a] = 0.0; nx[a] = Z[(long long)(pv.s0[0] + a) * ncols + col]; }
   for (int q = 0; q < nq; ++q) {
     const double* __restrict__ Cq = pv.T + (long long)q * S3 * S3;
     const double* __restrict__ Lq = pv.U + (long long)(q - 1) * S3 * S3;     // L(q, q-1)
 #pragma unroll
-    for (int a = 0; a < S3; ++a) rv[a] = Z[(long long)(pv.s0[q] + a) * ncols + col];
+    for (int a = 0; a < S3; ++a) rv[a] = nx[a];
+    if (q + 1 < nq) {
+#pragma unroll
+      for (int a = 0; a < S3; ++a) nx[a] = Z[(long long)(pv.s0[q + 1] + a) * ncols + col];
+    }
     if (q > 0) {
 #pragma unroll
       for (int a = 0; a < S3; ++a)
@@ -568,16 +576,22 @@ __global__ __launch_bounds__(64) void k_sep_rhs(PartView pv, int ncols, double* 
       double sacc = rv[a];
 #pragma unroll
       for (int jj = 0; jj < S3; ++jj) if (jj < a) sacc -= Cq[a * S3 + jj] * rv[jj];
-      rv[a] = sacc / Cq[a * S3 + a];
+      rv[a] = sacc * Cq[a * S3 + a];            // diagonal stored as 1 / C(a,a)
     }
 #pragma unroll
     for (int a = 0; a < S3; ++a) { prev[a] = rv[a]; Z[(long long)(pv.s0[q] + a) * ncols + col] = rv[a]; }
   }
+#pragma unroll
+  for (int a = 0; a < S3; ++a) nx[a] = prev[a];
   for (int q = nq - 1; q >= 0; --q) {
     const double* __restrict__ Cq = pv.T + (long long)q * S3 * S3;
     const double* __restrict__ Ln = pv.U + (long long)q * S3 * S3;           // L(q+1, q)
 #pragma unroll
-    for (int a = 0; a < S3; ++a) rv[a] = Z[(long long)(pv.s0[q] + a) * ncols + col];
+    for (int a = 0; a < S3; ++a) rv[a] = nx[a];
+    if (q > 0) {
+#pragma unroll
+      for (int a = 0; a < S3; ++a) nx[a] = Z[(long long)(pv.s0[q - 1] + a) * ncols + col];
+    }
     if (q + 1 < nq) {
 #pragma unroll
       for (int k = 0; k < S3; ++k)
@@ -589,7 +603,7 @@ __global__ __launch_bounds__(64) void k_sep_rhs(PartView pv, int ncols, double* 
       double sacc = rv[a];
 #pragma unroll
       for (int jj = 0; jj < S3; ++jj) if (jj > a) sacc -= Cq[jj * S3 + a] * rv[jj];
-      rv[a] = sacc / Cq[a * S3 + a];
+      rv[a] = sacc * Cq[a * S3 + a];
     }
 #pragma unroll
     for (int a = 0; a < S3; ++a) { prev[a] = rv[a]; Z[(long long)(pv.s0[q] + a) * ncols + col] = rv[a]; }
@@ -726,10 +740,10 @@ __global__ void k_schur_finish(NEView ne, int ncols, double lambda, const double
 constexpr int kNB = 32;
 
 // Cholesky of the kNB x kNB diagonal block by ONE wavefront in LDS (no workgroup barriers across 16 wavefronts)
-__global__ __launch_bounds__(64) void k_potrf_diag(int nn, int kb, double* __restrict__ Sa, int* __restrict__ fail) {
+__global__ __launch_bounds__(256) void k_potrf_diag(int nn, int kb, double* __restrict__ Sa, int* __restrict__ fail) {
   __shared__ double D[kNB][kNB + 1];
   const int nb = min(kNB, nn - kb), lane = threadIdx.x;
-  for (int e = lane; e < kNB * kNB; e += 64) {
+  for (int e = lane; e < kNB * kNB; e += 256) {
     const int r = e / kNB, c = e % kNB;
     D[r][c] = (r < nb && c < nb) ? Sa[(long long)(kb + r) * nn + kb + c] : (r == c ? 1.0 : 0.0);
   }
@@ -743,13 +757,13 @@ __global__ __launch_bounds__(64) void k_potrf_diag(int nn, int kb, double* __res
     if (lane > k && lane < nb) D[lane][k] /= d;
     __syncthreads();
     const int rem = nb - k - 1;                      // trailing lower triangle, rem*(rem+1)/2 entries
-    for (int e = lane; e < rem * rem; e += 64) {
+    for (int e = lane; e < rem * rem; e += 256) {
       const int r = k + 1 + e / rem, c = k + 1 + e % rem;
       if (c <= r) D[r][c] -= D[r][k] * D[c][k];
     }
     __syncthreads();
   }
-  for (int e = lane; e < kNB * kNB; e += 64) {
+  for (int e = lane; e < kNB * kNB; e += 256) {
     const int r = e / kNB, c = e % kNB;
     if (r < nb && c < nb) Sa[(long long)(kb + r) * nn + kb + c] = (c <= r) ? D[r][c] : 0.0;
   }
@@ -989,7 +1003,7 @@ struct HipSchur {
       const int nn = ne.CB;
       for (int kb = 0; kb < nn; kb += kNB) {
         const int nb = std::min(kNB, nn - kb), below = nn + 1 - (kb + nb);       // rows under the panel incl. the rhs row
-        hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(64), 0, be.stream, nn, kb, S, fail);
+        hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(256), 0, be.stream, nn, kb, S, fail);
         hipLaunchKernelGGL(k_trsm_panel, dim3((below + kTrsmThreads - 1) / kTrsmThreads), dim3(kTrsmThreads), 0, be.stream, nn, kb, S);
         const int tiles = (below + kNB - 1) / kNB;
         hipLaunchKernelGGL(k_syrk_update, dim3(tiles, tiles), dim3(kNB * kNB), 0, be.stream, nn, kb, S);
