@@ -47,21 +47,31 @@ __global__ __launch_bounds__(kThreads) void k_assemble(DevProblem dp, const doub
   const int r0 = redo[2 * chunk], r1 = redo[2 * chunk + 1];
   if (!r0 && !r1) return;
   const int c = dp.chunk_cam[chunk];
-  if ((int)threadIdx.x >= dp.chunk_count[chunk] || !(threadIdx.x < kThreads / 2 ? r0 : r1)) return;
-  const long long i = dp.chunk_start[chunk] + threadIdx.x;
+  const bool active = (int)threadIdx.x < dp.chunk_count[chunk] && (threadIdx.x < kThreads / 2 ? r0 : r1);
+  const long long i = dp.chunk_start[chunk] + (active ? threadIdx.x : 0);
   const long long a0 = dp.det_off[c], Mc = dp.det_off[c + 1] - a0;
-  const int g = span[i];
-  if (g < 0) return;
+  const int g = active ? span[i] : -1;
+  const int lane = threadIdx.x & 63;
   double jx[NS], jy[NS];
+  double fx = 0.0, fy = 0.0;
 #pragma unroll
-  for (int k = 0; k < NS; ++k) { jx[k] = J[(long long)k * dp.M + i]; jy[k] = J[(long long)(NS + k) * dp.M + i]; }
-  const double fx = f[2 * a0 + (i - a0)], fy = f[2 * a0 + Mc + (i - a0)];
+  for (int k = 0; k < NS; ++k) { jx[k] = g >= 0 ? J[(long long)k * dp.M + i] : 0.0; jy[k] = g >= 0 ? J[(long long)(NS + k) * dp.M + i] : 0.0; }
+  if (g >= 0) { fx = f[2 * a0 + (i - a0)]; fy = f[2 * a0 + Mc + (i - a0)]; }
+  // the camera block is shared by every lane: reduce over the wavefront first, one atomic per entry and wavefront
 #pragma unroll
   for (int a = 0; a < B; ++a) {
-    unsafeAtomicAdd(&ne.gc[c * B + a], jx[a] * fx + jy[a] * fy);
+    double v = wave_sum(jx[a] * fx + jy[a] * fy);
+    if (lane == 0 && v != 0.0) unsafeAtomicAdd(&ne.gc[c * B + a], v);
 #pragma unroll
-    for (int b = 0; b < B; ++b) unsafeAtomicAdd(&ne.A[((long long)c * B + a) * B + b], jx[a] * jx[b] + jy[a] * jy[b]);
+    for (int b = 0; b <= a; ++b) {
+      v = wave_sum(jx[a] * jx[b] + jy[a] * jy[b]);
+      if (lane == 0 && v != 0.0) {
+        unsafeAtomicAdd(&ne.A[((long long)c * B + a) * B + b], v);
+        if (a != b) unsafeAtomicAdd(&ne.A[((long long)c * B + b) * B + a], v);
+      }
+    }
   }
+  if (g < 0) return;
 #pragma unroll
   for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -951,6 +961,12 @@ struct HipSchur {
         hipLaunchKernelGGL(k_assemble_gather<21>, dim3(2 * nc), dim3(kThreads), 0, be.stream, be.dp, be.J, be.span, f_dev, ne, redo);
         hipLaunchKernelGGL(k_assemble<21>, dim3(nc), dim3(kThreads), 0, be.stream, be.dp, be.J, be.span, f_dev, ne, redo);
       }
+    }
+    if (std::getenv("MVUS_DEBUG") && be.dp.n_chunks > 0) {
+      std::vector<int> rh(2 * be.dp.n_chunks);
+      MVUS_HIP(hipMemcpy(rh.data(), redo, sizeof(int) * rh.size(), hipMemcpyDeviceToHost));
+      int cntf = 0; for (int v : rh) cntf += v != 0;
+      std::fprintf(stderr, "assemble: %d of %zu half chunks deferred to the atomic kernel\n", cntf, rh.size());
     }
     if (be.hp.T > 0)
       hipLaunchKernelGGL(k_assemble_motion, dim3((be.hp.T + kThreads - 1) / kThreads), dim3(kThreads), 0, be.stream, be.dp, be.mJ, be.mctrl,
