@@ -70,6 +70,7 @@ struct HipBackend {
     dp.H = dupload(hp.H); dp.Kfix = dupload(hp.K); dp.dfix = dupload(hp.dist);
     dp.sp.S = hp.S; dp.sp.istart = dupload(hp.istart); dp.sp.iend = dupload(hp.iend); dp.sp.knots = dupload(hp.knots);
     dp.sp.knot_off = dupload(hp.knot_off); dp.sp.ctrl_off = dupload(hp.ctrl_off); dp.sp.xoff = dupload(hp.xoff);
+    dp.sp.lut = dupload(hp.lut); dp.sp.lut_off = dupload(hp.lut_off); dp.sp.lut_scale = dupload(hp.lut_scale);
     dp.mv.T = hp.T; dp.mv.type = hp.motion_type; dp.mv.w = hp.w;
     dp.mv.t = dupload(hp.ms_t); dp.mv.basis = dupload(hp.ms_basis); dp.mv.ctrl = dupload(hp.ms_ctrl);
     dp.mv.part = dupload(hp.ms_part); dp.mv.pat = dupload(hp.ms_pat);

@@ -198,7 +198,24 @@ struct SplineView {
   const int32_t* knot_off;  // [S+1] offsets into knots
   const int32_t* ctrl_off;  // [S+1] cumulative number of control points (global control index base)
   const int32_t* xoff;      // [S]  index in x of spline s coefficient block: cx(n_s) cy(n_s) cz(n_s)
+  // optional span look-up table (nullptr -> binary search): per spline a uniform grid over [start, end] whose
+  // cell b stores the span of the cell's left edge, so the search is one table read plus ~1 forward step
+  const int32_t* lut;       // concatenated tables
+  const int32_t* lut_off;   // [S+1]
+  const double* lut_scale;  // [S] cells per unit time
 };
+
+// Same result as find_span, through the look-up table when the view carries one.
+MVUS_HD int find_span_lut(const SplineView& sp, int s, const double* t, int n, double x) {
+  if (!sp.lut) return find_span(t, n, x);
+  const int nb = sp.lut_off[s + 1] - sp.lut_off[s];
+  int b = (int)((x - t[3]) * sp.lut_scale[s]);
+  b = b < 0 ? 0 : (b >= nb ? nb - 1 : b);
+  int l = sp.lut[sp.lut_off[s] + b];
+  while (l > 3 && t[l] > x) --l;                 // rounding of the cell index can land one cell too far
+  while (l + 1 < n && t[l + 1] <= x) ++l;
+  return l;
+}
 
 struct ObsResult {
   double ex, ey;     // |residual| per axis (0 when not visible)
@@ -220,7 +237,7 @@ MVUS_HD ObsResult eval_observation(const CamState& cam, const SplineView& sp, co
   if (s < 0) return out;
   const double* t = sp.knots + sp.knot_off[s];
   const int n = sp.ctrl_off[s + 1] - sp.ctrl_off[s];
-  const int l = find_span(t, n, tau);
+  const int l = find_span_lut(sp, s, t, n, tau);
   double h[4], dh[4];
   bspline_basis<JAC>(t, l, tau, h, dh);
   const double* cx_ = x + sp.xoff[s] + (l - 3);

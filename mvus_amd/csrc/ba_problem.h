@@ -24,13 +24,16 @@ struct HostProblem {
   std::vector<int64_t> det_off;
   std::vector<double> frame, u_raw, v_raw, H, K, dist, istart, iend, knots;
   std::vector<int32_t> knot_off, ctrl_off, xoff, ctrl_x0, ctrl_stride;
+  std::vector<int32_t> lut, lut_off;
+  std::vector<double> lut_scale;
   std::vector<int32_t> chunk_cam, chunk_count;
   std::vector<int64_t> chunk_start;
   std::vector<double> ms_t, ms_basis;
   std::vector<int32_t> ms_ctrl, ms_part, ms_pat;
 
   SplineView spline_view() const {
-    return SplineView{S, istart.data(), iend.data(), knots.data(), knot_off.data(), ctrl_off.data(), xoff.data()};
+    return SplineView{S, istart.data(), iend.data(), knots.data(), knot_off.data(), ctrl_off.data(), xoff.data(),
+                      lut.data(), lut_off.data(), lut_scale.data()};
   }
   MotionView motion_view() const {
     return MotionView{T, motion_type, w, ms_t.data(), ms_basis.data(), ms_ctrl.data(), ms_part.data(), ms_pat.data(),
@@ -94,6 +97,17 @@ struct HostProblem {
     ctrl_x0.resize(N); ctrl_stride.resize(N);
     for (int s = 0; s < S; ++s)
       for (int g = ctrl_off[s]; g < ctrl_off[s + 1]; ++g) { ctrl_x0[g] = xoff[s] + (g - ctrl_off[s]); ctrl_stride[g] = ctrl_off[s + 1] - ctrl_off[s]; }
+    // span look-up tables: 2 cells per control point
+    lut.clear(); lut_off.assign(S + 1, 0); lut_scale.assign(S, 0.0);
+    for (int s = 0; s < S; ++s) {
+      const double* t = knots.data() + knot_off[s];
+      const int ns = ctrl_off[s + 1] - ctrl_off[s];
+      const int nb = 2 * ns;
+      const double t0 = t[3], t1 = t[ns];
+      lut_scale[s] = nb / (t1 - t0);
+      for (int b = 0; b < nb; ++b) lut.push_back(find_span(t, ns, t0 + b / lut_scale[s]));
+      lut_off[s + 1] = (int32_t)lut.size();
+    }
     // launch chunks
     chunk_cam.clear(); chunk_start.clear(); chunk_count.clear();
     for (int c = 0; c < C; ++c)
