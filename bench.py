@@ -89,11 +89,18 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (the BA hot path has no CPU fallback)')
+    # MVUS_BENCH_ONE_DEVICE=1 (flow test on a 1-GPU box): every rank uses cuda:0 and gloo carries the sums
+    one_device = os.environ.get('MVUS_BENCH_ONE_DEVICE') == '1'
+    if one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+        if one_device:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
 
     from mvus_amd import problem as mp, synth
     from mvus_amd import ba

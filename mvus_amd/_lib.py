@@ -91,6 +91,14 @@ def load(path=None):
         raise RuntimeError(
             'libmvusba.so is not built (%s). Build it with `python -c "import __graft_entry__ as g; g.build()"` '
             'or `make -C mvus_amd/csrc`. mvus_amd has no CPU fallback for the BA hot path.' % p)
+    # PyTorch-ROCm wheels bundle their own libamdhip64; if libmvusba.so pulls in /opt/rocm's copy first, a later
+    # `import torch` in the same process finds no GPU (observed: "ProcessGroupNCCL ... no GPUs found").  Let torch's
+    # runtime initialise first whenever torch is installed, so both share one HIP runtime.
+    try:
+        import torch
+        torch.cuda.is_available()
+    except ImportError:
+        pass
     lib = ctypes.CDLL(p)
     for name, restype, argtypes in API:
         fn = getattr(lib, name)          # AttributeError here = header/library mismatch

@@ -510,15 +510,34 @@ __global__ __launch_bounds__(64) void k_sep_factor(PartView pv, int* __restrict_
   __shared__ double Lq[S3 * S3];
   __shared__ double Uq[S3 * S3];
   const int nq = pv.P - 1, lane = threadIdx.x;
+  constexpr int kPer = (S3 * S3 + 63) / 64;          // entries of T_q / U_q held per lane
+  double tn[kPer], un[kPer];                         // next step's blocks, fetched one step ahead
+#pragma unroll
+  for (int r = 0; r < kPer; ++r) {
+    const int e = lane + 64 * r;
+    tn[r] = (nq > 0 && e < S3 * S3) ? pv.T[e] : 0.0;
+    un[r] = (nq > 0 && e < S3 * S3) ? pv.U[e] : 0.0;
+  }
   for (int q = 0; q < nq; ++q) {
     double* Tq = pv.T + (long long)q * S3 * S3;
     double* Ug = pv.U + (long long)q * S3 * S3;
-    for (int e = lane; e < S3 * S3; e += 64) {
-      const int a = e / S3, b = e % S3;
-      double v = Tq[e];
-      if (q > 0) for (int k = 0; k < S3; ++k) v -= Lq[a * S3 + k] * Lq[b * S3 + k];
-      Cq[e] = v;
-      Uq[e] = Ug[e];
+#pragma unroll
+    for (int r = 0; r < kPer; ++r) {
+      const int e = lane + 64 * r;
+      if (e < S3 * S3) {
+        const int a = e / S3, b = e % S3;
+        double v = tn[r];
+        if (q > 0) for (int k = 0; k < S3; ++k) v -= Lq[a * S3 + k] * Lq[b * S3 + k];
+        Cq[e] = v;
+        Uq[e] = un[r];
+      }
+    }
+    if (q + 1 < nq) {
+#pragma unroll
+      for (int r = 0; r < kPer; ++r) {
+        const int e = lane + 64 * r;
+        if (e < S3 * S3) { tn[r] = Tq[S3 * S3 + e]; un[r] = Ug[S3 * S3 + e]; }
+      }
     }
     __syncthreads();
     // right-looking Cholesky of the S3 x S3 block, lanes over the trailing entries
