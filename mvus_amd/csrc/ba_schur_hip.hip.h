@@ -423,15 +423,24 @@ __global__ __launch_bounds__(64) void k_part_cholesky(PartView pv, double* __res
   }
 }
 
-// interior solves: thread t < ncols -> right-hand side column of Z (in place); t >= ncols -> coupling column
+// interior solves: thread t < ncols -> right-hand side column of Z (in place); t >= ncols -> coupling column.
+// The interior's factor is staged in LDS once per workgroup (entries reaching outside the interior zeroed, so the
+// substitution loops are branch free) and read as broadcasts; the next row's right-hand side is fetched before the
+// current row's dependent chain.
 template <int BW>
 __global__ __launch_bounds__(64) void k_part_solve(PartView pv, int ncols, const double* __restrict__ Lb, double* __restrict__ Z) {
   constexpr int R = BW + 1;
+  __shared__ double Ls[kPartRowsMax * R];
   const int p = blockIdx.x;
   const int t = blockIdx.y * blockDim.x + threadIdx.x;
   const int s3 = pv.s3;
+  const int r0 = pv.i0[p], r1 = pv.i1[p], nr = r1 - r0;
+  for (int e = threadIdx.x; e < nr * R; e += 64) {
+    const int row = e / R, jj = e % R;
+    Ls[e] = (jj <= row) ? Lb[(long long)r0 * R + e] : 0.0;       // column row-jj inside the interior
+  }
+  __syncthreads();
   if (t >= ncols + 2 * s3) return;
-  const int r0 = pv.i0[p], r1 = pv.i1[p];
   int kind = 0, ccol = 0;                    // 0: rhs, 1: left coupling, 2: right coupling
   if (t >= ncols) {
     const int k = t - ncols;
@@ -440,34 +449,65 @@ __global__ __launch_bounds__(64) void k_part_solve(PartView pv, int ncols, const
   }
   double* out = kind == 0 ? nullptr : pv.VW + ((long long)p * kPartRowsMax) * (2 * s3) + (t - ncols);
   const int ostride = 2 * s3;
-  double yw[BW];
+  // The rows of Z a thread walks are ncols*8 bytes apart (no cache-line reuse), so every step would wait for a fresh
+  // HBM line (~1-2 us >> the ~0.1 us of arithmetic): rows are fetched kPf at a time into registers, one batch ahead.
+  constexpr int kPf = 16;
+  double yw[BW];           // yw[0] = newest value
 #pragma unroll
   for (int j = 0; j < BW; ++j) yw[j] = 0.0;
-  for (int i = r0; i < r1; ++i) {
-    const double* Lr = Lb + (long long)i * R;
-    double acc = kind == 0 ? Z[(long long)i * ncols + t] : band_entry<BW>(Lb, i, ccol);
+  auto rhs_at = [&](int i) { return kind == 0 ? Z[(long long)(r0 + i) * ncols + t] : band_entry<BW>(Lb, r0 + i, ccol); };
+  double cur[kPf], nxt[kPf];
 #pragma unroll
-    for (int j = 1; j <= BW; ++j) acc -= (i - j >= r0 ? Lr[j] : 0.0) * yw[j - 1];
-    const double y = acc * Lr[0];
-    if (kind == 0) Z[(long long)i * ncols + t] = y; else out[(long long)(i - r0) * ostride] = y;
+  for (int k = 0; k < kPf; ++k) nxt[k] = k < nr ? rhs_at(k) : 0.0;
+  for (int ib = 0; ib < nr; ib += kPf) {
 #pragma unroll
-    for (int j = BW - 1; j >= 1; --j) yw[j] = yw[j - 1];
-    yw[0] = y;
-  }
+    for (int k = 0; k < kPf; ++k) cur[k] = nxt[k];
 #pragma unroll
-  for (int j = 0; j < BW; ++j) yw[j] = 0.0;
-  for (int i = r1 - 1; i >= r0; --i) {
-    double acc = kind == 0 ? Z[(long long)i * ncols + t] : out[(long long)(i - r0) * ostride];
+    for (int k = 0; k < kPf; ++k) nxt[k] = (ib + kPf + k < nr) ? rhs_at(ib + kPf + k) : 0.0;
 #pragma unroll
-    for (int j = 1; j <= BW; ++j) {
-      const double l = (i + j < r1) ? Lb[(long long)(i + j) * R + j] : 0.0;
-      acc -= l * yw[j - 1];
+    for (int k = 0; k < kPf; ++k) {
+      const int i = ib + k;
+      if (i < nr) {
+        const double* Lr = Ls + i * R;
+        double acc = cur[k];
+#pragma unroll
+        for (int j = 1; j <= BW; ++j) acc -= Lr[j] * yw[j - 1];
+        const double y = acc * Lr[0];
+        if (kind == 0) Z[(long long)(r0 + i) * ncols + t] = y; else out[(long long)i * ostride] = y;
+#pragma unroll
+        for (int j = BW - 1; j >= 1; --j) yw[j] = yw[j - 1];
+        yw[0] = y;
+      }
     }
-    const double xv = acc * Lb[(long long)i * R];
-    if (kind == 0) Z[(long long)i * ncols + t] = xv; else out[(long long)(i - r0) * ostride] = xv;
+  }
+  // backward: x(i) = (y(i) - sum_j L(i+j, i) x(i+j)) / L(i,i)
 #pragma unroll
-    for (int j = BW - 1; j >= 1; --j) yw[j] = yw[j - 1];
-    yw[0] = xv;
+  for (int j = 0; j < BW; ++j) yw[j] = 0.0;
+  auto y_at = [&](int i) { return kind == 0 ? Z[(long long)(r0 + i) * ncols + t] : out[(long long)i * ostride]; };
+#pragma unroll
+  for (int k = 0; k < kPf; ++k) nxt[k] = (nr - 1 - k >= 0) ? y_at(nr - 1 - k) : 0.0;
+  for (int ib = nr - 1; ib >= 0; ib -= kPf) {
+#pragma unroll
+    for (int k = 0; k < kPf; ++k) cur[k] = nxt[k];
+#pragma unroll
+    for (int k = 0; k < kPf; ++k) nxt[k] = (ib - kPf - k >= 0) ? y_at(ib - kPf - k) : 0.0;
+#pragma unroll
+    for (int k = 0; k < kPf; ++k) {
+      const int i = ib - k;
+      if (i >= 0) {
+        double acc = cur[k];
+#pragma unroll
+        for (int j = 1; j <= BW; ++j) {
+          const double l = (i + j < nr) ? Ls[(i + j) * R + j] : 0.0;
+          acc -= l * yw[j - 1];
+        }
+        const double xv = acc * Ls[i * R];
+        if (kind == 0) Z[(long long)(r0 + i) * ncols + t] = xv; else out[(long long)i * ostride] = xv;
+#pragma unroll
+        for (int j = BW - 1; j >= 1; --j) yw[j] = yw[j - 1];
+        yw[0] = xv;
+      }
+    }
   }
 }
 
