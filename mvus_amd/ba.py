@@ -157,6 +157,23 @@ class BAHandle:
                     'mvus_ba_outlier_mask')
         return keep.astype(bool)
 
+    def remove_outliers(self, x, thres):
+        """Scene.remove_outliers on the handle itself: the device-resident detections are filtered in place and the
+        handle (and ``self.prob``) describe the inliers afterwards.  Returns the keep mask over the old detections."""
+        x = self._x(x, self.n)
+        keep = np.empty(self.M, dtype=np.uint8)
+        off = np.zeros(self.prob.C + 1, dtype=np.int64)
+        self._check(self.lib.mvus_ba_remove_outliers(self.h, _lib.dptr(x), float(thres), keep.ctypes.data_as(_lib.c_uint8_p),
+                                                     off.ctypes.data_as(_lib.c_int64_p)), 'mvus_ba_remove_outliers')
+        keep = keep.astype(bool)
+        import dataclasses
+        self.prob = dataclasses.replace(self.prob, det_offsets=off, frame=self.prob.frame[keep], u_raw=self.prob.u_raw[keep],
+                                        v_raw=self.prob.v_raw[keep])
+        self.M = self.prob.M
+        self.m = int(self.lib.mvus_ba_num_residuals(self.h))
+        assert self.m == self.prob.n_residuals
+        return keep
+
     def set_x(self, x):
         x = self._x(x, self.n)
         self._check(self.lib.mvus_ba_set_x(self.h, _lib.dptr(x)), 'mvus_ba_set_x')

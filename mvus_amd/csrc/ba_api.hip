@@ -228,6 +228,63 @@ struct HipBackend {
     has_jacobian = true;
   }
 
+  // Scene.remove_outliers on the resident data: mask at x, stable compaction, new launch tables.
+  void remove_outliers(const double* x_dev, double thres, uint8_t* keep_out, int64_t* det_off_out) {
+    residual(x_dev, f_cur);
+    const int nc = dp.n_chunks;
+    uint8_t* keep = nullptr;
+    MVUS_HIP(hipMalloc(reinterpret_cast<void**>(&keep), std::max<int64_t>(hp.M, 1)));
+    int32_t* counts = nullptr;
+    MVUS_HIP(hipMalloc(reinterpret_cast<void**>(&counts), sizeof(int32_t) * std::max(nc, 1)));
+    std::vector<int32_t> cnt_h(nc);
+    std::vector<long long> off_h(nc);
+    long long* off_d = nullptr;
+    MVUS_HIP(hipMalloc(reinterpret_cast<void**>(&off_d), sizeof(long long) * std::max(nc, 1)));
+    auto cleanup = [&]() { (void)hipFree(keep); (void)hipFree(counts); (void)hipFree(off_d); };
+    try {
+      if (nc > 0) {
+        hipLaunchKernelGGL(k_outlier_mask, dim3(nc), dim3(kThreads), 0, stream, dp, f_cur, thres, keep);
+        hipLaunchKernelGGL(k_compact_count, dim3(nc), dim3(kThreads), 0, stream, dp, keep, counts);
+        MVUS_HIP(hipMemcpyAsync(cnt_h.data(), counts, sizeof(int32_t) * nc, hipMemcpyDeviceToHost, stream));
+      }
+      if (keep_out && hp.M > 0) MVUS_HIP(hipMemcpyAsync(keep_out, keep, hp.M, hipMemcpyDeviceToHost, stream));
+      MVUS_HIP(hipStreamSynchronize(stream));
+      std::vector<int64_t> new_off(hp.C + 1, 0);
+      long long run = 0;
+      for (int k = 0; k < nc; ++k) { off_h[k] = run; run += cnt_h[k]; new_off[hp.chunk_cam[k] + 1] += cnt_h[k]; }
+      for (int c = 0; c < hp.C; ++c) new_off[c + 1] += new_off[c];
+      const int64_t newM = run;
+      double* nf = dalloc<double>(newM); double* nu = dalloc<double>(newM); double* nv = dalloc<double>(newM);
+      double* nuo = dalloc<double>(newM); double* nvo = dalloc<double>(newM);
+      if (nc > 0) {
+        MVUS_HIP(hipMemcpyAsync(off_d, off_h.data(), sizeof(long long) * nc, hipMemcpyHostToDevice, stream));
+        hipLaunchKernelGGL(k_compact_scatter, dim3(nc), dim3(kThreads), 0, stream, dp, keep, off_d, nf, nu, nv, nuo, nvo);
+        MVUS_HIP(hipGetLastError());
+      }
+      MVUS_HIP(hipStreamSynchronize(stream));
+      // the handle now describes the filtered problem
+      hp.det_off = new_off; hp.M = newM; hp.m = 2 * newM + hp.T;
+      hp.frame.clear(); hp.u_raw.clear(); hp.v_raw.clear();          // host copies are no longer current
+      hp.chunk_cam.clear(); hp.chunk_start.clear(); hp.chunk_count.clear();
+      for (int c = 0; c < hp.C; ++c)
+        for (int64_t a = hp.det_off[c]; a < hp.det_off[c + 1]; a += kChunk) {
+          hp.chunk_cam.push_back(c); hp.chunk_start.push_back(a);
+          hp.chunk_count.push_back((int32_t)std::min<int64_t>(kChunk, hp.det_off[c + 1] - a));
+        }
+      dp.frame = nf; dp.u_raw = nu; dp.v_raw = nv; dp.u_obs = nuo; dp.v_obs = nvo;
+      dp.M = newM;
+      dp.chunk_cam = dupload(hp.chunk_cam); dp.chunk_count = dupload(hp.chunk_count);
+      std::vector<long long> cs(hp.chunk_start.begin(), hp.chunk_start.end()), doff(hp.det_off.begin(), hp.det_off.end());
+      dp.chunk_start = dupload(cs); dp.det_off = dupload(doff);
+      dp.n_chunks = (int)hp.chunk_cam.size();
+      MVUS_HIP(hipStreamSynchronize(stream));
+      has_pattern = false; has_jacobian = false; fd_ngroups = 0;
+      m_glob = hp.m;
+      if (det_off_out) std::memcpy(det_off_out, new_off.data(), sizeof(int64_t) * (hp.C + 1));
+    } catch (...) { cleanup(); throw; }
+    cleanup();
+  }
+
   void set_pattern(const double* x0_dev) {
     hipLaunchKernelGGL(k_cam_states, dim3((hp.C + 63) / 64), dim3(64), 0, stream, dp, x0_dev, cams);
     if (dp.n_chunks > 0) hipLaunchKernelGGL(k_pattern, dim3(dp.n_chunks), dim3(kThreads), 0, stream, dp, cams, pat0);
@@ -474,6 +531,17 @@ int mvus_ba_outlier_mask(mvus_ba* h, const double* x, double thres, uint8_t* kee
     if (e == hipSuccess) e = hipStreamSynchronize(be.stream);
     (void)hipFree(kd);
     MVUS_HIP(e);
+    return MVUS_OK;
+  });
+}
+
+int mvus_ba_remove_outliers(mvus_ba* h, const double* x, double thres, uint8_t* keep_out, int64_t* det_offsets_out) {
+  return guarded(h, [&] {
+    HipBackend& be = h->be;
+    if (be.allreduce) { be.err = "remove_outliers on a sharded handle: filter every shard's problem on the host instead"; return MVUS_E_INVALID; }
+    be.upload(be.x_cur, x, be.hp.n);
+    h->schur.reset();                       // sized by the launch tables
+    be.remove_outliers(be.x_cur, thres, keep_out, det_offsets_out);
     return MVUS_OK;
   });
 }

@@ -486,4 +486,31 @@ __global__ __launch_bounds__(kThreads) void k_fd_fill_motion(DevProblem dp, long
     }
 }
 
+// ---- in-place removal of outliers (stable stream compaction per chunk) ----------------------------------------
+__global__ __launch_bounds__(kThreads) void k_compact_count(DevProblem dp, const uint8_t* __restrict__ keep, int32_t* __restrict__ counts) {
+  const int chunk = blockIdx.x;
+  const bool k = (int)threadIdx.x < dp.chunk_count[chunk] && keep[dp.chunk_start[chunk] + threadIdx.x];
+  const int c = __syncthreads_count(k ? 1 : 0);
+  if (threadIdx.x == 0) counts[chunk] = c;
+}
+__global__ __launch_bounds__(kThreads) void k_compact_scatter(DevProblem dp, const uint8_t* __restrict__ keep, const long long* __restrict__ out_off,
+                                                              double* __restrict__ frame, double* __restrict__ u_raw, double* __restrict__ v_raw,
+                                                              double* __restrict__ u_obs, double* __restrict__ v_obs) {
+  __shared__ int wave_cnt[kThreads / 64];
+  const int chunk = blockIdx.x;
+  const bool act = (int)threadIdx.x < dp.chunk_count[chunk];
+  const long long i = dp.chunk_start[chunk] + (act ? threadIdx.x : 0);
+  const bool k = act && keep[i];
+  const unsigned long long bal = __ballot(k);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) wave_cnt[wave] = __popcll(bal);
+  __syncthreads();
+  int base = 0;
+  for (int w = 0; w < wave; ++w) base += wave_cnt[w];
+  if (k) {
+    const long long o = out_off[chunk] + base + __popcll(bal & ((1ull << lane) - 1ull));
+    frame[o] = dp.frame[i]; u_raw[o] = dp.u_raw[i]; v_raw[o] = dp.v_raw[i]; u_obs[o] = dp.u_obs[i]; v_obs[o] = dp.v_obs[i];
+  }
+}
+
 }  // namespace mvus

@@ -136,6 +136,14 @@ class Scene:
         self.rs = []
         self.ref_cam = 0
         self.find_order = True
+        self._ba_handle = None      # GPU handle kept between BA -> remove_outliers -> BA (main.py:49-62)
+        self._ba_key = None
+
+    def __getstate__(self):         # the output pickle (main.py:93) carries data only
+        state = dict(self.__dict__)
+        state['_ba_handle'] = None
+        state['_ba_key'] = None
+        return state
 
     # ---- bookkeeping --------------------------------------------------------------------------
     def addCamera(self, *camera):
@@ -277,6 +285,27 @@ class Scene:
         from ..ba import BAHandle          # raises if libmvusba.so is missing: no CPU fallback
         return BAHandle(prob, device=int(self.settings.get('device', 0)) if isinstance(self.settings, dict) else 0)
 
+    @staticmethod
+    def _same_problem(a, b):
+        if (a.num_cam, a.opt_calib, a.undist_points, a.rs_free, a.rs_bounds, a.motion_reg, a.motion_type, a.motion_weight) != \
+           (b.num_cam, b.opt_calib, b.undist_points, b.rs_free, b.rs_bounds, b.motion_reg, b.motion_type, b.motion_weight):
+            return False
+        pairs = [(a.det_offsets, b.det_offsets), (a.frame, b.frame), (a.u_raw, b.u_raw), (a.v_raw, b.v_raw),
+                 (a.img_height, b.img_height), (a.interval, b.interval), (a.knot_offsets, b.knot_offsets), (a.knots, b.knots)]
+        if not a.opt_calib:                      # with opt_calib K and d are parameters (in x), not problem data
+            pairs += [(a.K, b.K), (a.dist, b.dist)]
+        return all(x.shape == y.shape and np.array_equal(x, y) for x, y in pairs)
+
+    def _resident_handle(self, prob, cams):
+        """The handle of the previous BA over the same cameras if its (device-resident) problem is still this one."""
+        h = self._ba_handle
+        if h is not None and h.h and self._ba_key == tuple(cams) and self._same_problem(h.prob, prob):
+            return h
+        if h is not None:
+            h.close()
+        self._ba_handle, self._ba_key = self._handle(prob), tuple(cams)
+        return self._ba_handle
+
     def error_cam(self, cam_id, mode='dist', motion_prior=False, norm=False):
         """Reprojection errors of one camera (common.py:304-359), evaluated by the HIP residual kernel."""
         if motion_prior or norm:
@@ -323,8 +352,8 @@ class Scene:
         solver = _ba.SOLVER_LM_SCHUR if st.get('ba_solver', 'trf') == 'lm' else _ba.SOLVER_TRF_LSMR
         default_jac = 'analytic' if solver == _ba.SOLVER_LM_SCHUR else 'pattern'
         jac_mode = {'analytic': _ba.JAC_ANALYTIC, 'pattern': _ba.JAC_PATTERN, 'fd': _ba.JAC_FD}[st.get('ba_jacobian', default_jac)]
-        with self._handle(prob) as h:
-            res = h.solve(model, solver=solver, jac_mode=jac_mode, max_nfev=max_iter)
+        h = self._resident_handle(prob, cams)      # stays resident for remove_outliers and the next BA
+        res = h.solve(model, solver=solver, jac_mode=jac_mode, max_nfev=max_iter)
         alpha, beta, rs_new, cam_states, coefs = _problem.unpack_x(prob, res.x)
         self.alpha[cams], self.beta[cams], self.rs[cams] = alpha, beta, rs_new
         for k, i in enumerate(cams):
@@ -349,10 +378,23 @@ class Scene:
         cams = list(cams)
         for i in cams:
             self.detection_to_global(i)
-        prob = self._ba_problem(cams)
-        with self._handle(prob) as h:
-            keep = h.outlier_mask(self._pack(prob, cams), thres)
-            f = h.residual(self._pack(prob, cams)) if verbose else None
+        h = self._ba_handle
+        resident = (h is not None and h.h and self._ba_key == tuple(cams)
+                    and all(h.prob.det_offsets[k + 1] - h.prob.det_offsets[k] == self.detections[i].shape[1] for k, i in enumerate(cams))
+                    and np.array_equal(h.prob.frame, np.concatenate([self.detections[i][0] for i in cams])))
+        if resident:
+            # the detections of the last BA are still on the GPU: filter them there (mvus_ba_remove_outliers)
+            prob_old = h.prob
+            x = self._pack(prob_old, cams)
+            f = h.residual(x) if verbose else None
+            keep = h.remove_outliers(x, thres)
+            prob = prob_old
+        else:
+            prob = self._ba_problem(cams)
+            with self._handle(prob) as tmp:
+                x = self._pack(prob, cams)
+                keep = tmp.outlier_mask(x, thres)
+                f = tmp.residual(x) if verbose else None
         for k, i in enumerate(cams):
             a, b = int(prob.det_offsets[k]), int(prob.det_offsets[k + 1])
             if verbose:

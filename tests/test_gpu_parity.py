@@ -279,3 +279,31 @@ def test_fd_mode_ba_vs_reference_result(BAHandle, name):
     assert abs(r.cost - float(g['ba10_cost'])) < 5e-2 * float(g['ba10_cost'])
     assert abs(orc.reprojection_rmse(oprob, r.x) - float(g['ba10_rmse'])) < 0.2
     assert np.mean(keep.astype(np.uint8) == g['outlier_keep']) >= 0.96
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_remove_outliers_in_place_equals_fresh_handle(BAHandle, name):
+    """mvus_ba_remove_outliers: mask bit-exact vs the reference, and the compacted resident problem behaves exactly
+    like a new handle built from the filtered detections (residual bit for bit, same BA result)."""
+    scene, g = load_case(name)
+    prob, _ = mp.problem_from_scene(scene)
+    x = g['ba10_x']
+    thres = float(g['thres_outlier'])
+    with BAHandle(prob) as h:
+        keep = h.remove_outliers(x, thres)
+        assert np.array_equal(keep.astype(np.uint8), g['outlier_keep'])
+        off = g['det_offsets']
+        for i in range(scene.num_cam):
+            scene.detections[i] = scene.detections[i][:, keep[off[i]:off[i + 1]]]
+        prob2, _ = mp.problem_from_scene(scene)
+        assert np.array_equal(h.prob.det_offsets, prob2.det_offsets) and np.array_equal(h.prob.frame, prob2.frame)
+        with BAHandle(prob2) as h2:
+            assert np.array_equal(h.residual(x), h2.residual(x))
+            opts = _lib.default_opts(_lib.SOLVER_LM_SCHUR, _lib.JAC_ANALYTIC, 6)
+            r1, r2 = h.solve(x, opts=opts), h2.solve(x, opts=opts)
+            assert (r1.nfev, r1.njev, r1.status) == (r2.nfev, r2.njev, r2.status)
+            np.testing.assert_allclose(r1.cost, r2.cost, rtol=1e-10)
+            np.testing.assert_allclose(r1.x, r2.x, rtol=0, atol=1e-8 * max(1.0, np.abs(r2.x).max()))
+        # a second pass removes nothing new at the same x and threshold... unless the fit moved: here x is unchanged
+        keep2 = h.remove_outliers(x, thres)
+        assert keep2.all()

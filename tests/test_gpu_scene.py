@@ -37,6 +37,8 @@ def test_ba_outliers_ba_sequence(name):
     before = np.array([np.mean(s.error_cam(i)) for i in range(C)])
     np.testing.assert_allclose(before, g['mean_err_before'], rtol=0, atol=1e-9)      # same numbers main.py:46 prints
     res = s.BA(C, **kw)
+    handle = s._ba_handle
+    assert handle is not None and handle.h
     assert res.nfev == int(g['ba10_nfev'])
     assert res.cost < float(g['ba10_cost']) * (1 + 5e-3)
     n_before = sum(d.shape[1] for d in s.detections)
@@ -44,7 +46,11 @@ def test_ba_outliers_ba_sequence(name):
     removed = n_before - sum(d.shape[1] for d in s.detections)
     ref_removed = int((g['outlier_keep'] == 0).sum())
     assert abs(removed - ref_removed) <= max(3, 0.6 * ref_removed)
+    assert s._ba_handle is handle and handle.M == sum(d.shape[1] for d in s.detections)    # filtered in place on the GPU
     res2 = s.BA(C, **kw)
+    assert s._ba_handle is handle                                                            # no new handle, no re-upload
+    import pickle
+    assert pickle.loads(pickle.dumps(s))._ba_handle is None                                  # the output pickle carries data only
     rmse = np.sqrt(np.mean(np.concatenate([s.error_cam(i, 'dist') for i in range(C)]) ** 2))
     # Final answer of the pipeline.  Both runs stop unconverged after 10 evaluations on slightly different inlier
     # sets, and with motion_reg the cost trades reprojection error against the (heavily weighted) motion term, so the
