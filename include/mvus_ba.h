@@ -101,7 +101,8 @@ typedef struct mvus_solve_opts {
 /* scipy.optimize.OptimizeResult fields Scene.BA returns (common.py:670,697) */
 typedef struct mvus_result {
   double cost;        /* 0.5*|f|^2 */
-  double optimality;  /* |g|_inf (scaled by the Coleman-Li vector when bounded) */
+  double optimality;  /* |g|_inf (scaled by the Coleman-Li vector when bounded); LM_SCHUR stopped by max_nfev: at its last
+                         linearisation point (the final accepted point is not re-linearised) */
   int32_t nfev, njev;
   int32_t status;     /* 0 max_nfev, 1 gtol, 2 ftol, 3 xtol, 4 ftol&xtol (scipy codes) */
   int32_t lin_iters;  /* total LSMR iterations / Cholesky solves */

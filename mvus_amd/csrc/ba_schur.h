@@ -104,6 +104,12 @@ SolveResult lm_schur(B& be, Schur& sc, std::vector<double>& x, const std::vector
       x = x_new;
       cost = cost_new;
       be.copy(x_dev, xt_dev, n);
+      if (status == -1 && res.nfev >= opt.max_nfev) {
+        // evaluation budget spent: no further step will be taken, so the accepted point is not re-linearised (one
+        // Jacobian + assembly saved per call); the reported optimality is then that of the last linearisation
+        be.copy(f_dev, f_new, m);
+        break;
+      }
       be.jacobian(x_dev, f_dev, opt.jac_mode);
       ++res.njev;
       sc.assemble(be, f_dev);

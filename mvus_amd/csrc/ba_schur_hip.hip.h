@@ -36,8 +36,8 @@ __device__ __forceinline__ int wave_min_i(int v) {
 }
 
 // ---- assembly of the detection rows, atomic form (fallback) ---------------------------------------------------
-// Only for the half chunks the gather kernel below defers (`redo` flag: knot spans that interleave in index order, or
-// more spans than the window holds -- sparse or badly ordered detections): one thread per detection adds its
+// Only for the half chunks the gather kernel below defers (`redo` flag: more knot spans than its window holds, i.e.
+// very sparse detections): one thread per detection adds its
 // contributions straight into the global blocks with fp64 atomics.  Rare, so simplicity beats speed here.
 template <int NS>
 __global__ __launch_bounds__(kThreads) void k_assemble(DevProblem dp, const double* __restrict__ J, const int32_t* __restrict__ span,
@@ -96,14 +96,15 @@ __global__ __launch_bounds__(kThreads) void k_assemble(DevProblem dp, const doub
 // detections of one knot span occupy one contiguous index range, so every output entry -- camera block, gradient,
 // cross block E, spline band C -- is owned by exactly one thread, which sums the (at most four) span ranges that
 // touch it and issues ONE global fp64 atomic.  No LDS atomics (fp64 ds_add measured at ~8 cycles per lane), no
-// shuffles.  Chunks whose spans interleave or overflow the window are handled by k_assemble (atomic form).
+// shuffles.  Half chunks whose spans interleave are first sorted by span in LDS; only those that overflow the window
+// (very sparse detections) are left to k_assemble (atomic form).
 constexpr int kGaObs = 128, kGaWin = 96, kGaStride = kGaObs + 1;
 template <int NS>
 __global__ __launch_bounds__(kThreads) void k_assemble_gather(DevProblem dp, const double* __restrict__ J, const int32_t* __restrict__ span,
                                                               const double* __restrict__ f, NEView ne, int* __restrict__ redo) {
   constexpr int B = NS - 12;
   __shared__ double Js[(2 * NS + 2) * kGaStride];     // rows 0..NS-1: x-row slots, NS..2NS-1: y-row slots, then fx, fy
-  __shared__ int lo[kGaWin], hi[kGaWin];
+  __shared__ int lo[kGaWin], hi[kGaWin], key[kGaObs];
   __shared__ int g0_s, bad_s, lmax_s;
   const int chunk = blockIdx.x >> 1, half = blockIdx.x & 1;
   const int c = dp.chunk_cam[chunk];
@@ -138,9 +139,26 @@ __global__ __launch_bounds__(kThreads) void k_assemble_gather(DevProblem dp, con
   __syncthreads();
   if (tid < kGaWin && hi[tid] > 0)
     for (int u = tid + 1; u < kGaWin; ++u)
-      if (hi[u] > 0) { if (lo[u] < hi[tid]) atomicOr(&bad_s, 1); break; }
+      if (hi[u] > 0) { if (lo[u] < hi[tid]) atomicOr(&bad_s, 2); break; }
+  if (tid < kGaObs) key[tid] = g >= 0 ? g - g0 : 0x7fff;
   __syncthreads();
-  if (bad_s) { if (tid == 0) redo[blockIdx.x] = 1; return; }
+  if (bad_s & 1) { if (tid == 0) redo[blockIdx.x] = 1; return; }
+  if (bad_s) {
+    // knot spans interleave in index order (a large rolling-shutter coefficient reorders the time stamps): stable
+    // rank sort of the staged columns by span, after which every span is one contiguous range again
+    int pos = 0;
+    const int kt = key[t];
+    for (int u = 0; u < kGaObs; ++u) { const int ku = key[u]; pos += (ku < kt) || (ku == kt && u < t); }
+    double tmp[NS + 1];                                  // this thread's rows: (tid >> 7) + 2k, k = 0 .. NS
+#pragma unroll
+    for (int k = 0; k <= NS; ++k) tmp[k] = Js[((tid >> 7) + 2 * k) * kGaStride + t];
+    for (int k = tid; k < kGaWin; k += kThreads) { lo[k] = 0x7fffffff; hi[k] = 0; }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k <= NS; ++k) Js[((tid >> 7) + 2 * k) * kGaStride + pos] = tmp[k];
+    if (tid < kGaObs && g >= 0) { atomicMin(&lo[kt], pos); atomicMax(&hi[kt], pos + 1); }
+    __syncthreads();
+  }
   const int nctrl = lmax_s + 4;                        // local control points 0 .. lmax+3
   const double* fxs = Js + (2 * NS) * kGaStride;
   const double* fys = fxs + kGaStride;
@@ -368,7 +386,7 @@ __global__ __launch_bounds__(64) void k_band_cholesky(int n3, double* __restrict
 // B) the separator system (block tridiagonal, blocks of 3(W-1)) is formed from short dot products;
 // C) it is solved sequentially by one workgroup (P-1 small steps, all right-hand sides in parallel);
 // D) the interiors are corrected: X_I = Y - V X_{S_{p-1}} - W X_{S_p}.
-constexpr int kPartL = 64;
+constexpr int kPartL = 32;
 constexpr int kPartRowsMax = 3 * (kPartL + 6);
 
 struct PartView {
@@ -380,6 +398,7 @@ struct PartView {
   double* VW;            // [P][kPartRowsMax][2*s3]
   double* T;             // [P-1][s3][s3] diagonal blocks of the separator system
   double* U;             // [P-1][s3][s3] U[q] = T(q, q+1)
+  double *U2, *Ha, *Hc;  // [P-1][s3][s3] each: cyclic-reduction workspace (k_sep_bcr_*)
 };
 
 // original (damped) matrix entry H(i, c) read from the lower band; valid for separator rows/columns and for
@@ -679,6 +698,161 @@ __global__ __launch_bounds__(64) void k_sep_rhs(PartView pv, int ncols, double* 
   }
 }
 
+// ---- block cyclic reduction of the separator system ---------------------------------------------------------
+// The sequential block-tridiagonal Cholesky above walks P-1 dependent steps.  Cyclic reduction needs only
+// ceil(log2(P)) of them: at stride h the nodes j with (j+1)/h odd are eliminated, x_j = D_j^-1 (r_j - A_j x_{j-h} -
+// C_j x_{j+h}), and folded into their neighbours at distance h, which form the next (half as long) block-tridiagonal
+// system.  Every Schur complement of an SPD matrix is SPD, so no pivoting is needed.  Stored per node, at the level
+// that eliminates it: Dinv_j (in T), Ha_j = Dinv_j A_j, Hc_j = Dinv_j C_j; only the coupling to the right neighbour,
+// C_j, is carried through the levels (A_j = C_{j-h}^T).
+//   survivors i:  D_i -= C_{i-h}^T Hc_{i-h} + C_i Ha_{i+h},   C_i <- -C_i Hc_{i+h},   r_i -= Hc_{i-h}^T r_{i-h} + Ha_{i+h}^T r_{i+h}
+// k_sep_bcr_factor: the matrix part, one workgroup (all levels, blocks stay in L2/LDS);
+// k_sep_bcr_rhs: the right-hand sides, kBcrCols columns per workgroup staged in LDS through all levels and back.
+template <int S3>
+__global__ __launch_bounds__(1024) void k_sep_bcr_factor(PartView pv, int* __restrict__ fail) {
+  constexpr int SS = S3 * S3;
+  constexpr int NB = 20736 / (8 * SS) > 0 ? 20736 / (8 * SS) : 1;     // nodes inverted per batch: two LDS copies <= 41 KB
+  __shared__ double M0[NB * SS], M1[NB * SS];
+  const int m = pv.P - 1, tid = threadIdx.x;
+  double* Ccur = pv.U;
+  double* Cnxt = pv.U2;
+  for (int h = 1; h <= m; h <<= 1) {
+    const int ne = (m / h + 1) / 2, ns = m / (2 * h);
+    // in-place Gauss-Jordan (sweep) inversion of the eliminated nodes' diagonal blocks, NB nodes at a time
+    for (int b0 = 0; b0 < ne; b0 += NB) {
+      const int cnt = min(NB, ne - b0) * SS;
+      for (int e = tid; e < cnt; e += 1024) {
+        const int j = h * (2 * (b0 + e / SS) + 1) - 1;
+        M0[e] = pv.T[(long long)j * SS + e % SS];
+      }
+      __syncthreads();
+      double* src = M0;
+      double* dst = M1;
+      for (int k = 0; k < S3; ++k) {
+        for (int e = tid; e < cnt; e += 1024) {
+          const int r = e % SS, a = r / S3, b = r % S3;
+          const double* Mn = src + (e - r);
+          double piv = Mn[k * S3 + k];
+          if (!(piv > 0.0)) { fail[0] = 3; piv = 1.0; }
+          const double ip = 1.0 / piv;
+          double v;
+          if (a == k) v = (b == k) ? ip : Mn[k * S3 + b] * ip;
+          else if (b == k) v = -Mn[a * S3 + k] * ip;
+          else v = Mn[r] - Mn[a * S3 + k] * Mn[k * S3 + b] * ip;
+          dst[e] = v;
+        }
+        __syncthreads();
+        double* t_ = src; src = dst; dst = t_;
+      }
+      for (int e = tid; e < cnt; e += 1024) {
+        const int j = h * (2 * (b0 + e / SS) + 1) - 1;
+        pv.T[(long long)j * SS + e % SS] = src[e];
+      }
+      __syncthreads();
+    }
+    // Ha_j = Dinv_j C_{j-h}^T, Hc_j = Dinv_j C_j
+    for (int e = tid; e < ne * 2 * SS; e += 1024) {
+      const int which = e / (ne * SS), e2 = e % (ne * SS);
+      const int j = h * (2 * (e2 / SS) + 1) - 1, r = e2 % SS, a = r / S3, b = r % S3;
+      const double* Di = pv.T + (long long)j * SS + a * S3;
+      double acc = 0.0;
+      if (which == 0) {
+        if (j - h >= 0) { const double* Cl = Ccur + (long long)(j - h) * SS + b * S3; for (int k = 0; k < S3; ++k) acc += Di[k] * Cl[k]; }
+        pv.Ha[(long long)j * SS + r] = acc;
+      } else {
+        if (j + h < m) { const double* Cj = Ccur + (long long)j * SS + b; for (int k = 0; k < S3; ++k) acc += Di[k] * Cj[k * S3]; }
+        pv.Hc[(long long)j * SS + r] = acc;
+      }
+    }
+    __syncthreads();
+    for (int e = tid; e < ns * 2 * SS; e += 1024) {
+      const int which = e / (ns * SS), e2 = e % (ns * SS);
+      const int i = 2 * h * (e2 / SS + 1) - 1, r = e2 % SS, a = r / S3, b = r % S3;
+      const bool right = i + h < m;
+      const double* Ci = Ccur + (long long)i * SS + a * S3;
+      if (which == 0) {
+        const double* Cl = Ccur + (long long)(i - h) * SS + a;
+        const double* Hl = pv.Hc + (long long)(i - h) * SS + b;
+        double acc = pv.T[(long long)i * SS + r];
+        for (int k = 0; k < S3; ++k) acc -= Cl[k * S3] * Hl[k * S3];
+        if (right) { const double* Hr = pv.Ha + (long long)(i + h) * SS + b; for (int k = 0; k < S3; ++k) acc -= Ci[k] * Hr[k * S3]; }
+        pv.T[(long long)i * SS + r] = acc;
+      } else {
+        double acc = 0.0;
+        if (right) { const double* Hr = pv.Hc + (long long)(i + h) * SS + b; for (int k = 0; k < S3; ++k) acc -= Ci[k] * Hr[k * S3]; }
+        Cnxt[(long long)i * SS + r] = acc;
+      }
+    }
+    __syncthreads();
+    double* t_ = Ccur; Ccur = Cnxt; Cnxt = t_;
+  }
+}
+
+constexpr int kBcrCols = 2;
+template <int S3>
+__global__ __launch_bounds__(256) void k_sep_bcr_rhs(PartView pv, int ncols, double* __restrict__ Z) {
+  constexpr int SS = S3 * S3, TC = kBcrCols;
+  extern __shared__ double bcr_lds[];
+  const int m = pv.P - 1, tid = threadIdx.x;
+  double* rs = bcr_lds;                       // [m][S3][TC]
+  double* xs = bcr_lds + (size_t)m * S3 * TC;
+  const int col0 = blockIdx.x * TC;
+  for (int e = tid; e < m * S3 * TC; e += 256) {
+    const int c = e % TC, a = (e / TC) % S3, q = e / (TC * S3);
+    rs[e] = col0 + c < ncols ? Z[(long long)(pv.s0[q] + a) * ncols + col0 + c] : 0.0;
+  }
+  __syncthreads();
+  int h = 1;
+  for (; 2 * h <= m; h <<= 1) {
+    const int ns = m / (2 * h);
+    for (int e = tid; e < ns * S3 * TC; e += 256) {
+      const int c = e % TC, a = (e / TC) % S3, i = 2 * h * (e / (TC * S3) + 1) - 1;
+      double acc = rs[(i * S3 + a) * TC + c];
+      const double* Hl = pv.Hc + (long long)(i - h) * SS + a;
+      const double* rl = rs + (i - h) * S3 * TC + c;
+#pragma unroll
+      for (int k = 0; k < S3; ++k) acc -= Hl[k * S3] * rl[k * TC];
+      if (i + h < m) {
+        const double* Hr = pv.Ha + (long long)(i + h) * SS + a;
+        const double* rr = rs + (i + h) * S3 * TC + c;
+#pragma unroll
+        for (int k = 0; k < S3; ++k) acc -= Hr[k * S3] * rr[k * TC];
+      }
+      rs[(i * S3 + a) * TC + c] = acc;
+    }
+    __syncthreads();
+  }
+  for (; h >= 1; h >>= 1) {
+    const int ne = (m / h + 1) / 2;
+    for (int e = tid; e < ne * S3 * TC; e += 256) {
+      const int c = e % TC, a = (e / TC) % S3, j = h * (2 * (e / (TC * S3)) + 1) - 1;
+      const double* Di = pv.T + (long long)j * SS + a * S3;
+      const double* rj = rs + j * S3 * TC + c;
+      double acc = 0.0;
+#pragma unroll
+      for (int k = 0; k < S3; ++k) acc += Di[k] * rj[k * TC];
+      if (j - h >= 0) {
+        const double* Hl = pv.Ha + (long long)j * SS + a * S3;
+        const double* xl = xs + (j - h) * S3 * TC + c;
+#pragma unroll
+        for (int k = 0; k < S3; ++k) acc -= Hl[k] * xl[k * TC];
+      }
+      if (j + h < m) {
+        const double* Hr = pv.Hc + (long long)j * SS + a * S3;
+        const double* xr = xs + (j + h) * S3 * TC + c;
+#pragma unroll
+        for (int k = 0; k < S3; ++k) acc -= Hr[k] * xr[k * TC];
+      }
+      xs[(j * S3 + a) * TC + c] = acc;
+    }
+    __syncthreads();
+  }
+  for (int e = tid; e < m * S3 * TC; e += 256) {
+    const int c = e % TC, a = (e / TC) % S3, q = e / (TC * S3);
+    if (col0 + c < ncols) Z[(long long)(pv.s0[q] + a) * ncols + col0 + c] = xs[e];
+  }
+}
+
 // interiors: X = Y - V X_{S_{p-1}} - W X_{S_p}
 __global__ __launch_bounds__(256) void k_part_back(PartView pv, int ncols, double* __restrict__ Z) {
   const int p = blockIdx.x, s3 = pv.s3, st = 2 * s3;
@@ -803,133 +977,162 @@ __global__ void k_schur_finish(NEView ne, int ncols, double lambda, const double
   if (b == 0) S[(long long)ne.CB * ne.CB + a] = ne.gc[a] - G[(long long)a * ncols + ne.CB];   // rhs rides as row CB
 }
 
-// Dense Cholesky + solve of the reduced camera system (nn <= 1152), blocked with panels of kNB columns.
-// The right-hand side rides along as row nn of the (nn+1) x nn array `Sa` (Sa[nn][:] = rhs), so the panel
-// triangular solve performs the forward substitution; the backward substitution runs panel by panel.
+// Dense Cholesky + solve of the reduced camera system (nn <= 1152), blocked with panels of kNB columns, ONE launch
+// per panel.  The right-hand side rides along as row nn of the (nn+1) x nn array `Sa` (Sa[nn][:] = rhs), so the panel
+// step also performs the forward substitution.  The inverse of every diagonal block's factor is kept (Linv), which
+// turns the panel's triangular solve into a small matrix product, P = A_panel L11^-T, free of sequential dependence:
+//   k_chol_step(kb): every 32x32 tile (I >= J) of the trailing matrix recomputes P_I and P_J from the raw panel
+//   entries, subtracts P_I P_J^T, and the first tile column stores P_I as the final factor (into `Lf`, so that the
+//   raw panel stays readable for the other tiles).  The workgroup of tile (0,0) then holds the next diagonal block:
+//   its first wavefront factorises it in registers (row per lane, pivot column broadcast with v_readlane) and
+//   inverts the factor.  The critical path per panel is that one wavefront: ~32 dependent column steps.
 constexpr int kNB = 32;
 
-// Cholesky of the kNB x kNB diagonal block by ONE wavefront in LDS (no workgroup barriers across 16 wavefronts)
-__global__ __launch_bounds__(256) void k_potrf_diag(int nn, int kb, double* __restrict__ Sa, int* __restrict__ fail) {
-  __shared__ double D[kNB][kNB + 1];
-  const int nb = min(kNB, nn - kb), lane = threadIdx.x;
-  for (int e = lane; e < kNB * kNB; e += 256) {
-    const int r = e / kNB, c = e % kNB;
-    D[r][c] = (r < nb && c < nb) ? Sa[(long long)(kb + r) * nn + kb + c] : (r == c ? 1.0 : 0.0);
+__device__ __forceinline__ double bcast_lane(double v, int src) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+
+// first wavefront of the workgroup: Cholesky of the block in Dm (lower part valid, identity padded beyond nbk),
+// factor -> Lf[(row0+r)*nn + row0+c], inverse factor -> Li[r*kNB+c].  Lanes 0..31 hold one row of the block each;
+// lanes 32..63 hold the rows of the identity, treated as rows BELOW the block: the column operations that turn the
+// block into L turn them into L^-T, so the inverse costs no extra instruction.  1/sqrt(pivot) comes from v_rsq_f64
+// refined by two Newton steps (the pivot chain is the critical path of the whole dense factorisation).
+__device__ __forceinline__ void potrf_inv_wave(double (*Dm)[kNB + 1], int nbk, int nn, int row0,
+                                               double* __restrict__ Lf, double* __restrict__ Li, int* __restrict__ fail) {
+  const int lane = threadIdx.x & 63;
+  const int row = lane & (kNB - 1);
+  double a[kNB];
+#pragma unroll
+  for (int k = 0; k < kNB; ++k) a[k] = lane < kNB ? Dm[row][k] : (k == row ? 1.0 : 0.0);
+#pragma unroll
+  for (int k = 0; k < kNB; ++k) {
+    double dkk = bcast_lane(a[k], k);
+    if (!(dkk > 0.0)) { if (lane == 0) fail[0] = 2; dkk = 1.0; }
+    double inv = __builtin_amdgcn_rsq(dkk);
+    inv = inv * (1.5 - 0.5 * dkk * inv * inv);
+    inv = inv * (1.5 - 0.5 * dkk * inv * inv);
+    a[k] = (lane == k) ? dkk * inv : a[k] * inv;
+#pragma unroll
+    for (int j = k + 1; j < kNB; ++j) a[j] -= a[k] * bcast_lane(a[k], j);
   }
-  __syncthreads();
-  for (int k = 0; k < nb; ++k) {
-    double d = D[k][k];
-    if (!(d > 0.0)) { if (lane == 0) fail[0] = 2; d = 1.0; }
-    d = sqrt(d);
-    __syncthreads();
-    if (lane == k) D[k][k] = d;
-    if (lane > k && lane < nb) D[lane][k] /= d;
-    __syncthreads();
-    const int rem = nb - k - 1;                      // trailing lower triangle, rem*(rem+1)/2 entries
-    for (int e = lane; e < rem * rem; e += 256) {
-      const int r = k + 1 + e / rem, c = k + 1 + e % rem;
-      if (c <= r) D[r][c] -= D[r][k] * D[c][k];
-    }
-    __syncthreads();
-  }
-  for (int e = lane; e < kNB * kNB; e += 256) {
-    const int r = e / kNB, c = e % kNB;
-    if (r < nb && c < nb) Sa[(long long)(kb + r) * nn + kb + c] = (c <= r) ? D[r][c] : 0.0;
+  if (lane < kNB) {
+#pragma unroll
+    for (int k = 0; k < kNB; ++k)
+      if (row < nbk && k <= row) Lf[(long long)(row0 + row) * nn + row0 + k] = a[k];
+  } else {
+#pragma unroll
+    for (int k = 0; k < kNB; ++k) Li[k * kNB + row] = k >= row ? a[k] : 0.0;      // lane 32+c holds row c of L^-T
   }
 }
 
-// rows below the panel (and the rhs row): X <- X L11^-T.  One thread per row; the row's panel entries live in
-// LDS (column-major over threads, conflict free) so nothing is spilled.
-constexpr int kTrsmThreads = 128;
-__global__ __launch_bounds__(kTrsmThreads) void k_trsm_panel(int nn, int kb, double* __restrict__ Sa) {
-  __shared__ double L11[kNB][kNB + 1];
-  __shared__ double xs[kNB][kTrsmThreads];
-  const int nb = min(kNB, nn - kb), tid = threadIdx.x;
-  for (int e = tid; e < kNB * kNB; e += blockDim.x) {
+__global__ __launch_bounds__(64) void k_chol_first(int nn, const double* __restrict__ Sa, double* __restrict__ Lf, double* __restrict__ Linv,
+                                                   int* __restrict__ fail) {
+  __shared__ double Dm[kNB][kNB + 1];
+  const int nb = min(kNB, nn);
+  for (int e = threadIdx.x; e < kNB * kNB; e += 64) {
     const int r = e / kNB, c = e % kNB;
-    L11[r][c] = (r < nb && c < nb) ? Sa[(long long)(kb + r) * nn + kb + c] : (r == c ? 1.0 : 0.0);
+    Dm[r][c] = (r < nb && c < nb) ? Sa[(long long)r * nn + c] : (r == c ? 1.0 : 0.0);
   }
   __syncthreads();
-  const int i = kb + nb + blockIdx.x * blockDim.x + tid;     // rows kb+nb .. nn (row nn = rhs)
-  const bool valid = i <= nn;
-  for (int c = 0; c < nb; ++c) xs[c][tid] = valid ? Sa[(long long)i * nn + kb + c] : 0.0;
-  for (int c = 0; c < nb; ++c) {
-    double sacc = xs[c][tid];
-    for (int jj = 0; jj < c; ++jj) sacc -= xs[jj][tid] * L11[c][jj];
-    xs[c][tid] = sacc / L11[c][c];
-  }
-  if (valid) for (int c = 0; c < nb; ++c) Sa[(long long)i * nn + kb + c] = xs[c][tid];
+  potrf_inv_wave(Dm, nb, nn, 0, Lf, Linv, fail);
 }
 
-// trailing update: Sa[i][j] -= sum_c P[i][c] P[j][c] for kb+nb <= j <= i <= nn (tiles of 32x32, lower part)
-__global__ __launch_bounds__(1024) void k_syrk_update(int nn, int kb, double* __restrict__ Sa) {
-  if (blockIdx.y > blockIdx.x) return;
-  __shared__ double Pi[kNB][kNB + 1];
-  __shared__ double Pj[kNB][kNB + 1];
-  const int nb = min(kNB, nn - kb);
-  const int i0 = kb + nb + blockIdx.x * kNB, j0 = kb + nb + blockIdx.y * kNB;
+__global__ __launch_bounds__(1024) void k_chol_step(int nn, int kb, double* __restrict__ Sa, double* __restrict__ Lf, double* __restrict__ Linv,
+                                                    int* __restrict__ fail) {
+  const int ti = blockIdx.x, tj = blockIdx.y;
+  if (tj > ti) return;
+  __shared__ double Ai[kNB][kNB + 1], Aj[kNB][kNB + 1], Li[kNB][kNB + 1], Pi[kNB][kNB + 1], Pj[kNB][kNB + 1];
+  const int nb = min(kNB, nn - kb), base = kb + nb;
+  const int i0 = base + ti * kNB, j0 = base + tj * kNB;
   const int r = threadIdx.x / kNB, c = threadIdx.x % kNB;
-  Pi[r][c] = (i0 + r <= nn && c < nb) ? Sa[(long long)(i0 + r) * nn + kb + c] : 0.0;
-  Pj[r][c] = (j0 + r < nn && c < nb) ? Sa[(long long)(j0 + r) * nn + kb + c] : 0.0;
+  Ai[r][c] = (i0 + r <= nn && c < nb) ? Sa[(long long)(i0 + r) * nn + kb + c] : 0.0;
+  Aj[r][c] = (j0 + r < nn && c < nb) ? Sa[(long long)(j0 + r) * nn + kb + c] : 0.0;
+  Li[r][c] = Linv[(long long)(kb / kNB) * kNB * kNB + threadIdx.x];
+  const int i = i0 + r, j = j0 + c;
+  const bool valid = i <= nn && j < nn && j <= i;
+  double v = valid ? Sa[(long long)i * nn + j] : 0.0;
   __syncthreads();
-  const int i = i0 + r, jcol = j0 + c;
-  if (i > nn || jcol >= nn || jcol > i) return;
+  {
+    double pi = 0.0, pj = 0.0;
+#pragma unroll
+    for (int k = 0; k < kNB; ++k) { const double l = Li[c][k]; pi += Ai[r][k] * l; pj += Aj[r][k] * l; }
+    Pi[r][c] = pi; Pj[r][c] = pj;
+    if (tj == 0 && i <= nn && c < nb) Lf[(long long)i * nn + kb + c] = pi;
+  }
+  __syncthreads();
   double acc = 0.0;
 #pragma unroll
   for (int k = 0; k < kNB; ++k) acc += Pi[r][k] * Pj[c][k];
-  Sa[(long long)i * nn + jcol] -= acc;
+  v -= acc;
+  if (ti != 0 || tj != 0) { if (valid) Sa[(long long)i * nn + j] = v; return; }
+  // tile (0,0): rows/cols base .. base+31 = the next diagonal block (nb2 of them real; a row nn inside the tile is the rhs)
+  const int nb2 = min(kNB, nn - base);
+  if (nb2 <= 0) return;
+  if (valid && r >= nb2) Sa[(long long)i * nn + j] = v;
+  __syncthreads();                                     // Ai is reused as the block to factorise
+  Ai[r][c] = (r < nb2 && c < nb2) ? v : (r == c ? 1.0 : 0.0);
+  __syncthreads();
+  if (threadIdx.x < 64) potrf_inv_wave(Ai, nb2, nn, base, Lf, Linv + (long long)(base / kNB) * kNB * kNB, fail);
 }
 
-// backward substitution L^T x = y, one panel per launch (from the last panel to the first); y = row nn of Sa
-__global__ __launch_bounds__(256) void k_backsub_panel(int nn, int kb, double* __restrict__ Sa) {
-  __shared__ double L11[kNB][kNB + 1];
-  __shared__ double xs[kNB];
-  const int nb = min(kNB, nn - kb);
-  double* y = Sa + (long long)nn * nn;
-  for (int e = threadIdx.x; e < kNB * kNB; e += blockDim.x) {
-    const int r = e / kNB, c = e % kNB;
-    L11[r][c] = (r < nb && c < nb) ? Sa[(long long)(kb + r) * nn + kb + c] : 0.0;
-  }
-  if (threadIdx.x < kNB) xs[threadIdx.x] = threadIdx.x < nb ? y[kb + threadIdx.x] : 0.0;
-  __syncthreads();
-  if (threadIdx.x < 64) {                     // column-oriented back substitution by the first wavefront
-    const int lane = threadIdx.x;
-    for (int k = nb - 1; k >= 0; --k) {
-      const double xk = xs[k] / L11[k][k];
-      __builtin_amdgcn_wave_barrier();
-      if (lane == k) xs[k] = xk;
-      if (lane < k) xs[lane] -= L11[k][lane] * xk;
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+// backward substitution L^T x = y by one workgroup, panel by panel from the last: x_k = Linv_k^T (y_k - sum_{j>k} L_jk^T x_j);
+// y = row nn of Lf.  Writes pc = -x (the camera part of the LM step).
+__global__ __launch_bounds__(1024) void k_chol_backsub(int nn, const double* __restrict__ Lf, const double* __restrict__ Linv, double* __restrict__ pc) {
+  __shared__ double y[1152];
+  __shared__ double Ls[kNB][kNB + 1];
+  __shared__ double xk[kNB];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < nn; i += 1024) y[i] = Lf[(long long)nn * nn + i];
+  for (int kb = ((nn - 1) / kNB) * kNB; kb >= 0; kb -= kNB) {
+    const int nb = min(kNB, nn - kb);
+    Ls[tid / kNB][tid % kNB] = Linv[(long long)(kb / kNB) * kNB * kNB + tid];
+    // the rows of the factor this panel needs, fetched before the dependent part (all loads in flight together)
+    double lv[kNB];
+    const int i = tid;
+#pragma unroll
+    for (int cc = 0; cc < kNB; ++cc) lv[cc] = (i < kb && cc < nb) ? Lf[(long long)(kb + cc) * nn + i] : 0.0;
+    __syncthreads();
+    if (tid < kNB) {
+      double acc = 0.0;
+#pragma unroll
+      for (int rr = 0; rr < kNB; ++rr) acc += (rr < nb && tid < nb) ? Ls[rr][tid] * y[kb + rr] : 0.0;      // Linv is lower triangular
+      xk[tid] = acc;
+      if (tid < nb) pc[kb + tid] = -acc;
     }
+    __syncthreads();
+    if (i < kb) {
+      double vv = y[i];
+#pragma unroll
+      for (int cc = 0; cc < kNB; ++cc) vv -= lv[cc] * xk[cc];
+      y[i] = vv;
+    }
+    for (int i2 = tid + 1024; i2 < kb; i2 += 1024) {
+      double vv = y[i2];
+      for (int cc = 0; cc < nb; ++cc) vv -= Lf[(long long)(kb + cc) * nn + i2] * xk[cc];
+      y[i2] = vv;
+    }
+    __syncthreads();
   }
-  __syncthreads();
-  for (int k = threadIdx.x; k < nb; k += blockDim.x) y[kb + k] = xs[k];
-  for (int i = threadIdx.x; i < kb; i += blockDim.x) {
-    double v = y[i];
-    for (int c = 0; c < nb; ++c) v -= Sa[(long long)(kb + c) * nn + i] * xs[c];
-    y[i] = v;
-  }
-}
-
-__global__ void k_negate_copy(int nn, const double* __restrict__ src, double* __restrict__ dst) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < nn) dst[i] = -src[i];
 }
 
 // p (x order) from p_c and p_s = -(z_g + Z_E p_c)
 __global__ __launch_bounds__(kThreads) void k_back_substitute(DevProblem dp, NEView ne, int ncols, const double* __restrict__ Z,
                                                               const double* __restrict__ pc, double* __restrict__ px) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx < ne.CB) {
-    px[cam_col(dp.C, dp.P, idx / ne.B, idx % ne.B)] = pc[idx];
-  } else if (idx < ne.CB + ne.N3) {
-    const int r = idx - ne.CB;
-    const double* zr = Z + (long long)r * ncols;
-    double acc = zr[ne.CB];
-    for (int k = 0; k < ne.CB; ++k) acc += zr[k] * pc[k];
+  // one wavefront per spline row: lanes stride over the row of Z (coalesced), then a shuffle reduction
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+  if (blockIdx.x == 0)
+    for (int idx = threadIdx.x; idx < ne.CB; idx += kThreads) px[cam_col(dp.C, dp.P, idx / ne.B, idx % ne.B)] = pc[idx];
+  if (r >= ne.N3) return;
+  const double* zr = Z + (long long)r * ncols;
+  double acc = 0.0;
+  for (int k = lane; k < ne.CB; k += 64) acc += zr[k] * pc[k];
+  acc = wave_sum(acc);
+  if (lane == 0) {
     const int g = r / 3, d = r % 3;
-    px[dp.mv.ctrl_x0[g] + d * dp.mv.ctrl_stride[g]] = -acc;
+    px[dp.mv.ctrl_x0[g] + d * dp.mv.ctrl_stride[g]] = -(acc + zr[ne.CB]);
   }
 }
 
@@ -940,11 +1143,13 @@ struct HipSchur {
   int ncols = 0, BW = 0;
   size_t ne_count = 0;
   double *Erm = nullptr;
-  double *NE = nullptr, *Lb = nullptr, *Z = nullptr, *G = nullptr, *S = nullptr, *rhs = nullptr, *pc = nullptr, *D = nullptr, *gx = nullptr, *px = nullptr;
+  double *NE = nullptr, *Lb = nullptr, *Z = nullptr, *G = nullptr, *S = nullptr, *Lf = nullptr, *Linv = nullptr, *rhs = nullptr, *pc = nullptr, *D = nullptr, *gx = nullptr, *px = nullptr;
   int* fail = nullptr;
   int* fail_host = nullptr;
   PartView pv{};
   int* part_tables = nullptr;
+  size_t bcr_lds = 0;       // dynamic LDS of k_sep_bcr_rhs; the sequential separator kernels remain for chains too long for it
+  bool use_bcr = false;
   int* redo = nullptr;      // per half chunk: 1 = the gather assembly deferred it to the atomic kernel
 
   explicit HipSchur(BE& b) : be(b) {
@@ -972,6 +1177,8 @@ struct HipSchur {
     G = be.alloc((size_t)ne.CB * ncols);
     S = be.alloc((size_t)(ne.CB + 1) * ne.CB);
     rhs = be.alloc(ne.CB); pc = be.alloc(ne.CB);
+    Lf = be.alloc((size_t)(ne.CB + 1) * ne.CB);
+    Linv = be.alloc((size_t)((ne.CB + kNB - 1) / kNB) * kNB * kNB);
     D = be.alloc(hp.n); gx = be.alloc(hp.n); px = be.alloc(hp.n);
     MVUS_HIP(hipMalloc(reinterpret_cast<void**>(&fail), sizeof(int)));
     MVUS_HIP(hipHostMalloc(reinterpret_cast<void**>(&fail_host), sizeof(int), hipHostMallocDefault));
@@ -999,9 +1206,14 @@ struct HipSchur {
     pv.VW = be.alloc((size_t)pv.P * kPartRowsMax * 2 * pv.s3);
     pv.T = be.alloc((size_t)std::max(pv.P - 1, 1) * pv.s3 * pv.s3);
     pv.U = be.alloc((size_t)std::max(pv.P - 1, 1) * pv.s3 * pv.s3);
+    pv.U2 = be.alloc((size_t)std::max(pv.P - 1, 1) * pv.s3 * pv.s3);
+    pv.Ha = be.alloc((size_t)std::max(pv.P - 1, 1) * pv.s3 * pv.s3);
+    pv.Hc = be.alloc((size_t)std::max(pv.P - 1, 1) * pv.s3 * pv.s3);
+    bcr_lds = (size_t)2 * std::max(pv.P - 1, 1) * pv.s3 * kBcrCols * sizeof(double);
+    use_bcr = bcr_lds <= 64 * 1024 && !std::getenv("MVUS_SEP_SEQUENTIAL");
   }
   ~HipSchur() {
-    for (double* p : {Erm, NE, Lb, Z, G, S, rhs, pc, D, gx, px, pv.VW, pv.T, pv.U}) be.release(p);
+    for (double* p : {Erm, NE, Lb, Z, G, S, Lf, Linv, rhs, pc, D, gx, px, pv.VW, pv.T, pv.U, pv.U2, pv.Ha, pv.Hc}) be.release(p);
     if (part_tables) (void)hipFree(part_tables);
     if (redo) (void)hipFree(redo);
     if (fail) (void)hipFree(fail);
@@ -1057,16 +1269,26 @@ struct HipSchur {
       hipLaunchKernelGGL(k_part_solve<11>, gsolve, dim3(64), 0, be.stream, pv, ncols, Lb, Z);
       if (pv.P > 1) {
         hipLaunchKernelGGL(k_part_reduce<11>, dim3(pv.P - 1), dim3(256), 0, be.stream, pv, ncols, Lb, Z);
-        hipLaunchKernelGGL(k_sep_factor<9>, dim3(1), dim3(64), 0, be.stream, pv, fail);
-        hipLaunchKernelGGL(k_sep_rhs<9>, dim3((ncols + 63) / 64), dim3(64), 0, be.stream, pv, ncols, Z);
+        if (use_bcr) {
+          hipLaunchKernelGGL(k_sep_bcr_factor<9>, dim3(1), dim3(1024), 0, be.stream, pv, fail);
+          hipLaunchKernelGGL(k_sep_bcr_rhs<9>, dim3((ncols + kBcrCols - 1) / kBcrCols), dim3(256), bcr_lds, be.stream, pv, ncols, Z);
+        } else {
+          hipLaunchKernelGGL(k_sep_factor<9>, dim3(1), dim3(64), 0, be.stream, pv, fail);
+          hipLaunchKernelGGL(k_sep_rhs<9>, dim3((ncols + 63) / 64), dim3(64), 0, be.stream, pv, ncols, Z);
+        }
       }
     } else {
       hipLaunchKernelGGL(k_part_cholesky<17>, dim3(pv.P), dim3(64), 0, be.stream, pv, Lb, fail);
       hipLaunchKernelGGL(k_part_solve<17>, gsolve, dim3(64), 0, be.stream, pv, ncols, Lb, Z);
       if (pv.P > 1) {
         hipLaunchKernelGGL(k_part_reduce<17>, dim3(pv.P - 1), dim3(256), 0, be.stream, pv, ncols, Lb, Z);
-        hipLaunchKernelGGL(k_sep_factor<15>, dim3(1), dim3(64), 0, be.stream, pv, fail);
-        hipLaunchKernelGGL(k_sep_rhs<15>, dim3((ncols + 63) / 64), dim3(64), 0, be.stream, pv, ncols, Z);
+        if (use_bcr) {
+          hipLaunchKernelGGL(k_sep_bcr_factor<15>, dim3(1), dim3(1024), 0, be.stream, pv, fail);
+          hipLaunchKernelGGL(k_sep_bcr_rhs<15>, dim3((ncols + kBcrCols - 1) / kBcrCols), dim3(256), bcr_lds, be.stream, pv, ncols, Z);
+        } else {
+          hipLaunchKernelGGL(k_sep_factor<15>, dim3(1), dim3(64), 0, be.stream, pv, fail);
+          hipLaunchKernelGGL(k_sep_rhs<15>, dim3((ncols + 63) / 64), dim3(64), 0, be.stream, pv, ncols, Z);
+        }
       }
     }
     if (pv.P > 1) hipLaunchKernelGGL(k_part_back, dim3(pv.P, 8), dim3(256), 0, be.stream, pv, ncols, Z);
@@ -1076,20 +1298,17 @@ struct HipSchur {
     hipLaunchKernelGGL(k_schur_finish, dim3((unsigned)((nS + 255) / 256)), dim3(256), 0, be.stream, ne, ncols, lambda, G, S, rhs);
     {
       const int nn = ne.CB;
+      hipLaunchKernelGGL(k_chol_first, dim3(1), dim3(64), 0, be.stream, nn, S, Lf, Linv, fail);
       for (int kb = 0; kb < nn; kb += kNB) {
         const int nb = std::min(kNB, nn - kb), below = nn + 1 - (kb + nb);       // rows under the panel incl. the rhs row
-        hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(256), 0, be.stream, nn, kb, S, fail);
-        hipLaunchKernelGGL(k_trsm_panel, dim3((below + kTrsmThreads - 1) / kTrsmThreads), dim3(kTrsmThreads), 0, be.stream, nn, kb, S);
         const int tiles = (below + kNB - 1) / kNB;
-        hipLaunchKernelGGL(k_syrk_update, dim3(tiles, tiles), dim3(kNB * kNB), 0, be.stream, nn, kb, S);
+        hipLaunchKernelGGL(k_chol_step, dim3(tiles, tiles), dim3(kNB * kNB), 0, be.stream, nn, kb, S, Lf, Linv, fail);
       }
-      for (int kb = ((nn - 1) / kNB) * kNB; kb >= 0; kb -= kNB)
-        hipLaunchKernelGGL(k_backsub_panel, dim3(1), dim3(256), 0, be.stream, nn, kb, S);
-      hipLaunchKernelGGL(k_negate_copy, dim3((nn + 255) / 256), dim3(256), 0, be.stream, nn, S + (size_t)nn * nn, pc);
+      hipLaunchKernelGGL(k_chol_backsub, dim3(1), dim3(1024), 0, be.stream, nn, Lf, Linv, pc);
     }
     MVUS_HIP(hipMemsetAsync(px, 0, be.hp.n * sizeof(double), be.stream));
     const int tot = ne.CB + ne.N3;
-    hipLaunchKernelGGL(k_back_substitute, dim3((tot + kThreads - 1) / kThreads), dim3(kThreads), 0, be.stream, be.dp, ne, ncols, Z, pc, px);
+    hipLaunchKernelGGL(k_back_substitute, dim3((ne.N3 + kThreads / 64 - 1) / (kThreads / 64)), dim3(kThreads), 0, be.stream, be.dp, ne, ncols, Z, pc, px);
     MVUS_HIP(hipGetLastError());
     MVUS_HIP(hipMemcpyAsync(fail_host, fail, sizeof(int), hipMemcpyDeviceToHost, be.stream));
     p.resize(be.hp.n);

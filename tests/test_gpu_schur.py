@@ -108,13 +108,38 @@ def test_partitioned_band_solver_many_partitions(motion):
     np.testing.assert_allclose(r.x, xh, rtol=0, atol=1e-5 * max(1.0, np.abs(xh).max()))
 
 
+@pytest.mark.parametrize('num_knots', [75, 140, 210, 280, 420, 560])
+@pytest.mark.parametrize('sequential', [False, True])
+def test_separator_chain_lengths(num_knots, sequential, monkeypatch):
+    """1, 2, 3, 4, 6 and 8 separators (odd, even, power of two): the cyclic-reduction separator solve and the
+    sequential block-tridiagonal one (MVUS_SEP_SEQUENTIAL, also the path for very long chains) both reproduce the
+    dense host LM."""
+    from mvus_amd import synth
+    from mvus_amd.ba import BAHandle
+    if sequential:
+        monkeypatch.setenv('MVUS_SEP_SEQUENTIAL', '1')
+    sc = synth.make_scene(3, 3000, seed=31, rolling_shutter=True, num_knots=num_knots)
+    prob, x0 = mp.problem_from_scene(sc)
+    opts = _lib.default_opts(_lib.SOLVER_LM_SCHUR, _lib.JAC_ANALYTIC, 3)
+    xh, rh, fh = _host(prob).solve(x0, opts)
+    with BAHandle(prob) as h:
+        r = h.solve(x0, opts=opts)
+    assert (r.nfev, r.njev, r.status) == (rh.nfev, rh.njev, rh.status)
+    np.testing.assert_allclose(r.cost, rh.cost, rtol=1e-7)
+    np.testing.assert_allclose(r.x, xh, rtol=0, atol=1e-5 * max(1.0, np.abs(xh).max()))
+
+
 def test_unsorted_and_sparse_detections_take_the_atomic_fallback():
-    """Detections shuffled in time (knot spans interleave in index order) and a camera with huge frame gaps (more spans
-    than a chunk window holds): the gather kernels defer those chunks to the atomic kernels; results are unchanged."""
+    """Detections shuffled locally (knot spans interleave in index order: sorted by span in LDS), shuffled globally and a
+    camera with huge frame gaps (more spans than a chunk window holds: deferred to the atomic kernels); results are
+    unchanged."""
     from mvus_amd import synth
     from mvus_amd.ba import BAHandle
     sc = synth.make_scene(3, 3000, seed=23, rolling_shutter=True, num_knots=400)
     rng = np.random.default_rng(5)
+    n0 = sc.detections[0].shape[1]
+    local = np.concatenate([b + rng.permutation(min(16, n0 - b)) for b in range(0, n0, 16)])
+    sc.detections[0] = sc.detections[0][:, local]                                            # spans interleave, window fits
     sc.detections[1] = sc.detections[1][:, rng.permutation(sc.detections[1].shape[1])]       # unsorted
     sc.detections[2] = sc.detections[2][:, ::9]                                              # sparse: ~27 frames apart
     prob, x0 = mp.problem_from_scene(sc)
@@ -138,3 +163,4 @@ def test_unsorted_and_sparse_detections_take_the_atomic_fallback():
         for w in range(band.shape[1]):
             if gi + w < band.shape[0]:
                 np.testing.assert_allclose(band[gi, w], Hs[3 * gi:3 * gi + 3, 3 * (gi + w):3 * (gi + w) + 3], rtol=0, atol=1e-12 * scale)
+
