@@ -710,77 +710,88 @@ __global__ __launch_bounds__(64) void k_sep_rhs(PartView pv, int ncols, double* 
 // k_sep_bcr_rhs: the right-hand sides, kBcrCols columns per workgroup staged in LDS through all levels and back.
 template <int S3>
 __global__ __launch_bounds__(1024) void k_sep_bcr_factor(PartView pv, int* __restrict__ fail) {
+  // one thread per (node, block row): the row lives in registers, only the pivot row of each Gauss-Jordan step goes
+  // through LDS (double buffered: one barrier per step)
   constexpr int SS = S3 * S3;
-  constexpr int NB = 20736 / (8 * SS) > 0 ? 20736 / (8 * SS) : 1;     // nodes inverted per batch: two LDS copies <= 41 KB
-  __shared__ double M0[NB * SS], M1[NB * SS];
+  constexpr int NBT = 1024 / S3;                     // nodes per pass
+  __shared__ double prow[2][NBT][S3];
   const int m = pv.P - 1, tid = threadIdx.x;
+  const int n = tid / S3, a = tid % S3;
   double* Ccur = pv.U;
   double* Cnxt = pv.U2;
   for (int h = 1; h <= m; h <<= 1) {
     const int ne = (m / h + 1) / 2, ns = m / (2 * h);
-    // in-place Gauss-Jordan (sweep) inversion of the eliminated nodes' diagonal blocks, NB nodes at a time
-    for (int b0 = 0; b0 < ne; b0 += NB) {
-      const int cnt = min(NB, ne - b0) * SS;
-      for (int e = tid; e < cnt; e += 1024) {
-        const int j = h * (2 * (b0 + e / SS) + 1) - 1;
-        M0[e] = pv.T[(long long)j * SS + e % SS];
-      }
-      __syncthreads();
-      double* src = M0;
-      double* dst = M1;
+    for (int b0 = 0; b0 < ne; b0 += NBT) {
+      const bool act = n < NBT && b0 + n < ne;
+      const int j = act ? h * (2 * (b0 + n) + 1) - 1 : 0;
+      double row[S3];
+#pragma unroll
+      for (int b = 0; b < S3; ++b) row[b] = act ? pv.T[(long long)j * SS + a * S3 + b] : 0.0;
+#pragma unroll
       for (int k = 0; k < S3; ++k) {
-        for (int e = tid; e < cnt; e += 1024) {
-          const int r = e % SS, a = r / S3, b = r % S3;
-          const double* Mn = src + (e - r);
-          double piv = Mn[k * S3 + k];
-          if (!(piv > 0.0)) { fail[0] = 3; piv = 1.0; }
-          const double ip = 1.0 / piv;
-          double v;
-          if (a == k) v = (b == k) ? ip : Mn[k * S3 + b] * ip;
-          else if (b == k) v = -Mn[a * S3 + k] * ip;
-          else v = Mn[r] - Mn[a * S3 + k] * Mn[k * S3 + b] * ip;
-          dst[e] = v;
+        if (act && a == k) {
+#pragma unroll
+          for (int b = 0; b < S3; ++b) prow[k & 1][n][b] = row[b];
         }
         __syncthreads();
-        double* t_ = src; src = dst; dst = t_;
+        if (act) {
+          const double* pr = prow[k & 1][n];
+          double piv = pr[k];
+          if (!(piv > 0.0)) { fail[0] = 3; piv = 1.0; }
+          double ip = __builtin_amdgcn_rcp(piv);
+          ip = ip * (2.0 - piv * ip);
+          ip = ip * (2.0 - piv * ip);
+          if (a == k) {
+#pragma unroll
+            for (int b = 0; b < S3; ++b) row[b] = (b == k) ? ip : row[b] * ip;
+          } else {
+            const double f = row[k] * ip;
+#pragma unroll
+            for (int b = 0; b < S3; ++b) row[b] = (b == k) ? -f : row[b] - f * pr[b];
+          }
+        }
       }
-      for (int e = tid; e < cnt; e += 1024) {
-        const int j = h * (2 * (b0 + e / SS) + 1) - 1;
-        pv.T[(long long)j * SS + e % SS] = src[e];
+      if (act) {
+        // row a of Dinv_j, Ha_j = Dinv_j C_{j-h}^T and Hc_j = Dinv_j C_j
+        const bool left = j - h >= 0, right = j + h < m;
+        const double* Cl = Ccur + (long long)(left ? j - h : j) * SS;
+        const double* Cj = Ccur + (long long)j * SS;
+#pragma unroll
+        for (int b = 0; b < S3; ++b) {
+          double xa = 0.0, xc = 0.0;
+#pragma unroll
+          for (int k = 0; k < S3; ++k) { xa += row[k] * Cl[b * S3 + k]; xc += row[k] * Cj[k * S3 + b]; }
+          pv.T[(long long)j * SS + a * S3 + b] = row[b];
+          pv.Ha[(long long)j * SS + a * S3 + b] = left ? xa : 0.0;
+          pv.Hc[(long long)j * SS + a * S3 + b] = right ? xc : 0.0;
+        }
       }
       __syncthreads();
     }
-    // Ha_j = Dinv_j C_{j-h}^T, Hc_j = Dinv_j C_j
-    for (int e = tid; e < ne * 2 * SS; e += 1024) {
-      const int which = e / (ne * SS), e2 = e % (ne * SS);
-      const int j = h * (2 * (e2 / SS) + 1) - 1, r = e2 % SS, a = r / S3, b = r % S3;
-      const double* Di = pv.T + (long long)j * SS + a * S3;
-      double acc = 0.0;
-      if (which == 0) {
-        if (j - h >= 0) { const double* Cl = Ccur + (long long)(j - h) * SS + b * S3; for (int k = 0; k < S3; ++k) acc += Di[k] * Cl[k]; }
-        pv.Ha[(long long)j * SS + r] = acc;
-      } else {
-        if (j + h < m) { const double* Cj = Ccur + (long long)j * SS + b; for (int k = 0; k < S3; ++k) acc += Di[k] * Cj[k * S3]; }
-        pv.Hc[(long long)j * SS + r] = acc;
-      }
-    }
-    __syncthreads();
-    for (int e = tid; e < ns * 2 * SS; e += 1024) {
-      const int which = e / (ns * SS), e2 = e % (ns * SS);
-      const int i = 2 * h * (e2 / SS + 1) - 1, r = e2 % SS, a = r / S3, b = r % S3;
-      const bool right = i + h < m;
-      const double* Ci = Ccur + (long long)i * SS + a * S3;
-      if (which == 0) {
-        const double* Cl = Ccur + (long long)(i - h) * SS + a;
-        const double* Hl = pv.Hc + (long long)(i - h) * SS + b;
-        double acc = pv.T[(long long)i * SS + r];
-        for (int k = 0; k < S3; ++k) acc -= Cl[k * S3] * Hl[k * S3];
-        if (right) { const double* Hr = pv.Ha + (long long)(i + h) * SS + b; for (int k = 0; k < S3; ++k) acc -= Ci[k] * Hr[k * S3]; }
-        pv.T[(long long)i * SS + r] = acc;
-      } else {
-        double acc = 0.0;
-        if (right) { const double* Hr = pv.Hc + (long long)(i + h) * SS + b; for (int k = 0; k < S3; ++k) acc -= Ci[k] * Hr[k * S3]; }
-        Cnxt[(long long)i * SS + r] = acc;
+    for (int b0 = 0; b0 < ns; b0 += NBT) {
+      if (n < NBT && b0 + n < ns) {
+        const int i = 2 * h * (b0 + n + 1) - 1;
+        const bool right = i + h < m;
+        const double* Cl = Ccur + (long long)(i - h) * SS;
+        const double* Ci = Ccur + (long long)i * SS + a * S3;
+        const double* Hl = pv.Hc + (long long)(i - h) * SS;
+        const double* Hra = pv.Ha + (long long)(right ? i + h : i) * SS;
+        const double* Hrc = pv.Hc + (long long)(right ? i + h : i) * SS;
+        double ci[S3], cl[S3];
+#pragma unroll
+        for (int k = 0; k < S3; ++k) { ci[k] = right ? Ci[k] : 0.0; cl[k] = Cl[k * S3 + a]; }
+#pragma unroll
+        for (int b = 0; b < S3; ++b) {
+          double dd = pv.T[(long long)i * SS + a * S3 + b], cc = 0.0;
+#pragma unroll
+          for (int k = 0; k < S3; ++k) dd -= cl[k] * Hl[k * S3 + b];
+          if (right) {
+#pragma unroll
+            for (int k = 0; k < S3; ++k) { dd -= ci[k] * Hra[k * S3 + b]; cc -= ci[k] * Hrc[k * S3 + b]; }
+          }
+          pv.T[(long long)i * SS + a * S3 + b] = dd;
+          Cnxt[(long long)i * SS + a * S3 + b] = cc;
+        }
       }
     }
     __syncthreads();
@@ -919,54 +930,99 @@ __global__ __launch_bounds__(64) void k_band_solve(int n3, int ncols, const doub
   }
 }
 
-// G[CB][ncols] += Et^T Z : the one dense contraction of the solve (2 * CB^2 * 3N flops).  64x64 output tile per
-// workgroup, 4x4 outputs per thread held in registers, 32-row slices of both operands staged in LDS, split over the
-// long K (= 3N) dimension with one fp64 atomic per output element and K-slab.
-constexpr int kGemmT = 64, kGemmKs = 32, kGemmSlab = 1024;
-__global__ __launch_bounds__(256) void k_schur_gemm(NEView ne, int ncols, const double* __restrict__ Erm, const double* __restrict__ Z, double* __restrict__ G) {
-  __shared__ double Es[kGemmKs][kGemmT + 1];
-  __shared__ double Zs[kGemmKs][kGemmT + 1];
-  const int a0 = blockIdx.x * kGemmT, b0 = blockIdx.y * kGemmT;
-  const int kbeg = blockIdx.z * kGemmSlab, kend = min(kbeg + kGemmSlab, ne.N3);
-  const int ta = (threadIdx.x / 16) * 4, tb = (threadIdx.x % 16) * 4;
-  double acc[4][4];
+// Gp[slab][CB][ncols] = Et^T Z over one K-slab: the one dense contraction of the solve (2 * CB^2 * 3N flops), on the
+// fp64 matrix cores (v_mfma_f64_16x16x4_f64).  Both operands are stored K-major ([3N][CB] and [3N][ncols]), which is
+// exactly the MFMA operand layout (lane l: A[l&15][k = l>>4], B[k = l>>4][l&15]; every 16-lane group reads 128
+// contiguous bytes), so fragments go from global memory straight to registers -- no LDS staging.  One wavefront owns a
+// 48x48 output tile (3x3 MFMA tiles, 36 accumulator registers) over kGemmWaveK rows of K; the four wavefronts of a
+// workgroup take consecutive K ranges of the same tile and are summed through LDS.  Et^T C^-1 Et is symmetric: only
+// tiles on or below the block diagonal are computed (k_schur_finish mirrors), plus one 48x16 tile per block row for
+// the right-hand-side column.  Partial sums per slab are written, not atomically added: no memset, deterministic.
+using d4 = __attribute__((ext_vector_type(4))) double;
+constexpr int kGemmT = 48, kGemmWaveK = 256, kGemmSlab = 4 * kGemmWaveK;
+
+template <int NJ>   // NJ = 3: 48x48 tile of the symmetric part, NJ = 1: 48x16 tile holding the rhs column
+__device__ __forceinline__ void schur_gemm_tile(const NEView& ne, int ncols, const double* __restrict__ Erm, const double* __restrict__ Z,
+                                                double* __restrict__ Gp, int a0, int b0, int kbeg, int kend, double* red) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lr = lane & 15, lk = lane >> 4;
+  d4 acc[3][NJ];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 3; ++i)
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj) acc[i][jj] = 0.0;
-  for (int k0 = kbeg; k0 < kend; k0 += kGemmKs) {
-    for (int e = threadIdx.x; e < kGemmKs * kGemmT; e += 256) {
-      const int kk = e / kGemmT, cc = e % kGemmT, r = k0 + kk;
-      Es[kk][cc] = (r < kend && a0 + cc < ne.CB) ? Erm[(long long)r * ne.CB + a0 + cc] : 0.0;
-      Zs[kk][cc] = (r < kend && b0 + cc < ncols) ? Z[(long long)r * ncols + b0 + cc] : 0.0;
-    }
-    __syncthreads();
+    for (int j = 0; j < NJ; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+  bool av[3], bv[NJ];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) av[i] = a0 + 16 * i + lr < ne.CB;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) bv[j] = NJ == 3 ? (b0 + 16 * j + lr < ne.CB) : (lr == 0);
+  const int k0 = kbeg + wave * kGemmWaveK, k1 = min(k0 + kGemmWaveK, kend);
+  const double* ap = Erm + (long long)(k0 + lk) * ne.CB + a0 + lr;
+  const double* bp = Z + (long long)(k0 + lk) * ncols + b0 + lr;
 #pragma unroll 4
-    for (int kk = 0; kk < kGemmKs; ++kk) {
-      double ea[4], zb[4];
+  for (int k = k0; k < k1; k += 4) {
+    const bool kv = k + lk < k1;
+    double a[3], b[NJ];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { ea[i] = Es[kk][ta + i]; zb[i] = Zs[kk][tb + i]; }
+    for (int i = 0; i < 3; ++i) a[i] = (kv && av[i]) ? ap[16 * i] : 0.0;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < NJ; ++j) b[j] = (kv && bv[j]) ? bp[16 * j] : 0.0;
+    ap += 4 * (long long)ne.CB; bp += 4 * (long long)ncols;
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) acc[i][jj] += ea[i] * zb[jj];
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+  }
+  // sum the four wavefronts through LDS, then store: element (i, j, reg) of lane l is row 16i + (l>>4) + 4 reg, col 16j + (l&15)
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            double* dst = red + ((i * NJ + j) * 4 + r) * 64 + lane;
+            *dst = (w == 0 ? 0.0 : *dst) + acc[i][j][r];
+          }
     }
     __syncthreads();
   }
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj)
-      if (a0 + ta + i < ne.CB && b0 + tb + jj < ncols && acc[i][jj] != 0.0)
-        unsafeAtomicAdd(&G[(long long)(a0 + ta + i) * ncols + b0 + tb + jj], acc[i][jj]);
+  for (int e = threadIdx.x; e < 3 * NJ * 4 * 64; e += 256) {
+    const int l = e & 63, r = (e >> 6) & 3, ij = e >> 8, i = ij / NJ, j = ij % NJ;
+    const int row = a0 + 16 * i + (l >> 4) + 4 * r, col = b0 + 16 * j + (l & 15);
+    if (row < ne.CB && col < ncols && (NJ == 3 ? col < ne.CB : (l & 15) == 0)) Gp[(long long)row * ncols + col] = red[e];
+  }
 }
 
-// S = (A + lambda D_c) - G[:, :CB] (dense CB x CB), rhs = gc - G[:, CB]
-__global__ void k_schur_finish(NEView ne, int ncols, double lambda, const double* __restrict__ G, double* __restrict__ S, double* __restrict__ rhs) {
+__global__ __launch_bounds__(256) void k_schur_gemm(NEView ne, int ncols, const double* __restrict__ Erm, const double* __restrict__ Z, double* __restrict__ Gp) {
+  __shared__ double red[9 * 4 * 64];
+  const int nbk = (ne.CB + kGemmT - 1) / kGemmT, nsym = nbk * (nbk + 1) / 2;
+  const int t = blockIdx.x;
+  const int kbeg = blockIdx.y * kGemmSlab, kend = min(kbeg + kGemmSlab, ne.N3);
+  double* G = Gp + (long long)blockIdx.y * ne.CB * ncols;
+  if (t < nsym) {
+    int bi = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+    while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
+    while (bi * (bi + 1) / 2 > t) --bi;
+    const int bj = t - bi * (bi + 1) / 2;
+    schur_gemm_tile<3>(ne, ncols, Erm, Z, G, bi * kGemmT, bj * kGemmT, kbeg, kend, red);
+  } else {
+    schur_gemm_tile<1>(ne, ncols, Erm, Z, G, (t - nsym) * kGemmT, ne.CB, kbeg, kend, red);
+  }
+}
+
+// S = (A + lambda D_c) - sum_slabs Gp[:, :CB] (dense CB x CB, both triangles from the computed lower block triangle),
+// rhs = gc - sum_slabs Gp[:, CB]
+__global__ void k_schur_finish(NEView ne, int ncols, int nslab, double lambda, const double* __restrict__ Gp, double* __restrict__ S, double* __restrict__ rhs) {
   const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (idx >= (long long)ne.CB * ne.CB) return;
   const int a = (int)(idx / ne.CB), b = (int)(idx % ne.CB);
-  double v = -G[(long long)a * ncols + b];
+  const int hi = a / kGemmT >= b / kGemmT ? a : b, lo = a / kGemmT >= b / kGemmT ? b : a;
+  const long long stride = (long long)ne.CB * ncols;
+  double g = 0.0;
+  for (int sl = 0; sl < nslab; ++sl) g += Gp[sl * stride + (long long)hi * ncols + lo];
+  double v = -g;
   if (a / ne.B == b / ne.B) {
     const int c = a / ne.B;
     double h = ne.A[((long long)c * ne.B + a % ne.B) * ne.B + b % ne.B];
@@ -974,7 +1030,11 @@ __global__ void k_schur_finish(NEView ne, int ncols, double lambda, const double
     v += h;
   }
   S[idx] = v;
-  if (b == 0) S[(long long)ne.CB * ne.CB + a] = ne.gc[a] - G[(long long)a * ncols + ne.CB];   // rhs rides as row CB
+  if (b == 0) {
+    double gr = 0.0;
+    for (int sl = 0; sl < nslab; ++sl) gr += Gp[sl * stride + (long long)a * ncols + ne.CB];
+    S[(long long)ne.CB * ne.CB + a] = ne.gc[a] - gr;   // rhs rides as row CB
+  }
 }
 
 // Dense Cholesky + solve of the reduced camera system (nn <= 1152), blocked with panels of kNB columns, ONE launch
@@ -1079,41 +1139,51 @@ __global__ __launch_bounds__(1024) void k_chol_step(int nn, int kb, double* __re
 
 // backward substitution L^T x = y by one workgroup, panel by panel from the last: x_k = Linv_k^T (y_k - sum_{j>k} L_jk^T x_j);
 // y = row nn of Lf.  Writes pc = -x (the camera part of the LM step).
-__global__ __launch_bounds__(1024) void k_chol_backsub(int nn, const double* __restrict__ Lf, const double* __restrict__ Linv, double* __restrict__ pc) {
+constexpr int kBsThreads = 512;    // 2 x 32 prefetched doubles per thread must stay in registers (256 VGPRs at 8 waves per CU)
+__global__ __launch_bounds__(kBsThreads) void k_chol_backsub(int nn, const double* __restrict__ Lf, const double* __restrict__ Linv, double* __restrict__ pc) {
   __shared__ double y[1152];
-  __shared__ double Ls[kNB][kNB + 1];
+  __shared__ double Ls[2][kNB][kNB + 1];
   __shared__ double xk[kNB];
   const int tid = threadIdx.x;
-  for (int i = tid; i < nn; i += 1024) y[i] = Lf[(long long)nn * nn + i];
-  for (int kb = ((nn - 1) / kNB) * kNB; kb >= 0; kb -= kNB) {
+  for (int i = tid; i < nn; i += kBsThreads) y[i] = Lf[(long long)nn * nn + i];
+  // the factor rows and inverse block a panel needs do not depend on the solution: they are fetched one panel ahead,
+  // so the dependent part of every step only touches LDS
+  double lv[kNB], ln[kNB];
+  const int kb_last = ((nn - 1) / kNB) * kNB;
+  auto fetch = [&](int kb, double* dst, int buf) {
     const int nb = min(kNB, nn - kb);
-    Ls[tid / kNB][tid % kNB] = Linv[(long long)(kb / kNB) * kNB * kNB + tid];
-    // the rows of the factor this panel needs, fetched before the dependent part (all loads in flight together)
-    double lv[kNB];
-    const int i = tid;
 #pragma unroll
-    for (int cc = 0; cc < kNB; ++cc) lv[cc] = (i < kb && cc < nb) ? Lf[(long long)(kb + cc) * nn + i] : 0.0;
+    for (int cc = 0; cc < kNB; ++cc) dst[cc] = (kb >= 0 && tid < kb && cc < nb) ? Lf[(long long)(kb + cc) * nn + tid] : 0.0;
+    if (kb >= 0)
+      for (int e = tid; e < kNB * kNB; e += kBsThreads) Ls[buf][e / kNB][e % kNB] = Linv[(long long)(kb / kNB) * kNB * kNB + e];
+  };
+  fetch(kb_last, ln, 0);
+  int buf = 0;
+  for (int kb = kb_last; kb >= 0; kb -= kNB, buf ^= 1) {
+    const int nb = min(kNB, nn - kb);
+#pragma unroll
+    for (int cc = 0; cc < kNB; ++cc) lv[cc] = ln[cc];
+    fetch(kb - kNB, ln, buf ^ 1);
     __syncthreads();
     if (tid < kNB) {
       double acc = 0.0;
 #pragma unroll
-      for (int rr = 0; rr < kNB; ++rr) acc += (rr < nb && tid < nb) ? Ls[rr][tid] * y[kb + rr] : 0.0;      // Linv is lower triangular
+      for (int rr = 0; rr < kNB; ++rr) acc += (rr < nb && tid < nb) ? Ls[buf][rr][tid] * y[kb + rr] : 0.0;      // Linv is lower triangular
       xk[tid] = acc;
       if (tid < nb) pc[kb + tid] = -acc;
     }
     __syncthreads();
-    if (i < kb) {
-      double vv = y[i];
+    if (tid < kb) {
+      double vv = y[tid];
 #pragma unroll
       for (int cc = 0; cc < kNB; ++cc) vv -= lv[cc] * xk[cc];
-      y[i] = vv;
+      y[tid] = vv;
     }
-    for (int i2 = tid + 1024; i2 < kb; i2 += 1024) {
+    for (int i2 = tid + kBsThreads; i2 < kb; i2 += kBsThreads) {
       double vv = y[i2];
       for (int cc = 0; cc < nb; ++cc) vv -= Lf[(long long)(kb + cc) * nn + i2] * xk[cc];
       y[i2] = vv;
     }
-    __syncthreads();
   }
 }
 
@@ -1148,6 +1218,7 @@ struct HipSchur {
   int* fail_host = nullptr;
   PartView pv{};
   int* part_tables = nullptr;
+  int nslab = 1;            // K-slabs of the Schur product (partial sums in G)
   size_t bcr_lds = 0;       // dynamic LDS of k_sep_bcr_rhs; the sequential separator kernels remain for chains too long for it
   bool use_bcr = false;
   int* redo = nullptr;      // per half chunk: 1 = the gather assembly deferred it to the atomic kernel
@@ -1174,7 +1245,8 @@ struct HipSchur {
     Lb = be.alloc((size_t)ne.N3 * (BW + 1));
     Z = be.alloc((size_t)ne.N3 * ncols);
     Erm = be.alloc((size_t)ne.N3 * ne.CB);
-    G = be.alloc((size_t)ne.CB * ncols);
+    nslab = (ne.N3 + kGemmSlab - 1) / kGemmSlab;
+    G = be.alloc((size_t)nslab * ne.CB * ncols);
     S = be.alloc((size_t)(ne.CB + 1) * ne.CB);
     rhs = be.alloc(ne.CB); pc = be.alloc(ne.CB);
     Lf = be.alloc((size_t)(ne.CB + 1) * ne.CB);
@@ -1292,10 +1364,12 @@ struct HipSchur {
       }
     }
     if (pv.P > 1) hipLaunchKernelGGL(k_part_back, dim3(pv.P, 8), dim3(256), 0, be.stream, pv, ncols, Z);
-    MVUS_HIP(hipMemsetAsync(G, 0, (size_t)ne.CB * ncols * sizeof(double), be.stream));
-    hipLaunchKernelGGL(k_schur_gemm, dim3((ne.CB + kGemmT - 1) / kGemmT, (ncols + kGemmT - 1) / kGemmT, (ne.N3 + kGemmSlab - 1) / kGemmSlab), dim3(256), 0, be.stream, ne, ncols, Erm, Z, G);
+    {
+      const int nbk = (ne.CB + kGemmT - 1) / kGemmT;
+      hipLaunchKernelGGL(k_schur_gemm, dim3(nbk * (nbk + 1) / 2 + nbk, nslab), dim3(256), 0, be.stream, ne, ncols, Erm, Z, G);
+    }
     const long long nS = (long long)ne.CB * ne.CB;
-    hipLaunchKernelGGL(k_schur_finish, dim3((unsigned)((nS + 255) / 256)), dim3(256), 0, be.stream, ne, ncols, lambda, G, S, rhs);
+    hipLaunchKernelGGL(k_schur_finish, dim3((unsigned)((nS + 255) / 256)), dim3(256), 0, be.stream, ne, ncols, nslab, lambda, G, S, rhs);
     {
       const int nn = ne.CB;
       hipLaunchKernelGGL(k_chol_first, dim3(1), dim3(64), 0, be.stream, nn, S, Lf, Linv, fail);
@@ -1304,7 +1378,7 @@ struct HipSchur {
         const int tiles = (below + kNB - 1) / kNB;
         hipLaunchKernelGGL(k_chol_step, dim3(tiles, tiles), dim3(kNB * kNB), 0, be.stream, nn, kb, S, Lf, Linv, fail);
       }
-      hipLaunchKernelGGL(k_chol_backsub, dim3(1), dim3(1024), 0, be.stream, nn, Lf, Linv, pc);
+      hipLaunchKernelGGL(k_chol_backsub, dim3(1), dim3(kBsThreads), 0, be.stream, nn, Lf, Linv, pc);
     }
     MVUS_HIP(hipMemsetAsync(px, 0, be.hp.n * sizeof(double), be.stream));
     const int tot = ne.CB + ne.N3;
