@@ -35,77 +35,39 @@ __device__ __forceinline__ int wave_min_i(int v) {
   return v;
 }
 
-// ---- assembly of the detection rows, atomic form (fallback) ---------------------------------------------------
-// Only for the half chunks the gather kernel below defers (`redo` flag: more knot spans than its window holds, i.e.
-// very sparse detections): one thread per detection adds its
-// contributions straight into the global blocks with fp64 atomics.  Rare, so simplicity beats speed here.
-template <int NS>
-__global__ __launch_bounds__(kThreads) void k_assemble(DevProblem dp, const double* __restrict__ J, const int32_t* __restrict__ span,
-                                                       const double* __restrict__ f, NEView ne, const int* __restrict__ redo) {
-  constexpr int B = NS - 12;
-  const int chunk = blockIdx.x;
-  const int r0 = redo[2 * chunk], r1 = redo[2 * chunk + 1];
-  if (!r0 && !r1) return;
-  const int c = dp.chunk_cam[chunk];
-  const bool active = (int)threadIdx.x < dp.chunk_count[chunk] && (threadIdx.x < kThreads / 2 ? r0 : r1);
-  const long long i = dp.chunk_start[chunk] + (active ? threadIdx.x : 0);
-  const long long a0 = dp.det_off[c], Mc = dp.det_off[c + 1] - a0;
-  const int g = active ? span[i] : -1;
-  const int lane = threadIdx.x & 63;
-  double jx[NS], jy[NS];
-  double fx = 0.0, fy = 0.0;
-#pragma unroll
-  for (int k = 0; k < NS; ++k) { jx[k] = g >= 0 ? J[(long long)k * dp.M + i] : 0.0; jy[k] = g >= 0 ? J[(long long)(NS + k) * dp.M + i] : 0.0; }
-  if (g >= 0) { fx = f[2 * a0 + (i - a0)]; fy = f[2 * a0 + Mc + (i - a0)]; }
-  // the camera block is shared by every lane: reduce over the wavefront first, one atomic per entry and wavefront
-#pragma unroll
-  for (int a = 0; a < B; ++a) {
-    double v = wave_sum(jx[a] * fx + jy[a] * fy);
-    if (lane == 0 && v != 0.0) unsafeAtomicAdd(&ne.gc[c * B + a], v);
-#pragma unroll
-    for (int b = 0; b <= a; ++b) {
-      v = wave_sum(jx[a] * jx[b] + jy[a] * jy[b]);
-      if (lane == 0 && v != 0.0) {
-        unsafeAtomicAdd(&ne.A[((long long)c * B + a) * B + b], v);
-        if (a != b) unsafeAtomicAdd(&ne.A[((long long)c * B + b) * B + a], v);
-      }
-    }
-  }
-  if (g < 0) return;
-#pragma unroll
-  for (int q = 0; q < 4; ++q)
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-      const int sq = B + 3 * q + d;
-      const double vx = jx[sq], vy = jy[sq];
-      const long long r = 3 * (g + q) + d;
-      unsafeAtomicAdd(&ne.gs[r], vx * fx + vy * fy);
-#pragma unroll
-      for (int k = 0; k < B; ++k) unsafeAtomicAdd(&ne.Et[((long long)c * ne.N3 + r) * B + k], jx[k] * vx + jy[k] * vy);
-#pragma unroll
-      for (int q2 = q; q2 < 4; ++q2)
-#pragma unroll
-        for (int d2 = 0; d2 < 3; ++d2)
-          unsafeAtomicAdd(&ne.Cb[((long long)(g + q) * ne.W + (q2 - q)) * 9 + 3 * d + d2], vx * jx[B + 3 * q2 + d2] + vy * jy[B + 3 * q2 + d2]);
-    }
-}
-
-// ---- assembly of the detection rows, gather form --------------------------------------------------------
+// ---- assembly of the detection rows ------------------------------------------------------------------------
 // One workgroup per HALF chunk (<=128 consecutive detections of one camera).  The 2*NS Jacobian slots and the two
-// residuals of those detections are staged in LDS (row stride padded to 129 doubles: bank-conflict free);
-// detections of one knot span occupy one contiguous index range, so every output entry -- camera block, gradient,
-// cross block E, spline band C -- is owned by exactly one thread, which sums the (at most four) span ranges that
-// touch it and issues ONE global fp64 atomic.  No LDS atomics (fp64 ds_add measured at ~8 cycles per lane), no
-// shuffles.  Half chunks whose spans interleave are first sorted by span in LDS; only those that overflow the window
-// (very sparse detections) are left to k_assemble (atomic form).
-constexpr int kGaObs = 128, kGaWin = 96, kGaStride = kGaObs + 1;
+// residuals of those detections are staged in LDS (row stride padded to 129 doubles).  Detections of one knot span
+// touch the same four control points and (sorted by time) occupy one contiguous index range.
+//   1. accumulate: thread (range, xyz d) forms, in registers, the outer products of its range -- 4 control points x
+//      (B camera columns + the gradient) for the cross block and the 10 control-point pairs x 3 coordinates of the
+//      spline band -- reading LDS ~0.4 times per FMA (a plain one-output-per-thread gather reads it twice per FMA and
+//      was LDS bound); the camera block is split four ways over the detections and summed with two shuffles;
+//   2. flush: the staged Jacobian is dead, its LDS is reused for the per-range partial blocks; every output entry is
+//      then owned by ONE thread, which sums the (at most four) ranges that touch its control point and issues one
+//      global fp64 atomic, consecutive threads on consecutive addresses.  (Measured: the L2 retires ~35 G atomic
+//      cache-line transactions/s, so scattered per-range atomics cost 1 ms here while coalesced ones are free; LDS
+//      fp64 atomics cost ~8 cycles per lane and are not used at all.)
+// When a large rolling-shutter coefficient reorders the time stamps (spans interleave in index order) the staged
+// columns are first rank-sorted by span in LDS.  Half chunks with more than kGaMaxR ranges (very sparse detections)
+// take the slow path: per-range atomics straight from the registers.
+constexpr int kGaObs = 128, kGaStride = kGaObs + 1, kGaThreads = 512, kGaMaxR = kGaThreads / 6;
 template <int NS>
-__global__ __launch_bounds__(kThreads) void k_assemble_gather(DevProblem dp, const double* __restrict__ J, const int32_t* __restrict__ span,
-                                                              const double* __restrict__ f, NEView ne, int* __restrict__ redo) {
+__global__ __launch_bounds__(kGaThreads) void k_assemble_spans(DevProblem dp, const double* __restrict__ J, const int32_t* __restrict__ span,
+                                                             const double* __restrict__ f, NEView ne) {
   constexpr int B = NS - 12;
-  __shared__ double Js[(2 * NS + 2) * kGaStride];     // rows 0..NS-1: x-row slots, NS..2NS-1: y-row slots, then fx, fy
-  __shared__ int lo[kGaWin], hi[kGaWin], key[kGaObs];
-  __shared__ int g0_s, bad_s, lmax_s;
+  constexpr int kJs = (2 * NS + 2) * kGaStride;
+  constexpr int kEp = 4 * 3 * B, kGp = 12, kCp = 10 * 9;        // partial block sizes per range: cross, gradient, band
+  constexpr int kRbE = kJs / (kEp + kGp), kRbC = kJs / kCp;     // ranges per flush round
+  __shared__ double Js[kJs];                             // rows 0..NS-1: x-row slots, NS..2NS-1: y-row slots, then fx, fy
+  __shared__ int meta[kGaObs + kGaObs / 2], rg[kGaObs];
+  __shared__ int any_s, sort_s, nr_s;
+  int* key = meta;                                                   // span per staged column
+  unsigned char* rs = reinterpret_cast<unsigned char*>(meta + kGaObs);   // first / one-past-last column of a range
+  unsigned char* re = rs + kGaObs;
+  // after the accumulation the three arrays above are dead and their storage holds the owner tables of the flush
+  unsigned char* own_r = reinterpret_cast<unsigned char*>(meta);         // [<= 4*kGaMaxR] range that owns control point i
+  unsigned short* obase = reinterpret_cast<unsigned short*>(meta + 96);  // [<= kGaMaxR + 1] first owned point of a range
   const int chunk = blockIdx.x >> 1, half = blockIdx.x & 1;
   const int c = dp.chunk_cam[chunk];
   const int cnt = min(kGaObs, dp.chunk_count[chunk] - half * kGaObs);
@@ -113,14 +75,17 @@ __global__ __launch_bounds__(kThreads) void k_assemble_gather(DevProblem dp, con
   const long long i0 = dp.chunk_start[chunk] + half * kGaObs;
   const long long a0 = dp.det_off[c], Mc = dp.det_off[c + 1] - a0;
   const int tid = threadIdx.x;
-  if (tid == 0) { g0_s = 0x7fffffff; bad_s = 0; lmax_s = -1; }
-  for (int k = tid; k < kGaWin; k += kThreads) { lo[k] = 0x7fffffff; hi[k] = 0; }
-  __syncthreads();
+  if (tid == 0) { any_s = 0; sort_s = 0; nr_s = 0; }
   const int t = tid & (kGaObs - 1);                    // detection handled while staging
   const int g = t < cnt ? span[i0 + t] : -1;
-  if (tid < kGaObs && g >= 0) atomicMin(&g0_s, g);
-  // stage: thread (tid) loads rows tid/128, tid/128+2, ... for detection t
-  for (int r = tid >> 7; r < 2 * NS + 2; r += 2) {
+  const int kt = g >= 0 ? g : 0x7fffffff;              // invisible detections sort last
+  if (tid < kGaObs) key[tid] = kt;
+  // stage: thread (tid) loads rows tid/128, tid/128+4, ... for detection t
+  constexpr int kRowsPer = (2 * NS + 2 + 3) / 4;
+#pragma unroll
+  for (int k = 0; k < kRowsPer; ++k) {
+    const int r = (tid >> 7) + 4 * k;
+    if (r >= 2 * NS + 2) break;
     double v = 0.0;
     if (g >= 0) {
       if (r < 2 * NS) v = J[(long long)r * dp.M + i0 + t];
@@ -129,95 +94,255 @@ __global__ __launch_bounds__(kThreads) void k_assemble_gather(DevProblem dp, con
     Js[r * kGaStride + t] = v;
   }
   __syncthreads();
-  const int g0 = g0_s;
-  if (g0 == 0x7fffffff) return;                        // nothing visible (uniform)
-  if (tid < kGaObs && g >= 0) {
-    const int l = g - g0;
-    if (l + 3 >= kGaWin) atomicOr(&bad_s, 1);
-    else { atomicMin(&lo[l], t); atomicMax(&hi[l], t + 1); atomicMax(&lmax_s, l); }
+  if (tid < kGaObs) {
+    if (g >= 0) any_s = 1;
+    if (tid > 0 && kt < key[tid - 1]) sort_s = 1;
   }
   __syncthreads();
-  if (tid < kGaWin && hi[tid] > 0)
-    for (int u = tid + 1; u < kGaWin; ++u)
-      if (hi[u] > 0) { if (lo[u] < hi[tid]) atomicOr(&bad_s, 2); break; }
-  if (tid < kGaObs) key[tid] = g >= 0 ? g - g0 : 0x7fff;
-  __syncthreads();
-  if (bad_s & 1) { if (tid == 0) redo[blockIdx.x] = 1; return; }
-  if (bad_s) {
-    // knot spans interleave in index order (a large rolling-shutter coefficient reorders the time stamps): stable
-    // rank sort of the staged columns by span, after which every span is one contiguous range again
+  if (!any_s) return;                                   // nothing visible (uniform)
+  if (sort_s) {
     int pos = 0;
-    const int kt = key[t];
     for (int u = 0; u < kGaObs; ++u) { const int ku = key[u]; pos += (ku < kt) || (ku == kt && u < t); }
-    double tmp[NS + 1];                                  // this thread's rows: (tid >> 7) + 2k, k = 0 .. NS
+    double tmp[kRowsPer];                                // this thread's rows: (tid >> 7) + 4k
 #pragma unroll
-    for (int k = 0; k <= NS; ++k) tmp[k] = Js[((tid >> 7) + 2 * k) * kGaStride + t];
-    for (int k = tid; k < kGaWin; k += kThreads) { lo[k] = 0x7fffffff; hi[k] = 0; }
+    for (int k = 0; k < kRowsPer; ++k) { const int r = (tid >> 7) + 4 * k; tmp[k] = r < 2 * NS + 2 ? Js[r * kGaStride + t] : 0.0; }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k <= NS; ++k) Js[((tid >> 7) + 2 * k) * kGaStride + pos] = tmp[k];
-    if (tid < kGaObs && g >= 0) { atomicMin(&lo[kt], pos); atomicMax(&hi[kt], pos + 1); }
+    for (int k = 0; k < kRowsPer; ++k) { const int r = (tid >> 7) + 4 * k; if (r < 2 * NS + 2) Js[r * kGaStride + pos] = tmp[k]; }
+    if (tid < kGaObs) key[pos] = kt;
     __syncthreads();
   }
-  const int nctrl = lmax_s + 4;                        // local control points 0 .. lmax+3
+  // ranges of equal span, in span order (slot = number of range starts before this one, from the wave ballots)
+  {
+    const int ks = tid < kGaObs ? key[tid] : 0x7fffffff;
+    const bool start = tid < kGaObs && ks != 0x7fffffff && (tid == 0 || key[tid - 1] != ks);
+    const unsigned long long mask = __ballot(start);
+    if (tid == 0) nr_s = __popcll(mask);                 // starts in the first wavefront
+    __syncthreads();
+    if (start) {
+      int e = tid + 1;
+      while (e < kGaObs && key[e] == ks) ++e;
+      const int slot = (tid >= 64 ? nr_s : 0) + __popcll(mask & ((1ull << (tid & 63)) - 1ull));
+      rs[slot] = (unsigned char)tid; re[slot] = (unsigned char)e; rg[slot] = ks;
+    }
+    __syncthreads();
+    if (tid == 64) nr_s += __popcll(mask);
+  }
+  __syncthreads();
+  const int nr = nr_s;
   const double* fxs = Js + (2 * NS) * kGaStride;
   const double* fys = fxs + kGaStride;
-  // camera block (lower triangle) and camera gradient: full-range sums
-  for (int o = tid; o < B * (B + 1) / 2 + B; o += kThreads) {
-    double acc = 0.0;
-    if (o < B) {
-      const double* jxa = Js + o * kGaStride; const double* jya = Js + (NS + o) * kGaStride;
-      for (int u = 0; u < cnt; ++u) acc += jxa[u] * fxs[u] + jya[u] * fys[u];
-      if (acc != 0.0) unsafeAtomicAdd(&ne.gc[c * B + o], acc);
+  // camera block (lower triangle) and camera gradient on the fp64 matrix cores: G = R R^T with R = [camera slots; f]
+  // ((B+1) x 2*128, x rows then y rows).  For v_mfma_f64_16x16x4 the A fragment (lane l: R[l&15][k0 + (l>>4)]) IS the
+  // B fragment of R^T, so one LDS read feeds both operands.  The LAST wavefront does all of it (64 MFMAs per tile pair)
+  // while the others go on to the outer products below, where it would have been idle; one atomic per entry -- all
+  // workgroups of a camera add to the same (B+1)(B+2)/2 addresses, so fewer, larger contributions matter here.
+  if (tid >= kGaThreads - 64) {
+    using d4v = __attribute__((ext_vector_type(4))) double;
+    constexpr int TI = (B + 1 + 15) / 16;                 // 16-row tiles of R
+    const int lane = tid & 63;
+    const int lr = lane & 15, lk = lane >> 4;
+    d4v cacc[TI][TI];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int j = 0; j < TI; ++j) cacc[i][j] = d4v{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int xy = 0; xy < 2; ++xy)
+#pragma unroll 8
+      for (int ks = 0; ks < kGaObs / 4; ++ks) {
+        const int u = ks * 4 + lk;
+        double a[TI];
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+          const int row = 16 * i + lr;
+          a[i] = row < B ? Js[(xy * NS + row) * kGaStride + u] : (row == B ? Js[(2 * NS + xy) * kGaStride + u] : 0.0);
+        }
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+          for (int j = 0; j <= i; ++j) cacc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], a[j], cacc[i][j], 0, 0, 0);
+      }
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int j = 0; j <= i; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ra = 16 * i + lk + 4 * r, rb = 16 * j + lr;      // C/D layout: row = (lane>>4) + 4 reg, col = lane&15
+          const double v = cacc[i][j][r];
+          if (ra > B || rb > ra || rb >= B || v == 0.0) continue;
+          if (ra == B) unsafeAtomicAdd(&ne.gc[c * B + rb], v);
+          else {
+            unsafeAtomicAdd(&ne.A[((long long)c * B + ra) * B + rb], v);
+            if (ra != rb) unsafeAtomicAdd(&ne.A[((long long)c * B + rb) * B + ra], v);
+          }
+        }
+  }
+  const bool fast = nr <= kGaMaxR;                        // uniform
+  // one register file for both roles -- E role: EA(q, k) cross block + gradient (k = B) of (range, d);
+  // C role: CA(qa, w, d2) band blocks (w = qb - qa), row coordinate d
+  constexpr int kAcc = 4 * (B + 1) > 48 ? 4 * (B + 1) : 48;
+  double acc_[kAcc];
+#define EA(q, k) acc_[(q) * (B + 1) + (k)]
+#define CA(qa, w, d2) acc_[((qa) * 4 + (w)) * 3 + (d2)]
+  int myr = -1, myd = 0;
+  bool crole = false;
+  for (int item = tid; item < 6 * nr; item += kGaThreads) {
+    crole = item >= 3 * nr;
+    const int it2 = crole ? item - 3 * nr : item;
+    const int r = it2 / 3, d = it2 % 3;
+    const int b = rs[r], e = re[r];
+    const double* sx = Js + B * kGaStride;               // spline slot (q, d2) x-row: sx[(3q+d2)*stride + u]
+    const double* sy = Js + (NS + B) * kGaStride;
+    myr = r; myd = d;
+    if (!crole) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int k = 0; k <= B; ++k) EA(q, k) = 0.0;
+      for (int u = b; u < e; ++u) {
+        double ax[4], ay[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { ax[q] = sx[(3 * q + d) * kGaStride + u]; ay[q] = sy[(3 * q + d) * kGaStride + u]; }
+#pragma unroll
+        for (int k = 0; k <= B; ++k) {
+          const double cx = k < B ? Js[k * kGaStride + u] : fxs[u];
+          const double cy = k < B ? Js[(NS + k) * kGaStride + u] : fys[u];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) EA(q, k) += cx * ax[q] + cy * ay[q];
+        }
+      }
     } else {
-      int e = o - B, ra = 0;
-      while ((ra + 1) * (ra + 2) / 2 <= e) ++ra;
-      const int rb = e - ra * (ra + 1) / 2;
-      const double* jxa = Js + ra * kGaStride; const double* jya = Js + (NS + ra) * kGaStride;
-      const double* jxb = Js + rb * kGaStride; const double* jyb = Js + (NS + rb) * kGaStride;
-      for (int u = 0; u < cnt; ++u) acc += jxa[u] * jxb[u] + jya[u] * jyb[u];
-      if (acc != 0.0) {
-        unsafeAtomicAdd(&ne.A[((long long)c * B + ra) * B + rb], acc);
-        if (ra != rb) unsafeAtomicAdd(&ne.A[((long long)c * B + rb) * B + ra], acc);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+#pragma unroll
+          for (int d2 = 0; d2 < 3; ++d2) CA(q, w, d2) = 0.0;
+      for (int u = b; u < e; ++u) {
+        double vx[12], vy[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) { vx[k] = sx[k * kGaStride + u]; vy[k] = sy[k * kGaStride + u]; }
+#pragma unroll
+        for (int qa = 0; qa < 4; ++qa) {                 // vx[3qa + d] with d a run-time value: select, keeps vx in registers
+          const double ax = d == 0 ? vx[3 * qa] : (d == 1 ? vx[3 * qa + 1] : vx[3 * qa + 2]);
+          const double ay = d == 0 ? vy[3 * qa] : (d == 1 ? vy[3 * qa + 1] : vy[3 * qa + 2]);
+#pragma unroll
+          for (int w = 0; qa + w < 4; ++w)
+#pragma unroll
+            for (int d2 = 0; d2 < 3; ++d2) CA(qa, w, d2) += ax * vx[3 * (qa + w) + d2] + ay * vy[3 * (qa + w) + d2];
+        }
+      }
+    }
+    if (!fast) {                                         // slow path: too many ranges to keep one per thread
+      const int gq = rg[r];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (!crole) {
+          const int row = 3 * (gq + q) + d;
+          double* er = ne.Et + ((long long)c * ne.N3 + row) * B;
+#pragma unroll
+          for (int k = 0; k < B; ++k) if (EA(q, k) != 0.0) unsafeAtomicAdd(&er[k], EA(q, k));
+          if (EA(q, B) != 0.0) unsafeAtomicAdd(&ne.gs[row], EA(q, B));
+        } else {
+#pragma unroll
+          for (int w = 0; q + w < 4; ++w)
+#pragma unroll
+            for (int d2 = 0; d2 < 3; ++d2)
+              if (CA(q, w, d2) != 0.0) unsafeAtomicAdd(&ne.Cb[((long long)(gq + q) * ne.W + w) * 9 + 3 * d + d2], CA(q, w, d2));
+        }
       }
     }
   }
-  // spline gradient + cross block: output (lc, d, k), k = B means the gradient entry
-  const int nE = nctrl * 3 * (B + 1);
-  for (int o = tid; o < nE; o += kThreads) {
-    const int k = o % (B + 1), ld = o / (B + 1), d = ld % 3, lc = ld / 3;
-    const double* cx = k < B ? Js + k * kGaStride : fxs;
-    const double* cy = k < B ? Js + (NS + k) * kGaStride : fys;
-    double acc = 0.0;
+  if (!fast) return;
+  __syncthreads();                                        // every thread holds its partials in registers: Js is dead
+  // owner tables of one flush round over ranges [r0, r0 + nb): a control point is owned by the first range of the
+  // round that reaches it; range rl owns its last min(4, rg[rl] - rg[rl-1]) points.  Returns the number of owned points.
+  auto build_owners = [&](int r0, int nb) {
+    if (tid < nb) {
+      int bs = 0;
+      for (int j = 0; j < tid; ++j) bs += j == 0 ? 4 : min(4, rg[r0 + j] - rg[r0 + j - 1]);
+      const int nc = tid == 0 ? 4 : min(4, rg[r0 + tid] - rg[r0 + tid - 1]);
+      obase[tid] = (unsigned short)bs;
+      if (tid == nb - 1) obase[nb] = (unsigned short)(bs + nc);
+      for (int j = 0; j < nc; ++j) own_r[bs + j] = (unsigned char)tid;
+    }
+    __syncthreads();
+    return (int)obase[nb];
+  };
+  // ---- flush of the cross block + gradient, kRbE ranges per round: Ep[rl][q][3][B], Gp[rl][q][3] ----
+  for (int r0 = 0; r0 < nr; r0 += kRbE) {
+    const int nb = min(kRbE, nr - r0);
+    double* Ep = Js;
+    double* Gp = Js + kRbE * kEp;
+    if (!crole && myr >= r0 && myr < r0 + nb) {
+      const int rl = myr - r0;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int s_ = lc - q;
-      if (s_ < 0 || s_ >= kGaWin) continue;
-      const int b = lo[s_], e = hi[s_];
-      const double* sx = Js + (B + 3 * q + d) * kGaStride; const double* sy = Js + (NS + B + 3 * q + d) * kGaStride;
-      for (int u = b; u < e; ++u) acc += cx[u] * sx[u] + cy[u] * sy[u];
+      for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int k = 0; k < B; ++k) Ep[(rl * 4 + q) * 3 * B + myd * B + k] = EA(q, k);
+        Gp[(rl * 4 + q) * 3 + myd] = EA(q, B);
+      }
     }
-    if (acc != 0.0) {
-      const int r = 3 * (g0 + lc) + d;
-      if (k < B) unsafeAtomicAdd(&ne.Et[((long long)c * ne.N3 + r) * B + k], acc);
-      else unsafeAtomicAdd(&ne.gs[r], acc);
+    const int nown = build_owners(r0, nb);
+    constexpr int per = 3 * B + 3;                       // entries per owned control point: 3 x B cross + 3 gradient
+    for (int o = tid; o < nown * per; o += kGaThreads) {
+      const int i = o / per, dk = o % per;
+      const int rl = own_r[i];
+      const int q = 4 - ((int)obase[rl + 1] - (int)obase[rl]) + (i - (int)obase[rl]);
+      const int ctrl = rg[r0 + rl] + q;
+      const bool grad = dk >= 3 * B;
+      double acc = 0.0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r2 = rl + j;
+        if (r2 >= nb) break;
+        const int q2 = ctrl - rg[r0 + r2];
+        if (q2 < 0) break;
+        acc += grad ? Gp[(r2 * 4 + q2) * 3 + dk - 3 * B] : Ep[(r2 * 4 + q2) * 3 * B + dk];
+      }
+      if (acc != 0.0) {
+        if (grad) unsafeAtomicAdd(&ne.gs[3 * ctrl + dk - 3 * B], acc);
+        else unsafeAtomicAdd(&ne.Et[((long long)c * ne.N3 + 3 * ctrl) * B + dk], acc);
+      }
     }
+    __syncthreads();
   }
-  // spline band: output (lc, w, d, d2) = block (ctrl lc, ctrl lc+w)
-  const int nC = nctrl * 36;
-  for (int o = tid; o < nC; o += kThreads) {
-    const int d2 = o % 3, d = (o / 3) % 3, w = (o / 9) % 4, lc = o / 36;
-    double acc = 0.0;
-    for (int q = 0; q + w < 4; ++q) {
-      const int s_ = lc - q;
-      if (s_ < 0 || s_ >= kGaWin) continue;
-      const int b = lo[s_], e = hi[s_];
-      const double* ax = Js + (B + 3 * q + d) * kGaStride; const double* ay = Js + (NS + B + 3 * q + d) * kGaStride;
-      const double* bx = Js + (B + 3 * (q + w) + d2) * kGaStride; const double* by = Js + (NS + B + 3 * (q + w) + d2) * kGaStride;
-      for (int u = b; u < e; ++u) acc += ax[u] * bx[u] + ay[u] * by[u];
+  // ---- flush of the spline band, kRbC ranges per round: Cp[rl][pair (qa, w)][3][3], pair = 4 qa - qa (qa - 1) / 2 + w ----
+  for (int r0 = 0; r0 < nr; r0 += kRbC) {
+    const int nb = min(kRbC, nr - r0);
+    double* Cp = Js;
+    if (crole && myr >= r0 && myr < r0 + nb) {
+      const int rl = myr - r0;
+#pragma unroll
+      for (int qa = 0; qa < 4; ++qa)
+#pragma unroll
+        for (int w = 0; qa + w < 4; ++w)
+#pragma unroll
+          for (int d2 = 0; d2 < 3; ++d2) Cp[(rl * 10 + 4 * qa - qa * (qa - 1) / 2 + w) * 9 + 3 * myd + d2] = CA(qa, w, d2);
     }
-    if (acc != 0.0) unsafeAtomicAdd(&ne.Cb[((long long)(g0 + lc) * ne.W + w) * 9 + 3 * d + d2], acc);
+    const int nown = build_owners(r0, nb);
+    for (int o = tid; o < nown * 36; o += kGaThreads) {
+      const int i = o / 36, wd = o % 36, w = wd / 9, dd = wd % 9;
+      const int rl = own_r[i];
+      const int qa = 4 - ((int)obase[rl + 1] - (int)obase[rl]) + (i - (int)obase[rl]);
+      const int ctrl = rg[r0 + rl] + qa;
+      double acc = 0.0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r2 = rl + j;
+        if (r2 >= nb) break;
+        const int q2 = ctrl - rg[r0 + r2];
+        if (q2 < 0) break;
+        if (q2 + w < 4) acc += Cp[(r2 * 10 + 4 * q2 - q2 * (q2 - 1) / 2 + w) * 9 + dd];
+      }
+      if (acc != 0.0) unsafeAtomicAdd(&ne.Cb[((long long)ctrl * ne.W) * 9 + wd], acc);
+    }
+    __syncthreads();
   }
+#undef EA
+#undef CA
 }
 
 // motion-regulariser rows: spline block and gradient only (the rows do not depend on camera parameters).
@@ -1221,7 +1346,6 @@ struct HipSchur {
   int nslab = 1;            // K-slabs of the Schur product (partial sums in G)
   size_t bcr_lds = 0;       // dynamic LDS of k_sep_bcr_rhs; the sequential separator kernels remain for chains too long for it
   bool use_bcr = false;
-  int* redo = nullptr;      // per half chunk: 1 = the gather assembly deferred it to the atomic kernel
 
   explicit HipSchur(BE& b) : be(b) {
     const HostProblem& hp = be.hp;
@@ -1254,7 +1378,6 @@ struct HipSchur {
     D = be.alloc(hp.n); gx = be.alloc(hp.n); px = be.alloc(hp.n);
     MVUS_HIP(hipMalloc(reinterpret_cast<void**>(&fail), sizeof(int)));
     MVUS_HIP(hipHostMalloc(reinterpret_cast<void**>(&fail_host), sizeof(int), hipHostMallocDefault));
-    MVUS_HIP(hipMalloc(reinterpret_cast<void**>(&redo), sizeof(int) * 2 * std::max(be.dp.n_chunks, 1)));
     // partition of the control-point chain: interiors of kPartL control points, separators of W-1
     const int sctrl = W - 1;
     std::vector<int> i0, i1, s0;
@@ -1287,7 +1410,6 @@ struct HipSchur {
   ~HipSchur() {
     for (double* p : {Erm, NE, Lb, Z, G, S, Lf, Linv, rhs, pc, D, gx, px, pv.VW, pv.T, pv.U, pv.U2, pv.Ha, pv.Hc}) be.release(p);
     if (part_tables) (void)hipFree(part_tables);
-    if (redo) (void)hipFree(redo);
     if (fail) (void)hipFree(fail);
     if (fail_host) (void)hipHostFree(fail_host);
   }
@@ -1296,20 +1418,8 @@ struct HipSchur {
     MVUS_HIP(hipMemsetAsync(NE, 0, ne_count * sizeof(double), be.stream));
     if (be.dp.n_chunks > 0) {
       const int nc = be.dp.n_chunks;
-      MVUS_HIP(hipMemsetAsync(redo, 0, sizeof(int) * 2 * nc, be.stream));
-      if (be.hp.calib) {
-        hipLaunchKernelGGL(k_assemble_gather<30>, dim3(2 * nc), dim3(kThreads), 0, be.stream, be.dp, be.J, be.span, f_dev, ne, redo);
-        hipLaunchKernelGGL(k_assemble<30>, dim3(nc), dim3(kThreads), 0, be.stream, be.dp, be.J, be.span, f_dev, ne, redo);
-      } else {
-        hipLaunchKernelGGL(k_assemble_gather<21>, dim3(2 * nc), dim3(kThreads), 0, be.stream, be.dp, be.J, be.span, f_dev, ne, redo);
-        hipLaunchKernelGGL(k_assemble<21>, dim3(nc), dim3(kThreads), 0, be.stream, be.dp, be.J, be.span, f_dev, ne, redo);
-      }
-    }
-    if (std::getenv("MVUS_DEBUG") && be.dp.n_chunks > 0) {
-      std::vector<int> rh(2 * be.dp.n_chunks);
-      MVUS_HIP(hipMemcpy(rh.data(), redo, sizeof(int) * rh.size(), hipMemcpyDeviceToHost));
-      int cntf = 0; for (int v : rh) cntf += v != 0;
-      std::fprintf(stderr, "assemble: %d of %zu half chunks deferred to the atomic kernel\n", cntf, rh.size());
+      if (be.hp.calib) hipLaunchKernelGGL(k_assemble_spans<30>, dim3(2 * nc), dim3(kGaThreads), 0, be.stream, be.dp, be.J, be.span, f_dev, ne);
+      else hipLaunchKernelGGL(k_assemble_spans<21>, dim3(2 * nc), dim3(kGaThreads), 0, be.stream, be.dp, be.J, be.span, f_dev, ne);
     }
     if (be.hp.T > 0)
       hipLaunchKernelGGL(k_assemble_motion, dim3((be.hp.T + kThreads - 1) / kThreads), dim3(kThreads), 0, be.stream, be.dp, be.mJ, be.mctrl,
