@@ -833,89 +833,129 @@ __global__ __launch_bounds__(64) void k_sep_rhs(PartView pv, int ncols, double* 
 //   survivors i:  D_i -= C_{i-h}^T Hc_{i-h} + C_i Ha_{i+h},   C_i <- -C_i Hc_{i+h},   r_i -= Hc_{i-h}^T r_{i-h} + Ha_{i+h}^T r_{i+h}
 // k_sep_bcr_factor: the matrix part, one workgroup (all levels, blocks stay in L2/LDS);
 // k_sep_bcr_rhs: the right-hand sides, kBcrCols columns per workgroup staged in LDS through all levels and back.
+// One S3 x S3 product on the fp64 matrix cores, one wavefront: acc += op(A) op(B), the blocks zero-padded to 16 x 16.
+// ta: A is read transposed; tb: B is read transposed.  Fragment layout of v_mfma_f64_16x16x4: lane l holds
+// A[l&15][k0 + (l>>4)] and B[k0 + (l>>4)][l&15].
+using bcr_d4 = __attribute__((ext_vector_type(4))) double;
 template <int S3>
-__global__ __launch_bounds__(1024) void k_sep_bcr_factor(PartView pv, int* __restrict__ fail) {
-  // one thread per (node, block row): the row lives in registers, only the pivot row of each Gauss-Jordan step goes
-  // through LDS (double buffered: one barrier per step)
-  constexpr int SS = S3 * S3;
-  constexpr int NBT = 1024 / S3;                     // nodes per pass
-  __shared__ double prow[2][NBT][S3];
-  const int m = pv.P - 1, tid = threadIdx.x;
-  const int n = tid / S3, a = tid % S3;
+struct BcrFrag { double a[(S3 + 3) / 4], b[(S3 + 3) / 4]; };
+template <int S3>
+__device__ __forceinline__ void bcr_load(BcrFrag<S3>& f, const double* __restrict__ A, bool ta, const double* __restrict__ Bm, bool tb, bool on) {
+  const int lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
+#pragma unroll
+  for (int s_ = 0; s_ < (S3 + 3) / 4; ++s_) {
+    const int k = 4 * s_ + lk;
+    const bool ok = on && lr < S3 && k < S3;
+    f.a[s_] = ok ? (ta ? A[k * S3 + lr] : A[lr * S3 + k]) : 0.0;
+    f.b[s_] = ok ? (tb ? Bm[lr * S3 + k] : Bm[k * S3 + lr]) : 0.0;
+  }
+}
+template <int S3>
+__device__ __forceinline__ bcr_d4 bcr_mma(const BcrFrag<S3>& f, bcr_d4 acc) {
+#pragma unroll
+  for (int s_ = 0; s_ < (S3 + 3) / 4; ++s_) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(f.a[s_], f.b[s_], acc, 0, 0, 0);
+  return acc;
+}
+
+constexpr int kBcrWaves = 8;     // 512 threads: up to 256 VGPRs each, the prefetched operand fragments need them
+template <int S3>
+__global__ __launch_bounds__(kBcrWaves * 64) void k_sep_bcr_factor(PartView pv, int* __restrict__ fail) {
+  // One workgroup of kBcrWaves wavefronts, three phases per level, all blocks in global memory (L2 resident):
+  //   1. inversion of the eliminated nodes' diagonal blocks: 64/S3 nodes per wavefront, a block row per lane, the
+  //      pivot row of each Gauss-Jordan step broadcast with shuffles -- no workgroup barrier inside;
+  //   2. Ha_j = Dinv_j C_{j-h}^T and Hc_j = Dinv_j C_j, 3. the survivors' D_i and C_i: one matrix-core product
+  //      chain per wavefront, the operands of kTb products fetched together to overlap their latency.
+  constexpr int SS = S3 * S3, NPW = 64 / S3, kTb = 4;
+  const int m = pv.P - 1, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lk = lane >> 4;
   double* Ccur = pv.U;
   double* Cnxt = pv.U2;
   for (int h = 1; h <= m; h <<= 1) {
     const int ne = (m / h + 1) / 2, ns = m / (2 * h);
-    for (int b0 = 0; b0 < ne; b0 += NBT) {
-      const bool act = n < NBT && b0 + n < ne;
-      const int j = act ? h * (2 * (b0 + n) + 1) - 1 : 0;
+    // ---- 1. Dinv_j (in place in T) ----
+    for (int nb0 = wave * NPW; nb0 < ne; nb0 += kBcrWaves * NPW) {
+      const int nl = lane / S3, a = lane % S3;
+      const bool act = nl < NPW && nb0 + nl < ne;
+      const int j = act ? h * (2 * (nb0 + nl) + 1) - 1 : 0;
       double row[S3];
 #pragma unroll
-      for (int b = 0; b < S3; ++b) row[b] = act ? pv.T[(long long)j * SS + a * S3 + b] : 0.0;
+      for (int b = 0; b < S3; ++b) row[b] = act ? pv.T[(long long)j * SS + a * S3 + b] : (a == b ? 1.0 : 0.0);
 #pragma unroll
       for (int k = 0; k < S3; ++k) {
-        if (act && a == k) {
+        const int src = (nl < NPW ? nl : 0) * S3 + k;     // lane holding the pivot row of this lane's node
+        double pr[S3];
 #pragma unroll
-          for (int b = 0; b < S3; ++b) prow[k & 1][n][b] = row[b];
-        }
-        __syncthreads();
-        if (act) {
-          const double* pr = prow[k & 1][n];
-          double piv = pr[k];
-          if (!(piv > 0.0)) { fail[0] = 3; piv = 1.0; }
-          double ip = __builtin_amdgcn_rcp(piv);
-          ip = ip * (2.0 - piv * ip);
-          ip = ip * (2.0 - piv * ip);
-          if (a == k) {
+        for (int b = 0; b < S3; ++b) pr[b] = __shfl(row[b], src, 64);
+        double piv = pr[k];
+        if (!(piv > 0.0)) { if (act) fail[0] = 3; piv = 1.0; }
+        double ip = __builtin_amdgcn_rcp(piv);
+        ip = ip * (2.0 - piv * ip);
+        ip = ip * (2.0 - piv * ip);
+        if (a == k) {
 #pragma unroll
-            for (int b = 0; b < S3; ++b) row[b] = (b == k) ? ip : row[b] * ip;
-          } else {
-            const double f = row[k] * ip;
+          for (int b = 0; b < S3; ++b) row[b] = (b == k) ? ip : row[b] * ip;
+        } else {
+          const double f = row[k] * ip;
 #pragma unroll
-            for (int b = 0; b < S3; ++b) row[b] = (b == k) ? -f : row[b] - f * pr[b];
-          }
+          for (int b = 0; b < S3; ++b) row[b] = (b == k) ? -f : row[b] - f * pr[b];
         }
       }
       if (act) {
-        // row a of Dinv_j, Ha_j = Dinv_j C_{j-h}^T and Hc_j = Dinv_j C_j
-        const bool left = j - h >= 0, right = j + h < m;
-        const double* Cl = Ccur + (long long)(left ? j - h : j) * SS;
-        const double* Cj = Ccur + (long long)j * SS;
 #pragma unroll
-        for (int b = 0; b < S3; ++b) {
-          double xa = 0.0, xc = 0.0;
+        for (int b = 0; b < S3; ++b) pv.T[(long long)j * SS + a * S3 + b] = row[b];
+      }
+    }
+    __syncthreads();
+    // ---- 2. Ha_j, Hc_j: task t = 2 * (eliminated node) + which ----
+    for (int t0 = wave * kTb; t0 < 2 * ne; t0 += kBcrWaves * kTb) {
+      BcrFrag<S3> fr[kTb];
 #pragma unroll
-          for (int k = 0; k < S3; ++k) { xa += row[k] * Cl[b * S3 + k]; xc += row[k] * Cj[k * S3 + b]; }
-          pv.T[(long long)j * SS + a * S3 + b] = row[b];
-          pv.Ha[(long long)j * SS + a * S3 + b] = left ? xa : 0.0;
-          pv.Hc[(long long)j * SS + a * S3 + b] = right ? xc : 0.0;
+      for (int u = 0; u < kTb; ++u) {
+        const int t = t0 + u, j = h * (2 * (t >> 1) + 1) - 1, which = t & 1;
+        const bool on = t < 2 * ne && (which == 0 ? j - h >= 0 : j + h < m);
+        const double* Cm = Ccur + (long long)(which == 0 ? (on ? j - h : 0) : (on ? j : 0)) * SS;
+        bcr_load<S3>(fr[u], pv.T + (long long)(on ? j : 0) * SS, false, Cm, which == 0, on);
+      }
+#pragma unroll
+      for (int u = 0; u < kTb; ++u) {
+        const int t = t0 + u;
+        if (t >= 2 * ne) break;
+        const int j = h * (2 * (t >> 1) + 1) - 1;
+        const bcr_d4 acc = bcr_mma<S3>(fr[u], bcr_d4{0.0, 0.0, 0.0, 0.0});
+        double* H = ((t & 1) ? pv.Hc : pv.Ha) + (long long)j * SS;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int rw = lk + 4 * r; if (rw < S3 && lr < S3) H[rw * S3 + lr] = acc[r]; }
+      }
+    }
+    __syncthreads();
+    // ---- 3. survivors: task t = 2 * (survivor) + which; which 0: D_i -= C_{i-h}^T Hc_{i-h} + C_i Ha_{i+h}, 1: C_i' = -C_i Hc_{i+h} ----
+    for (int t0 = wave * kTb; t0 < 2 * ns; t0 += kBcrWaves * kTb) {
+      BcrFrag<S3> f1[kTb], f2[kTb];
+#pragma unroll
+      for (int u = 0; u < kTb; ++u) {
+        const int t = t0 + u, i = 2 * h * ((t >> 1) + 1) - 1, which = t & 1;
+        const bool in = t < 2 * ns, right = in && i + h < m;
+        const int il = in ? i - h : 0, ir = right ? i + h : 0, ic = in ? i : 0;
+        if (which == 0) {
+          bcr_load<S3>(f1[u], Ccur + (long long)il * SS, true, pv.Hc + (long long)il * SS, false, in);
+          bcr_load<S3>(f2[u], Ccur + (long long)ic * SS, false, pv.Ha + (long long)ir * SS, false, right);
+        } else {
+          bcr_load<S3>(f1[u], Ccur + (long long)ic * SS, false, pv.Hc + (long long)ir * SS, false, right);
+          bcr_load<S3>(f2[u], Ccur, false, Ccur, false, false);
         }
       }
-      __syncthreads();
-    }
-    for (int b0 = 0; b0 < ns; b0 += NBT) {
-      if (n < NBT && b0 + n < ns) {
-        const int i = 2 * h * (b0 + n + 1) - 1;
-        const bool right = i + h < m;
-        const double* Cl = Ccur + (long long)(i - h) * SS;
-        const double* Ci = Ccur + (long long)i * SS + a * S3;
-        const double* Hl = pv.Hc + (long long)(i - h) * SS;
-        const double* Hra = pv.Ha + (long long)(right ? i + h : i) * SS;
-        const double* Hrc = pv.Hc + (long long)(right ? i + h : i) * SS;
-        double ci[S3], cl[S3];
 #pragma unroll
-        for (int k = 0; k < S3; ++k) { ci[k] = right ? Ci[k] : 0.0; cl[k] = Cl[k * S3 + a]; }
+      for (int u = 0; u < kTb; ++u) {
+        const int t = t0 + u;
+        if (t >= 2 * ns) break;
+        const int i = 2 * h * ((t >> 1) + 1) - 1;
+        bcr_d4 acc = bcr_mma<S3>(f1[u], bcr_d4{0.0, 0.0, 0.0, 0.0});
+        acc = bcr_mma<S3>(f2[u], acc);
+        double* dst = ((t & 1) ? Cnxt : pv.T) + (long long)i * SS;
 #pragma unroll
-        for (int b = 0; b < S3; ++b) {
-          double dd = pv.T[(long long)i * SS + a * S3 + b], cc = 0.0;
-#pragma unroll
-          for (int k = 0; k < S3; ++k) dd -= cl[k] * Hl[k * S3 + b];
-          if (right) {
-#pragma unroll
-            for (int k = 0; k < S3; ++k) { dd -= ci[k] * Hra[k * S3 + b]; cc -= ci[k] * Hrc[k * S3 + b]; }
-          }
-          pv.T[(long long)i * SS + a * S3 + b] = dd;
-          Cnxt[(long long)i * SS + a * S3 + b] = cc;
+        for (int r = 0; r < 4; ++r) {
+          const int rw = lk + 4 * r;
+          if (rw < S3 && lr < S3) dst[rw * S3 + lr] = ((t & 1) ? 0.0 : dst[rw * S3 + lr]) - acc[r];
         }
       }
     }
@@ -1452,7 +1492,7 @@ struct HipSchur {
       if (pv.P > 1) {
         hipLaunchKernelGGL(k_part_reduce<11>, dim3(pv.P - 1), dim3(256), 0, be.stream, pv, ncols, Lb, Z);
         if (use_bcr) {
-          hipLaunchKernelGGL(k_sep_bcr_factor<9>, dim3(1), dim3(1024), 0, be.stream, pv, fail);
+          hipLaunchKernelGGL(k_sep_bcr_factor<9>, dim3(1), dim3(kBcrWaves * 64), 0, be.stream, pv, fail);
           hipLaunchKernelGGL(k_sep_bcr_rhs<9>, dim3((ncols + kBcrCols - 1) / kBcrCols), dim3(256), bcr_lds, be.stream, pv, ncols, Z);
         } else {
           hipLaunchKernelGGL(k_sep_factor<9>, dim3(1), dim3(64), 0, be.stream, pv, fail);
@@ -1465,7 +1505,7 @@ struct HipSchur {
       if (pv.P > 1) {
         hipLaunchKernelGGL(k_part_reduce<17>, dim3(pv.P - 1), dim3(256), 0, be.stream, pv, ncols, Lb, Z);
         if (use_bcr) {
-          hipLaunchKernelGGL(k_sep_bcr_factor<15>, dim3(1), dim3(1024), 0, be.stream, pv, fail);
+          hipLaunchKernelGGL(k_sep_bcr_factor<15>, dim3(1), dim3(kBcrWaves * 64), 0, be.stream, pv, fail);
           hipLaunchKernelGGL(k_sep_bcr_rhs<15>, dim3((ncols + kBcrCols - 1) / kBcrCols), dim3(256), bcr_lds, be.stream, pv, ncols, Z);
         } else {
           hipLaunchKernelGGL(k_sep_factor<15>, dim3(1), dim3(64), 0, be.stream, pv, fail);
