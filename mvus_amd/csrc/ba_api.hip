@@ -164,6 +164,40 @@ struct HipBackend {
     if (!allreduce) return;
     if (allreduce(allreduce_user, buf, count, stream) != 0) throw HipError{"all-reduce callback failed"};
   }
+  // device-resident LM driver (ba_schur.h)
+  std::vector<double> lb_host, ub_host;
+  double *lb_dev = nullptr, *ub_dev = nullptr;
+  void set_bounds(const std::vector<double>& lb, const std::vector<double>& ub) {
+    if (!lb_dev) { lb_dev = dalloc<double>(hp.n); ub_dev = dalloc<double>(hp.n); }
+    if (lb != lb_host) { lb_host = lb; upload(lb_dev, lb_host.data(), hp.n); }
+    if (ub != ub_host) { ub_host = ub; upload(ub_dev, ub_host.data(), hp.n); }
+  }
+  const double* lb_ptr() const { return lb_dev; }
+  const double* ub_ptr() const { return ub_dev; }
+  double* lm_scalars() { return scal_dev + 8; }
+  void dot_m_into(const double* a, const double* b, double* out) {
+    const int nb = grid_for(hp.m);
+    if (hp.m > 0) {
+      hipLaunchKernelGGL(k_dot_partial, dim3(nb), dim3(kThreads), 0, stream, (long long)hp.m, a, b, partials);
+      hipLaunchKernelGGL(k_dot_final, dim3(1), dim3(kThreads), 0, stream, nb, partials, out);
+    } else {
+      MVUS_HIP(hipMemsetAsync(out, 0, sizeof(double), stream));
+    }
+    reduce(out, 1);
+  }
+  void lm_gnorm(const double* x, const double* lb, const double* ub, const double* g, double* out) {
+    hipLaunchKernelGGL(k_lm_gnorm, dim3(1), dim3(1024), 0, stream, (int)hp.n, x, lb, ub, g, out);
+  }
+  void lm_trial(const double* x, const double* p, const double* lb, const double* ub, const double* g, const double* D,
+                const int* fail, double* x_new, double* out) {
+    hipLaunchKernelGGL(k_lm_trial, dim3(1), dim3(1024), 0, stream, (int)hp.n, x, p, lb, ub, g, D, fail, x_new, out);
+  }
+  void fetch(const double* src, int k, double* host) {       // src inside scal_dev: staged through the pinned mirror
+    const int64_t off = src - scal_dev;
+    MVUS_HIP(hipMemcpyAsync(scal_host + off, src, sizeof(double) * k, hipMemcpyDeviceToHost, stream));
+    MVUS_HIP(hipStreamSynchronize(stream));
+    for (int i = 0; i < k; ++i) host[i] = scal_host[off + i];
+  }
   double dot_n(const double* a, const double* b, int64_t len) { dot_to_slot(a, b, len, 0); return read_slot(0); }
   double dot_m(const double* a, const double* b) { dot_to_slot(a, b, hp.m, 1); reduce(scal_dev + 1, 1); return read_slot(1); }
 

@@ -414,6 +414,58 @@ __global__ __launch_bounds__(kThreads) void k_dot_final(int nb, const double* __
   }
 }
 
+// ---- LM driver (ba_schur.h): the two small vector reductions of an iteration, one workgroup each ------------
+// projected gradient norm: a component pushing against an active bound does not count
+__global__ __launch_bounds__(1024) void k_lm_gnorm(int n, const double* __restrict__ x, const double* __restrict__ lb, const double* __restrict__ ub,
+                                                   const double* __restrict__ g, double* __restrict__ out) {
+  __shared__ double red[16];
+  double gn = 0.0;
+  for (int i = threadIdx.x; i < n; i += 1024) {
+    const double gi = g[i], xi = x[i];
+    const bool blocked = (xi <= lb[i] && gi > 0) || (xi >= ub[i] && gi < 0);
+    if (!blocked) gn = fmax(gn, fabs(gi));
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) gn = fmax(gn, __shfl_down(gn, off, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = gn;
+  __syncthreads();
+  if (threadIdx.x == 0) { double t = 0.0; for (int w = 0; w < 16; ++w) t = fmax(t, red[w]); *out = t; }
+}
+// trial point x_new = P(x + p) and out = [g.step, step^T D step, |step|^2, |x|^2]; a failed (fail flag) or
+// non-finite solve gives x_new = x and out[0] = NaN, so the residual kernels never see a non-finite parameter
+__global__ __launch_bounds__(1024) void k_lm_trial(int n, const double* __restrict__ x, const double* __restrict__ p, const double* __restrict__ lb,
+                                                   const double* __restrict__ ub, const double* __restrict__ g, const double* __restrict__ D,
+                                                   const int* __restrict__ fail, double* __restrict__ x_new, double* __restrict__ out) {
+  __shared__ double red[4][16];
+  __shared__ int bad_s;
+  if (threadIdx.x == 0) bad_s = fail[0] != 0;
+  __syncthreads();
+  int bad = 0;
+  for (int i = threadIdx.x; i < n; i += 1024) bad |= !isfinite(p[i]);
+  if (bad) bad_s = 1;
+  __syncthreads();
+  const bool dead = bad_s != 0;
+  double s[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int i = threadIdx.x; i < n; i += 1024) {
+    const double xi = x[i];
+    const double xn = dead ? xi : fmin(fmax(xi + p[i], lb[i]), ub[i]);
+    const double st = xn - xi;
+    x_new[i] = xn;
+    s[0] += g[i] * st; s[1] += st * D[i] * st; s[2] += st * st; s[3] += xi * xi;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const double v = wave_sum(s[k]);
+    if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    double t = 0.0;
+    for (int w = 0; w < 16; ++w) t += red[threadIdx.x][w];
+    out[threadIdx.x] = (threadIdx.x == 0 && dead) ? __longlong_as_double(0x7ff8000000000000LL) : t;
+  }
+}
+
 // ---- MVUS_JAC_FD: scipy's sparse 2-point differences (scipy/optimize/_numdiff.py:628-700) ----------------
 // steps: h_j and dx_j = (x_j + h_j) - x_j ; bounds are [0,1] on the rs block when rs_bounds, else infinite
 __global__ void k_fd_steps(int n, int C, int rs_bounds, const double* __restrict__ x, double* __restrict__ h, double* __restrict__ dx) {

@@ -15,8 +15,18 @@
 // counting and the result fields follow scipy's conventions (check_termination, nfev/njev/status) so that
 // Scene.BA can switch solvers without changing its contract.
 //
-// `Schur` concept:  void assemble(B&, const double* f_dev);  void gradient(std::vector<double>& g);
-//                   void diagonal(std::vector<double>& d);   bool solve(double lambda, std::vector<double>& p);
+// The iteration is driven from the host but keeps every vector in the backend's memory: one LM iteration is ONE
+// batch of asynchronous work -- projected-gradient norm, damped solve, trial point with the model's predicted
+// reduction, residuals at the trial point, their squared norm -- followed by ONE fetch of seven scalars on which
+// the host decides (accept / reject, damping update, termination).  The trial is launched speculatively before the
+// gradient-norm test is known; when that test terminates the solve the trial is simply dropped (not counted).
+//
+// `Schur` concept:  void assemble(B&, const double* f);            normal equations of the backend's Jacobian
+//                   const double* grad_ptr(), diag_ptr();          g = J^T f and D = diag(H) (1 where zero), x order
+//                   void solve_async(double lambda);               p = -(H + lambda D)^-1 g -> step_ptr()
+//                   const double* step_ptr(); const int* fail_ptr();  bool solve_ok();   (solve_ok after a fetch)
+// Backend additions: set_bounds(lb, ub) -> lb_ptr()/ub_ptr(); lm_scalars() (>= 8 doubles); dot_m_into(a, b, out);
+//                   lm_gnorm(x, lb, ub, g, out); lm_trial(x, p, lb, ub, g, D, fail, x_new, out4); fetch(src, k, host).
 #pragma once
 #include <algorithm>
 #include <cmath>
@@ -27,6 +37,32 @@
 #include "ba_solver.h"
 
 namespace mvus {
+
+// host restatements of the two small vector kernels (used by the host test backend; the HIP backend has kernels)
+// projected gradient: a component pushing against an active bound does not count
+inline double lm_gnorm_host(int64_t n, const double* x, const double* lb, const double* ub, const double* g) {
+  double gn = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    const bool blocked = (x[i] <= lb[i] && g[i] > 0) || (x[i] >= ub[i] && g[i] < 0);
+    if (!blocked) gn = std::max(gn, std::fabs(g[i]));
+  }
+  return gn;
+}
+// trial point x_new = P(x + p) (projection onto the rs box) and out = [g.step, step^T D step, |step|^2, |x|^2];
+// a failed or non-finite solve gives step 0 and out[0] = NaN
+inline void lm_trial_host(int64_t n, const double* x, const double* p, const double* lb, const double* ub, const double* g,
+                          const double* D, int fail, double* x_new, double* out) {
+  double gp = 0, pDp = 0, s2 = 0, x2 = 0;
+  bool bad = fail != 0;
+  for (int64_t i = 0; i < n && !bad; ++i) bad = !std::isfinite(p[i]);
+  for (int64_t i = 0; i < n; ++i) {
+    const double xn = bad ? x[i] : std::min(std::max(x[i] + p[i], lb[i]), ub[i]);
+    const double st = xn - x[i];
+    x_new[i] = xn;
+    gp += g[i] * st; pDp += st * D[i] * st; s2 += st * st; x2 += x[i] * x[i];
+  }
+  out[0] = bad ? std::numeric_limits<double>::quiet_NaN() : gp; out[1] = pDp; out[2] = s2; out[3] = x2;
+}
 
 template <class B, class Schur>
 SolveResult lm_schur(B& be, Schur& sc, std::vector<double>& x, const std::vector<double>& lb, const std::vector<double>& ub,
@@ -39,56 +75,65 @@ SolveResult lm_schur(B& be, Schur& sc, std::vector<double>& x, const std::vector
   double* xt_dev = be.alloc(n);
   double* f_new = be.alloc(m);
   auto cleanup = [&]() { be.release(x_dev); be.release(xt_dev); be.release(f_new); };
+  be.set_bounds(lb, ub);
+  const double* lbp = be.lb_ptr();
+  const double* ubp = be.ub_ptr();
+  double* S = be.lm_scalars();   // [0] |f|^2 at x0, [1] projected |g|_inf, [2..5] trial scalars, [6] |f(x_trial)|^2
+  double hs[7] = {0, 0, 0, 0, 0, 0, 0};
 
   be.upload(x_dev, x.data(), n);
   be.jacobian(x_dev, f_dev, opt.jac_mode);
   res.nfev = 1; res.njev = 1;
-  double cost = 0.5 * be.dot_m(f_dev, f_dev);
-  if (!std::isfinite(cost)) { res.error = -3; cleanup(); return res; }
-  res.initial_cost = cost;
+  be.dot_m_into(f_dev, f_dev, S);
   sc.assemble(be, f_dev);
-  std::vector<double> g(n), D(n), p(n), x_new(n), step(n);
-  sc.gradient(g);
-  sc.diagonal(D);
+
+  auto launch_trial = [&](double lambda) {
+    sc.solve_async(lambda);
+    be.lm_trial(x_dev, sc.step_ptr(), lbp, ubp, sc.grad_ptr(), sc.diag_ptr(), sc.fail_ptr(), xt_dev, S + 2);
+    be.residual(xt_dev, f_new);
+    be.dot_m_into(f_new, f_new, S + 6);
+  };
 
   double lambda = opt.lm_lambda0 > 0 ? opt.lm_lambda0 : 1e-4, nu = 2.0;
+  double cost = 0;
+  bool cost_known = false;
   int status = -1;
   double g_norm = 0;
   while (true) {
-    g_norm = 0;
-    for (int64_t i = 0; i < n; ++i) {
-      // projected gradient: a component pushing against an active bound does not count
-      const bool blocked = (x[i] <= lb[i] && g[i] > 0) || (x[i] >= ub[i] && g[i] < 0);
-      if (!blocked) g_norm = std::max(g_norm, std::fabs(g[i]));
+    be.lm_gnorm(x_dev, lbp, ubp, sc.grad_ptr(), S + 1);
+    const bool can_try = res.nfev < opt.max_nfev;
+    if (can_try) launch_trial(lambda);             // speculative: dropped if the gradient test below ends the solve
+    be.fetch(S, can_try ? 7 : 2, hs);
+    if (!cost_known) {
+      cost = 0.5 * hs[0];
+      if (!std::isfinite(cost)) { res.error = -3; cleanup(); return res; }
+      res.initial_cost = cost;
+      cost_known = true;
     }
+    g_norm = hs[1];
     if (g_norm < opt.gtol) status = 1;
-    if (status != -1 || res.nfev >= opt.max_nfev) break;
+    if (status != -1 || !can_try) break;
 
     double actual_reduction = -1, cost_new = cost;
+    bool have_trial = true;
     while (actual_reduction <= 0 && res.nfev < opt.max_nfev) {
-      if (!sc.solve(lambda, p)) {           // not positive definite at this damping: raise it
+      if (!have_trial) { launch_trial(lambda); be.fetch(S + 2, 5, hs + 2); }
+      have_trial = false;
+      if (!sc.solve_ok() || !std::isfinite(hs[2]) || !std::isfinite(hs[3])) {   // not positive definite at this damping: raise it
         lambda *= 10.0;
         if (lambda > 1e12) { status = 0; break; }
         continue;
       }
       ++res.lin_iters;
-      for (int64_t i = 0; i < n; ++i) {
-        x_new[i] = std::min(std::max(x[i] + p[i], lb[i]), ub[i]);     // projection onto the rs box
-        step[i] = x_new[i] - x[i];
-      }
       // predicted reduction of the quadratic model: -(g.p + 0.5 p^T H p) = 0.5 (lambda p^T D p - g.p)
-      double gp = 0, pDp = 0;
-      for (int64_t i = 0; i < n; ++i) { gp += g[i] * step[i]; pDp += step[i] * D[i] * step[i]; }
-      const double predicted = 0.5 * (lambda * pDp - gp);
-      be.upload(xt_dev, x_new.data(), n);
-      be.residual(xt_dev, f_new);
+      const double predicted = 0.5 * (lambda * hs[3] - hs[2]);
       ++res.nfev;
-      cost_new = 0.5 * be.dot_m(f_new, f_new);
+      cost_new = 0.5 * hs[6];
       if (!std::isfinite(cost_new)) { lambda *= nu; nu *= 2.0; continue; }
       actual_reduction = cost - cost_new;
       const double ratio = predicted > 0 ? actual_reduction / predicted : (actual_reduction > 0 ? 1.0 : 0.0);
-      const double step_norm = norm2(step);
-      const int term = check_termination(actual_reduction, cost, step_norm, norm2(x), ratio, opt.ftol, opt.xtol);
+      const double step_norm = std::sqrt(hs[4]);
+      const int term = check_termination(actual_reduction, cost, step_norm, std::sqrt(hs[5]), ratio, opt.ftol, opt.xtol);
       if (opt.verbose >= 2)
         std::fprintf(stderr, "lm: nfev=%d cost=%.10e -> %.10e lambda=%.3e ratio=%.3f |step|=%.3e\n", res.nfev, cost, cost_new, lambda, ratio, step_norm);
       if (actual_reduction > 0) {
@@ -101,9 +146,8 @@ SolveResult lm_schur(B& be, Schur& sc, std::vector<double>& x, const std::vector
       if (term != -1) { status = term; break; }
     }
     if (actual_reduction > 0) {
-      x = x_new;
+      std::swap(x_dev, xt_dev);
       cost = cost_new;
-      be.copy(x_dev, xt_dev, n);
       if (status == -1 && res.nfev >= opt.max_nfev) {
         // evaluation budget spent: no further step will be taken, so the accepted point is not re-linearised (one
         // Jacobian + assembly saved per call); the reported optimality is then that of the last linearisation
@@ -113,12 +157,16 @@ SolveResult lm_schur(B& be, Schur& sc, std::vector<double>& x, const std::vector
       be.jacobian(x_dev, f_dev, opt.jac_mode);
       ++res.njev;
       sc.assemble(be, f_dev);
-      sc.gradient(g);
-      sc.diagonal(D);
     }
-    if (status != -1) continue;   // re-evaluate g_norm once, then leave through the break above
+    if (status != -1) {                 // converged / gave up: report the gradient norm of the final linearisation
+      be.lm_gnorm(x_dev, lbp, ubp, sc.grad_ptr(), S + 1);
+      be.fetch(S + 1, 1, hs + 1);
+      g_norm = hs[1];
+      break;
+    }
   }
   if (status == -1) status = 0;
+  be.download(x.data(), x_dev, n);
   res.status = status;
   res.cost = cost;
   res.optimality = g_norm;
@@ -150,9 +198,17 @@ struct HostSchur {
       for (int64_t j = 0; j < n; ++j) if (r[j] != 0.0) nz.push_back((int)j);
       for (int a : nz) { g[a] += r[a] * f[i]; for (int b : nz) H[(size_t)a * n + b] += r[a] * r[b]; }
     }
+    Dd.resize(n);
+    for (int64_t i = 0; i < n; ++i) Dd[i] = damp_scale(H[(size_t)i * n + i]);
   }
-  void gradient(std::vector<double>& out) { out = g; }
-  void diagonal(std::vector<double>& d) { d.resize(n); for (int64_t i = 0; i < n; ++i) d[i] = damp_scale(H[(size_t)i * n + i]); }
+  std::vector<double> Dd, pstep;
+  int fail = 0;
+  const double* grad_ptr() const { return g.data(); }
+  const double* diag_ptr() const { return Dd.data(); }
+  const double* step_ptr() const { return pstep.data(); }
+  const int* fail_ptr() const { return &fail; }
+  bool solve_ok() const { return fail == 0; }
+  void solve_async(double lambda) { fail = solve(lambda, pstep) ? 0 : 1; if (fail) pstep.assign(n, 0.0); }
   static double damp_scale(double hii) { return hii > 0 ? hii : 1.0; }
   bool solve(double lambda, std::vector<double>& p) {
     std::vector<double> L(H);

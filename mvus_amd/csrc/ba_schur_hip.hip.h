@@ -1476,10 +1476,17 @@ struct HipSchur {
     hipLaunchKernelGGL(k_ne_diag_grad, dim3((tot + 255) / 256), dim3(256), 0, be.stream, be.dp, ne, D, gx);
     MVUS_HIP(hipGetLastError());
   }
-  void gradient(std::vector<double>& g) { g.resize(be.hp.n); be.download(g.data(), gx, be.hp.n); }
-  void diagonal(std::vector<double>& d) { d.resize(be.hp.n); be.download(d.data(), D, be.hp.n); }
 
-  bool solve(double lambda, std::vector<double>& p) {
+  const double* grad_ptr() const { return gx; }
+  const double* diag_ptr() const { return D; }
+  const double* step_ptr() const { return px; }
+  const int* fail_ptr() const { return fail; }
+  bool solve_ok() const {                 // valid after the stream has been synchronised (the driver's fetch)
+    if (*fail_host != 0 && std::getenv("MVUS_DEBUG")) std::fprintf(stderr, "schur solve: fail code %d\n", *fail_host);
+    return *fail_host == 0;
+  }
+
+  void solve_async(double lambda) {
     const long long nLb = (long long)ne.N3 * (BW + 1);
     MVUS_HIP(hipMemsetAsync(fail, 0, sizeof(int), be.stream));
     hipLaunchKernelGGL(k_band_pack, dim3((unsigned)((nLb + 255) / 256)), dim3(256), 0, be.stream, ne, lambda, BW, Lb);
@@ -1535,11 +1542,6 @@ struct HipSchur {
     hipLaunchKernelGGL(k_back_substitute, dim3((ne.N3 + kThreads / 64 - 1) / (kThreads / 64)), dim3(kThreads), 0, be.stream, be.dp, ne, ncols, Z, pc, px);
     MVUS_HIP(hipGetLastError());
     MVUS_HIP(hipMemcpyAsync(fail_host, fail, sizeof(int), hipMemcpyDeviceToHost, be.stream));
-    p.resize(be.hp.n);
-    be.download(p.data(), px, be.hp.n);
-    if (*fail_host != 0) { if (std::getenv("MVUS_DEBUG")) std::fprintf(stderr, "schur solve: fail code %d at lambda %.3e\n", *fail_host, lambda); return false; }
-    for (double v : p) if (!std::isfinite(v)) return false;
-    return true;
   }
 };
 

@@ -42,6 +42,18 @@ struct HostBackend {
   void mul(int64_t len, const double* x, const double* y, double* out) { for (int64_t i = 0; i < len; ++i) out[i] = x[i] * y[i]; }
   double dot_n(const double* a, const double* b, int64_t len) { double s = 0; for (int64_t i = 0; i < len; ++i) s += a[i] * b[i]; return s; }
   double dot_m(const double* a, const double* b) { return dot_n(a, b, hp.m); }
+  // device-resident LM driver (ba_schur.h): host memory plays the role of device memory
+  std::vector<double> lbv, ubv;
+  double lm_s[8];
+  void set_bounds(const std::vector<double>& lb, const std::vector<double>& ub) { lbv = lb; ubv = ub; }
+  const double* lb_ptr() const { return lbv.data(); }
+  const double* ub_ptr() const { return ubv.data(); }
+  double* lm_scalars() { return lm_s; }
+  void dot_m_into(const double* a, const double* b, double* out) { *out = dot_m(a, b); }
+  void lm_gnorm(const double* x, const double* lb, const double* ub, const double* g, double* out) { *out = mvus::lm_gnorm_host(hp.n, x, lb, ub, g); }
+  void lm_trial(const double* x, const double* p, const double* lb, const double* ub, const double* g, const double* D,
+                const int* fail, double* x_new, double* out) { mvus::lm_trial_host(hp.n, x, p, lb, ub, g, D, *fail, x_new, out); }
+  void fetch(const double* src, int k, double* host) { std::memcpy(host, src, sizeof(double) * k); }
 
   void init() {
     J.assign((size_t)2 * hp.NS * hp.M, 0.0); span.assign(hp.M, -1); pat0.assign(hp.M, -1);
