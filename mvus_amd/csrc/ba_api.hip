@@ -167,8 +167,12 @@ struct HipBackend {
   // device-resident LM driver (ba_schur.h)
   std::vector<double> lb_host, ub_host;
   double *lb_dev = nullptr, *ub_dev = nullptr;
+  unsigned* lm_counter = nullptr;   // ticket counter of the last-block reductions (k_lm_gnorm / k_lm_trial), kept at 0 between launches
   void set_bounds(const std::vector<double>& lb, const std::vector<double>& ub) {
-    if (!lb_dev) { lb_dev = dalloc<double>(hp.n); ub_dev = dalloc<double>(hp.n); }
+    if (!lb_dev) {
+      lb_dev = dalloc<double>(hp.n); ub_dev = dalloc<double>(hp.n); lm_counter = dalloc<unsigned>(1);
+      MVUS_HIP(hipMemsetAsync(lm_counter, 0, sizeof(unsigned), stream));
+    }
     if (lb != lb_host) { lb_host = lb; upload(lb_dev, lb_host.data(), hp.n); }
     if (ub != ub_host) { ub_host = ub; upload(ub_dev, ub_host.data(), hp.n); }
   }
@@ -186,11 +190,11 @@ struct HipBackend {
     reduce(out, 1);
   }
   void lm_gnorm(const double* x, const double* lb, const double* ub, const double* g, double* out) {
-    hipLaunchKernelGGL(k_lm_gnorm, dim3(1), dim3(1024), 0, stream, (int)hp.n, x, lb, ub, g, out);
+    hipLaunchKernelGGL(k_lm_gnorm, dim3((unsigned)((hp.n + 1023) / 1024)), dim3(1024), 0, stream, (int)hp.n, x, lb, ub, g, out, partials, lm_counter);
   }
   void lm_trial(const double* x, const double* p, const double* lb, const double* ub, const double* g, const double* D,
                 const int* fail, double* x_new, double* out) {
-    hipLaunchKernelGGL(k_lm_trial, dim3(1), dim3(1024), 0, stream, (int)hp.n, x, p, lb, ub, g, D, fail, x_new, out);
+    hipLaunchKernelGGL(k_lm_trial, dim3((unsigned)((hp.n + 1023) / 1024)), dim3(1024), 0, stream, (int)hp.n, x, p, lb, ub, g, D, fail, x_new, out, partials, lm_counter);
   }
   void fetch(const double* src, int k, double* host) {       // src inside scal_dev: staged through the pinned mirror
     const int64_t off = src - scal_dev;

@@ -414,44 +414,62 @@ __global__ __launch_bounds__(kThreads) void k_dot_final(int nb, const double* __
   }
 }
 
-// ---- LM driver (ba_schur.h): the two small vector reductions of an iteration, one workgroup each ------------
+// ---- LM driver (ba_schur.h): the two small vector reductions of an iteration --------------------------------
+// One element per thread; every workgroup leaves its partial result in `part`, the last one to finish (ticket from an
+// atomic counter, which it resets) combines them -- one launch, deterministic, no zero-initialised accumulator.
+__device__ __forceinline__ bool last_block_done(unsigned* counter) {
+  __shared__ bool last_s;
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned ticket = atomicAdd(counter, 1u);
+    last_s = ticket == gridDim.x - 1;
+    if (last_s) *counter = 0u;
+  }
+  __syncthreads();
+  if (last_s) __threadfence();
+  return last_s;
+}
 // projected gradient norm: a component pushing against an active bound does not count
 __global__ __launch_bounds__(1024) void k_lm_gnorm(int n, const double* __restrict__ x, const double* __restrict__ lb, const double* __restrict__ ub,
-                                                   const double* __restrict__ g, double* __restrict__ out) {
+                                                   const double* __restrict__ g, double* __restrict__ out, double* part, unsigned* counter) {
   __shared__ double red[16];
+  const int i = blockIdx.x * 1024 + threadIdx.x;
   double gn = 0.0;
-  for (int i = threadIdx.x; i < n; i += 1024) {
+  if (i < n) {
     const double gi = g[i], xi = x[i];
     const bool blocked = (xi <= lb[i] && gi > 0) || (xi >= ub[i] && gi < 0);
-    if (!blocked) gn = fmax(gn, fabs(gi));
+    if (!blocked) gn = fabs(gi);
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) gn = fmax(gn, __shfl_down(gn, off, 64));
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = gn;
   __syncthreads();
-  if (threadIdx.x == 0) { double t = 0.0; for (int w = 0; w < 16; ++w) t = fmax(t, red[w]); *out = t; }
+  if (threadIdx.x == 0) { double t = 0.0; for (int w = 0; w < 16; ++w) t = fmax(t, red[w]); part[blockIdx.x] = t; }
+  if (last_block_done(counter) && threadIdx.x == 0) {
+    double t = 0.0;
+    for (unsigned b = 0; b < gridDim.x; ++b) t = fmax(t, const_cast<volatile double*>(part)[b]);
+    *out = t;
+  }
 }
-// trial point x_new = P(x + p) and out = [g.step, step^T D step, |step|^2, |x|^2]; a failed (fail flag) or
-// non-finite solve gives x_new = x and out[0] = NaN, so the residual kernels never see a non-finite parameter
+// trial point x_new = P(x + p) and out = [g.step, step^T D step, |step|^2, |x|^2]; after a failed solve (fail flag)
+// x_new = x, a non-finite component of p is not applied, and either way out[0] = NaN: the residual kernels never
+// see a non-finite parameter and the driver rejects the trial
 __global__ __launch_bounds__(1024) void k_lm_trial(int n, const double* __restrict__ x, const double* __restrict__ p, const double* __restrict__ lb,
                                                    const double* __restrict__ ub, const double* __restrict__ g, const double* __restrict__ D,
-                                                   const int* __restrict__ fail, double* __restrict__ x_new, double* __restrict__ out) {
+                                                   const int* __restrict__ fail, double* __restrict__ x_new, double* __restrict__ out,
+                                                   double* part, unsigned* counter) {
   __shared__ double red[4][16];
-  __shared__ int bad_s;
-  if (threadIdx.x == 0) bad_s = fail[0] != 0;
-  __syncthreads();
-  int bad = 0;
-  for (int i = threadIdx.x; i < n; i += 1024) bad |= !isfinite(p[i]);
-  if (bad) bad_s = 1;
-  __syncthreads();
-  const bool dead = bad_s != 0;
-  double s[4] = {0.0, 0.0, 0.0, 0.0};
-  for (int i = threadIdx.x; i < n; i += 1024) {
-    const double xi = x[i];
-    const double xn = dead ? xi : fmin(fmax(xi + p[i], lb[i]), ub[i]);
+  const int i = blockIdx.x * 1024 + threadIdx.x;
+  const bool dead = fail[0] != 0;
+  double s[4] = {dead ? __longlong_as_double(0x7ff8000000000000LL) : 0.0, 0.0, 0.0, 0.0};
+  if (i < n) {
+    const double xi = x[i], pi = p[i];
+    const bool ok = isfinite(pi);
+    const double xn = (dead || !ok) ? xi : fmin(fmax(xi + pi, lb[i]), ub[i]);
     const double st = xn - xi;
     x_new[i] = xn;
-    s[0] += g[i] * st; s[1] += st * D[i] * st; s[2] += st * st; s[3] += xi * xi;
+    s[0] += ok ? g[i] * st : pi * 0.0; s[1] = st * D[i] * st; s[2] = st * st; s[3] = xi * xi;
   }
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -462,7 +480,12 @@ __global__ __launch_bounds__(1024) void k_lm_trial(int n, const double* __restri
   if (threadIdx.x < 4) {
     double t = 0.0;
     for (int w = 0; w < 16; ++w) t += red[threadIdx.x][w];
-    out[threadIdx.x] = (threadIdx.x == 0 && dead) ? __longlong_as_double(0x7ff8000000000000LL) : t;
+    part[blockIdx.x * 4 + threadIdx.x] = t;
+  }
+  if (last_block_done(counter) && threadIdx.x < 4) {
+    double t = 0.0;
+    for (unsigned b = 0; b < gridDim.x; ++b) t += const_cast<volatile double*>(part)[b * 4 + threadIdx.x];
+    out[threadIdx.x] = t;
   }
 }
 

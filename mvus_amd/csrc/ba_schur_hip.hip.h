@@ -446,8 +446,9 @@ __global__ void k_ne_diag_grad(DevProblem dp, NEView ne, double* __restrict__ D,
 }
 
 // scalar lower band of (C + lambda D_s): Lb[i][j] = (C + lambda D)(i, i-j), j = 0..BW
-__global__ void k_band_pack(NEView ne, double lambda, int BW, double* __restrict__ Lb) {
+__global__ void k_band_pack(NEView ne, double lambda, int BW, double* __restrict__ Lb, int* __restrict__ fail) {
   const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (idx == 0) fail[0] = 0;              // first kernel of a solve: clears the failure flag the later ones may raise
   const long long total = (long long)ne.N3 * (BW + 1);
   if (idx >= total) return;
   const int i = (int)(idx / (BW + 1)), j = (int)(idx % (BW + 1));
@@ -545,7 +546,9 @@ __global__ __launch_bounds__(64) void k_part_cholesky(PartView pv, double* __res
   for (int k = 0; k < n; ++k) {
     double piv = T[k * R];
     if (!(piv > 0.0)) { if (lane == 0) fail[0] = 1; piv = 1.0; }
-    const double inv = 1.0 / sqrt(piv);
+    double inv = __builtin_amdgcn_rsq(piv);              // two Newton steps on v_rsq_f64: the pivot chain is the critical path
+    inv = inv * (1.5 - 0.5 * piv * inv * inv);
+    inv = inv * (1.5 - 0.5 * piv * inv * inv);
     const int nb = min(BW, n - 1 - k);
     if (lane >= 1 && lane <= nb) T[(k + lane) * R + lane] *= inv;
     __syncthreads();
@@ -1029,16 +1032,38 @@ __global__ __launch_bounds__(256) void k_sep_bcr_rhs(PartView pv, int ncols, dou
   }
 }
 
-// interiors: X = Y - V X_{S_{p-1}} - W X_{S_p}
-__global__ __launch_bounds__(256) void k_part_back(PartView pv, int ncols, double* __restrict__ Z) {
-  const int p = blockIdx.x, s3 = pv.s3, st = 2 * s3;
+// interiors: X = Y - V X_{S_{p-1}} - W X_{S_p}.  One thread per right-hand-side column: the 2*S3 separator values of
+// its column stay in registers, the rows of V|W are the same for every lane (scalar loads), so each interior entry
+// costs one coalesced load, 2*S3 FMAs and one store.
+constexpr int kBackRows = 16;      // rows per workgroup: enough workgroups in flight to hide the load latency
+template <int S3>
+__global__ __launch_bounds__(64) void k_part_back(PartView pv, int ncols, double* __restrict__ Z) {
+  const int p = blockIdx.x, col = blockIdx.y * 64 + threadIdx.x;
+  if (col >= ncols) return;
+  constexpr int st = 2 * S3;
   const int r0 = pv.i0[p], n = pv.i1[p] - r0;
-  const double* VWp = pv.VW + ((long long)p * kPartRowsMax) * st;
-  for (int e = blockIdx.y * blockDim.x + threadIdx.x; e < n * ncols; e += gridDim.y * blockDim.x) {
-    const int i = e / ncols, col = e % ncols;
+  const int ia = blockIdx.z * kBackRows, ib = min(n, ia + kBackRows);      // rows of this workgroup
+  if (ia >= n) return;
+  const bool left = p > 0, right = p < pv.P - 1;
+  const double* __restrict__ VWp = pv.VW + ((long long)p * kPartRowsMax) * st;
+  double zl[S3], zr[S3];
+#pragma unroll
+  for (int a = 0; a < S3; ++a) {
+    zl[a] = left ? Z[(long long)(pv.s0[left ? p - 1 : 0] + a) * ncols + col] : 0.0;
+    zr[a] = right ? Z[(long long)(pv.s0[right ? p : 0] + a) * ncols + col] : 0.0;
+  }
+#pragma unroll 4
+  for (int i = ia; i < ib; ++i) {
     double v = Z[(long long)(r0 + i) * ncols + col];
-    if (p > 0) for (int a = 0; a < s3; ++a) v -= VWp[(long long)i * st + a] * Z[(long long)(pv.s0[p - 1] + a) * ncols + col];
-    if (p < pv.P - 1) for (int a = 0; a < s3; ++a) v -= VWp[(long long)i * st + s3 + a] * Z[(long long)(pv.s0[p] + a) * ncols + col];
+    const double* __restrict__ vw = VWp + (long long)i * st;
+    if (left) {
+#pragma unroll
+      for (int a = 0; a < S3; ++a) v -= vw[a] * zl[a];
+    }
+    if (right) {
+#pragma unroll
+      for (int a = 0; a < S3; ++a) v -= vw[S3 + a] * zr[a];
+    }
     Z[(long long)(r0 + i) * ncols + col] = v;
   }
 }
@@ -1469,10 +1494,7 @@ struct HipSchur {
   void assemble(BE&, const double* f_dev) {
     assemble_local(f_dev);
     be.reduce(NE, ne_count);          // one sum-all-reduce of the packed normal-equation blocks per iteration
-    const int tot = ne.CB + ne.N3;
-    MVUS_HIP(hipMemsetAsync(D, 0, be.hp.n * sizeof(double), be.stream));
-    be.fill(D, 1.0, be.hp.n);
-    MVUS_HIP(hipMemsetAsync(gx, 0, be.hp.n * sizeof(double), be.stream));
+    const int tot = ne.CB + ne.N3;          // every entry of x is a camera column or a control-point coordinate
     hipLaunchKernelGGL(k_ne_diag_grad, dim3((tot + 255) / 256), dim3(256), 0, be.stream, be.dp, ne, D, gx);
     MVUS_HIP(hipGetLastError());
   }
@@ -1488,8 +1510,7 @@ struct HipSchur {
 
   void solve_async(double lambda) {
     const long long nLb = (long long)ne.N3 * (BW + 1);
-    MVUS_HIP(hipMemsetAsync(fail, 0, sizeof(int), be.stream));
-    hipLaunchKernelGGL(k_band_pack, dim3((unsigned)((nLb + 255) / 256)), dim3(256), 0, be.stream, ne, lambda, BW, Lb);
+    hipLaunchKernelGGL(k_band_pack, dim3((unsigned)((nLb + 255) / 256)), dim3(256), 0, be.stream, ne, lambda, BW, Lb, fail);
     const long long nZ = (long long)ne.N3 * ncols;
     hipLaunchKernelGGL(k_build_rhs, dim3((unsigned)((nZ + 255) / 256)), dim3(256), 0, be.stream, ne, ncols, Z, Erm);
     const dim3 gsolve(pv.P, (ncols + 2 * pv.s3 + 63) / 64);
@@ -1520,7 +1541,11 @@ struct HipSchur {
         }
       }
     }
-    if (pv.P > 1) hipLaunchKernelGGL(k_part_back, dim3(pv.P, 8), dim3(256), 0, be.stream, pv, ncols, Z);
+    if (pv.P > 1) {
+      const dim3 gback(pv.P, (ncols + 63) / 64, (kPartRowsMax + kBackRows - 1) / kBackRows);
+      if (BW == 11) hipLaunchKernelGGL(k_part_back<9>, gback, dim3(64), 0, be.stream, pv, ncols, Z);
+      else hipLaunchKernelGGL(k_part_back<15>, gback, dim3(64), 0, be.stream, pv, ncols, Z);
+    }
     {
       const int nbk = (ne.CB + kGemmT - 1) / kGemmT;
       hipLaunchKernelGGL(k_schur_gemm, dim3(nbk * (nbk + 1) / 2 + nbk, nslab), dim3(256), 0, be.stream, ne, ncols, Erm, Z, G);
@@ -1537,8 +1562,6 @@ struct HipSchur {
       }
       hipLaunchKernelGGL(k_chol_backsub, dim3(1), dim3(kBsThreads), 0, be.stream, nn, Lf, Linv, pc);
     }
-    MVUS_HIP(hipMemsetAsync(px, 0, be.hp.n * sizeof(double), be.stream));
-    const int tot = ne.CB + ne.N3;
     hipLaunchKernelGGL(k_back_substitute, dim3((ne.N3 + kThreads / 64 - 1) / (kThreads / 64)), dim3(kThreads), 0, be.stream, be.dp, ne, ncols, Z, pc, px);
     MVUS_HIP(hipGetLastError());
     MVUS_HIP(hipMemcpyAsync(fail_host, fail, sizeof(int), hipMemcpyDeviceToHost, be.stream));
