@@ -542,6 +542,18 @@ __global__ __launch_bounds__(64) void k_part_cholesky(PartView pv, double* __res
   const int p = blockIdx.x, lane = threadIdx.x;
   const int r0 = pv.i0[p], n = pv.i1[p] - r0;
   for (int e = lane; e < n * R; e += 64) T[e] = Lb[(long long)r0 * R + e];
+  // trailing-update pairs (rr >= ss >= 1) owned by this lane, as offsets from the pivot row: fixed for all columns
+  constexpr int kPairs = BW * (BW + 1) / 2, kSlots = (kPairs + 63) / 64;
+  int prr[kSlots], offA[kSlots], offB[kSlots], offC[kSlots];
+#pragma unroll
+  for (int sl = 0; sl < kSlots; ++sl) {
+    const int e = lane + 64 * sl;
+    int r = 0;
+    while ((r + 1) * (r + 2) / 2 <= e) ++r;
+    const int rr = r + 1, ss = e - r * (r + 1) / 2 + 1;
+    prr[sl] = e < kPairs ? rr : BW + 1;
+    offA[sl] = rr * R + (rr - ss); offB[sl] = rr * R + rr; offC[sl] = ss * R + ss;
+  }
   __syncthreads();
   for (int k = 0; k < n; ++k) {
     double piv = T[k * R];
@@ -552,14 +564,10 @@ __global__ __launch_bounds__(64) void k_part_cholesky(PartView pv, double* __res
     const int nb = min(BW, n - 1 - k);
     if (lane >= 1 && lane <= nb) T[(k + lane) * R + lane] *= inv;
     __syncthreads();
-    const int npairs = nb * (nb + 1) / 2;
-    for (int e = lane; e < npairs; e += 64) {
-      int r = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
-      while ((r + 1) * (r + 2) / 2 <= e) ++r;
-      while (r * (r + 1) / 2 > e) --r;
-      const int rr = r + 1, ss = e - r * (r + 1) / 2 + 1;
-      T[(k + rr) * R + (rr - ss)] -= T[(k + rr) * R + rr] * T[(k + ss) * R + ss];
-    }
+    double* Tk = T + k * R;
+#pragma unroll
+    for (int sl = 0; sl < kSlots; ++sl)
+      if (prr[sl] <= nb) Tk[offA[sl]] -= Tk[offB[sl]] * Tk[offC[sl]];
     if (lane == 0) T[k * R] = inv;      // reciprocal of L(k,k)
     __syncthreads();
   }
@@ -570,92 +578,103 @@ __global__ __launch_bounds__(64) void k_part_cholesky(PartView pv, double* __res
   }
 }
 
-// interior solves: thread t < ncols -> right-hand side column of Z (in place); t >= ncols -> coupling column.
-// The interior's factor is staged in LDS once per workgroup (entries reaching outside the interior zeroed, so the
-// substitution loops are branch free) and read as broadcasts; the next row's right-hand side is fetched before the
-// current row's dependent chain.
-template <int BW>
-__global__ __launch_bounds__(64) void k_part_solve(PartView pv, int ncols, const double* __restrict__ Lb, double* __restrict__ Z) {
-  constexpr int R = BW + 1;
-  __shared__ double Ls[kPartRowsMax * R];
-  const int p = blockIdx.x;
-  const int t = blockIdx.y * blockDim.x + threadIdx.x;
+// interior solves, one thread per column, one wavefront per (interior, 64 columns).  COUPLING = false: right-hand-side
+// columns of Z, in place.  COUPLING = true (one extra wavefront per interior): the 2*s3 coupling columns
+// V_p = B_p^-1 H[I_p, S_{p-1}], W_p = B_p^-1 H[I_p, S_p] -> pv.VW.
+// A lone wavefront per SIMD issues in order, so the kernel is bound by its instruction count: the factor is staged in
+// LDS once (entries reaching outside the interior zeroed, rows padded to whole batches with identity rows: the
+// substitution loops are branch free) and read as broadcasts, rows are addressed by pointer increments, and the rows of
+// the right-hand side are fetched one batch of kPf rows ahead (they are ncols*8 bytes apart: every row is a fresh
+// cache line, ~1-2 us away).
+constexpr int kPsPf = 16;
+template <int BW, bool COUPLING>
+__device__ __forceinline__ void part_solve_block(const PartView& pv, int ncols, const double* __restrict__ Lb, double* __restrict__ Z, double* Ls) {
+  constexpr int R = BW + 1, kPf = kPsPf;
+  const int p = blockIdx.x, tid = threadIdx.x;
   const int s3 = pv.s3;
-  const int r0 = pv.i0[p], r1 = pv.i1[p], nr = r1 - r0;
-  for (int e = threadIdx.x; e < nr * R; e += 64) {
+  const int r0 = pv.i0[p], nr = pv.i1[p] - r0;
+  const int nrp = (nr + kPf - 1) / kPf * kPf;                // rows padded to whole batches
+  for (int e = tid; e < (nrp + kPf) * R; e += 64) {
     const int row = e / R, jj = e % R;
-    Ls[e] = (jj <= row) ? Lb[(long long)r0 * R + e] : 0.0;       // column row-jj inside the interior
+    Ls[e] = row < nr ? ((jj <= row) ? Lb[(long long)r0 * R + e] : 0.0) : (jj == 0 ? 1.0 : 0.0);   // column row-jj inside the interior
   }
   __syncthreads();
-  if (t >= ncols + 2 * s3) return;
-  int kind = 0, ccol = 0;                    // 0: rhs, 1: left coupling, 2: right coupling
-  if (t >= ncols) {
-    const int k = t - ncols;
-    if (k < s3) { if (p == 0) return; kind = 1; ccol = pv.s0[p - 1] + k; }
-    else { if (p == pv.P - 1) return; kind = 2; ccol = pv.s0[p] + (k - s3); }
+  int ccol = 0;
+  bool live;
+  if (COUPLING) {
+    live = tid < 2 * s3 && (tid < s3 ? p > 0 : p < pv.P - 1);
+    if (live) ccol = tid < s3 ? pv.s0[p - 1] + tid : pv.s0[p] + (tid - s3);
+  } else {
+    live = (int)(blockIdx.y * 64 + tid) < ncols;
   }
-  double* out = kind == 0 ? nullptr : pv.VW + ((long long)p * kPartRowsMax) * (2 * s3) + (t - ncols);
-  const int ostride = 2 * s3;
-  // The rows of Z a thread walks are ncols*8 bytes apart (no cache-line reuse), so every step would wait for a fresh
-  // HBM line (~1-2 us >> the ~0.1 us of arithmetic): rows are fetched kPf at a time into registers, one batch ahead.
-  constexpr int kPf = 16;
+  if (!live) return;                                         // no barrier below
+  double* out = COUPLING ? pv.VW + ((long long)p * kPartRowsMax) * (2 * s3) + tid : Z + (long long)r0 * ncols + blockIdx.y * 64 + tid;
+  const long long ostride = COUPLING ? 2 * s3 : ncols;
+  auto rhs_at = [&](int i) { return i < nr ? (COUPLING ? band_entry<BW>(Lb, r0 + i, ccol) : out[(long long)i * ostride]) : 0.0; };
   double yw[BW];           // yw[0] = newest value
 #pragma unroll
   for (int j = 0; j < BW; ++j) yw[j] = 0.0;
-  auto rhs_at = [&](int i) { return kind == 0 ? Z[(long long)(r0 + i) * ncols + t] : band_entry<BW>(Lb, r0 + i, ccol); };
   double cur[kPf], nxt[kPf];
 #pragma unroll
-  for (int k = 0; k < kPf; ++k) nxt[k] = k < nr ? rhs_at(k) : 0.0;
-  for (int ib = 0; ib < nr; ib += kPf) {
+  for (int k = 0; k < kPf; ++k) nxt[k] = rhs_at(k);
+  for (int ib = 0; ib < nrp; ib += kPf) {
 #pragma unroll
     for (int k = 0; k < kPf; ++k) cur[k] = nxt[k];
+    if (ib + kPf < nrp) {
 #pragma unroll
-    for (int k = 0; k < kPf; ++k) nxt[k] = (ib + kPf + k < nr) ? rhs_at(ib + kPf + k) : 0.0;
+      for (int k = 0; k < kPf; ++k) nxt[k] = rhs_at(ib + kPf + k);
+    }
+    const double* Lr = Ls + ib * R;
+    double* yo = out + (long long)ib * ostride;
 #pragma unroll
     for (int k = 0; k < kPf; ++k) {
-      const int i = ib + k;
-      if (i < nr) {
-        const double* Lr = Ls + i * R;
-        double acc = cur[k];
+      // only the j = 1 term depends on the previous row's result: summing from the far end of the band leaves a
+      // two-operation dependent chain per row
+      double acc = cur[k];
 #pragma unroll
-        for (int j = 1; j <= BW; ++j) acc -= Lr[j] * yw[j - 1];
-        const double y = acc * Lr[0];
-        if (kind == 0) Z[(long long)(r0 + i) * ncols + t] = y; else out[(long long)i * ostride] = y;
+      for (int j = BW; j >= 1; --j) acc -= Lr[k * R + j] * yw[j - 1];
+      const double y = acc * Lr[k * R];
+      if (ib + k < nr) yo[(long long)k * ostride] = y;
 #pragma unroll
-        for (int j = BW - 1; j >= 1; --j) yw[j] = yw[j - 1];
-        yw[0] = y;
-      }
+      for (int j = BW - 1; j >= 1; --j) yw[j] = yw[j - 1];
+      yw[0] = y;
     }
   }
-  // backward: x(i) = (y(i) - sum_j L(i+j, i) x(i+j)) / L(i,i)
+  // backward: x(i) = (y(i) - sum_j L(i+j, i) x(i+j)) / L(i,i); the padded rows give x = 0
 #pragma unroll
   for (int j = 0; j < BW; ++j) yw[j] = 0.0;
-  auto y_at = [&](int i) { return kind == 0 ? Z[(long long)(r0 + i) * ncols + t] : out[(long long)i * ostride]; };
+  auto y_at = [&](int i) { return i < nr ? out[(long long)i * ostride] : 0.0; };
 #pragma unroll
-  for (int k = 0; k < kPf; ++k) nxt[k] = (nr - 1 - k >= 0) ? y_at(nr - 1 - k) : 0.0;
-  for (int ib = nr - 1; ib >= 0; ib -= kPf) {
+  for (int k = 0; k < kPf; ++k) nxt[k] = y_at(nrp - kPf + k);
+  for (int ib = nrp - kPf; ib >= 0; ib -= kPf) {
 #pragma unroll
     for (int k = 0; k < kPf; ++k) cur[k] = nxt[k];
+    if (ib > 0) {
 #pragma unroll
-    for (int k = 0; k < kPf; ++k) nxt[k] = (ib - kPf - k >= 0) ? y_at(ib - kPf - k) : 0.0;
+      for (int k = 0; k < kPf; ++k) nxt[k] = y_at(ib - kPf + k);
+    }
 #pragma unroll
-    for (int k = 0; k < kPf; ++k) {
-      const int i = ib - k;
-      if (i >= 0) {
-        double acc = cur[k];
+    for (int k = kPf - 1; k >= 0; --k) {
+      const int i = ib + k;
+      double acc = cur[k];
 #pragma unroll
-        for (int j = 1; j <= BW; ++j) {
-          const double l = (i + j < nr) ? Ls[(i + j) * R + j] : 0.0;
-          acc -= l * yw[j - 1];
-        }
-        const double xv = acc * Ls[i * R];
-        if (kind == 0) Z[(long long)(r0 + i) * ncols + t] = xv; else out[(long long)i * ostride] = xv;
+      for (int j = BW; j >= 1; --j) acc -= Ls[(i + j) * R + j] * yw[j - 1];     // rows up to nrp + BW - 1 are staged
+      const double xv = acc * Ls[i * R];
+      if (i < nr) out[(long long)i * ostride] = xv;
 #pragma unroll
-        for (int j = BW - 1; j >= 1; --j) yw[j] = yw[j - 1];
-        yw[0] = xv;
-      }
+      for (int j = BW - 1; j >= 1; --j) yw[j] = yw[j - 1];
+      yw[0] = xv;
     }
   }
+}
+
+// blockIdx.y < gridDim.y - 1: 64 right-hand-side columns; the last block row: the coupling columns (same launch, so
+// that they run beside the others instead of after them)
+template <int BW>
+__global__ __launch_bounds__(64) void k_part_solve(PartView pv, int ncols, const double* __restrict__ Lb, double* __restrict__ Z) {
+  __shared__ double Ls[(kPartRowsMax + 2 * kPsPf) * (BW + 1)];
+  if (blockIdx.y + 1 == gridDim.y) part_solve_block<BW, true>(pv, ncols, Lb, Z, Ls);
+  else part_solve_block<BW, false>(pv, ncols, Lb, Z, Ls);
 }
 
 // separator system: T(q,q), T(q,q+1) and the reduced right-hand sides (in place in the separator rows of Z)
@@ -1513,7 +1532,7 @@ struct HipSchur {
     hipLaunchKernelGGL(k_band_pack, dim3((unsigned)((nLb + 255) / 256)), dim3(256), 0, be.stream, ne, lambda, BW, Lb, fail);
     const long long nZ = (long long)ne.N3 * ncols;
     hipLaunchKernelGGL(k_build_rhs, dim3((unsigned)((nZ + 255) / 256)), dim3(256), 0, be.stream, ne, ncols, Z, Erm);
-    const dim3 gsolve(pv.P, (ncols + 2 * pv.s3 + 63) / 64);
+    const dim3 gsolve(pv.P, (ncols + 63) / 64 + 1);      // + one block row for the coupling columns
     if (BW == 11) {
       hipLaunchKernelGGL(k_part_cholesky<11>, dim3(pv.P), dim3(64), 0, be.stream, pv, Lb, fail);
       hipLaunchKernelGGL(k_part_solve<11>, gsolve, dim3(64), 0, be.stream, pv, ncols, Lb, Z);
