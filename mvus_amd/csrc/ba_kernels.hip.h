@@ -42,6 +42,15 @@ struct DevProblem {  // trivially copyable: passed to kernels by value
   int n_chunks;
 };
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding global load
+// (vmcnt(0): gfx9 counts loads and stores together), which defeats prefetching across a barrier; kernels that keep
+// global loads in flight over LDS-only phases use this instead.  Global data written before it is NOT made visible.
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);

@@ -684,17 +684,26 @@ __global__ __launch_bounds__(256) void k_part_reduce(PartView pv, int ncols, con
   const int c0 = pv.s0[q];
   const int a0 = pv.i0[q], a1 = pv.i1[q];             // interior before the separator
   const int b0 = pv.i0[q + 1], b1 = pv.i1[q + 1];     // interior after it
-  const int alo = max(a0, a1 - BW), bhi = min(b1, b0 + BW);   // rows that can couple to the separator
+  // only the last BW rows of the interior before and the first BW rows of the one after couple to the separator; the
+  // loops run over exactly BW rows with the out-of-range ones masked, so that all their loads are issued together
   const double* VWa = pv.VW + ((long long)q * kPartRowsMax) * st;
   const double* VWb = pv.VW + ((long long)(q + 1) * kPartRowsMax) * st;
   for (int e = threadIdx.x; e < s3 * s3; e += blockDim.x) {
     const int a = e / s3, b = e % s3;
     double t = band_entry<BW>(Lb, c0 + a, c0 + b), u = 0.0;
-    for (int i = alo; i < a1; ++i) t -= band_entry<BW>(Lb, i, c0 + a) * VWa[(long long)(i - a0) * st + s3 + b];     // F_right(q)^T W_q
-    for (int i = b0; i < bhi; ++i) {
-      const double fl = band_entry<BW>(Lb, i, c0 + a);
-      t -= fl * VWb[(long long)(i - b0) * st + b];                                                                  // F_left(q+1)^T V_{q+1}
-      u -= fl * VWb[(long long)(i - b0) * st + s3 + b];                                                             // F_left(q+1)^T W_{q+1}
+#pragma unroll
+    for (int jj = 0; jj < BW; ++jj) {
+      const int i = a1 - BW + jj;
+      if (i >= a0) t -= band_entry<BW>(Lb, i, c0 + a) * VWa[(long long)(i - a0) * st + s3 + b];                    // F_right(q)^T W_q
+    }
+#pragma unroll
+    for (int jj = 0; jj < BW; ++jj) {
+      const int i = b0 + jj;
+      if (i < b1) {
+        const double fl = band_entry<BW>(Lb, i, c0 + a);
+        t -= fl * VWb[(long long)(i - b0) * st + b];                                                                 // F_left(q+1)^T V_{q+1}
+        u -= fl * VWb[(long long)(i - b0) * st + s3 + b];                                                            // F_left(q+1)^T W_{q+1}
+      }
     }
     pv.T[((long long)q * s3 + a) * s3 + b] = t;
     pv.U[((long long)q * s3 + a) * s3 + b] = (q + 1 < pv.P - 1) ? u : 0.0;
@@ -702,8 +711,16 @@ __global__ __launch_bounds__(256) void k_part_reduce(PartView pv, int ncols, con
   for (int e = threadIdx.x; e < s3 * ncols; e += blockDim.x) {
     const int a = e / ncols, col = e % ncols;
     double r = Z[(long long)(c0 + a) * ncols + col];
-    for (int i = alo; i < a1; ++i) r -= band_entry<BW>(Lb, i, c0 + a) * Z[(long long)i * ncols + col];
-    for (int i = b0; i < bhi; ++i) r -= band_entry<BW>(Lb, i, c0 + a) * Z[(long long)i * ncols + col];
+#pragma unroll
+    for (int jj = 0; jj < BW; ++jj) {
+      const int i = a1 - BW + jj;
+      if (i >= a0) r -= band_entry<BW>(Lb, i, c0 + a) * Z[(long long)i * ncols + col];
+    }
+#pragma unroll
+    for (int jj = 0; jj < BW; ++jj) {
+      const int i = b0 + jj;
+      if (i < b1) r -= band_entry<BW>(Lb, i, c0 + a) * Z[(long long)i * ncols + col];
+    }
     Z[(long long)(c0 + a) * ncols + col] = r;
   }
 }
@@ -1359,21 +1376,24 @@ __global__ __launch_bounds__(kBsThreads) void k_chol_backsub(int nn, const doubl
   // so the dependent part of every step only touches LDS
   double lv[kNB], ln[kNB];
   const int kb_last = ((nn - 1) / kNB) * kNB;
-  auto fetch = [&](int kb, double* dst, int buf) {
+  double li[kNB * kNB / kBsThreads], lin[kNB * kNB / kBsThreads];     // this thread's entries of the inverse diagonal block
+  auto fetch = [&](int kb, double* dst, double* ldst) {
     const int nb = min(kNB, nn - kb);
 #pragma unroll
     for (int cc = 0; cc < kNB; ++cc) dst[cc] = (kb >= 0 && tid < kb && cc < nb) ? Lf[(long long)(kb + cc) * nn + tid] : 0.0;
-    if (kb >= 0)
-      for (int e = tid; e < kNB * kNB; e += kBsThreads) Ls[buf][e / kNB][e % kNB] = Linv[(long long)(kb / kNB) * kNB * kNB + e];
+#pragma unroll
+    for (int e = 0; e < kNB * kNB / kBsThreads; ++e) ldst[e] = kb >= 0 ? Linv[(long long)(kb / kNB) * kNB * kNB + tid + e * kBsThreads] : 0.0;
   };
-  fetch(kb_last, ln, 0);
+  fetch(kb_last, ln, lin);
   int buf = 0;
   for (int kb = kb_last; kb >= 0; kb -= kNB, buf ^= 1) {
     const int nb = min(kNB, nn - kb);
 #pragma unroll
     for (int cc = 0; cc < kNB; ++cc) lv[cc] = ln[cc];
-    fetch(kb - kNB, ln, buf ^ 1);
-    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < kNB * kNB / kBsThreads; ++e) { li[e] = lin[e]; const int q = tid + e * kBsThreads; Ls[buf][q / kNB][q % kNB] = li[e]; }
+    fetch(kb - kNB, ln, lin);                            // next panel's loads stay in flight across this step
+    lds_barrier();
     if (tid < kNB) {
       double acc = 0.0;
 #pragma unroll
@@ -1381,7 +1401,7 @@ __global__ __launch_bounds__(kBsThreads) void k_chol_backsub(int nn, const doubl
       xk[tid] = acc;
       if (tid < nb) pc[kb + tid] = -acc;
     }
-    __syncthreads();
+    lds_barrier();
     if (tid < kb) {
       double vv = y[tid];
 #pragma unroll
@@ -1393,6 +1413,49 @@ __global__ __launch_bounds__(kBsThreads) void k_chol_backsub(int nn, const doubl
       for (int cc = 0; cc < nb; ++cc) vv -= Lf[(long long)(kb + cc) * nn + i2] * xk[cc];
       y[i2] = vv;
     }
+  }
+}
+
+// The same back substitution for nn <= kBrPanels * kNB with every operand fetched ONCE, up front, into registers (the
+// factor was just written by workgroups on other XCDs, so each dependent round trip to it costs ~3 us -- nine of them
+// in a row in the streaming version above).  1024 threads; lane c = t % 32, group g = t / 32:
+//   - thread holds L[kb + c][g + 32 m] for every panel kb = 32 P and m < P  (P (P-1) / 2 + m, <= 45 values), and the
+//     entry Linv_P[c][g] of every inverse diagonal block;
+//   - step P: x_P[g] = sum_c Linv_P[c][g] t[c]  (32-lane shuffle reduction), then y[g + 32 m] -= sum_c L[..] x_P[c].
+constexpr int kBrPanels = 10;
+__global__ __launch_bounds__(1024) void k_chol_backsub_regs(int nn, const double* __restrict__ Lf, const double* __restrict__ Linv, double* __restrict__ pc) {
+  __shared__ double y[kBrPanels * kNB];
+  __shared__ double xk[kNB];
+  const int tid = threadIdx.x, c = tid & 31, g = tid >> 5;
+  const int np = (nn + kNB - 1) / kNB;
+  double Lr[kBrPanels * (kBrPanels - 1) / 2], Li[kBrPanels];
+#pragma unroll
+  for (int P = 0; P < kBrPanels; ++P) {
+    const int row = P * kNB + c;
+    Li[P] = P < np ? Linv[(long long)P * kNB * kNB + c * kNB + g] : 0.0;
+#pragma unroll
+    for (int m = 0; m < P; ++m) Lr[P * (P - 1) / 2 + m] = (P < np && row < nn) ? Lf[(long long)row * nn + g + kNB * m] : 0.0;
+  }
+  if (tid < kBrPanels * kNB) y[tid] = tid < nn ? Lf[(long long)nn * nn + tid] : 0.0;
+  __syncthreads();
+#pragma unroll
+  for (int P = kBrPanels - 1; P >= 0; --P) {
+    if (P >= np) continue;                                 // uniform
+    // x_P[g] = sum_c Linv_P[c][g] * y[32 P + c]
+    double v = Li[P] * y[P * kNB + c];
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (c == 0) { xk[g] = v; if (P * kNB + g < nn) pc[P * kNB + g] = -v; }
+    lds_barrier();
+    const double xc = xk[c];
+#pragma unroll
+    for (int m = 0; m < P; ++m) {
+      double w = Lr[P * (P - 1) / 2 + m] * xc;
+#pragma unroll
+      for (int off = 16; off > 0; off >>= 1) w += __shfl_xor(w, off, 64);
+      if (c == 0) y[g + kNB * m] -= w;
+    }
+    lds_barrier();
   }
 }
 
@@ -1579,7 +1642,8 @@ struct HipSchur {
         const int tiles = (below + kNB - 1) / kNB;
         hipLaunchKernelGGL(k_chol_step, dim3(tiles, tiles), dim3(kNB * kNB), 0, be.stream, nn, kb, S, Lf, Linv, fail);
       }
-      hipLaunchKernelGGL(k_chol_backsub, dim3(1), dim3(kBsThreads), 0, be.stream, nn, Lf, Linv, pc);
+      if (nn <= kBrPanels * kNB) hipLaunchKernelGGL(k_chol_backsub_regs, dim3(1), dim3(1024), 0, be.stream, nn, Lf, Linv, pc);
+      else hipLaunchKernelGGL(k_chol_backsub, dim3(1), dim3(kBsThreads), 0, be.stream, nn, Lf, Linv, pc);
     }
     hipLaunchKernelGGL(k_back_substitute, dim3((ne.N3 + kThreads / 64 - 1) / (kThreads / 64)), dim3(kThreads), 0, be.stream, be.dp, ne, ncols, Z, pc, px);
     MVUS_HIP(hipGetLastError());

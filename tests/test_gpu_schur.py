@@ -129,6 +129,22 @@ def test_separator_chain_lengths(num_knots, sequential, monkeypatch):
     np.testing.assert_allclose(r.x, xh, rtol=0, atol=1e-5 * max(1.0, np.abs(xh).max()))
 
 
+def test_many_cameras_streaming_back_substitution():
+    """40 cameras -> a 360 x 360 reduced camera system: more than the register-resident back substitution holds
+    (10 panels of 32), so the streaming one runs; 12 panels of the dense factorisation."""
+    from mvus_amd import synth
+    from mvus_amd.ba import BAHandle
+    sc = synth.make_scene(40, 6000, seed=37, rolling_shutter=True, num_knots=30)
+    prob, x0 = mp.problem_from_scene(sc)
+    opts = _lib.default_opts(_lib.SOLVER_LM_SCHUR, _lib.JAC_ANALYTIC, 3)
+    xh, rh, fh = _host(prob).solve(x0, opts)
+    with BAHandle(prob) as h:
+        r = h.solve(x0, opts=opts)
+    assert (r.nfev, r.njev, r.status) == (rh.nfev, rh.njev, rh.status)
+    np.testing.assert_allclose(r.cost, rh.cost, rtol=1e-7)
+    np.testing.assert_allclose(r.x, xh, rtol=0, atol=1e-5 * max(1.0, np.abs(xh).max()))
+
+
 def test_unsorted_and_sparse_detections_take_the_atomic_fallback():
     """Detections shuffled locally (knot spans interleave in index order: sorted by span in LDS), shuffled globally and a
     camera with huge frame gaps (more spans than a chunk window holds: deferred to the atomic kernels); results are

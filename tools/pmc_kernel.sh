@@ -9,8 +9,9 @@ for grp in "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU" "SQ_INSTS_VMEM_RD SQ_INSTS
 import sqlite3
 cur=sqlite3.connect('gpurun_out/pmck_$tag/r_results.db').cursor()
 try:
-    for r in cur.execute("select kernel_name,counter_name,count(*),avg(value) from counters_collection where kernel_name like '%$pat%' group by kernel_name,counter_name"):
-        print(r[0][:36], r[1], r[2], '%.4g'%r[3])
+    import re
+    for r in cur.execute("select kernel_name,counter_name,count(*),avg(value) from counters_collection group by kernel_name,counter_name"):
+        if re.search(r'$pat', r[0]): print(re.sub(r'^void |mvus::', '', r[0])[:28], r[1], r[2], '%.4g'%r[3])
 except Exception as e: print('err', e)
 PY
 done
