@@ -177,6 +177,19 @@ int mvus_ba_remove_outliers(mvus_ba* h, const double* x, double thres, uint8_t* 
  * replicated terms (motion rows, damping) exactly once. */
 int mvus_ba_set_allreduce(mvus_ba* h, mvus_allreduce_fn fn, void* user, int32_t is_root);
 
+/* Time sharding for the LM/Schur solver ("shard by time range"): this handle was created with the
+ * detections of ONE time slice and owns the spline control points [ctrl_cuts[rank], ctrl_cuts[rank+1]) (global
+ * control-point indices over all splines, ctrl_cuts[0] = 0, ctrl_cuts[world] = N; every rank passes the same array).
+ * Each rank then assembles and factorises only its slice of the spline blocks; the cross block never leaves its GPU.
+ * Per LM iteration the all-reduce callback (mvus_ba_set_allreduce, required) sums: the camera blocks + the blocks of the
+ * control points within `halo` of a cut (rows of both neighbours land there), the separator system of the band solver,
+ * the Schur complement contributions, the step, diag(H) and g -- a few MB in all, instead of the whole cross block.
+ * A detection whose four control points leave [own range -+ halo) (time-stamp drift larger than the halo) makes the
+ * next solve fail with MVUS_E_HIP and a message saying so.  Motion rows are evaluated by the rank owning their first
+ * control point (is_root of mvus_ba_set_allreduce is ignored).  Call before mvus_ba_set_allreduce.  world = 1 turns
+ * it off.  No reference counterpart (the reference is single-process). */
+int mvus_ba_set_time_shard(mvus_ba* h, int32_t rank, int32_t world, const int32_t* ctrl_cuts, int32_t halo);
+
 /* Measurement hook for bench.py: runs `launches` back-to-back launches of one kernel on the handle's
  * stream between two hipEvents and returns the average duration in milliseconds.
  *   which: 0 residual, 1 residual+Jacobian, 2 J v, 3 J^T u, 4 normal-equation assembly */

@@ -75,6 +75,7 @@ API = [
     ('mvus_ba_outlier_mask', ctypes.c_int, [ctypes.c_void_p, c_double_p, ctypes.c_double, c_uint8_p]),
     ('mvus_ba_remove_outliers', ctypes.c_int, [ctypes.c_void_p, c_double_p, ctypes.c_double, c_uint8_p, c_int64_p]),
     ('mvus_ba_set_allreduce', ctypes.c_int, [ctypes.c_void_p, ALLREDUCE_FN, ctypes.c_void_p, ctypes.c_int32]),
+    ('mvus_ba_set_time_shard', ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, c_int32_p, ctypes.c_int32]),
     ('mvus_ba_time_kernel', ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, c_double_p]),
     ('mvus_ba_set_x', ctypes.c_int, [ctypes.c_void_p, c_double_p]),
 ]

@@ -184,6 +184,14 @@ class BAHandle:
         self._check(self.lib.mvus_ba_time_kernel(self.h, which, launches, ctypes.byref(ms)), 'mvus_ba_time_kernel')
         return ms.value
 
+    def set_time_shard(self, rank, world, cuts, halo=8):
+        """This handle holds time slice ``rank`` of ``world`` (BAProblem.shard_time): the LM/Schur solver keeps only the
+        spline blocks of control points cuts[rank]..cuts[rank+1] (+- halo).  Call before set_allreduce."""
+        cuts = np.ascontiguousarray(cuts, dtype=np.int32)
+        assert cuts.size == world + 1
+        self._check(self.lib.mvus_ba_set_time_shard(self.h, int(rank), int(world), cuts.ctypes.data_as(_lib.c_int32_p), int(halo)),
+                    'mvus_ba_set_time_shard')
+
     def set_allreduce(self, fn, is_root=True):
         """fn(buf_dev_ptr:int, count:int, stream:int) -> None sums ``count`` doubles in place across ranks."""
         if fn is None:

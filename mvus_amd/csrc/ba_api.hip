@@ -38,6 +38,9 @@ struct HipBackend {
   void* allreduce_user = nullptr;
   int is_root = 1;
   int64_t m_glob = 0;
+  // time shard (mvus_ba_set_time_shard): this handle holds the detections of one time slice and owns the control points
+  // cuts[rank] .. cuts[rank+1]; the LM/Schur path then keeps the spline blocks of that slice (+- halo) only
+  struct TimeShard { bool on = false; int rank = 0, world = 1, halo = 8; std::vector<int> cuts; } tshard;
   double lm_lambda = 0;   // LM damping carried from one solve on this handle to the next
   // MVUS_JAC_FD
   int32_t* fd_groups = nullptr;
@@ -79,6 +82,7 @@ struct HipBackend {
     std::vector<long long> cs(hp.chunk_start.begin(), hp.chunk_start.end()), doff(hp.det_off.begin(), hp.det_off.end());
     dp.chunk_start = dupload(cs); dp.det_off = dupload(doff);
     dp.n_chunks = (int)hp.chunk_cam.size();
+    dp.mot_lo = 0; dp.mot_hi = 0x7fffffff;
     double* uo = dalloc<double>(hp.M); double* vo = dalloc<double>(hp.M);
     dp.u_obs = uo; dp.v_obs = vo;
     cams = dalloc<CamState>(hp.C);
@@ -220,7 +224,7 @@ struct HipBackend {
       }
     }
     if (hp.T > 0) {
-      if (is_root) {
+      if (is_root || tshard.on) {
         const dim3 g((hp.T + kThreads - 1) / kThreads), b(kThreads);
         if (jac) hipLaunchKernelGGL(k_motion<true>, g, b, 0, stream, dp, x, f + 2 * hp.M, mJ, mctrl, (int)masked);
         else hipLaunchKernelGGL(k_motion<false>, g, b, 0, stream, dp, x, f + 2 * hp.M, mJ, mctrl, 0);
@@ -590,11 +594,29 @@ int mvus_ba_set_allreduce(mvus_ba* h, mvus_allreduce_fn fn, void* user, int32_t 
     be.allreduce = fn; be.allreduce_user = user; be.is_root = is_root;
     be.m_glob = be.hp.m;
     if (fn) {   // global row count = sum of the shards' detection rows + the motion rows once
-      be.scal_host[2] = (double)(2 * be.hp.M + (is_root ? be.hp.T : 0));
+      const bool counts_motion = be.tshard.on ? be.tshard.rank == 0 : is_root != 0;
+      be.scal_host[2] = (double)(2 * be.hp.M + (counts_motion ? be.hp.T : 0));
       MVUS_HIP(hipMemcpyAsync(be.scal_dev + 2, be.scal_host + 2, sizeof(double), hipMemcpyHostToDevice, be.stream));
       be.reduce(be.scal_dev + 2, 1);
       be.m_glob = (int64_t)(be.read_slot(2) + 0.5);
     }
+    return MVUS_OK;
+  });
+}
+
+int mvus_ba_set_time_shard(mvus_ba* h, int32_t rank, int32_t world, const int32_t* ctrl_cuts, int32_t halo) {
+  return guarded(h, [&] {
+    HipBackend& be = h->be;
+    if (world < 1 || rank < 0 || rank >= world || !ctrl_cuts || halo < 1) { be.err = "set_time_shard: bad arguments"; return MVUS_E_INVALID; }
+    if (ctrl_cuts[0] != 0 || ctrl_cuts[world] != be.hp.N) { be.err = "set_time_shard: cuts must run from 0 to the number of control points"; return MVUS_E_INVALID; }
+    for (int r = 0; r < world; ++r)
+      if (ctrl_cuts[r + 1] <= ctrl_cuts[r]) { be.err = "set_time_shard: cuts must increase"; return MVUS_E_INVALID; }
+    h->schur.reset();
+    be.tshard.on = world > 1; be.tshard.rank = rank; be.tshard.world = world; be.tshard.halo = halo;
+    be.tshard.cuts.assign(ctrl_cuts, ctrl_cuts + world + 1);
+    be.dp.mot_lo = be.tshard.on ? ctrl_cuts[rank] : 0;
+    be.dp.mot_hi = be.tshard.on ? ctrl_cuts[rank + 1] : 0x7fffffff;
+    be.has_jacobian = false;
     return MVUS_OK;
   });
 }

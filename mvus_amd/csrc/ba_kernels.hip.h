@@ -40,6 +40,7 @@ struct DevProblem {  // trivially copyable: passed to kernels by value
   const int32_t *chunk_cam, *chunk_count;
   const long long *chunk_start, *det_off;
   int n_chunks;
+  int mot_lo, mot_hi;   // motion rows whose first control point lies in [mot_lo, mot_hi) are evaluated (time shards), the rest are zero rows
 };
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding global load
@@ -147,6 +148,15 @@ __global__ __launch_bounds__(kThreads) void k_motion(DevProblem dp, const double
   if (j >= dp.T) return;
   double jrow[36];
   int32_t cidx[3];
+  const int key = dp.mv.ctrl[j];
+  if (key < dp.mot_lo || key >= dp.mot_hi) {          // owned by another time shard: a row of zeros here
+    fm[j] = 0.0;
+    if (JAC) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) mctrl[(long long)k * dp.T + j] = -1;
+    }
+    return;
+  }
   fm[j] = eval_motion_row<JAC>(dp.mv, x, j, masked != 0, jrow, cidx);
   if (JAC) {
 #pragma unroll

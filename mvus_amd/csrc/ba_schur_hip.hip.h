@@ -24,9 +24,13 @@ namespace mvus {
 
 constexpr int kNWin = 64;   // control points covered by a workgroup's LDS accumulation window
 
+// N, N3 and every control-point index inside the kernels are LOCAL to this handle's slice, which starts at global
+// control point row0 (0 and the whole spline unless the handle is a time shard)
 struct NEView {
   double *A, *gc, *Cb, *gs, *Et;
   int C, B, CB, N, N3, W;
+  int row0;
+  int* err;              // set when a row reaches outside the slice
 };
 
 __device__ __forceinline__ int wave_min_i(int v) {
@@ -123,7 +127,10 @@ __global__ __launch_bounds__(kGaThreads) void k_assemble_spans(DevProblem dp, co
       int e = tid + 1;
       while (e < kGaObs && key[e] == ks) ++e;
       const int slot = (tid >= 64 ? nr_s : 0) + __popcll(mask & ((1ull << (tid & 63)) - 1ull));
-      rs[slot] = (unsigned char)tid; re[slot] = (unsigned char)e; rg[slot] = ks;
+      const int kl = ks - ne.row0;                       // local control point; a time shard must hold all four
+      const bool inr = kl >= 0 && kl + 3 < ne.N;
+      if (!inr) atomicOr(ne.err, 1);
+      rs[slot] = (unsigned char)tid; re[slot] = (unsigned char)(inr ? e : tid); rg[slot] = inr ? kl : 0;
     }
     __syncthreads();
     if (tid == 64) nr_s += __popcll(mask);
@@ -361,11 +368,18 @@ __global__ __launch_bounds__(kThreads) void k_assemble_motion(DevProblem dp, con
   // compact the row: control points lo .. lo+kMotW-1, 3 coordinates each
   int lo = 0x7fffffff, hi = -1;
   int cid[3] = {-1, -1, -1};
-  if (j < dp.T)
+  if (j < dp.T) {
+    bool outside = false;
     for (int k = 0; k < 3; ++k) {
       cid[k] = mctrl[(long long)k * dp.T + j];
-      if (cid[k] >= 0) { lo = min(lo, cid[k]); hi = max(hi, cid[k] + 3); }
+      if (cid[k] >= 0) {
+        cid[k] -= ne.row0;                               // local control point
+        if (cid[k] < 0 || cid[k] + 3 >= ne.N) outside = true;
+        lo = min(lo, cid[k]); hi = max(hi, cid[k] + 3);
+      }
     }
+    if (outside) { atomicOr(ne.err, 1); lo = 0x7fffffff; hi = -1; cid[0] = cid[1] = cid[2] = -1; }
+  }
   double rv[kMotW * 3];
 #pragma unroll
   for (int e = 0; e < kMotW * 3; ++e) rv[e] = 0.0;
@@ -428,9 +442,12 @@ __global__ __launch_bounds__(kThreads) void k_assemble_motion(DevProblem dp, con
 }
 
 // D = diag(H) in x order (0 -> 1 so that unused columns stay put), and g in x order
-__global__ void k_ne_diag_grad(DevProblem dp, NEView ne, double* __restrict__ D, double* __restrict__ gx) {
+__global__ void k_ne_diag_grad(DevProblem dp, NEView ne, int own_lo, int own_hi, int cams, double* __restrict__ D, double* __restrict__ gx) {
+  // own_lo / own_hi: local control points this slice owns (a time shard leaves its halo to the neighbour);
+  // cams: write the camera entries (one rank only does, before the vectors are summed over the ranks)
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx < ne.CB) {
+    if (!cams) return;
     const int c = idx / ne.B, k = idx % ne.B;
     const double h = ne.A[((long long)c * ne.B + k) * ne.B + k];
     const int col = cam_col(dp.C, dp.P, c, k);
@@ -438,11 +455,44 @@ __global__ void k_ne_diag_grad(DevProblem dp, NEView ne, double* __restrict__ D,
     gx[col] = ne.gc[idx];
   } else if (idx < ne.CB + ne.N3) {
     const int r = idx - ne.CB, g = r / 3, d = r % 3;
+    if (g < own_lo || g >= own_hi) return;
     const double h = ne.Cb[((long long)g * ne.W) * 9 + 4 * d];
-    const int col = dp.mv.ctrl_x0[g] + d * dp.mv.ctrl_stride[g];
+    const int gg = g + ne.row0;
+    const int col = dp.mv.ctrl_x0[gg] + d * dp.mv.ctrl_stride[gg];
     D[col] = h > 0.0 ? h : 1.0;
     gx[col] = ne.gs[r];
   }
+}
+
+// ---- time shards: the blocks of the control points within `halo` of a cut receive rows from both neighbours --------
+// Packed exchange buffer: [boundary b = 1 .. world-1][2*halo control points from cut_b - halo][3*CB cross | W*9 band | 3 grad].
+// pack: this rank's partial blocks of its (<= 2) boundaries, everything else stays zero; after the sum over the ranks
+// unpack overwrites the local blocks with the totals.
+__global__ void k_halo_copy(NEView ne, int halo, int nb, const int* __restrict__ bcut, const int* __restrict__ bidx, int Ntot,
+                            double* __restrict__ buf, int unpack) {
+  const int per = 3 * ne.CB + ne.W * 9 + 3;
+  const long long total = (long long)nb * 2 * halo * per;
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const int f = (int)(e % per);
+    const int ci = (int)((e / per) % (2 * halo)), b = (int)(e / ((long long)per * 2 * halo));
+    const int ctrl = bcut[b] - halo + ci;              // global control point
+    if (ctrl < 0 || ctrl >= Ntot) continue;
+    const int l = ctrl - ne.row0;
+    if (l < 0 || l >= ne.N) continue;                  // cannot happen: the slice spans its own range +- halo
+    double* slot;
+    if (f < 3 * ne.CB) { const int c = f / (3 * ne.B), dk = f % (3 * ne.B); slot = ne.Et + ((long long)c * ne.N3 + 3 * l) * ne.B + dk; }
+    else if (f < 3 * ne.CB + ne.W * 9) slot = ne.Cb + (long long)l * ne.W * 9 + (f - 3 * ne.CB);
+    else slot = ne.gs + 3 * l + (f - 3 * ne.CB - ne.W * 9);
+    double* dst = buf + ((long long)bidx[b] * 2 * halo + ci) * per + f;
+    if (unpack) *slot = *dst; else *dst = *slot;
+  }
+}
+__global__ void k_sum_slabs(long long count, int nslab, const double* __restrict__ Gp, double* __restrict__ G0) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  double t = 0.0;
+  for (int sl = 0; sl < nslab; ++sl) t += Gp[sl * count + i];
+  G0[i] = t;
 }
 
 // scalar lower band of (C + lambda D_s): Lb[i][j] = (C + lambda D)(i, i-j), j = 0..BW
@@ -515,16 +565,26 @@ __global__ __launch_bounds__(64) void k_band_cholesky(int n3, double* __restrict
 constexpr int kPartL = 32;
 constexpr int kPartRowsMax = 3 * (kPartL + 6);
 
+// Rows are LOCAL scalar rows of this handle's slice of the spline system (the whole system unless the handle is a
+// time shard); separators are numbered GLOBALLY along the whole chain, 0 .. m-1.
 struct PartView {
-  int P;                 // interiors
+  int P;                 // interiors of this slice
   int s3;                // separator size in scalars, 3*(W-1)
   const int* i0;         // [P]  first scalar row of interior p
   const int* i1;         // [P]  one past the last scalar row of interior p
-  const int* s0;         // [P-1] first scalar row of separator q
+  const int* sl;         // [P]  first scalar row of the separator left of interior p (global number q_off+p-1), -1: none
+  const int* sr;         // [P]  first scalar row of the separator right of interior p (global number q_off+p), -1: none
+  int q_off;             // global number of the separator right of interior 0
+  int m;                 // separators of the whole chain
+  // separator tasks of k_part_reduce, [nt] each: row of the separator, interior left / right of it held here (-1: held
+  // by the neighbouring shard, which adds that part), global number, own = this slice adds H(S,S) and the rhs rows
+  int nt;
+  const int *tc0, *tpl, *tpr, *tgq, *town;
   double* VW;            // [P][kPartRowsMax][2*s3]
-  double* T;             // [P-1][s3][s3] diagonal blocks of the separator system
-  double* U;             // [P-1][s3][s3] U[q] = T(q, q+1)
-  double *U2, *Ha, *Hc;  // [P-1][s3][s3] each: cyclic-reduction workspace (k_sep_bcr_*)
+  double* T;             // [m][s3][s3] diagonal blocks of the separator system
+  double* U;             // [m][s3][s3] U[q] = T(q, q+1)
+  double *U2, *Ha, *Hc;  // [m][s3][s3] each: cyclic-reduction workspace (k_sep_bcr_*)
+  double* R;             // [m][s3][ncols] reduced right-hand sides -> solution of the separator system
 };
 
 // original (damped) matrix entry H(i, c) read from the lower band; valid for separator rows/columns and for
@@ -602,8 +662,8 @@ __device__ __forceinline__ void part_solve_block(const PartView& pv, int ncols, 
   int ccol = 0;
   bool live;
   if (COUPLING) {
-    live = tid < 2 * s3 && (tid < s3 ? p > 0 : p < pv.P - 1);
-    if (live) ccol = tid < s3 ? pv.s0[p - 1] + tid : pv.s0[p] + (tid - s3);
+    live = tid < 2 * s3 && (tid < s3 ? pv.sl[p] >= 0 : pv.sr[p] >= 0);
+    if (live) ccol = tid < s3 ? pv.sl[p] + tid : pv.sr[p] + (tid - s3);
   } else {
     live = (int)(blockIdx.y * 64 + tid) < ncols;
   }
@@ -679,49 +739,50 @@ __global__ __launch_bounds__(64) void k_part_solve(PartView pv, int ncols, const
 
 // separator system: T(q,q), T(q,q+1) and the reduced right-hand sides (in place in the separator rows of Z)
 template <int BW>
-__global__ __launch_bounds__(256) void k_part_reduce(PartView pv, int ncols, const double* __restrict__ Lb, double* __restrict__ Z) {
-  const int q = blockIdx.x, s3 = pv.s3, st = 2 * s3;
-  const int c0 = pv.s0[q];
-  const int a0 = pv.i0[q], a1 = pv.i1[q];             // interior before the separator
-  const int b0 = pv.i0[q + 1], b1 = pv.i1[q + 1];     // interior after it
+__global__ __launch_bounds__(256) void k_part_reduce(PartView pv, int ncols, const double* __restrict__ Lb, const double* __restrict__ Z) {
+  const int t = blockIdx.x, s3 = pv.s3, st = 2 * s3;
+  const int c0 = pv.tc0[t], pl = pv.tpl[t], pr = pv.tpr[t], gq = pv.tgq[t];
+  const bool own = pv.town[t] != 0;
+  const int a0 = pl >= 0 ? pv.i0[pl] : 0, a1 = pl >= 0 ? pv.i1[pl] : 0;     // interior before the separator
+  const int b0 = pr >= 0 ? pv.i0[pr] : 0, b1 = pr >= 0 ? pv.i1[pr] : 0;     // interior after it
   // only the last BW rows of the interior before and the first BW rows of the one after couple to the separator; the
   // loops run over exactly BW rows with the out-of-range ones masked, so that all their loads are issued together
-  const double* VWa = pv.VW + ((long long)q * kPartRowsMax) * st;
-  const double* VWb = pv.VW + ((long long)(q + 1) * kPartRowsMax) * st;
+  const double* VWa = pv.VW + ((long long)(pl >= 0 ? pl : 0) * kPartRowsMax) * st;
+  const double* VWb = pv.VW + ((long long)(pr >= 0 ? pr : 0) * kPartRowsMax) * st;
   for (int e = threadIdx.x; e < s3 * s3; e += blockDim.x) {
     const int a = e / s3, b = e % s3;
-    double t = band_entry<BW>(Lb, c0 + a, c0 + b), u = 0.0;
+    double tt = own ? band_entry<BW>(Lb, c0 + a, c0 + b) : 0.0, u = 0.0;
 #pragma unroll
     for (int jj = 0; jj < BW; ++jj) {
       const int i = a1 - BW + jj;
-      if (i >= a0) t -= band_entry<BW>(Lb, i, c0 + a) * VWa[(long long)(i - a0) * st + s3 + b];                    // F_right(q)^T W_q
+      if (pl >= 0 && i >= a0) tt -= band_entry<BW>(Lb, i, c0 + a) * VWa[(long long)(i - a0) * st + s3 + b];          // F_right(q)^T W_q
     }
 #pragma unroll
     for (int jj = 0; jj < BW; ++jj) {
       const int i = b0 + jj;
-      if (i < b1) {
+      if (pr >= 0 && i < b1) {
         const double fl = band_entry<BW>(Lb, i, c0 + a);
-        t -= fl * VWb[(long long)(i - b0) * st + b];                                                                 // F_left(q+1)^T V_{q+1}
+        tt -= fl * VWb[(long long)(i - b0) * st + b];                                                                // F_left(q+1)^T V_{q+1}
         u -= fl * VWb[(long long)(i - b0) * st + s3 + b];                                                            // F_left(q+1)^T W_{q+1}
       }
     }
-    pv.T[((long long)q * s3 + a) * s3 + b] = t;
-    pv.U[((long long)q * s3 + a) * s3 + b] = (q + 1 < pv.P - 1) ? u : 0.0;
+    pv.T[((long long)gq * s3 + a) * s3 + b] = tt;
+    pv.U[((long long)gq * s3 + a) * s3 + b] = (gq + 1 < pv.m) ? u : 0.0;
   }
   for (int e = threadIdx.x; e < s3 * ncols; e += blockDim.x) {
     const int a = e / ncols, col = e % ncols;
-    double r = Z[(long long)(c0 + a) * ncols + col];
+    double r = own ? Z[(long long)(c0 + a) * ncols + col] : 0.0;
 #pragma unroll
     for (int jj = 0; jj < BW; ++jj) {
       const int i = a1 - BW + jj;
-      if (i >= a0) r -= band_entry<BW>(Lb, i, c0 + a) * Z[(long long)i * ncols + col];
+      if (pl >= 0 && i >= a0) r -= band_entry<BW>(Lb, i, c0 + a) * Z[(long long)i * ncols + col];
     }
 #pragma unroll
     for (int jj = 0; jj < BW; ++jj) {
       const int i = b0 + jj;
-      if (i < b1) r -= band_entry<BW>(Lb, i, c0 + a) * Z[(long long)i * ncols + col];
+      if (pr >= 0 && i < b1) r -= band_entry<BW>(Lb, i, c0 + a) * Z[(long long)i * ncols + col];
     }
-    Z[(long long)(c0 + a) * ncols + col] = r;
+    pv.R[((long long)gq * s3 + a) * ncols + col] = r;
   }
 }
 
@@ -732,7 +793,7 @@ __global__ __launch_bounds__(64) void k_sep_factor(PartView pv, int* __restrict_
   __shared__ double Cq[S3 * S3];
   __shared__ double Lq[S3 * S3];
   __shared__ double Uq[S3 * S3];
-  const int nq = pv.P - 1, lane = threadIdx.x;
+  const int nq = pv.m, lane = threadIdx.x;
   constexpr int kPer = (S3 * S3 + 63) / 64;          // entries of T_q / U_q held per lane
   double tn[kPer], un[kPer];                         // next step's blocks, fetched one step ahead
 #pragma unroll
@@ -801,13 +862,14 @@ __global__ __launch_bounds__(64) void k_sep_factor(PartView pv, int* __restrict_
 // broadcasts through the caches); the next step's right-hand-side rows are fetched before the current step's
 // dependent chain, and the diagonal of C_q is stored inverted (k_sep_factor) so the chain has no divisions.
 template <int S3>
-__global__ __launch_bounds__(64) void k_sep_rhs(PartView pv, int ncols, double* __restrict__ Z) {
+__global__ __launch_bounds__(64) void k_sep_rhs(PartView pv, int ncols) {
+  double* __restrict__ Rr = pv.R;
   const int col = blockIdx.x * blockDim.x + threadIdx.x;
   if (col >= ncols) return;
-  const int nq = pv.P - 1;
+  const int nq = pv.m;
   double prev[S3], rv[S3], nx[S3];
 #pragma unroll
-  for (int a = 0; a < S3; ++a) { prev[a] = 0.0; nx[a] = Z[(long long)(pv.s0[0] + a) * ncols + col]; }
+  for (int a = 0; a < S3; ++a) { prev[a] = 0.0; nx[a] = Rr[((long long)(0) * S3 + a) * ncols + col]; }
   for (int q = 0; q < nq; ++q) {
     const double* __restrict__ Cq = pv.T + (long long)q * S3 * S3;
     const double* __restrict__ Lq = pv.U + (long long)(q - 1) * S3 * S3;     // L(q, q-1)
@@ -815,7 +877,7 @@ __global__ __launch_bounds__(64) void k_sep_rhs(PartView pv, int ncols, double* 
     for (int a = 0; a < S3; ++a) rv[a] = nx[a];
     if (q + 1 < nq) {
 #pragma unroll
-      for (int a = 0; a < S3; ++a) nx[a] = Z[(long long)(pv.s0[q + 1] + a) * ncols + col];
+      for (int a = 0; a < S3; ++a) nx[a] = Rr[((long long)(q + 1) * S3 + a) * ncols + col];
     }
     if (q > 0) {
 #pragma unroll
@@ -831,7 +893,7 @@ __global__ __launch_bounds__(64) void k_sep_rhs(PartView pv, int ncols, double* 
       rv[a] = sacc * Cq[a * S3 + a];            // diagonal stored as 1 / C(a,a)
     }
 #pragma unroll
-    for (int a = 0; a < S3; ++a) { prev[a] = rv[a]; Z[(long long)(pv.s0[q] + a) * ncols + col] = rv[a]; }
+    for (int a = 0; a < S3; ++a) { prev[a] = rv[a]; Rr[((long long)(q) * S3 + a) * ncols + col] = rv[a]; }
   }
 #pragma unroll
   for (int a = 0; a < S3; ++a) nx[a] = prev[a];
@@ -842,7 +904,7 @@ __global__ __launch_bounds__(64) void k_sep_rhs(PartView pv, int ncols, double* 
     for (int a = 0; a < S3; ++a) rv[a] = nx[a];
     if (q > 0) {
 #pragma unroll
-      for (int a = 0; a < S3; ++a) nx[a] = Z[(long long)(pv.s0[q - 1] + a) * ncols + col];
+      for (int a = 0; a < S3; ++a) nx[a] = Rr[((long long)(q - 1) * S3 + a) * ncols + col];
     }
     if (q + 1 < nq) {
 #pragma unroll
@@ -858,7 +920,7 @@ __global__ __launch_bounds__(64) void k_sep_rhs(PartView pv, int ncols, double* 
       rv[a] = sacc * Cq[a * S3 + a];
     }
 #pragma unroll
-    for (int a = 0; a < S3; ++a) { prev[a] = rv[a]; Z[(long long)(pv.s0[q] + a) * ncols + col] = rv[a]; }
+    for (int a = 0; a < S3; ++a) { prev[a] = rv[a]; Rr[((long long)(q) * S3 + a) * ncols + col] = rv[a]; }
   }
 }
 
@@ -905,7 +967,7 @@ __global__ __launch_bounds__(kBcrWaves * 64) void k_sep_bcr_factor(PartView pv, 
   //   2. Ha_j = Dinv_j C_{j-h}^T and Hc_j = Dinv_j C_j, 3. the survivors' D_i and C_i: one matrix-core product
   //      chain per wavefront, the operands of kTb products fetched together to overlap their latency.
   constexpr int SS = S3 * S3, NPW = 64 / S3, kTb = 4;
-  const int m = pv.P - 1, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m = pv.m, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lk = lane >> 4;
   double* Ccur = pv.U;
   double* Cnxt = pv.U2;
@@ -1005,16 +1067,17 @@ __global__ __launch_bounds__(kBcrWaves * 64) void k_sep_bcr_factor(PartView pv, 
 
 constexpr int kBcrCols = 2;
 template <int S3>
-__global__ __launch_bounds__(256) void k_sep_bcr_rhs(PartView pv, int ncols, double* __restrict__ Z) {
+__global__ __launch_bounds__(256) void k_sep_bcr_rhs(PartView pv, int ncols) {
+  double* __restrict__ Rr = pv.R;
   constexpr int SS = S3 * S3, TC = kBcrCols;
   extern __shared__ double bcr_lds[];
-  const int m = pv.P - 1, tid = threadIdx.x;
+  const int m = pv.m, tid = threadIdx.x;
   double* rs = bcr_lds;                       // [m][S3][TC]
   double* xs = bcr_lds + (size_t)m * S3 * TC;
   const int col0 = blockIdx.x * TC;
   for (int e = tid; e < m * S3 * TC; e += 256) {
     const int c = e % TC, a = (e / TC) % S3, q = e / (TC * S3);
-    rs[e] = col0 + c < ncols ? Z[(long long)(pv.s0[q] + a) * ncols + col0 + c] : 0.0;
+    rs[e] = col0 + c < ncols ? Rr[((long long)q * S3 + a) * ncols + col0 + c] : 0.0;
   }
   __syncthreads();
   int h = 1;
@@ -1064,7 +1127,7 @@ __global__ __launch_bounds__(256) void k_sep_bcr_rhs(PartView pv, int ncols, dou
   }
   for (int e = tid; e < m * S3 * TC; e += 256) {
     const int c = e % TC, a = (e / TC) % S3, q = e / (TC * S3);
-    if (col0 + c < ncols) Z[(long long)(pv.s0[q] + a) * ncols + col0 + c] = xs[e];
+    if (col0 + c < ncols) Rr[((long long)q * S3 + a) * ncols + col0 + c] = xs[e];
   }
 }
 
@@ -1080,13 +1143,17 @@ __global__ __launch_bounds__(64) void k_part_back(PartView pv, int ncols, double
   const int r0 = pv.i0[p], n = pv.i1[p] - r0;
   const int ia = blockIdx.z * kBackRows, ib = min(n, ia + kBackRows);      // rows of this workgroup
   if (ia >= n) return;
-  const bool left = p > 0, right = p < pv.P - 1;
+  const bool left = pv.sl[p] >= 0, right = pv.sr[p] >= 0;
   const double* __restrict__ VWp = pv.VW + ((long long)p * kPartRowsMax) * st;
   double zl[S3], zr[S3];
 #pragma unroll
   for (int a = 0; a < S3; ++a) {
-    zl[a] = left ? Z[(long long)(pv.s0[left ? p - 1 : 0] + a) * ncols + col] : 0.0;
-    zr[a] = right ? Z[(long long)(pv.s0[right ? p : 0] + a) * ncols + col] : 0.0;
+    zl[a] = left ? pv.R[((long long)(pv.q_off + p - 1) * S3 + a) * ncols + col] : 0.0;
+    zr[a] = right ? pv.R[((long long)(pv.q_off + p) * S3 + a) * ncols + col] : 0.0;
+  }
+  if (right && blockIdx.z == 0) {          // the solved separator right of this interior goes back into its rows of Z
+#pragma unroll
+    for (int a = 0; a < S3; ++a) Z[(long long)(pv.sr[p] + a) * ncols + col] = zr[a];
   }
 #pragma unroll 4
   for (int i = ia; i < ib; ++i) {
@@ -1221,11 +1288,11 @@ __device__ __forceinline__ void schur_gemm_tile(const NEView& ne, int ncols, con
   }
 }
 
-__global__ __launch_bounds__(256) void k_schur_gemm(NEView ne, int ncols, const double* __restrict__ Erm, const double* __restrict__ Z, double* __restrict__ Gp) {
+__global__ __launch_bounds__(256) void k_schur_gemm(NEView ne, int ncols, int row_lo, int row_hi, const double* __restrict__ Erm, const double* __restrict__ Z, double* __restrict__ Gp) {
   __shared__ double red[9 * 4 * 64];
   const int nbk = (ne.CB + kGemmT - 1) / kGemmT, nsym = nbk * (nbk + 1) / 2;
   const int t = blockIdx.x;
-  const int kbeg = blockIdx.y * kGemmSlab, kend = min(kbeg + kGemmSlab, ne.N3);
+  const int kbeg = row_lo + blockIdx.y * kGemmSlab, kend = min(kbeg + kGemmSlab, row_hi);      // rows this slice owns
   double* G = Gp + (long long)blockIdx.y * ne.CB * ncols;
   if (t < nsym) {
     int bi = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
@@ -1460,22 +1527,46 @@ __global__ __launch_bounds__(1024) void k_chol_backsub_regs(int nn, const double
 }
 
 // p (x order) from p_c and p_s = -(z_g + Z_E p_c)
-__global__ __launch_bounds__(kThreads) void k_back_substitute(DevProblem dp, NEView ne, int ncols, const double* __restrict__ Z,
-                                                              const double* __restrict__ pc, double* __restrict__ px) {
-  // one wavefront per spline row: lanes stride over the row of Z (coalesced), then a shuffle reduction
+__global__ __launch_bounds__(kThreads) void k_back_substitute(DevProblem dp, NEView ne, int ncols, int row_lo, int row_hi, int cams,
+                                                              const double* __restrict__ Z, const double* __restrict__ pc, double* __restrict__ px) {
+  // one wavefront per owned spline row: lanes stride over the row of Z (coalesced), then a shuffle reduction
   const int lane = threadIdx.x & 63;
-  const int r = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
-  if (blockIdx.x == 0)
+  const int r = row_lo + blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+  if (blockIdx.x == 0 && cams)
     for (int idx = threadIdx.x; idx < ne.CB; idx += kThreads) px[cam_col(dp.C, dp.P, idx / ne.B, idx % ne.B)] = pc[idx];
-  if (r >= ne.N3) return;
+  if (r >= row_hi) return;
   const double* zr = Z + (long long)r * ncols;
   double acc = 0.0;
   for (int k = lane; k < ne.CB; k += 64) acc += zr[k] * pc[k];
   acc = wave_sum(acc);
   if (lane == 0) {
-    const int g = r / 3, d = r % 3;
+    const int g = r / 3 + ne.row0, d = r % 3;
     px[dp.mv.ctrl_x0[g] + d * dp.mv.ctrl_stride[g]] = -(acc + zr[ne.CB]);
   }
+}
+
+// Partition of a chain of `n` control points starting at local control point `c0`: interiors of kPartL control points
+// separated by separators of sctrl; `close` = the chain must END with a separator (the cut towards the next time
+// shard), otherwise a tail too short for another interior is merged into the last one.
+struct ChainPart { std::vector<int> i0, i1, sep; };     // scalar rows; sep[k] = separator right of interior k
+inline ChainPart partition_chain(int c0, int n, int sctrl, bool close) {
+  ChainPart cp;
+  const int end = c0 + n;
+  for (int g = c0; g < end;) {
+    int e = std::min(g + kPartL, end);
+    if (close) {
+      e = std::min(g + kPartL, end - sctrl);
+      const int rem = end - sctrl - e;                 // control points between this interior and the closing separator
+      if (rem > 0 && rem < sctrl + 1) e = end - sctrl; // not enough for a separator and another interior: merge
+    }
+    cp.i0.push_back(3 * g); cp.i1.push_back(3 * e); g = e;
+    if (g < end) {
+      const int e2 = std::min(g + sctrl, end);
+      if (!close && end - e2 < 1) { cp.i1.back() = 3 * end; g = end; }          // tail too short for another interior: merge
+      else { cp.sep.push_back(3 * g); g = e2; }
+    }
+  }
+  return cp;
 }
 
 template <class BE>
@@ -1485,18 +1576,34 @@ struct HipSchur {
   int ncols = 0, BW = 0;
   size_t ne_count = 0;
   double *Erm = nullptr;
-  double *NE = nullptr, *Lb = nullptr, *Z = nullptr, *G = nullptr, *S = nullptr, *Lf = nullptr, *Linv = nullptr, *rhs = nullptr, *pc = nullptr, *D = nullptr, *gx = nullptr, *px = nullptr;
-  int* fail = nullptr;
+  double *NE = nullptr, *Lb = nullptr, *Z = nullptr, *G = nullptr, *G0 = nullptr, *S = nullptr, *Lf = nullptr, *Linv = nullptr, *rhs = nullptr, *pc = nullptr,
+         *DG = nullptr, *D = nullptr, *gx = nullptr, *px = nullptr, *sepbuf = nullptr;
+  int* fail = nullptr;      // [0] numerical failure of a solve, [1] a row reached outside the slice (assembly)
   int* fail_host = nullptr;
   PartView pv{};
   int* part_tables = nullptr;
   int nslab = 1;            // K-slabs of the Schur product (partial sums in G)
   size_t bcr_lds = 0;       // dynamic LDS of k_sep_bcr_rhs; the sequential separator kernels remain for chains too long for it
   bool use_bcr = false;
+  // slice of the spline system held by this handle (everything unless it is a time shard)
+  bool shard = false;
+  int Ntot = 0, own_lo = 0, own_hi = 0;        // owned control points, LOCAL indices (slice starts at ne.row0)
+  size_t sep_count = 0, halo_count = 0, nAg = 0;
+  int nbound = 0;
+  int* halo_tables = nullptr;                  // [nbound] cut, [nbound] index in the packed buffer
 
   explicit HipSchur(BE& b) : be(b) {
     const HostProblem& hp = be.hp;
-    ne.C = hp.C; ne.B = 3 + hp.P; ne.CB = ne.C * ne.B; ne.N = hp.N; ne.N3 = 3 * hp.N;
+    const auto& ts = be.tshard;
+    shard = ts.on && ts.world > 1;
+    Ntot = hp.N;
+    int glo = 0, ghi = hp.N, olo = 0, ohi = hp.N;          // slice and owned range, global control points
+    if (shard) {
+      olo = ts.cuts[ts.rank]; ohi = ts.cuts[ts.rank + 1];
+      glo = std::max(0, olo - ts.halo); ghi = std::min(hp.N, ohi + ts.halo);
+    }
+    ne.C = hp.C; ne.B = 3 + hp.P; ne.CB = ne.C * ne.B; ne.N = ghi - glo; ne.N3 = 3 * ne.N; ne.row0 = glo;
+    own_lo = olo - glo; own_hi = ohi - glo;
     int W = 4;
     for (int j = 1; j + 1 < hp.T; ++j) {
       if (hp.ms_part[j] < 0 || hp.ms_part[j - 1] != hp.ms_part[j]) continue;
@@ -1509,54 +1616,97 @@ struct HipSchur {
     ne.W = W;
     BW = 3 * W - 1;
     ncols = ne.CB + 1;
+    const int sctrl = W - 1;
+    if (shard) {
+      if (ts.halo < sctrl + 3) throw HipError{"time shard: halo must be at least band half-width + 3 control points"};
+      for (int r = 0; r < ts.world; ++r)
+        if (ts.cuts[r + 1] - ts.cuts[r] < 2 * ts.halo + sctrl + 1) throw HipError{"time shard: a rank owns fewer control points than 2 * halo + separator"};
+    }
+    // packed normal equations [A | gc | (halo exchange buffer) | Cb | gs | Et]: the head is what a time shard sums over the ranks
+    nbound = shard ? (ts.rank > 0) + (ts.rank + 1 < ts.world) : 0;
+    halo_count = shard ? (size_t)(ts.world - 1) * 2 * ts.halo * (3 * ne.CB + W * 9 + 3) : 0;
     const size_t nA = (size_t)ne.C * ne.B * ne.B, ngc = ne.CB, nCb = (size_t)ne.N * W * 9, ngs = ne.N3, nEt = (size_t)ne.N3 * ne.CB;
-    ne_count = nA + ngc + nCb + ngs + nEt;
+    nAg = nA + ngc;
+    ne_count = nA + ngc + halo_count + nCb + ngs + nEt;
     NE = be.alloc(ne_count);
-    ne.A = NE; ne.gc = ne.A + nA; ne.Cb = ne.gc + ngc; ne.gs = ne.Cb + nCb; ne.Et = ne.gs + ngs;
+    ne.A = NE; ne.gc = ne.A + nA; ne.Cb = ne.gc + ngc + halo_count; ne.gs = ne.Cb + nCb; ne.Et = ne.gs + ngs;
     Lb = be.alloc((size_t)ne.N3 * (BW + 1));
     Z = be.alloc((size_t)ne.N3 * ncols);
     Erm = be.alloc((size_t)ne.N3 * ne.CB);
-    nslab = (ne.N3 + kGemmSlab - 1) / kGemmSlab;
+    nslab = (3 * (own_hi - own_lo) + kGemmSlab - 1) / kGemmSlab;
     G = be.alloc((size_t)nslab * ne.CB * ncols);
+    G0 = be.alloc((size_t)ne.CB * ncols);
     S = be.alloc((size_t)(ne.CB + 1) * ne.CB);
     rhs = be.alloc(ne.CB); pc = be.alloc(ne.CB);
     Lf = be.alloc((size_t)(ne.CB + 1) * ne.CB);
     Linv = be.alloc((size_t)((ne.CB + kNB - 1) / kNB) * kNB * kNB);
-    D = be.alloc(hp.n); gx = be.alloc(hp.n); px = be.alloc(hp.n);
-    MVUS_HIP(hipMalloc(reinterpret_cast<void**>(&fail), sizeof(int)));
-    MVUS_HIP(hipHostMalloc(reinterpret_cast<void**>(&fail_host), sizeof(int), hipHostMallocDefault));
-    // partition of the control-point chain: interiors of kPartL control points, separators of W-1
-    const int sctrl = W - 1;
-    std::vector<int> i0, i1, s0;
-    for (int g = 0; g < ne.N;) {
-      int e = std::min(g + kPartL, ne.N);
-      i0.push_back(3 * g); i1.push_back(3 * e); g = e;
-      if (g < ne.N) {
-        const int e2 = std::min(g + sctrl, ne.N);
-        if (ne.N - e2 < 1) { i1.back() = 3 * ne.N; g = ne.N; }      // tail too short for another interior: merge
-        else { s0.push_back(3 * g); g = e2; }
+    DG = be.alloc(2 * (size_t)hp.n); D = DG; gx = DG + hp.n;      // contiguous: one sum over the ranks
+    px = be.alloc(hp.n);
+    MVUS_HIP(hipMalloc(reinterpret_cast<void**>(&fail), 2 * sizeof(int)));
+    MVUS_HIP(hipMemsetAsync(fail, 0, 2 * sizeof(int), be.stream));
+    MVUS_HIP(hipHostMalloc(reinterpret_cast<void**>(&fail_host), 2 * sizeof(int), hipHostMallocDefault));
+    fail_host[0] = fail_host[1] = 0;
+    ne.err = fail + 1;
+    // partition of the owned chain; the separators are numbered along the chain of ALL ranks (each rank can compute
+    // every other rank's count from the cuts)
+    const bool close = shard && ts.rank + 1 < ts.world;
+    const ChainPart cp = partition_chain(own_lo, own_hi - own_lo, sctrl, close);
+    pv.P = (int)cp.i0.size(); pv.s3 = 3 * sctrl;
+    pv.q_off = 0; pv.m = (int)cp.sep.size();
+    if (shard) {
+      pv.m = 0;
+      for (int r = 0; r < ts.world; ++r) {
+        const ChainPart o = partition_chain(0, ts.cuts[r + 1] - ts.cuts[r], sctrl, r + 1 < ts.world);
+        if (r == ts.rank) pv.q_off = pv.m;
+        pv.m += (int)o.sep.size();
       }
     }
-    pv.P = (int)i0.size(); pv.s3 = 3 * sctrl;
+    const bool ghost = shard && ts.rank > 0;          // the separator that closes the previous rank's chain: left of interior 0
+    std::vector<int> sl(pv.P, -1), sr(pv.P, -1), tc0, tpl, tpr, tgq, town;
+    for (int k = 0; k < pv.P; ++k) {
+      if (k < (int)cp.sep.size()) sr[k] = cp.sep[k];
+      if (k > 0) sl[k] = cp.sep[k - 1];
+    }
+    if (ghost) {
+      sl[0] = 3 * (own_lo - sctrl);
+      tc0.push_back(sl[0]); tpl.push_back(-1); tpr.push_back(0); tgq.push_back(pv.q_off - 1); town.push_back(0);
+    }
+    for (int k = 0; k < (int)cp.sep.size(); ++k) {
+      tc0.push_back(cp.sep[k]); tpl.push_back(k); tpr.push_back(k + 1 < pv.P ? k + 1 : -1); tgq.push_back(pv.q_off + k); town.push_back(1);
+    }
+    pv.nt = (int)tc0.size();
     std::vector<int> tab;
-    tab.insert(tab.end(), i0.begin(), i0.end()); tab.insert(tab.end(), i1.begin(), i1.end()); tab.insert(tab.end(), s0.begin(), s0.end());
+    for (const std::vector<int>* v : std::initializer_list<const std::vector<int>*>{&cp.i0, &cp.i1, &sl, &sr, &tc0, &tpl, &tpr, &tgq, &town}) tab.insert(tab.end(), v->begin(), v->end());
     tab.push_back(0);
     MVUS_HIP(hipMalloc(reinterpret_cast<void**>(&part_tables), tab.size() * sizeof(int)));
     MVUS_HIP(hipMemcpyAsync(part_tables, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice, be.stream));
+    pv.i0 = part_tables; pv.i1 = pv.i0 + pv.P; pv.sl = pv.i1 + pv.P; pv.sr = pv.sl + pv.P;
+    pv.tc0 = pv.sr + pv.P; pv.tpl = pv.tc0 + pv.nt; pv.tpr = pv.tpl + pv.nt; pv.tgq = pv.tpr + pv.nt; pv.town = pv.tgq + pv.nt;
+    if (nbound > 0) {
+      std::vector<int> hb;
+      if (ts.rank > 0) hb.push_back(ts.cuts[ts.rank]);
+      if (ts.rank + 1 < ts.world) hb.push_back(ts.cuts[ts.rank + 1]);
+      if (ts.rank > 0) hb.push_back(ts.rank - 1);
+      if (ts.rank + 1 < ts.world) hb.push_back(ts.rank);
+      MVUS_HIP(hipMalloc(reinterpret_cast<void**>(&halo_tables), hb.size() * sizeof(int)));
+      MVUS_HIP(hipMemcpyAsync(halo_tables, hb.data(), hb.size() * sizeof(int), hipMemcpyHostToDevice, be.stream));
+    }
     MVUS_HIP(hipStreamSynchronize(be.stream));
-    pv.i0 = part_tables; pv.i1 = part_tables + pv.P; pv.s0 = part_tables + 2 * pv.P;
     pv.VW = be.alloc((size_t)pv.P * kPartRowsMax * 2 * pv.s3);
-    pv.T = be.alloc((size_t)std::max(pv.P - 1, 1) * pv.s3 * pv.s3);
-    pv.U = be.alloc((size_t)std::max(pv.P - 1, 1) * pv.s3 * pv.s3);
-    pv.U2 = be.alloc((size_t)std::max(pv.P - 1, 1) * pv.s3 * pv.s3);
-    pv.Ha = be.alloc((size_t)std::max(pv.P - 1, 1) * pv.s3 * pv.s3);
-    pv.Hc = be.alloc((size_t)std::max(pv.P - 1, 1) * pv.s3 * pv.s3);
-    bcr_lds = (size_t)2 * std::max(pv.P - 1, 1) * pv.s3 * kBcrCols * sizeof(double);
+    const size_t mm = (size_t)std::max(pv.m, 1), ss = (size_t)pv.s3 * pv.s3;
+    sep_count = mm * (2 * ss + (size_t)pv.s3 * ncols);
+    sepbuf = be.alloc(sep_count);                    // [T | U | R]: one sum over the ranks
+    pv.T = sepbuf; pv.U = pv.T + mm * ss; pv.R = pv.U + mm * ss;
+    pv.U2 = be.alloc(mm * ss);
+    pv.Ha = be.alloc(mm * ss);
+    pv.Hc = be.alloc(mm * ss);
+    bcr_lds = (size_t)2 * mm * pv.s3 * kBcrCols * sizeof(double);
     use_bcr = bcr_lds <= 64 * 1024 && !std::getenv("MVUS_SEP_SEQUENTIAL");
   }
   ~HipSchur() {
-    for (double* p : {Erm, NE, Lb, Z, G, S, Lf, Linv, rhs, pc, D, gx, px, pv.VW, pv.T, pv.U, pv.U2, pv.Ha, pv.Hc}) be.release(p);
+    for (double* p : {Erm, NE, Lb, Z, G, G0, S, Lf, Linv, rhs, pc, DG, px, pv.VW, sepbuf, pv.U2, pv.Ha, pv.Hc}) be.release(p);
     if (part_tables) (void)hipFree(part_tables);
+    if (halo_tables) (void)hipFree(halo_tables);
     if (fail) (void)hipFree(fail);
     if (fail_host) (void)hipHostFree(fail_host);
   }
@@ -1575,9 +1725,21 @@ struct HipSchur {
   }
   void assemble(BE&, const double* f_dev) {
     assemble_local(f_dev);
-    be.reduce(NE, ne_count);          // one sum-all-reduce of the packed normal-equation blocks per iteration
     const int tot = ne.CB + ne.N3;          // every entry of x is a camera column or a control-point coordinate
-    hipLaunchKernelGGL(k_ne_diag_grad, dim3((tot + 255) / 256), dim3(256), 0, be.stream, be.dp, ne, D, gx);
+    if (shard) {
+      // time shard: sum the camera blocks and the blocks of the control points near a cut; the cross block never moves
+      double* hb = NE + nAg;
+      const int halo = be.tshard.halo;
+      if (nbound > 0) hipLaunchKernelGGL(k_halo_copy, dim3(256), dim3(256), 0, be.stream, ne, halo, nbound, halo_tables, halo_tables + nbound, Ntot, hb, 0);
+      be.reduce(NE, nAg + halo_count);
+      if (nbound > 0) hipLaunchKernelGGL(k_halo_copy, dim3(256), dim3(256), 0, be.stream, ne, halo, nbound, halo_tables, halo_tables + nbound, Ntot, hb, 1);
+      MVUS_HIP(hipMemsetAsync(DG, 0, 2 * be.hp.n * sizeof(double), be.stream));
+      hipLaunchKernelGGL(k_ne_diag_grad, dim3((tot + 255) / 256), dim3(256), 0, be.stream, be.dp, ne, own_lo, own_hi, (int)(be.tshard.rank == 0), D, gx);
+      be.reduce(DG, 2 * (size_t)be.hp.n);
+    } else {
+      be.reduce(NE, ne_count);          // observation shards: one sum-all-reduce of the packed normal-equation blocks per iteration
+      hipLaunchKernelGGL(k_ne_diag_grad, dim3((tot + 255) / 256), dim3(256), 0, be.stream, be.dp, ne, 0, ne.N, 1, D, gx);
+    }
     MVUS_HIP(hipGetLastError());
   }
 
@@ -1586,8 +1748,30 @@ struct HipSchur {
   const double* step_ptr() const { return px; }
   const int* fail_ptr() const { return fail; }
   bool solve_ok() const {                 // valid after the stream has been synchronised (the driver's fetch)
-    if (*fail_host != 0 && std::getenv("MVUS_DEBUG")) std::fprintf(stderr, "schur solve: fail code %d\n", *fail_host);
-    return *fail_host == 0;
+    if (fail_host[1] != 0) throw HipError{"time shard: a detection or motion row reaches control points outside this rank's slice (halo too small for the time-stamp drift)"};
+    if (fail_host[0] != 0 && std::getenv("MVUS_DEBUG")) std::fprintf(stderr, "schur solve: fail code %d\n", fail_host[0]);
+    return fail_host[0] == 0;
+  }
+
+  template <int BWT, int S3T>
+  void band_chain() {
+    const dim3 gsolve(pv.P, (ncols + 63) / 64 + 1);      // + one block row for the coupling columns
+    hipLaunchKernelGGL(k_part_cholesky<BWT>, dim3(pv.P), dim3(64), 0, be.stream, pv, Lb, fail);
+    hipLaunchKernelGGL(k_part_solve<BWT>, gsolve, dim3(64), 0, be.stream, pv, ncols, Lb, Z);
+    if (pv.m > 0) {
+      if (shard) MVUS_HIP(hipMemsetAsync(sepbuf, 0, sep_count * sizeof(double), be.stream));      // other ranks' separators: zero here
+      if (pv.nt > 0) hipLaunchKernelGGL(k_part_reduce<BWT>, dim3(pv.nt), dim3(256), 0, be.stream, pv, ncols, Lb, Z);
+      if (shard) be.reduce(sepbuf, sep_count);        // every rank now holds the whole separator system
+      if (use_bcr) {
+        hipLaunchKernelGGL(k_sep_bcr_factor<S3T>, dim3(1), dim3(kBcrWaves * 64), 0, be.stream, pv, fail);
+        hipLaunchKernelGGL(k_sep_bcr_rhs<S3T>, dim3((ncols + kBcrCols - 1) / kBcrCols), dim3(256), bcr_lds, be.stream, pv, ncols);
+      } else {
+        hipLaunchKernelGGL(k_sep_factor<S3T>, dim3(1), dim3(64), 0, be.stream, pv, fail);
+        hipLaunchKernelGGL(k_sep_rhs<S3T>, dim3((ncols + 63) / 64), dim3(64), 0, be.stream, pv, ncols);
+      }
+      const dim3 gback(pv.P, (ncols + 63) / 64, (kPartRowsMax + kBackRows - 1) / kBackRows);
+      hipLaunchKernelGGL(k_part_back<S3T>, gback, dim3(64), 0, be.stream, pv, ncols, Z);
+    }
   }
 
   void solve_async(double lambda) {
@@ -1595,45 +1779,21 @@ struct HipSchur {
     hipLaunchKernelGGL(k_band_pack, dim3((unsigned)((nLb + 255) / 256)), dim3(256), 0, be.stream, ne, lambda, BW, Lb, fail);
     const long long nZ = (long long)ne.N3 * ncols;
     hipLaunchKernelGGL(k_build_rhs, dim3((unsigned)((nZ + 255) / 256)), dim3(256), 0, be.stream, ne, ncols, Z, Erm);
-    const dim3 gsolve(pv.P, (ncols + 63) / 64 + 1);      // + one block row for the coupling columns
-    if (BW == 11) {
-      hipLaunchKernelGGL(k_part_cholesky<11>, dim3(pv.P), dim3(64), 0, be.stream, pv, Lb, fail);
-      hipLaunchKernelGGL(k_part_solve<11>, gsolve, dim3(64), 0, be.stream, pv, ncols, Lb, Z);
-      if (pv.P > 1) {
-        hipLaunchKernelGGL(k_part_reduce<11>, dim3(pv.P - 1), dim3(256), 0, be.stream, pv, ncols, Lb, Z);
-        if (use_bcr) {
-          hipLaunchKernelGGL(k_sep_bcr_factor<9>, dim3(1), dim3(kBcrWaves * 64), 0, be.stream, pv, fail);
-          hipLaunchKernelGGL(k_sep_bcr_rhs<9>, dim3((ncols + kBcrCols - 1) / kBcrCols), dim3(256), bcr_lds, be.stream, pv, ncols, Z);
-        } else {
-          hipLaunchKernelGGL(k_sep_factor<9>, dim3(1), dim3(64), 0, be.stream, pv, fail);
-          hipLaunchKernelGGL(k_sep_rhs<9>, dim3((ncols + 63) / 64), dim3(64), 0, be.stream, pv, ncols, Z);
-        }
-      }
-    } else {
-      hipLaunchKernelGGL(k_part_cholesky<17>, dim3(pv.P), dim3(64), 0, be.stream, pv, Lb, fail);
-      hipLaunchKernelGGL(k_part_solve<17>, gsolve, dim3(64), 0, be.stream, pv, ncols, Lb, Z);
-      if (pv.P > 1) {
-        hipLaunchKernelGGL(k_part_reduce<17>, dim3(pv.P - 1), dim3(256), 0, be.stream, pv, ncols, Lb, Z);
-        if (use_bcr) {
-          hipLaunchKernelGGL(k_sep_bcr_factor<15>, dim3(1), dim3(kBcrWaves * 64), 0, be.stream, pv, fail);
-          hipLaunchKernelGGL(k_sep_bcr_rhs<15>, dim3((ncols + kBcrCols - 1) / kBcrCols), dim3(256), bcr_lds, be.stream, pv, ncols, Z);
-        } else {
-          hipLaunchKernelGGL(k_sep_factor<15>, dim3(1), dim3(64), 0, be.stream, pv, fail);
-          hipLaunchKernelGGL(k_sep_rhs<15>, dim3((ncols + 63) / 64), dim3(64), 0, be.stream, pv, ncols, Z);
-        }
-      }
-    }
-    if (pv.P > 1) {
-      const dim3 gback(pv.P, (ncols + 63) / 64, (kPartRowsMax + kBackRows - 1) / kBackRows);
-      if (BW == 11) hipLaunchKernelGGL(k_part_back<9>, gback, dim3(64), 0, be.stream, pv, ncols, Z);
-      else hipLaunchKernelGGL(k_part_back<15>, gback, dim3(64), 0, be.stream, pv, ncols, Z);
-    }
+    if (BW == 11) band_chain<11, 9>(); else band_chain<17, 15>();
+    const int row_lo = 3 * own_lo, row_hi = 3 * own_hi;
     {
       const int nbk = (ne.CB + kGemmT - 1) / kGemmT;
-      hipLaunchKernelGGL(k_schur_gemm, dim3(nbk * (nbk + 1) / 2 + nbk, nslab), dim3(256), 0, be.stream, ne, ncols, Erm, Z, G);
+      hipLaunchKernelGGL(k_schur_gemm, dim3(nbk * (nbk + 1) / 2 + nbk, nslab), dim3(256), 0, be.stream, ne, ncols, row_lo, row_hi, Erm, Z, G);
     }
     const long long nS = (long long)ne.CB * ne.CB;
-    hipLaunchKernelGGL(k_schur_finish, dim3((unsigned)((nS + 255) / 256)), dim3(256), 0, be.stream, ne, ncols, nslab, lambda, G, S, rhs);
+    if (shard) {
+      const long long cnt = (long long)ne.CB * ncols;
+      hipLaunchKernelGGL(k_sum_slabs, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, be.stream, cnt, nslab, G, G0);
+      be.reduce(G0, (size_t)cnt);                   // the Schur complement contributions of all time slices
+      hipLaunchKernelGGL(k_schur_finish, dim3((unsigned)((nS + 255) / 256)), dim3(256), 0, be.stream, ne, ncols, 1, lambda, G0, S, rhs);
+    } else {
+      hipLaunchKernelGGL(k_schur_finish, dim3((unsigned)((nS + 255) / 256)), dim3(256), 0, be.stream, ne, ncols, nslab, lambda, G, S, rhs);
+    }
     {
       const int nn = ne.CB;
       hipLaunchKernelGGL(k_chol_first, dim3(1), dim3(64), 0, be.stream, nn, S, Lf, Linv, fail);
@@ -1645,9 +1805,13 @@ struct HipSchur {
       if (nn <= kBrPanels * kNB) hipLaunchKernelGGL(k_chol_backsub_regs, dim3(1), dim3(1024), 0, be.stream, nn, Lf, Linv, pc);
       else hipLaunchKernelGGL(k_chol_backsub, dim3(1), dim3(kBsThreads), 0, be.stream, nn, Lf, Linv, pc);
     }
-    hipLaunchKernelGGL(k_back_substitute, dim3((ne.N3 + kThreads / 64 - 1) / (kThreads / 64)), dim3(kThreads), 0, be.stream, be.dp, ne, ncols, Z, pc, px);
+    if (shard) MVUS_HIP(hipMemsetAsync(px, 0, be.hp.n * sizeof(double), be.stream));
+    const int nrows = row_hi - row_lo, per = kThreads / 64;
+    hipLaunchKernelGGL(k_back_substitute, dim3((unsigned)std::max(1, (nrows + per - 1) / per)), dim3(kThreads), 0, be.stream, be.dp, ne, ncols,
+                       row_lo, row_hi, (int)(!shard || be.tshard.rank == 0), Z, pc, px);
+    if (shard) be.reduce(px, (size_t)be.hp.n);      // every rank's part of the step
     MVUS_HIP(hipGetLastError());
-    MVUS_HIP(hipMemcpyAsync(fail_host, fail, sizeof(int), hipMemcpyDeviceToHost, be.stream));
+    MVUS_HIP(hipMemcpyAsync(fail_host, fail, 2 * sizeof(int), hipMemcpyDeviceToHost, be.stream));
   }
 };
 
@@ -1655,6 +1819,7 @@ struct HipSchur {
 template <class BE>
 int schur_export(BE& be, HipSchur<BE>& sc, double* g, double* JtJ_cam, double* band, double* cross, int32_t* W_out) {
   if (!be.has_jacobian) { be.err = "no Jacobian held: call mvus_ba_residual_jacobian first"; return MVUS_E_INVALID; }
+  if (sc.shard) { be.err = "normal_equations: not available on a time shard (every rank holds a slice of the spline blocks)"; return MVUS_E_INVALID; }
   if (W_out) *W_out = sc.ne.W;
   if (!g && !JtJ_cam && !band && !cross) return MVUS_OK;
   sc.assemble(be, be.f_cur);

@@ -35,18 +35,28 @@ def make_gpu_allreduce(device_index, group=None):
     return fn
 
 
-def sharded_handle(prob, rank, world, device_index, group=None):
+def sharded_handle(prob, rank, world, device_index, group=None, time_x=None, halo=8):
     """BAHandle over observation shard ``rank`` of ``world`` on ``cuda:device_index``.
+
+    ``time_x`` given (the start parameters): shard by TIME (BAProblem.shard_time + mvus_ba_set_time_shard) -- the
+    LM/Schur solver then exchanges a few MB per iteration instead of the whole cross block; every rank must pass the
+    same ``time_x``.  Without it every camera's detections are cut into ``world`` pieces (any solver).
 
     The handle runs on torch's current stream of that device so that its kernels and the collective are
     ordered without extra events.  Motion-regulariser rows are replicated inputs but must be counted
     once: every shard keeps the same layout and `is_root` tells the library which rank evaluates them."""
     import torch
     torch.cuda.set_device(device_index)
-    shard, keep = prob.shard(rank, world)       # motion samples stay in every shard (same layout on all ranks);
+    cuts = None
+    if time_x is not None and world > 1:
+        shard, keep, cuts = prob.shard_time(rank, world, time_x, halo)
+    else:
+        shard, keep = prob.shard(rank, world)   # motion samples stay in every shard (same layout on all ranks);
                                                 # the library evaluates them on the root rank only (is_root)
     stream = torch.cuda.current_stream(device_index).cuda_stream
     h = BAHandle(shard, device=device_index, stream=stream)
+    if cuts is not None:
+        h.set_time_shard(rank, world, cuts, halo)
     if world > 1 or group is not None:
         cb = make_gpu_allreduce(device_index, group)
         h.set_allreduce(cb, is_root=(rank == 0))

@@ -124,6 +124,75 @@ class BAProblem:
             knots=self.knots), keep
 
 
+    # ---- time sharding --------------------------------------------------------------------------
+    def detection_spans(self, x):
+        """Global index of the first of the four control points each detection touches at parameters ``x``
+        (-1 = outside every spline interval), the quantity time shards are cut by."""
+        C = self.C
+        alpha, beta, rs = x[:C], x[C:2 * C], x[2 * C:3 * C]
+        from .bspline import find_span
+        ctrl_off = np.concatenate(([0], np.cumsum(self.n_coef))).astype(np.int64)
+        out = np.full(self.M, -1, dtype=np.int64)
+        for c in range(C):
+            a, b = int(self.det_offsets[c]), int(self.det_offsets[c + 1])
+            tau = alpha[c] * (self.frame[a:b] + (rs[c] * self.v_raw[a:b] / self.img_height[c] if self.rs_free else 0.0)) + beta[c]
+            for s_ in range(self.S):
+                t = self.knots[int(self.knot_offsets[s_]):int(self.knot_offsets[s_ + 1])]
+                inside = (tau >= self.interval[0, s_]) & (tau < self.interval[1, s_])
+                if inside.any():
+                    out[a:b][inside] = ctrl_off[s_] + find_span(t, tau[inside]) - 3
+        return out
+
+    def time_cuts(self, x, world, halo=8):
+        """Control-point cuts [0, c_1, .., N] giving every rank about the same number of detections."""
+        g = self.detection_spans(x)
+        g = np.sort(g[g >= 0])
+        N = int(np.sum(self.n_coef))
+        cuts = [0]
+        for r in range(1, world):
+            cuts.append(int(g[min(g.size - 1, (g.size * r) // world)]) if g.size else (N * r) // world)
+        cuts.append(N)
+        gap = 2 * halo + 8                               # the library needs room for the halo and one separator per rank
+        for r in range(1, world):
+            cuts[r] = min(max(cuts[r], cuts[r - 1] + gap), N - gap * (world - r))
+        if any(cuts[r + 1] - cuts[r] < gap for r in range(world)):
+            raise ValueError('too few control points (%d) for %d time shards with halo %d' % (N, world, halo))
+        return np.asarray(cuts, dtype=np.int32)
+
+    def shard_time(self, rank, world, x, halo=8, cuts=None):
+        """Time shard ``rank`` of ``world``: the detections whose first control point (at parameters ``x``) lies in
+        [cuts[rank], cuts[rank+1]); detections outside every interval follow their predecessor in the camera.
+        Returns (sub-problem, kept detection indices, cuts).  Parameters, splines and motion samples stay replicated."""
+        if cuts is None:
+            cuts = self.time_cuts(x, world, halo)
+        g = self.detection_spans(x)
+        keep, new_off = [], [0]
+        for c in range(self.C):
+            a, b = int(self.det_offsets[c]), int(self.det_offsets[c + 1])
+            gc = g[a:b].copy()
+            last = -1
+            for i in range(gc.size):                     # forward fill the invisible ones
+                if gc[i] < 0:
+                    gc[i] = last
+                else:
+                    last = gc[i]
+            gc[gc < 0] = 0
+            owner = np.searchsorted(cuts[1:-1], gc, side='right')
+            idx = a + np.nonzero(owner == rank)[0]
+            keep.append(idx)
+            new_off.append(new_off[-1] + idx.size)
+        keep = np.concatenate(keep) if keep else np.zeros(0, dtype=np.int64)
+        sub = BAProblem(
+            num_cam=self.num_cam, opt_calib=self.opt_calib, undist_points=self.undist_points,
+            rs_free=self.rs_free, rs_bounds=self.rs_bounds, motion_reg=self.motion_reg,
+            motion_type=self.motion_type, motion_weight=self.motion_weight,
+            det_offsets=np.asarray(new_off, dtype=np.int64), frame=self.frame[keep].copy(),
+            u_raw=self.u_raw[keep].copy(), v_raw=self.v_raw[keep].copy(), img_height=self.img_height,
+            K=self.K, dist=self.dist, interval=self.interval, knot_offsets=self.knot_offsets,
+            knots=self.knots)
+        return sub, keep, cuts
+
+
 def problem_from_arrays(detections, cameras, tck, interval, *, opt_calib=False, undist_points=True,
                         rs=False, rs_bounds=False, motion_reg=False, motion_type='F', motion_weights=1.0):
     """Build a BAProblem from the reference's containers: ``detections[i]`` float64[3,M_i] rows
