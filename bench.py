@@ -13,7 +13,10 @@ per step only the n-vector x crosses PCIe).  BA iterations/s is r
 Workload at N=1: BASELINE.json configs[2] ("synthetic 32 cams x 500k obs, RS on, ~5k spline knots"), the
 configuration the north star quotes its HBM target on; configs[1] (7 cams x 100k) via ``--config 1``.
 For N>1 the observation count grows with N (weak scaling: ~500k observations per GPU; cameras and
-spline knots fixed, so the timeline gets denser) and observations are sharded over the ranks with one RCCL all-reduce per J^T u / dot product.
+spline knots fixed, so the timeline gets denser).  The LM solver shards by TIME: every rank holds the
+detections of one time slice and that slice of the spline blocks, and the ranks sum a few MB per iteration (camera
+blocks + halo, separator system, Schur contributions, step) over RCCL; ``--shard obs`` (always used by ``--solver trf``)
+cuts every camera's detections into N pieces instead, with one all-reduce per J^T u / dot product / normal-equation set.
 
 The JSON line also carries the roofline of the dominant kernel (residual+Jacobian), measured with
 HIP events on the kernel's own stream, and a CPU baseline (the oracle's restatement of the scipy path,
@@ -76,6 +79,7 @@ def main():
     ap.add_argument('--solver', choices=['trf', 'lm'], default=os.environ.get('MVUS_BENCH_SOLVER', 'lm'))
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-parity-solver', action='store_true', help='skip the extra timing of the scipy-TRF+LSMR restatement')
+    ap.add_argument('--shard', choices=['time', 'obs'], default=None, help='N>1: how observations are cut over the ranks (default: time for lm, obs for trf)')
     args = ap.parse_args()
 
     import numpy as np
@@ -112,7 +116,11 @@ def main():
                                                                # cameras and the spline (knots) stay as configured
     scene = synth.make_scene(**kw)
     prob, x0 = mp.problem_from_scene(scene)
-    handle, _ = sharded_handle(prob, rank, world, local_rank) if world > 1 else (ba.BAHandle(prob, device=local_rank), None)
+    shard_mode = args.shard or ('time' if args.solver == 'lm' else 'obs')
+    if world > 1:
+        handle, _ = sharded_handle(prob, rank, world, local_rank, time_x=x0 if shard_mode == 'time' else None)
+    else:
+        handle = ba.BAHandle(prob, device=local_rank)
     solver = ba.SOLVER_LM_SCHUR if args.solver == 'lm' else ba.SOLVER_TRF_LSMR
     jac_mode = ba.JAC_ANALYTIC if args.solver == 'lm' else ba.JAC_PATTERN
 
@@ -190,7 +198,7 @@ def main():
                                       int(prob.n_coef.sum()), prob.n_params, prob.n_residuals,
                                       'LM normal equations + Schur solve' if args.solver == 'lm'
                                       else 'scipy-TRF restatement with LSMR on the block-sparse J (%.0f LSMR its/step)' % (lin_iters / max(args.steps, 1))),
-                       'solver': args.solver, 'parallelism': 'obs-shard x%d' % world,
+                       'solver': args.solver, 'parallelism': '%s-shard x%d' % (shard_mode, world),
                        'cost_first': cost0, 'cost_last': r.cost},
             'roofline': {'bound': 'hbm', 'kernel': 'k_observations<calib=%s,jac=true>' % ('true' if prob.opt_calib else 'false'),
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,

@@ -41,7 +41,7 @@ struct HipBackend {
   // time shard (mvus_ba_set_time_shard): this handle holds the detections of one time slice and owns the control points
   // cuts[rank] .. cuts[rank+1]; the LM/Schur path then keeps the spline blocks of that slice (+- halo) only
   struct TimeShard { bool on = false; int rank = 0, world = 1, halo = 8; std::vector<int> cuts; } tshard;
-  double lm_lambda = 0;   // LM damping carried from one solve on this handle to the next
+  double lm_lambda = 0, lm_nu = 0;   // LM damping and its growth factor, carried from one solve on this handle to the next
   // MVUS_JAC_FD
   int32_t* fd_groups = nullptr;
   int fd_ngroups = 0;
@@ -545,9 +545,9 @@ int mvus_ba_solve(mvus_ba* h, double* x, const mvus_solve_opts* opts, mvus_resul
     if (opts->solver == MVUS_SOLVER_LM_SCHUR) {
       if (be.hp.C * (3 + be.hp.P) > 1152) throw HipError{"LM_SCHUR: reduced camera system larger than 1152 unknowns"};
       if (!h->schur) h->schur.reset(new HipSchur<HipBackend>(be));
-      so.lm_lambda0 = be.lm_lambda;
+      so.lm_lambda0 = be.lm_lambda; so.lm_nu0 = be.lm_nu;
       sr = lm_schur(be, *h->schur, xv, lb, ub, so, be.f_cur);
-      if (!sr.error) be.lm_lambda = std::min(std::max(sr.lm_lambda, 1e-12), 1e6);
+      if (!sr.error) { be.lm_lambda = std::min(std::max(sr.lm_lambda, 1e-12), 1e6); be.lm_nu = std::min(sr.lm_nu, 1024.0); }
     }
     else sr = trf_lsmr(be, xv, lb, ub, so, be.f_cur);
     if (sr.error) { be.err = "residuals are not finite in the initial point, or x0 is outside of the bounds"; return MVUS_E_NUMERIC; }

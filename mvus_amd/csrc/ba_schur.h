@@ -94,7 +94,7 @@ SolveResult lm_schur(B& be, Schur& sc, std::vector<double>& x, const std::vector
     be.dot_m_into(f_new, f_new, S + 6);
   };
 
-  double lambda = opt.lm_lambda0 > 0 ? opt.lm_lambda0 : 1e-4, nu = 2.0;
+  double lambda = opt.lm_lambda0 > 0 ? opt.lm_lambda0 : 1e-4, nu = opt.lm_nu0 > 0 ? opt.lm_nu0 : 2.0;
   double cost = 0;
   bool cost_known = false;
   int status = -1;
@@ -171,6 +171,7 @@ SolveResult lm_schur(B& be, Schur& sc, std::vector<double>& x, const std::vector
   res.cost = cost;
   res.optimality = g_norm;
   res.lm_lambda = lambda;
+  res.lm_nu = nu;
   cleanup();
   return res;
 }

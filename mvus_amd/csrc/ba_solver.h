@@ -45,6 +45,8 @@ struct SolveOptions {
   int lsmr_maxiter = 0;
   int verbose = 0;
   double lm_lambda0 = 0;   // > 0: initial LM damping (a handle carries it over from its previous solve)
+  double lm_nu0 = 0;       // > 0: initial damping growth factor (carried with it, so that a run of one-trial solves
+                           // escalates the damping like one long solve does)
 };
 
 struct SolveResult {
@@ -52,6 +54,7 @@ struct SolveResult {
   int nfev = 0, njev = 0, status = 0, lin_iters = 0;
   int error = 0;  // 0 ok, -3 numeric (non-finite f0 / infeasible x0)
   double lm_lambda = 0;  // final LM damping
+  double lm_nu = 2;      // final growth factor of the damping
 };
 
 namespace detail {
