@@ -145,3 +145,71 @@ def test_motion_sample_times_match_oracle():
     ts, sid = prob.motion_sample_times()
     np.testing.assert_array_equal(ts, traj[0])
     assert prob.num_motion_rows == traj.shape[1]
+
+
+@pytest.mark.parametrize('name', ['rs_F_2int_3cam', 'c1_pinhole_2cam'])
+def test_detection_spans_match_the_jacobian_support(name):
+    """BAProblem.detection_spans (what time shards are cut by) = first control point with a non-zero Jacobian entry in the
+    detection's row, from the host restatement of the device math."""
+    from hostcheck_util import HostHandle
+    from mvus_amd import _lib
+    scene, g = load_case(name)
+    prob, x0 = mp.problem_from_scene(scene)
+    x = g['x0'] + g['delta']
+    f, D = HostHandle(prob).dense_jacobian(x, _lib.JAC_ANALYTIC)
+    spans = prob.detection_spans(x)
+    # x column -> global control point
+    col2ctrl = np.full(prob.n_params, -1)
+    goff = 0
+    for s, n in enumerate(prob.n_coef):
+        for d in range(3):
+            base = int(prob.spline_x_offsets[s]) + d * int(n)
+            col2ctrl[base:base + int(n)] = goff + np.arange(int(n))
+        goff += int(n)
+    row = 0
+    checked = 0
+    for c in range(prob.C):
+        a, b = int(prob.det_offsets[c]), int(prob.det_offsets[c + 1])
+        for i in range(a, b):
+            r = row + (i - a)                      # |ex| row of detection i
+            nz = np.nonzero(D[r])[0]
+            ctrl = col2ctrl[nz]
+            ctrl = ctrl[ctrl >= 0]
+            if ctrl.size == 0:
+                assert spans[i] == -1 or abs(f[r]) == 0.0
+                continue
+            assert spans[i] >= 0 and spans[i] <= ctrl.min() and ctrl.max() <= spans[i] + 3
+            checked += 1
+        row += 2 * (b - a)
+    assert checked > 0.5 * prob.M
+
+
+@pytest.mark.parametrize('world', [2, 3, 8])
+def test_time_shards_cover_every_observation_once(world):
+    from mvus_amd import synth
+    sc = synth.make_scene(4, 8000, seed=43, rolling_shutter=True, num_knots=400)
+    prob, x0 = mp.problem_from_scene(sc)
+    halo = 8
+    cuts = prob.time_cuts(x0, world, halo)
+    assert cuts[0] == 0 and cuts[-1] == int(prob.n_coef.sum()) and np.all(np.diff(cuts) >= 2 * halo + 8)
+    spans = prob.detection_spans(x0)
+    seen = np.zeros(prob.M, dtype=int)
+    sizes = []
+    for r in range(world):
+        shard, keep, cuts_r = prob.shard_time(r, world, x0, halo)
+        assert np.array_equal(cuts_r, cuts)
+        seen[keep] += 1
+        sizes.append(keep.size)
+        vis = spans[keep] >= 0
+        assert np.all((spans[keep][vis] >= cuts[r]) & (spans[keep][vis] < cuts[r + 1]))     # every visible detection in its owner's range
+        assert shard.M == keep.size and shard.n_params == prob.n_params
+        assert np.all(np.diff(shard.det_offsets) >= 0)
+    assert (seen == 1).all()
+    assert max(sizes) < 1.5 * prob.M / world                                                # balanced by detection count
+
+
+def test_time_cuts_refuse_too_few_control_points():
+    scene, g = load_case('c1_pinhole_2cam')
+    prob, x0 = mp.problem_from_scene(scene)
+    with pytest.raises(ValueError):
+        prob.time_cuts(x0, 8, halo=8)
