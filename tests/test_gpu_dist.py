@@ -164,3 +164,55 @@ def test_time_shards_on_one_gpu_match_unsharded(world, motion):
     # the cross block (3N x C(3+P) doubles) is never exchanged: the traffic per linearisation stays far below it
     cross_bytes = 8 * 3 * int(prob.n_coef.sum()) * prob.C * (3 + 6)
     assert nbytes[0] / max(1, ref.njev + ref.nfev) < 40 * cross_bytes        # small scene: separator rhs dominates
+
+
+def test_time_shard_reports_detections_that_leave_its_slice():
+    """Cuts made at x0, solve started from time shifts 60 frames away: rank 0's detections now reach control points its
+    slice does not hold -- the solve must fail loudly (no silent dropping of rows)."""
+    import threading
+    import torch
+    from mvus_amd import synth
+    from mvus_amd.ba import BAHandle
+    from mvus_amd.dist import _DeviceDoubles
+    sc = synth.make_scene(3, 6000, seed=41, rolling_shutter=True, num_knots=300)
+    prob, x0 = mp.problem_from_scene(sc)
+    x_bad = x0.copy()
+    x_bad[prob.C:2 * prob.C] += 60.0
+    opts = _lib.default_opts(_lib.SOLVER_LM_SCHUR, _lib.JAC_ANALYTIC, 3)
+    world = 2
+    barrier = threading.Barrier(world)
+    bufs, total, errors = [None] * world, [None], []
+
+    def make_cb(rank):
+        def cb(ptr, count, stream):
+            t = torch.as_tensor(_DeviceDoubles(ptr, count), device='cuda:0')
+            torch.cuda.synchronize()
+            bufs[rank] = t
+            barrier.wait(30)
+            if rank == 0:
+                total[0] = bufs[0] + bufs[1]
+                torch.cuda.synchronize()
+            barrier.wait(30)
+            t.copy_(total[0])
+            torch.cuda.synchronize()
+            barrier.wait(30)
+        return cb
+
+    def run(rank):
+        try:
+            shard, keep, cuts = prob.shard_time(rank, world, x0)
+            h = BAHandle(shard, device=0)
+            h.set_time_shard(rank, world, cuts)
+            h.set_allreduce(make_cb(rank), is_root=(rank == 0))
+            try:
+                h.solve(x_bad, opts=opts)
+            finally:
+                h.close()
+        except Exception as e:
+            errors.append(str(e))
+            barrier.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in threads]
+    [t.join(120) for t in threads]
+    assert any('outside this rank' in e for e in errors), errors
