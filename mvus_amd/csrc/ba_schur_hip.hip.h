@@ -55,7 +55,7 @@ __device__ __forceinline__ int wave_min_i(int v) {
 // When a large rolling-shutter coefficient reorders the time stamps (spans interleave in index order) the staged
 // columns are first rank-sorted by span in LDS.  Half chunks with more than kGaMaxR ranges (very sparse detections)
 // take the slow path: per-range atomics straight from the registers.
-constexpr int kGaObs = 128, kGaStride = kGaObs + 1, kGaThreads = 512, kGaMaxR = kGaThreads / 6;
+constexpr int kGaObs = 128, kGaStride = kGaObs + 1, kGaThreads = 512, kGaMaxR = kGaThreads / 6, kGaSplit = 8;
 template <int NS>
 __global__ __launch_bounds__(kGaThreads) void k_assemble_spans(DevProblem dp, const double* __restrict__ J, const int32_t* __restrict__ span,
                                                              const double* __restrict__ f, NEView ne) {
@@ -119,13 +119,17 @@ __global__ __launch_bounds__(kGaThreads) void k_assemble_spans(DevProblem dp, co
   // ranges of equal span, in span order (slot = number of range starts before this one, from the wave ballots)
   {
     const int ks = tid < kGaObs ? key[tid] : 0x7fffffff;
-    const bool start = tid < kGaObs && ks != 0x7fffffff && (tid == 0 || key[tid - 1] != ks);
+    // a run of equal span longer than kGaSplit columns (dense timelines: many detections per knot span) is cut into
+    // pieces of kGaSplit so that the outer products below are spread over more threads
+    int back = 0;
+    if (tid < kGaObs && ks != 0x7fffffff) while (back < tid && key[tid - back - 1] == ks) ++back;
+    const bool start = tid < kGaObs && ks != 0x7fffffff && back % kGaSplit == 0;
     const unsigned long long mask = __ballot(start);
     if (tid == 0) nr_s = __popcll(mask);                 // starts in the first wavefront
     __syncthreads();
     if (start) {
       int e = tid + 1;
-      while (e < kGaObs && key[e] == ks) ++e;
+      while (e < kGaObs && key[e] == ks && e - tid < kGaSplit) ++e;
       const int slot = (tid >= 64 ? nr_s : 0) + __popcll(mask & ((1ull << (tid & 63)) - 1ull));
       const int kl = ks - ne.row0;                       // local control point; a time shard must hold all four
       const bool inr = kl >= 0 && kl + 3 < ne.N;
@@ -301,10 +305,7 @@ __global__ __launch_bounds__(kGaThreads) void k_assemble_spans(DevProblem dp, co
       const int ctrl = rg[r0 + rl] + q;
       const bool grad = dk >= 3 * B;
       double acc = 0.0;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int r2 = rl + j;
-        if (r2 >= nb) break;
+      for (int r2 = rl; r2 < nb; ++r2) {                 // every range of the round that reaches the control point
         const int q2 = ctrl - rg[r0 + r2];
         if (q2 < 0) break;
         acc += grad ? Gp[(r2 * 4 + q2) * 3 + dk - 3 * B] : Ep[(r2 * 4 + q2) * 3 * B + dk];
@@ -336,10 +337,7 @@ __global__ __launch_bounds__(kGaThreads) void k_assemble_spans(DevProblem dp, co
       const int qa = 4 - ((int)obase[rl + 1] - (int)obase[rl]) + (i - (int)obase[rl]);
       const int ctrl = rg[r0 + rl] + qa;
       double acc = 0.0;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int r2 = rl + j;
-        if (r2 >= nb) break;
+      for (int r2 = rl; r2 < nb; ++r2) {
         const int q2 = ctrl - rg[r0 + r2];
         if (q2 < 0) break;
         if (q2 + w < 4) acc += Cp[(r2 * 10 + 4 * q2 - q2 * (q2 - 1) / 2 + w) * 9 + dd];
