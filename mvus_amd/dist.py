@@ -24,9 +24,12 @@ def make_gpu_allreduce(device_index, group=None):
     import torch
     import torch.distributed as dist
     stats = {'calls': 0, 'doubles': 0}
+    views = {}                    # the library reduces the same few persistent buffers every iteration: alias them once
 
     def fn(ptr, count, stream):
-        t = torch.as_tensor(_DeviceDoubles(ptr, count), device='cuda:%d' % device_index)
+        t = views.get((ptr, count))
+        if t is None:
+            t = views[(ptr, count)] = torch.as_tensor(_DeviceDoubles(ptr, count), device='cuda:%d' % device_index)
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
         stats['calls'] += 1
         stats['doubles'] += count
