@@ -440,26 +440,27 @@ __global__ __launch_bounds__(kThreads) void k_assemble_motion(DevProblem dp, con
 }
 
 // D = diag(H) in x order (0 -> 1 so that unused columns stay put), and g in x order
-__global__ void k_ne_diag_grad(DevProblem dp, NEView ne, int own_lo, int own_hi, int cams, double* __restrict__ D, double* __restrict__ gx) {
-  // own_lo / own_hi: local control points this slice owns (a time shard leaves its halo to the neighbour);
-  // cams: write the camera entries (one rank only does, before the vectors are summed over the ranks)
+__global__ void k_ne_diag_grad(DevProblem dp, NEView ne, int raw, double* __restrict__ D, double* __restrict__ gx) {
+  // raw (time shards): this rank's PARTIAL diagonal, to be summed over the ranks before k_diag_fix replaces zeros by 1
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx < ne.CB) {
-    if (!cams) return;
     const int c = idx / ne.B, k = idx % ne.B;
     const double h = ne.A[((long long)c * ne.B + k) * ne.B + k];
     const int col = cam_col(dp.C, dp.P, c, k);
-    D[col] = h > 0.0 ? h : 1.0;
+    D[col] = (raw || h > 0.0) ? h : 1.0;
     gx[col] = ne.gc[idx];
   } else if (idx < ne.CB + ne.N3) {
     const int r = idx - ne.CB, g = r / 3, d = r % 3;
-    if (g < own_lo || g >= own_hi) return;
     const double h = ne.Cb[((long long)g * ne.W) * 9 + 4 * d];
     const int gg = g + ne.row0;
     const int col = dp.mv.ctrl_x0[gg] + d * dp.mv.ctrl_stride[gg];
-    D[col] = h > 0.0 ? h : 1.0;
+    D[col] = (raw || h > 0.0) ? h : 1.0;
     gx[col] = ne.gs[r];
   }
+}
+__global__ void k_diag_fix(long long n, double* __restrict__ D) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i < n && !(D[i] > 0.0)) D[i] = 1.0;
 }
 
 // ---- time shards: the blocks of the control points within `halo` of a cut receive rows from both neighbours --------
@@ -1625,9 +1626,11 @@ struct HipSchur {
     halo_count = shard ? (size_t)(ts.world - 1) * 2 * ts.halo * (3 * ne.CB + W * 9 + 3) : 0;
     const size_t nA = (size_t)ne.C * ne.B * ne.B, ngc = ne.CB, nCb = (size_t)ne.N * W * 9, ngs = ne.N3, nEt = (size_t)ne.N3 * ne.CB;
     nAg = nA + ngc;
-    ne_count = nA + ngc + halo_count + nCb + ngs + nEt;
+    // time shards: diag(H) and g ride in the summed head too ([A | gc | halo | D | g])
+    const size_t ndg = shard ? 2 * (size_t)hp.n : 0;
+    ne_count = nA + ngc + halo_count + ndg + nCb + ngs + nEt;
     NE = be.alloc(ne_count);
-    ne.A = NE; ne.gc = ne.A + nA; ne.Cb = ne.gc + ngc + halo_count; ne.gs = ne.Cb + nCb; ne.Et = ne.gs + ngs;
+    ne.A = NE; ne.gc = ne.A + nA; ne.Cb = ne.gc + ngc + halo_count + ndg; ne.gs = ne.Cb + nCb; ne.Et = ne.gs + ngs;
     Lb = be.alloc((size_t)ne.N3 * (BW + 1));
     Z = be.alloc((size_t)ne.N3 * ncols);
     Erm = be.alloc((size_t)ne.N3 * ne.CB);
@@ -1638,7 +1641,8 @@ struct HipSchur {
     rhs = be.alloc(ne.CB); pc = be.alloc(ne.CB);
     Lf = be.alloc((size_t)(ne.CB + 1) * ne.CB);
     Linv = be.alloc((size_t)((ne.CB + kNB - 1) / kNB) * kNB * kNB);
-    DG = be.alloc(2 * (size_t)hp.n); D = DG; gx = DG + hp.n;      // contiguous: one sum over the ranks
+    if (shard) { DG = nullptr; D = NE + nAg + halo_count; gx = D + hp.n; }
+    else { DG = be.alloc(2 * (size_t)hp.n); D = DG; gx = DG + hp.n; }
     px = be.alloc(hp.n);
     MVUS_HIP(hipMalloc(reinterpret_cast<void**>(&fail), 2 * sizeof(int)));
     MVUS_HIP(hipMemsetAsync(fail, 0, 2 * sizeof(int), be.stream));
@@ -1702,7 +1706,7 @@ struct HipSchur {
     use_bcr = bcr_lds <= 64 * 1024 && !std::getenv("MVUS_SEP_SEQUENTIAL");
   }
   ~HipSchur() {
-    for (double* p : {Erm, NE, Lb, Z, G, G0, S, Lf, Linv, rhs, pc, DG, px, pv.VW, sepbuf, pv.U2, pv.Ha, pv.Hc}) be.release(p);
+    for (double* p : {Erm, NE, Lb, Z, G, G0, S, Lf, Linv, rhs, pc, DG, px, pv.VW, sepbuf, pv.U2, pv.Ha, pv.Hc}) if (p) be.release(p);
     if (part_tables) (void)hipFree(part_tables);
     if (halo_tables) (void)hipFree(halo_tables);
     if (fail) (void)hipFree(fail);
@@ -1726,17 +1730,18 @@ struct HipSchur {
     const int tot = ne.CB + ne.N3;          // every entry of x is a camera column or a control-point coordinate
     if (shard) {
       // time shard: sum the camera blocks and the blocks of the control points near a cut; the cross block never moves
+      // ... and diag(H), g in x order: every rank adds its PARTIAL sums (rows of a control point near a cut sit on two
+      // ranks), so they go into the same all-reduce, before the halo blocks are completed
       double* hb = NE + nAg;
       const int halo = be.tshard.halo;
       if (nbound > 0) hipLaunchKernelGGL(k_halo_copy, dim3(256), dim3(256), 0, be.stream, ne, halo, nbound, halo_tables, halo_tables + nbound, Ntot, hb, 0);
-      be.reduce(NE, nAg + halo_count);
+      hipLaunchKernelGGL(k_ne_diag_grad, dim3((tot + 255) / 256), dim3(256), 0, be.stream, be.dp, ne, 1, D, gx);
+      be.reduce(NE, nAg + halo_count + 2 * (size_t)be.hp.n);
       if (nbound > 0) hipLaunchKernelGGL(k_halo_copy, dim3(256), dim3(256), 0, be.stream, ne, halo, nbound, halo_tables, halo_tables + nbound, Ntot, hb, 1);
-      MVUS_HIP(hipMemsetAsync(DG, 0, 2 * be.hp.n * sizeof(double), be.stream));
-      hipLaunchKernelGGL(k_ne_diag_grad, dim3((tot + 255) / 256), dim3(256), 0, be.stream, be.dp, ne, own_lo, own_hi, (int)(be.tshard.rank == 0), D, gx);
-      be.reduce(DG, 2 * (size_t)be.hp.n);
+      hipLaunchKernelGGL(k_diag_fix, dim3((unsigned)((be.hp.n + 255) / 256)), dim3(256), 0, be.stream, (long long)be.hp.n, D);
     } else {
       be.reduce(NE, ne_count);          // observation shards: one sum-all-reduce of the packed normal-equation blocks per iteration
-      hipLaunchKernelGGL(k_ne_diag_grad, dim3((tot + 255) / 256), dim3(256), 0, be.stream, be.dp, ne, 0, ne.N, 1, D, gx);
+      hipLaunchKernelGGL(k_ne_diag_grad, dim3((tot + 255) / 256), dim3(256), 0, be.stream, be.dp, ne, 0, D, gx);
     }
     MVUS_HIP(hipGetLastError());
   }
