@@ -169,14 +169,9 @@ class BAProblem:
         keep, new_off = [], [0]
         for c in range(self.C):
             a, b = int(self.det_offsets[c]), int(self.det_offsets[c + 1])
-            gc = g[a:b].copy()
-            last = -1
-            for i in range(gc.size):                     # forward fill the invisible ones
-                if gc[i] < 0:
-                    gc[i] = last
-                else:
-                    last = gc[i]
-            gc[gc < 0] = 0
+            gc = g[a:b]
+            src = np.maximum.accumulate(np.where(gc >= 0, np.arange(gc.size), -1))     # forward fill the invisible ones
+            gc = np.where(src >= 0, gc[np.maximum(src, 0)], 0)
             owner = np.searchsorted(cuts[1:-1], gc, side='right')
             idx = a + np.nonzero(owner == rank)[0]
             keep.append(idx)
