@@ -1064,11 +1064,11 @@ __global__ __launch_bounds__(kBcrWaves * 64) void k_sep_bcr_factor(PartView pv, 
   }
 }
 
-constexpr int kBcrCols = 2;
-template <int S3>
+constexpr int kBcrCols = 2;       // columns per workgroup; 1 for chains whose two columns do not fit the LDS
+template <int S3, int TC>
 __global__ __launch_bounds__(256) void k_sep_bcr_rhs(PartView pv, int ncols) {
   double* __restrict__ Rr = pv.R;
-  constexpr int SS = S3 * S3, TC = kBcrCols;
+  constexpr int SS = S3 * S3;
   extern __shared__ double bcr_lds[];
   const int m = pv.m, tid = threadIdx.x;
   double* rs = bcr_lds;                       // [m][S3][TC]
@@ -1582,6 +1582,7 @@ struct HipSchur {
   PartView pv{};
   int* part_tables = nullptr;
   int nslab = 1;            // K-slabs of the Schur product (partial sums in G)
+  int bcr_cols = kBcrCols;
   size_t bcr_lds = 0;       // dynamic LDS of k_sep_bcr_rhs; the sequential separator kernels remain for chains too long for it
   bool use_bcr = false;
   // slice of the spline system held by this handle (everything unless it is a time shard)
@@ -1702,7 +1703,9 @@ struct HipSchur {
     pv.U2 = be.alloc(mm * ss);
     pv.Ha = be.alloc(mm * ss);
     pv.Hc = be.alloc(mm * ss);
-    bcr_lds = (size_t)2 * mm * pv.s3 * kBcrCols * sizeof(double);
+    bcr_cols = kBcrCols;
+    bcr_lds = (size_t)2 * mm * pv.s3 * bcr_cols * sizeof(double);
+    if (bcr_lds > 64 * 1024) { bcr_cols = 1; bcr_lds /= kBcrCols; }
     use_bcr = bcr_lds <= 64 * 1024 && !std::getenv("MVUS_SEP_SEQUENTIAL");
   }
   ~HipSchur() {
@@ -1767,7 +1770,8 @@ struct HipSchur {
       if (shard) be.reduce(sepbuf, sep_count);        // every rank now holds the whole separator system
       if (use_bcr) {
         hipLaunchKernelGGL(k_sep_bcr_factor<S3T>, dim3(1), dim3(kBcrWaves * 64), 0, be.stream, pv, fail);
-        hipLaunchKernelGGL(k_sep_bcr_rhs<S3T>, dim3((ncols + kBcrCols - 1) / kBcrCols), dim3(256), bcr_lds, be.stream, pv, ncols);
+        if (bcr_cols == kBcrCols) hipLaunchKernelGGL((k_sep_bcr_rhs<S3T, kBcrCols>), dim3((ncols + kBcrCols - 1) / kBcrCols), dim3(256), bcr_lds, be.stream, pv, ncols);
+        else hipLaunchKernelGGL((k_sep_bcr_rhs<S3T, 1>), dim3(ncols), dim3(256), bcr_lds, be.stream, pv, ncols);
       } else {
         hipLaunchKernelGGL(k_sep_factor<S3T>, dim3(1), dim3(64), 0, be.stream, pv, fail);
         hipLaunchKernelGGL(k_sep_rhs<S3T>, dim3((ncols + 63) / 64), dim3(64), 0, be.stream, pv, ncols);
