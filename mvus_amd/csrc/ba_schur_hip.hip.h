@@ -1329,15 +1329,19 @@ __global__ void k_schur_finish(NEView ne, int ncols, int nslab, double lambda, c
   }
 }
 
-// Dense Cholesky + solve of the reduced camera system (nn <= 1152), blocked with panels of kNB columns, ONE launch
-// per panel.  The right-hand side rides along as row nn of the (nn+1) x nn array `Sa` (Sa[nn][:] = rhs), so the panel
-// step also performs the forward substitution.  The inverse of every diagonal block's factor is kept (Linv), which
-// turns the panel's triangular solve into a small matrix product, P = A_panel L11^-T, free of sequential dependence:
-//   k_chol_step(kb): every 32x32 tile (I >= J) of the trailing matrix recomputes P_I and P_J from the raw panel
-//   entries, subtracts P_I P_J^T, and the first tile column stores P_I as the final factor (into `Lf`, so that the
-//   raw panel stays readable for the other tiles).  The workgroup of tile (0,0) then holds the next diagonal block:
-//   its first wavefront factorises it in registers (row per lane, pivot column broadcast with v_readlane) and
-//   inverts the factor.  The critical path per panel is that one wavefront: ~32 dependent column steps.
+// Dense solve of the reduced camera system S x = b (nn <= 1152, SPD) by BLOCK GAUSS-JORDAN, 32-column panels, ONE
+// launch per panel and no back substitution.  The right-hand side rides along as row nn of the (nn+1) x nn array
+// (row-major, both triangles of S filled).  In column-operation form, with P_k the inverse of the current pivot block:
+//     every row block I below the panel (the rhs row included), every column block J != k:
+//         Q_I = M[I][k] P_k ;   M[I][J] -= Q_I M[k][J] ;   M[I][k] <- Q_I
+// After the last panel the rhs row holds x.  Rows above the panel are never touched again, the trailing block stays the
+// (symmetric positive definite) Schur complement, so P_k = L^-T L^-1 comes from a Cholesky of the 32x32 pivot block done
+// in registers by ONE wavefront of the workgroup that produced that block (row per lane, pivot column by v_readlane,
+// 1/sqrt(pivot) by v_rsq_f64 + 2 Newton steps; lanes 32..63 carry the identity and end up holding L^-T).  Each step
+// reads `src` and writes `dst` (ping-pong), so all tiles of a step are independent.  Against a blocked Cholesky this
+// trades ~3x the (tiny, perfectly parallel) tile flops for the removal of the sequential back substitution (44 us at
+// nn = 288: nine dependent round trips to data other XCDs wrote).  The critical path per panel is the one wavefront:
+// ~32 dependent column steps.
 constexpr int kNB = 32;
 
 __device__ __forceinline__ double bcast_lane(double v, int src) {
@@ -1346,13 +1350,9 @@ __device__ __forceinline__ double bcast_lane(double v, int src) {
   return __hiloint2double(hi, lo);
 }
 
-// first wavefront of the workgroup: Cholesky of the block in Dm (lower part valid, identity padded beyond nbk),
-// factor -> Lf[(row0+r)*nn + row0+c], inverse factor -> Li[r*kNB+c].  Lanes 0..31 hold one row of the block each;
-// lanes 32..63 hold the rows of the identity, treated as rows BELOW the block: the column operations that turn the
-// block into L turn them into L^-T, so the inverse costs no extra instruction.  1/sqrt(pivot) comes from v_rsq_f64
-// refined by two Newton steps (the pivot chain is the critical path of the whole dense factorisation).
-__device__ __forceinline__ void potrf_inv_wave(double (*Dm)[kNB + 1], int nbk, int nn, int row0,
-                                               double* __restrict__ Lf, double* __restrict__ Li, int* __restrict__ fail) {
+// first wavefront of the workgroup: Cholesky of the block in Dm (lower part valid, identity padded beyond the block),
+// inverse factor L^-1 -> Li[r*kNB+c].
+__device__ __forceinline__ void potrf_inv_wave(double (*Dm)[kNB + 1], double* __restrict__ Li, int* __restrict__ fail) {
   const int lane = threadIdx.x & 63;
   const int row = lane & (kNB - 1);
   double a[kNB];
@@ -1369,18 +1369,13 @@ __device__ __forceinline__ void potrf_inv_wave(double (*Dm)[kNB + 1], int nbk, i
 #pragma unroll
     for (int j = k + 1; j < kNB; ++j) a[j] -= a[k] * bcast_lane(a[k], j);
   }
-  if (lane < kNB) {
-#pragma unroll
-    for (int k = 0; k < kNB; ++k)
-      if (row < nbk && k <= row) Lf[(long long)(row0 + row) * nn + row0 + k] = a[k];
-  } else {
+  if (lane >= kNB) {
 #pragma unroll
     for (int k = 0; k < kNB; ++k) Li[k * kNB + row] = k >= row ? a[k] : 0.0;      // lane 32+c holds row c of L^-T
   }
 }
 
-__global__ __launch_bounds__(64) void k_chol_first(int nn, const double* __restrict__ Sa, double* __restrict__ Lf, double* __restrict__ Linv,
-                                                   int* __restrict__ fail) {
+__global__ __launch_bounds__(64) void k_gj_first(int nn, const double* __restrict__ Sa, double* __restrict__ Linv, int* __restrict__ fail) {
   __shared__ double Dm[kNB][kNB + 1];
   const int nb = min(kNB, nn);
   for (int e = threadIdx.x; e < kNB * kNB; e += 64) {
@@ -1388,141 +1383,56 @@ __global__ __launch_bounds__(64) void k_chol_first(int nn, const double* __restr
     Dm[r][c] = (r < nb && c < nb) ? Sa[(long long)r * nn + c] : (r == c ? 1.0 : 0.0);
   }
   __syncthreads();
-  potrf_inv_wave(Dm, nb, nn, 0, Lf, Linv, fail);
+  potrf_inv_wave(Dm, Linv, fail);
 }
 
-__global__ __launch_bounds__(1024) void k_chol_step(int nn, int kb, double* __restrict__ Sa, double* __restrict__ Lf, double* __restrict__ Linv,
-                                                    int* __restrict__ fail) {
-  const int ti = blockIdx.x, tj = blockIdx.y;
-  if (tj > ti) return;
-  __shared__ double Ai[kNB][kNB + 1], Aj[kNB][kNB + 1], Li[kNB][kNB + 1], Pi[kNB][kNB + 1], Pj[kNB][kNB + 1];
+// one panel step; grid (row tiles below the panel incl. the rhs row, all column tiles); pc != nullptr on the last step
+__global__ __launch_bounds__(1024) void k_gj_step(int nn, int kb, const double* __restrict__ src, double* __restrict__ dst,
+                                                  double* __restrict__ Linv, int* __restrict__ fail, double* __restrict__ pc) {
+  __shared__ double Ai[kNB][kNB + 1], Li[kNB][kNB + 1], Pk[kNB][kNB + 1], Q[kNB][kNB + 1], Bk[kNB][kNB + 1];
   const int nb = min(kNB, nn - kb), base = kb + nb;
-  const int i0 = base + ti * kNB, j0 = base + tj * kNB;
+  const int i0 = base + blockIdx.x * kNB, j0 = blockIdx.y * kNB;
+  const bool pivcol = j0 == kb;                              // this tile is column block k: it stores Q_I
   const int r = threadIdx.x / kNB, c = threadIdx.x % kNB;
-  Ai[r][c] = (i0 + r <= nn && c < nb) ? Sa[(long long)(i0 + r) * nn + kb + c] : 0.0;
-  Aj[r][c] = (j0 + r < nn && c < nb) ? Sa[(long long)(j0 + r) * nn + kb + c] : 0.0;
-  Li[r][c] = Linv[(long long)(kb / kNB) * kNB * kNB + threadIdx.x];
   const int i = i0 + r, j = j0 + c;
-  const bool valid = i <= nn && j < nn && j <= i;
-  double v = valid ? Sa[(long long)i * nn + j] : 0.0;
+  Ai[r][c] = (i <= nn && c < nb) ? src[(long long)i * nn + kb + c] : 0.0;
+  Li[r][c] = Linv[(long long)(kb / kNB) * kNB * kNB + threadIdx.x];
+  Bk[r][c] = (r < nb && j < nn) ? src[(long long)(kb + r) * nn + j] : 0.0;
+  const bool valid = i <= nn && j < nn;
+  double v = (valid && !pivcol) ? src[(long long)i * nn + j] : 0.0;
+  __syncthreads();
+  {                                                          // P_k = L^-T L^-1 (L^-1 lower triangular, identity padded)
+    double acc = 0.0;
+#pragma unroll
+    for (int m = 0; m < kNB; ++m) acc += Li[m][r] * Li[m][c];
+    Pk[r][c] = acc;
+  }
   __syncthreads();
   {
-    double pi = 0.0, pj = 0.0;
+    double acc = 0.0;
 #pragma unroll
-    for (int k = 0; k < kNB; ++k) { const double l = Li[c][k]; pi += Ai[r][k] * l; pj += Aj[r][k] * l; }
-    Pi[r][c] = pi; Pj[r][c] = pj;
-    if (tj == 0 && i <= nn && c < nb) Lf[(long long)i * nn + kb + c] = pi;
+    for (int m = 0; m < kNB; ++m) acc += Ai[r][m] * Pk[m][c];
+    Q[r][c] = acc;
   }
   __syncthreads();
-  double acc = 0.0;
+  if (pivcol) v = Q[r][c];
+  else {
+    double acc = 0.0;
 #pragma unroll
-  for (int k = 0; k < kNB; ++k) acc += Pi[r][k] * Pj[c][k];
-  v -= acc;
-  if (ti != 0 || tj != 0) { if (valid) Sa[(long long)i * nn + j] = v; return; }
-  // tile (0,0): rows/cols base .. base+31 = the next diagonal block (nb2 of them real; a row nn inside the tile is the rhs)
+    for (int m = 0; m < kNB; ++m) acc += Q[r][m] * Bk[m][c];
+    v -= acc;
+  }
+  if (valid && (!pivcol || c < nb)) {
+    dst[(long long)i * nn + j] = v;
+    if (pc && i == nn) pc[j] = -v;                           // last panel: the rhs row is the solution
+  }
+  // the tile holding the next pivot block factorises it
   const int nb2 = min(kNB, nn - base);
-  if (nb2 <= 0) return;
-  if (valid && r >= nb2) Sa[(long long)i * nn + j] = v;
-  __syncthreads();                                     // Ai is reused as the block to factorise
-  Ai[r][c] = (r < nb2 && c < nb2) ? v : (r == c ? 1.0 : 0.0);
+  if (blockIdx.x != 0 || j0 != base || nb2 <= 0) return;
+  __syncthreads();                                           // Ai is reused as the block to factorise
+  Ai[r][c] = (r < nb2 && c < nb2 && c <= r) ? v : ((r < nb2 && c < nb2) ? 0.0 : (r == c ? 1.0 : 0.0));
   __syncthreads();
-  if (threadIdx.x < 64) potrf_inv_wave(Ai, nb2, nn, base, Lf, Linv + (long long)(base / kNB) * kNB * kNB, fail);
-}
-
-// backward substitution L^T x = y by one workgroup, panel by panel from the last: x_k = Linv_k^T (y_k - sum_{j>k} L_jk^T x_j);
-// y = row nn of Lf.  Writes pc = -x (the camera part of the LM step).
-constexpr int kBsThreads = 512;    // 2 x 32 prefetched doubles per thread must stay in registers (256 VGPRs at 8 waves per CU)
-__global__ __launch_bounds__(kBsThreads) void k_chol_backsub(int nn, const double* __restrict__ Lf, const double* __restrict__ Linv, double* __restrict__ pc) {
-  __shared__ double y[1152];
-  __shared__ double Ls[2][kNB][kNB + 1];
-  __shared__ double xk[kNB];
-  const int tid = threadIdx.x;
-  for (int i = tid; i < nn; i += kBsThreads) y[i] = Lf[(long long)nn * nn + i];
-  // the factor rows and inverse block a panel needs do not depend on the solution: they are fetched one panel ahead,
-  // so the dependent part of every step only touches LDS
-  double lv[kNB], ln[kNB];
-  const int kb_last = ((nn - 1) / kNB) * kNB;
-  double li[kNB * kNB / kBsThreads], lin[kNB * kNB / kBsThreads];     // this thread's entries of the inverse diagonal block
-  auto fetch = [&](int kb, double* dst, double* ldst) {
-    const int nb = min(kNB, nn - kb);
-#pragma unroll
-    for (int cc = 0; cc < kNB; ++cc) dst[cc] = (kb >= 0 && tid < kb && cc < nb) ? Lf[(long long)(kb + cc) * nn + tid] : 0.0;
-#pragma unroll
-    for (int e = 0; e < kNB * kNB / kBsThreads; ++e) ldst[e] = kb >= 0 ? Linv[(long long)(kb / kNB) * kNB * kNB + tid + e * kBsThreads] : 0.0;
-  };
-  fetch(kb_last, ln, lin);
-  int buf = 0;
-  for (int kb = kb_last; kb >= 0; kb -= kNB, buf ^= 1) {
-    const int nb = min(kNB, nn - kb);
-#pragma unroll
-    for (int cc = 0; cc < kNB; ++cc) lv[cc] = ln[cc];
-#pragma unroll
-    for (int e = 0; e < kNB * kNB / kBsThreads; ++e) { li[e] = lin[e]; const int q = tid + e * kBsThreads; Ls[buf][q / kNB][q % kNB] = li[e]; }
-    fetch(kb - kNB, ln, lin);                            // next panel's loads stay in flight across this step
-    lds_barrier();
-    if (tid < kNB) {
-      double acc = 0.0;
-#pragma unroll
-      for (int rr = 0; rr < kNB; ++rr) acc += (rr < nb && tid < nb) ? Ls[buf][rr][tid] * y[kb + rr] : 0.0;      // Linv is lower triangular
-      xk[tid] = acc;
-      if (tid < nb) pc[kb + tid] = -acc;
-    }
-    lds_barrier();
-    if (tid < kb) {
-      double vv = y[tid];
-#pragma unroll
-      for (int cc = 0; cc < kNB; ++cc) vv -= lv[cc] * xk[cc];
-      y[tid] = vv;
-    }
-    for (int i2 = tid + kBsThreads; i2 < kb; i2 += kBsThreads) {
-      double vv = y[i2];
-      for (int cc = 0; cc < nb; ++cc) vv -= Lf[(long long)(kb + cc) * nn + i2] * xk[cc];
-      y[i2] = vv;
-    }
-  }
-}
-
-// The same back substitution for nn <= kBrPanels * kNB with every operand fetched ONCE, up front, into registers (the
-// factor was just written by workgroups on other XCDs, so each dependent round trip to it costs ~3 us -- nine of them
-// in a row in the streaming version above).  1024 threads; lane c = t % 32, group g = t / 32:
-//   - thread holds L[kb + c][g + 32 m] for every panel kb = 32 P and m < P  (P (P-1) / 2 + m, <= 45 values), and the
-//     entry Linv_P[c][g] of every inverse diagonal block;
-//   - step P: x_P[g] = sum_c Linv_P[c][g] t[c]  (32-lane shuffle reduction), then y[g + 32 m] -= sum_c L[..] x_P[c].
-constexpr int kBrPanels = 10;
-__global__ __launch_bounds__(1024) void k_chol_backsub_regs(int nn, const double* __restrict__ Lf, const double* __restrict__ Linv, double* __restrict__ pc) {
-  __shared__ double y[kBrPanels * kNB];
-  __shared__ double xk[kNB];
-  const int tid = threadIdx.x, c = tid & 31, g = tid >> 5;
-  const int np = (nn + kNB - 1) / kNB;
-  double Lr[kBrPanels * (kBrPanels - 1) / 2], Li[kBrPanels];
-#pragma unroll
-  for (int P = 0; P < kBrPanels; ++P) {
-    const int row = P * kNB + c;
-    Li[P] = P < np ? Linv[(long long)P * kNB * kNB + c * kNB + g] : 0.0;
-#pragma unroll
-    for (int m = 0; m < P; ++m) Lr[P * (P - 1) / 2 + m] = (P < np && row < nn) ? Lf[(long long)row * nn + g + kNB * m] : 0.0;
-  }
-  if (tid < kBrPanels * kNB) y[tid] = tid < nn ? Lf[(long long)nn * nn + tid] : 0.0;
-  __syncthreads();
-#pragma unroll
-  for (int P = kBrPanels - 1; P >= 0; --P) {
-    if (P >= np) continue;                                 // uniform
-    // x_P[g] = sum_c Linv_P[c][g] * y[32 P + c]
-    double v = Li[P] * y[P * kNB + c];
-#pragma unroll
-    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    if (c == 0) { xk[g] = v; if (P * kNB + g < nn) pc[P * kNB + g] = -v; }
-    lds_barrier();
-    const double xc = xk[c];
-#pragma unroll
-    for (int m = 0; m < P; ++m) {
-      double w = Lr[P * (P - 1) / 2 + m] * xc;
-#pragma unroll
-      for (int off = 16; off > 0; off >>= 1) w += __shfl_xor(w, off, 64);
-      if (c == 0) y[g + kNB * m] -= w;
-    }
-    lds_barrier();
-  }
+  if (threadIdx.x < 64) potrf_inv_wave(Ai, Linv + (long long)(base / kNB) * kNB * kNB, fail);
 }
 
 // p (x order) from p_c and p_s = -(z_g + Z_E p_c)
@@ -1575,7 +1485,7 @@ struct HipSchur {
   int ncols = 0, BW = 0;
   size_t ne_count = 0;
   double *Erm = nullptr;
-  double *NE = nullptr, *Lb = nullptr, *Z = nullptr, *G = nullptr, *G0 = nullptr, *S = nullptr, *Lf = nullptr, *Linv = nullptr, *rhs = nullptr, *pc = nullptr,
+  double *NE = nullptr, *Lb = nullptr, *Z = nullptr, *G = nullptr, *G0 = nullptr, *S = nullptr, *S2 = nullptr, *Linv = nullptr, *rhs = nullptr, *pc = nullptr,
          *DG = nullptr, *D = nullptr, *gx = nullptr, *px = nullptr, *sepbuf = nullptr;
   int* fail = nullptr;      // [0] numerical failure of a solve, [1] a row reached outside the slice (assembly)
   int* fail_host = nullptr;
@@ -1640,7 +1550,7 @@ struct HipSchur {
     G0 = be.alloc((size_t)ne.CB * ncols);
     S = be.alloc((size_t)(ne.CB + 1) * ne.CB);
     rhs = be.alloc(ne.CB); pc = be.alloc(ne.CB);
-    Lf = be.alloc((size_t)(ne.CB + 1) * ne.CB);
+    S2 = be.alloc((size_t)(ne.CB + 1) * ne.CB);
     Linv = be.alloc((size_t)((ne.CB + kNB - 1) / kNB) * kNB * kNB);
     if (shard) { DG = nullptr; D = NE + nAg + halo_count; gx = D + hp.n; }
     else { DG = be.alloc(2 * (size_t)hp.n); D = DG; gx = DG + hp.n; }
@@ -1709,7 +1619,7 @@ struct HipSchur {
     use_bcr = bcr_lds <= 64 * 1024 && !std::getenv("MVUS_SEP_SEQUENTIAL");
   }
   ~HipSchur() {
-    for (double* p : {Erm, NE, Lb, Z, G, G0, S, Lf, Linv, rhs, pc, DG, px, pv.VW, sepbuf, pv.U2, pv.Ha, pv.Hc}) if (p) be.release(p);
+    for (double* p : {Erm, NE, Lb, Z, G, G0, S, S2, Linv, rhs, pc, DG, px, pv.VW, sepbuf, pv.U2, pv.Ha, pv.Hc}) if (p) be.release(p);
     if (part_tables) (void)hipFree(part_tables);
     if (halo_tables) (void)hipFree(halo_tables);
     if (fail) (void)hipFree(fail);
@@ -1803,14 +1713,16 @@ struct HipSchur {
     }
     {
       const int nn = ne.CB;
-      hipLaunchKernelGGL(k_chol_first, dim3(1), dim3(64), 0, be.stream, nn, S, Lf, Linv, fail);
+      hipLaunchKernelGGL(k_gj_first, dim3(1), dim3(64), 0, be.stream, nn, S, Linv, fail);
+      double* a = S;
+      double* b = S2;
       for (int kb = 0; kb < nn; kb += kNB) {
         const int nb = std::min(kNB, nn - kb), below = nn + 1 - (kb + nb);       // rows under the panel incl. the rhs row
-        const int tiles = (below + kNB - 1) / kNB;
-        hipLaunchKernelGGL(k_chol_step, dim3(tiles, tiles), dim3(kNB * kNB), 0, be.stream, nn, kb, S, Lf, Linv, fail);
+        const bool last = kb + nb >= nn;
+        hipLaunchKernelGGL(k_gj_step, dim3((below + kNB - 1) / kNB, (nn + kNB - 1) / kNB), dim3(kNB * kNB), 0, be.stream, nn, kb, a, b, Linv, fail,
+                           last ? pc : (double*)nullptr);
+        std::swap(a, b);
       }
-      if (nn <= kBrPanels * kNB) hipLaunchKernelGGL(k_chol_backsub_regs, dim3(1), dim3(1024), 0, be.stream, nn, Lf, Linv, pc);
-      else hipLaunchKernelGGL(k_chol_backsub, dim3(1), dim3(kBsThreads), 0, be.stream, nn, Lf, Linv, pc);
     }
     if (shard) MVUS_HIP(hipMemsetAsync(px, 0, be.hp.n * sizeof(double), be.stream));
     const int nrows = row_hi - row_lo, per = kThreads / 64;
