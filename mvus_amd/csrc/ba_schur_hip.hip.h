@@ -1305,28 +1305,40 @@ __global__ __launch_bounds__(256) void k_schur_gemm(NEView ne, int ncols, int ro
 }
 
 // S = (A + lambda D_c) - sum_slabs Gp[:, :CB] (dense CB x CB, both triangles from the computed lower block triangle),
-// rhs = gc - sum_slabs Gp[:, CB]
-__global__ void k_schur_finish(NEView ne, int ncols, int nslab, double lambda, const double* __restrict__ Gp, double* __restrict__ S, double* __restrict__ rhs) {
-  const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-  if (idx >= (long long)ne.CB * ne.CB) return;
-  const int a = (int)(idx / ne.CB), b = (int)(idx % ne.CB);
-  const int hi = a / kGemmT >= b / kGemmT ? a : b, lo = a / kGemmT >= b / kGemmT ? b : a;
+// rhs = gc - sum_slabs Gp[:, CB], in 32x32 tiles; the workgroup of tile (0,0) goes on to factorise the first pivot block of
+// the Gauss-Jordan solve below (k_gj_pivot), saving a launch.
+constexpr int kNB = 32;
+__device__ __forceinline__ void potrf_inv_wave(double (*Dm)[kNB + 1], double* __restrict__ Li, int* __restrict__ fail);
+__global__ __launch_bounds__(kNB * kNB) void k_schur_finish(NEView ne, int ncols, int nslab, double lambda, const double* __restrict__ Gp, double* __restrict__ S,
+                                                            double* __restrict__ Linv, int* __restrict__ fail) {
+  __shared__ double Dm[kNB][kNB + 1];
+  const int r = threadIdx.x / kNB, c = threadIdx.x % kNB;
+  const int a = blockIdx.y * kNB + r, b = blockIdx.x * kNB + c;
   const long long stride = (long long)ne.CB * ncols;
-  double g = 0.0;
-  for (int sl = 0; sl < nslab; ++sl) g += Gp[sl * stride + (long long)hi * ncols + lo];
-  double v = -g;
-  if (a / ne.B == b / ne.B) {
-    const int c = a / ne.B;
-    double h = ne.A[((long long)c * ne.B + a % ne.B) * ne.B + b % ne.B];
-    if (a == b) h += lambda * (h > 0.0 ? h : 1.0);
-    v += h;
+  double v = 0.0;
+  if (a < ne.CB && b < ne.CB) {
+    const int hi = a / kGemmT >= b / kGemmT ? a : b, lo = a / kGemmT >= b / kGemmT ? b : a;
+    double g = 0.0;
+    for (int sl = 0; sl < nslab; ++sl) g += Gp[sl * stride + (long long)hi * ncols + lo];
+    v = -g;
+    if (a / ne.B == b / ne.B) {
+      const int cam = a / ne.B;
+      double h = ne.A[((long long)cam * ne.B + a % ne.B) * ne.B + b % ne.B];
+      if (a == b) h += lambda * (h > 0.0 ? h : 1.0);
+      v += h;
+    }
+    S[(long long)a * ne.CB + b] = v;
   }
-  S[idx] = v;
-  if (b == 0) {
+  if (blockIdx.y == 0 && r == 0 && b < ne.CB) {               // rhs rides as row CB
     double gr = 0.0;
-    for (int sl = 0; sl < nslab; ++sl) gr += Gp[sl * stride + (long long)a * ncols + ne.CB];
-    S[(long long)ne.CB * ne.CB + a] = ne.gc[a] - gr;   // rhs rides as row CB
+    for (int sl = 0; sl < nslab; ++sl) gr += Gp[sl * stride + (long long)b * ncols + ne.CB];
+    S[(long long)ne.CB * ne.CB + b] = ne.gc[b] - gr;
   }
+  if (blockIdx.x != 0 || blockIdx.y != 0) return;
+  const int nb = min(kNB, ne.CB);
+  Dm[r][c] = (r < nb && c < nb && c <= r) ? v : ((r < nb && c < nb) ? 0.0 : (r == c ? 1.0 : 0.0));
+  __syncthreads();
+  if (threadIdx.x < 64) potrf_inv_wave(Dm, Linv, fail);
 }
 
 // Dense solve of the reduced camera system S x = b (nn <= 1152, SPD) by BLOCK GAUSS-JORDAN, 32-column panels, ONE
@@ -1342,7 +1354,6 @@ __global__ void k_schur_finish(NEView ne, int ncols, int nslab, double lambda, c
 // trades ~3x the (tiny, perfectly parallel) tile flops for the removal of the sequential back substitution (44 us at
 // nn = 288: nine dependent round trips to data other XCDs wrote).  The critical path per panel is the one wavefront:
 // ~32 dependent column steps.
-constexpr int kNB = 32;
 
 __device__ __forceinline__ double bcast_lane(double v, int src) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
@@ -1373,17 +1384,6 @@ __device__ __forceinline__ void potrf_inv_wave(double (*Dm)[kNB + 1], double* __
 #pragma unroll
     for (int k = 0; k < kNB; ++k) Li[k * kNB + row] = k >= row ? a[k] : 0.0;      // lane 32+c holds row c of L^-T
   }
-}
-
-__global__ __launch_bounds__(64) void k_gj_first(int nn, const double* __restrict__ Sa, double* __restrict__ Linv, int* __restrict__ fail) {
-  __shared__ double Dm[kNB][kNB + 1];
-  const int nb = min(kNB, nn);
-  for (int e = threadIdx.x; e < kNB * kNB; e += 64) {
-    const int r = e / kNB, c = e % kNB;
-    Dm[r][c] = (r < nb && c < nb) ? Sa[(long long)r * nn + c] : (r == c ? 1.0 : 0.0);
-  }
-  __syncthreads();
-  potrf_inv_wave(Dm, Linv, fail);
 }
 
 // one panel step; grid (row tiles below the panel incl. the rhs row, all column tiles); pc != nullptr on the last step
@@ -1702,18 +1702,17 @@ struct HipSchur {
       const int nbk = (ne.CB + kGemmT - 1) / kGemmT;
       hipLaunchKernelGGL(k_schur_gemm, dim3(nbk * (nbk + 1) / 2 + nbk, nslab), dim3(256), 0, be.stream, ne, ncols, row_lo, row_hi, Erm, Z, G);
     }
-    const long long nS = (long long)ne.CB * ne.CB;
+    const int ntile = (ne.CB + kNB - 1) / kNB;
     if (shard) {
       const long long cnt = (long long)ne.CB * ncols;
       hipLaunchKernelGGL(k_sum_slabs, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, be.stream, cnt, nslab, G, G0);
       be.reduce(G0, (size_t)cnt);                   // the Schur complement contributions of all time slices
-      hipLaunchKernelGGL(k_schur_finish, dim3((unsigned)((nS + 255) / 256)), dim3(256), 0, be.stream, ne, ncols, 1, lambda, G0, S, rhs);
+      hipLaunchKernelGGL(k_schur_finish, dim3(ntile, ntile), dim3(kNB * kNB), 0, be.stream, ne, ncols, 1, lambda, G0, S, Linv, fail);
     } else {
-      hipLaunchKernelGGL(k_schur_finish, dim3((unsigned)((nS + 255) / 256)), dim3(256), 0, be.stream, ne, ncols, nslab, lambda, G, S, rhs);
+      hipLaunchKernelGGL(k_schur_finish, dim3(ntile, ntile), dim3(kNB * kNB), 0, be.stream, ne, ncols, nslab, lambda, G, S, Linv, fail);
     }
     {
       const int nn = ne.CB;
-      hipLaunchKernelGGL(k_gj_first, dim3(1), dim3(64), 0, be.stream, nn, S, Linv, fail);
       double* a = S;
       double* b = S2;
       for (int kb = 0; kb < nn; kb += kNB) {

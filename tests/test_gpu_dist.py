@@ -67,14 +67,14 @@ def test_two_shards_on_one_gpu_match_unsharded(solver, case):
             t = torch.as_tensor(_DeviceDoubles(ptr, count), device='cuda:0')
             torch.cuda.synchronize()
             bufs[rank] = t
-            barrier.wait()
+            barrier.wait(60)
             if rank == 0:
                 total[0] = bufs[0] + bufs[1]
                 torch.cuda.synchronize()
-            barrier.wait()
+            barrier.wait(60)
             t.copy_(total[0])
             torch.cuda.synchronize()
-            barrier.wait()
+            barrier.wait(60)
         return cb
 
     def run(rank):
@@ -88,7 +88,7 @@ def test_two_shards_on_one_gpu_match_unsharded(solver, case):
             errors.append(e)
             barrier.abort()
 
-    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    threads = [threading.Thread(target=run, args=(r,), daemon=True) for r in range(world)]      # daemon: a failure must not hang the exit
     [t.start() for t in threads]
     [t.join(120) for t in threads]
     assert not errors, errors
@@ -126,16 +126,16 @@ def test_time_shards_on_one_gpu_match_unsharded(world, motion):
             t = torch.as_tensor(_DeviceDoubles(ptr, count), device='cuda:0')
             torch.cuda.synchronize()
             bufs[rank] = t
-            barrier.wait()
+            barrier.wait(60)
             if rank == 0:
                 assert all(b.numel() == bufs[0].numel() for b in bufs)
                 total[0] = torch.stack(bufs).sum(0)
                 nbytes[0] += 8 * count
                 torch.cuda.synchronize()
-            barrier.wait()
+            barrier.wait(60)
             t.copy_(total[0])
             torch.cuda.synchronize()
-            barrier.wait()
+            barrier.wait(60)
         return cb
 
     def run(rank):
@@ -150,7 +150,7 @@ def test_time_shards_on_one_gpu_match_unsharded(world, motion):
             errors.append(e)
             barrier.abort()
 
-    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    threads = [threading.Thread(target=run, args=(r,), daemon=True) for r in range(world)]      # daemon: a failure must not hang the exit
     [t.start() for t in threads]
     [t.join(180) for t in threads]
     assert not errors, errors
@@ -212,7 +212,7 @@ def test_time_shard_reports_detections_that_leave_its_slice():
             errors.append(str(e))
             barrier.abort()
 
-    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    threads = [threading.Thread(target=run, args=(r,), daemon=True) for r in range(world)]      # daemon: a failure must not hang the exit
     [t.start() for t in threads]
     [t.join(120) for t in threads]
     assert any('outside this rank' in e for e in errors), errors
