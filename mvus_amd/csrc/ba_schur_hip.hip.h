@@ -486,6 +486,12 @@ __global__ void k_halo_copy(NEView ne, int halo, int nb, const int* __restrict__
     if (unpack) *slot = *dst; else *dst = *slot;
   }
 }
+// time shards: the two failure flags travel with the step (px[n], px[n+1]) through its sum over the ranks, so that every
+// rank takes the same decision (a rank whose own interiors factorise fine must still see its neighbour's failure)
+__global__ void k_fail_pack(const int* __restrict__ fail, double* __restrict__ tail) { if (threadIdx.x < 2) tail[threadIdx.x] = (double)fail[threadIdx.x]; }
+__global__ void k_fail_unpack(const double* __restrict__ tail, int* __restrict__ fail) {
+  if (threadIdx.x < 2 && tail[threadIdx.x] != 0.0 && fail[threadIdx.x] == 0) fail[threadIdx.x] = threadIdx.x == 0 ? 8 : 1;
+}
 __global__ void k_sum_slabs(long long count, int nslab, const double* __restrict__ Gp, double* __restrict__ G0) {
   const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (i >= count) return;
@@ -1554,7 +1560,7 @@ struct HipSchur {
     Linv = be.alloc((size_t)((ne.CB + kNB - 1) / kNB) * kNB * kNB);
     if (shard) { DG = nullptr; D = NE + nAg + halo_count; gx = D + hp.n; }
     else { DG = be.alloc(2 * (size_t)hp.n); D = DG; gx = DG + hp.n; }
-    px = be.alloc(hp.n);
+    px = be.alloc(hp.n + 2);                         // + the two failure flags of a time shard
     MVUS_HIP(hipMalloc(reinterpret_cast<void**>(&fail), 2 * sizeof(int)));
     MVUS_HIP(hipMemsetAsync(fail, 0, 2 * sizeof(int), be.stream));
     MVUS_HIP(hipHostMalloc(reinterpret_cast<void**>(&fail_host), 2 * sizeof(int), hipHostMallocDefault));
@@ -1727,7 +1733,11 @@ struct HipSchur {
     const int nrows = row_hi - row_lo, per = kThreads / 64;
     hipLaunchKernelGGL(k_back_substitute, dim3((unsigned)std::max(1, (nrows + per - 1) / per)), dim3(kThreads), 0, be.stream, be.dp, ne, ncols,
                        row_lo, row_hi, (int)(!shard || be.tshard.rank == 0), Z, pc, px);
-    if (shard) be.reduce(px, (size_t)be.hp.n);      // every rank's part of the step
+    if (shard) {
+      hipLaunchKernelGGL(k_fail_pack, dim3(1), dim3(64), 0, be.stream, fail, px + be.hp.n);
+      be.reduce(px, (size_t)be.hp.n + 2);             // every rank's part of the step (+ failure flags)
+      hipLaunchKernelGGL(k_fail_unpack, dim3(1), dim3(64), 0, be.stream, px + be.hp.n, fail);
+    }
     MVUS_HIP(hipGetLastError());
     MVUS_HIP(hipMemcpyAsync(fail_host, fail, 2 * sizeof(int), hipMemcpyDeviceToHost, be.stream));
   }
