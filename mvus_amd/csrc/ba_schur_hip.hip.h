@@ -518,46 +518,6 @@ __global__ void k_band_pack(NEView ne, double lambda, int BW, double* __restrict
   Lb[idx] = v;
 }
 
-// In-place banded Cholesky (right-looking) by ONE wavefront, staged through LDS in tiles of kTile columns.
-// fail[0] is set when a pivot is not positive.  After the call Lb[i][0] holds 1 / L(i,i).
-constexpr int kTile = 384;
-template <int BW>
-__global__ __launch_bounds__(64) void k_band_cholesky(int n3, double* __restrict__ Lb, int* __restrict__ fail) {
-  constexpr int R = BW + 1;
-  __shared__ double T[(kTile + BW) * R];
-  const int lane = threadIdx.x;
-  for (int k0 = 0; k0 < n3; k0 += kTile) {
-    const int rows = min(kTile + BW, n3 - k0);
-    for (int e = lane; e < rows * R; e += 64) T[e] = Lb[(long long)k0 * R + e];
-    __syncthreads();
-    const int cols = min(kTile, n3 - k0);
-    for (int k = 0; k < cols; ++k) {
-      double piv = T[k * R];
-      if (!(piv > 0.0)) { if (lane == 0) fail[0] = 1; piv = 1.0; }
-      const double d = sqrt(piv), inv = 1.0 / d;
-      const int nb = min(BW, rows - 1 - k);          // rows below k inside the band and the tile
-      // scale column k: L(k+r, k) = A(k+r, k) / d, r = 1..nb   (stored at T[(k+r)*R + r])
-      if (lane >= 1 && lane <= nb) T[(k + lane) * R + lane] *= inv;
-      __syncthreads();
-      // trailing update: A(k+r, k+s) -= L(k+r,k) L(k+s,k), 1 <= s <= r <= nb
-      const int npairs = nb * (nb + 1) / 2;
-      for (int e = lane; e < npairs; e += 64) {
-        int r = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
-        while ((r + 1) * (r + 2) / 2 <= e) ++r;
-        while (r * (r + 1) / 2 > e) --r;
-        const int s = e - r * (r + 1) / 2;           // 0 <= s <= r
-        const int rr = r + 1, ss = s + 1;
-        T[(k + rr) * R + (rr - ss)] -= T[(k + rr) * R + rr] * T[(k + ss) * R + ss];
-      }
-      if (lane == 0) T[k * R] = inv;
-      __syncthreads();
-    }
-    // rows [k0, k0+cols) are final; the next BW rows carry partial updates and are reloaded by the next tile
-    for (int e = lane; e < rows * R; e += 64) Lb[(long long)k0 * R + e] = T[e];
-    __syncthreads();
-  }
-}
-
 // ---- partitioned (separator-based) parallel solve of the banded spline system ---------------------------
 // The chain of control points is cut into P interiors of kPartL control points separated by separators of
 // W-1 control points (= the block half-bandwidth, so two interiors never couple directly):
@@ -1188,43 +1148,6 @@ __global__ void k_build_rhs(NEView ne, int ncols, double* __restrict__ Z, double
     Erm[(long long)r * ne.CB + cidx] = v;
   } else {
     Z[idx] = ne.gs[r];
-  }
-}
-
-// Z <- (L L^T)^-1 Z, one thread per right-hand-side column, forward then backward substitution.
-template <int BW>
-__global__ __launch_bounds__(64) void k_band_solve(int n3, int ncols, const double* __restrict__ Lb, double* __restrict__ Z) {
-  constexpr int R = BW + 1;
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= ncols) return;
-  double yw[BW];
-#pragma unroll
-  for (int j = 0; j < BW; ++j) yw[j] = 0.0;
-  for (int i = 0; i < n3; ++i) {
-    const double* Lr = Lb + (long long)i * R;
-    double acc = Z[(long long)i * ncols + t];
-#pragma unroll
-    for (int j = 1; j <= BW; ++j) acc -= Lr[j] * yw[j - 1];      // L(i, i-j) y(i-j); zero outside the matrix
-    const double y = acc * Lr[0];
-    Z[(long long)i * ncols + t] = y;
-#pragma unroll
-    for (int j = BW - 1; j >= 1; --j) yw[j] = yw[j - 1];
-    yw[0] = y;
-  }
-#pragma unroll
-  for (int j = 0; j < BW; ++j) yw[j] = 0.0;
-  for (int i = n3 - 1; i >= 0; --i) {
-    double acc = Z[(long long)i * ncols + t];
-#pragma unroll
-    for (int j = 1; j <= BW; ++j) {
-      const double l = (i + j < n3) ? Lb[(long long)(i + j) * R + j] : 0.0;   // L(i+j, i)
-      acc -= l * yw[j - 1];
-    }
-    const double xv = acc * Lb[(long long)i * R];
-    Z[(long long)i * ncols + t] = xv;
-#pragma unroll
-    for (int j = BW - 1; j >= 1; --j) yw[j] = yw[j - 1];
-    yw[0] = xv;
   }
 }
 
