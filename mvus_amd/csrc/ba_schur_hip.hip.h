@@ -2,14 +2,22 @@
 // (camera blocks, block-banded spline block, cross block, gradient) from the slot Jacobian, and the
 // damped solve by elimination of the spline block.
 //
-// Layout (one packed buffer `NE`, so that a single all-reduce sums every shard's contribution):
+// Layout (one packed buffer `NE`; observation shards sum all of it, time shards only its head):
 //   A  [C][B][B]        camera diagonal blocks, B = 3+P (alpha, beta, rs, camera params)
 //   gc [C][B]           camera part of g = J^T f
+//   (time shards only: the halo exchange buffer, diag(H) and g in x order -- the part summed over the ranks)
 //   Cb [N][W][3][3]     Cb[g][w] = H[3g.., 3(g+w)..]: upper block band of the spline block, W >= 4
 //   gs [3N]             spline part of g, internal order 3*ctrl + xyz
-//   Ec [C][3N][B]       cross block, camera-major: the window a workgroup accumulates for one camera is one
-//                       contiguous run of 3*nwin*B doubles, so its flush is fully coalesced; k_build_rhs transposes
-//                       it into the row-major [3N][C*B] right-hand-side / GEMM operand
+//   Et [C][3N][B]       cross block, camera-major: the control points a half chunk touches are one contiguous run of
+//                       doubles per camera, so its flush is coalesced; k_build_rhs transposes it into the row-major
+//                       [3N][C*B] right-hand-side / GEMM operand
+// N here is the number of control points of the slice this handle holds: all of them, or -- time shard -- the owned
+// range plus a halo on each side.
+//
+// Solve chain (solve_async): k_band_pack, k_build_rhs -> interiors (k_part_cholesky, k_part_solve) -> separator system
+// (k_part_reduce, k_sep_bcr_factor, k_sep_bcr_rhs | sequential k_sep_factor, k_sep_rhs) -> k_part_back -> Schur product
+// on the fp64 matrix cores (k_schur_gemm, k_schur_finish) -> block Gauss-Jordan on the reduced camera system (k_gj_step)
+// -> k_back_substitute.
 #pragma once
 #include <hip/hip_runtime.h>
 
