@@ -202,6 +202,13 @@ def test_empty_and_ragged_cameras(BAHandle):
         assert not f[2 * prob.det_offsets[2]:].any()
         r = h.solve(x0, jac_mode=_lib.JAC_ANALYTIC, max_nfev=5)
         assert np.isfinite(r.cost) and r.cost <= r.initial_cost
+        # the LM / Schur path: the empty camera's block is all zero (damped by the unit diagonal), its parameters stay put
+        r2 = h.solve(x0, solver=_lib.SOLVER_LM_SCHUR, jac_mode=_lib.JAC_ANALYTIC, max_nfev=8)
+        assert np.isfinite(r2.cost) and r2.cost < r2.initial_cost
+        C, P = prob.C, prob.P
+        for cam in (1, 2):
+            cols = [cam, C + cam, 2 * C + cam] + list(range(3 * C + cam * P, 3 * C + (cam + 1) * P))
+            np.testing.assert_array_equal(r2.x[cols], x0[cols])
 
 
 def test_full_size_properties(BAHandle):
@@ -232,6 +239,12 @@ def test_full_size_properties(BAHandle):
         err = np.abs((fp - fm)[ok] / (2 * eps) - jd[ok])
         assert np.quantile(err / (np.abs(jd[ok]) + 1e-3), 0.999) < 1e-3
         # outlier mask == threshold on the residual pairs, bit for bit
+        # normal equations of the LM path: gradient = J^T f (assembled from the same slot Jacobian by other kernels)
+        h.residual_jacobian(x0, _lib.JAC_ANALYTIC)                 # (the residual calls above overwrote the held f)
+        gg, A, band, cross = h.normal_equations()
+        z_f = h.jtu(f1)
+        np.testing.assert_allclose(gg, z_f, rtol=0, atol=1e-9 * np.abs(z_f).max())
+        del A, band, cross
         keep = h.outlier_mask(x0, 10.0)
         off = prob.det_offsets
         ex = np.concatenate([f1[2 * a:2 * a + (b - a)] for a, b in zip(off[:-1], off[1:])])
