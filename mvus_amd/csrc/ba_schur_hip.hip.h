@@ -1128,7 +1128,6 @@ __global__ __launch_bounds__(64) void k_part_back(PartView pv, int ncols, double
 #pragma unroll
     for (int a = 0; a < S3; ++a) Z[(long long)(pv.sr[p] + a) * ncols + col] = zr[a];
   }
-#pragma unroll 4
   for (int i = ia; i < ib; ++i) {
     double v = Z[(long long)(r0 + i) * ncols + col];
     const double* __restrict__ vw = VWp + (long long)i * st;
@@ -1188,19 +1187,24 @@ __device__ __forceinline__ void schur_gemm_tile(const NEView& ne, int ncols, con
   const int k0 = kbeg + wave * kGemmWaveK, k1 = min(k0 + kGemmWaveK, kend);
   const double* ap = Erm + (long long)(k0 + lk) * ne.CB + a0 + lr;
   const double* bp = Z + (long long)(k0 + lk) * ncols + b0 + lr;
-#pragma unroll 4
-  for (int k = k0; k < k1; k += 4) {
-    const bool kv = k + lk < k1;
-    double a[3], b[NJ];
+  constexpr int kUn = 4;                                   // k-steps whose operand loads are issued together
+  for (int k = k0; k < k1; k += 4 * kUn) {
+    double a[kUn][3], b[kUn][NJ];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) a[i] = (kv && av[i]) ? ap[16 * i] : 0.0;
+    for (int u = 0; u < kUn; ++u) {
+      const bool kv = k + 4 * u + lk < k1;
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) b[j] = (kv && bv[j]) ? bp[16 * j] : 0.0;
-    ap += 4 * (long long)ne.CB; bp += 4 * (long long)ncols;
+      for (int i = 0; i < 3; ++i) a[u][i] = (kv && av[i]) ? ap[(long long)(4 * u) * ne.CB + 16 * i] : 0.0;
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < NJ; ++j) b[u][j] = (kv && bv[j]) ? bp[(long long)(4 * u) * ncols + 16 * j] : 0.0;
+    }
+    ap += 4 * kUn * (long long)ne.CB; bp += 4 * kUn * (long long)ncols;
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+    for (int u = 0; u < kUn; ++u)
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][i], b[u][j], acc[i][j], 0, 0, 0);
   }
   // sum the four wavefronts through LDS, then store: element (i, j, reg) of lane l is row 16i + (l>>4) + 4 reg, col 16j + (l&15)
   for (int w = 0; w < 4; ++w) {
