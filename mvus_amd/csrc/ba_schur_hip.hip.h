@@ -722,7 +722,7 @@ __global__ __launch_bounds__(256) void k_part_reduce(PartView pv, int ncols, con
   // loops run over exactly BW rows with the out-of-range ones masked, so that all their loads are issued together
   const double* VWa = pv.VW + ((long long)(pl >= 0 ? pl : 0) * kPartRowsMax) * st;
   const double* VWb = pv.VW + ((long long)(pr >= 0 ? pr : 0) * kPartRowsMax) * st;
-  for (int e = threadIdx.x; e < s3 * s3; e += blockDim.x) {
+  for (int e = threadIdx.x; blockIdx.y == 0 && e < s3 * s3; e += blockDim.x) {
     const int a = e / s3, b = e % s3;
     double tt = own ? band_entry<BW>(Lb, c0 + a, c0 + b) : 0.0, u = 0.0;
 #pragma unroll
@@ -742,7 +742,8 @@ __global__ __launch_bounds__(256) void k_part_reduce(PartView pv, int ncols, con
     pv.T[((long long)gq * s3 + a) * s3 + b] = tt;
     pv.U[((long long)gq * s3 + a) * s3 + b] = (gq + 1 < pv.m) ? u : 0.0;
   }
-  for (int e = threadIdx.x; e < s3 * ncols; e += blockDim.x) {
+  // the right-hand sides: gridDim.y workgroups per separator share the entries (few dependent load rounds each)
+  for (int e = blockIdx.y * blockDim.x + threadIdx.x; e < s3 * ncols; e += gridDim.y * blockDim.x) {
     const int a = e / ncols, col = e % ncols;
     double r = own ? Z[(long long)(c0 + a) * ncols + col] : 0.0;
 #pragma unroll
@@ -1617,7 +1618,7 @@ struct HipSchur {
     hipLaunchKernelGGL(k_part_solve<BWT>, gsolve, dim3(64), 0, be.stream, pv, ncols, Lb, Z);
     if (pv.m > 0) {
       if (shard) MVUS_HIP(hipMemsetAsync(sepbuf, 0, sep_count * sizeof(double), be.stream));      // other ranks' separators: zero here
-      if (pv.nt > 0) hipLaunchKernelGGL(k_part_reduce<BWT>, dim3(pv.nt), dim3(256), 0, be.stream, pv, ncols, Lb, Z);
+      if (pv.nt > 0) hipLaunchKernelGGL(k_part_reduce<BWT>, dim3(pv.nt, (pv.s3 * ncols + 255) / 256), dim3(256), 0, be.stream, pv, ncols, Lb, Z);
       if (shard) be.reduce(sepbuf, sep_count);        // every rank now holds the whole separator system
       if (use_bcr) {
         hipLaunchKernelGGL(k_sep_bcr_factor<S3T>, dim3(1), dim3(kBcrWaves * 64), 0, be.stream, pv, fail);
