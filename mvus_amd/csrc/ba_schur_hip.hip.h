@@ -1039,7 +1039,7 @@ __global__ __launch_bounds__(kBcrWaves * 64) void k_sep_bcr_factor(PartView pv, 
   }
 }
 
-constexpr int kBcrCols = 2;       // columns per workgroup; 1 for chains whose two columns do not fit the LDS
+constexpr int kBcrCols = 1;       // columns per workgroup (one: more workgroups, fewer items per level and thread)
 template <int S3, int TC>
 __global__ __launch_bounds__(256) void k_sep_bcr_rhs(PartView pv, int ncols) {
   double* __restrict__ Rr = pv.R;
