@@ -54,8 +54,11 @@ extern "C" {
 
 /* Solver used by mvus_ba_solve */
 #define MVUS_SOLVER_TRF_LSMR 0 /* restatement of scipy trf + lsmr (the reference's optimiser), J kept as operator */
-#define MVUS_SOLVER_LM_SCHUR 1 /* Levenberg-Marquardt on device-assembled normal equations, spline block
-                                  eliminated by a block-banded Cholesky, dense reduced camera system */
+#define MVUS_SOLVER_LM_SCHUR 1 /* Levenberg-Marquardt on device-assembled normal equations: spline block eliminated
+                                  by a partitioned band Cholesky + cyclic reduction, Schur complement on the fp64
+                                  matrix cores, reduced camera system by block Gauss-Jordan; all vectors stay on the
+                                  device, one 7-scalar read-back per iteration.  The damping (and its growth factor)
+                                  is carried from one mvus_ba_solve on a handle to the next. */
 
 typedef struct mvus_ba mvus_ba; /* opaque */
 
@@ -161,7 +164,9 @@ int mvus_ba_jtu(mvus_ba* h, const double* u, double* z);
 int mvus_ba_normal_equations(mvus_ba* h, double* g, double* JtJ_cam, double* band, double* cross, int32_t* W_out);
 
 /* The least_squares call of Scene.BA (common.py:670) -- x is read and overwritten with res.x.
- * lb/ub come from opts of the problem (rs_bounds).  f_out[m] may be NULL. */
+ * lb/ub come from opts of the problem (rs_bounds).  f_out[m] may be NULL.  Synchronises before returning.
+ * Termination tests, nfev/njev counting and status codes follow scipy for both solvers (max_nfev = the reference's
+ * max_iter); MVUS_SOLVER_LM_SCHUR does not re-linearise the accepted point when max_nfev stops it. */
 int mvus_ba_solve(mvus_ba* h, double* x, const mvus_solve_opts* opts, mvus_result* res, double* f_out);
 
 /* Scene.remove_outliers (common.py:700-717): keep[i] = sqrt(ex^2 + ey^2) < thres, camera-segmented order. */
