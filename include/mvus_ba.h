@@ -163,6 +163,11 @@ int mvus_ba_jtu(mvus_ba* h, const double* u, double* z);
  *   cross[C*B*3N]: cross[(c*B + k)*3N + 3g + d].  Any output may be NULL; *W_out receives W. */
 int mvus_ba_normal_equations(mvus_ba* h, double* g, double* JtJ_cam, double* band, double* cross, int32_t* W_out);
 
+/* One damped Gauss-Newton step of MVUS_SOLVER_LM_SCHUR with the Jacobian and residual currently held:
+ * p[n] = -(J^T J + lambda D)^-1 J^T f, D = diag(J^T J) (1 where 0).  Inspection hook for the whole solve chain
+ * (assembly, band solver, Schur complement, reduced system); no trial evaluation, no bounds.  No reference counterpart. */
+int mvus_ba_lm_step(mvus_ba* h, double lambda, double* p_out);
+
 /* The least_squares call of Scene.BA (common.py:670) -- x is read and overwritten with res.x.
  * lb/ub come from opts of the problem (rs_bounds).  f_out[m] may be NULL.  Synchronises before returning.
  * Termination tests, nfev/njev counting and status codes follow scipy for both solvers (max_nfev = the reference's

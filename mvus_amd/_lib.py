@@ -71,6 +71,7 @@ API = [
     ('mvus_ba_jv', ctypes.c_int, [ctypes.c_void_p, c_double_p, c_double_p]),
     ('mvus_ba_jtu', ctypes.c_int, [ctypes.c_void_p, c_double_p, c_double_p]),
     ('mvus_ba_normal_equations', ctypes.c_int, [ctypes.c_void_p, c_double_p, c_double_p, c_double_p, c_double_p, c_int32_p]),
+    ('mvus_ba_lm_step', ctypes.c_int, [ctypes.c_void_p, ctypes.c_double, c_double_p]),
     ('mvus_ba_solve', ctypes.c_int, [ctypes.c_void_p, c_double_p, ctypes.POINTER(MvusSolveOpts), ctypes.POINTER(MvusResult), c_double_p]),
     ('mvus_ba_outlier_mask', ctypes.c_int, [ctypes.c_void_p, c_double_p, ctypes.c_double, c_uint8_p]),
     ('mvus_ba_remove_outliers', ctypes.c_int, [ctypes.c_void_p, c_double_p, ctypes.c_double, c_uint8_p, c_int64_p]),

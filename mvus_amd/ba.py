@@ -133,6 +133,12 @@ class BAHandle:
                                                       ctypes.byref(W)), 'mvus_ba_normal_equations')
         return g, cam, band, cross
 
+    def lm_step(self, lam):
+        """p = -(J^T J + lam diag(J^T J))^-1 J^T f for the Jacobian / residual currently held (after residual_jacobian)."""
+        p = np.empty(self.n)
+        self._check(self.lib.mvus_ba_lm_step(self.h, float(lam), _lib.dptr(p)), 'mvus_ba_lm_step')
+        return p
+
     def solve(self, x0, solver=SOLVER_TRF_LSMR, jac_mode=JAC_PATTERN, max_nfev=10, opts=None, return_fun=True):
         """The least_squares call of Scene.BA.  Returns an OptimizeResult-like namespace
         (x, cost, fun, nfev, njev, status, optimality, ...)."""

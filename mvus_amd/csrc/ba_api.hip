@@ -521,6 +521,22 @@ int mvus_ba_normal_equations(mvus_ba* h, double* g, double* JtJ_cam, double* ban
   });
 }
 
+int mvus_ba_lm_step(mvus_ba* h, double lambda, double* p_out) {
+  return guarded(h, [&] {
+    HipBackend& be = h->be;
+    if (!p_out || !(lambda >= 0)) { be.err = "lm_step: bad arguments"; return MVUS_E_INVALID; }
+    if (!be.has_jacobian) { be.err = "no Jacobian held: call mvus_ba_residual_jacobian first"; return MVUS_E_INVALID; }
+    if (be.hp.C * (3 + be.hp.P) > 1152) throw HipError{"LM_SCHUR: reduced camera system larger than 1152 unknowns"};
+    if (!h->schur) h->schur.reset(new HipSchur<HipBackend>(be));
+    HipSchur<HipBackend>& sc = *h->schur;
+    sc.assemble(be, be.f_cur);
+    sc.solve_async(lambda);
+    be.download(p_out, sc.step_ptr(), be.hp.n);          // synchronises
+    if (!sc.solve_ok()) { be.err = "lm_step: the damped normal equations are not positive definite at this lambda"; return MVUS_E_NUMERIC; }
+    return MVUS_OK;
+  });
+}
+
 int mvus_ba_solve(mvus_ba* h, double* x, const mvus_solve_opts* opts, mvus_result* res, double* f_out) {
   return guarded(h, [&] {
     HipBackend& be = h->be;

@@ -244,7 +244,41 @@ def test_full_size_properties(BAHandle):
         gg, A, band, cross = h.normal_equations()
         z_f = h.jtu(f1)
         np.testing.assert_allclose(gg, z_f, rtol=0, atol=1e-9 * np.abs(z_f).max())
-        del A, band, cross
+        # ... and the damped step of the whole GPU solve chain at this size (155 separators, 8 levels of cyclic reduction)
+        # against LAPACK: banded Cholesky of the spline block, dense Schur complement
+        from scipy.linalg import solveh_banded
+        lam = 0.5
+        p_gpu = h.lm_step(lam)
+        C, B, N, W = prob.C, 3 + prob.P, band.shape[0], band.shape[1]
+        cam_cols = np.array([[c, C + c, 2 * C + c] + list(range(3 * C + c * prob.P, 3 * C + (c + 1) * prob.P)) for c in range(C)])
+        spl_cols = np.concatenate([[int(prob.spline_x_offsets[s_]) + d * int(n_) + j for j in range(int(n_)) for d in range(3)]
+                                   for s_, n_ in enumerate(prob.n_coef)])
+        bw = 3 * W - 1
+        ab = np.zeros((bw + 1, 3 * N))                                  # upper banded storage of the spline block
+        for w in range(W):
+            for a_ in range(3):
+                for b_ in range(3):
+                    off = 3 * w + b_ - a_
+                    if off < 0:
+                        continue
+                    rows = 3 * np.arange(N - w) + a_
+                    ab[bw - off, rows + off] = band[:N - w, w, a_, b_]
+        dS = ab[bw].copy()
+        ab[bw] += lam * np.where(dS > 0, dS, 1.0)
+        Esp = cross.reshape(C * B, 3 * N)
+        Z = solveh_banded(ab, np.column_stack([Esp.T, gg[spl_cols]]))
+        Acam = np.zeros((C * B, C * B))
+        for c in range(C):
+            Acam[c * B:(c + 1) * B, c * B:(c + 1) * B] = A[c]
+        dA = np.diag(Acam).copy()
+        Sred = Acam + lam * np.diag(np.where(dA > 0, dA, 1.0)) - Esp @ Z[:, :-1]
+        pc = -np.linalg.solve(Sred, gg[cam_cols.ravel()] - Esp @ Z[:, -1])
+        ps = -(Z[:, -1] + Z[:, :-1] @ pc)
+        p_ref = np.zeros(h.n)
+        p_ref[cam_cols.ravel()] = pc
+        p_ref[spl_cols] = ps
+        np.testing.assert_allclose(p_gpu, p_ref, rtol=0, atol=1e-6 * np.abs(p_ref).max())
+        del A, band, cross, Z, Esp
         keep = h.outlier_mask(x0, 10.0)
         off = prob.det_offsets
         ex = np.concatenate([f1[2 * a:2 * a + (b - a)] for a, b in zip(off[:-1], off[1:])])

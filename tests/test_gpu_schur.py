@@ -180,3 +180,46 @@ def test_unsorted_and_sparse_detections_take_the_atomic_fallback():
             if gi + w < band.shape[0]:
                 np.testing.assert_allclose(band[gi, w], Hs[3 * gi:3 * gi + 3, 3 * (gi + w):3 * (gi + w) + 3], rtol=0, atol=1e-12 * scale)
 
+
+
+def test_lm_step_matches_sparse_direct_solve_on_a_long_chain():
+    """~2300 control points -> ~65 separators, 7 levels of cyclic reduction: the damped step of the whole GPU chain
+    (mvus_ba_lm_step: assembly, band solver, Schur complement, reduced system) must solve (H + lambda diag H) p = -g with
+    H and g taken from mvus_ba_normal_equations and the system solved by scipy's sparse LU on the CPU."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    from mvus_amd import synth
+    from mvus_amd.ba import BAHandle
+    sc = synth.make_scene(3, 12000, seed=47, rolling_shutter=True, num_knots=2400)
+    prob, x0 = mp.problem_from_scene(sc)
+    N = int(prob.n_coef.sum())
+    assert N > 2200
+    cam_idx, spl_idx = internal_index(prob)
+    lams = (1e-4, 3.0)
+    with BAHandle(prob) as h:
+        h.residual_jacobian(x0, _lib.JAC_ANALYTIC)
+        g, A, band, cross = h.normal_equations()
+        steps = [h.lm_step(lam) for lam in lams]
+    n, C, B, W = prob.n_params, prob.C, 3 + prob.P, band.shape[1]
+    rows, cols, vals = [], [], []
+    for c in range(C):                                        # camera blocks
+        ii, jj = np.meshgrid(cam_idx[c], cam_idx[c], indexing='ij')
+        rows.append(ii.ravel()); cols.append(jj.ravel()); vals.append(A[c].ravel())
+    E = cross.reshape(C * B, 3 * N)                           # cross block and its transpose
+    ci = cam_idx.ravel()
+    nz = np.nonzero(E)
+    rows += [ci[nz[0]], spl_idx[nz[1]]]; cols += [spl_idx[nz[1]], ci[nz[0]]]; vals += [E[nz], E[nz]]
+    for w in range(W):                                        # spline band (upper blocks + mirror)
+        for gi in range(N - w):
+            blk = band[gi, w]
+            ri, cj = spl_idx[3 * gi:3 * gi + 3], spl_idx[3 * (gi + w):3 * (gi + w) + 3]
+            ii, jj = np.meshgrid(ri, cj, indexing='ij')
+            rows.append(ii.ravel()); cols.append(jj.ravel()); vals.append(blk.ravel())
+            if w > 0:
+                rows.append(jj.ravel()); cols.append(ii.ravel()); vals.append(blk.ravel())
+    H = sp.csc_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(n, n))
+    d = H.diagonal()
+    d = np.where(d > 0, d, 1.0)
+    for lam, p in zip(lams, steps):
+        p_ref = spla.spsolve(H + lam * sp.diags(d), -g)
+        np.testing.assert_allclose(p, p_ref, rtol=0, atol=1e-7 * np.abs(p_ref).max())
