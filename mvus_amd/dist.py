@@ -26,11 +26,22 @@ def make_gpu_allreduce(device_index, group=None):
     stats = {'calls': 0, 'doubles': 0}
     views = {}                    # the library reduces the same few persistent buffers every iteration: alias them once
 
+    streams = {}
+
     def fn(ptr, count, stream):
         t = views.get((ptr, count))
         if t is None:
             t = views[(ptr, count)] = torch.as_tensor(_DeviceDoubles(ptr, count), device='cuda:%d' % device_index)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        # the collective must be ordered on the stream the library's kernels run on (its own stream unless the handle was
+        # created on an explicit one): make that stream torch's current stream around the call
+        if stream:
+            ext = streams.get(stream)
+            if ext is None:
+                ext = streams[stream] = torch.cuda.ExternalStream(stream, device='cuda:%d' % device_index)
+            with torch.cuda.stream(ext):
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
         stats['calls'] += 1
         stats['doubles'] += count
 
