@@ -1,7 +1,8 @@
 """Host-side interval helpers with the reference's names and semantics (``tools/util.py`` there).
 
 Only what the BA path and its immediate callers need: ``homogeneous`` (util.py:54), ``find_intervals``
-(util.py:58-87), ``sampling`` (util.py:90-116).  Written against the behaviour, vectorised over intervals.
+(util.py:58-87), ``sampling`` (util.py:90-116), ``match_overlap`` (util.py:119-135, for the ground-truth report).
+Written against the behaviour, vectorised over intervals.
 """
 import numpy as np
 
@@ -57,3 +58,15 @@ def sampling(x, interval, belong=False):
     mask = ids.astype(bool)
     picked = x[mask] if x.ndim == 1 else x[:, mask]
     return picked, (ids if belong else mask)
+
+
+def match_overlap(x, y):
+    """The parts of two [t; x; y; z] tracks on one timeline that overlap in time: ``x`` restricted to the contiguous
+    parts of ``y``, and ``y`` interpolated (cubic, through its samples) at those timestamps.  ``x`` is assumed to be the
+    denser one."""
+    from scipy import interpolate
+    x_s, _ = sampling(x, find_intervals(y[0]))
+    tck, _ = interpolate.splprep(y[1:], u=y[0], s=0, k=3)
+    y_s = np.vstack((x_s[0], np.asarray(interpolate.splev(x_s[0], tck))))
+    assert (x_s[0] == y_s[0]).all(), 'Both outputs should have the same timestamps'
+    return x_s, y_s
