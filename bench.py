@@ -163,7 +163,7 @@ def main():
 
     # the reference-faithful solver (scipy TRF + LSMR restated) on the same workload, a few steps, for the record
     parity = None
-    if not args.no_parity_solver and args.solver == 'lm':
+    if world == 1 and not args.no_parity_solver and args.solver == 'lm':      # (an N=1 report, like the CPU baseline)
         xs = x0.copy()
         handle.solve(xs, solver=ba.SOLVER_TRF_LSMR, jac_mode=ba.JAC_PATTERN, max_nfev=2, return_fun=False)
         barrier()
