@@ -1397,8 +1397,9 @@ __global__ __launch_bounds__(kThreads) void k_back_substitute(DevProblem dp, NEV
 }
 
 // Partition of a chain of `n` control points starting at local control point `c0`: interiors of kPartL control points
-// separated by separators of sctrl; `close` = the chain must END with a separator (the cut towards the next time
-// shard), otherwise a tail too short for another interior is merged into the last one.
+// separated by separators of sctrl (every interior BETWEEN two separators is at least sctrl long, so that separators
+// never couple directly); `close` = the chain must END with a separator (the cut towards the next time shard),
+// otherwise a tail too short for another interior is merged into the last one.
 struct ChainPart { std::vector<int> i0, i1, sep; };     // scalar rows; sep[k] = separator right of interior k
 inline ChainPart partition_chain(int c0, int n, int sctrl, bool close) {
   ChainPart cp;
@@ -1407,8 +1408,11 @@ inline ChainPart partition_chain(int c0, int n, int sctrl, bool close) {
     int e = std::min(g + kPartL, end);
     if (close) {
       e = std::min(g + kPartL, end - sctrl);
-      const int rem = end - sctrl - e;                 // control points between this interior and the closing separator
-      if (rem > 0 && rem < sctrl + 1) e = end - sctrl; // not enough for a separator and another interior: merge
+      // control points between this interior and the closing separator: none, or a separator plus an interior of at
+      // least sctrl control points -- a shorter interior would let its two separators couple directly through the band,
+      // which the reduced (block tridiagonal) separator system cannot express.  Shorten this interior to leave exactly that.
+      const int rem = end - sctrl - e;
+      if (rem > 0 && rem < 2 * sctrl) e = end - 3 * sctrl;
     }
     cp.i0.push_back(3 * g); cp.i1.push_back(3 * e); g = e;
     if (g < end) {

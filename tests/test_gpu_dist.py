@@ -220,3 +220,63 @@ def test_time_shard_reports_detections_that_leave_its_slice():
     [t.start() for t in threads]
     [t.join(120) for t in threads]
     assert any('outside this rank' in e for e in errors), errors
+
+
+def test_time_shard_every_cut_position():
+    """The closing interior of a rank's chain takes every length as the cut moves (a control point at a time over more
+    than one partition period): the sharded damped step must equal the unsharded one for all of them -- an interior
+    shorter than the band half-width between two separators would let them couple directly."""
+    import threading
+    import torch
+    from mvus_amd import synth
+    from mvus_amd.ba import BAHandle
+    from mvus_amd.dist import _DeviceDoubles
+    sc = synth.make_scene(3, 5000, seed=53, rolling_shutter=True, num_knots=260)
+    prob, x0 = mp.problem_from_scene(sc)
+    N = int(prob.n_coef.sum())
+    with BAHandle(prob) as h0:
+        h0.residual_jacobian(x0, _lib.JAC_ANALYTIC)
+        p_ref = h0.lm_step(0.3)
+    world = 2
+    spans = prob.detection_spans(x0)
+    worst = 0.0
+    for cut in range(N // 2 - 20, N // 2 + 20):
+        cuts = np.array([0, cut, N], dtype=np.int32)
+        barrier = threading.Barrier(world)
+        bufs, total, steps, errors = [None] * world, [None], [None] * world, []
+
+        def make_cb(rank):
+            def cb(ptr, count, stream):
+                t = torch.as_tensor(_DeviceDoubles(ptr, count), device='cuda:0')
+                torch.cuda.synchronize()
+                bufs[rank] = t
+                barrier.wait(60)
+                if rank == 0:
+                    total[0] = bufs[0] + bufs[1]
+                    torch.cuda.synchronize()
+                barrier.wait(60)
+                t.copy_(total[0])
+                torch.cuda.synchronize()
+                barrier.wait(60)
+            return cb
+
+        def run(rank):
+            try:
+                shard, keep, _ = prob.shard_time(rank, world, x0, cuts=cuts)
+                h = BAHandle(shard, device=0)
+                h.set_time_shard(rank, world, cuts)
+                h.set_allreduce(make_cb(rank), is_root=(rank == 0))
+                h.residual_jacobian(x0, _lib.JAC_ANALYTIC)
+                steps[rank] = h.lm_step(0.3)
+                h.close()
+            except Exception as e:                      # pragma: no cover
+                errors.append(e)
+                barrier.abort()
+
+        threads = [threading.Thread(target=run, args=(r,), daemon=True) for r in range(world)]
+        [t.start() for t in threads]
+        [t.join(120) for t in threads]
+        assert not errors, (cut, errors)
+        for p in steps:
+            worst = max(worst, float(np.abs(p - p_ref).max()))
+    assert worst < 1e-9 * np.abs(p_ref).max(), worst

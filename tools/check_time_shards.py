@@ -17,7 +17,18 @@ opts = _lib.default_opts(_lib.SOLVER_LM_SCHUR, _lib.JAC_ANALYTIC, nfev)
 opts.verbose = 2 if len(sys.argv) > 4 else 0
 calls = int(os.environ.get('CALLS', '1'))          # CALLS > 1: a run of short solves on one handle, like bench.py
 
+lm_lambda = float(os.environ['LMSTEP']) if 'LMSTEP' in os.environ else None      # LMSTEP=<lambda>: compare one damped step only
+
+
+class _Step:
+    def __init__(self, p):
+        self.x, self.nfev, self.njev, self.initial_cost, self.cost = p, 0, 0, 0.0, 0.0
+
+
 def run_calls(h):
+    if lm_lambda is not None:
+        h.residual_jacobian(x0, 0)
+        return _Step(h.lm_step(lm_lambda))
     x, out = x0, None
     for _ in range(calls):
         out = h.solve(x, opts=opts)
