@@ -222,7 +222,8 @@ def test_time_shard_reports_detections_that_leave_its_slice():
     assert any('outside this rank' in e for e in errors), errors
 
 
-def test_time_shard_every_cut_position():
+@pytest.mark.parametrize('motion', [False, True])
+def test_time_shard_every_cut_position(motion):
     """The closing interior of a rank's chain takes every length as the cut moves (a control point at a time over more
     than one partition period): the sharded damped step must equal the unsharded one for all of them -- an interior
     shorter than the band half-width between two separators would let them couple directly."""
@@ -231,7 +232,8 @@ def test_time_shard_every_cut_position():
     from mvus_amd import synth
     from mvus_amd.ba import BAHandle
     from mvus_amd.dist import _DeviceDoubles
-    sc = synth.make_scene(3, 5000, seed=53, rolling_shutter=True, num_knots=260)
+    sc = synth.make_scene(3, 5000, seed=53, rolling_shutter=True, num_knots=260, motion_reg=motion, motion_type='F',
+                          motion_weights=30.0)          # the motion prior widens the band: separators of 5 control points
     prob, x0 = mp.problem_from_scene(sc)
     N = int(prob.n_coef.sum())
     with BAHandle(prob) as h0:
