@@ -223,3 +223,40 @@ def test_lm_step_matches_sparse_direct_solve_on_a_long_chain():
     for lam, p in zip(lams, steps):
         p_ref = spla.spsolve(H + lam * sp.diags(d), -g)
         np.testing.assert_allclose(p, p_ref, rtol=0, atol=1e-7 * np.abs(p_ref).max())
+
+
+def test_damped_step_for_every_tail_length():
+    """Spline lengths from 2 to 4 partitions, one control point at a time: the last interior takes every length (and the
+    tail-merge rule triggers): the damped step must match a dense solve of the exported normal equations each time."""
+    from mvus_amd import synth
+    from mvus_amd.ba import BAHandle
+    worst = 0.0
+    seen = set()
+    for nk in range(72, 150):
+        sc = synth.make_scene(2, 700, seed=59, rolling_shutter=True, num_knots=nk)
+        prob, x0 = mp.problem_from_scene(sc)
+        N = int(prob.n_coef.sum())
+        if N in seen:
+            continue
+        seen.add(N)
+        cam_idx, spl_idx = internal_index(prob)
+        with BAHandle(prob) as h:
+            h.residual_jacobian(x0, _lib.JAC_ANALYTIC)
+            g, A, band, cross = h.normal_equations()
+            p = h.lm_step(0.2)
+        n, C, B, W = prob.n_params, prob.C, 3 + prob.P, band.shape[1]
+        H = np.zeros((n, n))
+        for c in range(C):
+            H[np.ix_(cam_idx[c], cam_idx[c])] = A[c]
+        E = cross.reshape(C * B, 3 * N)
+        H[np.ix_(cam_idx.ravel(), spl_idx)] = E
+        H[np.ix_(spl_idx, cam_idx.ravel())] = E.T
+        for w in range(W):
+            for gi in range(N - w):
+                ri, cj = spl_idx[3 * gi:3 * gi + 3], spl_idx[3 * (gi + w):3 * (gi + w) + 3]
+                H[np.ix_(ri, cj)] = band[gi, w]
+                H[np.ix_(cj, ri)] = band[gi, w].T
+        d = np.diag(H).copy()
+        p_ref = np.linalg.solve(H + 0.2 * np.diag(np.where(d > 0, d, 1.0)), -g)
+        worst = max(worst, float(np.abs(p - p_ref).max() / np.abs(p_ref).max()))
+    assert len(seen) > 60 and worst < 1e-8, (len(seen), worst)
