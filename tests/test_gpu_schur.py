@@ -260,3 +260,54 @@ def test_damped_step_for_every_tail_length():
         p_ref = np.linalg.solve(H + 0.2 * np.diag(np.where(d > 0, d, 1.0)), -g)
         worst = max(worst, float(np.abs(p - p_ref).max() / np.abs(p_ref).max()))
     assert len(seen) > 60 and worst < 1e-8, (len(seen), worst)
+
+
+@pytest.mark.parametrize('seed', range(8))
+def test_assembly_randomised_layouts(seed):
+    """Randomised detection layouts -- density from a fraction of a detection to ~50 per knot span, random local shuffles,
+    random dropped stretches, detections outside the spline, with and without free calibration -- against the dense J^T J
+    of the host build (ranges of one span of every length, the in-LDS sort, split runs, the many-ranges path)."""
+    from mvus_amd import synth
+    from mvus_amd.ba import BAHandle
+    rng = np.random.default_rng(100 + seed)
+    calib = bool(seed % 2)
+    nk = int(rng.choice([40, 90, 400, 1500]))
+    sc = synth.make_scene(3, int(rng.choice([1500, 4000])), seed=200 + seed, rolling_shutter=True, num_knots=nk,
+                          distortion=calib, opt_calib=calib)
+    for c in range(3):
+        d = sc.detections[c]
+        n = d.shape[1]
+        mode = rng.integers(0, 4)
+        if mode == 1:                                    # local shuffles: spans interleave
+            blk = int(rng.choice([4, 16, 64]))
+            d = d[:, np.concatenate([b + rng.permutation(min(blk, n - b)) for b in range(0, n, blk)])]
+        elif mode == 2:                                  # random stretches dropped + a block shifted outside every interval
+            keep = np.ones(n, bool)
+            for _ in range(5):
+                a = rng.integers(0, n)
+                keep[a:a + rng.integers(1, n // 6)] = False
+            d = d[:, keep].copy()
+            d[0, :7] += 1e6
+        elif mode == 3:                                  # thinned: many spans per half chunk
+            d = d[:, ::int(rng.choice([2, 5, 11]))]
+        sc.detections[c] = d
+    prob, x0 = mp.problem_from_scene(sc)
+    if prob.n_params > 5000:
+        pytest.skip('dense host Jacobian too large for this draw')
+    f, D = _host(prob).dense_jacobian(x0, _lib.JAC_ANALYTIC)
+    H, grad = D.T @ D, D.T @ f
+    cam_idx, spl_idx = internal_index(prob)
+    with BAHandle(prob) as h:
+        h.residual_jacobian(x0, _lib.JAC_ANALYTIC)
+        gg, A, band, cross = h.normal_equations()
+    scale = np.abs(H).max()
+    np.testing.assert_allclose(gg, grad, rtol=0, atol=1e-11 * np.abs(grad).max())
+    for c in range(prob.C):
+        np.testing.assert_allclose(A[c], H[np.ix_(cam_idx[c], cam_idx[c])], rtol=0, atol=1e-12 * scale)
+    E = H[np.ix_(cam_idx.ravel(), spl_idx)]
+    np.testing.assert_allclose(cross.reshape(E.shape), E, rtol=0, atol=1e-12 * scale)
+    Hs = H[np.ix_(spl_idx, spl_idx)]
+    for gi in range(band.shape[0]):
+        for w in range(band.shape[1]):
+            if gi + w < band.shape[0]:
+                np.testing.assert_allclose(band[gi, w], Hs[3 * gi:3 * gi + 3, 3 * (gi + w):3 * (gi + w) + 3], rtol=0, atol=1e-12 * scale)
