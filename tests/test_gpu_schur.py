@@ -300,6 +300,10 @@ def test_assembly_randomised_layouts(seed):
     with BAHandle(prob) as h:
         h.residual_jacobian(x0, _lib.JAC_ANALYTIC)
         gg, A, band, cross = h.normal_equations()
+        u, v = rng.normal(size=h.m), rng.normal(size=h.n)
+        z, y = h.jtu(u), h.jv(v)                              # the operator pair of the TRF + LSMR path on the same layout
+    np.testing.assert_allclose(z, D.T @ u, rtol=0, atol=1e-11 * np.abs(D.T @ u).max())
+    np.testing.assert_allclose(y, D @ v, rtol=0, atol=1e-11 * np.abs(D @ v).max())
     scale = np.abs(H).max()
     np.testing.assert_allclose(gg, grad, rtol=0, atol=1e-11 * np.abs(grad).max())
     for c in range(prob.C):
