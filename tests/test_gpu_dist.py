@@ -282,3 +282,71 @@ def test_time_shard_every_cut_position(motion):
         for p in steps:
             worst = max(worst, float(np.abs(p - p_ref).max()))
     assert worst < 1e-9 * np.abs(p_ref).max(), worst
+
+
+@pytest.mark.parametrize('seed', [1, 2, 3])
+def test_time_shards_randomised_layouts(seed):
+    """Three time shards of scenes with locally shuffled detections, dropped stretches and detections outside every
+    interval: the damped step of the sharded chain equals the unsharded one."""
+    import threading
+    import torch
+    from mvus_amd import synth
+    from mvus_amd.ba import BAHandle
+    from mvus_amd.dist import _DeviceDoubles
+    rng = np.random.default_rng(300 + seed)
+    sc = synth.make_scene(3, 6000, seed=400 + seed, rolling_shutter=True, num_knots=int(rng.choice([200, 500])))
+    for c in range(3):
+        d = sc.detections[c]
+        n = d.shape[1]
+        if (c + seed) % 3 == 0:
+            d = d[:, np.concatenate([b + rng.permutation(min(16, n - b)) for b in range(0, n, 16)])]
+        elif (c + seed) % 3 == 1:
+            keep = np.ones(n, bool)
+            for _ in range(4):
+                a = rng.integers(0, n)
+                keep[a:a + rng.integers(1, n // 8)] = False
+            d = d[:, keep].copy()
+            d[0, 100:110] += 1e6
+        sc.detections[c] = d
+    prob, x0 = mp.problem_from_scene(sc)
+    with BAHandle(prob) as h0:
+        h0.residual_jacobian(x0, _lib.JAC_ANALYTIC)
+        p_ref = h0.lm_step(0.1)
+    world = 3
+    barrier = threading.Barrier(world)
+    bufs, total, steps, errors = [None] * world, [None], [None] * world, []
+
+    def make_cb(rank):
+        def cb(ptr, count, stream):
+            t = torch.as_tensor(_DeviceDoubles(ptr, count), device='cuda:0')
+            torch.cuda.synchronize()
+            bufs[rank] = t
+            barrier.wait(60)
+            if rank == 0:
+                total[0] = torch.stack(bufs).sum(0)
+                torch.cuda.synchronize()
+            barrier.wait(60)
+            t.copy_(total[0])
+            torch.cuda.synchronize()
+            barrier.wait(60)
+        return cb
+
+    def run(rank):
+        try:
+            shard, keep, cuts = prob.shard_time(rank, world, x0)
+            h = BAHandle(shard, device=0)
+            h.set_time_shard(rank, world, cuts)
+            h.set_allreduce(make_cb(rank), is_root=(rank == 0))
+            h.residual_jacobian(x0, _lib.JAC_ANALYTIC)
+            steps[rank] = h.lm_step(0.1)
+            h.close()
+        except Exception as e:                      # pragma: no cover
+            errors.append(e)
+            barrier.abort()
+
+    threads = [threading.Thread(target=run, args=(r,), daemon=True) for r in range(world)]
+    [t.start() for t in threads]
+    [t.join(120) for t in threads]
+    assert not errors, errors
+    for p in steps:
+        np.testing.assert_allclose(p, p_ref, rtol=0, atol=1e-9 * np.abs(p_ref).max())
