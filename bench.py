@@ -58,9 +58,11 @@ def cpu_baseline(config_index):
         kw['num_knots'] = max(kw['num_knots'] // scale, 16)
     sc = synth.make_scene(**kw)
     oprob, x0 = orc.problem_from_scene(sc)
-    t0 = time.perf_counter()
-    res = orc.solve(oprob, x0, max_iter=16)            # ~15 s of single-core work at the 1/32 sample
-    dt = time.perf_counter() - t0
+    from threadpoolctl import threadpool_limits
+    with threadpool_limits(limits=1):                  # `cores: 1` must be true: no BLAS / OpenMP thread pools
+        t0 = time.perf_counter()
+        res = orc.solve(oprob, x0, max_iter=48)        # ~15 s of single-core work at the 1/32 sample
+        dt = time.perf_counter() - t0
     M = sum(d.shape[1] for d in oprob.detections)
     iters = max(res.nfev - 1, 1)
     return {'value': M * iters / dt, 'unit': 'residuals/s', 'cores': 1, 'kind': 'port',
