@@ -180,7 +180,8 @@ int mvus_ba_outlier_mask(mvus_ba* h, const double* x, double thres, uint8_t* kee
 /* Scene.remove_outliers applied to the handle itself (common.py:709-714: `detections[i] = detections[i][:, error<thres]`):
  * evaluates the mask at x, compacts the device-resident detection arrays in place (order kept) and rebuilds the launch
  * tables, so the next mvus_ba_solve -- the second BA of main.py:59 -- runs on the inliers without a new handle or any
- * re-upload.  keep_out[M_old] (may be NULL) receives the mask, det_offsets_out[C+1] the new camera offsets. */
+ * re-upload.  keep_out[M_old] (may be NULL) receives the mask, det_offsets_out[C+1] the new camera offsets.
+ * On a sharded handle every rank filters its own detections (all ranks must call it: the global row count is re-summed). */
 int mvus_ba_remove_outliers(mvus_ba* h, const double* x, double thres, uint8_t* keep_out, int64_t* det_offsets_out);
 
 /* Multi-GPU: observations sharded across ranks, this handle holds one shard.  `is_root` ranks add the

@@ -596,10 +596,16 @@ int mvus_ba_outlier_mask(mvus_ba* h, const double* x, double thres, uint8_t* kee
 int mvus_ba_remove_outliers(mvus_ba* h, const double* x, double thres, uint8_t* keep_out, int64_t* det_offsets_out) {
   return guarded(h, [&] {
     HipBackend& be = h->be;
-    if (be.allreduce) { be.err = "remove_outliers on a sharded handle: filter every shard's problem on the host instead"; return MVUS_E_INVALID; }
     be.upload(be.x_cur, x, be.hp.n);
     h->schur.reset();                       // sized by the launch tables
     be.remove_outliers(be.x_cur, thres, keep_out, det_offsets_out);
+    if (be.allreduce) {                     // a shard filters its own detections; only the global row count is shared
+      const bool counts_motion = be.tshard.on ? be.tshard.rank == 0 : be.is_root != 0;
+      be.scal_host[2] = (double)(2 * be.hp.M + (counts_motion ? be.hp.T : 0));
+      MVUS_HIP(hipMemcpyAsync(be.scal_dev + 2, be.scal_host + 2, sizeof(double), hipMemcpyHostToDevice, be.stream));
+      be.reduce(be.scal_dev + 2, 1);
+      be.m_glob = (int64_t)(be.read_slot(2) + 0.5);
+    }
     return MVUS_OK;
   });
 }

@@ -354,3 +354,68 @@ def test_time_shards_randomised_layouts(seed):
     assert not errors, errors
     for p in steps:
         np.testing.assert_allclose(p, p_ref, rtol=0, atol=1e-9 * np.abs(p_ref).max())
+
+
+def test_ba_outliers_ba_on_time_shards():
+    """The BA -> remove_outliers -> BA sequence of main.py:49-62 with the detections resident on two time shards: every rank
+    filters its own slice in place; masks, detection counts and the second BA equal the unsharded sequence."""
+    import threading
+    import torch
+    from mvus_amd import synth
+    from mvus_amd.ba import BAHandle
+    from mvus_amd.dist import _DeviceDoubles
+    sc = synth.make_scene(3, 6000, seed=61, rolling_shutter=True, num_knots=300)
+    prob, x0 = mp.problem_from_scene(sc)
+    opts = _lib.default_opts(_lib.SOLVER_LM_SCHUR, _lib.JAC_ANALYTIC, 6)
+
+    def sequence(h):
+        r1 = h.solve(x0, opts=opts)
+        keep = h.remove_outliers(r1.x, 10.0)
+        r2 = h.solve(r1.x, opts=opts)
+        return r1, keep, r2
+
+    with BAHandle(prob) as h0:
+        ref1, keep_ref, ref2 = sequence(h0)
+    assert 0 < (~keep_ref).sum() < prob.M // 4
+    world = 2
+    barrier = threading.Barrier(world)
+    bufs, total, results, errors = [None] * world, [None], [None] * world, []
+
+    def make_cb(rank):
+        def cb(ptr, count, stream):
+            t = torch.as_tensor(_DeviceDoubles(ptr, count), device='cuda:0')
+            torch.cuda.synchronize()
+            bufs[rank] = t
+            barrier.wait(60)
+            if rank == 0:
+                total[0] = bufs[0] + bufs[1]
+                torch.cuda.synchronize()
+            barrier.wait(60)
+            t.copy_(total[0])
+            torch.cuda.synchronize()
+            barrier.wait(60)
+        return cb
+
+    def run(rank):
+        try:
+            shard, idx, cuts = prob.shard_time(rank, world, x0)
+            h = BAHandle(shard, device=0)
+            h.set_time_shard(rank, world, cuts)
+            h.set_allreduce(make_cb(rank), is_root=(rank == 0))
+            results[rank] = sequence(h) + (idx,)
+            h.close()
+        except Exception as e:                      # pragma: no cover
+            errors.append(e)
+            barrier.abort()
+
+    threads = [threading.Thread(target=run, args=(r,), daemon=True) for r in range(world)]
+    [t.start() for t in threads]
+    [t.join(180) for t in threads]
+    assert not errors, errors
+    keep_all = np.zeros(prob.M, dtype=bool)
+    for r1, keep, r2, idx in results:
+        keep_all[idx] = keep
+        np.testing.assert_allclose(r1.cost, ref1.cost, rtol=1e-9)
+        np.testing.assert_allclose(r2.cost, ref2.cost, rtol=1e-9)
+        np.testing.assert_allclose(r2.x, ref2.x, rtol=0, atol=1e-7 * max(1.0, np.abs(ref2.x).max()))
+    np.testing.assert_array_equal(keep_all, keep_ref)
