@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "ba_kernels.hip.h"
+#include "ba_partition.h"
 #include "ba_schur.h"
 
 namespace mvus {
@@ -535,8 +536,6 @@ __global__ void k_band_pack(NEView ne, double lambda, int BW, double* __restrict
 // B) the separator system (block tridiagonal, blocks of 3(W-1)) is formed from short dot products;
 // C) it is solved sequentially by one workgroup (P-1 small steps, all right-hand sides in parallel);
 // D) the interiors are corrected: X_I = Y - V X_{S_{p-1}} - W X_{S_p}.
-constexpr int kPartL = 32;
-constexpr int kPartRowsMax = 3 * (kPartL + 6);
 
 // Rows are LOCAL scalar rows of this handle's slice of the spline system (the whole system unless the handle is a
 // time shard); separators are numbered GLOBALLY along the whole chain, 0 .. m-1.
@@ -1394,34 +1393,6 @@ __global__ __launch_bounds__(kThreads) void k_back_substitute(DevProblem dp, NEV
     const int g = r / 3 + ne.row0, d = r % 3;
     px[dp.mv.ctrl_x0[g] + d * dp.mv.ctrl_stride[g]] = -(acc + zr[ne.CB]);
   }
-}
-
-// Partition of a chain of `n` control points starting at local control point `c0`: interiors of kPartL control points
-// separated by separators of sctrl (every interior BETWEEN two separators is at least sctrl long, so that separators
-// never couple directly); `close` = the chain must END with a separator (the cut towards the next time shard),
-// otherwise a tail too short for another interior is merged into the last one.
-struct ChainPart { std::vector<int> i0, i1, sep; };     // scalar rows; sep[k] = separator right of interior k
-inline ChainPart partition_chain(int c0, int n, int sctrl, bool close) {
-  ChainPart cp;
-  const int end = c0 + n;
-  for (int g = c0; g < end;) {
-    int e = std::min(g + kPartL, end);
-    if (close) {
-      e = std::min(g + kPartL, end - sctrl);
-      // control points between this interior and the closing separator: none, or a separator plus an interior of at
-      // least sctrl control points -- a shorter interior would let its two separators couple directly through the band,
-      // which the reduced (block tridiagonal) separator system cannot express.  Shorten this interior to leave exactly that.
-      const int rem = end - sctrl - e;
-      if (rem > 0 && rem < 2 * sctrl) e = end - 3 * sctrl;
-    }
-    cp.i0.push_back(3 * g); cp.i1.push_back(3 * e); g = e;
-    if (g < end) {
-      const int e2 = std::min(g + sctrl, end);
-      if (!close && end - e2 < 1) { cp.i1.back() = 3 * end; g = end; }          // tail too short for another interior: merge
-      else { cp.sep.push_back(3 * g); g = e2; }
-    }
-  }
-  return cp;
 }
 
 template <class BE>

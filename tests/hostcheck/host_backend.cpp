@@ -5,6 +5,7 @@
 // the block-sparse J v / J^T u operators, the pattern mask and the normal-equation algebra against
 // the oracle without a GPU.  It is compiled into tests/hostcheck/libhostcheck.so only -- the
 // product library libmvusba.so has no CPU path.
+#include "../../mvus_amd/csrc/ba_partition.h"
 #include <cstring>
 #include <string>
 #include <vector>
@@ -320,6 +321,16 @@ extern "C" int hostcheck_lsmr(void* h, const double* b, double damp, double atol
   HostBackend* be = static_cast<HostBackend*>(h);
   Lsmr<HostBackend> l(*be);
   return l.run(nullptr, nullptr, b, damp, atol, btol, conlim, maxiter > 0 ? maxiter : std::min(be->hp.m, be->hp.n), x_out, itn);
+}
+
+// partition of a control-point chain (ba_partition.h): returns the number of interiors, fills i0/i1 (scalar rows) and the
+// separators' first rows; *nsep receives their count
+extern "C" int hostcheck_partition(int c0, int n, int sctrl, int close, int* i0, int* i1, int* sep, int* nsep) {
+  const mvus::ChainPart cp = mvus::partition_chain(c0, n, sctrl, close != 0);
+  for (size_t k = 0; k < cp.i0.size(); ++k) { i0[k] = cp.i0[k]; i1[k] = cp.i1[k]; }
+  for (size_t k = 0; k < cp.sep.size(); ++k) sep[k] = cp.sep[k];
+  *nsep = (int)cp.sep.size();
+  return (int)cp.i0.size();
 }
 
 extern "C" void hostcheck_tr2d(const double* B, const double* g, double Delta, double* p) {

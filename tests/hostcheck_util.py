@@ -10,7 +10,7 @@ from mvus_amd import _lib
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SRC = [os.path.join(HERE, 'hostcheck', f) for f in ('hostcheck.cpp', 'host_backend.cpp')]
-DEPS = SRC + [os.path.join(ROOT, 'mvus_amd', 'csrc', f) for f in ('ba_math.h', 'ba_solver.h', 'ba_problem.h', 'ba_schur.h')] \
+DEPS = SRC + [os.path.join(ROOT, 'mvus_amd', 'csrc', f) for f in ('ba_math.h', 'ba_solver.h', 'ba_problem.h', 'ba_schur.h', 'ba_partition.h')] \
     + [os.path.join(ROOT, 'include', 'mvus_ba.h')]
 SO = os.path.join(HERE, 'hostcheck', 'libhostcheck.so')
 
