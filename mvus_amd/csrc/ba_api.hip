@@ -197,8 +197,8 @@ struct HipBackend {
     hipLaunchKernelGGL(k_lm_gnorm, dim3((unsigned)((hp.n + 1023) / 1024)), dim3(1024), 0, stream, (int)hp.n, x, lb, ub, g, out, partials, lm_counter);
   }
   void lm_trial(const double* x, const double* p, const double* lb, const double* ub, const double* g, const double* D,
-                const int* fail, double* x_new, double* out) {
-    hipLaunchKernelGGL(k_lm_trial, dim3((unsigned)((hp.n + 1023) / 1024)), dim3(1024), 0, stream, (int)hp.n, x, p, lb, ub, g, D, fail, x_new, out, partials, lm_counter);
+                const int* fail, double* x_new, double* out, double* gnorm_out) {
+    hipLaunchKernelGGL(k_lm_trial, dim3((unsigned)((hp.n + 1023) / 1024)), dim3(1024), 0, stream, (int)hp.n, x, p, lb, ub, g, D, fail, x_new, out, gnorm_out, partials, lm_counter);
   }
   void fetch(const double* src, int k, double* host) {       // src inside scal_dev: staged through the pinned mirror
     const int64_t off = src - scal_dev;

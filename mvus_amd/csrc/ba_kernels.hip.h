@@ -477,34 +477,46 @@ __global__ __launch_bounds__(1024) void k_lm_gnorm(int n, const double* __restri
 __global__ __launch_bounds__(1024) void k_lm_trial(int n, const double* __restrict__ x, const double* __restrict__ p, const double* __restrict__ lb,
                                                    const double* __restrict__ ub, const double* __restrict__ g, const double* __restrict__ D,
                                                    const int* __restrict__ fail, double* __restrict__ x_new, double* __restrict__ out,
-                                                   double* part, unsigned* counter) {
-  __shared__ double red[4][16];
+                                                   double* __restrict__ gnorm_out, double* part, unsigned* counter) {
+  // also delivers the projected gradient norm of k_lm_gnorm (x, g and the bounds are read here anyway): slot 4 = max
+  __shared__ double red[5][16];
   const int i = blockIdx.x * 1024 + threadIdx.x;
   const bool dead = fail[0] != 0;
-  double s[4] = {dead ? __longlong_as_double(0x7ff8000000000000LL) : 0.0, 0.0, 0.0, 0.0};
+  double s[5] = {dead ? __longlong_as_double(0x7ff8000000000000LL) : 0.0, 0.0, 0.0, 0.0, 0.0};
   if (i < n) {
-    const double xi = x[i], pi = p[i];
+    const double xi = x[i], pi = p[i], gi = g[i], lo = lb[i], hi = ub[i];
     const bool ok = isfinite(pi);
-    const double xn = (dead || !ok) ? xi : fmin(fmax(xi + pi, lb[i]), ub[i]);
+    const double xn = (dead || !ok) ? xi : fmin(fmax(xi + pi, lo), hi);
     const double st = xn - xi;
     x_new[i] = xn;
-    s[0] += ok ? g[i] * st : pi * 0.0; s[1] = st * D[i] * st; s[2] = st * st; s[3] = xi * xi;
+    s[0] += ok ? gi * st : pi * 0.0; s[1] = st * D[i] * st; s[2] = st * st; s[3] = xi * xi;
+    const bool blocked = (xi <= lo && gi > 0) || (xi >= hi && gi < 0);
+    s[4] = blocked ? 0.0 : fabs(gi);
   }
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const double v = wave_sum(s[k]);
     if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = v;
   }
-  __syncthreads();
-  if (threadIdx.x < 4) {
-    double t = 0.0;
-    for (int w = 0; w < 16; ++w) t += red[threadIdx.x][w];
-    part[blockIdx.x * 4 + threadIdx.x] = t;
+  {
+    double v = s[4];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
+    if ((threadIdx.x & 63) == 0) red[4][threadIdx.x >> 6] = v;
   }
-  if (last_block_done(counter) && threadIdx.x < 4) {
+  __syncthreads();
+  if (threadIdx.x < 5) {
     double t = 0.0;
-    for (unsigned b = 0; b < gridDim.x; ++b) t += const_cast<volatile double*>(part)[b * 4 + threadIdx.x];
-    out[threadIdx.x] = t;
+    for (int w = 0; w < 16; ++w) t = threadIdx.x < 4 ? t + red[threadIdx.x][w] : fmax(t, red[4][w]);
+    part[blockIdx.x * 5 + threadIdx.x] = t;
+  }
+  if (last_block_done(counter) && threadIdx.x < 5) {
+    double t = 0.0;
+    for (unsigned b = 0; b < gridDim.x; ++b) {
+      const double v = const_cast<volatile double*>(part)[b * 5 + threadIdx.x];
+      t = threadIdx.x < 4 ? t + v : fmax(t, v);
+    }
+    if (threadIdx.x < 4) out[threadIdx.x] = t; else *gnorm_out = t;
   }
 }
 

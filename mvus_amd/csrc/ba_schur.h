@@ -26,7 +26,8 @@
 //                   void solve_async(double lambda);               p = -(H + lambda D)^-1 g -> step_ptr()
 //                   const double* step_ptr(); const int* fail_ptr();  bool solve_ok();   (solve_ok after a fetch)
 // Backend additions: set_bounds(lb, ub) -> lb_ptr()/ub_ptr(); lm_scalars() (>= 8 doubles); dot_m_into(a, b, out);
-//                   lm_gnorm(x, lb, ub, g, out); lm_trial(x, p, lb, ub, g, D, fail, x_new, out4); fetch(src, k, host).
+//                   lm_gnorm(x, lb, ub, g, out); lm_trial(x, p, lb, ub, g, D, fail, x_new, out4, gnorm_out) (the trial
+//                   kernel reads x, g and the bounds anyway, so it also delivers the gradient norm); fetch(src, k, host).
 #pragma once
 #include <algorithm>
 #include <cmath>
@@ -51,7 +52,7 @@ inline double lm_gnorm_host(int64_t n, const double* x, const double* lb, const 
 // trial point x_new = P(x + p) (projection onto the rs box) and out = [g.step, step^T D step, |step|^2, |x|^2];
 // a failed or non-finite solve gives step 0 and out[0] = NaN
 inline void lm_trial_host(int64_t n, const double* x, const double* p, const double* lb, const double* ub, const double* g,
-                          const double* D, int fail, double* x_new, double* out) {
+                          const double* D, int fail, double* x_new, double* out, double* gnorm_out) {
   double gp = 0, pDp = 0, s2 = 0, x2 = 0;
   bool bad = fail != 0;
   for (int64_t i = 0; i < n && !bad; ++i) bad = !std::isfinite(p[i]);
@@ -62,6 +63,7 @@ inline void lm_trial_host(int64_t n, const double* x, const double* p, const dou
     gp += g[i] * st; pDp += st * D[i] * st; s2 += st * st; x2 += x[i] * x[i];
   }
   out[0] = bad ? std::numeric_limits<double>::quiet_NaN() : gp; out[1] = pDp; out[2] = s2; out[3] = x2;
+  *gnorm_out = lm_gnorm_host(n, x, lb, ub, g);
 }
 
 template <class B, class Schur>
@@ -89,7 +91,7 @@ SolveResult lm_schur(B& be, Schur& sc, std::vector<double>& x, const std::vector
 
   auto launch_trial = [&](double lambda) {
     sc.solve_async(lambda);
-    be.lm_trial(x_dev, sc.step_ptr(), lbp, ubp, sc.grad_ptr(), sc.diag_ptr(), sc.fail_ptr(), xt_dev, S + 2);
+    be.lm_trial(x_dev, sc.step_ptr(), lbp, ubp, sc.grad_ptr(), sc.diag_ptr(), sc.fail_ptr(), xt_dev, S + 2, S + 1);
     be.residual(xt_dev, f_new);
     be.dot_m_into(f_new, f_new, S + 6);
   };
@@ -100,9 +102,9 @@ SolveResult lm_schur(B& be, Schur& sc, std::vector<double>& x, const std::vector
   int status = -1;
   double g_norm = 0;
   while (true) {
-    be.lm_gnorm(x_dev, lbp, ubp, sc.grad_ptr(), S + 1);
     const bool can_try = res.nfev < opt.max_nfev;
     if (can_try) launch_trial(lambda);             // speculative: dropped if the gradient test below ends the solve
+    else be.lm_gnorm(x_dev, lbp, ubp, sc.grad_ptr(), S + 1);
     be.fetch(S, can_try ? 7 : 2, hs);
     if (!cost_known) {
       cost = 0.5 * hs[0];

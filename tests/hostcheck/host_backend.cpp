@@ -53,7 +53,7 @@ struct HostBackend {
   void dot_m_into(const double* a, const double* b, double* out) { *out = dot_m(a, b); }
   void lm_gnorm(const double* x, const double* lb, const double* ub, const double* g, double* out) { *out = mvus::lm_gnorm_host(hp.n, x, lb, ub, g); }
   void lm_trial(const double* x, const double* p, const double* lb, const double* ub, const double* g, const double* D,
-                const int* fail, double* x_new, double* out) { mvus::lm_trial_host(hp.n, x, p, lb, ub, g, D, *fail, x_new, out); }
+                const int* fail, double* x_new, double* out, double* gn) { mvus::lm_trial_host(hp.n, x, p, lb, ub, g, D, *fail, x_new, out, gn); }
   void fetch(const double* src, int k, double* host) { std::memcpy(host, src, sizeof(double) * k); }
 
   void init() {
