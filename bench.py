@@ -65,8 +65,11 @@ def cpu_baseline(config_index):
         dt = time.perf_counter() - t0
     M = sum(d.shape[1] for d in oprob.detections)
     iters = max(res.nfev - 1, 1)
+    import numpy, scipy
+    blas = [(d.get('internal_api'), d.get('version'), d.get('num_threads')) for d in __import__('threadpoolctl').threadpool_info()]
     return {'value': M * iters / dt, 'unit': 'residuals/s', 'cores': 1, 'kind': 'port',
-            'ba_iters_per_s': iters / dt,
+            'ba_iters_per_s': iters / dt, 'os_cpu_count': os.cpu_count(), 'numpy': numpy.__version__, 'scipy': scipy.__version__,
+            'blas': blas, 'blas_threads_during_timing': 1,
             'sample': '%d cams x %d obs (%d params), 1/%d-scale sample of the workload from the same generator; '
                       'oracle restatement of Scene.BA: scipy least_squares(jac_sparsity, lsmr, 2-point FD), '
                       '%d trial steps in %.1f s' % (oprob.C, M, x0.size, scale, iters, dt)}
@@ -114,8 +117,11 @@ def main():
 
     kw = dict(synth.BASELINE_CONFIGS[args.config])
     per_gpu_obs = kw['total_obs']
-    kw['total_obs'] = per_gpu_obs * world                      # weak scaling: fixed observations per GPU;
-                                                               # cameras and the spline (knots) stay as configured
+    # configs[3] IS a multi-GPU configuration (64 cams x 2M obs sharded over the node): the fixed problem is cut over the
+    # ranks (strong scaling).  Every other config scales weakly: fixed observations per GPU, cameras and knots as configured.
+    strong = args.config == 3
+    if not strong:
+        kw['total_obs'] = per_gpu_obs * world
     scene = synth.make_scene(**kw)
     prob, x0 = mp.problem_from_scene(scene)
     shard_mode = args.shard or ('time' if args.solver == 'lm' else 'obs')
@@ -154,7 +160,8 @@ def main():
 
     # roofline of the dominant kernel: residual + Jacobian, HIP events on the kernel's own stream
     handle.set_x(x)
-    t_rj = handle.time_kernel(ba.KERNEL_RESIDUAL_JACOBIAN, 50)
+    t_rj = handle.time_kernel(ba.KERNEL_RESIDUAL_JACOBIAN, 100)          # outputs rotate over >= 1 GiB: every launch goes to HBM
+    t_rj_one = handle.time_kernel(ba.KERNEL_RESIDUAL_JACOBIAN_ONE_BUFFER, 20)   # same kernel into one (Infinity-Cache sized) set
     t_r = handle.time_kernel(ba.KERNEL_RESIDUAL, 50)
     t_jv = handle.time_kernel(ba.KERNEL_JV, 50)
     t_jtu = handle.time_kernel(ba.KERNEL_JTU, 50)
@@ -191,7 +198,7 @@ def main():
         out = {
             'metric': 'residuals/sec', 'value': M_total * args.steps / dt, 'unit': 'residuals/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'strong' if strong else 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'ba_iters_per_sec': args.steps / dt,
             'config': {'workload': 'BASELINE configs[%d]: %d cams x %d obs (%d per GPU), rolling shutter %s, %d spline '
                                    'control points, %d params, %d residual rows; step = 1 trust-region trial '
@@ -204,8 +211,12 @@ def main():
                        'cost_first': cost0, 'cost_last': r.cost},
             'roofline': {'bound': 'hbm', 'kernel': 'k_observations<calib=%s,jac=true>' % ('true' if prob.opt_calib else 'false'),
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': traffic, 'bytes_per_launch': bytes_launch, 'avg_launch_ms': t_rj,
-                         'bytes_per_obs': per_obs, 'obs_per_launch': handle.prob.M},
+                         'traffic': traffic, 'traffic_source': 'profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, gfx950 corrections applied)' if traffic else None,
+                         'bytes_per_launch': bytes_launch, 'avg_launch_ms': t_rj,
+                         'bytes_per_obs': per_obs, 'obs_per_launch': handle.prob.M,
+                         'timing': 'HIP events over 100 launches whose outputs rotate over >= 3 buffer sets (>= 1 GiB, 4x the Infinity Cache)',
+                         'one_buffer': {'avg_launch_ms': t_rj_one, 'achieved': bytes_launch / (t_rj_one * 1e-3) / 1e9,
+                                        'frac': bytes_launch / (t_rj_one * 1e-3) / 1e9 / HBM_PEAK_GBS}},
             'parity_solver': parity,
             'kernels_ms': {'residual': t_r, 'residual_jacobian': t_rj, 'jv': t_jv, 'jtu': t_jtu, 'normal_eq_assembly': t_asm},
         }

@@ -71,6 +71,8 @@ typedef struct mvus_problem {
   int32_t rs_bounds;     /* `rs_bounds`: 0 <= rs <= 1   common.py:655-662 */
   int32_t motion_reg;    /* `motion_reg`                common.py:483-485 */
   int32_t motion_type;   /* MVUS_MOTION_*  settings['motion_type'] common.py:416-420 */
+  int32_t opt_sync;      /* settings['opt_sync'] (absent = 1): 0 freezes alpha and beta -- their columns leave the
+                            pattern and every Jacobian, common.py:512-515 */
   double motion_weight;  /* `motion_weights`            common.py:413 */
   const int64_t* det_offsets; /* [C+1] detections of camera c are [det_offsets[c], det_offsets[c+1]) */
   const double* frame;        /* [M] detections[c][0]  (np.loadtxt usecols=(2,0,1), common.py:1190) */
@@ -144,9 +146,26 @@ int mvus_ba_residual_jacobian(mvus_ba* h, const double* x, int32_t jac_mode, dou
  * samples j-1, j, j+1), mctrl[3*T] first control point of each of the three samples (-1 = unused). */
 int mvus_ba_motion_rows(mvus_ba* h, const double* x, int32_t jac_mode, double* mf, double* mJ, int32_t* mctrl);
 
-/* Fix the reference sparsity pattern at x0 (jac_BA + compute_visibility, common.py:427-438,490-610):
- * pat[M] = global index of the first of the three in-pattern control points, -1 for all-zero rows. */
+/* Fix the reference sparsity pattern at x0 (jac_BA + compute_visibility, common.py:427-438,490-610), computed on the
+ * GPU.  pat[M]: per detection row a PATTERN CODE  p | (mask << 25)  -- p = global index of the lowest in-pattern
+ * control point, bit k of the 4-bit mask set when control point p+k is in the pattern (three bits set) -- or -1 for
+ * an all-zero row.  The nearest-three rule of common.py:559-563 gives three consecutive points (mask 0x7).  In rows
+ * where exactly one of two control points with the SAME centre knot (t[2:-2] repeats the interval start and end) is
+ * among the three nearest, which twin np.argsort returns depends on numpy's sort kernel (scalar / AVX2 / AVX512
+ * builds differ): the reference's pattern is implementation defined there.  Those rows get the canonical choice and
+ * bit 30 (MVUS_PAT_TIE) set in pat_out. */
+#define MVUS_PAT_SHIFT 25
+#define MVUS_PAT_TIE (1 << 30)
 int mvus_ba_set_pattern(mvus_ba* h, const double* x0, int32_t* pat_out);
+
+/* The pattern codes of the T motion rows (common.py:573-585; parameter independent, canonical unless uploaded). */
+int mvus_ba_motion_pattern(mvus_ba* h, int32_t* motion_pat_out);
+
+/* Supply the pattern instead: the matrix A the reference passes as jac_sparsity at common.py:670 is an INPUT of the
+ * call this library replaces.  pat[M] / motion_pat[T] (NULL = keep) are pattern codes as above (bit 30 ignored); every
+ * point of a code must belong to one spline.  Stays in force -- MVUS_JAC_PATTERN solves do not recompute it -- until
+ * the next mvus_ba_set_pattern or mvus_ba_remove_outliers.  Column groups for MVUS_JAC_FD must be set afterwards. */
+int mvus_ba_upload_pattern(mvus_ba* h, const int32_t* pat, const int32_t* motion_pat);
 
 /* Column groups for MVUS_JAC_FD: groups[n] in [0, num_groups), two columns share a group only if no row of the
  * reference pattern contains both (scipy.optimize._numdiff.group_columns on jac_BA's matrix). */
@@ -203,7 +222,9 @@ int mvus_ba_set_time_shard(mvus_ba* h, int32_t rank, int32_t world, const int32_
 
 /* Measurement hook for bench.py: runs `launches` back-to-back launches of one kernel on the handle's
  * stream between two hipEvents and returns the average duration in milliseconds.
- *   which: 0 residual, 1 residual+Jacobian, 2 J v, 3 J^T u, 4 normal-equation assembly */
+ *   which: 0 residual, 1 residual+Jacobian with the outputs ROTATING over >= 3 buffer sets (>= 1 GiB in rotation, so no
+ *   launch writes into lines its predecessor left in the 256 MiB Infinity Cache), 2 J v, 3 J^T u, 4 normal-equation
+ *   assembly, 5 residual+Jacobian re-launched into one buffer set (cache-resident variant, for comparison) */
 int mvus_ba_time_kernel(mvus_ba* h, int32_t which, int32_t launches, double* avg_ms);
 
 /* Upload x to the handle without evaluating anything (used with mvus_ba_time_kernel). */

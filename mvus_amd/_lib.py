@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get('MVUS_LIB_PATH') or os.path.join(_HERE, 'csrc', 'libmv
 MVUS_OK = 0
 MVUS_E_INVALID, MVUS_E_HIP, MVUS_E_NUMERIC, MVUS_E_COMM = -1, -2, -3, -4
 JAC_ANALYTIC, JAC_PATTERN, JAC_FD = 0, 1, 2
+PAT_SHIFT, PAT_TIE = 25, 1 << 30          # pattern codes of mvus_ba_set_pattern (include/mvus_ba.h)
 SOLVER_TRF_LSMR, SOLVER_LM_SCHUR = 0, 1
 
 c_double_p = ctypes.POINTER(ctypes.c_double)
@@ -26,7 +27,7 @@ class MvusProblem(ctypes.Structure):
     _fields_ = [
         ('num_cam', ctypes.c_int32), ('opt_calib', ctypes.c_int32), ('undist_points', ctypes.c_int32),
         ('rs_free', ctypes.c_int32), ('rs_bounds', ctypes.c_int32), ('motion_reg', ctypes.c_int32),
-        ('motion_type', ctypes.c_int32), ('motion_weight', ctypes.c_double),
+        ('motion_type', ctypes.c_int32), ('opt_sync', ctypes.c_int32), ('motion_weight', ctypes.c_double),
         ('det_offsets', c_int64_p), ('frame', c_double_p), ('u_raw', c_double_p), ('v_raw', c_double_p),
         ('img_height', c_double_p), ('K', c_double_p), ('dist', c_double_p),
         ('num_splines', ctypes.c_int32), ('interval', c_double_p), ('knot_offsets', c_int64_p),
@@ -67,6 +68,8 @@ API = [
     ('mvus_ba_residual_jacobian', ctypes.c_int, [ctypes.c_void_p, c_double_p, ctypes.c_int32, c_double_p, c_double_p, c_int32_p]),
     ('mvus_ba_motion_rows', ctypes.c_int, [ctypes.c_void_p, c_double_p, ctypes.c_int32, c_double_p, c_double_p, c_int32_p]),
     ('mvus_ba_set_pattern', ctypes.c_int, [ctypes.c_void_p, c_double_p, c_int32_p]),
+    ('mvus_ba_motion_pattern', ctypes.c_int, [ctypes.c_void_p, c_int32_p]),
+    ('mvus_ba_upload_pattern', ctypes.c_int, [ctypes.c_void_p, c_int32_p, c_int32_p]),
     ('mvus_ba_set_fd_groups', ctypes.c_int, [ctypes.c_void_p, c_int32_p, ctypes.c_int32]),
     ('mvus_ba_jv', ctypes.c_int, [ctypes.c_void_p, c_double_p, c_double_p]),
     ('mvus_ba_jtu', ctypes.c_int, [ctypes.c_void_p, c_double_p, c_double_p]),
@@ -132,6 +135,7 @@ def make_problem_struct(prob, device=0, stream=None):
     s.rs_bounds = int(prob.rs_bounds)
     s.motion_reg = int(prob.motion_reg)
     s.motion_type = int(prob.motion_type)
+    s.opt_sync = int(getattr(prob, 'opt_sync', True))
     s.motion_weight = float(prob.motion_weight)
     s.det_offsets = keep['det_offsets'].ctypes.data_as(c_int64_p)
     for k in ('frame', 'u_raw', 'v_raw', 'img_height', 'K', 'dist', 'interval', 'knots'):

@@ -88,10 +88,30 @@ class BAHandle:
         return mf, mJ, mctrl
 
     def set_pattern(self, x0):
+        """Canonical pattern codes of the detection rows at x0, computed on the GPU (tie rows carry ``_lib.PAT_TIE``)."""
         x0 = self._x(x0, self.n)
         pat = np.empty(self.M, dtype=np.int32)
         self._check(self.lib.mvus_ba_set_pattern(self.h, _lib.dptr(x0), pat.ctypes.data_as(_lib.c_int32_p)), 'mvus_ba_set_pattern')
         return pat
+
+    def motion_pattern(self):
+        mp = np.empty(self.T, dtype=np.int32)
+        self._check(self.lib.mvus_ba_motion_pattern(self.h, mp.ctypes.data_as(_lib.c_int32_p)), 'mvus_ba_motion_pattern')
+        return mp
+
+    def upload_pattern(self, pat, motion_pat=None):
+        """Supply the pattern (codes of include/mvus_ba.h) instead of the GPU's canonical one -- the reference's matrix is
+        an input of the call this library replaces (common.py:670)."""
+        pat = np.ascontiguousarray(pat, dtype=np.int32)
+        if pat.shape != (self.M,):
+            raise ValueError('pat has shape %s, expected (%d,)' % (pat.shape, self.M))
+        mp = None
+        if motion_pat is not None and self.T:
+            mp = np.ascontiguousarray(motion_pat, dtype=np.int32)
+            if mp.shape != (self.T,):
+                raise ValueError('motion_pat has shape %s, expected (%d,)' % (mp.shape, self.T))
+        self._check(self.lib.mvus_ba_upload_pattern(self.h, pat.ctypes.data_as(_lib.c_int32_p),
+                                                    mp.ctypes.data_as(_lib.c_int32_p) if mp is not None else None), 'mvus_ba_upload_pattern')
 
     def set_fd_groups(self, groups, num_groups):
         groups = np.ascontiguousarray(groups, dtype=np.int32)
@@ -100,11 +120,23 @@ class BAHandle:
         self._check(self.lib.mvus_ba_set_fd_groups(self.h, groups.ctypes.data_as(_lib.c_int32_p), int(num_groups)),
                     'mvus_ba_set_fd_groups')
 
-    def prepare_fd(self, x0):
-        """Set-up for JAC_FD at x0: the reference pattern on the GPU, scipy's column grouping on the host."""
+    def prepare_pattern(self, x0, ties='numpy', matrix=None):
+        """The reference pattern at x0 in force on the handle: canonical codes from the GPU, the twin rows decided
+        by ``ties`` ('numpy': like np.argsort of this process, what the reference would build here; 'canonical': the
+        library's choice), or -- ``matrix`` -- the codes a given reference matrix implies.  Returns (pat, motion_pat)."""
         from . import pattern
-        pat = self.set_pattern(x0)
-        groups, ng = pattern.fd_groups(self.prob, pat)
+        if matrix is not None:
+            pat, mpat = pattern.codes_from_matrix(self.prob, matrix)
+        else:
+            pat, mpat = pattern.resolve_ties(self.prob, x0, self.set_pattern(x0), self.motion_pattern() if self.T else None, how=ties)
+        self.upload_pattern(pat, mpat if self.T else None)
+        return pat, (mpat if self.T else None)
+
+    def prepare_fd(self, x0, ties='numpy', matrix=None):
+        """Set-up for JAC_FD at x0: the reference pattern (see prepare_pattern), scipy's column grouping on the host."""
+        from . import pattern
+        pat, mpat = self.prepare_pattern(x0, ties, matrix)
+        groups, ng = pattern.fd_groups(self.prob, pat, mpat)
         self.set_fd_groups(groups, ng)
         return ng
 
@@ -139,13 +171,17 @@ class BAHandle:
         self._check(self.lib.mvus_ba_lm_step(self.h, float(lam), _lib.dptr(p)), 'mvus_ba_lm_step')
         return p
 
-    def solve(self, x0, solver=SOLVER_TRF_LSMR, jac_mode=JAC_PATTERN, max_nfev=10, opts=None, return_fun=True):
+    def solve(self, x0, solver=SOLVER_TRF_LSMR, jac_mode=JAC_PATTERN, max_nfev=10, opts=None, return_fun=True,
+              ties='numpy', matrix=None):
         """The least_squares call of Scene.BA.  Returns an OptimizeResult-like namespace
-        (x, cost, fun, nfev, njev, status, optimality, ...)."""
+        (x, cost, fun, nfev, njev, status, optimality, ...).  ``ties`` / ``matrix``: how the reference pattern of the
+        JAC_PATTERN / JAC_FD modes is fixed at x0 (see prepare_pattern)."""
         x = np.array(self._x(x0, self.n))
         o = opts if opts is not None else _lib.default_opts(solver, jac_mode, max_nfev)
         if o.jac_mode == JAC_FD:
-            self.prepare_fd(x)
+            self.prepare_fd(x, ties, matrix)
+        elif o.jac_mode == JAC_PATTERN:
+            self.prepare_pattern(x, ties, matrix)
         res = _lib.MvusResult()
         f = np.empty(self.m) if return_fun else None
         self._check(self.lib.mvus_ba_solve(self.h, _lib.dptr(x), ctypes.byref(o), ctypes.byref(res),
@@ -216,4 +252,4 @@ class BAHandle:
 
 
 # kernel ids of mvus_ba_time_kernel
-KERNEL_RESIDUAL, KERNEL_RESIDUAL_JACOBIAN, KERNEL_JV, KERNEL_JTU, KERNEL_ASSEMBLY = 0, 1, 2, 3, 4
+KERNEL_RESIDUAL, KERNEL_RESIDUAL_JACOBIAN, KERNEL_JV, KERNEL_JTU, KERNEL_ASSEMBLY, KERNEL_RESIDUAL_JACOBIAN_ONE_BUFFER = 0, 1, 2, 3, 4, 5

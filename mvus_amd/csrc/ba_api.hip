@@ -31,6 +31,10 @@ struct HipBackend {
   double *J = nullptr, *mJ = nullptr, *x_cur = nullptr, *f_cur = nullptr;
   int32_t *span = nullptr, *pat0 = nullptr, *mctrl = nullptr;
   bool has_pattern = false, has_jacobian = false;
+  bool pattern_uploaded = false;     // the caller supplied the reference's pattern (mvus_ba_upload_pattern): solve keeps it
+  int32_t* ms_pat_dev = nullptr;
+  double* det_alt[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // second set of detection arrays (remove_outliers ping-pong)
+  int64_t det_capacity = 0;
   // reductions
   double *partials = nullptr, *scal_dev = nullptr, *scal_host = nullptr;
   // multi-GPU
@@ -68,7 +72,8 @@ struct HipBackend {
     if (p->stream) stream = static_cast<hipStream_t>(p->stream);
     else { MVUS_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking)); own_stream = true; }
     dp.C = hp.C; dp.P = hp.P; dp.NS = hp.NS; dp.S = hp.S; dp.calib = hp.calib; dp.undist = hp.undist;
-    dp.rs_free = hp.rs_free; dp.T = hp.T; dp.M = hp.M; dp.N = hp.N;
+    dp.rs_free = hp.rs_free; dp.sync_free = hp.sync_free; dp.T = hp.T; dp.M = hp.M; dp.N = hp.N;
+    det_capacity = std::max<int64_t>(hp.M, 1);
     dp.frame = dupload(hp.frame); dp.u_raw = dupload(hp.u_raw); dp.v_raw = dupload(hp.v_raw);
     dp.H = dupload(hp.H); dp.Kfix = dupload(hp.K); dp.dfix = dupload(hp.dist);
     dp.sp.S = hp.S; dp.sp.istart = dupload(hp.istart); dp.sp.iend = dupload(hp.iend); dp.sp.knots = dupload(hp.knots);
@@ -76,7 +81,7 @@ struct HipBackend {
     dp.sp.lut = dupload(hp.lut); dp.sp.lut_off = dupload(hp.lut_off); dp.sp.lut_scale = dupload(hp.lut_scale);
     dp.mv.T = hp.T; dp.mv.type = hp.motion_type; dp.mv.w = hp.w;
     dp.mv.t = dupload(hp.ms_t); dp.mv.basis = dupload(hp.ms_basis); dp.mv.ctrl = dupload(hp.ms_ctrl);
-    dp.mv.part = dupload(hp.ms_part); dp.mv.pat = dupload(hp.ms_pat);
+    dp.mv.part = dupload(hp.ms_part); ms_pat_dev = dupload(hp.ms_pat); dp.mv.pat = ms_pat_dev;
     dp.mv.ctrl_x0 = dupload(hp.ctrl_x0); dp.mv.ctrl_stride = dupload(hp.ctrl_stride);
     dp.chunk_cam = dupload(hp.chunk_cam); dp.chunk_count = dupload(hp.chunk_count);
     std::vector<long long> cs(hp.chunk_start.begin(), hp.chunk_start.end()), doff(hp.det_off.begin(), hp.det_off.end());
@@ -86,7 +91,6 @@ struct HipBackend {
     double* uo = dalloc<double>(hp.M); double* vo = dalloc<double>(hp.M);
     dp.u_obs = uo; dp.v_obs = vo;
     cams = dalloc<CamState>(hp.C);
-    J = dalloc<double>((size_t)2 * hp.NS * hp.M);
     span = dalloc<int32_t>(hp.M); pat0 = dalloc<int32_t>(hp.M);
     mJ = dalloc<double>((size_t)36 * hp.T); mctrl = dalloc<int32_t>((size_t)3 * hp.T);
     x_cur = dalloc<double>(hp.n); f_cur = dalloc<double>(hp.m);
@@ -209,7 +213,10 @@ struct HipBackend {
   double dot_n(const double* a, const double* b, int64_t len) { dot_to_slot(a, b, len, 0); return read_slot(0); }
   double dot_m(const double* a, const double* b) { dot_to_slot(a, b, hp.m, 1); reduce(scal_dev + 1, 1); return read_slot(1); }
 
+  // the slot Jacobian (2*NS*M doubles) is allocated on first use: residual-only handles (Scene.error_cam, outlier masks) never pay for it
+  void ensure_J() { if (!J) J = dalloc<double>((size_t)2 * hp.NS * std::max<int64_t>(hp.M, 1)); }
   void eval(const double* x, double* f, bool jac, int jac_mode) {
+    if (jac) ensure_J();
     const bool masked = jac && jac_mode == MVUS_JAC_PATTERN;
     if (masked && !has_pattern) throw HipError{"MVUS_JAC_PATTERN needs mvus_ba_set_pattern (or solve) first"};
     hipLaunchKernelGGL(k_cam_states, dim3((hp.C + 63) / 64), dim3(64), 0, stream, dp, x, cams);
@@ -253,6 +260,7 @@ struct HipBackend {
   void jacobian_fd(const double* x, double* f) {
     if (!has_pattern || fd_ngroups <= 0) throw HipError{"MVUS_JAC_FD needs mvus_ba_set_pattern and mvus_ba_set_fd_groups first"};
     const int n = (int)hp.n;
+    ensure_J();
     eval(x, f, false, 0);
     hipLaunchKernelGGL(k_fd_steps, dim3((n + 255) / 256), dim3(256), 0, stream, n, hp.C, hp.rs_bounds, x, fd_h, fd_dx);
     for (int g = 0; g < fd_ngroups; ++g) {
@@ -296,8 +304,12 @@ struct HipBackend {
       for (int k = 0; k < nc; ++k) { off_h[k] = run; run += cnt_h[k]; new_off[hp.chunk_cam[k] + 1] += cnt_h[k]; }
       for (int c = 0; c < hp.C; ++c) new_off[c + 1] += new_off[c];
       const int64_t newM = run;
-      double* nf = dalloc<double>(newM); double* nu = dalloc<double>(newM); double* nv = dalloc<double>(newM);
-      double* nuo = dalloc<double>(newM); double* nvo = dalloc<double>(newM);
+      // the compacted copy goes into a second set of detection arrays (allocated once, sized for the original problem);
+      // the two sets swap roles on every call
+      if (!det_alt[0]) for (double*& p : det_alt) p = dalloc<double>(det_capacity);
+      double *nf = det_alt[0], *nu = det_alt[1], *nv = det_alt[2], *nuo = det_alt[3], *nvo = det_alt[4];
+      det_alt[0] = const_cast<double*>(dp.frame); det_alt[1] = const_cast<double*>(dp.u_raw); det_alt[2] = const_cast<double*>(dp.v_raw);
+      det_alt[3] = const_cast<double*>(dp.u_obs); det_alt[4] = const_cast<double*>(dp.v_obs);
       if (nc > 0) {
         MVUS_HIP(hipMemcpyAsync(off_d, off_h.data(), sizeof(long long) * nc, hipMemcpyHostToDevice, stream));
         hipLaunchKernelGGL(k_compact_scatter, dim3(nc), dim3(kThreads), 0, stream, dp, keep, off_d, nf, nu, nv, nuo, nvo);
@@ -315,12 +327,20 @@ struct HipBackend {
         }
       dp.frame = nf; dp.u_raw = nu; dp.v_raw = nv; dp.u_obs = nuo; dp.v_obs = nvo;
       dp.M = newM;
-      dp.chunk_cam = dupload(hp.chunk_cam); dp.chunk_count = dupload(hp.chunk_count);
+      // the launch tables shrink (never more chunks per camera than before): rewritten in place
       std::vector<long long> cs(hp.chunk_start.begin(), hp.chunk_start.end()), doff(hp.det_off.begin(), hp.det_off.end());
-      dp.chunk_start = dupload(cs); dp.det_off = dupload(doff);
-      dp.n_chunks = (int)hp.chunk_cam.size();
+      const size_t nck = hp.chunk_cam.size();
+      if (nck > 0) {
+        MVUS_HIP(hipMemcpyAsync(const_cast<int32_t*>(dp.chunk_cam), hp.chunk_cam.data(), nck * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+        MVUS_HIP(hipMemcpyAsync(const_cast<int32_t*>(dp.chunk_count), hp.chunk_count.data(), nck * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+        MVUS_HIP(hipMemcpyAsync(const_cast<long long*>(dp.chunk_start), cs.data(), nck * sizeof(long long), hipMemcpyHostToDevice, stream));
+      }
+      MVUS_HIP(hipMemcpyAsync(const_cast<long long*>(dp.det_off), doff.data(), doff.size() * sizeof(long long), hipMemcpyHostToDevice, stream));
+      dp.n_chunks = (int)nck;
       MVUS_HIP(hipStreamSynchronize(stream));
       has_pattern = false; has_jacobian = false; fd_ngroups = 0;
+      if (pattern_uploaded && hp.T > 0) MVUS_HIP(hipMemcpyAsync(ms_pat_dev, hp.ms_pat.data(), sizeof(int32_t) * hp.T, hipMemcpyHostToDevice, stream));
+      pattern_uploaded = false;
       m_glob = hp.m;
       if (det_off_out) std::memcpy(det_off_out, new_off.data(), sizeof(int64_t) * (hp.C + 1));
     } catch (...) { cleanup(); throw; }
@@ -331,7 +351,26 @@ struct HipBackend {
     hipLaunchKernelGGL(k_cam_states, dim3((hp.C + 63) / 64), dim3(64), 0, stream, dp, x0_dev, cams);
     if (dp.n_chunks > 0) hipLaunchKernelGGL(k_pattern, dim3(dp.n_chunks), dim3(kThreads), 0, stream, dp, cams, pat0);
     MVUS_HIP(hipGetLastError());
-    has_pattern = true;
+    if (pattern_uploaded && hp.T > 0)      // back to the canonical motion-row codes
+      MVUS_HIP(hipMemcpyAsync(ms_pat_dev, hp.ms_pat.data(), sizeof(int32_t) * hp.T, hipMemcpyHostToDevice, stream));
+    has_pattern = true; pattern_uploaded = false;
+  }
+  // every point of a code must be a control point of ONE spline
+  bool code_ok(int32_t code) const {
+    if (code < 0) return code == -1;
+    const int p = pattern_index(code), mk = pattern_mask(code);
+    if (mk == 0 || p >= hp.N) return false;
+    int top = 3; while (!((mk >> top) & 1)) --top;
+    return p + top < hp.N && hp.ctrl_x0[p + top] == hp.ctrl_x0[p] + top;
+  }
+  std::string upload_pattern(const int32_t* pat, const int32_t* mpat) {
+    for (int64_t i = 0; i < hp.M; ++i) if (!code_ok(pat[i])) return "upload_pattern: bad code in detection row " + std::to_string(i);
+    if (hp.T > 0 && mpat) for (int j = 0; j < hp.T; ++j) if (mpat[j] < 0 || !code_ok(mpat[j])) return "upload_pattern: bad code in motion row " + std::to_string(j);
+    if (hp.M > 0) MVUS_HIP(hipMemcpyAsync(pat0, pat, sizeof(int32_t) * hp.M, hipMemcpyHostToDevice, stream));
+    if (hp.T > 0 && mpat) MVUS_HIP(hipMemcpyAsync(ms_pat_dev, mpat, sizeof(int32_t) * hp.T, hipMemcpyHostToDevice, stream));
+    MVUS_HIP(hipStreamSynchronize(stream));
+    has_pattern = true; pattern_uploaded = true; has_jacobian = false;
+    return "";
   }
 
   void jv(const double* v, double* y) {
@@ -393,9 +432,16 @@ void mvus_default_opts(mvus_solve_opts* o) {
 int mvus_ba_create(const mvus_problem* p, mvus_ba** out) {
   if (!out) return MVUS_E_INVALID;
   *out = nullptr;
-  mvus_ba* h = new mvus_ba();
-  std::string msg = h->be.hp.build(p);
-  if (!msg.empty()) { g_create_error = msg; delete h; return MVUS_E_INVALID; }
+  mvus_ba* h = nullptr;
+  try {
+    h = new mvus_ba();
+    std::string msg = h->be.hp.build(p);
+    if (!msg.empty()) { g_create_error = msg; delete h; return MVUS_E_INVALID; }
+  } catch (const std::exception& e) {          // bad_alloc / length_error on absurd sizes: nothing throws across the ABI
+    g_create_error = e.what();
+    delete h;
+    return MVUS_E_INVALID;
+  }
   try {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= p->device)
@@ -405,6 +451,10 @@ int mvus_ba_create(const mvus_problem* p, mvus_ba** out) {
     g_create_error = e.msg;
     delete h;
     return MVUS_E_HIP;
+  } catch (const std::exception& e) {
+    g_create_error = e.what();
+    delete h;
+    return MVUS_E_INVALID;
   }
   *out = h;
   return MVUS_OK;
@@ -438,7 +488,7 @@ int mvus_ba_residual_jacobian(mvus_ba* h, const double* x, int32_t jac_mode, dou
     HipBackend& be = h->be;
     be.upload(be.x_cur, x, be.hp.n);
     // rows that stay invisible are never written by the kernel: clear so the host copy is well defined
-    if (J) MVUS_HIP(hipMemsetAsync(be.J, 0, sizeof(double) * 2 * be.hp.NS * be.hp.M, be.stream));
+    if (J) { be.ensure_J(); MVUS_HIP(hipMemsetAsync(be.J, 0, sizeof(double) * 2 * be.hp.NS * be.hp.M, be.stream)); }
     be.jacobian(be.x_cur, be.f_cur, jac_mode);
     if (f) be.download(f, be.f_cur, be.hp.m);
     if (J) be.download(J, be.J, (int64_t)2 * be.hp.NS * be.hp.M);
@@ -473,6 +523,28 @@ int mvus_ba_set_pattern(mvus_ba* h, const double* x0, int32_t* pat_out) {
     be.set_pattern(be.x_cur);
     if (pat_out) {
       MVUS_HIP(hipMemcpyAsync(pat_out, be.pat0, sizeof(int32_t) * be.hp.M, hipMemcpyDeviceToHost, be.stream));
+      MVUS_HIP(hipStreamSynchronize(be.stream));
+    }
+    return MVUS_OK;
+  });
+}
+
+int mvus_ba_upload_pattern(mvus_ba* h, const int32_t* pat, const int32_t* motion_pat) {
+  return guarded(h, [&] {
+    HipBackend& be = h->be;
+    if ((!pat && be.hp.M > 0)) { be.err = "upload_pattern: NULL pattern"; return MVUS_E_INVALID; }
+    const std::string msg = be.upload_pattern(pat, motion_pat);
+    if (!msg.empty()) { be.err = msg; return MVUS_E_INVALID; }
+    return MVUS_OK;
+  });
+}
+
+int mvus_ba_motion_pattern(mvus_ba* h, int32_t* motion_pat_out) {
+  return guarded(h, [&] {
+    HipBackend& be = h->be;
+    if (be.hp.T > 0) {
+      if (!motion_pat_out) { be.err = "motion_pattern: NULL output"; return MVUS_E_INVALID; }
+      MVUS_HIP(hipMemcpyAsync(motion_pat_out, be.ms_pat_dev, sizeof(int32_t) * be.hp.T, hipMemcpyDeviceToHost, be.stream));
       MVUS_HIP(hipStreamSynchronize(be.stream));
     }
     return MVUS_OK;
@@ -549,7 +621,7 @@ int mvus_ba_solve(mvus_ba* h, double* x, const mvus_solve_opts* opts, mvus_resul
     so.jac_mode = opts->jac_mode; so.max_nfev = opts->max_nfev; so.ftol = opts->ftol; so.xtol = opts->xtol; so.gtol = opts->gtol;
     so.lsmr_atol = opts->lsmr_atol; so.lsmr_btol = opts->lsmr_btol; so.lsmr_conlim = opts->lsmr_conlim;
     so.lsmr_maxiter = opts->lsmr_maxiter; so.verbose = opts->verbose;
-    if (so.jac_mode == MVUS_JAC_PATTERN) {
+    if (so.jac_mode == MVUS_JAC_PATTERN && !be.pattern_uploaded) {
       be.upload(be.x_cur, xv.data(), n);
       be.set_pattern(be.x_cur);
     }
@@ -564,6 +636,7 @@ int mvus_ba_solve(mvus_ba* h, double* x, const mvus_solve_opts* opts, mvus_resul
       so.lm_lambda0 = be.lm_lambda; so.lm_nu0 = be.lm_nu;
       sr = lm_schur(be, *h->schur, xv, lb, ub, so, be.f_cur);
       if (!sr.error) { be.lm_lambda = std::min(std::max(sr.lm_lambda, 1e-12), 1e6); be.lm_nu = std::min(sr.lm_nu, 1024.0); }
+      if (sr.jac_stale) be.has_jacobian = false;      // mvus_ba_jv / jtu / lm_step must not pair J(x_old) with f(x_new)
     }
     else sr = trf_lsmr(be, xv, lb, ub, so, be.f_cur);
     if (sr.error) { be.err = "residuals are not finite in the initial point, or x0 is outside of the bounds"; return MVUS_E_NUMERIC; }
@@ -646,16 +719,40 @@ int mvus_ba_set_time_shard(mvus_ba* h, int32_t rank, int32_t world, const int32_
 int mvus_ba_time_kernel(mvus_ba* h, int32_t which, int32_t launches, double* avg_ms) {
   return guarded(h, [&] {
     HipBackend& be = h->be;
-    if (launches < 1 || !avg_ms) { be.err = "bad arguments"; return MVUS_E_INVALID; }
+    if (launches < 1 || !avg_ms || which < 0 || which > 5) { be.err = "bad arguments"; return MVUS_E_INVALID; }
+    be.ensure_J();
     hipEvent_t e0, e1;
     MVUS_HIP(hipEventCreate(&e0)); MVUS_HIP(hipEventCreate(&e1));
-    double* vn = be.alloc(be.hp.n); double* um = be.alloc(be.hp.m); double* zn = be.alloc(be.hp.n); double* ym = be.alloc(be.hp.m);
+    PoolGuard<HipBackend> pool(be);
+    double* vn = pool.get(be.hp.n); double* um = pool.get(be.hp.m); double* zn = pool.get(be.hp.n); double* ym = pool.get(be.hp.m);
     be.fill(vn, 1e-3, be.hp.n); be.fill(um, 1e-3, be.hp.m);
     hipLaunchKernelGGL(k_cam_states, dim3((be.hp.C + 63) / 64), dim3(64), 0, be.stream, be.dp, be.x_cur, be.cams);
-    if (which >= 2 && !be.has_jacobian) be.jacobian(be.x_cur, be.f_cur, MVUS_JAC_ANALYTIC);
+    if (which >= 2 && which <= 4 && !be.has_jacobian) be.jacobian(be.x_cur, be.f_cur, MVUS_JAC_ANALYTIC);
     const dim3 g(std::max(be.dp.n_chunks, 1)), b(kThreads);
-    if (which >= 4 && !h->schur) h->schur.reset(new HipSchur<HipBackend>(be));
+    if (which == 4 && !h->schur) h->schur.reset(new HipSchur<HipBackend>(be));
     HipSchur<HipBackend>* schur = h->schur.get();
+    // which == 1: the outputs (J, span, f) rotate over enough buffer sets that the bytes written between two uses of a
+    // set exceed the 256 MiB Infinity Cache several times -- every launch writes to HBM, not into lines the previous
+    // launch left in the cache.  which == 5 is the same kernel re-launched into ONE set, for comparison.
+    struct OutSet { double* J; int32_t* span; double* f; };
+    std::vector<OutSet> sets{{be.J, be.span, be.f_cur}};
+    std::vector<void*> extra;
+    auto free_extra = [&]() { for (void* p : extra) (void)hipFree(p); extra.clear(); };
+    if (which == 1) {
+      const size_t jb = sizeof(double) * 2 * (size_t)be.hp.NS * (size_t)std::max<int64_t>(be.hp.M, 1);
+      const size_t want = (size_t)1 << 30;                                   // >= 1 GiB in rotation (4x the Infinity Cache)
+      const int nrot = (int)std::min<size_t>(16, std::max<size_t>(3, (want + jb - 1) / jb));
+      for (int r = 1; r < nrot; ++r) {
+        void *pj = nullptr, *ps = nullptr, *pf = nullptr;
+        hipError_t e = hipMalloc(&pj, jb);
+        if (e == hipSuccess) { extra.push_back(pj); e = hipMalloc(&ps, sizeof(int32_t) * std::max<int64_t>(be.hp.M, 1)); }
+        if (e == hipSuccess) { extra.push_back(ps); e = hipMalloc(&pf, sizeof(double) * std::max<int64_t>(be.hp.m, 1)); }
+        if (e == hipSuccess) extra.push_back(pf);
+        if (e != hipSuccess) { free_extra(); MVUS_HIP(e); }
+        sets.push_back({static_cast<double*>(pj), static_cast<int32_t*>(ps), static_cast<double*>(pf)});
+      }
+    }
+    int turn = 0;
     auto launch = [&]() {
       switch (which) {
         case 0:
@@ -663,9 +760,13 @@ int mvus_ba_time_kernel(mvus_ba* h, int32_t which, int32_t launches, double* avg
           else hipLaunchKernelGGL((k_observations<false, false>), g, b, 0, be.stream, be.dp, be.cams, be.x_cur, be.f_cur, be.J, be.span, be.pat0, 0);
           break;
         case 1:
-          if (be.hp.calib) hipLaunchKernelGGL((k_observations<true, true>), g, b, 0, be.stream, be.dp, be.cams, be.x_cur, be.f_cur, be.J, be.span, be.pat0, 0);
-          else hipLaunchKernelGGL((k_observations<false, true>), g, b, 0, be.stream, be.dp, be.cams, be.x_cur, be.f_cur, be.J, be.span, be.pat0, 0);
+        case 5: {
+          const OutSet& o = sets[turn];
+          turn = (turn + 1) % (int)sets.size();
+          if (be.hp.calib) hipLaunchKernelGGL((k_observations<true, true>), g, b, 0, be.stream, be.dp, be.cams, be.x_cur, o.f, o.J, o.span, be.pat0, 0);
+          else hipLaunchKernelGGL((k_observations<false, true>), g, b, 0, be.stream, be.dp, be.cams, be.x_cur, o.f, o.J, o.span, be.pat0, 0);
           break;
+        }
         case 2:
           if (be.hp.calib) hipLaunchKernelGGL(k_jv<30>, g, b, 0, be.stream, be.dp, be.J, be.span, vn, ym);
           else hipLaunchKernelGGL(k_jv<21>, g, b, 0, be.stream, be.dp, be.J, be.span, vn, ym);
@@ -678,18 +779,23 @@ int mvus_ba_time_kernel(mvus_ba* h, int32_t which, int32_t launches, double* avg
           schur->assemble_local(be.f_cur);
       }
     };
-    if (be.dp.n_chunks == 0) { *avg_ms = 0; return MVUS_OK; }
-    launch();
-    MVUS_HIP(hipEventRecord(e0, be.stream));
-    for (int i = 0; i < launches; ++i) launch();
-    MVUS_HIP(hipEventRecord(e1, be.stream));
-    MVUS_HIP(hipEventSynchronize(e1));
+    if (be.dp.n_chunks == 0) { *avg_ms = 0; free_extra(); return MVUS_OK; }
     float ms = 0;
-    MVUS_HIP(hipEventElapsedTime(&ms, e0, e1));
+    try {
+      for (size_t w = 0; w < sets.size(); ++w) launch();                       // warm-up: every set touched once
+      MVUS_HIP(hipEventRecord(e0, be.stream));
+      for (int i = 0; i < launches; ++i) launch();
+      MVUS_HIP(hipEventRecord(e1, be.stream));
+      MVUS_HIP(hipEventSynchronize(e1));
+      MVUS_HIP(hipEventElapsedTime(&ms, e0, e1));
+      MVUS_HIP(hipGetLastError());
+    } catch (...) { free_extra(); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); throw; }
     *avg_ms = (double)ms / launches;
-    be.release(vn); be.release(um); be.release(zn); be.release(ym);
+    free_extra();
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    be.has_jacobian = which >= 1 ? true : be.has_jacobian;
+    if (which == 1 || which == 5) {            // the handle's own set holds J(x_cur) again (set 0 was written by one of the launches)
+      be.has_jacobian = true;
+    }
     return MVUS_OK;
   });
 }

@@ -32,7 +32,7 @@ struct HipError { std::string msg; };
   } while (0)
 
 struct DevProblem {  // trivially copyable: passed to kernels by value
-  int C, P, NS, S, calib, undist, rs_free, T, N;
+  int C, P, NS, S, calib, undist, rs_free, sync_free, T, N;
   long long M;
   const double *frame, *u_raw, *v_raw, *u_obs, *v_obs, *H, *Kfix, *dfix;
   SplineView sp;
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(kThreads) void k_observations(DevProblem dp, const 
   double jx[NS], jy[NS];
   const double uo = CALIB ? 0.0 : dp.u_obs[i], vo = CALIB ? 0.0 : dp.v_obs[i];
   const double ur = CALIB ? dp.u_raw[i] : 0.0;
-  ObsResult r = eval_observation<CALIB, JAC>(cam, dp.sp, x, dp.undist != 0, dp.rs_free != 0, dp.frame[i], ur, dp.v_raw[i],
+  ObsResult r = eval_observation<CALIB, JAC>(cam, dp.sp, x, dp.undist != 0, dp.rs_free != 0, dp.sync_free != 0, dp.frame[i], ur, dp.v_raw[i],
                                              uo, vo, jx, jy);
   f[2 * a + (i - a)] = r.ex;
   f[2 * a + Mc + (i - a)] = r.ey;
@@ -551,16 +551,14 @@ __global__ __launch_bounds__(kThreads) void k_fd_fill(DevProblem dp, long long m
   span[i] = p;
   if (p < 0) return;
   const double fx = f0[rx], fy = f0[ry];
-  // the row stores 4 consecutive control points base..base+3; the pattern triple p..p+2 sits at offset p-base
-  // (base = p unless the triple ends the spline, where a 4th point p+3 does not exist)
-  const bool room = (p + 3 < dp.N) && (dp.mv.ctrl_x0[p + 3] == dp.mv.ctrl_x0[p] + 3);
-  const int base = room ? p : p - 1, off = p - base;
+  // the row stores 4 consecutive control points base..base+3 of one spline; the pattern's points are among them
+  const int base = pattern_fd_base(p, dp.N, dp.mv.ctrl_x0);
   span[i] = base;
   const int x0 = dp.mv.ctrl_x0[base], st = dp.mv.ctrl_stride[base];
   for (int k = 0; k < NS; ++k) {
     int col = -1;
-    if (k < B) { if (!(k == 2 && !dp.rs_free)) col = cam_col(dp.C, dp.P, c, k); }
-    else { const int q = (k - B) / 3, d = (k - B) % 3; if (q >= off && q < off + 3) col = x0 + q + d * st; }
+    if (k < B) { if (!(k == 2 && !dp.rs_free) && !(k < 2 && !dp.sync_free)) col = cam_col(dp.C, dp.P, c, k); }
+    else { const int q = (k - B) / 3, d = (k - B) % 3; if (pattern_has(p, base + q)) col = x0 + q + d * st; }
     double jx = 0.0, jy = 0.0;
     if (col >= 0) {
       const double* Fg = F + (long long)groups[col] * m;
@@ -579,17 +577,18 @@ __global__ __launch_bounds__(kThreads) void k_fd_fill_motion(DevProblem dp, long
   for (int k = 0; k < 36; ++k) mJ[(long long)k * dp.T + j] = 0.0;
   mctrl[j] = -1; mctrl[(long long)2 * dp.T + j] = -1;
   if (dp.mv.part[j] < 0) { mctrl[(long long)dp.T + j] = -1; return; }     // row is identically zero
-  const int pc = dp.mv.ctrl[j] + dp.mv.pat[j];
-  const bool room = (pc + 3 < dp.N) && (dp.mv.ctrl_x0[pc + 3] == dp.mv.ctrl_x0[pc] + 3);
-  const int base = room ? pc : pc - 1, off = pc - base;
+  const int pc = dp.mv.pat[j];
+  const int base = pattern_fd_base(pc, dp.N, dp.mv.ctrl_x0);
   mctrl[(long long)dp.T + j] = base;
   const long long row = 2 * dp.M + j;
   const int x0 = dp.mv.ctrl_x0[base], st = dp.mv.ctrl_stride[base];
-  for (int q = off; q < off + 3; ++q)
+  for (int q = 0; q < 4; ++q) {
+    if (!pattern_has(pc, base + q)) continue;
     for (int d = 0; d < 3; ++d) {
       const int col = x0 + q + d * st;
       mJ[(long long)(12 + 3 * q + d) * dp.T + j] = (F[(long long)groups[col] * m + row] - f0[row]) / dx[col];
     }
+  }
 }
 
 // ---- in-place removal of outliers (stable stream compaction per chunk) ----------------------------------------

@@ -227,7 +227,7 @@ struct ObsResult {
 //   jx/jy : NS values each (see slot layout above); untouched when the observation is not visible.
 //   u_obs/v_obs: observed pixel when calibration is fixed (undistorted once at create time).
 template <bool CALIB, bool JAC>
-MVUS_HD ObsResult eval_observation(const CamState& cam, const SplineView& sp, const double* x, bool undist, bool rs_free,
+MVUS_HD ObsResult eval_observation(const CamState& cam, const SplineView& sp, const double* x, bool undist, bool rs_free, bool sync_free,
                                    double frame, double u_raw, double v_raw, double u_obs, double v_obs,
                                    double* jx, double* jy) {
   ObsResult out;
@@ -290,8 +290,9 @@ MVUS_HD ObsResult eval_observation(const CamState& cam, const SplineView& sp, co
   const double dta = frame + row;                       // d tau / d alpha
   const double dtr = rs_free ? cam.alpha * v_raw / cam.H : 0.0;   // d tau / d rs (column absent from the
                                                                   // reference pattern when rs=False, common.py:518-521)
-  jx[0] = dtu * dta; jx[1] = dtu; jx[2] = dtu * dtr;
-  jy[0] = dtv * dta; jy[1] = dtv; jy[2] = dtv * dtr;
+  const double sf = sync_free ? 1.0 : 0.0;               // opt_sync off: alpha, beta leave the pattern (common.py:512-515)
+  jx[0] = sf * dtu * dta; jx[1] = sf * dtu; jx[2] = dtu * dtr;
+  jy[0] = sf * dtv * dta; jy[1] = sf * dtv; jy[2] = dtv * dtr;
   // rotation vector: d Xc / d r = -[y]x W  ->  row a gives (y x a)^T W
   const double cu0 = y1 * au2 - y2 * 0.0, cu1 = y2 * au0 - y0 * au2, cu2 = y0 * 0.0 - y1 * au0;   // y x au, au = (au0,0,au2)
   const double cv0 = y1 * av2 - y2 * av1, cv1 = y2 * 0.0 - y0 * av2, cv2 = y0 * av1 - y1 * 0.0;   // y x av, av = (0,av1,av2)
@@ -335,15 +336,48 @@ MVUS_HD ObsResult eval_observation(const CamState& cam, const SplineView& sp, co
 }
 
 // Reference sparsity pattern for the spline columns of one row (common.py:559-563): the three
-// coefficients whose centre knots t[2:-2] are nearest to tau.  For tau in span l these are three of the
-// four active coefficients l-3..l -- the farther of the first (centre t[l-1]) and last (centre t[l+2])
-// is dropped.  Returns the index (0 or 1) of the first kept coefficient relative to l-3.
-MVUS_HD int pattern_first_kept(const double* t, int l, double tau) {
-  return ((tau - t[l - 1]) > (t[l + 2] - tau)) ? 1 : 0;
+// coefficients whose centre knots c_j = t[j+2] (`knot = t[2:-2]`) are nearest to tau.  On FITPACK-like knot
+// vectors these are three of the four active coefficients, but nothing in the reference enforces that: with a
+// strongly non-uniform knot spacing the window can hold an inactive coefficient, and it does so here too.
+// Pattern code of one row: the in-pattern control points as  p | (mask << 25)  with p the global index of the
+// lowest one and bit k of the 4-bit mask set when p + k is in the pattern (-1 = all-zero row).  The canonical
+// nearest-three rule gives three consecutive points (mask 0b0111).  Two centre knots are repeated in t[2:-2]
+// (coefficients 0,1 share the interval start, n-2,n-1 its end); when exactly one of such twins is among the three
+// nearest, which one np.argsort returns is decided by numpy's sort kernel (it differs between the scalar, AVX2
+// and AVX512 builds), so the reference's pattern is implementation defined in those rows: {0,2,3} (mask 0b1101)
+// or {1,2,3}, {n-4,n-3,n-1} (0b1011) or {n-4,n-3,n-2}.  The kernels compute the canonical code (the twin that is
+// an ACTIVE coefficient) and flag the row with kPatTie; a caller that holds the reference's own matrix -- it is
+// an input of the least_squares call, common.py:670 -- uploads the codes it implies (mvus_ba_upload_pattern).
+constexpr int kPatShift = 25;
+constexpr int32_t kPatIndexMask = (1 << kPatShift) - 1;
+constexpr int32_t kPatTie = 1 << 30;           // output flag of observation_pattern / motion tables only
+constexpr int32_t kPatCanon = 0x7;
+MVUS_HD int32_t pattern_code(int32_t p, int32_t mask) { return p | (mask << kPatShift); }
+MVUS_HD int32_t pattern_index(int32_t code) { return code & kPatIndexMask; }
+MVUS_HD int32_t pattern_mask(int32_t code) { return (code >> kPatShift) & 0xf; }
+MVUS_HD bool pattern_has(int32_t code, int32_t g) {
+  const int32_t d = g - pattern_index(code);
+  return d >= 0 && d < 4 && ((pattern_mask(code) >> d) & 1);
+}
+// canonical code of a row with timestamp tau in span l (t[l] <= tau < t[l+1], i.e. c_{l-2} <= tau < c_{l-1}) of a
+// spline with n coefficients starting at global control point c0: walk outwards from tau, taking the nearer of the
+// next centre on the left / right three times (exact ties between DISTINCT centres go left, like a stable sort).
+// Flagged when the window holds one member of a twin pair without the other.
+MVUS_HD int32_t pattern_canonical(const double* t, int n, int c0, int l, double tau) {
+  int lo = l - 2, hi = l - 1;          // next candidates
+  int first = hi, last = lo;           // chosen window, still empty
+  for (int k = 0; k < 3; ++k) {
+    const bool hl = lo >= 0, hr = hi <= n - 1;
+    const bool left = (hl && hr) ? (fabs(tau - t[lo + 2]) <= fabs(t[hi + 2] - tau)) : hl;
+    if (left) { first = lo; --lo; } else { last = hi; ++hi; }
+  }
+  int32_t code = pattern_code(c0 + first, kPatCanon);
+  if (first == 1 || last == n - 2) code |= kPatTie;
+  return code;
 }
 
-// Pattern of one detection row at x0 (jac_BA, common.py:553-566): global index of the first of the three
-// in-pattern control points, or -1 when the detection is not visible at x0 (all-zero row, common.py:566).
+// Pattern of one detection row at x0 (jac_BA, common.py:553-566): code of the three in-pattern control points
+// (canonical, see above), or -1 when the detection is not visible at x0 (all-zero row, common.py:566).
 MVUS_HD int32_t observation_pattern(const CamState& cam, const SplineView& sp, double frame, double v_raw) {
   const double tau = cam.alpha * (frame + cam.rs * v_raw / cam.H) + cam.beta;
   const int s = find_interval(sp.istart, sp.iend, sp.S, tau);
@@ -351,17 +385,24 @@ MVUS_HD int32_t observation_pattern(const CamState& cam, const SplineView& sp, d
   const double* t = sp.knots + sp.knot_off[s];
   const int n = sp.ctrl_off[s + 1] - sp.ctrl_off[s];
   const int l = find_span(t, n, tau);
-  return sp.ctrl_off[s] + (l - 3) + pattern_first_kept(t, l, tau);
+  return pattern_canonical(t, n, sp.ctrl_off[s], l, tau);
 }
 
-// Keep only the spline slots whose control point lies in the pattern {pat, pat+1, pat+2}.
+// Keep only the spline slots whose control point lies in the pattern.
 // base = index of the first spline slot (3 + P); ctrl = first active control point of the row.
 MVUS_HD void mask_to_pattern(double* jx, double* jy, int base, int32_t ctrl, int32_t pat) {
   for (int q = 0; q < 4; ++q) {
-    const int g = ctrl + q;
-    if (g < pat || g > pat + 2)
+    if (!pattern_has(pat, ctrl + q))
       for (int d = 0; d < 3; ++d) { jx[base + 3 * q + d] = 0.0; jy[base + 3 * q + d] = 0.0; }
   }
+}
+
+// Where the four stored control points of a finite-difference row start: the pattern's points must all be among
+// base .. base+3 of ONE spline (ctrl_x0 runs consecutively inside a spline).
+MVUS_HD int32_t pattern_fd_base(int32_t code, int N, const int32_t* ctrl_x0) {
+  const int32_t p = pattern_index(code);
+  const bool room = (p + 3 < N) && (ctrl_x0[p + 3] == ctrl_x0[p] + 3);
+  return room ? p : p - 1;            // a canonical triple that ends its spline: shift down by one
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -378,7 +419,7 @@ struct MotionView {
   const double* basis;    // [4*T] cubic basis values at the sample
   const int32_t* ctrl;    // [T] global index of the first active control point
   const int32_t* part;    // [T] interval the sample is a half-open member of, -1 = none (row stays 0)
-  const int32_t* pat;     // [T] 0/1: offset of the first of the 3 in-pattern control points (common.py:573-585)
+  const int32_t* pat;     // [T] pattern code of the row (pattern_code; common.py:573-585)
   const int32_t* ctrl_x0;     // [N] x-index of coordinate 0 of control point g
   const int32_t* ctrl_stride; // [N] n_s of the spline control point g belongs to
 };
@@ -455,11 +496,10 @@ MVUS_HD double eval_motion_row(const MotionView& mv, const double* x, int j, boo
     }
   }
   if (JAC && masked) {
-    const int pc = mv.ctrl[j] + mv.pat[j];
+    const int32_t pc = mv.pat[j];
     for (int k = 0; k < ns; ++k)
       for (int q = 0; q < 4; ++q) {
-        const int g = cidx[k] + q;
-        if (g < pc || g > pc + 2) { jrow[12 * k + 3 * q] = 0.0; jrow[12 * k + 3 * q + 1] = 0.0; jrow[12 * k + 3 * q + 2] = 0.0; }
+        if (!pattern_has(pc, cidx[k] + q)) { jrow[12 * k + 3 * q] = 0.0; jrow[12 * k + 3 * q + 1] = 0.0; jrow[12 * k + 3 * q + 2] = 0.0; }
       }
   }
   return row;

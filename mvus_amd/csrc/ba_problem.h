@@ -17,7 +17,7 @@ constexpr int kChunk = 256;  // observations per workgroup; a chunk never stradd
 
 struct HostProblem {
   int C = 0, P = 6, NS = 21, S = 0;
-  int calib = 0, undist = 1, rs_free = 0, rs_bounds = 0, motion_reg = 0, motion_type = 0;
+  int calib = 0, undist = 1, rs_free = 0, rs_bounds = 0, motion_reg = 0, motion_type = 0, sync_free = 1;
   double w = 1.0;
   int64_t M = 0, n = 0, m = 0;
   int T = 0, N = 0;
@@ -46,7 +46,7 @@ struct HostProblem {
     C = p->num_cam;
     if (C < 1) return "num_cam must be >= 1";
     calib = p->opt_calib != 0; undist = p->undist_points != 0; rs_free = p->rs_free != 0;
-    rs_bounds = p->rs_bounds != 0; motion_reg = p->motion_reg != 0; motion_type = p->motion_type;
+    rs_bounds = p->rs_bounds != 0; motion_reg = p->motion_reg != 0; motion_type = p->motion_type; sync_free = p->opt_sync != 0;
     if (motion_reg && motion_type != MVUS_MOTION_F && motion_type != MVUS_MOTION_KE)
       return "Motion type must be either F or KE";          // common.py:416
     w = p->motion_weight;
@@ -77,8 +77,10 @@ struct HostProblem {
     }
     knot_off.resize(S + 1); ctrl_off.resize(S + 1); xoff.resize(S);
     ctrl_off[0] = 0;
+    if (p->knot_offsets[0] != 0) return "knot_offsets[0] must be 0";
+    for (int s = 0; s < S; ++s)
+      if (p->knot_offsets[s + 1] < p->knot_offsets[s] + 8 || p->knot_offsets[s + 1] > 0x7fffffff) return "a cubic spline needs at least 8 knots (knot_offsets must increase)";
     for (int s = 0; s <= S; ++s) knot_off[s] = (int32_t)p->knot_offsets[s];
-    if (knot_off[0] != 0) return "knot_offsets[0] must be 0";
     knots.assign(p->knots, p->knots + knot_off[S]);
     int64_t xo = (int64_t)C * (3 + P);
     for (int s = 0; s < S; ++s) {
@@ -133,8 +135,17 @@ struct HostProblem {
           ms_t.push_back(ts);
           for (int q = 0; q < 4; ++q) ms_basis.push_back(h[q]);
           ms_ctrl.push_back(ctrl_off[s] + l - 3);
-          ms_part.push_back(find_interval(istart.data(), iend.data(), S, ts));   // half-open: util.py:105
-          ms_pat.push_back(pattern_first_kept(t, l, ts));
+          const int part = find_interval(istart.data(), iend.data(), S, ts);     // half-open: util.py:105
+          ms_part.push_back(part);
+          // reference pattern of the row (common.py:573-585); a sample that is a member of no interval (it sits on a
+          // closed end) indexes tck[-1] there: the LAST spline's knots.  Such rows are identically zero, their
+          // pattern only matters to the column grouping of the finite differences.
+          if (part >= 0) ms_pat.push_back(pattern_canonical(t, ns, ctrl_off[s], l, ts));
+          else {
+            const double* tl = knots.data() + knot_off[S - 1];
+            const int nl = ctrl_off[S] - ctrl_off[S - 1];
+            ms_pat.push_back(pattern_canonical(tl, nl, ctrl_off[S - 1], find_span(tl, nl, ts), ts));
+          }
         }
       }
       T = (int)ms_t.size();

@@ -73,10 +73,11 @@ SolveResult lm_schur(B& be, Schur& sc, std::vector<double>& x, const std::vector
   SolveResult res;
   const int64_t n = be.n(), m = be.m_local();
   if (!in_bounds(x, lb, ub)) { res.error = -3; return res; }
-  double* x_dev = be.alloc(n);
-  double* xt_dev = be.alloc(n);
-  double* f_new = be.alloc(m);
-  auto cleanup = [&]() { be.release(x_dev); be.release(xt_dev); be.release(f_new); };
+  PoolGuard<B> pool(be);             // returned on every exit, exceptions included (a time shard can throw out of solve_ok)
+  double* x_dev = pool.get(n);
+  double* xt_dev = pool.get(n);
+  double* f_new = pool.get(m);
+  auto cleanup = [] {};
   be.set_bounds(lb, ub);
   const double* lbp = be.lb_ptr();
   const double* ubp = be.ub_ptr();
@@ -154,6 +155,7 @@ SolveResult lm_schur(B& be, Schur& sc, std::vector<double>& x, const std::vector
         // evaluation budget spent: no further step will be taken, so the accepted point is not re-linearised (one
         // Jacobian + assembly saved per call); the reported optimality is then that of the last linearisation
         be.copy(f_dev, f_new, m);
+        res.jac_stale = true;             // J, span and the assembled blocks still belong to the previous point
         break;
       }
       be.jacobian(x_dev, f_dev, opt.jac_mode);

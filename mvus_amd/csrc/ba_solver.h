@@ -55,6 +55,19 @@ struct SolveResult {
   int error = 0;  // 0 ok, -3 numeric (non-finite f0 / infeasible x0)
   double lm_lambda = 0;  // final LM damping
   double lm_nu = 2;      // final growth factor of the damping
+  bool jac_stale = false;  // the Jacobian held by the backend belongs to an earlier point than the returned x
+};
+
+// returns the pooled work vectors of a solve when the driver leaves, by return or by exception
+template <class B>
+struct PoolGuard {
+  B& be;
+  std::vector<double*> bufs;
+  explicit PoolGuard(B& b) : be(b) {}
+  double* get(int64_t len) { double* p = be.alloc(len); bufs.push_back(p); return p; }
+  ~PoolGuard() { for (double* p : bufs) be.release(p); }
+  PoolGuard(const PoolGuard&) = delete;
+  PoolGuard& operator=(const PoolGuard&) = delete;
 };
 
 namespace detail {
@@ -391,19 +404,20 @@ SolveResult trf_lsmr(B& be, std::vector<double>& x, const std::vector<double>& l
   if (!in_bounds(x, lb, ub)) { res.error = -3; return res; }
   if (bounded) make_strictly_feasible(x, lb, ub, 1e-10);
 
-  double* x_dev = be.alloc(n);
-  double* xt_dev = be.alloc(n);
-  double* f_new = be.alloc(m);
-  double* JS0 = be.alloc(m);
-  double* JS1 = be.alloc(m);
-  double* tmp_m = be.alloc(m);
-  double* tmp_m2 = be.alloc(m);
-  double* vec_n = be.alloc(n);
-  double* D_dev = be.alloc(n);
-  double* E_dev = be.alloc(n);
-  double* gn_dev = be.alloc(n);
+  PoolGuard<B> pool(be);
+  double* x_dev = pool.get(n);
+  double* xt_dev = pool.get(n);
+  double* f_new = pool.get(m);
+  double* JS0 = pool.get(m);
+  double* JS1 = pool.get(m);
+  double* tmp_m = pool.get(m);
+  double* tmp_m2 = pool.get(m);
+  double* vec_n = pool.get(n);
+  double* D_dev = pool.get(n);
+  double* E_dev = pool.get(n);
+  double* gn_dev = pool.get(n);
   Lsmr<B> lsmr(be);
-  auto cleanup = [&]() { for (double* p : {x_dev, xt_dev, f_new, JS0, JS1, tmp_m, tmp_m2, vec_n, D_dev, E_dev, gn_dev}) be.release(p); };
+  auto cleanup = [] {};      // the pool guard returns the buffers
 
   std::vector<double> g(n), v, dv, d(n, 1.0), diag_h(n, 0.0), g_h(n), gn_h(n), S0(n), S1(n), tmpn(n);
   be.upload(x_dev, x.data(), n);

@@ -37,6 +37,7 @@ class BAProblem:
     interval: np.ndarray        # float64[2,S]
     knot_offsets: np.ndarray    # int64[S+1]
     knots: np.ndarray           # float64[sum(n_s+4)]
+    opt_sync: bool = True       # settings['opt_sync'] (absent = True): False freezes alpha and beta (common.py:512-515)
 
     @property
     def C(self):
@@ -121,7 +122,7 @@ class BAProblem:
             det_offsets=np.asarray(new_off, dtype=np.int64), frame=self.frame[keep].copy(),
             u_raw=self.u_raw[keep].copy(), v_raw=self.v_raw[keep].copy(), img_height=self.img_height,
             K=self.K, dist=self.dist, interval=self.interval, knot_offsets=self.knot_offsets,
-            knots=self.knots), keep
+            knots=self.knots, opt_sync=self.opt_sync), keep
 
 
     # ---- time sharding --------------------------------------------------------------------------
@@ -135,7 +136,7 @@ class BAProblem:
         out = np.full(self.M, -1, dtype=np.int64)
         for c in range(C):
             a, b = int(self.det_offsets[c]), int(self.det_offsets[c + 1])
-            tau = alpha[c] * (self.frame[a:b] + (rs[c] * self.v_raw[a:b] / self.img_height[c] if self.rs_free else 0.0)) + beta[c]
+            tau = alpha[c] * (self.frame[a:b] + rs[c] * self.v_raw[a:b] / self.img_height[c]) + beta[c]     # common.py:125, rs fixed or free
             for s_ in range(self.S):
                 t = self.knots[int(self.knot_offsets[s_]):int(self.knot_offsets[s_ + 1])]
                 inside = (tau >= self.interval[0, s_]) & (tau < self.interval[1, s_])
@@ -184,12 +185,12 @@ class BAProblem:
             det_offsets=np.asarray(new_off, dtype=np.int64), frame=self.frame[keep].copy(),
             u_raw=self.u_raw[keep].copy(), v_raw=self.v_raw[keep].copy(), img_height=self.img_height,
             K=self.K, dist=self.dist, interval=self.interval, knot_offsets=self.knot_offsets,
-            knots=self.knots)
+            knots=self.knots, opt_sync=self.opt_sync)
         return sub, keep, cuts
 
 
 def problem_from_arrays(detections, cameras, tck, interval, *, opt_calib=False, undist_points=True,
-                        rs=False, rs_bounds=False, motion_reg=False, motion_type='F', motion_weights=1.0):
+                        rs=False, rs_bounds=False, motion_reg=False, motion_type='F', motion_weights=1.0, opt_sync=True):
     """Build a BAProblem from the reference's containers: ``detections[i]`` float64[3,M_i] rows
     (frame, x, y); ``cameras[i]`` with K, d, resolution (dicts or objects); ``tck`` as in
     ``Scene.spline['tck']``; ``interval`` = ``Scene.spline['int']``.  Cameras are already in BA order."""
@@ -212,7 +213,7 @@ def problem_from_arrays(detections, cameras, tck, interval, *, opt_calib=False, 
         det_offsets=det_off, frame=np.ascontiguousarray(det[0]), u_raw=np.ascontiguousarray(det[1]),
         v_raw=np.ascontiguousarray(det[2]), img_height=H, K=K, dist=dist,
         interval=np.ascontiguousarray(np.asarray(interval, dtype=np.float64)),
-        knot_offsets=koff, knots=np.concatenate(knots) if knots else np.zeros(0))
+        knot_offsets=koff, knots=np.concatenate(knots) if knots else np.zeros(0), opt_sync=bool(opt_sync))
 
 
 def pack_x(prob, alpha, beta, rs, cameras, tck):
@@ -269,6 +270,6 @@ def problem_from_scene(scene, num_cam=None, **overrides):
         opt_calib=st.get('opt_calib', False), undist_points=st.get('undist_points', True),
         rs=st.get('rolling_shutter', False), rs_bounds=st.get('rs_bounds', False),
         motion_reg=st.get('motion_reg', False), motion_type=st.get('motion_type', 'F'),
-        motion_weights=st.get('motion_weights', 1.0))
+        motion_weights=st.get('motion_weights', 1.0), opt_sync=st.get('opt_sync', True))
     x0 = pack_x(prob, scene.alpha[:C], scene.beta[:C], scene.rs[:C], [scene.cameras[i] for i in range(C)], scene.tck)
     return prob, x0

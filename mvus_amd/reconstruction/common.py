@@ -275,7 +275,8 @@ class Scene:
         return _problem.problem_from_arrays(
             [self.detections[i] for i in cams], [self.cameras[i] for i in cams], self.spline['tck'], self.spline['int'],
             opt_calib=st['opt_calib'], undist_points=st['undist_points'], rs=rs, rs_bounds=rs_bounds,
-            motion_reg=motion_reg, motion_type=st.get('motion_type', 'F'), motion_weights=motion_weights)
+            motion_reg=motion_reg, motion_type=st.get('motion_type', 'F'), motion_weights=motion_weights,
+            opt_sync=st.get('opt_sync', True))                      # absent -> alpha, beta free (common.py:512-515)
 
     def _pack(self, prob, cams):
         return _problem.pack_x(prob, np.asarray(self.alpha)[cams], np.asarray(self.beta)[cams], np.asarray(self.rs)[cams],
@@ -287,8 +288,8 @@ class Scene:
 
     @staticmethod
     def _same_problem(a, b):
-        if (a.num_cam, a.opt_calib, a.undist_points, a.rs_free, a.rs_bounds, a.motion_reg, a.motion_type, a.motion_weight) != \
-           (b.num_cam, b.opt_calib, b.undist_points, b.rs_free, b.rs_bounds, b.motion_reg, b.motion_type, b.motion_weight):
+        if (a.num_cam, a.opt_calib, a.undist_points, a.rs_free, a.rs_bounds, a.motion_reg, a.motion_type, a.motion_weight, a.opt_sync) != \
+           (b.num_cam, b.opt_calib, b.undist_points, b.rs_free, b.rs_bounds, b.motion_reg, b.motion_type, b.motion_weight, b.opt_sync):
             return False
         pairs = [(a.det_offsets, b.det_offsets), (a.frame, b.frame), (a.u_raw, b.u_raw), (a.v_raw, b.v_raw),
                  (a.img_height, b.img_height), (a.interval, b.interval), (a.knot_offsets, b.knot_offsets), (a.knots, b.knots)]
@@ -306,14 +307,35 @@ class Scene:
         self._ba_handle, self._ba_key = self._handle(prob), tuple(cams)
         return self._ba_handle
 
+    def _resident_for(self, cams):
+        """The handle left by the last BA if it still describes the CURRENT scene state of its cameras (detections, knots,
+        intervals, fixed calibration, flags) and covers ``cams``; else None.  x is packed from the current state."""
+        h = self._ba_handle
+        if h is None or not h.h or self._ba_key is None or not set(cams) <= set(self._ba_key):
+            return None
+        key = list(self._ba_key)
+        if any(self.detections[i].shape[1] != int(h.prob.det_offsets[k + 1] - h.prob.det_offsets[k]) for k, i in enumerate(key)):
+            return None
+        now = self._ba_problem(key, rs=h.prob.rs_free, motion_reg=h.prob.motion_reg, motion_weights=h.prob.motion_weight,
+                               rs_bounds=h.prob.rs_bounds)
+        return h if self._same_problem(h.prob, now) else None
+
     def error_cam(self, cam_id, mode='dist', motion_prior=False, norm=False):
-        """Reprojection errors of one camera (common.py:304-359), evaluated by the HIP residual kernel."""
+        """Reprojection errors of one camera (common.py:304-359), evaluated by the HIP residual kernel: on the handle the
+        last BA left resident when it still describes the scene, else on a temporary residual-only handle."""
         if motion_prior or norm:
             raise NotImplementedError('motion_prior / norm variants are not on the BA hot path')
         self.detection_to_global(cam_id)
-        prob = self._ba_problem([cam_id])
-        with self._handle(prob) as h:
-            f = h.residual(self._pack(prob, [cam_id]))
+        h = self._resident_for([cam_id])
+        if h is not None:
+            key = list(self._ba_key)
+            k = key.index(cam_id)
+            a, b = int(h.prob.det_offsets[k]), int(h.prob.det_offsets[k + 1])
+            f = h.residual(self._pack(h.prob, key))[2 * a:2 * b]
+        else:
+            prob = self._ba_problem([cam_id])
+            with self._handle(prob) as tmp:
+                f = tmp.residual(self._pack(prob, [cam_id]))
         M = self.detections[cam_id].shape[1]
         ex, ey = f[:M], f[M:2 * M]
         if mode == 'each':
@@ -353,7 +375,7 @@ class Scene:
         default_jac = 'analytic' if solver == _ba.SOLVER_LM_SCHUR else 'pattern'
         jac_mode = {'analytic': _ba.JAC_ANALYTIC, 'pattern': _ba.JAC_PATTERN, 'fd': _ba.JAC_FD}[st.get('ba_jacobian', default_jac)]
         h = self._resident_handle(prob, cams)      # stays resident for remove_outliers and the next BA
-        res = h.solve(model, solver=solver, jac_mode=jac_mode, max_nfev=max_iter)
+        res = h.solve(model, solver=solver, jac_mode=jac_mode, max_nfev=max_iter, ties=st.get('ba_pattern_ties', 'numpy'))
         alpha, beta, rs_new, cam_states, coefs = _problem.unpack_x(prob, res.x)
         self.alpha[cams], self.beta[cams], self.rs[cams] = alpha, beta, rs_new
         for k, i in enumerate(cams):
@@ -378,11 +400,10 @@ class Scene:
         cams = list(cams)
         for i in cams:
             self.detection_to_global(i)
-        h = self._ba_handle
-        resident = (h is not None and h.h and self._ba_key == tuple(cams)
-                    and all(h.prob.det_offsets[k + 1] - h.prob.det_offsets[k] == self.detections[i].shape[1] for k, i in enumerate(cams))
-                    and np.array_equal(h.prob.frame, np.concatenate([self.detections[i][0] for i in cams])))
-        if resident:
+        # in place on the GPU only if the resident handle is over exactly these cameras AND still describes the current
+        # scene (detections, knots, intervals, fixed K/d, undist_points): the reference always evaluates current state
+        h = self._resident_for(cams) if self._ba_key == tuple(cams) else None
+        if h is not None:
             # the detections of the last BA are still on the GPU: filter them there (mvus_ba_remove_outliers)
             prob_old = h.prob
             x = self._pack(prob_old, cams)

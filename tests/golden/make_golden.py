@@ -184,6 +184,14 @@ def run_case(common, name, sc, max_iters=(10,), seed=123, max_iters2=(10,)):
 
         if k == 0:
             # outlier pass exactly as main.py:56 after the first BA
+            if st['motion_reg']:
+                # Scene.all_detect_to_traj at the state BA leaves behind (common.py:887-947): the attributes of the output pickle
+                ref.all_detect_to_traj(ref.sequence[:C])
+                out['adt_global_traj'] = np.array(ref.global_traj)
+                out['adt_global_detections'] = np.array(ref.global_detections)
+                out['adt_frame_id_all'] = np.array(ref.frame_id_all)
+                out['adt_global_time_stamps_all'] = np.array(ref.global_time_stamps_all)
+                out['adt_traj'] = np.array(ref.traj)
             frames_before = [d[0].copy() for d in ref.detections]
             ref.remove_outliers(ref.sequence[:C], thres=st['thres_outlier'])
             keep = [np.isin(fb, d[0]) for fb, d in zip(frames_before, ref.detections)]
@@ -198,6 +206,7 @@ def run_case(common, name, sc, max_iters=(10,), seed=123, max_iters2=(10,)):
 
                 def spy2(fn, x0, **kwargs):
                     cap2['x0'] = np.array(x0, dtype=np.float64)
+                    cap2['A'] = kwargs['jac_sparsity']
                     return real_ls(fn, x0, **kwargs)
                 common.least_squares = spy2
                 try:
@@ -206,13 +215,24 @@ def run_case(common, name, sc, max_iters=(10,), seed=123, max_iters2=(10,)):
                     common.least_squares = real_ls
                 t2 = 'ba2_%d' % mi2
                 out[t2 + '_x0'] = cap2['x0']
+                A2 = sparse.coo_matrix(np.asarray(cap2['A']))          # the matrix of the second BA (same x0 for every mi2)
+                order2 = np.lexsort((A2.col, A2.row))
+                out['ba2_pattern_shape'] = np.array(A2.shape, dtype=np.int64)
+                out['ba2_pattern_rows'] = A2.row[order2].astype(np.int32)
+                out['ba2_pattern_cols'] = A2.col[order2].astype(np.int32)
                 out[t2 + '_x'] = np.array(res2.x)
                 out[t2 + '_cost'] = np.float64(res2.cost)
                 out[t2 + '_nfev'] = np.int64(res2.nfev)
                 out[t2 + '_njev'] = np.int64(res2.njev)
                 out[t2 + '_status'] = np.int64(res2.status)
+                out[t2 + '_optimality'] = np.float64(res2.optimality)
                 rmse2 = np.sqrt(np.mean(np.concatenate([ref2.error_cam(i, 'dist') for i in range(C)]) ** 2))
                 out[t2 + '_rmse'] = np.float64(rmse2)
+                # the reference's own inlier mask at this (converged) point: remove_outliers once more, on a copy
+                # (over the detections the second BA ran on, i.e. those kept by 'outlier_keep')
+                frames2 = [d[0].copy() for d in ref2.detections]
+                ref2.remove_outliers(ref2.sequence[:C], thres=st['thres_outlier'])
+                out[t2 + '_keep'] = np.concatenate([np.isin(fb, d[0]) for fb, d in zip(frames2, ref2.detections)]).astype(np.uint8)
                 print('  %s second BA max_iter=%d: cost=%.9g nfev=%d njev=%d status=%d rmse=%.6f'
                       % (name, mi2, res2.cost, res2.nfev, res2.njev, res2.status, rmse2))
 
@@ -257,7 +277,7 @@ def main():
         if only and name not in only:
             continue
         print('case %s: C=%d M=%d' % (name, sc.num_cam, sc.num_obs))
-        run_case(common, name, sc, mis, max_iters2=(10, 200) if name.startswith('c1_') else (10,))
+        run_case(common, name, sc, mis, max_iters2=(10, 200))
 
 
 if __name__ == '__main__':

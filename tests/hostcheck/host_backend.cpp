@@ -24,7 +24,8 @@ struct HostBackend {
   HostProblem hp;
   std::vector<double> J, mJ, u_obs, v_obs;
   std::vector<int32_t> span, pat0, mctrl;
-  bool has_pattern = false;
+  bool has_pattern = false, pattern_uploaded = false;
+  std::vector<int32_t> ms_pat_canon;
   std::vector<int32_t> fd_groups;
   int fd_ngroups = 0;
 
@@ -81,8 +82,8 @@ struct HostBackend {
       load_cam_state(x, hp.C, c, hp.calib, hp.K.data(), hp.dist.data(), hp.H[c], cam);
       const int64_t a = hp.det_off[c], Mc = hp.det_off[c + 1] - a;
       for (int64_t i = a; i < a + Mc; ++i) {
-        ObsResult r = hp.calib ? eval_observation<true, JAC>(cam, sp, x, hp.undist, hp.rs_free, hp.frame[i], hp.u_raw[i], hp.v_raw[i], u_obs[i], v_obs[i], jx.data(), jy.data())
-                               : eval_observation<false, JAC>(cam, sp, x, hp.undist, hp.rs_free, hp.frame[i], hp.u_raw[i], hp.v_raw[i], u_obs[i], v_obs[i], jx.data(), jy.data());
+        ObsResult r = hp.calib ? eval_observation<true, JAC>(cam, sp, x, hp.undist, hp.rs_free, hp.sync_free, hp.frame[i], hp.u_raw[i], hp.v_raw[i], u_obs[i], v_obs[i], jx.data(), jy.data())
+                               : eval_observation<false, JAC>(cam, sp, x, hp.undist, hp.rs_free, hp.sync_free, hp.frame[i], hp.u_raw[i], hp.v_raw[i], u_obs[i], v_obs[i], jx.data(), jy.data());
         f[2 * a + (i - a)] = r.ex;
         f[2 * a + Mc + (i - a)] = r.ey;
         if (JAC) {
@@ -131,18 +132,14 @@ struct HostBackend {
       const int64_t a = hp.det_off[c], Mc = hp.det_off[c + 1] - a;
       for (int64_t i = a; i < a + Mc; ++i) {
         const int p = pat0[i];
-        int base = p, off = 0;
-        if (p >= 0) {
-          const bool room = (p + 3 < hp.N) && (hp.ctrl_x0[p + 3] == hp.ctrl_x0[p] + 3);
-          base = room ? p : p - 1; off = p - base;
-        }
+        const int base = p >= 0 ? pattern_fd_base(p, hp.N, hp.ctrl_x0.data()) : p;
         span[i] = base;
         const int64_t rx = 2 * a + (i - a), ry = rx + Mc;
         for (int k = 0; k < NS; ++k) {
           int col = -1;
           if (p >= 0) {
-            if (k < B) { if (!(k == 2 && !hp.rs_free)) col = col_of(c, k); }
-            else { const int q = (k - B) / 3, d = (k - B) % 3; if (q >= off && q < off + 3) col = hp.ctrl_x0[base] + q + d * hp.ctrl_stride[base]; }
+            if (k < B) { if (!(k == 2 && !hp.rs_free) && !(k < 2 && !hp.sync_free)) col = col_of(c, k); }
+            else { const int q = (k - B) / 3, d = (k - B) % 3; if (pattern_has(p, base + q)) col = hp.ctrl_x0[base] + q + d * hp.ctrl_stride[base]; }
           }
           J[(size_t)k * hp.M + i] = col >= 0 ? (F[(size_t)fd_groups[col] * m + rx] - f[rx]) / dx[col] : 0.0;
           J[(size_t)(NS + k) * hp.M + i] = col >= 0 ? (F[(size_t)fd_groups[col] * m + ry] - f[ry]) / dx[col] : 0.0;
@@ -153,16 +150,17 @@ struct HostBackend {
       for (int k = 0; k < 36; ++k) mJ[(size_t)k * hp.T + j] = 0.0;
       mctrl[j] = -1; mctrl[(size_t)2 * hp.T + j] = -1; mctrl[(size_t)hp.T + j] = -1;
       if (hp.ms_part[j] < 0) continue;
-      const int pc = hp.ms_ctrl[j] + hp.ms_pat[j];
-      const bool room = (pc + 3 < hp.N) && (hp.ctrl_x0[pc + 3] == hp.ctrl_x0[pc] + 3);
-      const int base = room ? pc : pc - 1, off = pc - base;
+      const int pc = hp.ms_pat[j];
+      const int base = pattern_fd_base(pc, hp.N, hp.ctrl_x0.data());
       mctrl[(size_t)hp.T + j] = base;
       const int64_t row = 2 * hp.M + j;
-      for (int q = off; q < off + 3; ++q)
+      for (int q = 0; q < 4; ++q) {
+        if (!pattern_has(pc, base + q)) continue;
         for (int d = 0; d < 3; ++d) {
           const int col = hp.ctrl_x0[base] + q + d * hp.ctrl_stride[base];
           mJ[(size_t)(12 + 3 * q + d) * hp.T + j] = (F[(size_t)fd_groups[col] * m + row] - f[row]) / dx[col];
         }
+      }
     }
   }
 
@@ -174,7 +172,14 @@ struct HostBackend {
       for (int64_t i = hp.det_off[c]; i < hp.det_off[c + 1]; ++i)
         pat0[i] = observation_pattern(cam, sp, hp.frame[i], hp.v_raw[i]);
     }
-    has_pattern = true;
+    if (pattern_uploaded) hp.ms_pat = ms_pat_canon;
+    has_pattern = true; pattern_uploaded = false;
+  }
+  void upload_pattern(const int32_t* pat, const int32_t* mpat) {
+    pat0.assign(pat, pat + hp.M);
+    if (!pattern_uploaded) ms_pat_canon = hp.ms_pat;
+    if (mpat && hp.T > 0) hp.ms_pat.assign(mpat, mpat + hp.T);
+    has_pattern = true; pattern_uploaded = true;
   }
 
   int col_of(int c, int k) const { return k < 3 ? k * hp.C + c : 3 * hp.C + c * hp.P + (k - 3); }
@@ -280,6 +285,13 @@ int hostcheck_dense_jacobian(void* h, const double* x, int jac_mode, double* f, 
   return 0;
 }
 
+int hostcheck_upload_pattern(void* h, const int32_t* pat, const int32_t* mpat) { static_cast<HostBackend*>(h)->upload_pattern(pat, mpat); return 0; }
+int hostcheck_motion_pattern(void* h, int32_t* mpat) {
+  HostBackend* be = static_cast<HostBackend*>(h);
+  if (be->hp.T > 0) std::memcpy(mpat, be->hp.ms_pat.data(), sizeof(int32_t) * be->hp.T);
+  return 0;
+}
+
 int hostcheck_set_fd_groups(void* h, const int32_t* groups, int ngroups) {
   HostBackend* be = static_cast<HostBackend*>(h);
   be->fd_groups.assign(groups, groups + be->hp.n);
@@ -297,7 +309,7 @@ int hostcheck_solve(void* h, double* x, const mvus_solve_opts* o, mvus_result* r
   SolveOptions so;
   so.jac_mode = o->jac_mode; so.max_nfev = o->max_nfev; so.ftol = o->ftol; so.xtol = o->xtol; so.gtol = o->gtol;
   so.lsmr_atol = o->lsmr_atol; so.lsmr_btol = o->lsmr_btol; so.lsmr_conlim = o->lsmr_conlim; so.lsmr_maxiter = o->lsmr_maxiter; so.verbose = o->verbose;
-  if (so.jac_mode == MVUS_JAC_PATTERN) be->set_pattern(x);
+  if (so.jac_mode == MVUS_JAC_PATTERN && !be->pattern_uploaded) be->set_pattern(x);
   std::vector<double> f(be->hp.m);
   SolveResult sr;
 #ifdef MVUS_WITH_SCHUR

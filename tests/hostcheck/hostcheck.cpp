@@ -27,8 +27,8 @@ extern "C" int hostcheck_eval(int C, int calib, int undist, int rs_free, const i
       double* jx = J + (2 * i) * NS;
       double* jy = J + (2 * i + 1) * NS;
       for (int k = 0; k < 2 * NS; ++k) jx[k] = 0.0;
-      ObsResult r = calib ? eval_observation<true, true>(cam, sp, x, undist != 0, rs_free != 0, frame[i], u_raw[i], v_raw[i], uo, vo, jx, jy)
-                          : eval_observation<false, true>(cam, sp, x, undist != 0, rs_free != 0, frame[i], u_raw[i], v_raw[i], uo, vo, jx, jy);
+      ObsResult r = calib ? eval_observation<true, true>(cam, sp, x, undist != 0, rs_free != 0, true, frame[i], u_raw[i], v_raw[i], uo, vo, jx, jy)
+                          : eval_observation<false, true>(cam, sp, x, undist != 0, rs_free != 0, true, frame[i], u_raw[i], v_raw[i], uo, vo, jx, jy);
       ex[i] = r.ex; ey[i] = r.ey; ctrl[i] = r.ctrl;
     }
   }

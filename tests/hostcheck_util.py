@@ -37,6 +37,8 @@ def load():
     lib.hostcheck_residual.argtypes = [ctypes.c_void_p, _lib.c_double_p, _lib.c_double_p]
     lib.hostcheck_set_pattern.argtypes = [ctypes.c_void_p, _lib.c_double_p, _lib.c_int32_p]
     lib.hostcheck_dense_jacobian.argtypes = [ctypes.c_void_p, _lib.c_double_p, ctypes.c_int, _lib.c_double_p, _lib.c_double_p]
+    lib.hostcheck_motion_pattern.argtypes = [ctypes.c_void_p, _lib.c_int32_p]
+    lib.hostcheck_upload_pattern.argtypes = [ctypes.c_void_p, _lib.c_int32_p, _lib.c_int32_p]
     lib.hostcheck_set_fd_groups.argtypes = [ctypes.c_void_p, _lib.c_int32_p, ctypes.c_int]
     lib.hostcheck_jtu.argtypes = [ctypes.c_void_p, _lib.c_double_p, _lib.c_double_p]
     lib.hostcheck_solve.argtypes = [ctypes.c_void_p, _lib.c_double_p, ctypes.POINTER(_lib.MvusSolveOpts),
@@ -79,10 +81,29 @@ class HostHandle:
         self.lib.hostcheck_set_pattern(self.h, _lib.dptr(x0), pat.ctypes.data_as(_lib.c_int32_p))
         return pat
 
-    def prepare_fd(self, x0):
+    def motion_pattern(self):
+        mp = np.zeros(self.T, dtype=np.int32)
+        self.lib.hostcheck_motion_pattern(self.h, mp.ctypes.data_as(_lib.c_int32_p))
+        return mp
+
+    def upload_pattern(self, pat, mpat=None):
+        pat = np.ascontiguousarray(pat, dtype=np.int32)
+        mp = np.ascontiguousarray(mpat, dtype=np.int32) if (mpat is not None and self.T) else None
+        self.lib.hostcheck_upload_pattern(self.h, pat.ctypes.data_as(_lib.c_int32_p), mp.ctypes.data_as(_lib.c_int32_p) if mp is not None else None)
+
+    def prepare_pattern(self, x0, ties='numpy', matrix=None):
         from mvus_amd import pattern
-        pat = self.set_pattern(x0)
-        groups, ng = pattern.fd_groups(self.prob, pat)
+        if matrix is not None:
+            pat, mpat = pattern.codes_from_matrix(self.prob, matrix)
+        else:
+            pat, mpat = pattern.resolve_ties(self.prob, x0, self.set_pattern(x0), self.motion_pattern() if self.T else None, how=ties)
+        self.upload_pattern(pat, mpat)
+        return pat, (mpat if self.T else None)
+
+    def prepare_fd(self, x0, ties='numpy', matrix=None):
+        from mvus_amd import pattern
+        pat, mpat = self.prepare_pattern(x0, ties, matrix)
+        groups, ng = pattern.fd_groups(self.prob, pat, mpat)
         self._groups = np.ascontiguousarray(groups, dtype=np.int32)
         self.lib.hostcheck_set_fd_groups(self.h, self._groups.ctypes.data_as(_lib.c_int32_p), ng)
         return pat, self._groups, ng
@@ -100,10 +121,12 @@ class HostHandle:
         self.lib.hostcheck_jtu(self.h, _lib.dptr(u), _lib.dptr(z))
         return z
 
-    def solve(self, x0, opts):
+    def solve(self, x0, opts, ties='numpy', matrix=None):
         x = np.array(x0, dtype=np.float64)
         if opts.jac_mode == _lib.JAC_FD:
-            self.prepare_fd(x)
+            self.prepare_fd(x, ties, matrix)
+        elif opts.jac_mode == _lib.JAC_PATTERN:
+            self.prepare_pattern(x, ties, matrix)
         res = _lib.MvusResult()
         f = np.zeros(self.m)
         rc = self.lib.hostcheck_solve(self.h, _lib.dptr(x), ctypes.byref(opts), ctypes.byref(res), _lib.dptr(f))

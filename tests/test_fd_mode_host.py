@@ -13,21 +13,61 @@ from mvus_amd import _lib, pattern
 from mvus_amd import problem as mp
 
 
+def golden_matrix(g, second=False):
+    pre = 'ba2_pattern' if second else 'pattern'
+    return sparse.csr_matrix((np.ones(g[pre + '_rows'].size, dtype=np.int8), (g[pre + '_rows'], g[pre + '_cols'])),
+                             shape=tuple(g[pre + '_shape']))
+
+
 @pytest.mark.parametrize('name', CASES)
 def test_full_pattern_matches_reference(name):
+    """The whole jac_BA matrix (detection AND motion rows) BIT-EXACT: canonical codes of the device math + the twin rows
+    decided like np.argsort decides them == the matrix the reference built.  The golden matrices were produced in this
+    container, whose numpy dispatches the AVX512 sort kernel; on a machine where numpy picks another kernel its answer
+    for the twin rows changes (tests/test_oracle_golden.py::test_argsort_tie_order_depends_on_the_sort_kernel), so
+    the 'numpy' leg is asserted only where this process reproduces the recorded tie choices."""
     scene, g = load_case(name)
     prob, _ = mp.problem_from_scene(scene)
     h = HostHandle(prob)
-    A = pattern.reference_pattern(prob, h.set_pattern(g['x0']))
-    ref = sparse.csr_matrix((np.ones(g['pattern_rows'].size), (g['pattern_rows'], g['pattern_cols'])), shape=tuple(g['pattern_shape']))
+    ref = golden_matrix(g)
+    pat_c, mp_c = h.set_pattern(g['x0']), (h.motion_pattern() if h.T else None)
+    # (1) codes <-> matrix is lossless for the reference's matrix
+    pg, mg = pattern.codes_from_matrix(prob, ref)
+    assert (pattern.reference_pattern(prob, pg, mg if h.T else None) != ref).nnz == 0
+    # (2) the canonical codes equal the reference's in every row that is not flagged as a twin tie, and in the flagged
+    #     rows they differ by exactly the twin (same centre knot): same rows, same number of entries
+    pc, mc = pattern.resolve_ties(prob, g['x0'], pat_c, mp_c, how='canonical')
+    differ = pc != pg
+    assert pattern.is_tie(pat_c)[differ].all()
+    assert np.array_equal(pc < 0, pg < 0)
+    if h.T:
+        assert pattern.is_tie(mp_c)[mc != mg].all()
+    for codes_c, codes_g in ((pc[differ], pg[differ]),) + (((mc[mc != mg], mg[mc != mg]),) if h.T else ()):
+        for a, b in zip(codes_c, codes_g):
+            pa = {int(pattern.code_index(a)) + k for k in range(4) if (int(pattern.code_mask(a)) >> k) & 1}
+            pb = {int(pattern.code_index(b)) + k for k in range(4) if (int(pattern.code_mask(b)) >> k) & 1}
+            (ta,), (tb,) = pa - pb, pb - pa                      # one control point swapped ...
+            s_ = int(np.searchsorted(prob.ctrl_offsets, ta, side='right') - 1)
+            t = prob.knots[int(prob.knot_offsets[s_]):int(prob.knot_offsets[s_ + 1])][2:-2]
+            assert t[ta - int(prob.ctrl_offsets[s_])] == t[tb - int(prob.ctrl_offsets[s_])]   # ... for its twin: same centre knot
+    # (3) with the twin rows decided by this process's np.argsort the matrix is the reference's, bit for bit
+    pn, mn = pattern.resolve_ties(prob, g['x0'], pat_c, mp_c, how='numpy')
+    A = pattern.reference_pattern(prob, pn, mn if h.T else None)
     assert A.shape == ref.shape
-    assert np.array_equal(np.diff(A.indptr), np.diff(ref.indptr))          # same number of entries in every row
-    bad = np.unique((A != ref).nonzero()[0])
-    assert bad.size <= 0.1 * A.shape[0]                                      # only argsort-tie rows (see oracle.jac_pattern)
-    groups, ng = pattern.fd_groups(prob, h.set_pattern(g['x0']))
+    if tie_order_is_the_recorded_one():
+        assert (A != ref).nnz == 0
+    groups, ng = pattern.fd_groups(prob, pn, mn if h.T else None)
     # a valid colouring: no row contains two columns of one group
     G = sparse.csr_matrix((np.ones(groups.size), (np.arange(groups.size), groups)), shape=(groups.size, ng))
     assert (A @ G).max() == 1
+
+
+def tie_order_is_the_recorded_one():
+    """Does np.argsort of this process break the twin ties like the numpy that produced the golden matrices?"""
+    scene, g = load_case('rs_F_2int_3cam')
+    prob, _ = mp.problem_from_scene(scene)
+    oprob, _ = orc.problem_from_scene(scene)
+    return (orc.jac_pattern(oprob, g['x0']) != golden_matrix(g)).nnz == 0
 
 
 @pytest.mark.parametrize('name', CASES)
@@ -36,7 +76,7 @@ def test_fd_jacobian_equals_scipy_approx_derivative(name):
     prob, _ = mp.problem_from_scene(scene)
     h = HostHandle(prob)
     pat, groups, ng = h.prepare_fd(g['x0'])
-    A = pattern.reference_pattern(prob, pat)
+    A = pattern.reference_pattern(prob, pat, h.motion_pattern() if h.T else None)
     x = g['x0'] + g['delta']
     lb, ub = prob.bounds()
     if prob.rs_bounds:
@@ -57,7 +97,7 @@ def test_fd_solver_is_the_reference_path(name):
     prob, _ = mp.problem_from_scene(scene)
     h = HostHandle(prob)
     pat, groups, ng = h.prepare_fd(g['x0'])
-    A = pattern.reference_pattern(prob, pat)
+    A = pattern.reference_pattern(prob, pat, h.motion_pattern() if h.T else None)
     lb, ub = prob.bounds()
     ref = least_squares(lambda z: h.residual(z), g['x0'], jac_sparsity=A, tr_solver='lsmr', tr_options=dict(maxiter=4),
                         xtol=1e-12, max_nfev=12, bounds=(lb, ub) if prob.rs_bounds else (-np.inf, np.inf))
@@ -78,14 +118,69 @@ def test_fd_solver_vs_reference_golden(name):
     prob, _ = mp.problem_from_scene(scene)
     oprob, _ = orc.problem_from_scene(scene)
     h = HostHandle(prob)
-    x, res, f = h.solve(g['x0'], _lib.default_opts(_lib.SOLVER_TRF_LSMR, _lib.JAC_FD, 10))
+    x, res, f = h.solve(g['x0'], _lib.default_opts(_lib.SOLVER_TRF_LSMR, _lib.JAC_FD, 10), matrix=golden_matrix(g))
     assert res.nfev == int(g['ba10_nfev'])
-    # Same algorithm as the reference up to (a) rounding order in LSMR's matvecs and (b) the argsort-tie rows of the
-    # pattern (0.5-4 % of the rows sit in a first/last knot span), so the unconverged 10-evaluation iterate agrees to
-    # a few 1e-3 relative in cost -- closer than the analytic-Jacobian modes -- and the masks to >= 96.5 %.
-    assert res.cost < float(g['ba10_cost']) * (1 + 5e-3)
-    assert abs(res.cost - float(g['ba10_cost'])) < 3e-2 * float(g['ba10_cost'])
-    assert abs(orc.reprojection_rmse(oprob, x) - float(g['ba10_rmse'])) < 0.15
+    # Same algorithm AND the same matrix as the reference (its jac_sparsity is an input of the call); what is left is
+    # the rounding order inside LSMR's products.  Measured: cost within 1e-4 / 6e-5 / 1e-3 / 5e-5 relative, RMSE within
+    # 9e-4 / 2e-5 / 6e-3 / 4e-4 px, mask flips 1 / 0 / 42 / 0 -- the calib+KE+bounds case is the one whose unconverged
+    # 10-evaluation iterate the reference itself does not reproduce (1e-15 residual noise moves its RMSE by 1e-2 px).
+    loose = name == 'calib_KE_bounds_3cam'
+    assert abs(res.cost - float(g['ba10_cost'])) < (3e-3 if loose else 3e-4) * float(g['ba10_cost'])
+    assert abs(orc.reprojection_rmse(oprob, x) - float(g['ba10_rmse'])) < (2e-2 if loose else 3e-3)
     keep = np.concatenate(orc.outlier_keep_mask(oprob, x, float(g['thres_outlier'])))
     flips = int(np.sum(keep.astype(np.uint8) != g['outlier_keep']))
-    assert flips <= 0.035 * keep.size, flips
+    assert flips <= (0.04 * keep.size if loose else 2), flips
+
+
+# ---- the converged answer of the pipeline: second BA after outlier removal, max_iter = 200 (main.py:49-62) ----------
+# |RMSE - reference| in px of the FD mode with the reference's matrix, measured on the host build: 1.5e-4, 1.0e-4,
+# 4.4e-3, 5.5e-6.  What the reference itself reproduces (tests/test_oracle_golden.py): its own scipy call on residuals
+# that differ in the 13th digit ends 1e-5, 5e-5, 1.6e-2, 4e-5 px away; numpy's scalar sort kernel (different twin
+# choices in the pattern) moves it by 1e-3, 3e-3, 1.8e-2, 7e-4 px.
+CONVERGED_RMSE_ATOL = {'c1_pinhole_2cam': 4e-4, 'rs_F_2int_3cam': 4e-4, 'calib_KE_bounds_3cam': 2e-2, 'dist_fixed_2cam': 4e-4}
+
+
+def filtered_case(name):
+    """The problem of the reference's second BA: detections kept by its own outlier mask after the first BA."""
+    scene, g = load_case(name)
+    off, keep = g['det_offsets'], g['outlier_keep'].astype(bool)
+    for i in range(scene.num_cam):
+        scene.detections[i] = scene.detections[i][:, keep[off[i]:off[i + 1]]]
+    return scene, g
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_converged_second_ba_fd_mode(name):
+    """The reference's algorithm end to end (TRF + LSMR + grouped forward differences over ITS matrix) from its own
+    start of the second BA to convergence: same termination status, final RMSE at the reference's reproducibility
+    floor, outlier mask at the converged point IDENTICAL to the reference's."""
+    scene, g = filtered_case(name)
+    prob, _ = mp.problem_from_scene(scene)
+    oprob, _ = orc.problem_from_scene(scene)
+    h = HostHandle(prob)
+    x, res, f = h.solve(g['ba2_200_x0'], _lib.default_opts(_lib.SOLVER_TRF_LSMR, _lib.JAC_FD, 200), matrix=golden_matrix(g, second=True))
+    assert res.status == int(g['ba2_200_status']) == 3
+    assert abs(res.nfev - int(g['ba2_200_nfev'])) <= 4
+    assert abs(orc.reprojection_rmse(oprob, x) - float(g['ba2_200_rmse'])) < CONVERGED_RMSE_ATOL[name]
+    assert abs(res.cost - float(g['ba2_200_cost'])) < (1e-2 if name == 'calib_KE_bounds_3cam' else 1e-3) * float(g['ba2_200_cost'])
+    keep = np.concatenate(orc.outlier_keep_mask(oprob, x, float(g['thres_outlier']))).astype(np.uint8)
+    assert np.array_equal(keep, g['ba2_200_keep'])
+
+
+def test_converged_second_ba_analytic_modes_go_lower():
+    """With the analytic Jacobian (masked to the reference pattern, or full inside LM + Schur) the iteration does not stop
+    where the reference does: the reference's status-3 stop is its trust region collapsing on a Jacobian that lumps a
+    dropped control point into its neighbours, not a stationary point.  Same objective, lower cost."""
+    scene, g = filtered_case('c1_pinhole_2cam')
+    prob, _ = mp.problem_from_scene(scene)
+    oprob, _ = orc.problem_from_scene(scene)
+    ref_cost, ref_rmse = float(g['ba2_200_cost']), float(g['ba2_200_rmse'])
+    for solver, jm in ((_lib.SOLVER_TRF_LSMR, _lib.JAC_PATTERN), (_lib.SOLVER_LM_SCHUR, _lib.JAC_ANALYTIC)):
+        x, res, f = HostHandle(prob).solve(g['ba2_200_x0'], _lib.default_opts(solver, jm, 200), matrix=golden_matrix(g, second=True) if jm == _lib.JAC_PATTERN else None)
+        fo = orc.residual(oprob, x)
+        assert abs(0.5 * float(fo @ fo) - res.cost) < 1e-9 * res.cost            # the oracle agrees on the objective value
+        assert res.cost < ref_cost * (1 - 1e-2)                                    # measured: 485.6 / 482.3 against 496.26
+        rmse = orc.reprojection_rmse(oprob, x)
+        assert ref_rmse - 2e-2 < rmse < ref_rmse - 5e-3                            # measured: 0.6886 / 0.6863 against 0.6962
+        keep = np.concatenate(orc.outlier_keep_mask(oprob, x, float(g['thres_outlier']))).astype(np.uint8)
+        assert np.array_equal(keep, g['ba2_200_keep'])

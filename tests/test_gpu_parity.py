@@ -5,12 +5,14 @@ import pytest
 
 from oracle import ba_oracle as orc
 from golden_util import CASES, load_case
+from test_fd_mode_host import CONVERGED_RMSE_ATOL, filtered_case, golden_matrix, tie_order_is_the_recorded_one
 from mvus_amd import _lib
 from mvus_amd import problem as mp
 
 pytestmark = pytest.mark.gpu
 
 RESIDUAL_ATOL = 1e-9        # px, fp64 residuals vs the reference's values
+GPU_CONVERGED_RMSE_ATOL = {k: 2.5 * v for k, v in CONVERGED_RMSE_ATOL.items()}     # 1e-3 px (5e-2 for the calib+KE+bounds scene)
 JAC_RTOL = 1e-10            # GPU vs host build of the same analytic formulas (relative to column scale)
 
 
@@ -101,6 +103,49 @@ def test_jacobian_operator_vs_host_build(BAHandle, name, mode):
 
 
 @pytest.mark.parametrize('name', CASES)
+def test_pattern_vs_reference_matrix(BAHandle, name):
+    """jac_BA + compute_visibility (common.py:427-438,490-610), integer: the codes k_pattern computes, against the matrix
+    the reference built (golden), row by row.  Bit-exact in every row that is not a twin tie; the flagged rows differ
+    from the reference's by exactly the twin control point (same centre knot, the one np.argsort happened to return);
+    with the twins decided by np.argsort the whole matrix -- motion rows included -- is the reference's."""
+    from mvus_amd import pattern
+    scene, g = load_case(name)
+    prob, _ = mp.problem_from_scene(scene)
+    ref = golden_matrix(g)
+    with BAHandle(prob) as h:
+        pat_c = h.set_pattern(g['x0'])
+        mp_c = h.motion_pattern() if h.T else None
+        hh = _host(prob)
+        assert np.array_equal(pat_c, hh.set_pattern(g['x0']))                  # device == host build of the same rule
+        if h.T:
+            assert np.array_equal(mp_c, hh.motion_pattern())
+        pg, mg = pattern.codes_from_matrix(prob, ref)
+        pc, mc = pattern.resolve_ties(prob, g['x0'], pat_c, mp_c, how='canonical')
+        differ = pc != pg
+        assert np.array_equal(pc < 0, pg < 0)                                   # visibility at x0: exact
+        assert pattern.is_tie(pat_c)[differ].all()                              # deviations only in flagged twin rows ...
+        assert differ.sum() <= pattern.is_tie(pat_c).sum() <= 0.06 * prob.M
+        coff = prob.ctrl_offsets
+        for a, b in zip(pc[differ], pg[differ]):                                # ... and only by the twin
+            pa = {int(pattern.code_index(a)) + k for k in range(4) if (int(pattern.code_mask(a)) >> k) & 1}
+            pb = {int(pattern.code_index(b)) + k for k in range(4) if (int(pattern.code_mask(b)) >> k) & 1}
+            (ta,), (tb,) = pa - pb, pb - pa
+            s_ = int(np.searchsorted(coff, ta, side='right') - 1)
+            t = prob.knots[int(prob.knot_offsets[s_]):int(prob.knot_offsets[s_ + 1])][2:-2]
+            assert t[ta - int(coff[s_])] == t[tb - int(coff[s_])]
+        # the reference's matrix uploaded as the pattern in force, read back through the masked Jacobian: structure exact
+        h.upload_pattern(pg, mg if h.T else None)
+        x = g['x0'] + g['delta']
+        f, J, ctrl = h.residual_jacobian(x, _lib.JAC_PATTERN)
+        mf, mJ, mctrl = h.motion_rows(x, _lib.JAC_PATTERN)
+        D = slots_to_dense(prob, J, ctrl, mJ if h.T else None, mctrl if h.T else None)
+        assert not D[ref.toarray() == 0].any()                                  # nothing outside the reference's matrix
+        if tie_order_is_the_recorded_one():
+            pn, mn = pattern.resolve_ties(prob, g['x0'], pat_c, mp_c, how='numpy')
+            assert (pattern.reference_pattern(prob, pn, mn if h.T else None) != ref).nnz == 0
+
+
+@pytest.mark.parametrize('name', CASES)
 def test_analytic_jacobian_vs_oracle_central_differences(BAHandle, name):
     scene, g = load_case(name)
     prob, _ = mp.problem_from_scene(scene)
@@ -158,9 +203,11 @@ def test_ba_vs_reference_result(BAHandle, name):
     prob, _ = mp.problem_from_scene(scene)
     oprob, _ = orc.problem_from_scene(scene)
     with BAHandle(prob) as h:
-        r = h.solve(g['x0'], solver=_lib.SOLVER_TRF_LSMR, jac_mode=_lib.JAC_PATTERN, max_nfev=10)
+        r = h.solve(g['x0'], solver=_lib.SOLVER_TRF_LSMR, jac_mode=_lib.JAC_PATTERN, max_nfev=10, matrix=golden_matrix(g))
         keep = h.outlier_mask(r.x, float(g['thres_outlier']))
     assert r.nfev == int(g['ba10_nfev'])
+    # analytic derivatives in the reference's matrix instead of its lumped forward differences: another (better) iterate
+    # after 10 evaluations -- one-sided bound; the two-sided comparison is test_fd_mode_ba_vs_reference_result
     assert r.cost < float(g['ba10_cost']) * (1 + 5e-3)
     assert orc.reprojection_rmse(oprob, r.x) < float(g['ba10_rmse']) + 2.5e-2
     assert np.mean(keep.astype(np.uint8) == g['outlier_keep']) > 0.95
@@ -246,39 +293,12 @@ def test_full_size_properties(BAHandle):
         np.testing.assert_allclose(gg, z_f, rtol=0, atol=1e-9 * np.abs(z_f).max())
         # ... and the damped step of the whole GPU solve chain at this size (155 separators, 8 levels of cyclic reduction)
         # against LAPACK: banded Cholesky of the spline block, dense Schur complement
-        from scipy.linalg import solveh_banded
+        from lm_reference import lapack_lm_step
         lam = 0.5
         p_gpu = h.lm_step(lam)
-        C, B, N, W = prob.C, 3 + prob.P, band.shape[0], band.shape[1]
-        cam_cols = np.array([[c, C + c, 2 * C + c] + list(range(3 * C + c * prob.P, 3 * C + (c + 1) * prob.P)) for c in range(C)])
-        spl_cols = np.concatenate([[int(prob.spline_x_offsets[s_]) + d * int(n_) + j for j in range(int(n_)) for d in range(3)]
-                                   for s_, n_ in enumerate(prob.n_coef)])
-        bw = 3 * W - 1
-        ab = np.zeros((bw + 1, 3 * N))                                  # upper banded storage of the spline block
-        for w in range(W):
-            for a_ in range(3):
-                for b_ in range(3):
-                    off = 3 * w + b_ - a_
-                    if off < 0:
-                        continue
-                    rows = 3 * np.arange(N - w) + a_
-                    ab[bw - off, rows + off] = band[:N - w, w, a_, b_]
-        dS = ab[bw].copy()
-        ab[bw] += lam * np.where(dS > 0, dS, 1.0)
-        Esp = cross.reshape(C * B, 3 * N)
-        Z = solveh_banded(ab, np.column_stack([Esp.T, gg[spl_cols]]))
-        Acam = np.zeros((C * B, C * B))
-        for c in range(C):
-            Acam[c * B:(c + 1) * B, c * B:(c + 1) * B] = A[c]
-        dA = np.diag(Acam).copy()
-        Sred = Acam + lam * np.diag(np.where(dA > 0, dA, 1.0)) - Esp @ Z[:, :-1]
-        pc = -np.linalg.solve(Sred, gg[cam_cols.ravel()] - Esp @ Z[:, -1])
-        ps = -(Z[:, -1] + Z[:, :-1] @ pc)
-        p_ref = np.zeros(h.n)
-        p_ref[cam_cols.ravel()] = pc
-        p_ref[spl_cols] = ps
+        p_ref = lapack_lm_step(prob, gg, A, band, cross, lam)
         np.testing.assert_allclose(p_gpu, p_ref, rtol=0, atol=1e-6 * np.abs(p_ref).max())
-        del A, band, cross, Z, Esp
+        del A, band, cross
         keep = h.outlier_mask(x0, 10.0)
         off = prob.det_offsets
         ex = np.concatenate([f1[2 * a:2 * a + (b - a)] for a, b in zip(off[:-1], off[1:])])
@@ -308,7 +328,7 @@ def test_fd_jacobian_gpu_vs_host_and_scipy(BAHandle, name):
     # (per column the noise floor is ~1e-13 px / 1.5e-8 = 1e-5 absolute; weak columns such as k3 have small scale)
     assert np.max(np.abs(D - D_ref) / np.maximum(scale, 1e-2 * np.abs(D_ref).max())) < 1e-3
     assert np.quantile(np.abs(D - D_ref) / scale, 0.999) < 1e-2
-    A = pattern.reference_pattern(prob, pat)
+    A = pattern.reference_pattern(prob, pat, hh.motion_pattern() if prob.motion_reg else None)
     assert not D[A.toarray() == 0].any()                      # nothing outside the reference pattern
 
 
@@ -319,13 +339,73 @@ def test_fd_mode_ba_vs_reference_result(BAHandle, name):
     prob, _ = mp.problem_from_scene(scene)
     oprob, _ = orc.problem_from_scene(scene)
     with BAHandle(prob) as h:
-        r = h.solve(g['x0'], solver=_lib.SOLVER_TRF_LSMR, jac_mode=_lib.JAC_FD, max_nfev=10)
+        r = h.solve(g['x0'], solver=_lib.SOLVER_TRF_LSMR, jac_mode=_lib.JAC_FD, max_nfev=10, matrix=golden_matrix(g))
         keep = h.outlier_mask(r.x, float(g['thres_outlier']))
     assert r.nfev == int(g['ba10_nfev'])
-    assert r.cost < float(g['ba10_cost']) * (1 + 5e-3)
-    assert abs(r.cost - float(g['ba10_cost'])) < 5e-2 * float(g['ba10_cost'])
-    assert abs(orc.reprojection_rmse(oprob, r.x) - float(g['ba10_rmse'])) < 0.2
-    assert np.mean(keep.astype(np.uint8) == g['outlier_keep']) >= 0.96
+    # same algorithm, same matrix: what is left is the rounding order of LSMR's products (tests/test_fd_mode_host.py has
+    # the host-build numbers; the calib+KE+bounds iterate is the one the reference itself does not reproduce)
+    loose = name == 'calib_KE_bounds_3cam'
+    d_cost = abs(r.cost - float(g['ba10_cost'])) / float(g['ba10_cost'])
+    d_rmse = abs(orc.reprojection_rmse(oprob, r.x) - float(g['ba10_rmse']))
+    flips = int(np.sum(keep.astype(np.uint8) != g['outlier_keep']))
+    print('FD 10 evaluations %s: cost rel %.2e, rmse %.2e px, %d mask flips' % (name, d_cost, d_rmse, flips))
+    assert d_cost < (5e-3 if loose else 5e-4)
+    assert d_rmse < (3e-2 if loose else 5e-3)
+    assert flips <= (0.05 * keep.size if loose else 3), flips
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_converged_second_ba_fd_mode(BAHandle, name):
+    """North-star parity at the one point where it is decidable: the reference's converged second BA (main.py:59 with
+    max_iter=200; status 3 on all four scenes).  The reference's algorithm on the GPU -- TRF + LSMR + grouped forward
+    differences over the reference's matrix -- from the reference's start: same status, final RMSE at the reference's
+    own reproducibility floor (see CONVERGED_RMSE_ATOL), inlier mask at the converged point identical."""
+    scene, g = filtered_case(name)
+    prob, _ = mp.problem_from_scene(scene)
+    oprob, _ = orc.problem_from_scene(scene)
+    with BAHandle(prob) as h:
+        r = h.solve(g['ba2_200_x0'], solver=_lib.SOLVER_TRF_LSMR, jac_mode=_lib.JAC_FD, max_nfev=200, matrix=golden_matrix(g, second=True))
+        keep = h.outlier_mask(r.x, float(g['thres_outlier']))
+    d_rmse = orc.reprojection_rmse(oprob, r.x) - float(g['ba2_200_rmse'])
+    print('converged FD %s: rmse %+.2e px, cost %.9g vs %.9g, nfev %d vs %d, status %d' % (name, d_rmse, r.cost, float(g['ba2_200_cost']), r.nfev, int(g['ba2_200_nfev']), r.status))
+    assert r.status == int(g['ba2_200_status']) == 3
+    assert abs(r.nfev - int(g['ba2_200_nfev'])) <= 6
+    # Measured on MI355X: -3.3e-4 (c1), -4.6e-4 (rs_F) px; the host build of the same solver lands 1.5e-4 / 1.0e-4 away and
+    # scipy's own least_squares on this repo's residual 1e-5 / 1e-6 (tests/test_fd_mode_host.py): the residual arithmetic
+    # is not what separates the runs, the summation order inside LSMR's J v / J^T u / norms is (scipy: sequential CSR loops
+    # and OpenBLAS ddot; here: one wavefront reduction tree per product), amplified by LSMR ~10x per 1-2 iterations.
+    assert abs(d_rmse) < GPU_CONVERGED_RMSE_ATOL[name]
+    assert np.array_equal(keep.astype(np.uint8), g['ba2_200_keep'])
+
+
+@pytest.mark.parametrize('name', CASES)
+@pytest.mark.parametrize('mode', ['trf_pattern', 'lm_schur'])
+def test_converged_second_ba_analytic_modes(BAHandle, name, mode):
+    """The analytic-Jacobian solvers from the same start: they do not stop where the reference's trust region collapses
+    (its Jacobian lumps the dropped control point into the kept ones) but go on to a LOWER value of the same objective.
+    Two-sided statement: the cost is below the reference's by the measured margin, the oracle confirms the value, and the
+    inlier mask at the end is compared with the reference's."""
+    scene, g = filtered_case(name)
+    prob, _ = mp.problem_from_scene(scene)
+    oprob, _ = orc.problem_from_scene(scene)
+    ref_cost, ref_rmse = float(g['ba2_200_cost']), float(g['ba2_200_rmse'])
+    with BAHandle(prob) as h:
+        if mode == 'trf_pattern':
+            r = h.solve(g['ba2_200_x0'], solver=_lib.SOLVER_TRF_LSMR, jac_mode=_lib.JAC_PATTERN, max_nfev=200, matrix=golden_matrix(g, second=True))
+        else:
+            r = h.solve(g['ba2_200_x0'], solver=_lib.SOLVER_LM_SCHUR, jac_mode=_lib.JAC_ANALYTIC, max_nfev=200)
+        keep = h.outlier_mask(r.x, float(g['thres_outlier']))
+    fo = orc.residual(oprob, r.x)
+    assert abs(0.5 * float(fo @ fo) - r.cost) < 1e-9 * r.cost
+    rmse = orc.reprojection_rmse(oprob, r.x)
+    flips = int(np.sum(keep.astype(np.uint8) != g['ba2_200_keep']))
+    print('converged %s %s: cost %.9g vs ref %.9g (%.2f %%), rmse %.6f vs %.6f, nfev %d status %d, %d mask flips'
+          % (mode, name, r.cost, ref_cost, 100 * (r.cost / ref_cost - 1), rmse, ref_rmse, r.nfev, r.status, flips))
+    assert r.cost <= ref_cost * (1 + 1e-6)
+    # measured on the host build (cost vs reference): -2.1/-2.8 % c1, -14/-6 % rs_F, -49/-76 % calib_KE, -0.9/-1.8 % dist
+    if not prob.motion_reg:
+        assert rmse <= ref_rmse + 1e-4           # without a regulariser in the objective lower cost IS lower reprojection error
+    assert flips <= 3
 
 
 @pytest.mark.parametrize('name', CASES)

@@ -12,28 +12,6 @@ from mvus_amd import _lib
 from mvus_amd import problem as mp
 
 
-def pattern_from_pat0(prob, pat):
-    """Expand per-observation pattern starts into the (rows, cols) of the detection block of jac_BA."""
-    rows, cols = [], []
-    C, P = prob.C, prob.P
-    coff = prob.ctrl_offsets
-    for c in range(C):
-        a, b = int(prob.det_offsets[c]), int(prob.det_offsets[c + 1])
-        Mc = b - a
-        base = [c, C + c] + ([2 * C + c] if prob.rs_free else []) + list(range(3 * C + c * P, 3 * C + (c + 1) * P))
-        for i in range(a, b):
-            if pat[i] < 0:
-                continue
-            s = int(np.searchsorted(coff, pat[i], side='right') - 1)
-            n = int(prob.n_coef[s])
-            j = int(pat[i] - coff[s])
-            cc = base + [int(prob.spline_x_offsets[s]) + d * n + j + q for d in range(3) for q in range(3)]
-            for r in (2 * a + (i - a), 2 * a + Mc + (i - a)):
-                rows += [r] * len(cc)
-                cols += cc
-    return np.array(rows), np.array(cols)
-
-
 @pytest.mark.parametrize('name', CASES)
 def test_full_residual_including_motion_rows(name):
     scene, g = load_case(name)
@@ -45,29 +23,6 @@ def test_full_residual_including_motion_rows(name):
         scale = np.maximum(1.0, np.abs(fref))
         assert np.max(np.abs(f - fref) / scale) < 1e-9
         assert np.array_equal(f == 0, fref == 0)
-
-
-@pytest.mark.parametrize('name', CASES)
-def test_pattern_matches_reference(name):
-    scene, g = load_case(name)
-    prob, _ = mp.problem_from_scene(scene)
-    h = HostHandle(prob)
-    pat = h.set_pattern(g['x0'])
-    rows, cols = pattern_from_pat0(prob, pat)
-    M2 = 2 * prob.M
-    ref = sparse.csr_matrix((np.ones(g['pattern_rows'].size), (g['pattern_rows'], g['pattern_cols'])),
-                            shape=tuple(g['pattern_shape']))[:M2]
-    mine = sparse.csr_matrix((np.ones(rows.size), (rows, cols)), shape=(M2, ref.shape[1]))
-    mine.data[:] = 1
-    diff = (mine != ref)
-    bad_rows = np.unique(diff.nonzero()[0])
-    # identical except for rows where numpy's unstable argsort breaks an exact tie between the two coincident
-    # end knots the other way (oracle.jac_pattern docstring) -- those rows sit in the first / last knot span
-    assert bad_rows.size <= 0.1 * M2
-    assert np.array_equal(np.diff(mine.indptr), np.diff(ref.indptr))
-    if bad_rows.size:
-        d = diff[bad_rows]
-        assert (d.sum(axis=1) == 6).all()          # one control point (3 coords) swapped for its twin
 
 
 @pytest.mark.parametrize('name', CASES)
@@ -108,7 +63,7 @@ def test_dense_jacobian_vs_central_differences(name):
 
 def _scipy_vs_restatement(prob, x0, max_nfev, lsmr_maxiter):
     h = HostHandle(prob)
-    h.set_pattern(x0)
+    h.prepare_pattern(x0)
     fun = lambda x: h.residual(x)
     jac = lambda x: sparse.csr_matrix(h.dense_jacobian(x, _lib.JAC_PATTERN)[1])
     lb, ub = prob.bounds()
