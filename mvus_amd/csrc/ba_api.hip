@@ -79,11 +79,14 @@ struct HipBackend {
     dp.sp.S = hp.S; dp.sp.istart = dupload(hp.istart); dp.sp.iend = dupload(hp.iend); dp.sp.knots = dupload(hp.knots);
     dp.sp.knot_off = dupload(hp.knot_off); dp.sp.ctrl_off = dupload(hp.ctrl_off); dp.sp.xoff = dupload(hp.xoff);
     dp.sp.lut = dupload(hp.lut); dp.sp.lut_off = dupload(hp.lut_off); dp.sp.lut_scale = dupload(hp.lut_scale);
+    dp.sp.info = dupload(hp.sinfo);
     dp.mv.T = hp.T; dp.mv.type = hp.motion_type; dp.mv.w = hp.w;
     dp.mv.t = dupload(hp.ms_t); dp.mv.basis = dupload(hp.ms_basis); dp.mv.ctrl = dupload(hp.ms_ctrl);
     dp.mv.part = dupload(hp.ms_part); ms_pat_dev = dupload(hp.ms_pat); dp.mv.pat = ms_pat_dev;
     dp.mv.ctrl_x0 = dupload(hp.ctrl_x0); dp.mv.ctrl_stride = dupload(hp.ctrl_stride);
-    dp.chunk_cam = dupload(hp.chunk_cam); dp.chunk_count = dupload(hp.chunk_count);
+    dp.mv.row_lo = dupload(hp.ms_row_lo); dp.mv.row_hi = dupload(hp.ms_row_hi);
+    dp.chunk_cam = dupload(hp.chunk_cam); dp.chunk_count = dupload(hp.chunk_count); dp.chunks = dupload(hp.chunks);
+    dp.cam_chunk_off = dupload(hp.cam_chunk_off);
     std::vector<long long> cs(hp.chunk_start.begin(), hp.chunk_start.end()), doff(hp.det_off.begin(), hp.det_off.end());
     dp.chunk_start = dupload(cs); dp.det_off = dupload(doff);
     dp.n_chunks = (int)hp.chunk_cam.size();
@@ -319,12 +322,7 @@ struct HipBackend {
       // the handle now describes the filtered problem
       hp.det_off = new_off; hp.M = newM; hp.m = 2 * newM + hp.T;
       hp.frame.clear(); hp.u_raw.clear(); hp.v_raw.clear();          // host copies are no longer current
-      hp.chunk_cam.clear(); hp.chunk_start.clear(); hp.chunk_count.clear();
-      for (int c = 0; c < hp.C; ++c)
-        for (int64_t a = hp.det_off[c]; a < hp.det_off[c + 1]; a += kChunk) {
-          hp.chunk_cam.push_back(c); hp.chunk_start.push_back(a);
-          hp.chunk_count.push_back((int32_t)std::min<int64_t>(kChunk, hp.det_off[c + 1] - a));
-        }
+      hp.build_chunks();
       dp.frame = nf; dp.u_raw = nu; dp.v_raw = nv; dp.u_obs = nuo; dp.v_obs = nvo;
       dp.M = newM;
       // the launch tables shrink (never more chunks per camera than before): rewritten in place
@@ -334,8 +332,10 @@ struct HipBackend {
         MVUS_HIP(hipMemcpyAsync(const_cast<int32_t*>(dp.chunk_cam), hp.chunk_cam.data(), nck * sizeof(int32_t), hipMemcpyHostToDevice, stream));
         MVUS_HIP(hipMemcpyAsync(const_cast<int32_t*>(dp.chunk_count), hp.chunk_count.data(), nck * sizeof(int32_t), hipMemcpyHostToDevice, stream));
         MVUS_HIP(hipMemcpyAsync(const_cast<long long*>(dp.chunk_start), cs.data(), nck * sizeof(long long), hipMemcpyHostToDevice, stream));
+        MVUS_HIP(hipMemcpyAsync(const_cast<ChunkInfo*>(dp.chunks), hp.chunks.data(), nck * sizeof(ChunkInfo), hipMemcpyHostToDevice, stream));
       }
       MVUS_HIP(hipMemcpyAsync(const_cast<long long*>(dp.det_off), doff.data(), doff.size() * sizeof(long long), hipMemcpyHostToDevice, stream));
+      MVUS_HIP(hipMemcpyAsync(const_cast<int32_t*>(dp.cam_chunk_off), hp.cam_chunk_off.data(), hp.cam_chunk_off.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
       dp.n_chunks = (int)nck;
       MVUS_HIP(hipStreamSynchronize(stream));
       has_pattern = false; has_jacobian = false; fd_ngroups = 0;
@@ -381,13 +381,28 @@ struct HipBackend {
     if (hp.T > 0) hipLaunchKernelGGL(k_motion_jv, dim3((hp.T + kThreads - 1) / kThreads), dim3(kThreads), 0, stream, dp, mJ, mctrl, v, y + 2 * hp.M);
     MVUS_HIP(hipGetLastError());
   }
+  // z = J^T u of this rank's rows: deterministic two-pass form (k_jtu_partial / k_jtu_reduce)
+  double *zc = nullptr, *zs = nullptr;
+  int32_t* zg0 = nullptr;
+  int* jt_nondet = nullptr;
   void jtu_local(const double* u, double* z) {
-    MVUS_HIP(hipMemsetAsync(z, 0, sizeof(double) * hp.n, stream));
-    if (dp.n_chunks > 0) {
-      if (hp.calib) hipLaunchKernelGGL(k_jtu_gather<30>, dim3(dp.n_chunks), dim3(kThreads), 0, stream, dp, J, span, u, z);
-      else hipLaunchKernelGGL(k_jtu_gather<21>, dim3(dp.n_chunks), dim3(kThreads), 0, stream, dp, J, span, u, z);
+    if (!zc) {
+      const size_t nc = std::max<size_t>(hp.chunks.size(), 1);
+      zc = dalloc<double>(nc * (size_t)(hp.NS - 12)); zs = dalloc<double>(nc * 3 * (size_t)kJtWin); zg0 = dalloc<int32_t>(nc);
+      jt_nondet = dalloc<int>(1);
+      MVUS_HIP(hipMemsetAsync(jt_nondet, 0, sizeof(int), stream));
     }
-    if (hp.T > 0) hipLaunchKernelGGL(k_motion_jtu, dim3((hp.T + kThreads - 1) / kThreads), dim3(kThreads), 0, stream, dp, mJ, mctrl, u + 2 * hp.M, z);
+    MVUS_HIP(hipMemsetAsync(z, 0, sizeof(double) * hp.n, stream));
+    const int cols = hp.C * (hp.NS - 12) + 3 * hp.N;
+    const dim3 g2((cols + kThreads - 1) / kThreads), b(kThreads);
+    const int motion = hp.T > 0 ? 1 : 0;
+    if (hp.calib) {
+      if (dp.n_chunks > 0) hipLaunchKernelGGL(k_jtu_partial<30>, dim3(dp.n_chunks), b, 0, stream, dp, J, span, u, z, zc, zs, zg0, jt_nondet);
+      hipLaunchKernelGGL(k_jtu_reduce<30>, g2, b, 0, stream, dp, zc, zs, zg0, mJ, mctrl, u + 2 * hp.M, motion, z);
+    } else {
+      if (dp.n_chunks > 0) hipLaunchKernelGGL(k_jtu_partial<21>, dim3(dp.n_chunks), b, 0, stream, dp, J, span, u, z, zc, zs, zg0, jt_nondet);
+      hipLaunchKernelGGL(k_jtu_reduce<21>, g2, b, 0, stream, dp, zc, zs, zg0, mJ, mctrl, u + 2 * hp.M, motion, z);
+    }
     MVUS_HIP(hipGetLastError());
   }
   void jtu(const double* u, double* z) { jtu_local(u, z); reduce(z, (size_t)hp.n); }
@@ -772,8 +787,7 @@ int mvus_ba_time_kernel(mvus_ba* h, int32_t which, int32_t launches, double* avg
           else hipLaunchKernelGGL(k_jv<21>, g, b, 0, be.stream, be.dp, be.J, be.span, vn, ym);
           break;
         case 3:
-          if (be.hp.calib) hipLaunchKernelGGL(k_jtu_gather<30>, g, b, 0, be.stream, be.dp, be.J, be.span, um, zn);
-          else hipLaunchKernelGGL(k_jtu_gather<21>, g, b, 0, be.stream, be.dp, be.J, be.span, um, zn);
+          be.jtu_local(um, zn);
           break;
         default:
           schur->assemble_local(be.f_cur);

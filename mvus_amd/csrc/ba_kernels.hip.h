@@ -38,6 +38,8 @@ struct DevProblem {  // trivially copyable: passed to kernels by value
   SplineView sp;
   MotionView mv;
   const int32_t *chunk_cam, *chunk_count;
+  const ChunkInfo* chunks;    // the same launch table, one 32-byte record per chunk
+  const int32_t* cam_chunk_off;   // [C+1] chunks of camera c are cam_chunk_off[c] .. cam_chunk_off[c+1]
   const long long *chunk_start, *det_off;
   int n_chunks;
   int mot_lo, mot_hi;   // motion rows whose first control point lies in [mot_lo, mot_hi) are evaluated (time shards), the rest are zero rows
@@ -91,22 +93,63 @@ __global__ void k_undistort_fixed(DevProblem dp, double* __restrict__ u_obs, dou
 
 // Fused per-observation kernel: timestamp -> interval/span search -> de Boor -> R,t -> K -> |residual|
 // and (JAC) the 2 x NS analytic Jacobian block.  masked != 0 keeps only the reference pattern (pat0).
+#ifndef MVUS_JAC_WAVES
+#define MVUS_JAC_WAVES 4
+#endif
+#if !defined(MVUS_JAC_ARRAY) && !defined(MVUS_JAC_DIRECT)
+#define MVUS_JAC_DIRECT 1        // default: values go to memory as they are produced (98 VGPRs; the array form needs 128 + scratch)
+#endif
+#ifdef MVUS_JAC_NT
+#define MVUS_JSTORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#else
+#define MVUS_JSTORE(ptr, val) (*(ptr) = (val))
+#endif
+// Sink of eval_observation_to that stores each value of the 2 x NS block straight to the slot-major Jacobian
+// (masked: spline slots outside the pattern become zeros; an all-zero pattern row stores nothing).
+struct JStoreSink {
+  double *Jx, *Jy;
+  long long stride;
+  int32_t pat;
+  int base;
+  bool masked, live;
+  int32_t ctrl;
+  __device__ __forceinline__ void begin(int32_t c) { ctrl = c; live = !(masked && pat < 0); }
+  __device__ __forceinline__ double keep(int k, double v) const {
+    return (masked && k >= base && !pattern_has(pat, ctrl + (k - base) / 3)) ? 0.0 : v;
+  }
+  // Jx / Jy are wave-uniform (the chunk's first column of slot 0), lane the 32-bit column inside the chunk: the address is
+  // an SGPR base plus a zero-extended VGPR offset, no per-lane 64-bit arithmetic and no address registers per store
+  unsigned lane;
+  __device__ __forceinline__ void x(int k, double v) { if (live) MVUS_JSTORE(&(Jx + (long long)k * stride)[lane], keep(k, v)); }
+  __device__ __forceinline__ void y(int k, double v) { if (live) MVUS_JSTORE(&(Jy + (long long)k * stride)[lane], keep(k, v)); }
+};
+
 template <bool CALIB, bool JAC>
-__global__ __launch_bounds__(kThreads) void k_observations(DevProblem dp, const CamState* __restrict__ cams,
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(JAC ? MVUS_JAC_WAVES : 4, 8))) void k_observations(DevProblem dp, const CamState* __restrict__ cams,
                                                            const double* __restrict__ x, double* __restrict__ f,
                                                            double* __restrict__ J, int32_t* __restrict__ span,
                                                            const int32_t* __restrict__ pat0, int masked) {
-  __shared__ CamState cam;
   constexpr int NS = 3 + (CALIB ? 15 : 6) + 12;
   const int chunk = blockIdx.x;
-  const int c = dp.chunk_cam[chunk];
-  stage_cam(cams, c, cam);
-  if ((int)threadIdx.x >= dp.chunk_count[chunk]) return;
-  const long long i = dp.chunk_start[chunk] + threadIdx.x;
-  const long long a = dp.det_off[c], Mc = dp.det_off[c + 1] - a;
-  double jx[NS], jy[NS];
+  const ChunkInfo ci = dp.chunks[chunk];                 // wave-uniform: one scalar load
+  // the camera state is wave-uniform too: it is read through the scalar cache into SGPRs (34 doubles that would occupy
+  // 68 VGPRs of every lane as hoisted LDS broadcasts, and no LDS staging + barrier before the first useful load)
+  const CamState& cam = cams[ci.cam];
+  if ((int)threadIdx.x >= ci.count) return;
+  const long long i = ci.start + threadIdx.x;
+  const long long a = ci.cam_start, Mc = ci.cam_count;
   const double uo = CALIB ? 0.0 : dp.u_obs[i], vo = CALIB ? 0.0 : dp.v_obs[i];
   const double ur = CALIB ? dp.u_raw[i] : 0.0;
+#ifdef MVUS_JAC_DIRECT
+  // every Jacobian value goes to memory as soon as it exists: the row never sits in registers as a whole
+  double* __restrict__ Jc = J + ci.start;          // wave-uniform
+  JStoreSink sink{Jc, Jc + (long long)NS * dp.M, dp.M, (JAC && masked) ? pat0[i] : 0, NS - 12, JAC && masked != 0, true, -1, threadIdx.x};
+  ObsResult r = eval_observation_to<CALIB, JAC>(cam, dp.sp, x, dp.undist != 0, dp.rs_free != 0, dp.sync_free != 0, dp.frame[i], ur, dp.v_raw[i], uo, vo, sink);
+  f[2 * a + (i - a)] = r.ex;
+  f[2 * a + Mc + (i - a)] = r.ey;
+  if (JAC) span[i] = (r.ctrl >= 0 && sink.live) ? r.ctrl : -1;
+#else
+  double jx[NS], jy[NS];
   ObsResult r = eval_observation<CALIB, JAC>(cam, dp.sp, x, dp.undist != 0, dp.rs_free != 0, dp.sync_free != 0, dp.frame[i], ur, dp.v_raw[i],
                                              uo, vo, jx, jy);
   f[2 * a + (i - a)] = r.ex;
@@ -122,11 +165,17 @@ __global__ __launch_bounds__(kThreads) void k_observations(DevProblem dp, const 
     if (ctrl >= 0) {
 #pragma unroll
       for (int k = 0; k < NS; ++k) {
-        J[(long long)k * dp.M + i] = jx[k];       // plain stores: nontemporal ones measured 60% slower (61 vs 38 us)
-        J[(long long)(NS + k) * dp.M + i] = jy[k];
+#ifdef MVUS_JAC_SADDR
+        MVUS_JSTORE(&(J + ci.start + (long long)k * dp.M)[threadIdx.x], jx[k]);         // SGPR base + 32-bit lane offset
+        MVUS_JSTORE(&(J + ci.start + (long long)(NS + k) * dp.M)[threadIdx.x], jy[k]);
+#else
+        MVUS_JSTORE(&J[(long long)k * dp.M + i], jx[k]);
+        MVUS_JSTORE(&J[(long long)(NS + k) * dp.M + i], jy[k]);
+#endif
       }
     }
   }
+#endif
 }
 
 // Reference sparsity pattern of the detection rows at x0 (jac_BA + compute_visibility).
@@ -203,81 +252,47 @@ __global__ __launch_bounds__(kThreads) void k_jv(DevProblem dp, const double* __
   y[2 * a + Mc + (i - a)] = sy;
 }
 
-// z += J^T u on the detection rows.  The camera/sync slots of a workgroup all hit the same B columns:
-// wavefront shuffle reduction, then LDS across the 4 wavefronts, then one fp64 atomic per column.
-template <int NS>
-__global__ __launch_bounds__(kThreads) void k_jtu(DevProblem dp, const double* __restrict__ J, const int32_t* __restrict__ span,
-                                                  const double* __restrict__ u, double* __restrict__ z) {
-  constexpr int B = NS - 12;
-  __shared__ double part[kThreads / 64][B];
-  const int chunk = blockIdx.x;
-  const int c = dp.chunk_cam[chunk];
-  const bool active = (int)threadIdx.x < dp.chunk_count[chunk];
-  const long long i = dp.chunk_start[chunk] + (active ? threadIdx.x : 0);
-  const long long a = dp.det_off[c], Mc = dp.det_off[c + 1] - a;
-  const int g = active ? span[i] : -1;
-  const double ux = g >= 0 ? u[2 * a + (i - a)] : 0.0;
-  const double uy = g >= 0 ? u[2 * a + Mc + (i - a)] : 0.0;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int k = 0; k < B; ++k) {
-    double val = 0.0;
-    if (g >= 0) val = J[(long long)k * dp.M + i] * ux + J[(long long)(NS + k) * dp.M + i] * uy;
-    val = wave_sum(val);
-    if (lane == 0) part[wave][k] = val;
-  }
-  if (g >= 0) {
-    const int x0 = dp.mv.ctrl_x0[g], st = dp.mv.ctrl_stride[g];
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-      for (int d = 0; d < 3; ++d) {
-        const double val = J[(long long)(B + 3 * q + d) * dp.M + i] * ux + J[(long long)(NS + B + 3 * q + d) * dp.M + i] * uy;
-        unsafeAtomicAdd(&z[x0 + q + d * st], val);
-      }
-  }
-  __syncthreads();
-  if (threadIdx.x < B) {
-    double s = 0.0;
-#pragma unroll
-    for (int w = 0; w < kThreads / 64; ++w) s += part[w][threadIdx.x];
-    unsafeAtomicAdd(&z[cam_col(dp.C, dp.P, c, threadIdx.x)], s);
-  }
-}
+constexpr int kJtWin = 144;     // control points per chunk window of the J^T u gather
 
-// z += J^T u, gather form.  The products p[q][d][i] = Jx[q,d](i) ux(i) + Jy[q,d](i) uy(i) of the chunk are staged in
-// LDS; the detections of one knot span form one contiguous index range (frames are time ordered), so output
-// (control point l, coordinate d) is owned by one thread that sums the <= 4 spans touching it: no LDS atomics, one
-// global atomic per output and chunk instead of 12 per detection.  Chunks whose spans are not sorted, or that
-// do not fit the window, take the atomic path of k_jtu (flagged per chunk).
-constexpr int kJtWin = 144;     // control points per chunk window
+// ---- z = J^T u, DETERMINISTIC two-pass form (what the TRF + LSMR parity solver uses) ---------------------------------
+// LSMR on these Jacobians amplifies last-bit differences of its products by ~10x every 1-2 iterations, so a J^T u whose
+// fp64 atomics arrive in a different order on every run makes the whole optimiser irreproducible from run to run.  Here
+// every output is written by exactly one thread that adds its contributions in a fixed order:
+//   pass 1 (k_jtu_partial, one workgroup per chunk): the chunk's B camera sums and the sums of its control-point window
+//          (the gather of k_jtu_gather) go to per-chunk buffers, nothing is added to z;
+//   pass 2 (k_jtu_reduce, one thread per column of z): camera columns add their camera's chunks in order; a spline
+//          column adds, camera by camera and chunk by chunk, the window entries that cover its control point, then the
+//          motion rows that touch it (a contiguous row range known in advance).
+// Chunks whose spans interleave (a large rolling-shutter coefficient) take an O(256) loop per output instead of the range
+// tables -- still ordered; only a chunk whose detections spread over more than kJtWin control points (very sparse
+// tracks) falls back to atomics, and raises *nondet so the caller can know.
 template <int NS>
-__global__ __launch_bounds__(kThreads) void k_jtu_gather(DevProblem dp, const double* __restrict__ J, const int32_t* __restrict__ span,
-                                                         const double* __restrict__ u, double* __restrict__ z) {
+__global__ __launch_bounds__(kThreads) void k_jtu_partial(DevProblem dp, const double* __restrict__ J, const int32_t* __restrict__ span,
+                                                          const double* __restrict__ u, double* __restrict__ z, double* __restrict__ zc,
+                                                          double* __restrict__ zs, int32_t* __restrict__ zg0, int* __restrict__ nondet) {
   constexpr int B = NS - 12;
-  constexpr int PS = kThreads + 1;                     // padded row stride of the staged products
+  constexpr int PS = kThreads + 1;
   __shared__ double part[kThreads / 64][B];
   __shared__ double prod[12 * PS];
-  __shared__ int lo[kJtWin], hi[kJtWin];
+  __shared__ int lo[kJtWin], hi[kJtWin], skey[kThreads];
   __shared__ int gmin_s[kThreads / 64];
-  __shared__ int bad_s;
+  __shared__ int bad_s, wide_s;
   const int chunk = blockIdx.x;
-  const int c = dp.chunk_cam[chunk];
-  const int cnt = dp.chunk_count[chunk];
-  const bool active = (int)threadIdx.x < cnt;
-  const long long i = dp.chunk_start[chunk] + (active ? threadIdx.x : 0);
-  const long long a = dp.det_off[c], Mc = dp.det_off[c + 1] - a;
+  const ChunkInfo ci = dp.chunks[chunk];
+  const bool active = (int)threadIdx.x < ci.count;
+  const long long i = ci.start + (active ? threadIdx.x : 0);
+  const long long a = ci.cam_start, Mc = ci.cam_count;
   const int g = active ? span[i] : -1;
   const double ux = g >= 0 ? u[2 * a + (i - a)] : 0.0;
   const double uy = g >= 0 ? u[2 * a + Mc + (i - a)] : 0.0;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int k = threadIdx.x; k < kJtWin; k += kThreads) { lo[k] = 0x7fffffff; hi[k] = 0; }
-  if (threadIdx.x == 0) bad_s = 0;
+  if (threadIdx.x == 0) { bad_s = 0; wide_s = 0; }
+  skey[threadIdx.x] = g;
   int gm = g >= 0 ? g : 0x7fffffff;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) gm = min(gm, __shfl_xor(gm, off, 64));
   if (lane == 0) gmin_s[wave] = gm;
-  // camera / sync columns: wavefront reduction as in k_jtu
 #pragma unroll
   for (int k = 0; k < B; ++k) {
     double val = 0.0;
@@ -290,12 +305,14 @@ __global__ __launch_bounds__(kThreads) void k_jtu_gather(DevProblem dp, const do
 #pragma unroll
   for (int w = 1; w < kThreads / 64; ++w) g0 = min(g0, gmin_s[w]);
   if (threadIdx.x < B) {
-    double s = 0.0;
+    double sacc = 0.0;
 #pragma unroll
-    for (int w = 0; w < kThreads / 64; ++w) s += part[w][threadIdx.x];
-    if (s != 0.0) unsafeAtomicAdd(&z[cam_col(dp.C, dp.P, c, threadIdx.x)], s);
+    for (int w = 0; w < kThreads / 64; ++w) sacc += part[w][threadIdx.x];
+    zc[(long long)chunk * B + threadIdx.x] = sacc;
   }
-  if (g0 == 0x7fffffff) return;                       // nothing visible (uniform)
+  if (threadIdx.x == 0) zg0[chunk] = g0;
+  double* zw = zs + (long long)chunk * (3 * kJtWin);
+  if (g0 == 0x7fffffff) return;                       // nothing visible (uniform): pass 2 skips the chunk
   const int l = g - g0;
   double pv[12];
 #pragma unroll
@@ -304,17 +321,17 @@ __global__ __launch_bounds__(kThreads) void k_jtu_gather(DevProblem dp, const do
     prod[e * PS + threadIdx.x] = pv[e];
   }
   if (g >= 0) {
-    if (l + 3 >= kJtWin) atomicOr(&bad_s, 1);
+    if (l + 3 >= kJtWin) atomicOr(&wide_s, 1);
     else { atomicMin(&lo[l], (int)threadIdx.x); atomicMax(&hi[l], (int)threadIdx.x + 1); }
   }
   __syncthreads();
-  // ranges of different spans must not interleave (they cannot when timestamps increase with the frame number)
   if (threadIdx.x < kJtWin && hi[threadIdx.x] > 0) {
     for (int t = threadIdx.x + 1; t < kJtWin; ++t)
       if (hi[t] > 0) { if (lo[t] < hi[threadIdx.x]) atomicOr(&bad_s, 1); break; }
   }
   __syncthreads();
-  if (bad_s) {                                         // fallback: per-detection atomics
+  if (wide_s) {                                        // detections spread over more control points than the window holds
+    if (threadIdx.x == 0) { zg0[chunk] = 0x7fffffff; atomicAdd(nondet, 1); }
     if (g >= 0) {
       const int x0 = dp.mv.ctrl_x0[g], st = dp.mv.ctrl_stride[g];
 #pragma unroll
@@ -325,21 +342,66 @@ __global__ __launch_bounds__(kThreads) void k_jtu_gather(DevProblem dp, const do
     return;
   }
   for (int o = threadIdx.x; o < 3 * kJtWin; o += kThreads) {
-    const int lc = o / 3, d = o % 3;                   // local control point, coordinate
+    const int lc = o / 3, d = o % 3;
     double acc = 0.0;
-    bool any = false;
+    if (!bad_s) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int s = lc - q;
-      if (s < 0) continue;
-      const int b = lo[s], e = hi[s];
-      for (int t = b; t < e; ++t) { acc += prod[(3 * q + d) * PS + t]; any = true; }
+      for (int q = 0; q < 4; ++q) {
+        const int sidx = lc - q;
+        if (sidx < 0) continue;
+        const int b = lo[sidx], e = hi[sidx];
+        for (int t = b; t < e; ++t) acc += prod[(3 * q + d) * PS + t];
+      }
+    } else {                                           // interleaved spans: every detection, in index order
+      for (int t = 0; t < ci.count; ++t) {
+        const int q = lc - (skey[t] - g0);
+        if (skey[t] >= 0 && q >= 0 && q < 4) acc += prod[(3 * q + d) * PS + t];
+      }
     }
-    if (any && acc != 0.0) {
-      const int gg = g0 + lc;
-      unsafeAtomicAdd(&z[dp.mv.ctrl_x0[gg] + d * dp.mv.ctrl_stride[gg]], acc);
+    zw[o] = acc;
+  }
+}
+
+// pass 2: one thread per column of z (camera columns first, then control point x coordinate)
+template <int NS>
+__global__ __launch_bounds__(kThreads) void k_jtu_reduce(DevProblem dp, const double* __restrict__ zc, const double* __restrict__ zs,
+                                                         const int32_t* __restrict__ zg0, const double* __restrict__ mJ,
+                                                         const int32_t* __restrict__ mctrl, const double* __restrict__ um, int motion,
+                                                         double* __restrict__ z) {
+  constexpr int B = NS - 12;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int CB = dp.C * B;
+  if (idx < CB) {
+    const int c = idx / B, k = idx % B;
+    double acc = 0.0;
+    for (int ch = dp.cam_chunk_off[c]; ch < dp.cam_chunk_off[c + 1]; ++ch) acc += zc[(long long)ch * B + k];
+    z[cam_col(dp.C, dp.P, c, k)] += acc;
+    return;
+  }
+  const int r = idx - CB;
+  if (r >= 3 * dp.N) return;
+  const int g = r / 3, d = r % 3;
+  double acc = 0.0;
+  for (int c = 0; c < dp.C; ++c) {
+    for (int ch = dp.cam_chunk_off[c]; ch < dp.cam_chunk_off[c + 1]; ++ch) {
+      const int g0 = zg0[ch];
+      if (g0 == 0x7fffffff) continue;
+      if (g0 > g + kJtWin) break;                      // chunks are time ordered: later windows start even further right
+      const int lc = g - g0;
+      if (lc >= 0 && lc < kJtWin) acc += zs[(long long)ch * (3 * kJtWin) + 3 * lc + d];
     }
   }
+  if (motion) {
+    for (int j = dp.mv.row_lo[g]; j < dp.mv.row_hi[g]; ++j) {
+      const double uj = um[j];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int cg = mctrl[(long long)k * dp.T + j];
+        if (cg >= 0 && g >= cg && g <= cg + 3) acc += mJ[(long long)(12 * k + 3 * (g - cg) + d) * dp.T + j] * uj;
+      }
+    }
+  }
+  z[dp.mv.ctrl_x0[g] + d * dp.mv.ctrl_stride[g]] += acc;
 }
 
 __global__ __launch_bounds__(kThreads) void k_motion_jv(DevProblem dp, const double* __restrict__ mJ, const int32_t* __restrict__ mctrl,
@@ -356,24 +418,6 @@ __global__ __launch_bounds__(kThreads) void k_motion_jv(DevProblem dp, const dou
       for (int d = 0; d < 3; ++d) s += mJ[(long long)(12 * k + 3 * q + d) * dp.T + j] * v[x0 + q + d * st];
   }
   ym[j] = s;
-}
-
-__global__ __launch_bounds__(kThreads) void k_motion_jtu(DevProblem dp, const double* __restrict__ mJ, const int32_t* __restrict__ mctrl,
-                                                         const double* __restrict__ um, double* __restrict__ z) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= dp.T) return;
-  const double uj = um[j];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const int g = mctrl[(long long)k * dp.T + j];
-    if (g < 0) continue;
-    const int x0 = dp.mv.ctrl_x0[g], st = dp.mv.ctrl_stride[g];
-    for (int q = 0; q < 4; ++q)
-      for (int d = 0; d < 3; ++d) {
-        const double val = mJ[(long long)(12 * k + 3 * q + d) * dp.T + j] * uj;
-        if (val != 0.0) unsafeAtomicAdd(&z[x0 + q + d * st], val);
-      }
-  }
 }
 
 // Scene.remove_outliers (common.py:709-713): keep = sqrt(ex^2 + ey^2) < thres.  Explicit round-to-nearest

@@ -22,6 +22,13 @@
 #else
 #define MVUS_HD inline
 #endif
+// Scheduling fence between the groups of Jacobian slots (device code, opt-in): the values of one group are stored before
+// the next group is computed, instead of the whole 2 x NS block sitting in registers until one burst of stores at the end.
+#if defined(__HIP_DEVICE_COMPILE__) && defined(MVUS_JAC_GROUP_FENCE)
+#define MVUS_GROUP_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define MVUS_GROUP_FENCE() ((void)0)
+#endif
 
 namespace mvus {
 
@@ -120,8 +127,9 @@ MVUS_HD int find_span(const double* t, int n, double x) {
 
 // FITPACK fpbspl.f for k=3: the four cubic B-splines that are non-zero on span l, and (optionally)
 // their derivatives  B'_i = 3 [ B_{i,2}/(t_{i+3}-t_i) - B_{i+1,2}/(t_{i+4}-t_{i+1}) ].
+// The knots enter as the window tt[j] = t[l-2+j], j = 0..5 (all the recurrence touches).
 template <bool DERIV>
-MVUS_HD void bspline_basis(const double* t, int l, double x, double h[4], double dh[4]) {
+MVUS_HD void bspline_basis_w(const double tt[6], double x, double h[4], double dh[4]) {
   double hh[3];
   h[0] = 1.0;
   double q[3] = {0.0, 0.0, 0.0};  // quadratic basis B_{l-2,2}, B_{l-1,2}, B_{l,2}
@@ -129,20 +137,26 @@ MVUS_HD void bspline_basis(const double* t, int l, double x, double h[4], double
     for (int i = 0; i < j; ++i) hh[i] = h[i];
     h[0] = 0.0;
     for (int i = 0; i < j; ++i) {
-      const int li = l + i + 1, lj = li - j;
-      const double f = hh[i] / (t[li] - t[lj]);
-      h[i] = h[i] + f * (t[li] - x);
-      h[i + 1] = f * (x - t[lj]);
+      const double tli = tt[i + 3], tlj = tt[i + 3 - j];          // t[l+i+1], t[l+i+1-j]
+      const double f = hh[i] / (tli - tlj);
+      h[i] = h[i] + f * (tli - x);
+      h[i + 1] = f * (x - tlj);
     }
     if (DERIV && j == 2) { q[0] = h[0]; q[1] = h[1]; q[2] = h[2]; }
   }
   if (DERIV) {
     // coefficient i = l-3+k ; quadratic index m = l-2+k' ; denominators t[m+3]-t[m]
-    const double e0 = 3.0 * q[0] / (t[l + 1] - t[l - 2]);
-    const double e1 = 3.0 * q[1] / (t[l + 2] - t[l - 1]);
-    const double e2 = 3.0 * q[2] / (t[l + 3] - t[l]);
+    const double e0 = 3.0 * q[0] / (tt[3] - tt[0]);
+    const double e1 = 3.0 * q[1] / (tt[4] - tt[1]);
+    const double e2 = 3.0 * q[2] / (tt[5] - tt[2]);
     dh[0] = -e0; dh[1] = e0 - e1; dh[2] = e1 - e2; dh[3] = e2;
   }
+}
+template <bool DERIV>
+MVUS_HD void bspline_basis(const double* t, int l, double x, double h[4], double dh[4]) {
+  double tt[6];
+  for (int j = 0; j < 6; ++j) tt[j] = t[l - 2 + j];
+  bspline_basis_w<DERIV>(tt, x, h, dh);
 }
 
 // cv2.undistortPoints (5 iterations) on normalised coordinates; with TANGENT also the derivatives of
@@ -189,6 +203,28 @@ MVUS_HD void undistort5(double x0, double y0, const double d[5], double& xo, dou
   xo = x; yo = y;
 }
 
+// One launch chunk (<= 256 consecutive detections of one camera), 32 bytes: one scalar load per workgroup.
+struct ChunkInfo {
+  long long start;          // first detection (camera-segmented index)
+  long long cam_start;      // det_offsets[cam]
+  long long cam_count;      // detections of the camera (M_c): the y residuals sit M_c after the x residuals
+  int32_t cam, count;
+};
+
+// Everything the kernels need to know about one spline interval, in one 64-byte record: after the interval of a
+// timestamp is known a single (vector) load fetches it, instead of a chain of dependent table reads.
+struct SplineInfo {
+  double istart, iend;      // spline['int'][:, s]
+  double t3;                // first knot of the interval (origin of the span look-up grid)
+  double lut_scale;         // cells per unit time
+  int32_t knot_off;         // offset of the knot vector in `knots`
+  int32_t ctrl_off;         // global index of the first control point
+  int32_t n;                // number of coefficients
+  int32_t xoff;             // index in x of the coefficient block cx(n) cy(n) cz(n)
+  int32_t lut_off, nb;      // span look-up table: offset and number of cells
+  int32_t pad0, pad1;
+};
+
 // Read-only view of the trajectory splines as they sit in device memory.
 struct SplineView {
   int S;                    // number of spline intervals
@@ -203,6 +239,7 @@ struct SplineView {
   const int32_t* lut;       // concatenated tables
   const int32_t* lut_off;   // [S+1]
   const double* lut_scale;  // [S] cells per unit time
+  const SplineInfo* info;   // [S] the same facts, one record per interval (nullptr -> the separate tables above)
 };
 
 // Same result as find_span, through the look-up table when the view carries one.
@@ -217,6 +254,68 @@ MVUS_HD int find_span_lut(const SplineView& sp, int s, const double* t, int n, d
   return l;
 }
 
+// Where a timestamp falls: interval, knot span l (FITPACK rule t[l] <= tau < t[l+1], clamped to [3, n-1]), the six knots
+// t[l-2 .. l+3] and the twelve active coefficients.  Written for a SHORT chain of dependent memory accesses, which is
+// what a wavefront of this kernel waits on: [interval record] -> [table cell] -> [8 knots + 18 coefficients around the
+// guessed span, issued together] -> arithmetic; the guess is corrected by +-1 from the loaded window (select, no
+// reload) and only a larger miss (strongly non-uniform knots) re-searches.  Results are those of find_interval +
+// find_span + plain indexing, bit for bit.
+struct SpanLoc {
+  int32_t n, xoff, ctrl;    // coefficients of the spline, index of its block in x, global index of control point l-3
+  double tt[6];             // t[l-2 .. l+3]
+  double c[3][4];           // coefficients l-3 .. l of x, y, z
+};
+MVUS_HD bool locate_span(const SplineView& sp, const double* x, double tau, SpanLoc& loc) {
+  int l;
+  const double* t;
+  if (sp.info && sp.lut) {
+    int s = 0;
+    if (sp.S > 1) { s = find_interval(sp.istart, sp.iend, sp.S, tau); if (s < 0) return false; }
+    const SplineInfo si = sp.info[s];
+    if (sp.S == 1 && ((tau - si.istart >= 0.0) == (tau - si.iend >= 0.0))) return false;    // util.py:105, half-open
+    t = sp.knots + si.knot_off;
+    int b = (int)((tau - si.t3) * si.lut_scale);
+    b = b < 0 ? 0 : (b >= si.nb ? si.nb - 1 : b);
+    const int l0 = sp.lut[si.lut_off + b];
+    loc.n = si.n; loc.xoff = si.xoff;
+    double tk[8], cw[3][6];
+    for (int j = 0; j < 8; ++j) tk[j] = t[l0 - 3 + j];                    // t[l0-3 .. l0+4]: always inside the n+4 knots
+    const double* cb = x + si.xoff;
+    for (int j = 0; j < 6; ++j) {                                          // c[l0-4 .. l0+1], clamped (the clamped ones are never selected)
+      int idx = l0 - 4 + j;
+      idx = idx < 0 ? 0 : (idx > si.n - 1 ? si.n - 1 : idx);
+      cw[0][j] = cb[idx]; cw[1][j] = cb[idx + si.n]; cw[2][j] = cb[idx + 2 * si.n];
+    }
+    int off = 0;
+    bool ok = true;
+    if (l0 > 3 && tk[3] > tau) { off = -1; ok = !(l0 - 1 > 3 && tk[2] > tau); }
+    else if (l0 + 1 < si.n && tk[4] <= tau) { off = 1; ok = !(l0 + 2 < si.n && tk[5] <= tau); }
+    if (ok) {
+      l = l0 + off;
+      for (int j = 0; j < 6; ++j) loc.tt[j] = off < 0 ? tk[j] : (off == 0 ? tk[j + 1] : tk[j + 2]);
+      for (int d = 0; d < 3; ++d)
+        for (int q = 0; q < 4; ++q) loc.c[d][q] = off < 0 ? cw[d][q] : (off == 0 ? cw[d][q + 1] : cw[d][q + 2]);
+      loc.ctrl = si.ctrl_off + (l - 3);
+      return true;
+    }
+    l = find_span(t, si.n, tau);
+    loc.ctrl = si.ctrl_off + (l - 3);
+  } else {
+    const int s = find_interval(sp.istart, sp.iend, sp.S, tau);
+    if (s < 0) return false;
+    t = sp.knots + sp.knot_off[s];
+    loc.n = sp.ctrl_off[s + 1] - sp.ctrl_off[s];
+    loc.xoff = sp.xoff[s];
+    l = find_span_lut(sp, s, t, loc.n, tau);
+    loc.ctrl = sp.ctrl_off[s] + (l - 3);
+  }
+  for (int j = 0; j < 6; ++j) loc.tt[j] = t[l - 2 + j];
+  const double* cb = x + loc.xoff + (l - 3);
+  for (int d = 0; d < 3; ++d)
+    for (int q = 0; q < 4; ++q) loc.c[d][q] = cb[q + d * loc.n];
+  return true;
+}
+
 struct ObsResult {
   double ex, ey;     // |residual| per axis (0 when not visible)
   int32_t ctrl;      // global index of the first of the 4 active control points, -1 when not visible
@@ -226,27 +325,20 @@ struct ObsResult {
 // that they are the derivatives of the absolute residuals the reference returns (common.py:357-358).
 //   jx/jy : NS values each (see slot layout above); untouched when the observation is not visible.
 //   u_obs/v_obs: observed pixel when calibration is fixed (undistorted once at create time).
-template <bool CALIB, bool JAC>
-MVUS_HD ObsResult eval_observation(const CamState& cam, const SplineView& sp, const double* x, bool undist, bool rs_free, bool sync_free,
-                                   double frame, double u_raw, double v_raw, double u_obs, double v_obs,
-                                   double* jx, double* jy) {
+template <bool CALIB, bool JAC, class Sink>
+MVUS_HD ObsResult eval_observation_to(const CamState& cam, const SplineView& sp, const double* x, bool undist, bool rs_free, bool sync_free,
+                                      double frame, double u_raw, double v_raw, double u_obs, double v_obs, Sink& sink) {
   ObsResult out;
   out.ex = 0.0; out.ey = 0.0; out.ctrl = -1;
   const double tau = cam.alpha * (frame + cam.rs * v_raw / cam.H) + cam.beta;
-  const int s = find_interval(sp.istart, sp.iend, sp.S, tau);
-  if (s < 0) return out;
-  const double* t = sp.knots + sp.knot_off[s];
-  const int n = sp.ctrl_off[s + 1] - sp.ctrl_off[s];
-  const int l = find_span_lut(sp, s, t, n, tau);
+  SpanLoc loc;
+  if (!locate_span(sp, x, tau, loc)) return out;
   double h[4], dh[4];
-  bspline_basis<JAC>(t, l, tau, h, dh);
-  const double* cx_ = x + sp.xoff[s] + (l - 3);
-  const double* cy_ = cx_ + n;
-  const double* cz_ = cy_ + n;
+  bspline_basis_w<JAC>(loc.tt, tau, h, dh);
   double X[3] = {0.0, 0.0, 0.0}, Xd[3] = {0.0, 0.0, 0.0};
   for (int q = 0; q < 4; ++q) {
-    X[0] = X[0] + cx_[q] * h[q]; X[1] = X[1] + cy_[q] * h[q]; X[2] = X[2] + cz_[q] * h[q];
-    if (JAC) { Xd[0] += cx_[q] * dh[q]; Xd[1] += cy_[q] * dh[q]; Xd[2] += cz_[q] * dh[q]; }
+    X[0] = X[0] + loc.c[0][q] * h[q]; X[1] = X[1] + loc.c[1][q] * h[q]; X[2] = X[2] + loc.c[2][q] * h[q];
+    if (JAC) { Xd[0] += loc.c[0][q] * dh[q]; Xd[1] += loc.c[1][q] * dh[q]; Xd[2] += loc.c[2][q] * dh[q]; }
   }
   const double* R = cam.R;
   const double y0 = R[0] * X[0] + R[1] * X[1] + R[2] * X[2];
@@ -273,8 +365,9 @@ MVUS_HD ObsResult eval_observation(const CamState& cam, const SplineView& sp, co
   }
   const double ru = uh - uo, rv = vh - vo;
   out.ex = fabs(ru); out.ey = fabs(rv);
-  out.ctrl = sp.ctrl_off[s] + (l - 3);
+  out.ctrl = loc.ctrl;
   if (!JAC) return out;
+  sink.begin(out.ctrl);
 
   const double su = (ru < 0.0) ? -1.0 : 1.0, sv = (rv < 0.0) ? -1.0 : 1.0;
   // d(uh)/dXc, d(vh)/dXc, signed
@@ -291,22 +384,25 @@ MVUS_HD ObsResult eval_observation(const CamState& cam, const SplineView& sp, co
   const double dtr = rs_free ? cam.alpha * v_raw / cam.H : 0.0;   // d tau / d rs (column absent from the
                                                                   // reference pattern when rs=False, common.py:518-521)
   const double sf = sync_free ? 1.0 : 0.0;               // opt_sync off: alpha, beta leave the pattern (common.py:512-515)
-  jx[0] = sf * dtu * dta; jx[1] = sf * dtu; jx[2] = dtu * dtr;
-  jy[0] = sf * dtv * dta; jy[1] = sf * dtv; jy[2] = dtv * dtr;
+  sink.x(0, sf * dtu * dta); sink.x(1, sf * dtu); sink.x(2, dtu * dtr);
+  sink.y(0, sf * dtv * dta); sink.y(1, sf * dtv); sink.y(2, dtv * dtr);
+  MVUS_GROUP_FENCE();
   // rotation vector: d Xc / d r = -[y]x W  ->  row a gives (y x a)^T W
   const double cu0 = y1 * au2 - y2 * 0.0, cu1 = y2 * au0 - y0 * au2, cu2 = y0 * 0.0 - y1 * au0;   // y x au, au = (au0,0,au2)
   const double cv0 = y1 * av2 - y2 * av1, cv1 = y2 * 0.0 - y0 * av2, cv2 = y0 * av1 - y1 * 0.0;   // y x av, av = (0,av1,av2)
   const double* W = cam.W;
   const int o = CALIB ? 7 : 3;   // slot of rvec
-  jx[o + 0] = cu0 * W[0] + cu1 * W[3] + cu2 * W[6];
-  jx[o + 1] = cu0 * W[1] + cu1 * W[4] + cu2 * W[7];
-  jx[o + 2] = cu0 * W[2] + cu1 * W[5] + cu2 * W[8];
-  jy[o + 0] = cv0 * W[0] + cv1 * W[3] + cv2 * W[6];
-  jy[o + 1] = cv0 * W[1] + cv1 * W[4] + cv2 * W[7];
-  jy[o + 2] = cv0 * W[2] + cv1 * W[5] + cv2 * W[8];
+  sink.x(o + 0, cu0 * W[0] + cu1 * W[3] + cu2 * W[6]);
+  sink.x(o + 1, cu0 * W[1] + cu1 * W[4] + cu2 * W[7]);
+  sink.x(o + 2, cu0 * W[2] + cu1 * W[5] + cu2 * W[8]);
+  sink.y(o + 0, cv0 * W[0] + cv1 * W[3] + cv2 * W[6]);
+  sink.y(o + 1, cv0 * W[1] + cv1 * W[4] + cv2 * W[7]);
+  sink.y(o + 2, cv0 * W[2] + cv1 * W[5] + cv2 * W[8]);
+  MVUS_GROUP_FENCE();
   // translation
-  jx[o + 3] = au0; jx[o + 4] = 0.0; jx[o + 5] = au2;
-  jy[o + 3] = 0.0; jy[o + 4] = av1; jy[o + 5] = av2;
+  sink.x(o + 3, au0); sink.x(o + 4, 0.0); sink.x(o + 5, au2);
+  sink.y(o + 3, 0.0); sink.y(o + 4, av1); sink.y(o + 5, av2);
+  MVUS_GROUP_FENCE();
   if (CALIB) {
     // r_u = fx*xn + cx - (fx*oxn + cx),  oxn = undist((u_raw-cx)/fx, (v_raw-cy)/fy; d)
     double duo[9], dvo[9];   // d(uo), d(vo) / d(fx,fy,cx,cy,k1,k2,p1,p2,k3)
@@ -323,16 +419,32 @@ MVUS_HD ObsResult eval_observation(const CamState& cam, const SplineView& sp, co
     } else {
       for (int k = 0; k < 9; ++k) { duo[k] = 0.0; dvo[k] = 0.0; }
     }
-    jx[3] = su * (xn - duo[0]); jx[4] = su * (-duo[1]); jx[5] = su * (1.0 - duo[2]); jx[6] = su * (-duo[3]);
-    jy[3] = sv * (-dvo[0]); jy[4] = sv * (yn - dvo[1]); jy[5] = sv * (-dvo[2]); jy[6] = sv * (1.0 - dvo[3]);
-    for (int k = 0; k < 5; ++k) { jx[13 + k] = -su * duo[4 + k]; jy[13 + k] = -sv * dvo[4 + k]; }
+    sink.x(3, su * (xn - duo[0])); sink.x(4, su * (-duo[1])); sink.x(5, su * (1.0 - duo[2])); sink.x(6, su * (-duo[3]));
+    sink.y(3, sv * (-dvo[0])); sink.y(4, sv * (yn - dvo[1])); sink.y(5, sv * (-dvo[2])); sink.y(6, sv * (1.0 - dvo[3]));
+    for (int k = 0; k < 5; ++k) { sink.x(13 + k, -su * duo[4 + k]); sink.y(13 + k, -sv * dvo[4 + k]); }
   }
   const int b = kSyncSlots + (CALIB ? 15 : 6);
   for (int q = 0; q < 4; ++q) {
-    jx[b + 3 * q + 0] = h[q] * gu0; jx[b + 3 * q + 1] = h[q] * gu1; jx[b + 3 * q + 2] = h[q] * gu2;
-    jy[b + 3 * q + 0] = h[q] * gv0; jy[b + 3 * q + 1] = h[q] * gv1; jy[b + 3 * q + 2] = h[q] * gv2;
+    sink.x(b + 3 * q + 0, h[q] * gu0); sink.x(b + 3 * q + 1, h[q] * gu1); sink.x(b + 3 * q + 2, h[q] * gu2);
+    sink.y(b + 3 * q + 0, h[q] * gv0); sink.y(b + 3 * q + 1, h[q] * gv1); sink.y(b + 3 * q + 2, h[q] * gv2);
+    MVUS_GROUP_FENCE();
   }
   return out;
+}
+
+// Sink that keeps the 2 x NS values in two arrays (the host harness, and kernels that post-process the row).
+struct ArraySink {
+  double *jx, *jy;
+  MVUS_HD void begin(int32_t) {}
+  MVUS_HD void x(int k, double v) { jx[k] = v; }
+  MVUS_HD void y(int k, double v) { jy[k] = v; }
+};
+template <bool CALIB, bool JAC>
+MVUS_HD ObsResult eval_observation(const CamState& cam, const SplineView& sp, const double* x, bool undist, bool rs_free, bool sync_free,
+                                   double frame, double u_raw, double v_raw, double u_obs, double v_obs,
+                                   double* jx, double* jy) {
+  ArraySink sink{jx, jy};
+  return eval_observation_to<CALIB, JAC>(cam, sp, x, undist, rs_free, sync_free, frame, u_raw, v_raw, u_obs, v_obs, sink);
 }
 
 // Reference sparsity pattern for the spline columns of one row (common.py:559-563): the three
@@ -422,6 +534,8 @@ struct MotionView {
   const int32_t* pat;     // [T] pattern code of the row (pattern_code; common.py:573-585)
   const int32_t* ctrl_x0;     // [N] x-index of coordinate 0 of control point g
   const int32_t* ctrl_stride; // [N] n_s of the spline control point g belongs to
+  const int32_t* row_lo;      // [N] motion rows that can touch control point g: row_lo[g] <= j < row_hi[g]
+  const int32_t* row_hi;      // [N]
 };
 
 MVUS_HD void motion_point(const MotionView& mv, const double* x, int j, double X[3]) {

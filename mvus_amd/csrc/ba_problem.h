@@ -28,16 +28,34 @@ struct HostProblem {
   std::vector<double> lut_scale;
   std::vector<int32_t> chunk_cam, chunk_count;
   std::vector<int64_t> chunk_start;
+  std::vector<ChunkInfo> chunks;
+  std::vector<SplineInfo> sinfo;
   std::vector<double> ms_t, ms_basis;
-  std::vector<int32_t> ms_ctrl, ms_part, ms_pat;
+  std::vector<int32_t> ms_ctrl, ms_part, ms_pat, ms_row_lo, ms_row_hi;
+  std::vector<int32_t> cam_chunk_off;
 
   SplineView spline_view() const {
     return SplineView{S, istart.data(), iend.data(), knots.data(), knot_off.data(), ctrl_off.data(), xoff.data(),
-                      lut.data(), lut_off.data(), lut_scale.data()};
+                      lut.data(), lut_off.data(), lut_scale.data(), sinfo.data()};
   }
   MotionView motion_view() const {
     return MotionView{T, motion_type, w, ms_t.data(), ms_basis.data(), ms_ctrl.data(), ms_part.data(), ms_pat.data(),
-                      ctrl_x0.data(), ctrl_stride.data()};
+                      ctrl_x0.data(), ctrl_stride.data(), ms_row_lo.data(), ms_row_hi.data()};
+  }
+
+  // launch chunks from det_off (again after detections were removed)
+  void build_chunks() {
+    chunk_cam.clear(); chunk_start.clear(); chunk_count.clear(); chunks.clear();
+    cam_chunk_off.assign(C + 1, 0);
+    for (int c = 0; c < C; ++c) {
+      cam_chunk_off[c] = (int32_t)chunks.size();
+      for (int64_t a = det_off[c]; a < det_off[c + 1]; a += kChunk) {
+        const int32_t cnt = (int32_t)std::min<int64_t>(kChunk, det_off[c + 1] - a);
+        chunk_cam.push_back(c); chunk_start.push_back(a); chunk_count.push_back(cnt);
+        chunks.push_back(ChunkInfo{(long long)a, (long long)det_off[c], (long long)(det_off[c + 1] - det_off[c]), c, cnt});
+      }
+    }
+    cam_chunk_off[C] = (int32_t)chunks.size();
   }
 
   // returns "" on success, otherwise what is wrong with the description
@@ -110,13 +128,13 @@ struct HostProblem {
       for (int b = 0; b < nb; ++b) lut.push_back(find_span(t, ns, t0 + b / lut_scale[s]));
       lut_off[s + 1] = (int32_t)lut.size();
     }
-    // launch chunks
-    chunk_cam.clear(); chunk_start.clear(); chunk_count.clear();
-    for (int c = 0; c < C; ++c)
-      for (int64_t a = det_off[c]; a < det_off[c + 1]; a += kChunk) {
-        chunk_cam.push_back(c); chunk_start.push_back(a);
-        chunk_count.push_back((int32_t)std::min<int64_t>(kChunk, det_off[c + 1] - a));
-      }
+    sinfo.resize(S);
+    for (int s = 0; s < S; ++s) {
+      const double* t = knots.data() + knot_off[s];
+      sinfo[s] = SplineInfo{istart[s], iend[s], t[3], lut_scale[s], knot_off[s], ctrl_off[s], ctrl_off[s + 1] - ctrl_off[s], xoff[s],
+                            lut_off[s], lut_off[s + 1] - lut_off[s], 0, 0};
+    }
+    build_chunks();
     // motion samples: ts = arange(int[0,0], int[1,-1], 1) kept where start <= ts <= end (common.py:289-292)
     ms_t.clear(); ms_basis.clear(); ms_ctrl.clear(); ms_part.clear(); ms_pat.clear();
     T = 0;
@@ -149,6 +167,23 @@ struct HostProblem {
         }
       }
       T = (int)ms_t.size();
+    }
+    // motion rows that can touch control point g (row j uses the samples j-1, j, j+1, each with four control points):
+    // a conservative contiguous range, the kernels test the exact membership
+    ms_row_lo.assign(N, 0); ms_row_hi.assign(N, 0);
+    if (T > 0) {
+      std::vector<int32_t> lo(N, T), hi(N, 0);
+      for (int j = 0; j < T; ++j)
+        for (int k = -1; k <= 1; ++k) {
+          const int js = j + k;
+          if (js < 0 || js >= T) continue;
+          for (int q = -1; q < 5; ++q) {                 // one point of margin: a finite-difference row stores the four
+            const int g = ms_ctrl[js] + q;               // points around its PATTERN, which can reach one past the active four
+            if (g < 0 || g >= N) continue;
+            lo[g] = std::min(lo[g], j); hi[g] = std::max(hi[g], j + 1);
+          }
+        }
+      for (int g = 0; g < N; ++g) { ms_row_lo[g] = lo[g] < hi[g] ? lo[g] : 0; ms_row_hi[g] = lo[g] < hi[g] ? hi[g] : 0; }
     }
     m = 2 * M + T;
     return "";

@@ -79,3 +79,33 @@ def test_traj_to_spline_and_back_match_the_reference():
         np.testing.assert_allclose(np.asarray(tck[1]), g['coefs_%d' % i], rtol=0, atol=1e-9)
     np.testing.assert_allclose(s.spline_to_traj(sampling_rate=1), g['traj_rate1'], rtol=0, atol=1e-9)
     np.testing.assert_allclose(s.spline_to_traj(t=g['t_query']), g['traj_query'], rtol=0, atol=1e-9)
+
+
+@pytest.mark.parametrize('name', ['rs_F_2int_3cam', 'calib_KE_bounds_3cam'])
+def test_all_detect_to_traj_vs_reference(name):
+    """Scene.all_detect_to_traj (common.py:887-947) at the state the reference's first BA left behind: global_traj,
+    global_detections, frame_id_all, global_time_stamps_all, traj -- the attributes of the output pickle -- equal to the
+    reference's."""
+    from golden_util import load_case
+    from test_gpu_scene import build_scene
+    from mvus_amd import problem as mp
+    scene, g = load_case(name)
+    s = build_scene(scene)
+    prob, _ = mp.problem_from_scene(scene)
+    alpha, beta, rs, cams, coefs = mp.unpack_x(prob, g['ba10_x'])
+    s.alpha, s.beta, s.rs = alpha, beta, rs
+    for k, c in enumerate(s.cameras):
+        if prob.opt_calib:
+            c.K, c.d = cams[k]['K'], cams[k]['d']
+        c.R, c.t = cams[k]['R'], cams[k]['t']
+        c.compose()
+    for i, c in enumerate(coefs):
+        s.spline['tck'][i][1] = c
+    s.all_detect_to_traj(s.sequence[:s.numCam])
+    np.testing.assert_array_equal(s.frame_id_all, g['adt_frame_id_all'])
+    np.testing.assert_allclose(s.global_time_stamps_all, g['adt_global_time_stamps_all'], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(s.global_detections, g['adt_global_detections'], rtol=0, atol=1e-9)
+    assert s.global_traj.shape == g['adt_global_traj'].shape and s.traj.shape == g['adt_traj'].shape
+    np.testing.assert_array_equal(s.global_traj[:3], g['adt_global_traj'][:3])          # order index, camera id, frame id: integers
+    np.testing.assert_allclose(s.global_traj[3:], g['adt_global_traj'][3:], rtol=0, atol=1e-8)
+    np.testing.assert_allclose(s.traj, g['adt_traj'], rtol=0, atol=1e-8)
