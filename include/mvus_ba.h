@@ -230,6 +230,16 @@ int mvus_ba_time_kernel(mvus_ba* h, int32_t which, int32_t launches, double* avg
 /* Upload x to the handle without evaluating anything (used with mvus_ba_time_kernel). */
 int mvus_ba_set_x(mvus_ba* h, const double* x);
 
+/* Two-view linear triangulation, epipolar.triangulate_matlab (reconstruction/epipolar.py:497-510) as called by
+ * Scene.triangulate (common.py:783): for each of N point pairs the right singular vector of the smallest singular value
+ * of the 4x4 matrix built from the two projections, divided by its last component.  x1, x2: [2*N] (u(N) then v(N)) pixel
+ * coordinates in camera 1 / 2; P1, P2: [12] row-major 3x4 projection matrices; X: [4*N] rows x, y, z, 1.
+ * err1 / err2 (NULL = skip): [N] reprojection distances of X in the two cameras (epipolar.reprojection_error of
+ * Camera.projectPoint, common.py:786-787), the quantity Scene.triangulate thresholds.  Stateless: no handle; errors of
+ * this call are reported by mvus_last_error(NULL).  No CPU fallback. */
+int mvus_triangulate(int32_t device, int64_t N, const double* x1, const double* x2, const double* P1, const double* P2,
+                     double* X, double* err1, double* err2);
+
 #ifdef __cplusplus
 }
 #endif

@@ -82,6 +82,7 @@ API = [
     ('mvus_ba_set_time_shard', ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, c_int32_p, ctypes.c_int32]),
     ('mvus_ba_time_kernel', ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, c_double_p]),
     ('mvus_ba_set_x', ctypes.c_int, [ctypes.c_void_p, c_double_p]),
+    ('mvus_triangulate', ctypes.c_int, [ctypes.c_int32, ctypes.c_int64, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]),
 ]
 
 _lib = None

@@ -14,6 +14,7 @@
 #include "ba_problem.h"
 #include "ba_solver.h"
 #include "ba_schur_hip.hip.h"
+#include "triangulate.hip.h"
 
 namespace mvus {
 
@@ -812,6 +813,41 @@ int mvus_ba_time_kernel(mvus_ba* h, int32_t which, int32_t launches, double* avg
     }
     return MVUS_OK;
   });
+}
+
+int mvus_triangulate(int32_t device, int64_t N, const double* x1, const double* x2, const double* P1, const double* P2,
+                     double* X, double* err1, double* err2) {
+  if (N < 0 || !P1 || !P2 || (N > 0 && (!x1 || !x2 || !X))) { g_create_error = "triangulate: bad arguments"; return MVUS_E_INVALID; }
+  if (N == 0) return MVUS_OK;
+  double *dx1 = nullptr, *dx2 = nullptr, *dX = nullptr, *de = nullptr;
+  hipStream_t st = nullptr;
+  auto cleanup = [&]() { (void)hipFree(dx1); (void)hipFree(dx2); (void)hipFree(dX); (void)hipFree(de); if (st) (void)hipStreamDestroy(st); };
+  try {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= device) throw HipError{"no usable HIP device (libmvusba has no CPU fallback)"};
+    MVUS_HIP(hipSetDevice(device));
+    MVUS_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    const size_t b2 = sizeof(double) * 2 * (size_t)N;
+    MVUS_HIP(hipMalloc(reinterpret_cast<void**>(&dx1), b2)); MVUS_HIP(hipMalloc(reinterpret_cast<void**>(&dx2), b2));
+    MVUS_HIP(hipMalloc(reinterpret_cast<void**>(&dX), 2 * b2)); MVUS_HIP(hipMalloc(reinterpret_cast<void**>(&de), b2));
+    MVUS_HIP(hipMemcpyAsync(dx1, x1, b2, hipMemcpyHostToDevice, st));
+    MVUS_HIP(hipMemcpyAsync(dx2, x2, b2, hipMemcpyHostToDevice, st));
+    TriCams cams;
+    std::memcpy(cams.P1, P1, sizeof(cams.P1)); std::memcpy(cams.P2, P2, sizeof(cams.P2));
+    hipLaunchKernelGGL(k_triangulate, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, cams, (long long)N, dx1, dx2, dX,
+                       err1 ? de : (double*)nullptr, err2 ? de + N : (double*)nullptr);
+    MVUS_HIP(hipGetLastError());
+    MVUS_HIP(hipMemcpyAsync(X, dX, 2 * b2, hipMemcpyDeviceToHost, st));
+    if (err1) MVUS_HIP(hipMemcpyAsync(err1, de, sizeof(double) * N, hipMemcpyDeviceToHost, st));
+    if (err2) MVUS_HIP(hipMemcpyAsync(err2, de + N, sizeof(double) * N, hipMemcpyDeviceToHost, st));
+    MVUS_HIP(hipStreamSynchronize(st));
+  } catch (const HipError& e) {
+    g_create_error = e.msg;
+    cleanup();
+    return MVUS_E_HIP;
+  }
+  cleanup();
+  return MVUS_OK;
 }
 
 }  // extern "C"

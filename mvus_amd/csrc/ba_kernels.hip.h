@@ -99,8 +99,10 @@ __global__ void k_undistort_fixed(DevProblem dp, double* __restrict__ u_obs, dou
 #if !defined(MVUS_JAC_ARRAY) && !defined(MVUS_JAC_DIRECT)
 #define MVUS_JAC_DIRECT 1        // default: values go to memory as they are produced (98 VGPRs; the array form needs 128 + scratch)
 #endif
-#ifdef MVUS_JAC_NT
+#if defined(MVUS_JAC_NT)
 #define MVUS_JSTORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#elif defined(MVUS_JAC_SC1)
+#define MVUS_JSTORE(ptr, val) __hip_atomic_store((ptr), (val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #else
 #define MVUS_JSTORE(ptr, val) (*(ptr) = (val))
 #endif

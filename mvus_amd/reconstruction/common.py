@@ -7,8 +7,9 @@ Kept from the reference: the ``Scene`` attribute set that ends up in the output 
 method names and signatures, the ``config.json`` schema (``create_scene``), the parameter-vector layout and the
 side effects of ``BA`` on ``alpha/beta/rs/cameras/spline/detections_global``.
 
-Out of scope: trajectory initialisation, PnP, triangulation, synchronisation search,
-plotting, and the dead ``motion_prior=True`` branch -- those methods raise ``NotImplementedError``.
+Out of scope: trajectory initialisation, PnP-RANSAC, synchronisation search, plotting, and the
+dead ``motion_prior=True`` branch -- those methods raise ``NotImplementedError``.  ``Scene.triangulate`` (SURVEY 8f rank
+4) is here, with its per-point SVD on the GPU.
 
 Extra ``settings`` keys (all optional): ``ba_solver`` ('lm' = Levenberg-Marquardt on device-assembled normal equations
 with the Schur complement, the default -- ~10-20x faster per BA iteration and it converges to a lower value of the same
@@ -431,12 +432,52 @@ class Scene:
             self.detections[i] = self.detections[i][:, keep[a:b]]
             self.detection_to_global(i)
 
+    def triangulate(self, cam_id, cams, factor_t2s, factor_s2t=0.02, thres=0, refit=True, verbose=0):
+        """Triangulate the detections of camera ``cam_id`` that lie outside the existing spline against the (already
+        processed) cameras ``cams`` and append them to the trajectory (common.py:754-815).  Same steps as the reference;
+        the per-point linear triangulation and both reprojection distances come from one GPU kernel
+        (``mvus_triangulate``) instead of a Python loop of 4x4 SVDs."""
+        from . import epipolar as ep
+        assert self.cameras[cam_id].P is not None, 'The camera pose must be computed first'
+        interval = self.spline['int']
+        self.detection_to_global(cam_id)
+        _, idx_ex = util.sampling(self.detections_global[cam_id], interval)
+        detect_new = self.detections_global[cam_id][:, np.logical_not(idx_ex)]
+        device = int(self.settings.get('device', 0)) if isinstance(self.settings, dict) else 0
+        X_new = np.empty([4, 0])
+        for i in cams:
+            self.detection_to_global(i)
+            detect_ex = self.detections_global[i]
+            try:
+                x1, x2 = util.match_overlap(detect_new, detect_ex)
+            except Exception:                       # no temporal overlap with this camera (the reference's bare except)
+                continue
+            X_h, err_1, err_2 = ep.triangulate_with_errors(x1[1:], x2[1:], self.cameras[cam_id].P, self.cameras[i].P, device=device)
+            X_i = np.vstack((x1[0], X_h[:-1]))
+            if thres:
+                mask = np.logical_and(err_1 < thres, err_2 < thres)
+                X_i = X_i[:, mask]
+                if verbose:
+                    print('{} out of {} points are triangulated'.format(sum(mask), len(err_1)))
+            X_new = np.hstack((X_new, X_i))
+            if verbose:
+                print('{} points are triangulated into the 3D spline'.format(X_i.shape[1]))
+        _, idx_empty = util.sampling(X_new, interval)
+        assert sum(idx_empty) == 0, 'Points should not be triangulated into the existing part of the 3D spline'
+        self.spline_to_traj(sampling_rate=factor_s2t)
+        self.traj = np.hstack((self.traj, X_new))
+        _, idx = np.unique(self.traj[0], return_index=True)
+        self.traj = self.traj[:, idx]
+        if refit:
+            self.traj_to_spline(smooth_factor=factor_t2s)
+        return X_new
+
     # ---- outside the hot path -----------------------------------------------------------------------
     def _out_of_scope(self, *a, **k):
         raise NotImplementedError('outside the BA hot path this package accelerates (SURVEY.md section 2); '
-                                  'use the reference implementation for initialisation / PnP / triangulation')
+                                  'use the reference implementation for initialisation / PnP / synchronisation search')
 
-    init_traj = get_camera_pose = triangulate = select_most_overlap = plot_reprojection = error_motion = _out_of_scope
+    init_traj = get_camera_pose = select_most_overlap = plot_reprojection = error_motion = _out_of_scope
 
 
 def create_scene(path_input):

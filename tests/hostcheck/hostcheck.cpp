@@ -2,6 +2,7 @@
 // Lets the CPU test-suite check the arithmetic the HIP kernels run (residual, analytic Jacobian)
 // against the oracle without a GPU.  Never linked into libmvusba.so.
 #include "../../mvus_amd/csrc/ba_math.h"
+#include "../../mvus_amd/csrc/triangulate.hip.h"
 
 using namespace mvus;
 
@@ -31,6 +32,19 @@ extern "C" int hostcheck_eval(int C, int calib, int undist, int rs_free, const i
                           : eval_observation<false, true>(cam, sp, x, undist != 0, rs_free != 0, true, frame[i], u_raw[i], v_raw[i], uo, vo, jx, jy);
       ex[i] = r.ex; ey[i] = r.ey; ctrl[i] = r.ctrl;
     }
+  }
+  return 0;
+}
+
+// host build of the per-pair triangulation math (mvus_amd/csrc/triangulate.hip.h); x1, x2: [2][N], X: [4][N]
+extern "C" int hostcheck_triangulate(long long N, const double* x1, const double* x2, const double* P1, const double* P2,
+                                     double* X, double* err1, double* err2) {
+  for (long long i = 0; i < N; ++i) {
+    double Xh[4];
+    triangulate_pair(P1, P2, x1[i], x1[N + i], x2[i], x2[N + i], Xh);
+    for (int k = 0; k < 4; ++k) X[k * N + i] = Xh[k];
+    if (err1) err1[i] = reprojection_distance(P1, Xh, x1[i], x1[N + i]);
+    if (err2) err2[i] = reprojection_distance(P2, Xh, x2[i], x2[N + i]);
   }
   return 0;
 }

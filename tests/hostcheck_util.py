@@ -10,7 +10,7 @@ from mvus_amd import _lib
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SRC = [os.path.join(HERE, 'hostcheck', f) for f in ('hostcheck.cpp', 'host_backend.cpp')]
-DEPS = SRC + [os.path.join(ROOT, 'mvus_amd', 'csrc', f) for f in ('ba_math.h', 'ba_solver.h', 'ba_problem.h', 'ba_schur.h', 'ba_partition.h')] \
+DEPS = SRC + [os.path.join(ROOT, 'mvus_amd', 'csrc', f) for f in ('ba_math.h', 'ba_solver.h', 'ba_problem.h', 'ba_schur.h', 'ba_partition.h', 'triangulate.hip.h')] \
     + [os.path.join(ROOT, 'include', 'mvus_ba.h')]
 SO = os.path.join(HERE, 'hostcheck', 'libhostcheck.so')
 
@@ -43,6 +43,7 @@ def load():
     lib.hostcheck_jtu.argtypes = [ctypes.c_void_p, _lib.c_double_p, _lib.c_double_p]
     lib.hostcheck_solve.argtypes = [ctypes.c_void_p, _lib.c_double_p, ctypes.POINTER(_lib.MvusSolveOpts),
                                     ctypes.POINTER(_lib.MvusResult), _lib.c_double_p]
+    lib.hostcheck_triangulate.argtypes = [ctypes.c_longlong] + [_lib.c_double_p] * 7
     _cached = lib
     return lib
 
@@ -133,3 +134,14 @@ class HostHandle:
         if rc != 0:
             raise ValueError(self.lib.hostcheck_error().decode())
         return x, res, f
+
+
+def host_triangulate(x1, x2, P1, P2, errors=True):
+    """Host build of mvus_amd/csrc/triangulate.hip.h: X[4,N] (and the two reprojection distances)."""
+    lib = load()
+    x1, x2 = np.ascontiguousarray(x1[:2], dtype=np.float64), np.ascontiguousarray(x2[:2], dtype=np.float64)
+    P1, P2 = np.ascontiguousarray(P1, dtype=np.float64), np.ascontiguousarray(P2, dtype=np.float64)
+    N = x1.shape[1]
+    X, e1, e2 = np.zeros((4, N)), np.zeros(N), np.zeros(N)
+    lib.hostcheck_triangulate(N, _lib.dptr(x1), _lib.dptr(x2), _lib.dptr(P1), _lib.dptr(P2), _lib.dptr(X), _lib.dptr(e1), _lib.dptr(e2))
+    return (X, e1, e2) if errors else X

@@ -138,3 +138,67 @@ def test_converged_second_ba_through_the_scene(name, mode):
         if not st['motion_reg']:
             assert rmse <= float(g['ba2_200_rmse']) + 1e-4
         assert int(np.sum(keep != g['ba2_200_keep'])) <= 3
+
+
+def test_pipeline_from_files_on_disk(tmp_path):
+    """the run starts from what a user of the reference has on disk -- detection text files
+    (`x y frame` per line, README "2D Detection Tracks"), calibration JSON files, config.json -- goes through
+    create_scene, BA -> remove_outliers -> BA on the GPU, and ends in the output pickle (main.py:93).  Checked against the
+    same pipeline fed from arrays (bit for bit: the files carry %.18e) and against the reference's golden first-BA state."""
+    import json
+    import pickle
+    scene, g = load_case('c1_pinhole_2cam')
+    st = scene.settings
+    dets, cams = [], []
+    for i in range(scene.num_cam):
+        d = scene.detections[i]
+        p = tmp_path / ('cam%d.txt' % i)
+        np.savetxt(p, np.column_stack((d[1], d[2], d[0])), fmt='%.18e')               # x y frame
+        dets.append(str(p))
+        c = scene.cameras[i]
+        q = tmp_path / ('cam%d.json' % i)
+        q.write_text(json.dumps({'comment': 'synthetic', 'K-matrix': c['K'].tolist(), 'distCoeff': c['d'].tolist()[:4],
+                                 'fps': c['fps'], 'resolution': [int(c['resolution'][0]), int(c['resolution'][1])]}))
+        cams.append(str(q))
+    cfg = {'comments': 'tests/test_gpu_scene.py',
+           'necessary inputs': {'path_detections': dets, 'path_cameras': cams, 'corresponding_frames': [0, 0]},
+           'optional inputs': {},
+           'settings': {'num_detections': 100000, 'opt_calib': False, 'cf_exact': True, 'undist_points': True,
+                        'rolling_shutter': False, 'init_rs': 0, 'rs_bounds': False, 'motion_reg': False, 'motion_weights': 1,
+                        'rs_bounds': False, 'camera_sequence': [0, 1], 'ref_cam': 0, 'thres_outlier': st['thres_outlier'],
+                        'smooth_factor': [10, 20], 'motion_type': 'F', 'ba_solver': 'trf', 'ba_jacobian': 'pattern'}}
+    path = tmp_path / 'config.json'
+    path.write_text(json.dumps(cfg))
+    flight = common.create_scene(str(path))
+    assert flight.numCam == 2 and flight.sequence == [0, 1] and not flight.find_order
+    for i in range(2):
+        np.testing.assert_array_equal(flight.detections[i], scene.detections[i])     # the text files round-trip exactly
+    # what initialisation (out of scope: epipolar geometry, PnP, triangulation) would have produced -- taken from the fixture
+    for i, c in enumerate(flight.cameras):
+        c.R, c.t = scene.cameras[i]['R'].copy(), scene.cameras[i]['t'].copy()
+        c.compose()
+    flight.alpha, flight.beta = scene.alpha.copy(), scene.beta.copy()
+    flight.spline = {'tck': [[t.copy(), [c.copy() for c in cs], 3] for t, cs, _ in scene.tck], 'int': scene.interval.copy()}
+    flight.detection_to_global()
+    ref = build_scene(scene)
+    ref.settings.update(ba_solver='trf', ba_jacobian='pattern')
+    before = np.array([np.mean(flight.error_cam(i)) for i in range(2)])
+    np.testing.assert_allclose(before, g['mean_err_before'], rtol=0, atol=1e-9)
+    r1, r1_ref = flight.BA(2), ref.BA(2)
+    np.testing.assert_array_equal(r1.x, r1_ref.x)                                    # same bits from disk as from memory
+    flight.remove_outliers(flight.sequence[:2], thres=flight.settings['thres_outlier'])
+    ref.remove_outliers(ref.sequence[:2], thres=st['thres_outlier'])
+    assert [d.shape for d in flight.detections] == [d.shape for d in ref.detections]
+    r2 = flight.BA(2)
+    assert r2.cost < r2.initial_cost
+    out = tmp_path / 'flight.pkl'
+    with open(out, 'wb') as fh:
+        pickle.dump(flight, fh)
+    with open(out, 'rb') as fh:
+        back = pickle.load(fh)
+    for name in ('alpha', 'beta', 'rs', 'sequence', 'settings', 'numCam'):          # README "Outputs"
+        assert hasattr(back, name)
+    np.testing.assert_array_equal(back.alpha, flight.alpha)
+    np.testing.assert_array_equal(back.spline['tck'][0][1][0], flight.spline['tck'][0][1][0])
+    np.testing.assert_array_equal(back.cameras[1].P, flight.cameras[1].P)
+    assert back._ba_handle is None
