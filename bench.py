@@ -166,6 +166,7 @@ def main():
     t_jv = handle.time_kernel(ba.KERNEL_JV, 50)
     t_jtu = handle.time_kernel(ba.KERNEL_JTU, 50)
     t_asm = handle.time_kernel(ba.KERNEL_ASSEMBLY, 20)
+    t_fused = handle.time_kernel(ba.KERNEL_FUSED_ASSEMBLY, 20)
     per_obs, once = algorithmic_bytes(handle.prob)
     bytes_launch = handle.prob.M * per_obs + once
     achieved = bytes_launch / (t_rj * 1e-3) / 1e9
@@ -218,7 +219,8 @@ def main():
                          'one_buffer': {'avg_launch_ms': t_rj_one, 'achieved': bytes_launch / (t_rj_one * 1e-3) / 1e9,
                                         'frac': bytes_launch / (t_rj_one * 1e-3) / 1e9 / HBM_PEAK_GBS}},
             'parity_solver': parity,
-            'kernels_ms': {'residual': t_r, 'residual_jacobian': t_rj, 'jv': t_jv, 'jtu': t_jtu, 'normal_eq_assembly': t_asm},
+            'kernels_ms': {'residual': t_r, 'residual_jacobian': t_rj, 'jv': t_jv, 'jtu': t_jtu, 'normal_eq_assembly_from_J': t_asm,
+                           'fused_jacobian_normal_eq_assembly': t_fused},
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.config)

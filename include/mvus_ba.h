@@ -224,7 +224,8 @@ int mvus_ba_set_time_shard(mvus_ba* h, int32_t rank, int32_t world, const int32_
  * stream between two hipEvents and returns the average duration in milliseconds.
  *   which: 0 residual, 1 residual+Jacobian with the outputs ROTATING over >= 3 buffer sets (>= 1 GiB in rotation, so no
  *   launch writes into lines its predecessor left in the 256 MiB Infinity Cache), 2 J v, 3 J^T u, 4 normal-equation
- *   assembly, 5 residual+Jacobian re-launched into one buffer set (cache-resident variant, for comparison) */
+ *   assembly from the materialised Jacobian, 5 residual+Jacobian re-launched into one buffer set (cache-resident variant,
+ *   for comparison), 6 the fused Jacobian + normal-equation assembly of the LM path (no Jacobian in memory) */
 int mvus_ba_time_kernel(mvus_ba* h, int32_t which, int32_t launches, double* avg_ms);
 
 /* Upload x to the handle without evaluating anything (used with mvus_ba_time_kernel). */

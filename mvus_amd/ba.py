@@ -252,4 +252,4 @@ class BAHandle:
 
 
 # kernel ids of mvus_ba_time_kernel
-KERNEL_RESIDUAL, KERNEL_RESIDUAL_JACOBIAN, KERNEL_JV, KERNEL_JTU, KERNEL_ASSEMBLY, KERNEL_RESIDUAL_JACOBIAN_ONE_BUFFER = 0, 1, 2, 3, 4, 5
+KERNEL_RESIDUAL, KERNEL_RESIDUAL_JACOBIAN, KERNEL_JV, KERNEL_JTU, KERNEL_ASSEMBLY, KERNEL_RESIDUAL_JACOBIAN_ONE_BUFFER, KERNEL_FUSED_ASSEMBLY = 0, 1, 2, 3, 4, 5, 6

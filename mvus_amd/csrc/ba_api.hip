@@ -249,6 +249,13 @@ struct HipBackend {
     if (jac) has_jacobian = true;
   }
   void residual(const double* x, double* f) { eval(x, f, false, 0); }
+  // motion rows only: their residuals and Jacobian blocks (the fused LM path evaluates the detection rows elsewhere)
+  void motion_jacobian(const double* x, double* f) {
+    if (hp.T <= 0) return;
+    if (is_root || tshard.on) hipLaunchKernelGGL(k_motion<true>, dim3((hp.T + kThreads - 1) / kThreads), dim3(kThreads), 0, stream, dp, x, f + 2 * hp.M, mJ, mctrl, 0);
+    else MVUS_HIP(hipMemsetAsync(f + 2 * hp.M, 0, sizeof(double) * hp.T, stream));
+    MVUS_HIP(hipGetLastError());
+  }
   void jacobian(const double* x, double* f, int jac_mode) {
     if (jac_mode == MVUS_JAC_FD) jacobian_fd(x, f); else eval(x, f, true, jac_mode);
   }
@@ -384,12 +391,12 @@ struct HipBackend {
   }
   // z = J^T u of this rank's rows: deterministic two-pass form (k_jtu_partial / k_jtu_reduce)
   double *zc = nullptr, *zs = nullptr;
-  int32_t* zg0 = nullptr;
+  int32_t *zg0 = nullptr, *zfill = nullptr;
   int* jt_nondet = nullptr;
   void jtu_local(const double* u, double* z) {
     if (!zc) {
       const size_t nc = std::max<size_t>(hp.chunks.size(), 1);
-      zc = dalloc<double>(nc * (size_t)(hp.NS - 12)); zs = dalloc<double>(nc * 3 * (size_t)kJtWin); zg0 = dalloc<int32_t>(nc);
+      zc = dalloc<double>(nc * (size_t)(hp.NS - 12)); zs = dalloc<double>(nc * 3 * (size_t)kJtWin); zg0 = dalloc<int32_t>(nc); zfill = dalloc<int32_t>(nc);
       jt_nondet = dalloc<int>(1);
       MVUS_HIP(hipMemsetAsync(jt_nondet, 0, sizeof(int), stream));
     }
@@ -399,10 +406,12 @@ struct HipBackend {
     const int motion = hp.T > 0 ? 1 : 0;
     if (hp.calib) {
       if (dp.n_chunks > 0) hipLaunchKernelGGL(k_jtu_partial<30>, dim3(dp.n_chunks), b, 0, stream, dp, J, span, u, z, zc, zs, zg0, jt_nondet);
-      hipLaunchKernelGGL(k_jtu_reduce<30>, g2, b, 0, stream, dp, zc, zs, zg0, mJ, mctrl, u + 2 * hp.M, motion, z);
+      hipLaunchKernelGGL(k_jtu_index, dim3((hp.C + 63) / 64), dim3(64), 0, stream, dp, zg0, zfill);
+      hipLaunchKernelGGL(k_jtu_reduce<30>, g2, b, 0, stream, dp, zc, zs, zg0, zfill, mJ, mctrl, u + 2 * hp.M, motion, z);
     } else {
       if (dp.n_chunks > 0) hipLaunchKernelGGL(k_jtu_partial<21>, dim3(dp.n_chunks), b, 0, stream, dp, J, span, u, z, zc, zs, zg0, jt_nondet);
-      hipLaunchKernelGGL(k_jtu_reduce<21>, g2, b, 0, stream, dp, zc, zs, zg0, mJ, mctrl, u + 2 * hp.M, motion, z);
+      hipLaunchKernelGGL(k_jtu_index, dim3((hp.C + 63) / 64), dim3(64), 0, stream, dp, zg0, zfill);
+      hipLaunchKernelGGL(k_jtu_reduce<21>, g2, b, 0, stream, dp, zc, zs, zg0, zfill, mJ, mctrl, u + 2 * hp.M, motion, z);
     }
     MVUS_HIP(hipGetLastError());
   }
@@ -735,7 +744,7 @@ int mvus_ba_set_time_shard(mvus_ba* h, int32_t rank, int32_t world, const int32_
 int mvus_ba_time_kernel(mvus_ba* h, int32_t which, int32_t launches, double* avg_ms) {
   return guarded(h, [&] {
     HipBackend& be = h->be;
-    if (launches < 1 || !avg_ms || which < 0 || which > 5) { be.err = "bad arguments"; return MVUS_E_INVALID; }
+    if (launches < 1 || !avg_ms || which < 0 || which > 6) { be.err = "bad arguments"; return MVUS_E_INVALID; }
     be.ensure_J();
     hipEvent_t e0, e1;
     MVUS_HIP(hipEventCreate(&e0)); MVUS_HIP(hipEventCreate(&e1));
@@ -744,8 +753,9 @@ int mvus_ba_time_kernel(mvus_ba* h, int32_t which, int32_t launches, double* avg
     be.fill(vn, 1e-3, be.hp.n); be.fill(um, 1e-3, be.hp.m);
     hipLaunchKernelGGL(k_cam_states, dim3((be.hp.C + 63) / 64), dim3(64), 0, be.stream, be.dp, be.x_cur, be.cams);
     if (which >= 2 && which <= 4 && !be.has_jacobian) be.jacobian(be.x_cur, be.f_cur, MVUS_JAC_ANALYTIC);
+    if (which == 6) be.residual(be.x_cur, be.f_cur);
     const dim3 g(std::max(be.dp.n_chunks, 1)), b(kThreads);
-    if (which == 4 && !h->schur) h->schur.reset(new HipSchur<HipBackend>(be));
+    if ((which == 4 || which == 6) && !h->schur) h->schur.reset(new HipSchur<HipBackend>(be));
     HipSchur<HipBackend>* schur = h->schur.get();
     // which == 1: the outputs (J, span, f) rotate over enough buffer sets that the bytes written between two uses of a
     // set exceed the 256 MiB Infinity Cache several times -- every launch writes to HBM, not into lines the previous
@@ -789,6 +799,9 @@ int mvus_ba_time_kernel(mvus_ba* h, int32_t which, int32_t launches, double* avg
           break;
         case 3:
           be.jtu_local(um, zn);
+          break;
+        case 6:
+          schur->assemble_local(be.f_cur, be.x_cur);       // Jacobian evaluated inside the assembly (the LM path)
           break;
         default:
           schur->assemble_local(be.f_cur);

@@ -364,10 +364,24 @@ __global__ __launch_bounds__(kThreads) void k_jtu_partial(DevProblem dp, const d
   }
 }
 
+// between the passes (one thread per camera): zfill[chunk] = running maximum of the window starts of the camera's chunks
+// -- non-decreasing whatever the data, so pass 2 can binary-search it; chunks are time ordered, so zfill exceeds a
+// chunk's own start by at most the few spans a rolling-shutter shift can reorder
+__global__ void k_jtu_index(DevProblem dp, const int32_t* __restrict__ zg0, int32_t* __restrict__ zfill) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= dp.C) return;
+  int run = -0x7fffffff;
+  for (int ch = dp.cam_chunk_off[c]; ch < dp.cam_chunk_off[c + 1]; ++ch) {
+    const int g0 = zg0[ch];
+    if (g0 != 0x7fffffff && g0 > run) run = g0;
+    zfill[ch] = run;
+  }
+}
+
 // pass 2: one thread per column of z (camera columns first, then control point x coordinate)
 template <int NS>
 __global__ __launch_bounds__(kThreads) void k_jtu_reduce(DevProblem dp, const double* __restrict__ zc, const double* __restrict__ zs,
-                                                         const int32_t* __restrict__ zg0, const double* __restrict__ mJ,
+                                                         const int32_t* __restrict__ zg0, const int32_t* __restrict__ zfill, const double* __restrict__ mJ,
                                                          const int32_t* __restrict__ mctrl, const double* __restrict__ um, int motion,
                                                          double* __restrict__ z) {
   constexpr int B = NS - 12;
@@ -385,12 +399,19 @@ __global__ __launch_bounds__(kThreads) void k_jtu_reduce(DevProblem dp, const do
   const int g = r / 3, d = r % 3;
   double acc = 0.0;
   for (int c = 0; c < dp.C; ++c) {
-    for (int ch = dp.cam_chunk_off[c]; ch < dp.cam_chunk_off[c + 1]; ++ch) {
+    // first chunk whose running-max window start is within reach of g (everything before ends left of g) ...
+    int lo = dp.cam_chunk_off[c], hi = dp.cam_chunk_off[c + 1];
+    const int end = hi;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (zfill[mid] + kJtWin > g) hi = mid; else lo = mid + 1;
+    }
+    // ... then forward until the running maximum is a whole window past g (a later chunk's own start is never that far
+    // below the running maximum), adding the covering windows in chunk order
+    for (int ch = lo; ch < end && zfill[ch] <= g + kJtWin; ++ch) {
       const int g0 = zg0[ch];
-      if (g0 == 0x7fffffff) continue;
-      if (g0 > g + kJtWin) break;                      // chunks are time ordered: later windows start even further right
       const int lc = g - g0;
-      if (lc >= 0 && lc < kJtWin) acc += zs[(long long)ch * (3 * kJtWin) + 3 * lc + d];
+      if (g0 != 0x7fffffff && lc >= 0 && lc < kJtWin) acc += zs[(long long)ch * (3 * kJtWin) + 3 * lc + d];
     }
   }
   if (motion) {

@@ -21,7 +21,9 @@
 // the host decides (accept / reject, damping update, termination).  The trial is launched speculatively before the
 // gradient-norm test is known; when that test terminates the solve the trial is simply dropped (not counted).
 //
-// `Schur` concept:  void assemble(B&, const double* f);            normal equations of the backend's Jacobian
+// `Schur` concept:  void linearize(B&, x, f, jac_mode, f_valid);    Jacobian at x (f = f(x) is already there when f_valid)
+//                                                                 and the normal equations; may fuse the two
+//                   void assemble(B&, const double* f);            normal equations of the backend's Jacobian
 //                   const double* grad_ptr(), diag_ptr();          g = J^T f and D = diag(H) (1 where zero), x order
 //                   void solve_async(double lambda);               p = -(H + lambda D)^-1 g -> step_ptr()
 //                   const double* step_ptr(); const int* fail_ptr();  bool solve_ok();   (solve_ok after a fetch)
@@ -85,10 +87,10 @@ SolveResult lm_schur(B& be, Schur& sc, std::vector<double>& x, const std::vector
   double hs[7] = {0, 0, 0, 0, 0, 0, 0};
 
   be.upload(x_dev, x.data(), n);
-  be.jacobian(x_dev, f_dev, opt.jac_mode);
+  be.residual(x_dev, f_dev);
   res.nfev = 1; res.njev = 1;
   be.dot_m_into(f_dev, f_dev, S);
-  sc.assemble(be, f_dev);
+  sc.linearize(be, x_dev, f_dev, opt.jac_mode, true);
 
   auto launch_trial = [&](double lambda) {
     sc.solve_async(lambda);
@@ -158,9 +160,9 @@ SolveResult lm_schur(B& be, Schur& sc, std::vector<double>& x, const std::vector
         res.jac_stale = true;             // J, span and the assembled blocks still belong to the previous point
         break;
       }
-      be.jacobian(x_dev, f_dev, opt.jac_mode);
+      be.copy(f_dev, f_new, m);                 // f at the accepted point is the trial residual: not evaluated again
       ++res.njev;
-      sc.assemble(be, f_dev);
+      sc.linearize(be, x_dev, f_dev, opt.jac_mode, true);
     }
     if (status != -1) {                 // converged / gave up: report the gradient norm of the final linearisation
       be.lm_gnorm(x_dev, lbp, ubp, sc.grad_ptr(), S + 1);
@@ -187,6 +189,8 @@ SolveResult lm_schur(B& be, Schur& sc, std::vector<double>& x, const std::vector
 struct HostSchur {
   int64_t n = 0;
   std::vector<double> H, g;
+  template <class B>
+  void linearize(B& be, const double* x, double* f, int jac_mode, bool) { be.jacobian(x, f, jac_mode); assemble(be, f); }
   template <class B>
   void assemble(B& be, const double* f) {
     n = be.n();

@@ -64,10 +64,22 @@ __device__ __forceinline__ int wave_min_i(int v) {
 // When a large rolling-shutter coefficient reorders the time stamps (spans interleave in index order) the staged
 // columns are first rank-sorted by span in LDS.  Half chunks with more than kGaMaxR ranges (very sparse detections)
 // take the slow path: per-range atomics straight from the registers.
+// FUSED (the LM path with the analytic Jacobian): the 2 x NS blocks are not read from a materialised J at all -- the first
+// two wavefronts evaluate their detection's residual and Jacobian (eval_observation_to, the arithmetic of k_observations)
+// straight into the LDS staging area.  Per LM iteration this removes the Jacobian kernel, its 183 MB of stores and the
+// 197 MB this kernel used to read back (BASELINE configs[2]); HBM traffic per observation falls to the 32 B of inputs.
 constexpr int kGaObs = 128, kGaStride = kGaObs + 1, kGaThreads = 512, kGaMaxR = kGaThreads / 6, kGaSplit = 8;
-template <int NS>
+struct LdsRowSink {          // eval_observation_to sink: slot k of the x / y row of staged column t
+  double* col;               // Js + t
+  int ns;
+  __device__ __forceinline__ void begin(int32_t) {}
+  __device__ __forceinline__ void x(int k, double v) { col[k * kGaStride] = v; }
+  __device__ __forceinline__ void y(int k, double v) { col[(ns + k) * kGaStride] = v; }
+};
+template <int NS, bool FUSED>
 __global__ __launch_bounds__(kGaThreads) void k_assemble_spans(DevProblem dp, const double* __restrict__ J, const int32_t* __restrict__ span,
-                                                             const double* __restrict__ f, NEView ne) {
+                                                             const double* __restrict__ f, NEView ne, const CamState* __restrict__ cams,
+                                                             const double* __restrict__ x) {
   constexpr int B = NS - 12;
   constexpr int kJs = (2 * NS + 2) * kGaStride;
   constexpr int kEp = 4 * 3 * B, kGp = 12, kCp = 10 * 9;        // partial block sizes per range: cross, gradient, band
@@ -90,23 +102,50 @@ __global__ __launch_bounds__(kGaThreads) void k_assemble_spans(DevProblem dp, co
   const int tid = threadIdx.x;
   if (tid == 0) { any_s = 0; sort_s = 0; nr_s = 0; }
   const int t = tid & (kGaObs - 1);                    // detection handled while staging
-  const int g = t < cnt ? span[i0 + t] : -1;
-  const int kt = g >= 0 ? g : 0x7fffffff;              // invisible detections sort last
-  if (tid < kGaObs) key[tid] = kt;
-  // stage: thread (tid) loads rows tid/128, tid/128+4, ... for detection t
   constexpr int kRowsPer = (2 * NS + 2 + 3) / 4;
+  int g, kt;
+  if (FUSED) {
+    // every staged value starts as zero (invisible detections, columns past the end); then one lane per detection fills its column
 #pragma unroll
-  for (int k = 0; k < kRowsPer; ++k) {
-    const int r = (tid >> 7) + 4 * k;
-    if (r >= 2 * NS + 2) break;
-    double v = 0.0;
-    if (g >= 0) {
-      if (r < 2 * NS) v = J[(long long)r * dp.M + i0 + t];
-      else v = f[2 * a0 + (r - 2 * NS) * Mc + (i0 + t - a0)];
+    for (int k = 0; k < kRowsPer; ++k) {
+      const int r = (tid >> 7) + 4 * k;
+      if (r < 2 * NS + 2) Js[r * kGaStride + t] = 0.0;
     }
-    Js[r * kGaStride + t] = v;
+    __syncthreads();
+    g = -1;
+    if (tid < kGaObs && t < cnt) {
+      constexpr bool CALIB = NS == 30;
+      const CamState& cam = cams[c];                    // wave-uniform: scalar loads
+      const long long i = i0 + t;
+      const double uo = CALIB ? 0.0 : dp.u_obs[i], vo = CALIB ? 0.0 : dp.v_obs[i];
+      const double ur = CALIB ? dp.u_raw[i] : 0.0;
+      LdsRowSink sink{Js + t, NS};
+      const ObsResult r = eval_observation_to<CALIB, true>(cam, dp.sp, x, dp.undist != 0, dp.rs_free != 0, dp.sync_free != 0,
+                                                           dp.frame[i], ur, dp.v_raw[i], uo, vo, sink);
+      g = r.ctrl;
+      if (g >= 0) { Js[(2 * NS) * kGaStride + t] = r.ex; Js[(2 * NS + 1) * kGaStride + t] = r.ey; }
+    }
+    kt = g >= 0 ? g : 0x7fffffff;
+    if (tid < kGaObs) key[tid] = kt;
+  } else {
+    g = t < cnt ? span[i0 + t] : -1;
+    kt = g >= 0 ? g : 0x7fffffff;                      // invisible detections sort last
+    if (tid < kGaObs) key[tid] = kt;
+    // stage: thread (tid) loads rows tid/128, tid/128+4, ... for detection t
+#pragma unroll
+    for (int k = 0; k < kRowsPer; ++k) {
+      const int r = (tid >> 7) + 4 * k;
+      if (r >= 2 * NS + 2) break;
+      double v = 0.0;
+      if (g >= 0) {
+        if (r < 2 * NS) v = J[(long long)r * dp.M + i0 + t];
+        else v = f[2 * a0 + (r - 2 * NS) * Mc + (i0 + t - a0)];
+      }
+      Js[r * kGaStride + t] = v;
+    }
   }
   __syncthreads();
+  if (FUSED) kt = key[t];                                // the key of column t, for the threads that did not evaluate it
   if (tid < kGaObs) {
     if (g >= 0) any_s = 1;
     if (tid > 0 && kt < key[tid - 1]) sort_s = 1;
@@ -1543,20 +1582,39 @@ struct HipSchur {
     if (fail_host) (void)hipHostFree(fail_host);
   }
 
-  void assemble_local(const double* f_dev) {
+  // x_fused != nullptr: the detection rows' Jacobian is evaluated inside the assembly kernel at x_fused (no J in memory);
+  // the motion rows (O(T), tiny) still go through k_motion
+  void assemble_local(const double* f_dev, const double* x_fused = nullptr) {
     MVUS_HIP(hipMemsetAsync(NE, 0, ne_count * sizeof(double), be.stream));
     if (be.dp.n_chunks > 0) {
       const int nc = be.dp.n_chunks;
-      if (be.hp.calib) hipLaunchKernelGGL(k_assemble_spans<30>, dim3(2 * nc), dim3(kGaThreads), 0, be.stream, be.dp, be.J, be.span, f_dev, ne);
-      else hipLaunchKernelGGL(k_assemble_spans<21>, dim3(2 * nc), dim3(kGaThreads), 0, be.stream, be.dp, be.J, be.span, f_dev, ne);
+      const dim3 g(2 * nc), b(kGaThreads);
+      if (x_fused) {
+        hipLaunchKernelGGL(k_cam_states, dim3((be.hp.C + 63) / 64), dim3(64), 0, be.stream, be.dp, x_fused, be.cams);
+        if (be.hp.calib) hipLaunchKernelGGL((k_assemble_spans<30, true>), g, b, 0, be.stream, be.dp, (const double*)nullptr, (const int32_t*)nullptr, f_dev, ne, be.cams, x_fused);
+        else hipLaunchKernelGGL((k_assemble_spans<21, true>), g, b, 0, be.stream, be.dp, (const double*)nullptr, (const int32_t*)nullptr, f_dev, ne, be.cams, x_fused);
+      } else {
+        if (be.hp.calib) hipLaunchKernelGGL((k_assemble_spans<30, false>), g, b, 0, be.stream, be.dp, be.J, be.span, f_dev, ne, be.cams, (const double*)nullptr);
+        else hipLaunchKernelGGL((k_assemble_spans<21, false>), g, b, 0, be.stream, be.dp, be.J, be.span, f_dev, ne, be.cams, (const double*)nullptr);
+      }
     }
     if (be.hp.T > 0)
       hipLaunchKernelGGL(k_assemble_motion, dim3((be.hp.T + kThreads - 1) / kThreads), dim3(kThreads), 0, be.stream, be.dp, be.mJ, be.mctrl,
                          f_dev + 2 * be.hp.M, ne);
     MVUS_HIP(hipGetLastError());
   }
-  void assemble(BE&, const double* f_dev) {
-    assemble_local(f_dev);
+  // Linearise at x: residual f (unless the caller already holds f(x) in f_dev), Jacobian, normal equations.  With the
+  // analytic Jacobian the detection rows are fused (assemble_local above); other Jacobian modes materialise J first.
+  void linearize(BE&, const double* x_dev, double* f_dev, int jac_mode, bool f_valid) {
+    const bool fused = jac_mode == MVUS_JAC_ANALYTIC && !std::getenv("MVUS_LM_MATERIALIZE_J");
+    if (!fused) { be.jacobian(x_dev, f_dev, jac_mode); assemble(be, f_dev); return; }
+    if (!f_valid) be.residual(x_dev, f_dev);
+    if (be.hp.T > 0) be.motion_jacobian(x_dev, f_dev);
+    be.has_jacobian = false;                               // no materialised J belongs to this point
+    assemble(be, f_dev, x_dev);
+  }
+  void assemble(BE&, const double* f_dev, const double* x_fused = nullptr) {
+    assemble_local(f_dev, x_fused);
     const int tot = ne.CB + ne.N3;          // every entry of x is a camera column or a control-point coordinate
     if (shard) {
       // time shard: sum the camera blocks and the blocks of the control points near a cut; the cross block never moves
