@@ -241,6 +241,20 @@ int mvus_ba_set_x(mvus_ba* h, const double* x);
 int mvus_triangulate(int32_t device, int64_t N, const double* x1, const double* x2, const double* P1, const double* P2,
                      double* X, double* err1, double* err2);
 
+/* Scene.spline_to_traj (common.py:273-301): evaluate the S trajectory splines at nt timestamps.  interval: [2*S] row-major
+ * spline['int'] (starts then ends); knot_offsets [S+1] / knots: concatenated spline['tck'][s][0]; coefs: concatenated
+ * spline['tck'][s][1] (cx(n_s) cy(n_s) cz(n_s) per spline).  which[nt] receives the interval each timestamp belongs to
+ * (start <= t <= end, closed like common.py:292) or -1; X[3*nt] (x(nt) y(nt) z(nt)) the point, 0 where which = -1.
+ * Same recurrence as scipy.interpolate.splev (FITPACK splev.f / fpbspl.f).  Stateless; no CPU fallback. */
+int mvus_spline_eval(int32_t device, int32_t S, const double* interval, const int64_t* knot_offsets, const double* knots,
+                     const double* coefs, int64_t nt, const double* t, double* X, int32_t* which);
+
+/* Least-squares cubic spline on a FIXED knot vector (num_knots = n + 4, first/last four equal): coefs[3*n] (cx cy cz)
+ * minimising sum_i |X(t_i) - X_i|^2 over the m data points t[m], X[3*m] (x(m) y(m) z(m)), t inside [knots[3], knots[n]].
+ * The coefficient refit of Scene.traj_to_spline (common.py:224-270) once FITPACK's adaptive search has placed the knots (that
+ * search stays on the host); equals scipy.interpolate.make_lsq_spline.  MVUS_E_NUMERIC when a coefficient has no data. */
+int mvus_spline_lsq(int32_t device, int32_t num_knots, const double* knots, int64_t m, const double* t, const double* X, double* coefs);
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,6 +15,7 @@
 #include "ba_solver.h"
 #include "ba_schur_hip.hip.h"
 #include "triangulate.hip.h"
+#include "spline_ops.hip.h"
 
 namespace mvus {
 
@@ -201,12 +202,14 @@ struct HipBackend {
     }
     reduce(out, 1);
   }
+  // the two vector reductions of an LM iteration: one workgroup up to 128k parameters (no cross-workgroup fences), else one per 1024
+  unsigned lm_grid() const { return hp.n <= (1 << 17) ? 1u : (unsigned)std::min<int64_t>(2048 / 5, (hp.n + 1023) / 1024); }
   void lm_gnorm(const double* x, const double* lb, const double* ub, const double* g, double* out) {
-    hipLaunchKernelGGL(k_lm_gnorm, dim3((unsigned)((hp.n + 1023) / 1024)), dim3(1024), 0, stream, (int)hp.n, x, lb, ub, g, out, partials, lm_counter);
+    hipLaunchKernelGGL(k_lm_gnorm, dim3(lm_grid()), dim3(1024), 0, stream, (int)hp.n, x, lb, ub, g, out, partials, lm_counter);
   }
   void lm_trial(const double* x, const double* p, const double* lb, const double* ub, const double* g, const double* D,
                 const int* fail, double* x_new, double* out, double* gnorm_out) {
-    hipLaunchKernelGGL(k_lm_trial, dim3((unsigned)((hp.n + 1023) / 1024)), dim3(1024), 0, stream, (int)hp.n, x, p, lb, ub, g, D, fail, x_new, out, gnorm_out, partials, lm_counter);
+    hipLaunchKernelGGL(k_lm_trial, dim3(lm_grid()), dim3(1024), 0, stream, (int)hp.n, x, p, lb, ub, g, D, fail, x_new, out, gnorm_out, partials, lm_counter);
   }
   void fetch(const double* src, int k, double* host) {       // src inside scal_dev: staged through the pinned mirror
     const int64_t off = src - scal_dev;
@@ -401,16 +404,15 @@ struct HipBackend {
       MVUS_HIP(hipMemsetAsync(jt_nondet, 0, sizeof(int), stream));
     }
     MVUS_HIP(hipMemsetAsync(z, 0, sizeof(double) * hp.n, stream));
-    const int cols = hp.C * (hp.NS - 12) + 3 * hp.N;
-    const dim3 g2((cols + kThreads - 1) / kThreads), b(kThreads);
+    const dim3 g2(hp.C + (hp.N + kThreads / 64 - 1) / (kThreads / 64)), b(kThreads);
     const int motion = hp.T > 0 ? 1 : 0;
     if (hp.calib) {
       if (dp.n_chunks > 0) hipLaunchKernelGGL(k_jtu_partial<30>, dim3(dp.n_chunks), b, 0, stream, dp, J, span, u, z, zc, zs, zg0, jt_nondet);
-      hipLaunchKernelGGL(k_jtu_index, dim3((hp.C + 63) / 64), dim3(64), 0, stream, dp, zg0, zfill);
+      hipLaunchKernelGGL(k_jtu_index, dim3(hp.C), dim3(64), 0, stream, dp, zg0, zfill);
       hipLaunchKernelGGL(k_jtu_reduce<30>, g2, b, 0, stream, dp, zc, zs, zg0, zfill, mJ, mctrl, u + 2 * hp.M, motion, z);
     } else {
       if (dp.n_chunks > 0) hipLaunchKernelGGL(k_jtu_partial<21>, dim3(dp.n_chunks), b, 0, stream, dp, J, span, u, z, zc, zs, zg0, jt_nondet);
-      hipLaunchKernelGGL(k_jtu_index, dim3((hp.C + 63) / 64), dim3(64), 0, stream, dp, zg0, zfill);
+      hipLaunchKernelGGL(k_jtu_index, dim3(hp.C), dim3(64), 0, stream, dp, zg0, zfill);
       hipLaunchKernelGGL(k_jtu_reduce<21>, g2, b, 0, stream, dp, zc, zs, zg0, zfill, mJ, mctrl, u + 2 * hp.M, motion, z);
     }
     MVUS_HIP(hipGetLastError());
@@ -429,6 +431,26 @@ struct mvus_ba {
 };
 
 static thread_local std::string g_create_error;
+
+// stateless helpers share this: device buffers of one call, freed on every exit
+namespace {
+struct CallBuffers {
+  std::vector<void*> bufs;
+  hipStream_t st = nullptr;
+  void open(int device) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= device) throw HipError{"no usable HIP device (libmvusba has no CPU fallback)"};
+    MVUS_HIP(hipSetDevice(device));
+    MVUS_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  }
+  template <class T>
+  T* get(size_t count) { void* p = nullptr; MVUS_HIP(hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T))); bufs.push_back(p); return static_cast<T*>(p); }
+  template <class T>
+  T* put(const T* host, size_t count) { T* d = get<T>(count); if (count) MVUS_HIP(hipMemcpyAsync(d, host, count * sizeof(T), hipMemcpyHostToDevice, st)); return d; }
+  ~CallBuffers() { for (void* p : bufs) (void)hipFree(p); if (st) (void)hipStreamDestroy(st); }
+};
+}  // namespace
+
 
 template <class F>
 static int guarded(mvus_ba* h, F&& fn) {
@@ -860,6 +882,69 @@ int mvus_triangulate(int32_t device, int64_t N, const double* x1, const double* 
     return MVUS_E_HIP;
   }
   cleanup();
+  return MVUS_OK;
+}
+
+int mvus_spline_eval(int32_t device, int32_t S, const double* interval, const int64_t* knot_offsets, const double* knots,
+                     const double* coefs, int64_t nt, const double* t, double* X, int32_t* which) {
+  if (S < 1 || !interval || !knot_offsets || !knots || !coefs || nt < 0 || (nt > 0 && (!t || !X || !which))) { g_create_error = "spline_eval: bad arguments"; return MVUS_E_INVALID; }
+  for (int s = 0; s < S; ++s)
+    if (knot_offsets[s + 1] - knot_offsets[s] < 8) { g_create_error = "spline_eval: a cubic spline needs at least 8 knots"; return MVUS_E_INVALID; }
+  if (nt == 0) return MVUS_OK;
+  try {
+    CallBuffers cb;
+    cb.open(device);
+    std::vector<long long> koff(knot_offsets, knot_offsets + S + 1), coff(S + 1, 0);
+    for (int s = 0; s < S; ++s) coff[s + 1] = coff[s] + 3 * (koff[s + 1] - koff[s] - 4);
+    SplineSet sp;
+    sp.S = S;
+    sp.istart = cb.put(interval, (size_t)S); sp.iend = cb.put(interval + S, (size_t)S);
+    sp.knot_off = cb.put(koff.data(), koff.size()); sp.knots = cb.put(knots, (size_t)koff[S]);
+    sp.coef_off = cb.put(coff.data(), coff.size()); sp.coefs = cb.put(coefs, (size_t)coff[S]);
+    const double* dt = cb.put(t, (size_t)nt);
+    double* dX = cb.get<double>(3 * (size_t)nt);
+    int32_t* dw = cb.get<int32_t>((size_t)nt);
+    hipLaunchKernelGGL(k_spline_eval, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, cb.st, sp, (long long)nt, dt, dX, dw);
+    MVUS_HIP(hipGetLastError());
+    MVUS_HIP(hipMemcpyAsync(X, dX, sizeof(double) * 3 * nt, hipMemcpyDeviceToHost, cb.st));
+    MVUS_HIP(hipMemcpyAsync(which, dw, sizeof(int32_t) * nt, hipMemcpyDeviceToHost, cb.st));
+    MVUS_HIP(hipStreamSynchronize(cb.st));
+  } catch (const HipError& e) {
+    g_create_error = e.msg;
+    return MVUS_E_HIP;
+  }
+  return MVUS_OK;
+}
+
+int mvus_spline_lsq(int32_t device, int32_t num_knots, const double* knots, int64_t m, const double* t, const double* X, double* coefs) {
+  const int n = num_knots - 4;
+  if (num_knots < 8 || !knots || m < 1 || !t || !X || !coefs) { g_create_error = "spline_lsq: bad arguments"; return MVUS_E_INVALID; }
+  for (int k = 1; k < num_knots; ++k) if (knots[k] < knots[k - 1]) { g_create_error = "spline_lsq: knot vector must be non-decreasing"; return MVUS_E_INVALID; }
+  for (int64_t i = 0; i < m; ++i) if (!(t[i] >= knots[3] && t[i] <= knots[n])) { g_create_error = "spline_lsq: data outside the knot interval"; return MVUS_E_INVALID; }
+  try {
+    CallBuffers cb;
+    cb.open(device);
+    const double* dk = cb.put(knots, (size_t)num_knots);
+    const double* dt = cb.put(t, (size_t)m);
+    const double* dX = cb.put(X, 3 * (size_t)m);
+    double* G = cb.get<double>(4 * (size_t)n);
+    double* rhs = cb.get<double>(3 * (size_t)n);
+    int* fail = cb.get<int>(1);
+    MVUS_HIP(hipMemsetAsync(G, 0, sizeof(double) * 4 * n, cb.st));
+    MVUS_HIP(hipMemsetAsync(rhs, 0, sizeof(double) * 3 * n, cb.st));
+    MVUS_HIP(hipMemsetAsync(fail, 0, sizeof(int), cb.st));
+    hipLaunchKernelGGL(k_lsq_accumulate, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, cb.st, dk, n, (long long)m, dt, dX, G, rhs);
+    hipLaunchKernelGGL(k_lsq_solve, dim3(1), dim3(64), 0, cb.st, n, G, rhs, fail);
+    MVUS_HIP(hipGetLastError());
+    int fh = 0;
+    MVUS_HIP(hipMemcpyAsync(coefs, rhs, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, cb.st));
+    MVUS_HIP(hipMemcpyAsync(&fh, fail, sizeof(int), hipMemcpyDeviceToHost, cb.st));
+    MVUS_HIP(hipStreamSynchronize(cb.st));
+    if (fh) { g_create_error = "spline_lsq: the normal equations are not positive definite (a coefficient without data: Schoenberg-Whitney violated)"; return MVUS_E_NUMERIC; }
+  } catch (const HipError& e) {
+    g_create_error = e.msg;
+    return MVUS_E_HIP;
+  }
   return MVUS_OK;
 }
 

@@ -364,41 +364,48 @@ __global__ __launch_bounds__(kThreads) void k_jtu_partial(DevProblem dp, const d
   }
 }
 
-// between the passes (one thread per camera): zfill[chunk] = running maximum of the window starts of the camera's chunks
+// between the passes (one wavefront per camera): zfill[chunk] = running maximum of the window starts of the camera's chunks
 // -- non-decreasing whatever the data, so pass 2 can binary-search it; chunks are time ordered, so zfill exceeds a
 // chunk's own start by at most the few spans a rolling-shutter shift can reorder
-__global__ void k_jtu_index(DevProblem dp, const int32_t* __restrict__ zg0, int32_t* __restrict__ zfill) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= dp.C) return;
-  int run = -0x7fffffff;
-  for (int ch = dp.cam_chunk_off[c]; ch < dp.cam_chunk_off[c + 1]; ++ch) {
-    const int g0 = zg0[ch];
-    if (g0 != 0x7fffffff && g0 > run) run = g0;
-    zfill[ch] = run;
+__global__ __launch_bounds__(64) void k_jtu_index(DevProblem dp, const int32_t* __restrict__ zg0, int32_t* __restrict__ zfill) {
+  const int c = blockIdx.x, lane = threadIdx.x;
+  int carry = -0x7fffffff;
+  for (int base = dp.cam_chunk_off[c]; base < dp.cam_chunk_off[c + 1]; base += 64) {
+    const int ch = base + lane;
+    const bool in = ch < dp.cam_chunk_off[c + 1];
+    const int g0 = in ? zg0[ch] : 0x7fffffff;
+    int v = g0 == 0x7fffffff ? -0x7fffffff : g0;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(v, off, 64); if (lane >= off) v = max(v, o); }
+    v = max(v, carry);
+    if (in) zfill[ch] = v;
+    carry = __shfl(v, 63, 64);
   }
 }
 
-// pass 2: one thread per column of z (camera columns first, then control point x coordinate)
+// pass 2.  Blocks [0, C): the B camera columns of camera blockIdx.x, each summed over the camera's chunks in order.
+// Blocks [C, ..): one wavefront per control point, lane = camera (cameras lane, lane + 64, ...): every lane adds, chunk by
+// chunk, the window entries of its camera that cover the control point; the lanes are then combined by a butterfly whose
+// pairing is fixed (the same bits every run), lane 0 adds the motion rows (a contiguous, precomputed row range) and writes z.
 template <int NS>
 __global__ __launch_bounds__(kThreads) void k_jtu_reduce(DevProblem dp, const double* __restrict__ zc, const double* __restrict__ zs,
                                                          const int32_t* __restrict__ zg0, const int32_t* __restrict__ zfill, const double* __restrict__ mJ,
                                                          const int32_t* __restrict__ mctrl, const double* __restrict__ um, int motion,
                                                          double* __restrict__ z) {
   constexpr int B = NS - 12;
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  const int CB = dp.C * B;
-  if (idx < CB) {
-    const int c = idx / B, k = idx % B;
+  if ((int)blockIdx.x < dp.C) {
+    const int c = blockIdx.x, k = threadIdx.x;
+    if (k >= B) return;
     double acc = 0.0;
     for (int ch = dp.cam_chunk_off[c]; ch < dp.cam_chunk_off[c + 1]; ++ch) acc += zc[(long long)ch * B + k];
     z[cam_col(dp.C, dp.P, c, k)] += acc;
     return;
   }
-  const int r = idx - CB;
-  if (r >= 3 * dp.N) return;
-  const int g = r / 3, d = r % 3;
-  double acc = 0.0;
-  for (int c = 0; c < dp.C; ++c) {
+  const int lane = threadIdx.x & 63;
+  const int g = ((int)blockIdx.x - dp.C) * (kThreads / 64) + (threadIdx.x >> 6);
+  if (g >= dp.N) return;
+  double acc[3] = {0.0, 0.0, 0.0};
+  for (int c = lane; c < dp.C; c += 64) {
     // first chunk whose running-max window start is within reach of g (everything before ends left of g) ...
     int lo = dp.cam_chunk_off[c], hi = dp.cam_chunk_off[c + 1];
     const int end = hi;
@@ -411,20 +418,38 @@ __global__ __launch_bounds__(kThreads) void k_jtu_reduce(DevProblem dp, const do
     for (int ch = lo; ch < end && zfill[ch] <= g + kJtWin; ++ch) {
       const int g0 = zg0[ch];
       const int lc = g - g0;
-      if (g0 != 0x7fffffff && lc >= 0 && lc < kJtWin) acc += zs[(long long)ch * (3 * kJtWin) + 3 * lc + d];
+      if (g0 != 0x7fffffff && lc >= 0 && lc < kJtWin) {
+        const double* w = zs + (long long)ch * (3 * kJtWin) + 3 * lc;
+        acc[0] += w[0]; acc[1] += w[1]; acc[2] += w[2];
+      }
     }
   }
+#pragma unroll
+  for (int d = 0; d < 3; ++d)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc[d] += __shfl_xor(acc[d], off, 64);      // fixed pairing: deterministic
   if (motion) {
-    for (int j = dp.mv.row_lo[g]; j < dp.mv.row_hi[g]; ++j) {
+    // motion rows: lanes take rows row_lo + lane, + 64, ...; same butterfly
+    double ma[3] = {0.0, 0.0, 0.0};
+    for (int j = dp.mv.row_lo[g] + lane; j < dp.mv.row_hi[g]; j += 64) {
       const double uj = um[j];
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         const int cg = mctrl[(long long)k * dp.T + j];
-        if (cg >= 0 && g >= cg && g <= cg + 3) acc += mJ[(long long)(12 * k + 3 * (g - cg) + d) * dp.T + j] * uj;
+        if (cg >= 0 && g >= cg && g <= cg + 3) {
+#pragma unroll
+          for (int d = 0; d < 3; ++d) ma[d] += mJ[(long long)(12 * k + 3 * (g - cg) + d) * dp.T + j] * uj;
+        }
       }
     }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) ma[d] += __shfl_xor(ma[d], off, 64);
+      acc[d] += ma[d];
+    }
   }
-  z[dp.mv.ctrl_x0[g] + d * dp.mv.ctrl_stride[g]] += acc;
+  if (lane < 3) z[dp.mv.ctrl_x0[g] + lane * dp.mv.ctrl_stride[g]] += (lane == 0 ? acc[0] : (lane == 1 ? acc[1] : acc[2]));
 }
 
 __global__ __launch_bounds__(kThreads) void k_motion_jv(DevProblem dp, const double* __restrict__ mJ, const int32_t* __restrict__ mctrl,
@@ -520,18 +545,18 @@ __device__ __forceinline__ bool last_block_done(unsigned* counter) {
 __global__ __launch_bounds__(1024) void k_lm_gnorm(int n, const double* __restrict__ x, const double* __restrict__ lb, const double* __restrict__ ub,
                                                    const double* __restrict__ g, double* __restrict__ out, double* part, unsigned* counter) {
   __shared__ double red[16];
-  const int i = blockIdx.x * 1024 + threadIdx.x;
   double gn = 0.0;
-  if (i < n) {
+  for (int i = blockIdx.x * 1024 + threadIdx.x; i < n; i += gridDim.x * 1024) {
     const double gi = g[i], xi = x[i];
     const bool blocked = (xi <= lb[i] && gi > 0) || (xi >= ub[i] && gi < 0);
-    if (!blocked) gn = fabs(gi);
+    if (!blocked) gn = fmax(gn, fabs(gi));
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) gn = fmax(gn, __shfl_down(gn, off, 64));
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = gn;
   __syncthreads();
-  if (threadIdx.x == 0) { double t = 0.0; for (int w = 0; w < 16; ++w) t = fmax(t, red[w]); part[blockIdx.x] = t; }
+  if (threadIdx.x == 0) { double t = 0.0; for (int w = 0; w < 16; ++w) t = fmax(t, red[w]); part[blockIdx.x] = t; if (gridDim.x == 1) *out = t; }
+  if (gridDim.x == 1) return;                              // one workgroup (n <= 128k): no cross-workgroup hand-off, no fences
   if (last_block_done(counter) && threadIdx.x == 0) {
     double t = 0.0;
     for (unsigned b = 0; b < gridDim.x; ++b) t = fmax(t, const_cast<volatile double*>(part)[b]);
@@ -547,18 +572,17 @@ __global__ __launch_bounds__(1024) void k_lm_trial(int n, const double* __restri
                                                    double* __restrict__ gnorm_out, double* part, unsigned* counter) {
   // also delivers the projected gradient norm of k_lm_gnorm (x, g and the bounds are read here anyway): slot 4 = max
   __shared__ double red[5][16];
-  const int i = blockIdx.x * 1024 + threadIdx.x;
   const bool dead = fail[0] != 0;
   double s[5] = {dead ? __longlong_as_double(0x7ff8000000000000LL) : 0.0, 0.0, 0.0, 0.0, 0.0};
-  if (i < n) {
+  for (int i = blockIdx.x * 1024 + threadIdx.x; i < n; i += gridDim.x * 1024) {
     const double xi = x[i], pi = p[i], gi = g[i], lo = lb[i], hi = ub[i];
     const bool ok = isfinite(pi);
     const double xn = (dead || !ok) ? xi : fmin(fmax(xi + pi, lo), hi);
     const double st = xn - xi;
     x_new[i] = xn;
-    s[0] += ok ? gi * st : pi * 0.0; s[1] = st * D[i] * st; s[2] = st * st; s[3] = xi * xi;
+    s[0] += ok ? gi * st : pi * 0.0; s[1] += st * D[i] * st; s[2] += st * st; s[3] += xi * xi;
     const bool blocked = (xi <= lo && gi > 0) || (xi >= hi && gi < 0);
-    s[4] = blocked ? 0.0 : fabs(gi);
+    s[4] = fmax(s[4], blocked ? 0.0 : fabs(gi));
   }
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -576,7 +600,9 @@ __global__ __launch_bounds__(1024) void k_lm_trial(int n, const double* __restri
     double t = 0.0;
     for (int w = 0; w < 16; ++w) t = threadIdx.x < 4 ? t + red[threadIdx.x][w] : fmax(t, red[4][w]);
     part[blockIdx.x * 5 + threadIdx.x] = t;
+    if (gridDim.x == 1) { if (threadIdx.x < 4) out[threadIdx.x] = t; else *gnorm_out = t; }
   }
+  if (gridDim.x == 1) return;                              // one workgroup: done, nothing to hand over
   if (last_block_done(counter) && threadIdx.x < 5) {
     double t = 0.0;
     for (unsigned b = 0; b < gridDim.x; ++b) {

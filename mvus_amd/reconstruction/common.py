@@ -205,7 +205,7 @@ class Scene:
             assert (keep[1] - keep[0] >= 0).all()
             self.detections[i], _ = util.sampling(det, keep)
 
-    # ---- spline <-> trajectory (host, outside the BA loop; SURVEY 8f "next") -----------------------
+    # ---- spline <-> trajectory: evaluation on the GPU, FITPACK's adaptive knot search on the host ----
     def traj_to_spline(self, smooth_factor):
         """One smoothing cubic spline per contiguous part of ``self.traj`` (FITPACK ``splprep`` with the
         reference's knot-density loop, common.py:224-270)."""
@@ -239,18 +239,23 @@ class Scene:
         return self.spline
 
     def spline_to_traj(self, sampling_rate=1, t=None):
-        from scipy import interpolate
+        """Discrete 3D points of the splines (common.py:273-301): sampled at a constant rate or at the given timestamps,
+        kept where they lie inside an interval (closed ends), interval by interval.  The evaluation runs on the GPU
+        (``mvus_spline_eval``, the FITPACK recurrence of the BA kernels) instead of scipy's splev."""
+        from .. import spline as _spline
         tck, interval = self.spline['tck'], self.spline['int']
         if t is not None:
             assert len(t.shape) == 1, 'Input timestamps must be a 1D array'
-            ts = t
+            ts = np.asarray(t, dtype=np.float64)
         else:
             ts = np.arange(interval[0, 0], interval[1, -1], sampling_rate)
+        device = int(self.settings.get('device', 0)) if isinstance(self.settings, dict) else 0
+        X, which = _spline.evaluate(tck, interval, ts, device=device)
         parts = [np.empty([4, 0])]
-        for i in range(interval.shape[1]):
-            tp = ts[(ts >= interval[0, i]) & (ts <= interval[1, i])]
-            if tp.size:
-                parts.append(np.vstack((tp, np.asarray(interpolate.splev(tp, tck[i])))))
+        for i in range(interval.shape[1]):                       # the reference's order: interval by interval
+            m = which == i
+            if m.any():
+                parts.append(np.vstack((ts[m], X[:, m])))
         self.traj = np.hstack(parts)
         assert (self.traj[0, 1:] >= self.traj[0, :-1]).all()
         return self.traj

@@ -38,6 +38,7 @@ def test_similarity_fit_recovers_a_known_transform():
         compare_gt.similarity_from_points(p[:, :2], q[:, :2])
 
 
+@pytest.mark.gpu            # Scene.spline_to_traj evaluates on the GPU
 def test_align_gt_matches_the_reference():
     scene, g = _flight('align_gt_2cam')
     out = compare_gt.align_gt(scene, float(g['f_gt']), np.asarray(g['gt']), verbose=False)
@@ -51,6 +52,7 @@ def test_align_gt_matches_the_reference():
     assert np.median(out['error']) < 0.03                     # 1 cm noise on the synthetic ground truth
 
 
+@pytest.mark.gpu
 def test_align_gt_input_handling(tmp_path):
     scene, g = _flight('align_gt_2cam')
     assert compare_gt.align_gt(scene, 5.0, '', verbose=False) is None
@@ -77,10 +79,59 @@ def test_traj_to_spline_and_back_match_the_reference():
     for i, tck in enumerate(sp['tck']):
         np.testing.assert_allclose(tck[0], g['knots_%d' % i], rtol=0, atol=1e-12)
         np.testing.assert_allclose(np.asarray(tck[1]), g['coefs_%d' % i], rtol=0, atol=1e-9)
-    np.testing.assert_allclose(s.spline_to_traj(sampling_rate=1), g['traj_rate1'], rtol=0, atol=1e-9)
-    np.testing.assert_allclose(s.spline_to_traj(t=g['t_query']), g['traj_query'], rtol=0, atol=1e-9)
 
 
+@pytest.mark.gpu
+def test_spline_to_traj_matches_the_reference():
+    """Scene.spline_to_traj (common.py:273-301) with the evaluation on the GPU, against the reference's resampled
+    trajectories (constant rate and at given timestamps, two intervals with a gap) and against scipy's splev."""
+    import os
+    from scipy import interpolate
+    from golden_util import GOLDEN_DIR
+    from mvus_amd import spline
+    g = dict(np.load(os.path.join(GOLDEN_DIR, 'traj_spline.npz')))
+    s = common.Scene()
+    s.settings = {}
+    s.spline = {'tck': [[g['knots_%d' % i], list(g['coefs_%d' % i]), 3] for i in range(int(g['n_int']))], 'int': g['interval']}
+    np.testing.assert_allclose(s.spline_to_traj(sampling_rate=1), g['traj_rate1'], rtol=0, atol=1e-11)
+    np.testing.assert_allclose(s.spline_to_traj(t=g['t_query']), g['traj_query'], rtol=0, atol=1e-11)
+    # closed interval ends, timestamps outside every interval, an empty query
+    iv = g['interval']
+    t = np.array([iv[0, 0] - 1.0, iv[0, 0], iv[1, 0], 0.5 * (iv[1, 0] + iv[0, 1]), iv[0, 1], iv[1, 1], iv[1, 1] + 1e-9])
+    X, which = spline.evaluate(s.spline['tck'], iv, t)
+    np.testing.assert_array_equal(which, [-1, 0, 0, -1, 1, 1, -1])
+    for k in (1, 2, 4, 5):
+        ref = np.asarray(interpolate.splev(t[k], s.spline['tck'][which[k]]))
+        np.testing.assert_allclose(X[:, k], ref, rtol=0, atol=1e-11)
+    assert spline.evaluate(s.spline['tck'], iv, np.zeros(0))[0].shape == (3, 0)
+    assert s.spline_to_traj(t=np.array([iv[0, 0] - 5.0])).shape == (4, 0)
+
+
+@pytest.mark.gpu
+def test_lsq_fit_on_fixed_knots_matches_scipy():
+    """mvus_spline_lsq: least-squares coefficients on the knots FITPACK placed, against scipy.interpolate.make_lsq_spline."""
+    import os
+    from scipy import interpolate
+    from golden_util import GOLDEN_DIR
+    from mvus_amd import spline
+    g = dict(np.load(os.path.join(GOLDEN_DIR, 'traj_spline.npz')))
+    traj = g['traj']
+    for i in range(int(g['n_int'])):
+        knots = g['knots_%d' % i]
+        m = (traj[0] >= g['interval'][0, i]) & (traj[0] <= g['interval'][1, i])
+        t, X = traj[0, m], traj[1:, m]
+        c = spline.lsq_fit(knots, t, X)
+        ref = interpolate.make_lsq_spline(t, X.T, knots, k=3).c.T
+        np.testing.assert_allclose(np.asarray(c), ref, rtol=0, atol=1e-9 * np.abs(ref).max())
+        # the least-squares fit is at least as close to the data as FITPACK's smoothing spline on the same knots
+        fit = np.asarray(interpolate.splev(t, [knots, c, 3]))
+        smooth = np.asarray(interpolate.splev(t, [knots, list(g['coefs_%d' % i]), 3]))
+        assert np.sum((fit - X) ** 2) <= np.sum((smooth - X) ** 2) * (1 + 1e-9)
+    with pytest.raises(ValueError):
+        spline.lsq_fit(knots, t[:5] + 1e6, X[:, :5])                  # data outside the knot interval
+
+
+@pytest.mark.gpu            # all_detect_to_traj resamples the spline (Scene.spline_to_traj, GPU)
 @pytest.mark.parametrize('name', ['rs_F_2int_3cam', 'calib_KE_bounds_3cam'])
 def test_all_detect_to_traj_vs_reference(name):
     """Scene.all_detect_to_traj (common.py:887-947) at the state the reference's first BA left behind: global_traj,

@@ -28,5 +28,27 @@ def pmc(db):
         print('%-100s %-12s %6d %14.3f %14.3f %14.3f %12.0f' % (name[:100], cname, n, avg, mn, mx, dur))
 
 
+def traffic(fetch_txt, write_txt):
+    """profiles/pmc_traffic.json: HBM bytes per launch of the residual+Jacobian kernel from the two PMC summaries, corrected as
+    /opt/skills/guides/MI355X_MICROARCH.md (HBM section) prescribes for gfx950: FETCH_SIZE doubled (128-B read requests are
+    tallied at 64 B), WRITE_SIZE as reported; both are KiB per dispatch in the summaries."""
+    import json
+
+    def avg(path, counter):
+        for line in open(path):
+            if 'k_observations<false, true>' in line and counter in line:
+                parts = line.split(counter)[1].split()
+                return int(parts[0]), float(parts[1]) * 1024.0
+        raise SystemExit('kernel not found in ' + path)
+    nf, fb = avg(fetch_txt, 'FETCH_SIZE')
+    nw, wb = avg(write_txt, 'WRITE_SIZE')
+    print(json.dumps({'config2_calib0': {
+        'kernel': 'k_observations<calib=false,jac=true>', 'dispatches': nw,
+        'WRITE_SIZE_bytes': wb, 'FETCH_SIZE_bytes_reported': fb, 'bytes_per_launch': wb + 2.0 * fb,
+        'note': 'rocprofv3 --pmc WRITE_SIZE and --pmc FETCH_SIZE in separate passes of `python3 bench.py` (profiles/r02_pmc_*_config2.txt); '
+                'the dispatches are the 100 launches with rotating outputs (>= 1 GiB in rotation) plus 20 into one buffer set; FETCH_SIZE '
+                'doubled per the gfx950 correction of the guide, WRITE_SIZE as reported'}}, indent=1))
+
+
 if __name__ == '__main__':
-    {'stats': stats, 'pmc': pmc}[sys.argv[1]](sys.argv[2])
+    {'stats': stats, 'pmc': pmc, 'traffic': traffic}[sys.argv[1]](*sys.argv[2:])
