@@ -141,13 +141,13 @@ def main():
     x = x0.copy()
     lin_iters = 0
     for _ in range(args.warmup):
-        r = handle.solve(x, solver=solver, jac_mode=jac_mode, max_nfev=2, return_fun=False)
+        r = handle.solve(x, solver=solver, jac_mode=jac_mode, max_nfev=2, return_fun=False, ties='canonical')
         x = r.x
     barrier()
     t0 = time.perf_counter()
     cost0 = None
     for _ in range(args.steps):
-        r = handle.solve(x, solver=solver, jac_mode=jac_mode, max_nfev=2, return_fun=False)
+        r = handle.solve(x, solver=solver, jac_mode=jac_mode, max_nfev=2, return_fun=False, ties='canonical')
         x = r.x
         lin_iters += r.lin_iters
         cost0 = r.initial_cost if cost0 is None else cost0
@@ -175,12 +175,12 @@ def main():
     parity = None
     if world == 1 and not args.no_parity_solver and args.solver == 'lm':      # (an N=1 report, like the CPU baseline)
         xs = x0.copy()
-        handle.solve(xs, solver=ba.SOLVER_TRF_LSMR, jac_mode=ba.JAC_PATTERN, max_nfev=2, return_fun=False)
+        handle.solve(xs, solver=ba.SOLVER_TRF_LSMR, jac_mode=ba.JAC_PATTERN, max_nfev=2, return_fun=False, ties='canonical')
         barrier()
         tp = time.perf_counter()
         nsteps, its = 3, 0
         for _ in range(nsteps):
-            rp = handle.solve(xs, solver=ba.SOLVER_TRF_LSMR, jac_mode=ba.JAC_PATTERN, max_nfev=2, return_fun=False)
+            rp = handle.solve(xs, solver=ba.SOLVER_TRF_LSMR, jac_mode=ba.JAC_PATTERN, max_nfev=2, return_fun=False, ties='canonical')
             xs = rp.x
             its += rp.lin_iters
         barrier()

@@ -87,11 +87,12 @@ class BAHandle:
                                                  mctrl.ctypes.data_as(_lib.c_int32_p)), 'mvus_ba_motion_rows')
         return mf, mJ, mctrl
 
-    def set_pattern(self, x0):
-        """Canonical pattern codes of the detection rows at x0, computed on the GPU (tie rows carry ``_lib.PAT_TIE``)."""
+    def set_pattern(self, x0, download=True):
+        """Canonical pattern codes of the detection rows at x0, computed on the GPU (tie rows carry ``_lib.PAT_TIE``);
+        ``download=False`` leaves them on the device only."""
         x0 = self._x(x0, self.n)
-        pat = np.empty(self.M, dtype=np.int32)
-        self._check(self.lib.mvus_ba_set_pattern(self.h, _lib.dptr(x0), pat.ctypes.data_as(_lib.c_int32_p)), 'mvus_ba_set_pattern')
+        pat = np.empty(self.M, dtype=np.int32) if download else None
+        self._check(self.lib.mvus_ba_set_pattern(self.h, _lib.dptr(x0), pat.ctypes.data_as(_lib.c_int32_p) if download else None), 'mvus_ba_set_pattern')
         return pat
 
     def motion_pattern(self):
@@ -180,8 +181,10 @@ class BAHandle:
         o = opts if opts is not None else _lib.default_opts(solver, jac_mode, max_nfev)
         if o.jac_mode == JAC_FD:
             self.prepare_fd(x, ties, matrix)
-        elif o.jac_mode == JAC_PATTERN:
+        elif o.jac_mode == JAC_PATTERN and (matrix is not None or ties != 'canonical'):
             self.prepare_pattern(x, ties, matrix)
+        elif o.jac_mode == JAC_PATTERN:
+            self.set_pattern(x, download=False)      # canonical codes stay on the GPU: no host round trip (clears an uploaded pattern)
         res = _lib.MvusResult()
         f = np.empty(self.m) if return_fun else None
         self._check(self.lib.mvus_ba_solve(self.h, _lib.dptr(x), ctypes.byref(o), ctypes.byref(res),

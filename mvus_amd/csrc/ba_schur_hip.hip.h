@@ -68,7 +68,12 @@ __device__ __forceinline__ int wave_min_i(int v) {
 // two wavefronts evaluate their detection's residual and Jacobian (eval_observation_to, the arithmetic of k_observations)
 // straight into the LDS staging area.  Per LM iteration this removes the Jacobian kernel, its 183 MB of stores and the
 // 197 MB this kernel used to read back (BASELINE configs[2]); HBM traffic per observation falls to the 32 B of inputs.
-constexpr int kGaObs = 128, kGaStride = kGaObs + 1, kGaThreads = 512, kGaMaxR = kGaThreads / 6, kGaSplit = 8;
+#ifndef MVUS_GA_OBS
+#define MVUS_GA_OBS 128
+#endif
+constexpr int kGaObs = MVUS_GA_OBS, kGaStride = kGaObs + 1, kGaThreads = 4 * kGaObs, kGaMaxR = kGaThreads / 6, kGaSplit = 8;
+constexpr int kGaShift = kGaObs == 128 ? 7 : 6, kGaParts = 256 / kGaObs;      // detections per workgroup: 128 or 64 (parts of a 256-chunk)
+static_assert(kGaObs == 128 || kGaObs == 64, "the assembly tile is 128 or 64 detections");
 struct LdsRowSink {          // eval_observation_to sink: slot k of the x / y row of staged column t
   double* col;               // Js + t
   int ns;
@@ -92,8 +97,9 @@ __global__ __launch_bounds__(kGaThreads) void k_assemble_spans(DevProblem dp, co
   unsigned char* re = rs + kGaObs;
   // after the accumulation the three arrays above are dead and their storage holds the owner tables of the flush
   unsigned char* own_r = reinterpret_cast<unsigned char*>(meta);         // [<= 4*kGaMaxR] range that owns control point i
-  unsigned short* obase = reinterpret_cast<unsigned short*>(meta + 96);  // [<= kGaMaxR + 1] first owned point of a range
-  const int chunk = blockIdx.x >> 1, half = blockIdx.x & 1;
+  unsigned short* obase = reinterpret_cast<unsigned short*>(meta + kGaMaxR);  // [<= kGaMaxR + 2] first owned point of a range
+  static_assert(kGaMaxR + (kGaMaxR + 2 + 1) / 2 <= kGaObs + kGaObs / 2, "owner tables must fit the dead key/range arrays");
+  const int chunk = blockIdx.x / kGaParts, half = blockIdx.x % kGaParts;
   const int c = dp.chunk_cam[chunk];
   const int cnt = min(kGaObs, dp.chunk_count[chunk] - half * kGaObs);
   if (cnt <= 0) return;
@@ -108,10 +114,10 @@ __global__ __launch_bounds__(kGaThreads) void k_assemble_spans(DevProblem dp, co
     // every staged value starts as zero (invisible detections, columns past the end); then one lane per detection fills its column
 #pragma unroll
     for (int k = 0; k < kRowsPer; ++k) {
-      const int r = (tid >> 7) + 4 * k;
+      const int r = (tid >> kGaShift) + 4 * k;
       if (r < 2 * NS + 2) Js[r * kGaStride + t] = 0.0;
     }
-    __syncthreads();
+    lds_barrier();
     g = -1;
     if (tid < kGaObs && t < cnt) {
       constexpr bool CALIB = NS == 30;
@@ -134,7 +140,7 @@ __global__ __launch_bounds__(kGaThreads) void k_assemble_spans(DevProblem dp, co
     // stage: thread (tid) loads rows tid/128, tid/128+4, ... for detection t
 #pragma unroll
     for (int k = 0; k < kRowsPer; ++k) {
-      const int r = (tid >> 7) + 4 * k;
+      const int r = (tid >> kGaShift) + 4 * k;
       if (r >= 2 * NS + 2) break;
       double v = 0.0;
       if (g >= 0) {
@@ -144,25 +150,25 @@ __global__ __launch_bounds__(kGaThreads) void k_assemble_spans(DevProblem dp, co
       Js[r * kGaStride + t] = v;
     }
   }
-  __syncthreads();
+  lds_barrier();
   if (FUSED) kt = key[t];                                // the key of column t, for the threads that did not evaluate it
   if (tid < kGaObs) {
     if (g >= 0) any_s = 1;
     if (tid > 0 && kt < key[tid - 1]) sort_s = 1;
   }
-  __syncthreads();
+  lds_barrier();
   if (!any_s) return;                                   // nothing visible (uniform)
   if (sort_s) {
     int pos = 0;
     for (int u = 0; u < kGaObs; ++u) { const int ku = key[u]; pos += (ku < kt) || (ku == kt && u < t); }
     double tmp[kRowsPer];                                // this thread's rows: (tid >> 7) + 4k
 #pragma unroll
-    for (int k = 0; k < kRowsPer; ++k) { const int r = (tid >> 7) + 4 * k; tmp[k] = r < 2 * NS + 2 ? Js[r * kGaStride + t] : 0.0; }
-    __syncthreads();
+    for (int k = 0; k < kRowsPer; ++k) { const int r = (tid >> kGaShift) + 4 * k; tmp[k] = r < 2 * NS + 2 ? Js[r * kGaStride + t] : 0.0; }
+    lds_barrier();
 #pragma unroll
-    for (int k = 0; k < kRowsPer; ++k) { const int r = (tid >> 7) + 4 * k; if (r < 2 * NS + 2) Js[r * kGaStride + pos] = tmp[k]; }
+    for (int k = 0; k < kRowsPer; ++k) { const int r = (tid >> kGaShift) + 4 * k; if (r < 2 * NS + 2) Js[r * kGaStride + pos] = tmp[k]; }
     if (tid < kGaObs) key[pos] = kt;
-    __syncthreads();
+    lds_barrier();
   }
   // ranges of equal span, in span order (slot = number of range starts before this one, from the wave ballots)
   {
@@ -174,7 +180,7 @@ __global__ __launch_bounds__(kGaThreads) void k_assemble_spans(DevProblem dp, co
     const bool start = tid < kGaObs && ks != 0x7fffffff && back % kGaSplit == 0;
     const unsigned long long mask = __ballot(start);
     if (tid == 0) nr_s = __popcll(mask);                 // starts in the first wavefront
-    __syncthreads();
+    lds_barrier();
     if (start) {
       int e = tid + 1;
       while (e < kGaObs && key[e] == ks && e - tid < kGaSplit) ++e;
@@ -184,13 +190,16 @@ __global__ __launch_bounds__(kGaThreads) void k_assemble_spans(DevProblem dp, co
       if (!inr) atomicOr(ne.err, 1);
       rs[slot] = (unsigned char)tid; re[slot] = (unsigned char)(inr ? e : tid); rg[slot] = inr ? kl : 0;
     }
-    __syncthreads();
+    lds_barrier();
     if (tid == 64) nr_s += __popcll(mask);
   }
-  __syncthreads();
+  lds_barrier();
   const int nr = nr_s;
   const double* fxs = Js + (2 * NS) * kGaStride;
   const double* fys = fxs + kGaStride;
+#if defined(MVUS_ASM_STOP) && MVUS_ASM_STOP == 1
+  if (nr >= 0) return;      // timing probe: staging + ranges only
+#endif
   // camera block (lower triangle) and camera gradient on the fp64 matrix cores: G = R R^T with R = [camera slots; f]
   // ((B+1) x 2*128, x rows then y rows).  For v_mfma_f64_16x16x4 the A fragment (lane l: R[l&15][k0 + (l>>4)]) IS the
   // B fragment of R^T, so one LDS read feeds both operands.  The LAST wavefront does all of it (64 MFMAs per tile pair)
@@ -315,19 +324,29 @@ __global__ __launch_bounds__(kGaThreads) void k_assemble_spans(DevProblem dp, co
     }
   }
   if (!fast) return;
-  __syncthreads();                                        // every thread holds its partials in registers: Js is dead
+#if defined(MVUS_ASM_STOP) && MVUS_ASM_STOP == 2
+  if (acc_[0] != 12345.678) return;      // timing probe: + accumulation, no flush
+#endif
+  lds_barrier();                                        // every thread holds its partials in registers: Js is dead
   // owner tables of one flush round over ranges [r0, r0 + nb): a control point is owned by the first range of the
   // round that reaches it; range rl owns its last min(4, rg[rl] - rg[rl-1]) points.  Returns the number of owned points.
   auto build_owners = [&](int r0, int nb) {
-    if (tid < nb) {
-      int bs = 0;
-      for (int j = 0; j < tid; ++j) bs += j == 0 ? 4 : min(4, rg[r0 + j] - rg[r0 + j - 1]);
-      const int nc = tid == 0 ? 4 : min(4, rg[r0 + tid] - rg[r0 + tid - 1]);
-      obase[tid] = (unsigned short)bs;
-      if (tid == nb - 1) obase[nb] = (unsigned short)(bs + nc);
-      for (int j = 0; j < nc; ++j) own_r[bs + j] = (unsigned char)tid;
+    // nb <= 85 ranges: thread t < nb owns range t; exclusive prefix sum of the owned counts over one or two wavefronts
+    const int mine = tid < nb ? (tid == 0 ? 4 : min(4, rg[r0 + tid] - rg[r0 + tid - 1])) : 0;
+    int incl = mine;
+    if (tid < 128) {
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(incl, off, 64); if ((tid & 63) >= off) incl += o; }
+      if (tid == 63) obase[kGaMaxR + 1] = (unsigned short)incl;         // total of the first wavefront (scratch slot)
     }
-    __syncthreads();
+    lds_barrier();
+    if (tid < nb) {
+      const int bs = incl - mine + (tid >= 64 ? (int)obase[kGaMaxR + 1] : 0);
+      obase[tid] = (unsigned short)bs;
+      if (tid == nb - 1) obase[nb] = (unsigned short)(bs + mine);
+      for (int j = 0; j < mine; ++j) own_r[bs + j] = (unsigned char)tid;
+    }
+    lds_barrier();
     return (int)obase[nb];
   };
   // ---- flush of the cross block + gradient, kRbE ranges per round: Ep[rl][q][3][B], Gp[rl][q][3] ----
@@ -363,8 +382,11 @@ __global__ __launch_bounds__(kGaThreads) void k_assemble_spans(DevProblem dp, co
         else unsafeAtomicAdd(&ne.Et[((long long)c * ne.N3 + 3 * ctrl) * B + dk], acc);
       }
     }
-    __syncthreads();
+    lds_barrier();
   }
+#if defined(MVUS_ASM_STOP) && MVUS_ASM_STOP == 3
+  if (nr >= 0) return;      // timing probe: + cross-block flush
+#endif
   // ---- flush of the spline band, kRbC ranges per round: Cp[rl][pair (qa, w)][3][3], pair = 4 qa - qa (qa - 1) / 2 + w ----
   for (int r0 = 0; r0 < nr; r0 += kRbC) {
     const int nb = min(kRbC, nr - r0);
@@ -392,7 +414,7 @@ __global__ __launch_bounds__(kGaThreads) void k_assemble_spans(DevProblem dp, co
       }
       if (acc != 0.0) unsafeAtomicAdd(&ne.Cb[((long long)ctrl * ne.W) * 9 + wd], acc);
     }
-    __syncthreads();
+    lds_barrier();
   }
 #undef EA
 #undef CA
@@ -1588,7 +1610,7 @@ struct HipSchur {
     MVUS_HIP(hipMemsetAsync(NE, 0, ne_count * sizeof(double), be.stream));
     if (be.dp.n_chunks > 0) {
       const int nc = be.dp.n_chunks;
-      const dim3 g(2 * nc), b(kGaThreads);
+      const dim3 g(kGaParts * nc), b(kGaThreads);
       if (x_fused) {
         hipLaunchKernelGGL(k_cam_states, dim3((be.hp.C + 63) / 64), dim3(64), 0, be.stream, be.dp, x_fused, be.cams);
         if (be.hp.calib) hipLaunchKernelGGL((k_assemble_spans<30, true>), g, b, 0, be.stream, be.dp, (const double*)nullptr, (const int32_t*)nullptr, f_dev, ne, be.cams, x_fused);
