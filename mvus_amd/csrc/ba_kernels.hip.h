@@ -546,10 +546,21 @@ __global__ __launch_bounds__(1024) void k_lm_gnorm(int n, const double* __restri
                                                    const double* __restrict__ g, double* __restrict__ out, double* part, unsigned* counter) {
   __shared__ double red[16];
   double gn = 0.0;
-  for (int i = blockIdx.x * 1024 + threadIdx.x; i < n; i += gridDim.x * 1024) {
-    const double gi = g[i], xi = x[i];
-    const bool blocked = (xi <= lb[i] && gi > 0) || (xi >= ub[i] && gi < 0);
-    if (!blocked) gn = fmax(gn, fabs(gi));
+  // batches of 8 elements per thread: all loads of a batch are issued before the first is used (one memory round trip per
+  // batch instead of one per element -- a single workgroup would otherwise be latency bound)
+  for (int i0 = blockIdx.x * 1024 + threadIdx.x; i0 < n; i0 += gridDim.x * 1024 * 8) {
+    double gi[8], xi[8], lo[8], hi[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u * gridDim.x * 1024;
+      const bool in = i < n;
+      gi[u] = in ? g[i] : 0.0; xi[u] = in ? x[i] : 0.0; lo[u] = in ? lb[i] : -INFINITY; hi[u] = in ? ub[i] : INFINITY;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const bool blocked = (xi[u] <= lo[u] && gi[u] > 0) || (xi[u] >= hi[u] && gi[u] < 0);
+      if (!blocked) gn = fmax(gn, fabs(gi[u]));
+    }
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) gn = fmax(gn, __shfl_down(gn, off, 64));
@@ -574,15 +585,28 @@ __global__ __launch_bounds__(1024) void k_lm_trial(int n, const double* __restri
   __shared__ double red[5][16];
   const bool dead = fail[0] != 0;
   double s[5] = {dead ? __longlong_as_double(0x7ff8000000000000LL) : 0.0, 0.0, 0.0, 0.0, 0.0};
-  for (int i = blockIdx.x * 1024 + threadIdx.x; i < n; i += gridDim.x * 1024) {
-    const double xi = x[i], pi = p[i], gi = g[i], lo = lb[i], hi = ub[i];
-    const bool ok = isfinite(pi);
-    const double xn = (dead || !ok) ? xi : fmin(fmax(xi + pi, lo), hi);
-    const double st = xn - xi;
-    x_new[i] = xn;
-    s[0] += ok ? gi * st : pi * 0.0; s[1] += st * D[i] * st; s[2] += st * st; s[3] += xi * xi;
-    const bool blocked = (xi <= lo && gi > 0) || (xi >= hi && gi < 0);
-    s[4] = fmax(s[4], blocked ? 0.0 : fabs(gi));
+  for (int i0 = blockIdx.x * 1024 + threadIdx.x; i0 < n; i0 += gridDim.x * 1024 * 4) {      // batches of 4: loads first, see k_lm_gnorm
+    double xv[4], pv[4], gv[4], lo[4], hi[4], dv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * gridDim.x * 1024;
+      const bool in = i < n;
+      xv[u] = in ? x[i] : 0.0; pv[u] = in ? p[i] : 0.0; gv[u] = in ? g[i] : 0.0;
+      lo[u] = in ? lb[i] : -INFINITY; hi[u] = in ? ub[i] : INFINITY; dv[u] = in ? D[i] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * gridDim.x * 1024;
+      if (i >= n) break;
+      const double xi = xv[u], pi = pv[u], gi = gv[u];
+      const bool ok = isfinite(pi);
+      const double xn = (dead || !ok) ? xi : fmin(fmax(xi + pi, lo[u]), hi[u]);
+      const double st = xn - xi;
+      x_new[i] = xn;
+      s[0] += ok ? gi * st : pi * 0.0; s[1] += st * dv[u] * st; s[2] += st * st; s[3] += xi * xi;
+      const bool blocked = (xi <= lo[u] && gi > 0) || (xi >= hi[u] && gi < 0);
+      s[4] = fmax(s[4], blocked ? 0.0 : fabs(gi));
+    }
   }
 #pragma unroll
   for (int k = 0; k < 4; ++k) {

@@ -37,6 +37,7 @@ constexpr int kNWin = 64;   // control points covered by a workgroup's LDS accum
 // control point row0 (0 and the whole spline unless the handle is a time shard)
 struct NEView {
   double *A, *gc, *Cb, *gs, *Et;
+  double* Apart;         // [assembly workgroups][8 wavefronts][(B+1)(B+2)/2] lower triangle of [camera slots; f] [..]^T, partial (k_cam_block_reduce sums them)
   int C, B, CB, N, N3, W;
   int row0;
   int* err;              // set when a row reaches outside the slice
@@ -92,13 +93,12 @@ __global__ __launch_bounds__(kGaThreads) void k_assemble_spans(DevProblem dp, co
   __shared__ double Js[kJs];                             // rows 0..NS-1: x-row slots, NS..2NS-1: y-row slots, then fx, fy
   __shared__ int meta[kGaObs + kGaObs / 2], rg[kGaObs];
   __shared__ int any_s, sort_s, nr_s;
+  // flush: per owned control point of the round -- its index, the first range that reaches it and how many consecutive ranges do
+  __shared__ int pt_ctrl[4 * kGaMaxR + 4];
+  __shared__ unsigned char pt_rl[4 * kGaMaxR + 4], pt_cnt[4 * kGaMaxR + 4], pt_q[4 * kGaMaxR + 4];
   int* key = meta;                                                   // span per staged column
   unsigned char* rs = reinterpret_cast<unsigned char*>(meta + kGaObs);   // first / one-past-last column of a range
   unsigned char* re = rs + kGaObs;
-  // after the accumulation the three arrays above are dead and their storage holds the owner tables of the flush
-  unsigned char* own_r = reinterpret_cast<unsigned char*>(meta);         // [<= 4*kGaMaxR] range that owns control point i
-  unsigned short* obase = reinterpret_cast<unsigned short*>(meta + kGaMaxR);  // [<= kGaMaxR + 2] first owned point of a range
-  static_assert(kGaMaxR + (kGaMaxR + 2 + 1) / 2 <= kGaObs + kGaObs / 2, "owner tables must fit the dead key/range arrays");
   const int chunk = blockIdx.x / kGaParts, half = blockIdx.x % kGaParts;
   const int c = dp.chunk_cam[chunk];
   const int cnt = min(kGaObs, dp.chunk_count[chunk] - half * kGaObs);
@@ -106,6 +106,13 @@ __global__ __launch_bounds__(kGaThreads) void k_assemble_spans(DevProblem dp, co
   const long long i0 = dp.chunk_start[chunk] + half * kGaObs;
   const long long a0 = dp.det_off[c], Mc = dp.det_off[c + 1] - a0;
   const int tid = threadIdx.x;
+#ifdef MVUS_ASM_PROBE
+  long long tp[8]; int np_ = 0; long long te[4] = {0, 0, 0, 0};
+#define MVUS_TP() do { if (np_ < 8) tp[np_++] = clock64(); } while (0)
+#else
+#define MVUS_TP() ((void)0)
+#endif
+  MVUS_TP();
   if (tid == 0) { any_s = 0; sort_s = 0; nr_s = 0; }
   const int t = tid & (kGaObs - 1);                    // detection handled while staging
   constexpr int kRowsPer = (2 * NS + 2 + 3) / 4;
@@ -152,6 +159,7 @@ __global__ __launch_bounds__(kGaThreads) void k_assemble_spans(DevProblem dp, co
   }
   lds_barrier();
   if (FUSED) kt = key[t];                                // the key of column t, for the threads that did not evaluate it
+  MVUS_TP();   // 1: staged
   if (tid < kGaObs) {
     if (g >= 0) any_s = 1;
     if (tid > 0 && kt < key[tid - 1]) sort_s = 1;
@@ -203,12 +211,15 @@ __global__ __launch_bounds__(kGaThreads) void k_assemble_spans(DevProblem dp, co
   // camera block (lower triangle) and camera gradient on the fp64 matrix cores: G = R R^T with R = [camera slots; f]
   // ((B+1) x 2*128, x rows then y rows).  For v_mfma_f64_16x16x4 the A fragment (lane l: R[l&15][k0 + (l>>4)]) IS the
   // B fragment of R^T, so one LDS read feeds both operands.  The LAST wavefront does all of it (64 MFMAs per tile pair)
-  // while the others go on to the outer products below, where it would have been idle; one atomic per entry -- all
-  // workgroups of a camera add to the same (B+1)(B+2)/2 addresses, so fewer, larger contributions matter here.
-  if (tid >= kGaThreads - 64) {
+  // while the others go on to the outer products below, where it would have been idle.
+  {
+    // every wavefront takes 1/8 of the k-steps (one wavefront doing all 64 matrix-core instructions shared its SIMD with
+    // three busy wavefronts and finished last: 13k cycles while the others needed 6k and waited) and leaves its own partial
+    // block; k_cam_block_reduce adds the 8 x (workgroups of the camera) partials
     using d4v = __attribute__((ext_vector_type(4))) double;
     constexpr int TI = (B + 1 + 15) / 16;                 // 16-row tiles of R
-    const int lane = tid & 63;
+    constexpr int kWaves = kGaThreads / 64, kStepsPerWave = (kGaObs / 4) / kWaves;
+    const int lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lk = lane >> 4;
     d4v cacc[TI][TI];
 #pragma unroll
@@ -217,20 +228,25 @@ __global__ __launch_bounds__(kGaThreads) void k_assemble_spans(DevProblem dp, co
       for (int j = 0; j < TI; ++j) cacc[i][j] = d4v{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int xy = 0; xy < 2; ++xy)
-#pragma unroll 8
-      for (int ks = 0; ks < kGaObs / 4; ++ks) {
-        const int u = ks * 4 + lk;
+#pragma unroll
+      for (int kk = 0; kk < kStepsPerWave; ++kk) {
+        const int u = (wave * kStepsPerWave + kk) * 4 + lk;
         double a[TI];
 #pragma unroll
         for (int i = 0; i < TI; ++i) {
+          // ONE unconditional LDS read per fragment (rows past B read row B and are zeroed by a select): a branch per case
+          // serialises the unrolled reads
           const int row = 16 * i + lr;
-          a[i] = row < B ? Js[(xy * NS + row) * kGaStride + u] : (row == B ? Js[(2 * NS + xy) * kGaStride + u] : 0.0);
+          const int src = row < B ? xy * NS + row : 2 * NS + xy;
+          const double v = Js[src * kGaStride + u];
+          a[i] = row <= B ? v : 0.0;
         }
 #pragma unroll
         for (int i = 0; i < TI; ++i)
 #pragma unroll
           for (int j = 0; j <= i; ++j) cacc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], a[j], cacc[i][j], 0, 0, 0);
       }
+    double* mine = ne.Apart + ((long long)blockIdx.x * kWaves + wave) * ((B + 1) * (B + 2) / 2);
 #pragma unroll
     for (int i = 0; i < TI; ++i)
 #pragma unroll
@@ -238,15 +254,11 @@ __global__ __launch_bounds__(kGaThreads) void k_assemble_spans(DevProblem dp, co
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int ra = 16 * i + lk + 4 * r, rb = 16 * j + lr;      // C/D layout: row = (lane>>4) + 4 reg, col = lane&15
-          const double v = cacc[i][j][r];
-          if (ra > B || rb > ra || rb >= B || v == 0.0) continue;
-          if (ra == B) unsafeAtomicAdd(&ne.gc[c * B + rb], v);
-          else {
-            unsafeAtomicAdd(&ne.A[((long long)c * B + ra) * B + rb], v);
-            if (ra != rb) unsafeAtomicAdd(&ne.A[((long long)c * B + rb) * B + ra], v);
-          }
+          if (ra > B || rb > ra) continue;
+          mine[ra * (ra + 1) / 2 + rb] = cacc[i][j][r];              // plain stores: no contention on the camera's few lines
         }
   }
+  MVUS_TP();   // 2: ranges (+ camera block on the last wavefront)
   const bool fast = nr <= kGaMaxR;                        // uniform
   // one register file for both roles -- E role: EA(q, k) cross block + gradient (k = B) of (range, d);
   // C role: CA(qa, w, d2) band blocks (w = qb - qa), row coordinate d
@@ -327,33 +339,50 @@ __global__ __launch_bounds__(kGaThreads) void k_assemble_spans(DevProblem dp, co
 #if defined(MVUS_ASM_STOP) && MVUS_ASM_STOP == 2
   if (acc_[0] != 12345.678) return;      // timing probe: + accumulation, no flush
 #endif
+  MVUS_TP();   // 3: accumulated
   lds_barrier();                                        // every thread holds its partials in registers: Js is dead
-  // owner tables of one flush round over ranges [r0, r0 + nb): a control point is owned by the first range of the
-  // round that reaches it; range rl owns its last min(4, rg[rl] - rg[rl-1]) points.  Returns the number of owned points.
-  auto build_owners = [&](int r0, int nb) {
-    // nb <= 85 ranges: thread t < nb owns range t; exclusive prefix sum of the owned counts over one or two wavefronts
-    const int mine = tid < nb ? (tid == 0 ? 4 : min(4, rg[r0 + tid] - rg[r0 + tid - 1])) : 0;
+  MVUS_TP();   // 4: everybody accumulated
+  // ---- owner tables of ALL flush rounds, built once ----------------------------------------------------------------
+  // A round covers kRb consecutive ranges (as many per-range partial blocks as fit the dead staging LDS).  Inside a round a
+  // control point is owned by the first range that reaches it: range t owns its last min(4, rg[t] - rg[t-1]) points (all four
+  // when it opens a round).  The thread of range t writes, for each point it owns: the control point, itself as the first
+  // reaching range, how many consecutive ranges of the round reach the point (ranges are span ordered) and the slot q2 of the
+  // point inside the first four of them -- so a flush thread reads one table entry and then its partial sums, with no chain of
+  // dependent look-ups per output (measured per workgroup of 68 ranges: 4 owner builds x 3k cycles + 2 x 2 loops x 4k cycles
+  // before; one build now).
+  constexpr int kRb = kRbE < kRbC ? kRbE : kRbC;
+  __shared__ int round_off[8];                            // first owned point of round rho; [rounds] = total
+  {
+    const int t = tid;
+    const bool has = t < nr;
+    const int rl = has ? t % kRb : 0;
+    const int mine = has ? (rl == 0 ? 4 : min(4, rg[t] - rg[t - 1])) : 0;
     int incl = mine;
     if (tid < 128) {
 #pragma unroll
       for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(incl, off, 64); if ((tid & 63) >= off) incl += o; }
-      if (tid == 63) obase[kGaMaxR + 1] = (unsigned short)incl;         // total of the first wavefront (scratch slot)
+      if (tid == 63) round_off[7] = incl;                // total of the first wavefront (scratch)
     }
     lds_barrier();
-    if (tid < nb) {
-      const int bs = incl - mine + (tid >= 64 ? (int)obase[kGaMaxR + 1] : 0);
-      obase[tid] = (unsigned short)bs;
-      if (tid == nb - 1) obase[nb] = (unsigned short)(bs + mine);
-      for (int j = 0; j < mine; ++j) own_r[bs + j] = (unsigned char)tid;
+    if (has) {
+      const int bs = incl - mine + (tid >= 64 ? round_off[7] : 0);
+      const int rend = min(nr, (t / kRb + 1) * kRb);     // one past the last range of this range's round
+      for (int j = 0; j < mine; ++j) {
+        const int ctrl = rg[t] + (4 - mine + j);
+        int cnt = 0, qp = 0;
+        while (t + cnt < rend && ctrl - rg[t + cnt] >= 0) { if (cnt < 4) qp |= (ctrl - rg[t + cnt]) << (2 * cnt); ++cnt; }
+        pt_ctrl[bs + j] = ctrl; pt_rl[bs + j] = (unsigned char)rl; pt_cnt[bs + j] = (unsigned char)cnt; pt_q[bs + j] = (unsigned char)qp;
+      }
+      if (rl == 0) round_off[t / kRb] = bs;
+      if (t == nr - 1) round_off[(nr - 1) / kRb + 1] = bs + mine;
     }
     lds_barrier();
-    return (int)obase[nb];
-  };
-  // ---- flush of the cross block + gradient, kRbE ranges per round: Ep[rl][q][3][B], Gp[rl][q][3] ----
-  for (int r0 = 0; r0 < nr; r0 += kRbE) {
-    const int nb = min(kRbE, nr - r0);
+  }
+  // ---- flush of the cross block + gradient: Ep[rl][q][3][B], Gp[rl][q][3] ----
+  for (int r0 = 0, rho = 0; r0 < nr; r0 += kRb, ++rho) {
+    const int nb = min(kRb, nr - r0);
     double* Ep = Js;
-    double* Gp = Js + kRbE * kEp;
+    double* Gp = Js + kRb * kEp;
     if (!crole && myr >= r0 && myr < r0 + nb) {
       const int rl = myr - r0;
 #pragma unroll
@@ -363,19 +392,20 @@ __global__ __launch_bounds__(kGaThreads) void k_assemble_spans(DevProblem dp, co
         Gp[(rl * 4 + q) * 3 + myd] = EA(q, B);
       }
     }
-    const int nown = build_owners(r0, nb);
+    lds_barrier();
+    const int p0 = round_off[rho], nown = round_off[rho + 1] - p0;
     constexpr int per = 3 * B + 3;                       // entries per owned control point: 3 x B cross + 3 gradient
     for (int o = tid; o < nown * per; o += kGaThreads) {
-      const int i = o / per, dk = o % per;
-      const int rl = own_r[i];
-      const int q = 4 - ((int)obase[rl + 1] - (int)obase[rl]) + (i - (int)obase[rl]);
-      const int ctrl = rg[r0 + rl] + q;
+      const int i = p0 + o / per, dk = o % per;
+      const int ctrl = pt_ctrl[i], rl = pt_rl[i], cnt = pt_cnt[i], qp = pt_q[i];
       const bool grad = dk >= 3 * B;
       double acc = 0.0;
-      for (int r2 = rl; r2 < nb; ++r2) {                 // every range of the round that reaches the control point
-        const int q2 = ctrl - rg[r0 + r2];
-        if (q2 < 0) break;
-        acc += grad ? Gp[(r2 * 4 + q2) * 3 + dk - 3 * B] : Ep[(r2 * 4 + q2) * 3 * B + dk];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)                        // the first four reaching ranges: slots from the table, reads independent
+        if (j < cnt) { const int q2 = (qp >> (2 * j)) & 3; acc += grad ? Gp[((rl + j) * 4 + q2) * 3 + dk - 3 * B] : Ep[((rl + j) * 4 + q2) * 3 * B + dk]; }
+      for (int j = 4; j < cnt; ++j) {                    // (a span cut into many pieces: rare)
+        const int q2 = ctrl - rg[r0 + rl + j];
+        acc += grad ? Gp[((rl + j) * 4 + q2) * 3 + dk - 3 * B] : Ep[((rl + j) * 4 + q2) * 3 * B + dk];
       }
       if (acc != 0.0) {
         if (grad) unsafeAtomicAdd(&ne.gs[3 * ctrl + dk - 3 * B], acc);
@@ -384,12 +414,13 @@ __global__ __launch_bounds__(kGaThreads) void k_assemble_spans(DevProblem dp, co
     }
     lds_barrier();
   }
+  MVUS_TP();   // 5: cross block flushed
 #if defined(MVUS_ASM_STOP) && MVUS_ASM_STOP == 3
   if (nr >= 0) return;      // timing probe: + cross-block flush
 #endif
-  // ---- flush of the spline band, kRbC ranges per round: Cp[rl][pair (qa, w)][3][3], pair = 4 qa - qa (qa - 1) / 2 + w ----
-  for (int r0 = 0; r0 < nr; r0 += kRbC) {
-    const int nb = min(kRbC, nr - r0);
+  // ---- flush of the spline band: Cp[rl][pair (qa, w)][3][3], pair = 4 qa - qa (qa - 1) / 2 + w ----
+  for (int r0 = 0, rho = 0; r0 < nr; r0 += kRb, ++rho) {
+    const int nb = min(kRb, nr - r0);
     double* Cp = Js;
     if (crole && myr >= r0 && myr < r0 + nb) {
       const int rl = myr - r0;
@@ -400,17 +431,18 @@ __global__ __launch_bounds__(kGaThreads) void k_assemble_spans(DevProblem dp, co
 #pragma unroll
           for (int d2 = 0; d2 < 3; ++d2) Cp[(rl * 10 + 4 * qa - qa * (qa - 1) / 2 + w) * 9 + 3 * myd + d2] = CA(qa, w, d2);
     }
-    const int nown = build_owners(r0, nb);
+    lds_barrier();
+    const int p0 = round_off[rho], nown = round_off[rho + 1] - p0;
     for (int o = tid; o < nown * 36; o += kGaThreads) {
-      const int i = o / 36, wd = o % 36, w = wd / 9, dd = wd % 9;
-      const int rl = own_r[i];
-      const int qa = 4 - ((int)obase[rl + 1] - (int)obase[rl]) + (i - (int)obase[rl]);
-      const int ctrl = rg[r0 + rl] + qa;
+      const int i = p0 + o / 36, wd = o % 36, w = wd / 9, dd = wd % 9;
+      const int ctrl = pt_ctrl[i], rl = pt_rl[i], cnt = pt_cnt[i], qp = pt_q[i];
       double acc = 0.0;
-      for (int r2 = rl; r2 < nb; ++r2) {
-        const int q2 = ctrl - rg[r0 + r2];
-        if (q2 < 0) break;
-        if (q2 + w < 4) acc += Cp[(r2 * 10 + 4 * q2 - q2 * (q2 - 1) / 2 + w) * 9 + dd];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (j < cnt) { const int q2 = (qp >> (2 * j)) & 3; if (q2 + w < 4) acc += Cp[((rl + j) * 10 + 4 * q2 - q2 * (q2 - 1) / 2 + w) * 9 + dd]; }
+      for (int j = 4; j < cnt; ++j) {
+        const int q2 = ctrl - rg[r0 + rl + j];
+        if (q2 + w < 4) acc += Cp[((rl + j) * 10 + 4 * q2 - q2 * (q2 - 1) / 2 + w) * 9 + dd];
       }
       if (acc != 0.0) unsafeAtomicAdd(&ne.Cb[((long long)ctrl * ne.W) * 9 + wd], acc);
     }
@@ -418,6 +450,54 @@ __global__ __launch_bounds__(kGaThreads) void k_assemble_spans(DevProblem dp, co
   }
 #undef EA
 #undef CA
+  MVUS_TP();   // 6: band flushed
+#ifdef MVUS_ASM_PROBE
+  if ((blockIdx.x % 997) == 5 && (tid == 0 || tid == 64 || tid == 300 || tid == kGaThreads - 64))
+    printf("blk %d tid %d nr %d: staged %lld ranges %lld accum %lld wait %lld Eflush %lld Cflush %lld | E round 0: write %lld owners %lld loop %lld barrier %lld\n", (int)blockIdx.x, tid, nr, tp[1] - tp[0], tp[2] - tp[1], tp[3] - tp[2], tp[4] - tp[3], tp[5] - tp[4], tp[6] - tp[5], te[0] - tp[4], te[1] - te[0], te[2] - te[1], te[3] - te[2]);
+#endif
+}
+
+// A[c] (both triangles) and gc[c] from the per-workgroup partial blocks of k_assemble_spans: one workgroup per camera, entry e
+// of the packed lower triangle summed over the camera's assembly workgroups in index order by four threads (quarters, then a
+// fixed combine) -- no atomics, the same bits every run.  Workgroups that had nothing to add left zeros (the buffer is
+// cleared with the rest of the normal equations).
+template <int B>
+__global__ __launch_bounds__(1024) void k_cam_block_reduce(DevProblem dp, NEView ne) {
+  constexpr int PSZ = (B + 1) * (B + 2) / 2, kLanes = PSZ <= 64 ? 64 : 256, kGroups = 1024 / kLanes;
+  __shared__ double part[kGroups][kLanes];
+  const int c = blockIdx.x;
+  constexpr int kPer = kGaParts * (kGaThreads / 64);                      // partial blocks per 256-chunk: assembly workgroups x wavefronts
+  const int w0 = dp.cam_chunk_off[c] * kPer, w1 = dp.cam_chunk_off[c + 1] * kPer;
+  const int k = threadIdx.x % kLanes, grp = threadIdx.x / kLanes;
+  // group grp adds the partial blocks w0 + grp, w0 + grp + kGroups, ... (independent loads, four in flight), then the groups are
+  // added in index order: a fixed summation tree
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  if (k < PSZ) {
+    int w = w0 + grp;
+    for (; w + 3 * kGroups < w1; w += 4 * kGroups) {
+      a0 += ne.Apart[(long long)w * PSZ + k];
+      a1 += ne.Apart[(long long)(w + kGroups) * PSZ + k];
+      a2 += ne.Apart[(long long)(w + 2 * kGroups) * PSZ + k];
+      a3 += ne.Apart[(long long)(w + 3 * kGroups) * PSZ + k];
+    }
+    for (; w < w1; w += kGroups) a0 += ne.Apart[(long long)w * PSZ + k];
+  }
+  part[grp][k] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (threadIdx.x < PSZ) {
+    double v = 0.0;
+#pragma unroll
+    for (int g = 0; g < kGroups; ++g) v += part[g][threadIdx.x];
+    const int kk = threadIdx.x;
+    int ra = 0;
+    while ((ra + 1) * (ra + 2) / 2 <= kk) ++ra;
+    const int rb = kk - ra * (ra + 1) / 2;
+    if (ra == B) { if (rb < B) ne.gc[c * B + rb] += v; }
+    else {
+      ne.A[((long long)c * B + ra) * B + rb] += v;
+      if (ra != rb) ne.A[((long long)c * B + rb) * B + ra] += v;
+    }
+  }
 }
 
 // motion-regulariser rows: spline block and gradient only (the rows do not depend on camera parameters).
@@ -510,9 +590,8 @@ __global__ __launch_bounds__(kThreads) void k_assemble_motion(DevProblem dp, con
 }
 
 // D = diag(H) in x order (0 -> 1 so that unused columns stay put), and g in x order
-__global__ void k_ne_diag_grad(DevProblem dp, NEView ne, int raw, double* __restrict__ D, double* __restrict__ gx) {
+__device__ __forceinline__ void ne_diag_grad_entry(const DevProblem& dp, const NEView& ne, int raw, int idx, double* __restrict__ D, double* __restrict__ gx) {
   // raw (time shards): this rank's PARTIAL diagonal, to be summed over the ranks before k_diag_fix replaces zeros by 1
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx < ne.CB) {
     const int c = idx / ne.B, k = idx % ne.B;
     const double h = ne.A[((long long)c * ne.B + k) * ne.B + k];
@@ -527,6 +606,9 @@ __global__ void k_ne_diag_grad(DevProblem dp, NEView ne, int raw, double* __rest
     D[col] = (raw || h > 0.0) ? h : 1.0;
     gx[col] = ne.gs[r];
   }
+}
+__global__ void k_ne_diag_grad(DevProblem dp, NEView ne, int raw, double* __restrict__ D, double* __restrict__ gx) {
+  ne_diag_grad_entry(dp, ne, raw, blockIdx.x * blockDim.x + threadIdx.x, D, gx);
 }
 __global__ void k_diag_fix(long long n, double* __restrict__ D) {
   const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
@@ -571,9 +653,14 @@ __global__ void k_sum_slabs(long long count, int nslab, const double* __restrict
 }
 
 // scalar lower band of (C + lambda D_s): Lb[i][j] = (C + lambda D)(i, i-j), j = 0..BW
-__global__ void k_band_pack(NEView ne, double lambda, int BW, double* __restrict__ Lb, int* __restrict__ fail) {
+__device__ __forceinline__ void ne_diag_grad_entry(const DevProblem& dp, const NEView& ne, int raw, int idx, double* __restrict__ D, double* __restrict__ gx);
+// with_diag: the launch also writes D = diag(H) and g in x order (k_ne_diag_grad's work, folded in: one launch less per
+// linearisation; the first solve after an assembly carries it)
+__global__ void k_band_pack(NEView ne, double lambda, int BW, double* __restrict__ Lb, int* __restrict__ fail, DevProblem dp, int with_diag,
+                            double* __restrict__ D, double* __restrict__ gx) {
   const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (idx == 0) fail[0] = 0;              // first kernel of a solve: clears the failure flag the later ones may raise
+  if (with_diag && idx < ne.CB + ne.N3) ne_diag_grad_entry(dp, ne, 0, (int)idx, D, gx);
   const long long total = (long long)ne.N3 * (BW + 1);
   if (idx >= total) return;
   const int i = (int)(idx / (BW + 1)), j = (int)(idx % (BW + 1));
@@ -1476,8 +1563,9 @@ struct HipSchur {
   // slice of the spline system held by this handle (everything unless it is a time shard)
   bool shard = false;
   int Ntot = 0, own_lo = 0, own_hi = 0;        // owned control points, LOCAL indices (slice starts at ne.row0)
-  size_t sep_count = 0, halo_count = 0, nAg = 0;
+  size_t sep_count = 0, halo_count = 0, nAg = 0, n_apart = 0;
   int nbound = 0;
+  bool diag_pending = false;                   // D / g in x order still to be written (folded into the next k_band_pack)
   int* halo_tables = nullptr;                  // [nbound] cut, [nbound] index in the packed buffer
 
   explicit HipSchur(BE& b) : be(b) {
@@ -1518,8 +1606,10 @@ struct HipSchur {
     // time shards: diag(H) and g ride in the summed head too ([A | gc | halo | D | g])
     const size_t ndg = shard ? 2 * (size_t)hp.n : 0;
     ne_count = nA + ngc + halo_count + ndg + nCb + ngs + nEt;
-    NE = be.alloc(ne_count);
-    ne.A = NE; ne.gc = ne.A + nA; ne.Cb = ne.gc + ngc + halo_count + ndg; ne.gs = ne.Cb + nCb; ne.Et = ne.gs + ngs;
+    // + the per-workgroup camera-block partials of the assembly, behind the blocks (cleared with them, never summed over ranks)
+    n_apart = (size_t)kGaParts * (kGaThreads / 64) * std::max<size_t>(hp.chunks.size(), 1) * (size_t)((ne.B + 1) * (ne.B + 2) / 2);
+    NE = be.alloc(ne_count + n_apart);
+    ne.A = NE; ne.gc = ne.A + nA; ne.Cb = ne.gc + ngc + halo_count + ndg; ne.gs = ne.Cb + nCb; ne.Et = ne.gs + ngs; ne.Apart = ne.Et + nEt;
     Lb = be.alloc((size_t)ne.N3 * (BW + 1));
     Z = be.alloc((size_t)ne.N3 * ncols);
     Erm = be.alloc((size_t)ne.N3 * ne.CB);
@@ -1607,18 +1697,22 @@ struct HipSchur {
   // x_fused != nullptr: the detection rows' Jacobian is evaluated inside the assembly kernel at x_fused (no J in memory);
   // the motion rows (O(T), tiny) still go through k_motion
   void assemble_local(const double* f_dev, const double* x_fused = nullptr) {
-    MVUS_HIP(hipMemsetAsync(NE, 0, ne_count * sizeof(double), be.stream));
+    be.fill(NE, 0.0, (int64_t)(ne_count + n_apart));      // one launch (hipMemsetAsync splits 36 MB into two fill kernels)
     if (be.dp.n_chunks > 0) {
       const int nc = be.dp.n_chunks;
       const dim3 g(kGaParts * nc), b(kGaThreads);
       if (x_fused) {
-        hipLaunchKernelGGL(k_cam_states, dim3((be.hp.C + 63) / 64), dim3(64), 0, be.stream, be.dp, x_fused, be.cams);
+        be.ensure_cams(x_fused);
         if (be.hp.calib) hipLaunchKernelGGL((k_assemble_spans<30, true>), g, b, 0, be.stream, be.dp, (const double*)nullptr, (const int32_t*)nullptr, f_dev, ne, be.cams, x_fused);
         else hipLaunchKernelGGL((k_assemble_spans<21, true>), g, b, 0, be.stream, be.dp, (const double*)nullptr, (const int32_t*)nullptr, f_dev, ne, be.cams, x_fused);
       } else {
         if (be.hp.calib) hipLaunchKernelGGL((k_assemble_spans<30, false>), g, b, 0, be.stream, be.dp, be.J, be.span, f_dev, ne, be.cams, (const double*)nullptr);
         else hipLaunchKernelGGL((k_assemble_spans<21, false>), g, b, 0, be.stream, be.dp, be.J, be.span, f_dev, ne, be.cams, (const double*)nullptr);
       }
+    }
+    if (be.dp.n_chunks > 0) {
+      if (be.hp.calib) hipLaunchKernelGGL(k_cam_block_reduce<18>, dim3(be.hp.C), dim3(1024), 0, be.stream, be.dp, ne);
+      else hipLaunchKernelGGL(k_cam_block_reduce<9>, dim3(be.hp.C), dim3(1024), 0, be.stream, be.dp, ne);
     }
     if (be.hp.T > 0)
       hipLaunchKernelGGL(k_assemble_motion, dim3((be.hp.T + kThreads - 1) / kThreads), dim3(kThreads), 0, be.stream, be.dp, be.mJ, be.mctrl,
@@ -1651,13 +1745,20 @@ struct HipSchur {
       hipLaunchKernelGGL(k_diag_fix, dim3((unsigned)((be.hp.n + 255) / 256)), dim3(256), 0, be.stream, (long long)be.hp.n, D);
     } else {
       be.reduce(NE, ne_count);          // observation shards: one sum-all-reduce of the packed normal-equation blocks per iteration
-      hipLaunchKernelGGL(k_ne_diag_grad, dim3((tot + 255) / 256), dim3(256), 0, be.stream, be.dp, ne, 0, D, gx);
+      diag_pending = true;              // D and g (x order) are written by the next solve's first kernel, or by flush_diag()
     }
     MVUS_HIP(hipGetLastError());
   }
 
-  const double* grad_ptr() const { return gx; }
-  const double* diag_ptr() const { return D; }
+  void flush_diag() {
+    if (!diag_pending) return;
+    const int tot = ne.CB + ne.N3;
+    hipLaunchKernelGGL(k_ne_diag_grad, dim3((tot + 255) / 256), dim3(256), 0, be.stream, be.dp, ne, 0, D, gx);
+    diag_pending = false;
+  }
+  // valid once the stream reaches this point: written by the solve that follows an assembly, or flushed here when none has run
+  const double* grad_ptr() { flush_diag(); return gx; }
+  const double* diag_ptr() { flush_diag(); return D; }
   const double* step_ptr() const { return px; }
   const int* fail_ptr() const { return fail; }
   bool solve_ok() const {                 // valid after the stream has been synchronised (the driver's fetch)
@@ -1690,7 +1791,8 @@ struct HipSchur {
 
   void solve_async(double lambda) {
     const long long nLb = (long long)ne.N3 * (BW + 1);
-    hipLaunchKernelGGL(k_band_pack, dim3((unsigned)((nLb + 255) / 256)), dim3(256), 0, be.stream, ne, lambda, BW, Lb, fail);
+    hipLaunchKernelGGL(k_band_pack, dim3((unsigned)((nLb + 255) / 256)), dim3(256), 0, be.stream, ne, lambda, BW, Lb, fail, be.dp, (int)diag_pending, D, gx);
+    diag_pending = false;
     const long long nZ = (long long)ne.N3 * ncols;
     hipLaunchKernelGGL(k_build_rhs, dim3((unsigned)((nZ + 255) / 256)), dim3(256), 0, be.stream, ne, ncols, Z, Erm);
     if (BW == 11) band_chain<11, 9>(); else band_chain<17, 15>();
@@ -1742,6 +1844,7 @@ int schur_export(BE& be, HipSchur<BE>& sc, double* g, double* JtJ_cam, double* b
   if (W_out) *W_out = sc.ne.W;
   if (!g && !JtJ_cam && !band && !cross) return MVUS_OK;
   sc.assemble(be, be.f_cur);
+  sc.flush_diag();
   const NEView& ne = sc.ne;
   if (g) be.download(g, sc.gx, be.hp.n);
   if (JtJ_cam) be.download(JtJ_cam, ne.A, (int64_t)ne.C * ne.B * ne.B);

@@ -174,6 +174,7 @@ class Problem:
     motion_type: str = 'F'
     motion_weights: float = 1.0
     rs_bounds: bool = False
+    opt_sync: bool = True         # settings['opt_sync'] (absent -> the except branch, common.py:512-515): False removes alpha, beta from the pattern
 
     @property
     def C(self):
@@ -368,7 +369,7 @@ def jac_pattern(prob, x0, near=3):
         M = dg.shape[1]
         r_cam, c_cam = [], []
         vis_rows = np.nonzero(visible)[0]
-        cam_cols = [i, i + C] + ([i + 2 * C] if prob.rs else []) + list(range(3 * C + i * P, 3 * C + (i + 1) * P))
+        cam_cols = ([i, i + C] if prob.opt_sync else []) + ([i + 2 * C] if prob.rs else []) + list(range(3 * C + i * P, 3 * C + (i + 1) * P))
         for cc in cam_cols:
             r_cam.append(vis_rows)
             c_cam.append(np.full(vis_rows.size, cc))
@@ -486,6 +487,7 @@ def problem_from_scene(scene, num_cam=None, rs=None, motion_reg=None, motion_wei
         motion_type=st.get('motion_type', 'F'),
         motion_weights=float(st.get('motion_weights', 1.0) if motion_weights is None else motion_weights),
         rs_bounds=bool(st.get('rs_bounds', False) if rs_bounds is None else rs_bounds),
+        opt_sync=bool(st.get('opt_sync', True)),
     )
     x0 = pack_x(prob, scene.alpha[:C], scene.beta[:C], scene.rs[:C],
                 [scene.cameras[i] for i in range(C)], [t[1] for t in scene.tck])

@@ -184,3 +184,32 @@ def test_converged_second_ba_analytic_modes_go_lower():
         assert ref_rmse - 2e-2 < rmse < ref_rmse - 5e-3                            # measured: 0.6886 / 0.6863 against 0.6962
         keep = np.concatenate(orc.outlier_keep_mask(oprob, x, float(g['thres_outlier']))).astype(np.uint8)
         assert np.array_equal(keep, g['ba2_200_keep'])
+
+
+def test_opt_sync_off_freezes_alpha_and_beta():
+    """settings['opt_sync'] = False (common.py:512-515): alpha and beta leave the matrix, so scipy's finite-difference
+    Jacobian has no entries for them and they never move.  Same in every Jacobian mode here, and the matrix equals the
+    oracle's restatement of jac_BA."""
+    scene, g = load_case('rs_F_2int_3cam')
+    scene.settings['opt_sync'] = False
+    prob, x0 = mp.problem_from_scene(scene)
+    oprob, _ = orc.problem_from_scene(scene)
+    assert not prob.opt_sync and not oprob.opt_sync
+    C = prob.C
+    h = HostHandle(prob)
+    pat, groups, ng = h.prepare_fd(x0)
+    A = pattern.reference_pattern(prob, pat, h.motion_pattern())
+    assert A[:, :2 * C].nnz == 0
+    if tie_order_is_the_recorded_one():
+        assert (A != orc.jac_pattern(oprob, x0)).nnz == 0
+    for jm in (_lib.JAC_FD, _lib.JAC_PATTERN, _lib.JAC_ANALYTIC):
+        f, J = h.dense_jacobian(x0 + g['delta'], jm)
+        assert not J[:, :2 * C].any()
+        x, res, _ = HostHandle(prob).solve(x0, _lib.default_opts(_lib.SOLVER_TRF_LSMR, jm, 6))
+        np.testing.assert_array_equal(x[:2 * C], x0[:2 * C])
+        assert res.cost < 0.5 * float(f @ f) * 1.5
+    x, res, f_lm = HostHandle(prob).solve(x0, _lib.default_opts(_lib.SOLVER_LM_SCHUR, _lib.JAC_ANALYTIC, 14))      # (the first five trials are rejected)
+    np.testing.assert_array_equal(x[:2 * C], x0[:2 * C])
+    assert res.cost < res.initial_cost and not np.array_equal(x, x0)
+    ref = orc.solve(oprob, x0, max_iter=6)                       # the reference's scipy call: alpha, beta stay put too
+    np.testing.assert_array_equal(ref.x[:2 * C], x0[:2 * C])

@@ -440,3 +440,21 @@ def test_remove_outliers_in_place_equals_fresh_handle(BAHandle, name):
         # a second pass removes nothing new at the same x and threshold... unless the fit moved: here x is unchanged
         keep2 = h.remove_outliers(x, thres)
         assert keep2.all()
+
+
+def test_opt_sync_off_freezes_alpha_and_beta(BAHandle):
+    """settings['opt_sync'] = False (common.py:512-515) on the GPU: no Jacobian entries for alpha / beta in any mode, and
+    both solvers leave them where they were."""
+    scene, g = load_case('rs_F_2int_3cam')
+    scene.settings['opt_sync'] = False
+    prob, x0 = mp.problem_from_scene(scene)
+    C = prob.C
+    with BAHandle(prob) as h:
+        for mode in (_lib.JAC_ANALYTIC, _lib.JAC_PATTERN):
+            h.prepare_pattern(x0)
+            f, J, ctrl = h.residual_jacobian(x0 + g['delta'], mode)
+            assert not J[:, :2, :].any()                                   # slots 0, 1 = alpha, beta
+        for solver, jm in ((_lib.SOLVER_TRF_LSMR, _lib.JAC_FD), (_lib.SOLVER_TRF_LSMR, _lib.JAC_PATTERN), (_lib.SOLVER_LM_SCHUR, _lib.JAC_ANALYTIC)):
+            r = h.solve(x0, solver=solver, jac_mode=jm, max_nfev=14)      # (LM rejects its first five trials from this start)
+            np.testing.assert_array_equal(r.x[:2 * C], x0[:2 * C])
+            assert r.cost < r.initial_cost
