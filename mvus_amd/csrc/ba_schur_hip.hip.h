@@ -1438,7 +1438,9 @@ __global__ __launch_bounds__(kNB * kNB) void k_schur_finish(NEView ne, int ncols
 // After the last panel the rhs row holds x.  Rows above the panel are never touched again, the trailing block stays the
 // (symmetric positive definite) Schur complement, so P_k = L^-T L^-1 comes from a Cholesky of the 32x32 pivot block done
 // in registers by ONE wavefront of the workgroup that produced that block (row per lane, pivot column by v_readlane,
-// 1/sqrt(pivot) by v_rsq_f64 + 2 Newton steps; lanes 32..63 carry the identity and end up holding L^-T).  Each step
+// 1/sqrt(pivot) by v_rsq_f64 + 2 Newton steps; lanes 32..63 carry the identity and end up holding L^-T).  Measured (cycle
+// counters, MVUS_GJ_PROBE): 22k cycles = 9 us per panel for this wavefront, 13k for the tile update before it; an LDS-broadcast
+// variant of the column exchange did not unroll under the 1024-thread register budget and was far slower -- kept as is.  Each step
 // reads `src` and writes `dst` (ping-pong), so all tiles of a step are independent.  Against a blocked Cholesky this
 // trades ~3x the (tiny, perfectly parallel) tile flops for the removal of the sequential back substitution (44 us at
 // nn = 288: nine dependent round trips to data other XCDs wrote).  The critical path per panel is the one wavefront:
@@ -1479,6 +1481,9 @@ __device__ __forceinline__ void potrf_inv_wave(double (*Dm)[kNB + 1], double* __
 __global__ __launch_bounds__(1024) void k_gj_step(int nn, int kb, const double* __restrict__ src, double* __restrict__ dst,
                                                   double* __restrict__ Linv, int* __restrict__ fail, double* __restrict__ pc) {
   __shared__ double Ai[kNB][kNB + 1], Li[kNB][kNB + 1], Pk[kNB][kNB + 1], Q[kNB][kNB + 1], Bk[kNB][kNB + 1];
+#ifdef MVUS_GJ_PROBE
+  const long long t0_ = clock64();
+#endif
   const int nb = min(kNB, nn - kb), base = kb + nb;
   const int i0 = base + blockIdx.x * kNB, j0 = blockIdx.y * kNB;
   const bool pivcol = j0 == kb;                              // this tile is column block k: it stores Q_I
@@ -1518,10 +1523,16 @@ __global__ __launch_bounds__(1024) void k_gj_step(int nn, int kb, const double* 
   // the tile holding the next pivot block factorises it
   const int nb2 = min(kNB, nn - base);
   if (blockIdx.x != 0 || j0 != base || nb2 <= 0) return;
+#ifdef MVUS_GJ_PROBE
+  const long long t1_ = clock64();
+#endif
   __syncthreads();                                           // Ai is reused as the block to factorise
   Ai[r][c] = (r < nb2 && c < nb2 && c <= r) ? v : ((r < nb2 && c < nb2) ? 0.0 : (r == c ? 1.0 : 0.0));
   __syncthreads();
   if (threadIdx.x < 64) potrf_inv_wave(Ai, Linv + (long long)(base / kNB) * kNB * kNB, fail);
+#ifdef MVUS_GJ_PROBE
+  if (threadIdx.x == 0 && kb == 0) printf("gj panel 0: tile %lld cycles, potrf %lld cycles\n", t1_ - t0_, clock64() - t1_);
+#endif
 }
 
 // p (x order) from p_c and p_s = -(z_g + Z_E p_c)
