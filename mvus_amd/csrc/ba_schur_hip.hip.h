@@ -656,9 +656,8 @@ __global__ void k_sum_slabs(long long count, int nslab, const double* __restrict
 __device__ __forceinline__ void ne_diag_grad_entry(const DevProblem& dp, const NEView& ne, int raw, int idx, double* __restrict__ D, double* __restrict__ gx);
 // with_diag: the launch also writes D = diag(H) and g in x order (k_ne_diag_grad's work, folded in: one launch less per
 // linearisation; the first solve after an assembly carries it)
-__global__ void k_band_pack(NEView ne, double lambda, int BW, double* __restrict__ Lb, int* __restrict__ fail, DevProblem dp, int with_diag,
-                            double* __restrict__ D, double* __restrict__ gx) {
-  const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+__device__ __forceinline__ void band_pack_entry(const NEView& ne, double lambda, int BW, double* __restrict__ Lb, int* __restrict__ fail, const DevProblem& dp,
+                                                int with_diag, double* __restrict__ D, double* __restrict__ gx, long long idx) {
   if (idx == 0) fail[0] = 0;              // first kernel of a solve: clears the failure flag the later ones may raise
   if (with_diag && idx < ne.CB + ne.N3) ne_diag_grad_entry(dp, ne, 0, (int)idx, D, gx);
   const long long total = (long long)ne.N3 * (BW + 1);
@@ -673,6 +672,10 @@ __global__ void k_band_pack(NEView ne, double lambda, int BW, double* __restrict
     if (j == 0) { const double h = v; v = h + lambda * (h > 0.0 ? h : 1.0); }
   }
   Lb[idx] = v;
+}
+__global__ void k_band_pack(NEView ne, double lambda, int BW, double* __restrict__ Lb, int* __restrict__ fail, DevProblem dp, int with_diag,
+                            double* __restrict__ D, double* __restrict__ gx) {
+  band_pack_entry(ne, lambda, BW, Lb, fail, dp, with_diag, D, gx, blockIdx.x * (long long)blockDim.x + threadIdx.x);
 }
 
 // ---- partitioned (separator-based) parallel solve of the banded spline system ---------------------------
@@ -1079,7 +1082,10 @@ __device__ __forceinline__ bcr_d4 bcr_mma(const BcrFrag<S3>& f, bcr_d4 acc) {
   return acc;
 }
 
-constexpr int kBcrWaves = 8;     // 512 threads: up to 256 VGPRs each, the prefetched operand fragments need them
+#ifndef MVUS_BCR_WAVES
+#define MVUS_BCR_WAVES 8
+#endif
+constexpr int kBcrWaves = MVUS_BCR_WAVES;     // wavefronts of the one workgroup that factorises the separator system
 template <int S3>
 __global__ __launch_bounds__(kBcrWaves * 64) void k_sep_bcr_factor(PartView pv, int* __restrict__ fail) {
   // One workgroup of kBcrWaves wavefronts, three phases per level, all blocks in global memory (L2 resident):
@@ -1292,8 +1298,12 @@ __global__ __launch_bounds__(64) void k_part_back(PartView pv, int ncols, double
 }
 
 // Z[3N][ncols] = [E^T | gs] and Erm[3N][CB] = E^T (row-major copies of the camera-major cross block)
-__global__ void k_build_rhs(NEView ne, int ncols, double* __restrict__ Z, double* __restrict__ Erm) {
+// The same launch also packs the damped band (band_pack_entry: the two are independent element-wise passes over the assembled
+// blocks, and every launch costs ~4.7 us before it does anything).
+__global__ void k_build_rhs(NEView ne, int ncols, double* __restrict__ Z, double* __restrict__ Erm, double lambda, int BW, double* __restrict__ Lb,
+                            int* __restrict__ fail, DevProblem dp, int with_diag, double* __restrict__ D, double* __restrict__ gx) {
   const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  band_pack_entry(ne, lambda, BW, Lb, fail, dp, with_diag, D, gx, idx);
   if (idx >= (long long)ne.N3 * ncols) return;
   const int r = (int)(idx / ncols), cidx = (int)(idx % ncols);
   if (cidx < ne.CB) {
@@ -1802,10 +1812,10 @@ struct HipSchur {
 
   void solve_async(double lambda) {
     const long long nLb = (long long)ne.N3 * (BW + 1);
-    hipLaunchKernelGGL(k_band_pack, dim3((unsigned)((nLb + 255) / 256)), dim3(256), 0, be.stream, ne, lambda, BW, Lb, fail, be.dp, (int)diag_pending, D, gx);
+    const long long nZ = (long long)ne.N3 * ncols;          // >= nLb: one launch covers both passes
+    hipLaunchKernelGGL(k_build_rhs, dim3((unsigned)((std::max(nZ, nLb) + 255) / 256)), dim3(256), 0, be.stream, ne, ncols, Z, Erm, lambda, BW, Lb, fail, be.dp,
+                       (int)diag_pending, D, gx);
     diag_pending = false;
-    const long long nZ = (long long)ne.N3 * ncols;
-    hipLaunchKernelGGL(k_build_rhs, dim3((unsigned)((nZ + 255) / 256)), dim3(256), 0, be.stream, ne, ncols, Z, Erm);
     if (BW == 11) band_chain<11, 9>(); else band_chain<17, 15>();
     const int row_lo = 3 * own_lo, row_hi = 3 * own_hi;
     {
