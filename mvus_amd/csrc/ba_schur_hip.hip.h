@@ -14,7 +14,7 @@
 // N here is the number of control points of the slice this handle holds: all of them, or -- time shard -- the owned
 // range plus a halo on each side.
 //
-// Solve chain (solve_async): k_band_pack, k_build_rhs -> interiors (k_part_cholesky, k_part_solve) -> separator system
+// Solve chain (solve_async): k_build_rhs (right-hand sides + damped band pack + diag/gradient in x order) -> interiors (k_part_cholesky, k_part_solve) -> separator system
 // (k_part_reduce, k_sep_bcr_factor, k_sep_bcr_rhs | sequential k_sep_factor, k_sep_rhs) -> k_part_back -> Schur product
 // on the fp64 matrix cores (k_schur_gemm, k_schur_finish) -> block Gauss-Jordan on the reduced camera system (k_gj_step)
 // -> k_back_substitute.
@@ -672,10 +672,6 @@ __device__ __forceinline__ void band_pack_entry(const NEView& ne, double lambda,
     if (j == 0) { const double h = v; v = h + lambda * (h > 0.0 ? h : 1.0); }
   }
   Lb[idx] = v;
-}
-__global__ void k_band_pack(NEView ne, double lambda, int BW, double* __restrict__ Lb, int* __restrict__ fail, DevProblem dp, int with_diag,
-                            double* __restrict__ D, double* __restrict__ gx) {
-  band_pack_entry(ne, lambda, BW, Lb, fail, dp, with_diag, D, gx, blockIdx.x * (long long)blockDim.x + threadIdx.x);
 }
 
 // ---- partitioned (separator-based) parallel solve of the banded spline system ---------------------------
@@ -1586,7 +1582,7 @@ struct HipSchur {
   int Ntot = 0, own_lo = 0, own_hi = 0;        // owned control points, LOCAL indices (slice starts at ne.row0)
   size_t sep_count = 0, halo_count = 0, nAg = 0, n_apart = 0;
   int nbound = 0;
-  bool diag_pending = false;                   // D / g in x order still to be written (folded into the next k_band_pack)
+  bool diag_pending = false;                   // D / g in x order still to be written (folded into the next k_build_rhs)
   int* halo_tables = nullptr;                  // [nbound] cut, [nbound] index in the packed buffer
 
   explicit HipSchur(BE& b) : be(b) {
