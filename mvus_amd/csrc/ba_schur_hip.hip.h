@@ -15,7 +15,7 @@
 // range plus a halo on each side.
 //
 // Solve chain (solve_async): k_build_rhs (right-hand sides + damped band pack + diag/gradient in x order) -> interiors (k_part_cholesky, k_part_solve) -> separator system
-// (k_part_reduce, k_sep_bcr_factor, k_sep_bcr_rhs | sequential k_sep_factor, k_sep_rhs) -> k_part_back -> Schur product
+// (k_part_reduce, k_sep_bcr_level / k_sep_bcr_tail, k_sep_bcr_rhs | sequential k_sep_factor, k_sep_rhs) -> k_part_back -> Schur product
 // on the fp64 matrix cores (k_schur_gemm, k_schur_finish) -> block Gauss-Jordan on the reduced camera system (k_gj_step)
 // -> k_back_substitute.
 #pragma once
@@ -1049,10 +1049,10 @@ __global__ __launch_bounds__(64) void k_sep_rhs(PartView pv, int ncols) {
 // ceil(log2(P)) of them: at stride h the nodes j with (j+1)/h odd are eliminated, x_j = D_j^-1 (r_j - A_j x_{j-h} -
 // C_j x_{j+h}), and folded into their neighbours at distance h, which form the next (half as long) block-tridiagonal
 // system.  Every Schur complement of an SPD matrix is SPD, so no pivoting is needed.  Stored per node, at the level
-// that eliminates it: Dinv_j (in T), Ha_j = Dinv_j A_j, Hc_j = Dinv_j C_j; only the coupling to the right neighbour,
+// that eliminates it: Dinv_j (in U2), Ha_j = Dinv_j A_j, Hc_j = Dinv_j C_j; only the coupling to the right neighbour,
 // C_j, is carried through the levels (A_j = C_{j-h}^T).
 //   survivors i:  D_i -= C_{i-h}^T Hc_{i-h} + C_i Ha_{i+h},   C_i <- -C_i Hc_{i+h},   r_i -= Hc_{i-h}^T r_{i-h} + Ha_{i+h}^T r_{i+h}
-// k_sep_bcr_factor: the matrix part, one workgroup (all levels, blocks stay in L2/LDS);
+// k_sep_bcr_level / k_sep_bcr_tail: the matrix part, a wavefront per survivor (bcr_survivor below);
 // k_sep_bcr_rhs: the right-hand sides, kBcrCols columns per workgroup staged in LDS through all levels and back.
 // One S3 x S3 product on the fp64 matrix cores, one wavefront: acc += op(A) op(B), the blocks zero-padded to 16 x 16.
 // ta: A is read transposed; tb: B is read transposed.  Fragment layout of v_mfma_f64_16x16x4: lane l holds
@@ -1079,112 +1079,163 @@ __device__ __forceinline__ bcr_d4 bcr_mma(const BcrFrag<S3>& f, bcr_d4 acc) {
 }
 
 #ifndef MVUS_BCR_WAVES
-#define MVUS_BCR_WAVES 8
+#define MVUS_BCR_WAVES 16
 #endif
-constexpr int kBcrWaves = MVUS_BCR_WAVES;     // wavefronts of the one workgroup that factorises the separator system
+#ifndef MVUS_BCR_TAIL_NS
+#define MVUS_BCR_TAIL_NS 16
+#endif
+constexpr int kBcrWaves = MVUS_BCR_WAVES;      // wavefronts of the one workgroup that runs the last levels (S3 = 15: half, LDS)
+constexpr int kBcrTailNs = MVUS_BCR_TAIL_NS;   // levels with more survivors than this get a launch of their own (one wavefront per survivor)
+
+__device__ __forceinline__ void lds_wave_sync() {      // orders the LDS traffic of ONE wavefront (writes of some lanes read by others)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+}
+
+// One survivor of one level, by ONE wavefront and without any exchange with other wavefronts: the survivor i = 2h(s+1)-1
+// inverts the diagonal blocks of BOTH eliminated neighbours jL = i-h and jR = i+h itself (its neighbours two places on
+// do the same work again -- 2x redundant and free, the level is latency bound), forms Hc_jL, Ha_jR, Hc_jR on the matrix
+// cores and applies them to its own D_i and C_i, in place: at one level D_i and C_i are touched by this wavefront only,
+// the blocks of eliminated nodes are only read.  The inverses therefore go to a buffer of their own (U2), not over T.
+// Stored for k_sep_bcr_rhs: Dinv_j, Ha_j, Hc_j of jR (and of jL for the first survivor, whose left neighbour nobody else
+// owns).  s = 0 with no survivor at all is the last level: the one remaining node is inverted.
+// w: 3 * S3 * S3 doubles of LDS private to the wavefront.
 template <int S3>
-__global__ __launch_bounds__(kBcrWaves * 64) void k_sep_bcr_factor(PartView pv, int* __restrict__ fail) {
-  // One workgroup of kBcrWaves wavefronts, three phases per level, all blocks in global memory (L2 resident):
-  //   1. inversion of the eliminated nodes' diagonal blocks: 64/S3 nodes per wavefront, a block row per lane, the
-  //      pivot row of each Gauss-Jordan step broadcast with shuffles -- no workgroup barrier inside;
-  //   2. Ha_j = Dinv_j C_{j-h}^T and Hc_j = Dinv_j C_j, 3. the survivors' D_i and C_i: one matrix-core product
-  //      chain per wavefront, the operands of kTb products fetched together to overlap their latency.
-  constexpr int SS = S3 * S3, NPW = 64 / S3, kTb = 4;
-  const int m = pv.m, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int lr = lane & 15, lk = lane >> 4;
-  double* Ccur = pv.U;
-  double* Cnxt = pv.U2;
-  for (int h = 1; h <= m; h <<= 1) {
-    const int ne = (m / h + 1) / 2, ns = m / (2 * h);
-    // ---- 1. Dinv_j (in place in T) ----
-    for (int nb0 = wave * NPW; nb0 < ne; nb0 += kBcrWaves * NPW) {
-      const int nl = lane / S3, a = lane % S3;
-      const bool act = nl < NPW && nb0 + nl < ne;
-      const int j = act ? h * (2 * (nb0 + nl) + 1) - 1 : 0;
-      double row[S3];
+__device__ __forceinline__ void bcr_survivor(const PartView& pv, int h, int s, double* __restrict__ w, int* __restrict__ fail) {
+  constexpr int SS = S3 * S3, KS = (S3 + 3) / 4;
+  const int m = pv.m, lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
+  const int i = 2 * h * (s + 1) - 1, jL = i - h, jR = i + h;
+  const bool has_i = i < m, right = jR < m, right2 = jR + h < m;
+  double* __restrict__ Cc = pv.U;
+  // ---- all global operands, issued together ----
+  const int nl = lane / S3, a = lane % S3;
+  const bool act = nl == 0 || (nl == 1 && right);
+  const double* Tsrc = pv.T + (long long)(nl == 0 ? jL : (right ? jR : 0)) * SS + a * S3;
+  double row[S3];
 #pragma unroll
-      for (int b = 0; b < S3; ++b) row[b] = act ? pv.T[(long long)j * SS + a * S3 + b] : (a == b ? 1.0 : 0.0);
+  for (int b = 0; b < S3; ++b) row[b] = act ? Tsrc[b] : (a == b ? 1.0 : 0.0);
+  double cL[KS], ci[KS], cR[KS], ti[4];
 #pragma unroll
-      for (int k = 0; k < S3; ++k) {
-        const int src = (nl < NPW ? nl : 0) * S3 + k;     // lane holding the pivot row of this lane's node
-        double pr[S3];
+  for (int s_ = 0; s_ < KS; ++s_) {
+    const int k = 4 * s_ + lk;
+    const bool ok = lr < S3 && k < S3;
+    cL[s_] = (ok && has_i) ? Cc[(long long)jL * SS + k * S3 + lr] : 0.0;        // C_jL[k][lr]: B operand of Hc_jL, A operand (transposed) of the D update
+    ci[s_] = (ok && right) ? Cc[(long long)i * SS + lr * S3 + k] : 0.0;         // C_i[lr][k]: B operand (transposed) of Ha_jR, A operand of both updates
+    cR[s_] = (ok && right2) ? Cc[(long long)jR * SS + k * S3 + lr] : 0.0;       // C_jR[k][lr]
+  }
 #pragma unroll
-        for (int b = 0; b < S3; ++b) pr[b] = __shfl(row[b], src, 64);
-        double piv = pr[k];
-        if (!(piv > 0.0)) { if (act) fail[0] = 3; piv = 1.0; }
-        double ip = __builtin_amdgcn_rcp(piv);
-        ip = ip * (2.0 - piv * ip);
-        ip = ip * (2.0 - piv * ip);
-        if (a == k) {
+  for (int r = 0; r < 4; ++r) { const int rw = lk + 4 * r; ti[r] = (has_i && rw < S3 && lr < S3) ? pv.T[(long long)i * SS + rw * S3 + lr] : 0.0; }
+  // ---- Dinv of both neighbours: a block row per lane, the pivot row of each Gauss-Jordan step broadcast with shuffles ----
 #pragma unroll
-          for (int b = 0; b < S3; ++b) row[b] = (b == k) ? ip : row[b] * ip;
-        } else {
-          const double f = row[k] * ip;
+  for (int k = 0; k < S3; ++k) {
+    const int src = (nl < 2 ? nl : 0) * S3 + k;
+    double pr[S3];
 #pragma unroll
-          for (int b = 0; b < S3; ++b) row[b] = (b == k) ? -f : row[b] - f * pr[b];
-        }
-      }
-      if (act) {
+    for (int b = 0; b < S3; ++b) pr[b] = __shfl(row[b], src, 64);
+    double piv = pr[k];
+    if (!(piv > 0.0)) { if (act) fail[0] = 3; piv = 1.0; }
+    double ip = __builtin_amdgcn_rcp(piv);
+    ip = ip * (2.0 - piv * ip);
+    ip = ip * (2.0 - piv * ip);
+    if (a == k) {
 #pragma unroll
-        for (int b = 0; b < S3; ++b) pv.T[(long long)j * SS + a * S3 + b] = row[b];
-      }
+      for (int b = 0; b < S3; ++b) row[b] = (b == k) ? ip : row[b] * ip;
+    } else {
+      const double f = row[k] * ip;
+#pragma unroll
+      for (int b = 0; b < S3; ++b) row[b] = (b == k) ? -f : row[b] - f * pr[b];
     }
-    __syncthreads();
-    // ---- 2. Ha_j, Hc_j: task t = 2 * (eliminated node) + which ----
-    for (int t0 = wave * kTb; t0 < 2 * ne; t0 += kBcrWaves * kTb) {
-      BcrFrag<S3> fr[kTb];
+  }
+  if (nl < 2) {
 #pragma unroll
-      for (int u = 0; u < kTb; ++u) {
-        const int t = t0 + u, j = h * (2 * (t >> 1) + 1) - 1, which = t & 1;
-        const bool on = t < 2 * ne && (which == 0 ? j - h >= 0 : j + h < m);
-        const double* Cm = Ccur + (long long)(which == 0 ? (on ? j - h : 0) : (on ? j : 0)) * SS;
-        bcr_load<S3>(fr[u], pv.T + (long long)(on ? j : 0) * SS, false, Cm, which == 0, on);
-      }
+    for (int b = 0; b < S3; ++b) w[nl * SS + a * S3 + b] = row[b];
+    if (nl == 0 ? s == 0 : right) {
+      double* Dg = pv.U2 + (long long)(nl == 0 ? jL : jR) * SS + a * S3;
 #pragma unroll
-      for (int u = 0; u < kTb; ++u) {
-        const int t = t0 + u;
-        if (t >= 2 * ne) break;
-        const int j = h * (2 * (t >> 1) + 1) - 1;
-        const bcr_d4 acc = bcr_mma<S3>(fr[u], bcr_d4{0.0, 0.0, 0.0, 0.0});
-        double* H = ((t & 1) ? pv.Hc : pv.Ha) + (long long)j * SS;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { const int rw = lk + 4 * r; if (rw < S3 && lr < S3) H[rw * S3 + lr] = acc[r]; }
-      }
+      for (int b = 0; b < S3; ++b) Dg[b] = row[b];
     }
-    __syncthreads();
-    // ---- 3. survivors: task t = 2 * (survivor) + which; which 0: D_i -= C_{i-h}^T Hc_{i-h} + C_i Ha_{i+h}, 1: C_i' = -C_i Hc_{i+h} ----
-    for (int t0 = wave * kTb; t0 < 2 * ns; t0 += kBcrWaves * kTb) {
-      BcrFrag<S3> f1[kTb], f2[kTb];
+  }
+  lds_wave_sync();
+  // ---- Hc_jL = Dinv_jL C_jL, Ha_jR = Dinv_jR C_i^T, Hc_jR = Dinv_jR C_jR ----
+  double aL[KS], aR[KS];
 #pragma unroll
-      for (int u = 0; u < kTb; ++u) {
-        const int t = t0 + u, i = 2 * h * ((t >> 1) + 1) - 1, which = t & 1;
-        const bool in = t < 2 * ns, right = in && i + h < m;
-        const int il = in ? i - h : 0, ir = right ? i + h : 0, ic = in ? i : 0;
-        if (which == 0) {
-          bcr_load<S3>(f1[u], Ccur + (long long)il * SS, true, pv.Hc + (long long)il * SS, false, in);
-          bcr_load<S3>(f2[u], Ccur + (long long)ic * SS, false, pv.Ha + (long long)ir * SS, false, right);
-        } else {
-          bcr_load<S3>(f1[u], Ccur + (long long)ic * SS, false, pv.Hc + (long long)ir * SS, false, right);
-          bcr_load<S3>(f2[u], Ccur, false, Ccur, false, false);
-        }
-      }
+  for (int s_ = 0; s_ < KS; ++s_) {
+    const int k = 4 * s_ + lk;
+    const bool ok = lr < S3 && k < S3;
+    aL[s_] = ok ? w[lr * S3 + k] : 0.0;
+    aR[s_] = (ok && right) ? w[SS + lr * S3 + k] : 0.0;
+  }
+  bcr_d4 hcl{0.0, 0.0, 0.0, 0.0}, har{0.0, 0.0, 0.0, 0.0}, hcr{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int u = 0; u < kTb; ++u) {
-        const int t = t0 + u;
-        if (t >= 2 * ns) break;
-        const int i = 2 * h * ((t >> 1) + 1) - 1;
-        bcr_d4 acc = bcr_mma<S3>(f1[u], bcr_d4{0.0, 0.0, 0.0, 0.0});
-        acc = bcr_mma<S3>(f2[u], acc);
-        double* dst = ((t & 1) ? Cnxt : pv.T) + (long long)i * SS;
+  for (int s_ = 0; s_ < KS; ++s_) {
+    hcl = __builtin_amdgcn_mfma_f64_16x16x4f64(aL[s_], cL[s_], hcl, 0, 0, 0);
+    har = __builtin_amdgcn_mfma_f64_16x16x4f64(aR[s_], ci[s_], har, 0, 0, 0);
+    hcr = __builtin_amdgcn_mfma_f64_16x16x4f64(aR[s_], cR[s_], hcr, 0, 0, 0);
+  }
+  lds_wave_sync();
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int rw = lk + 4 * r;
-          if (rw < S3 && lr < S3) dst[rw * S3 + lr] = ((t & 1) ? 0.0 : dst[rw * S3 + lr]) - acc[r];
-        }
-      }
+  for (int r = 0; r < 4; ++r) {
+    const int rw = lk + 4 * r;
+    if (rw < S3 && lr < S3) {
+      const int e = rw * S3 + lr;
+      w[e] = hcl[r]; w[SS + e] = har[r]; w[2 * SS + e] = hcr[r];
+      if (s == 0) { pv.Ha[(long long)jL * SS + e] = 0.0; pv.Hc[(long long)jL * SS + e] = hcl[r]; }
+      if (right) { pv.Ha[(long long)jR * SS + e] = har[r]; pv.Hc[(long long)jR * SS + e] = hcr[r]; }
     }
+  }
+  if (!has_i) return;                                  // wave-uniform: the last level has no survivor
+  lds_wave_sync();
+  // ---- D_i -= C_jL^T Hc_jL + C_i Ha_jR,  C_i <- -C_i Hc_jR ----
+  bcr_d4 dacc{0.0, 0.0, 0.0, 0.0}, cacc{0.0, 0.0, 0.0, 0.0};
+  double b1[KS], b2[KS], b3[KS];
+#pragma unroll
+  for (int s_ = 0; s_ < KS; ++s_) {
+    const int k = 4 * s_ + lk;
+    const bool ok = lr < S3 && k < S3;
+    b1[s_] = ok ? w[k * S3 + lr] : 0.0;
+    b2[s_] = ok ? w[SS + k * S3 + lr] : 0.0;
+    b3[s_] = ok ? w[2 * SS + k * S3 + lr] : 0.0;
+  }
+#pragma unroll
+  for (int s_ = 0; s_ < KS; ++s_) dacc = __builtin_amdgcn_mfma_f64_16x16x4f64(cL[s_], b1[s_], dacc, 0, 0, 0);
+#pragma unroll
+  for (int s_ = 0; s_ < KS; ++s_) dacc = __builtin_amdgcn_mfma_f64_16x16x4f64(ci[s_], b2[s_], dacc, 0, 0, 0);
+#pragma unroll
+  for (int s_ = 0; s_ < KS; ++s_) cacc = __builtin_amdgcn_mfma_f64_16x16x4f64(ci[s_], b3[s_], cacc, 0, 0, 0);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int rw = lk + 4 * r;
+    if (rw < S3 && lr < S3) {
+      pv.T[(long long)i * SS + rw * S3 + lr] = ti[r] - dacc[r];
+      Cc[(long long)i * SS + rw * S3 + lr] = 0.0 - cacc[r];
+    }
+  }
+}
+
+// one level in a launch of its own: one wavefront (= workgroup) per survivor
+template <int S3>
+__global__ __launch_bounds__(64) void k_sep_bcr_level(PartView pv, int h, int* __restrict__ fail) {
+  __shared__ double w[3 * S3 * S3];
+  bcr_survivor<S3>(pv, h, blockIdx.x, w, fail);
+}
+// the remaining levels from stride h0 on, one workgroup: a wavefront per survivor, one barrier per level
+constexpr int bcr_tail_waves(int s3) { return s3 > 9 ? kBcrWaves / 2 : kBcrWaves; }
+template <int S3>
+__global__ __launch_bounds__(bcr_tail_waves(S3) * 64) void k_sep_bcr_tail(PartView pv, int h0, int* __restrict__ fail) {
+  constexpr int NW = bcr_tail_waves(S3);
+  __shared__ double w[NW * 3 * S3 * S3];
+  const int wave = threadIdx.x >> 6;
+  for (int h = h0; h <= pv.m; h <<= 1) {
+    const int ns = pv.m / (2 * h), nt = ns > 0 ? ns : 1;
+#ifdef MVUS_BCR_PROBE
+    const long long p0_ = clock64();
+#endif
+    for (int s = wave; s < nt; s += NW) bcr_survivor<S3>(pv, h, s, w + wave * 3 * S3 * S3, fail);
     __syncthreads();
-    double* t_ = Ccur; Ccur = Cnxt; Cnxt = t_;
+#ifdef MVUS_BCR_PROBE
+    if (threadIdx.x == 0) printf("bcr tail h=%d ns=%d: %lld cycles\n", h, ns, clock64() - p0_);
+#endif
   }
 }
 
@@ -1227,7 +1278,7 @@ __global__ __launch_bounds__(256) void k_sep_bcr_rhs(PartView pv, int ncols) {
     const int ne = (m / h + 1) / 2;
     for (int e = tid; e < ne * S3 * TC; e += 256) {
       const int c = e % TC, a = (e / TC) % S3, j = h * (2 * (e / (TC * S3)) + 1) - 1;
-      const double* Di = pv.T + (long long)j * SS + a * S3;
+      const double* Di = pv.U2 + (long long)j * SS + a * S3;
       const double* rj = rs + j * S3 * TC + c;
       double acc = 0.0;
 #pragma unroll
@@ -1794,7 +1845,10 @@ struct HipSchur {
       if (pv.nt > 0) hipLaunchKernelGGL(k_part_reduce<BWT>, dim3(pv.nt, (pv.s3 * ncols + 255) / 256), dim3(256), 0, be.stream, pv, ncols, Lb, Z);
       if (shard) be.reduce(sepbuf, sep_count);        // every rank now holds the whole separator system
       if (use_bcr) {
-        hipLaunchKernelGGL(k_sep_bcr_factor<S3T>, dim3(1), dim3(kBcrWaves * 64), 0, be.stream, pv, fail);
+        int h = 1;                                        // wide levels: a launch each; the rest in one workgroup
+        for (; h <= pv.m && pv.m / (2 * h) > kBcrTailNs; h <<= 1)
+          hipLaunchKernelGGL(k_sep_bcr_level<S3T>, dim3(pv.m / (2 * h)), dim3(64), 0, be.stream, pv, h, fail);
+        if (h <= pv.m) hipLaunchKernelGGL(k_sep_bcr_tail<S3T>, dim3(1), dim3(bcr_tail_waves(S3T) * 64), 0, be.stream, pv, h, fail);
         if (bcr_cols == kBcrCols) hipLaunchKernelGGL((k_sep_bcr_rhs<S3T, kBcrCols>), dim3((ncols + kBcrCols - 1) / kBcrCols), dim3(256), bcr_lds, be.stream, pv, ncols);
         else hipLaunchKernelGGL((k_sep_bcr_rhs<S3T, 1>), dim3(ncols), dim3(256), bcr_lds, be.stream, pv, ncols);
       } else {
