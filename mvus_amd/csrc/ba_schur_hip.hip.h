@@ -1454,10 +1454,12 @@ __global__ __launch_bounds__(256) void k_schur_gemm(NEView ne, int ncols, int ro
 // rhs = gc - sum_slabs Gp[:, CB], in 32x32 tiles; the workgroup of tile (0,0) goes on to factorise the first pivot block of
 // the Gauss-Jordan solve below (k_gj_pivot), saving a launch.
 constexpr int kNB = 32;
-__device__ __forceinline__ void potrf_inv_wave(double (*Dm)[kNB + 1], double* __restrict__ Li, int* __restrict__ fail);
+__device__ __forceinline__ void pivot_inverse_wave(double (*Dm)[kNB + 1], double* __restrict__ W, double* __restrict__ Pout, int* __restrict__ fail);
+constexpr int kPivScratch = 5 * 16 * 17;      // doubles of LDS scratch pivot_inverse_wave needs
 __global__ __launch_bounds__(kNB * kNB) void k_schur_finish(NEView ne, int ncols, int nslab, double lambda, const double* __restrict__ Gp, double* __restrict__ S,
                                                             double* __restrict__ Linv, int* __restrict__ fail) {
   __shared__ double Dm[kNB][kNB + 1];
+  __shared__ double Wp[kPivScratch];
   const int r = threadIdx.x / kNB, c = threadIdx.x % kNB;
   const int a = blockIdx.y * kNB + r, b = blockIdx.x * kNB + c;
   const long long stride = (long long)ne.CB * ncols;
@@ -1484,7 +1486,7 @@ __global__ __launch_bounds__(kNB * kNB) void k_schur_finish(NEView ne, int ncols
   const int nb = min(kNB, ne.CB);
   Dm[r][c] = (r < nb && c < nb && c <= r) ? v : ((r < nb && c < nb) ? 0.0 : (r == c ? 1.0 : 0.0));
   __syncthreads();
-  if (threadIdx.x < 64) potrf_inv_wave(Dm, Linv, fail);
+  if (threadIdx.x < 64) pivot_inverse_wave(Dm, Wp, Linv, fail);
 }
 
 // Dense solve of the reduced camera system S x = b (nn <= 1152, SPD) by BLOCK GAUSS-JORDAN, 32-column panels, ONE
@@ -1493,15 +1495,16 @@ __global__ __launch_bounds__(kNB * kNB) void k_schur_finish(NEView ne, int ncols
 //     every row block I below the panel (the rhs row included), every column block J != k:
 //         Q_I = M[I][k] P_k ;   M[I][J] -= Q_I M[k][J] ;   M[I][k] <- Q_I
 // After the last panel the rhs row holds x.  Rows above the panel are never touched again, the trailing block stays the
-// (symmetric positive definite) Schur complement, so P_k = L^-T L^-1 comes from a Cholesky of the 32x32 pivot block done
-// in registers by ONE wavefront of the workgroup that produced that block (row per lane, pivot column by v_readlane,
-// 1/sqrt(pivot) by v_rsq_f64 + 2 Newton steps; lanes 32..63 carry the identity and end up holding L^-T).  Measured (cycle
-// counters, MVUS_GJ_PROBE): 22k cycles = 9 us per panel for this wavefront, 13k for the tile update before it; an LDS-broadcast
-// variant of the column exchange did not unroll under the 1024-thread register budget and was far slower -- kept as is.  Each step
-// reads `src` and writes `dst` (ping-pong), so all tiles of a step are independent.  Against a blocked Cholesky this
-// trades ~3x the (tiny, perfectly parallel) tile flops for the removal of the sequential back substitution (44 us at
-// nn = 288: nine dependent round trips to data other XCDs wrote).  The critical path per panel is the one wavefront:
-// ~32 dependent column steps.
+// (symmetric positive definite) Schur complement.  Each step reads `src` and writes `dst` (ping-pong), so all tiles of a
+// step are independent.  Against a blocked Cholesky this trades ~3x the (tiny, perfectly parallel) tile flops for the
+// removal of the sequential back substitution (44 us at nn = 288: nine dependent round trips to data other XCDs wrote).
+//
+// The critical path per panel is the inverse of the 32x32 pivot block, done by ONE wavefront of the workgroup that
+// produced that block (pivot_inverse_wave): 2x2 blocks of 16 -- Cholesky + inverse factor of a 16x16 block in registers
+// (row per lane, pivot column by v_readlane, 1/sqrt by v_rsq_f64 + 2 Newton steps; 16 more lanes carry the identity and
+// end up holding L^-T), the Schur complement, the off-diagonal block of L^-1 and P = L^-T L^-1 on the fp64 matrix cores.
+// Round 2 history (cycle counters, MVUS_GJ_PROBE): a 32-step register Cholesky took 22k cycles and the tile update 13k
+// (three 32-deep LDS dot products per thread: LDS-bandwidth bound); now 16-step halves + matrix-core tile products.
 
 __device__ __forceinline__ double bcast_lane(double v, int src) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
@@ -1509,16 +1512,11 @@ __device__ __forceinline__ double bcast_lane(double v, int src) {
   return __hiloint2double(hi, lo);
 }
 
-// first wavefront of the workgroup: Cholesky of the block in Dm (lower part valid, identity padded beyond the block),
-// inverse factor L^-1 -> Li[r*kNB+c].
-__device__ __forceinline__ void potrf_inv_wave(double (*Dm)[kNB + 1], double* __restrict__ Li, int* __restrict__ fail) {
-  const int lane = threadIdx.x & 63;
-  const int row = lane & (kNB - 1);
-  double a[kNB];
+// Cholesky of a 16x16 block by half a wavefront: lanes 0..15 hold its rows (lower triangle), lanes 16..31 the identity.
+// Column operations: on return lane i < 16 holds L[i][k] (k <= i), lane 16+c holds L^-1[k][c] (k >= c, zero above).
+__device__ __forceinline__ void chol_inv16(double (&a)[16], int lane, int* __restrict__ fail) {
 #pragma unroll
-  for (int k = 0; k < kNB; ++k) a[k] = lane < kNB ? Dm[row][k] : (k == row ? 1.0 : 0.0);
-#pragma unroll
-  for (int k = 0; k < kNB; ++k) {
+  for (int k = 0; k < 16; ++k) {
     double dkk = bcast_lane(a[k], k);
     if (!(dkk > 0.0)) { if (lane == 0) fail[0] = 2; dkk = 1.0; }
     double inv = __builtin_amdgcn_rsq(dkk);
@@ -1526,69 +1524,160 @@ __device__ __forceinline__ void potrf_inv_wave(double (*Dm)[kNB + 1], double* __
     inv = inv * (1.5 - 0.5 * dkk * inv * inv);
     a[k] = (lane == k) ? dkk * inv : a[k] * inv;
 #pragma unroll
-    for (int j = k + 1; j < kNB; ++j) a[j] -= a[k] * bcast_lane(a[k], j);
-  }
-  if (lane >= kNB) {
-#pragma unroll
-    for (int k = 0; k < kNB; ++k) Li[k * kNB + row] = k >= row ? a[k] : 0.0;      // lane 32+c holds row c of L^-T
+    for (int j = k + 1; j < 16; ++j) a[j] -= a[k] * bcast_lane(a[k], j);
   }
 }
 
-// one panel step; grid (row tiles below the panel incl. the rhs row, all column tiles); pc != nullptr on the last step
-__global__ __launch_bounds__(1024) void k_gj_step(int nn, int kb, const double* __restrict__ src, double* __restrict__ dst,
-                                                  double* __restrict__ Linv, int* __restrict__ fail, double* __restrict__ pc) {
-  __shared__ double Ai[kNB][kNB + 1], Li[kNB][kNB + 1], Pk[kNB][kNB + 1], Q[kNB][kNB + 1], Bk[kNB][kNB + 1];
+// acc += op(A) op(B) for 16x16 blocks in LDS (stride lda / ldb), K = 16: ta: A is read transposed, tb: B is.
+__device__ __forceinline__ bcr_d4 mma16(const double* __restrict__ A, int lda, bool ta, const double* __restrict__ B, int ldb, bool tb, bcr_d4 acc) {
+  const int lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
+#pragma unroll
+  for (int s_ = 0; s_ < 4; ++s_) {
+    const int k = 4 * s_ + lk;
+    const double av = ta ? A[k * lda + lr] : A[lr * lda + k];
+    const double bv = tb ? B[lr * ldb + k] : B[k * ldb + lr];
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+  }
+  return acc;
+}
+__device__ __forceinline__ void store16(double* __restrict__ M, int ld, bcr_d4 acc, double sign) {
+  const int lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) M[(lk + 4 * r) * ld + lr] = sign * acc[r];
+}
+
+// first wavefront of the workgroup: inverse P = L^-T L^-1 of the SPD block in Dm (lower part valid, identity padded
+// beyond the block) -> Pout[r*kNB+c], both triangles.  W: kPivScratch doubles of LDS.
+__device__ __forceinline__ void pivot_inverse_wave(double (*Dm)[kNB + 1], double* __restrict__ W, double* __restrict__ Pout, int* __restrict__ fail) {
+  constexpr int LD = 17, LDD = kNB + 1;
+  const int lane = threadIdx.x & 63, row = lane & 15, lr = lane & 15, lk = lane >> 4;
+  const bcr_d4 zero{0.0, 0.0, 0.0, 0.0};
+  double* M1 = W;                 // L11^-1
+  double* M2 = W + 16 * LD;       // L21
+  double* M3 = W + 2 * 16 * LD;   // S, later L^-1 (2,1)
+  double* M4 = W + 3 * 16 * LD;   // L22^-1
+  double* M5 = W + 4 * 16 * LD;   // L22^-1 L21
+  double a[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) a[k] = lane < 16 ? (k <= row ? Dm[row][k] : 0.0) : (lane < 32 && k == row ? 1.0 : 0.0);
+  chol_inv16(a, lane, fail);
+  if (lane >= 16 && lane < 32) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) M1[k * LD + row] = a[k];
+  }
+  lds_wave_sync();
+  // L21 = A21 L11^-T ;  S = A22 - L21 L21^T
+  bcr_d4 acc = mma16(&Dm[16][0], LDD, false, M1, LD, true, zero);
+  store16(M2, LD, acc, 1.0);
+  lds_wave_sync();
+  acc = mma16(M2, LD, false, M2, LD, true, zero);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) M3[(lk + 4 * r) * LD + lr] = Dm[16 + lk + 4 * r][16 + lr] - acc[r];
+  lds_wave_sync();
+#pragma unroll
+  for (int k = 0; k < 16; ++k) a[k] = lane < 16 ? (k <= row ? M3[row * LD + k] : 0.0) : (lane < 32 && k == row ? 1.0 : 0.0);
+  chol_inv16(a, lane, fail);
+  if (lane >= 16 && lane < 32) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) M4[k * LD + row] = a[k];
+  }
+  lds_wave_sync();
+  // L^-1 (2,1) = -L22^-1 L21 L11^-1
+  acc = mma16(M4, LD, false, M2, LD, false, zero);
+  store16(M5, LD, acc, 1.0);
+  lds_wave_sync();
+  acc = mma16(M5, LD, false, M1, LD, false, zero);
+  store16(M3, LD, acc, -1.0);
+  lds_wave_sync();
+  // P11 = L11^-T L11^-1 + X^T X,  P21 = L22^-T X,  P22 = L22^-T L22^-1     (X = L^-1 (2,1))
+  bcr_d4 p11 = mma16(M1, LD, true, M1, LD, false, zero);
+  p11 = mma16(M3, LD, true, M3, LD, false, p11);
+  const bcr_d4 p21 = mma16(M4, LD, true, M3, LD, false, zero);
+  const bcr_d4 p22 = mma16(M4, LD, true, M4, LD, false, zero);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int rw = lk + 4 * r;
+    Pout[rw * kNB + lr] = p11[r];
+    Pout[(16 + rw) * kNB + lr] = p21[r];
+    Pout[lr * kNB + 16 + rw] = p21[r];
+    Pout[(16 + rw) * kNB + 16 + lr] = p22[r];
+  }
+}
+
+// one panel step; grid (row tiles below the panel incl. the rhs row, all column tiles); pc != nullptr on the last step.
+// Four wavefronts, one 16x16 quarter of the tile each; both tile products on the fp64 matrix cores.
+constexpr int kGjThreads = 256;
+__global__ __launch_bounds__(kGjThreads) void k_gj_step(int nn, int kb, const double* __restrict__ src, double* __restrict__ dst,
+                                                        double* __restrict__ Pinv, int* __restrict__ fail, double* __restrict__ pc) {
+  constexpr int kTile = kNB * (kNB + 1);
+  __shared__ double lds[4 * kTile];
+  double (*Ai)[kNB + 1] = reinterpret_cast<double (*)[kNB + 1]>(lds);
+  double (*Pk)[kNB + 1] = reinterpret_cast<double (*)[kNB + 1]>(lds + kTile);
+  double (*Q)[kNB + 1] = reinterpret_cast<double (*)[kNB + 1]>(lds + 2 * kTile);
+  double (*Bk)[kNB + 1] = reinterpret_cast<double (*)[kNB + 1]>(lds + 3 * kTile);      // Q and Bk: one contiguous scratch area later
 #ifdef MVUS_GJ_PROBE
   const long long t0_ = clock64();
 #endif
   const int nb = min(kNB, nn - kb), base = kb + nb;
   const int i0 = base + blockIdx.x * kNB, j0 = blockIdx.y * kNB;
   const bool pivcol = j0 == kb;                              // this tile is column block k: it stores Q_I
-  const int r = threadIdx.x / kNB, c = threadIdx.x % kNB;
-  const int i = i0 + r, j = j0 + c;
-  Ai[r][c] = (i <= nn && c < nb) ? src[(long long)i * nn + kb + c] : 0.0;
-  Li[r][c] = Linv[(long long)(kb / kNB) * kNB * kNB + threadIdx.x];
-  Bk[r][c] = (r < nb && j < nn) ? src[(long long)(kb + r) * nn + j] : 0.0;
-  const bool valid = i <= nn && j < nn;
-  double v = (valid && !pivcol) ? src[(long long)i * nn + j] : 0.0;
-  __syncthreads();
-  {                                                          // P_k = L^-T L^-1 (L^-1 lower triangular, identity padded)
-    double acc = 0.0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 15, lk = lane >> 4;
+  const int br = (wave >> 1) * 16, bc = (wave & 1) * 16;     // this wavefront's quarter
 #pragma unroll
-    for (int m = 0; m < kNB; ++m) acc += Li[m][r] * Li[m][c];
-    Pk[r][c] = acc;
+  for (int q = 0; q < kNB * kNB / kGjThreads; ++q) {
+    const int e = threadIdx.x + kGjThreads * q, r = e / kNB, c = e % kNB;
+    Ai[r][c] = (i0 + r <= nn && c < nb) ? src[(long long)(i0 + r) * nn + kb + c] : 0.0;
+    Pk[r][c] = Pinv[(long long)(kb / kNB) * kNB * kNB + e];
+    Bk[r][c] = (r < nb && j0 + c < nn) ? src[(long long)(kb + r) * nn + j0 + c] : 0.0;
   }
-  __syncthreads();
-  {
-    double acc = 0.0;
+  double v[4];                                               // the tile itself, in the accumulator layout
 #pragma unroll
-    for (int m = 0; m < kNB; ++m) acc += Ai[r][m] * Pk[m][c];
-    Q[r][c] = acc;
+  for (int r = 0; r < 4; ++r) {
+    const int i = i0 + br + lk + 4 * r, j = j0 + bc + lr;
+    v[r] = (i <= nn && j < nn && !pivcol) ? src[(long long)i * nn + j] : 0.0;
   }
   __syncthreads();
-  if (pivcol) v = Q[r][c];
-  else {
-    double acc = 0.0;
+  bcr_d4 acc{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int m = 0; m < kNB; ++m) acc += Q[r][m] * Bk[m][c];
-    v -= acc;
+  for (int s_ = 0; s_ < kNB / 4; ++s_) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ai[br + lr][4 * s_ + lk], Pk[4 * s_ + lk][bc + lr], acc, 0, 0, 0);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) Q[br + lk + 4 * r][bc + lr] = acc[r];
+  __syncthreads();
+  if (pivcol) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = acc[r];
+  } else {
+    bcr_d4 upd{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s_ = 0; s_ < kNB / 4; ++s_) upd = __builtin_amdgcn_mfma_f64_16x16x4f64(Q[br + lr][4 * s_ + lk], Bk[4 * s_ + lk][bc + lr], upd, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] -= upd[r];
   }
-  if (valid && (!pivcol || c < nb)) {
-    dst[(long long)i * nn + j] = v;
-    if (pc && i == nn) pc[j] = -v;                           // last panel: the rhs row is the solution
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = i0 + br + lk + 4 * r, j = j0 + bc + lr;
+    if (i <= nn && j < nn && (!pivcol || bc + lr < nb)) {
+      dst[(long long)i * nn + j] = v[r];
+      if (pc && i == nn) pc[j] = -v[r];                      // last panel: the rhs row is the solution
+    }
   }
-  // the tile holding the next pivot block factorises it
+  // the tile holding the next pivot block inverts it
   const int nb2 = min(kNB, nn - base);
   if (blockIdx.x != 0 || j0 != base || nb2 <= 0) return;
 #ifdef MVUS_GJ_PROBE
   const long long t1_ = clock64();
 #endif
-  __syncthreads();                                           // Ai is reused as the block to factorise
-  Ai[r][c] = (r < nb2 && c < nb2 && c <= r) ? v : ((r < nb2 && c < nb2) ? 0.0 : (r == c ? 1.0 : 0.0));
+  __syncthreads();                                           // Ai is reused as the block to invert, Q and Bk as scratch
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int rr = br + lk + 4 * r, cc = bc + lr;
+    Ai[rr][cc] = (rr < nb2 && cc < nb2 && cc <= rr) ? v[r] : ((rr < nb2 && cc < nb2) ? 0.0 : (rr == cc ? 1.0 : 0.0));
+  }
   __syncthreads();
-  if (threadIdx.x < 64) potrf_inv_wave(Ai, Linv + (long long)(base / kNB) * kNB * kNB, fail);
+  static_assert(kPivScratch <= 2 * kNB * (kNB + 1), "pivot scratch must fit Q and Bk");
+  if (threadIdx.x < 64) pivot_inverse_wave(Ai, &Q[0][0], Pinv + (long long)(base / kNB) * kNB * kNB, fail);
 #ifdef MVUS_GJ_PROBE
-  if (threadIdx.x == 0 && kb == 0) printf("gj panel 0: tile %lld cycles, potrf %lld cycles\n", t1_ - t0_, clock64() - t1_);
+  if (threadIdx.x == 0 && kb == 0) printf("gj panel 0: tile %lld cycles, pivot inverse %lld cycles\n", t1_ - t0_, clock64() - t1_);
 #endif
 }
 
@@ -1888,7 +1977,7 @@ struct HipSchur {
       for (int kb = 0; kb < nn; kb += kNB) {
         const int nb = std::min(kNB, nn - kb), below = nn + 1 - (kb + nb);       // rows under the panel incl. the rhs row
         const bool last = kb + nb >= nn;
-        hipLaunchKernelGGL(k_gj_step, dim3((below + kNB - 1) / kNB, (nn + kNB - 1) / kNB), dim3(kNB * kNB), 0, be.stream, nn, kb, a, b, Linv, fail,
+        hipLaunchKernelGGL(k_gj_step, dim3((below + kNB - 1) / kNB, (nn + kNB - 1) / kNB), dim3(kGjThreads), 0, be.stream, nn, kb, a, b, Linv, fail,
                            last ? pc : (double*)nullptr);
         std::swap(a, b);
       }
