@@ -1127,6 +1127,7 @@ __device__ __forceinline__ void bcr_survivor(const PartView& pv, int h, int s, d
 #pragma unroll
   for (int r = 0; r < 4; ++r) { const int rw = lk + 4 * r; ti[r] = (has_i && rw < S3 && lr < S3) ? pv.T[(long long)i * SS + rw * S3 + lr] : 0.0; }
   // ---- Dinv of both neighbours: a block row per lane, the pivot row of each Gauss-Jordan step broadcast with shuffles ----
+  bool bad = false;
 #pragma unroll
   for (int k = 0; k < S3; ++k) {
     const int src = (nl < 2 ? nl : 0) * S3 + k;
@@ -1134,7 +1135,8 @@ __device__ __forceinline__ void bcr_survivor(const PartView& pv, int h, int s, d
 #pragma unroll
     for (int b = 0; b < S3; ++b) pr[b] = __shfl(row[b], src, 64);
     double piv = pr[k];
-    if (!(piv > 0.0)) { if (act) fail[0] = 3; piv = 1.0; }
+    bad |= !(piv > 0.0);
+    piv = piv > 0.0 ? piv : 1.0;
     double ip = __builtin_amdgcn_rcp(piv);
     ip = ip * (2.0 - piv * ip);
     ip = ip * (2.0 - piv * ip);
@@ -1147,6 +1149,7 @@ __device__ __forceinline__ void bcr_survivor(const PartView& pv, int h, int s, d
       for (int b = 0; b < S3; ++b) row[b] = (b == k) ? -f : row[b] - f * pr[b];
     }
   }
+  if (bad && act) fail[0] = 3;
   if (nl < 2) {
 #pragma unroll
     for (int b = 0; b < S3; ++b) w[nl * SS + a * S3 + b] = row[b];
@@ -1512,20 +1515,28 @@ __device__ __forceinline__ double bcast_lane(double v, int src) {
   return __hiloint2double(hi, lo);
 }
 
-// Cholesky of a 16x16 block by half a wavefront: lanes 0..15 hold its rows (lower triangle), lanes 16..31 the identity.
-// Column operations: on return lane i < 16 holds L[i][k] (k <= i), lane 16+c holds L^-1[k][c] (k >= c, zero above).
-__device__ __forceinline__ void chol_inv16(double (&a)[16], int lane, int* __restrict__ fail) {
+// L D L^T of a 16x16 SPD block by half a wavefront: lanes 0..15 hold its rows (lower triangle), lanes 16..31 the identity.
+// Column operations col_j -= col_k * (a_jk / d_k): on return lane 16+c holds X[k][c] = (L^-1)[k][c] (unit lower, zero
+// above) and rd[k] = 1 / d_k in every lane, so that block^-1 = X^T diag(rd) X.  No square root, and the broadcast of the
+// raw column (v_readlane) does not wait for the reciprocal: the dependent chain per column is pivot -> rcp + 2 Newton
+// steps -> one multiply -> the first trailing FMA.  No branch inside the loop (one basic block: the scheduler runs the
+// reciprocal of column k+1 under the trailing update of column k).
+__device__ __forceinline__ void ldl_inv16(double (&a)[16], double (&rd)[16], int lane, int* __restrict__ fail) {
+  bool bad = false;
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
-    double dkk = bcast_lane(a[k], k);
-    if (!(dkk > 0.0)) { if (lane == 0) fail[0] = 2; dkk = 1.0; }
-    double inv = __builtin_amdgcn_rsq(dkk);
-    inv = inv * (1.5 - 0.5 * dkk * inv * inv);
-    inv = inv * (1.5 - 0.5 * dkk * inv * inv);
-    a[k] = (lane == k) ? dkk * inv : a[k] * inv;
+    double d = bcast_lane(a[k], k);
+    bad |= !(d > 0.0);
+    d = d > 0.0 ? d : 1.0;
+    double r = __builtin_amdgcn_rcp(d);
+    r = r * (2.0 - d * r);
+    r = r * (2.0 - d * r);
+    rd[k] = r;
+    const double t = a[k] * r;
 #pragma unroll
-    for (int j = k + 1; j < 16; ++j) a[j] -= a[k] * bcast_lane(a[k], j);
+    for (int j = k + 1; j < 16; ++j) a[j] -= t * bcast_lane(a[k], j);
   }
+  if (bad && lane == 0) fail[0] = 2;
 }
 
 // acc += op(A) op(B) for 16x16 blocks in LDS (stride lda / ldb), K = 16: ta: A is read transposed, tb: B is.
@@ -1546,62 +1557,85 @@ __device__ __forceinline__ void store16(double* __restrict__ M, int ld, bcr_d4 a
   for (int r = 0; r < 4; ++r) M[(lk + 4 * r) * ld + lr] = sign * acc[r];
 }
 
-// first wavefront of the workgroup: inverse P = L^-T L^-1 of the SPD block in Dm (lower part valid, identity padded
-// beyond the block) -> Pout[r*kNB+c], both triangles.  W: kPivScratch doubles of LDS.
+// first wavefront of the workgroup: inverse P of the SPD block in Dm (lower part valid, identity padded beyond the
+// block) -> Pout[r*kNB+c], both triangles.  2x2 blocks of 16:  A11^-1 = X1^T D1^-1 X1 (ldl_inv16),  T = A21 A11^-1,
+// S = A22 - T A21^T,  P22 = S^-1 (ldl_inv16 again),  P21 = -P22 T,  P11 = A11^-1 - T^T P21.  W: kPivScratch doubles of LDS.
 __device__ __forceinline__ void pivot_inverse_wave(double (*Dm)[kNB + 1], double* __restrict__ W, double* __restrict__ Pout, int* __restrict__ fail) {
   constexpr int LD = 17, LDD = kNB + 1;
   const int lane = threadIdx.x & 63, row = lane & 15, lr = lane & 15, lk = lane >> 4;
   const bcr_d4 zero{0.0, 0.0, 0.0, 0.0};
-  double* M1 = W;                 // L11^-1
-  double* M2 = W + 16 * LD;       // L21
-  double* M3 = W + 2 * 16 * LD;   // S, later L^-1 (2,1)
-  double* M4 = W + 3 * 16 * LD;   // L22^-1
-  double* M5 = W + 4 * 16 * LD;   // L22^-1 L21
-  double a[16];
+  double* M1 = W;                 // X (unit lower inverse factor of the block being inverted)
+  double* M2 = W + 16 * LD;       // D^-1 X
+  double* M3 = W + 2 * 16 * LD;   // A11^-1
+  double* M4 = W + 3 * 16 * LD;   // T, later P21
+  double* M5 = W + 4 * 16 * LD;   // S, later P22
+  double a[16], rd[16];
+#ifdef MVUS_GJ_PROBE
+  const long long q0_ = clock64();
+#endif
 #pragma unroll
-  for (int k = 0; k < 16; ++k) a[k] = lane < 16 ? (k <= row ? Dm[row][k] : 0.0) : (lane < 32 && k == row ? 1.0 : 0.0);
-  chol_inv16(a, lane, fail);
+  for (int k = 0; k < 16; ++k) {          // unconditional LDS reads, then selects: no branch per element
+    const double t = Dm[row][k];
+    a[k] = lane < 16 ? (k <= row ? t : 0.0) : (lane < 32 && k == row ? 1.0 : 0.0);
+  }
+  ldl_inv16(a, rd, lane, fail);
   if (lane >= 16 && lane < 32) {
 #pragma unroll
-    for (int k = 0; k < 16; ++k) M1[k * LD + row] = a[k];
+    for (int k = 0; k < 16; ++k) { M1[k * LD + row] = a[k]; M2[k * LD + row] = rd[k] * a[k]; }
   }
   lds_wave_sync();
-  // L21 = A21 L11^-T ;  S = A22 - L21 L21^T
-  bcr_d4 acc = mma16(&Dm[16][0], LDD, false, M1, LD, true, zero);
-  store16(M2, LD, acc, 1.0);
+#ifdef MVUS_GJ_PROBE
+  const long long q1_ = clock64();
+#endif
+  bcr_d4 a11 = mma16(M1, LD, true, M2, LD, false, zero);                 // A11^-1 = X^T (D^-1 X)
+  store16(M3, LD, a11, 1.0);
   lds_wave_sync();
-  acc = mma16(M2, LD, false, M2, LD, true, zero);
-#pragma unroll
-  for (int r = 0; r < 4; ++r) M3[(lk + 4 * r) * LD + lr] = Dm[16 + lk + 4 * r][16 + lr] - acc[r];
+  bcr_d4 acc = mma16(&Dm[16][0], LDD, false, M3, LD, false, zero);       // T = A21 A11^-1
+  store16(M4, LD, acc, 1.0);
   lds_wave_sync();
+  acc = mma16(M4, LD, false, &Dm[16][0], LDD, true, zero);               // T A21^T
 #pragma unroll
-  for (int k = 0; k < 16; ++k) a[k] = lane < 16 ? (k <= row ? M3[row * LD + k] : 0.0) : (lane < 32 && k == row ? 1.0 : 0.0);
-  chol_inv16(a, lane, fail);
+  for (int r = 0; r < 4; ++r) M5[(lk + 4 * r) * LD + lr] = Dm[16 + lk + 4 * r][16 + lr] - acc[r];
+  lds_wave_sync();
+#ifdef MVUS_GJ_PROBE
+  const long long q2_ = clock64();
+#endif
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const double t = M5[row * LD + k];
+    a[k] = lane < 16 ? (k <= row ? t : 0.0) : (lane < 32 && k == row ? 1.0 : 0.0);
+  }
+  ldl_inv16(a, rd, lane, fail);
   if (lane >= 16 && lane < 32) {
 #pragma unroll
-    for (int k = 0; k < 16; ++k) M4[k * LD + row] = a[k];
+    for (int k = 0; k < 16; ++k) { M1[k * LD + row] = a[k]; M2[k * LD + row] = rd[k] * a[k]; }
   }
   lds_wave_sync();
-  // L^-1 (2,1) = -L22^-1 L21 L11^-1
-  acc = mma16(M4, LD, false, M2, LD, false, zero);
-  store16(M5, LD, acc, 1.0);
+#ifdef MVUS_GJ_PROBE
+  const long long q3_ = clock64();
+#endif
+  const bcr_d4 p22 = mma16(M1, LD, true, M2, LD, false, zero);           // S^-1
+  store16(M5, LD, p22, 1.0);
   lds_wave_sync();
-  acc = mma16(M5, LD, false, M1, LD, false, zero);
-  store16(M3, LD, acc, -1.0);
+  const bcr_d4 p21 = mma16(M5, LD, false, M4, LD, false, zero);          // P22 T  (sign applied on use)
+  lds_wave_sync();                                                       // every lane has read T before it is overwritten
+  store16(M4, LD, p21, -1.0);
   lds_wave_sync();
-  // P11 = L11^-T L11^-1 + X^T X,  P21 = L22^-T X,  P22 = L22^-T L22^-1     (X = L^-1 (2,1))
-  bcr_d4 p11 = mma16(M1, LD, true, M1, LD, false, zero);
-  p11 = mma16(M3, LD, true, M3, LD, false, p11);
-  const bcr_d4 p21 = mma16(M4, LD, true, M3, LD, false, zero);
-  const bcr_d4 p22 = mma16(M4, LD, true, M4, LD, false, zero);
+  const bcr_d4 tp = mma16(&Dm[16][0], LDD, true, M4, LD, false, zero);   // A21^T P21;  T^T = A11^-1 A21^T  =>  T^T P21 = A11^-1 (A21^T P21)
+  store16(M1, LD, tp, 1.0);
+  lds_wave_sync();
+  const bcr_d4 corr = mma16(M3, LD, false, M1, LD, false, zero);
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int rw = lk + 4 * r;
-    Pout[rw * kNB + lr] = p11[r];
-    Pout[(16 + rw) * kNB + lr] = p21[r];
-    Pout[lr * kNB + 16 + rw] = p21[r];
+    Pout[rw * kNB + lr] = a11[r] - corr[r];
+    Pout[(16 + rw) * kNB + lr] = -p21[r];
+    Pout[lr * kNB + 16 + rw] = -p21[r];
     Pout[(16 + rw) * kNB + 16 + lr] = p22[r];
   }
+#ifdef MVUS_GJ_PROBE
+  if (lane == 0 && blockIdx.x == 0) printf("pivot inverse: ldl %lld, A11inv+T+S %lld, ldl %lld, glue+P %lld cycles\n", q1_ - q0_, q2_ - q1_, q3_ - q2_, clock64() - q3_);
+#endif
 }
 
 // one panel step; grid (row tiles below the panel incl. the rhs row, all column tiles); pc != nullptr on the last step.
