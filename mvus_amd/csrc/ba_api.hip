@@ -40,6 +40,13 @@ struct HipBackend {
   int64_t det_capacity = 0;
   // reductions
   double *partials = nullptr, *scal_dev = nullptr, *scal_host = nullptr;
+  // pinned staging ring for the n-vectors that cross PCIe every solve / iteration (x, gradient, bounds): a copy from pageable
+  // memory costs ~30 us of host-side staging per call and a synchronisation; through a pinned slot the upload is asynchronous
+  static constexpr int kStageSlots = 4;
+  double* stage[kStageSlots] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t stage_ev[kStageSlots] = {nullptr, nullptr, nullptr, nullptr};
+  int64_t stage_cap = 0;
+  int stage_next = 0;
   // multi-GPU
   mvus_allreduce_fn allreduce = nullptr;
   void* allreduce_user = nullptr;
@@ -102,6 +109,11 @@ struct HipBackend {
     x_cur = dalloc<double>(hp.n); f_cur = dalloc<double>(hp.m);
     partials = dalloc<double>(2048); scal_dev = dalloc<double>(16);
     MVUS_HIP(hipHostMalloc(reinterpret_cast<void**>(&scal_host), 16 * sizeof(double), hipHostMallocDefault));
+    stage_cap = std::max<int64_t>(hp.n, 1024);
+    for (int i = 0; i < kStageSlots; ++i) {
+      MVUS_HIP(hipHostMalloc(reinterpret_cast<void**>(&stage[i]), stage_cap * sizeof(double), hipHostMallocDefault));
+      MVUS_HIP(hipEventCreateWithFlags(&stage_ev[i], hipEventDisableTiming));
+    }
     MVUS_HIP(hipMemsetAsync(span, 0xff, sizeof(int32_t) * std::max<int64_t>(hp.M, 1), stream));
     MVUS_HIP(hipMemsetAsync(pat0, 0xff, sizeof(int32_t) * std::max<int64_t>(hp.M, 1), stream));
     MVUS_HIP(hipMemsetAsync(mctrl, 0xff, sizeof(int32_t) * std::max<int64_t>(3 * hp.T, 1), stream));
@@ -123,6 +135,10 @@ struct HipBackend {
     for (void* p : owned) (void)hipFree(p);
     for (auto& kv : pool_size) (void)hipFree(kv.first);
     if (scal_host) (void)hipHostFree(scal_host);
+    for (int i = 0; i < kStageSlots; ++i) {
+      if (stage[i]) (void)hipHostFree(stage[i]);
+      if (stage_ev[i]) (void)hipEventDestroy(stage_ev[i]);
+    }
     if (own_stream && stream) (void)hipStreamDestroy(stream);
   }
 
@@ -152,12 +168,32 @@ struct HipBackend {
     hipLaunchKernelGGL(k_cam_states, dim3((hp.C + 63) / 64), dim3(64), 0, stream, dp, x, cams);
     cams_for = x;
   }
-  void upload(double* d, const double* s, int64_t len) {
+  int stage_slot() {                          // next pinned slot, free again once the copy that last used it has run
+    const int slot = stage_next;
+    stage_next = (stage_next + 1) % kStageSlots;
+    MVUS_HIP(hipEventSynchronize(stage_ev[slot]));
+    return slot;
+  }
+  void upload(double* d, const double* s, int64_t len) {      // the host buffer may be reused right away
     touch(d);
+    if (len <= stage_cap) {
+      const int slot = stage_slot();
+      std::memcpy(stage[slot], s, len * sizeof(double));
+      MVUS_HIP(hipMemcpyAsync(d, stage[slot], len * sizeof(double), hipMemcpyHostToDevice, stream));
+      MVUS_HIP(hipEventRecord(stage_ev[slot], stream));
+      return;
+    }
     MVUS_HIP(hipMemcpyAsync(d, s, len * sizeof(double), hipMemcpyHostToDevice, stream));
-    MVUS_HIP(hipStreamSynchronize(stream));   // the host buffer may be reused right away
+    MVUS_HIP(hipStreamSynchronize(stream));
   }
   void download(double* d, const double* s, int64_t len) {
+    if (len <= stage_cap) {
+      const int slot = stage_slot();
+      MVUS_HIP(hipMemcpyAsync(stage[slot], s, len * sizeof(double), hipMemcpyDeviceToHost, stream));
+      MVUS_HIP(hipStreamSynchronize(stream));
+      std::memcpy(d, stage[slot], len * sizeof(double));
+      return;
+    }
     MVUS_HIP(hipMemcpyAsync(d, s, len * sizeof(double), hipMemcpyDeviceToHost, stream));
     MVUS_HIP(hipStreamSynchronize(stream));
   }
