@@ -255,6 +255,18 @@ int mvus_spline_eval(int32_t device, int32_t S, const double* interval, const in
  * search stays on the host); equals scipy.interpolate.make_lsq_spline.  MVUS_E_NUMERIC when a coefficient has no data. */
 int mvus_spline_lsq(int32_t device, int32_t num_knots, const double* knots, int64_t m, const double* t, const double* X, double* coefs);
 
+/* The smoothing-spline fit inside Scene.traj_to_spline (common.py:247, :267): scipy.interpolate.splprep(X, u=u, s=s, k=3), i.e.
+ * FITPACK parcur / fppara with iopt = 0, unit weights, ub = u[0], ue = u[m-1], nest = m + 6.  u[m] strictly increasing, X[3*m]
+ * (x(m) y(m) z(m)), s > 0.  Outputs: *n_out knots in t_out (room for m + 6), the n - 4 coefficients of dimension d at
+ * c_out[d * (m + 6) + j] (room for 3 * (m + 6)), *fp_out = the weighted residual sum of squares, *ier_out = FITPACK's ier
+ * (0 smoothing spline, -1 interpolating spline, -2 least-squares polynomial, 1..3 its warnings).  FITPACK's knot search
+ * (fpknot), root finding (fprati) and discontinuity jumps (fpdisc) are followed line by line; the least-squares problems are
+ * solved through banded normal equations on the device instead of row-wise Givens rotations -- same knots, coefficients to
+ * ~1e-9 relative on the fixtures (tests/test_traj_to_spline.py), and O(m + n) per pass where FITPACK's smoothing iteration is
+ * O(n^2).  The smooth_factor loop around it (common.py:241-262) is mvus_amd.spline.traj_fit.  Stateless; no CPU fallback. */
+int mvus_spline_smooth(int32_t device, int64_t m, const double* u, const double* X, double s, int32_t* n_out, double* t_out, double* c_out,
+                       double* fp_out, int32_t* ier_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -16,6 +16,7 @@
 #include "ba_schur_hip.hip.h"
 #include "triangulate.hip.h"
 #include "spline_ops.hip.h"
+#include "spline_fit.hip.h"
 
 namespace mvus {
 
@@ -498,6 +499,37 @@ struct CallBuffers {
 };
 }  // namespace
 
+
+// device work arrays of the smoothing fit in one precision (double, or double-double for ill-conditioned knot sets)
+template <class T>
+struct FitWork {
+  T *SB = nullptr, *G5 = nullptr, *BtB = nullptr, *Mx = nullptr, *Lf = nullptr, *rhs = nullptr, *yw = nullptr;
+  bool ready = false, penalty = false;
+  void alloc(CallBuffers& cb, size_t nest) {
+    if (ready) return;
+    SB = cb.get<T>((size_t)kFitBlk * nest); G5 = cb.get<T>(5 * nest); BtB = cb.get<T>(5 * nest); Mx = cb.get<T>(5 * nest);
+    Lf = cb.get<T>(5 * nest); rhs = cb.get<T>(3 * nest); yw = cb.get<T>(3 * nest);
+    ready = true;
+  }
+};
+static dim3 fit_blocks(long long cnt) { return dim3((unsigned)((cnt + 255) / 256)); }
+// least-squares spline on the current knots: normal equations from the span blocks, banded Cholesky, coefficients -> cd
+template <class T>
+static void fit_lsq_pass(hipStream_t st, FitWork<T>& w, long long m, const long long* first, const double* q, const double* dX, int ncoef, int nrint,
+                         double* cd, double* out, int* fail) {
+  constexpr int NT = sizeof(T) == sizeof(double) ? 256 : 64;
+  hipLaunchKernelGGL((k_fit_blocks<T, NT>), dim3(nrint), dim3(NT), 0, st, m, first, q, dX, w.SB);
+  hipLaunchKernelGGL(k_fit_band<T>, fit_blocks(ncoef), dim3(256), 0, st, ncoef, nrint, w.SB, w.G5, w.rhs);
+  hipLaunchKernelGGL((k_band_solve<3, T>), dim3(1), dim3(64), 0, st, ncoef, w.G5, w.rhs, w.Lf, w.yw, cd, out, fail);
+  w.penalty = false;
+}
+// smoothing spline for one value of p on the same knots (fit_lsq_pass has run in this precision)
+template <class T>
+static void fit_smooth_pass(hipStream_t st, FitWork<T>& w, int ncoef, int n8, const double* bd, double pinv, double* cd, double* out, int* fail) {
+  if (!w.penalty) { hipLaunchKernelGGL(k_fit_penalty<T>, fit_blocks(ncoef), dim3(256), 0, st, ncoef, n8, bd, w.BtB); w.penalty = true; }
+  hipLaunchKernelGGL(k_fit_combine<T>, fit_blocks(5ll * ncoef), dim3(256), 0, st, 5ll * ncoef, w.G5, w.BtB, pinv, w.Mx);
+  hipLaunchKernelGGL((k_band_solve<4, T>), dim3(1), dim3(64), 0, st, ncoef, w.Mx, w.rhs, w.Lf, w.yw, cd, out, fail);
+}
 
 template <class F>
 static int guarded(mvus_ba* h, F&& fn) {
@@ -991,6 +1023,172 @@ int mvus_spline_lsq(int32_t device, int32_t num_knots, const double* knots, int6
   } catch (const HipError& e) {
     g_create_error = e.msg;
     return MVUS_E_HIP;
+  }
+  return MVUS_OK;
+}
+
+/* scipy.interpolate.splprep(X, u=u, s=s, k=3) on the GPU (spline_fit.hip.h): fppara's control flow here, every pass over the
+ * samples and every banded solve on the device. */
+int mvus_spline_smooth(int32_t device, int64_t m, const double* u, const double* X, double s, int32_t* n_out, double* t_out, double* c_out,
+                       double* fp_out, int32_t* ier_out) {
+  constexpr int k = 3, k1 = 4, k2 = 5, nmin = 8, maxit = 20;
+  constexpr double tol = 0.001;
+  if (m <= k || m > (1ll << 30) || !u || !X || !n_out || !t_out || !c_out || !(s > 0.0) || !std::isfinite(s)) { g_create_error = "spline_smooth: bad arguments (m > 3 samples, s > 0)"; return MVUS_E_INVALID; }
+  for (int64_t i = 1; i < m; ++i) if (!(u[i] > u[i - 1])) { g_create_error = "spline_smooth: the timestamps must be strictly increasing"; return MVUS_E_INVALID; }
+  for (int64_t i = 0; i < 3 * m; ++i) if (!std::isfinite(X[i])) { g_create_error = "spline_smooth: non-finite sample"; return MVUS_E_INVALID; }
+  const int nest = (int)m + 2 * k, nmax = (int)m + k1;
+  try {
+    CallBuffers cb;
+    cb.open(device);
+    const double* du = cb.put(u, (size_t)m);
+    const double* dX = cb.put(X, 3 * (size_t)m);
+    int32_t* span = cb.get<int32_t>((size_t)m);
+    double* q = cb.get<double>(4 * (size_t)m);
+    double* term = cb.get<double>((size_t)m);
+    long long* first = cb.get<long long>((size_t)nest + 1);
+    double* cd = cb.get<double>(3 * (size_t)nest);
+    double* td = cb.get<double>((size_t)nest);
+    double* bd = cb.get<double>(5 * (size_t)nest);
+    double* out = cb.get<double>((size_t)nest + 4);       // [0] sum diag(L), [1] f_p, [2] min diag(L), [3] max diag(L), [4..] residual per span
+    int* fail = cb.get<int>(1);
+    FitWork<double> w1;
+    FitWork<dd> w2;
+    w1.alloc(cb, (size_t)nest);
+    bool precise = false;                                  // double-double from the first ill-conditioned pass on
+    int lsq_dd_n = -1;                                     // knot count whose normal equations w2 holds
+    MVUS_HIP(hipMemsetAsync(fail, 0, sizeof(int), cb.st));
+    std::vector<double> t((size_t)nest, 0.0), fpint((size_t)nest, 0.0), host((size_t)nest + 4, 0.0), b;
+    std::vector<int> nrdata((size_t)nest, 0);
+    const double ub = u[0], ue = u[m - 1], acc = tol * s;
+    int n = nmin, nplus = 0, ier = 0, nrint = 1, failed = 0;
+    double fpold = 0.0, fp0 = 0.0, fp = 0.0, p = -1.0;
+    nrdata[0] = (int)m - 2;
+    auto blocks = fit_blocks;
+    auto residual = [&](int ncoef, bool spans, int nspan) {            // c -> f_p (and the per-span residuals), fetched
+      hipLaunchKernelGGL(k_fit_residual, blocks(m), dim3(256), 0, cb.st, (long long)m, ncoef, span, q, dX, cd, term);
+      hipLaunchKernelGGL(k_fit_total, dim3(1), dim3(256), 0, cb.st, (long long)m, term, out + 1);
+      if (spans) hipLaunchKernelGGL(k_fit_fpint, dim3(nspan), dim3(256), 0, cb.st, nspan, first, term, out + 4);
+      MVUS_HIP(hipGetLastError());
+      MVUS_HIP(hipMemcpyAsync(host.data(), out, sizeof(double) * (4 + (spans ? nspan : 0)), hipMemcpyDeviceToHost, cb.st));
+      MVUS_HIP(hipMemcpyAsync(&failed, fail, sizeof(int), hipMemcpyDeviceToHost, cb.st));
+      MVUS_HIP(hipStreamSynchronize(cb.st));
+    };
+    // a pass in fp64; when its Cholesky breaks down or the factor's diagonal spans more than four decades (cond(A^T A) >= 1e8)
+    // the pass is repeated in double-double, and so is every later pass of this call
+    auto ill = [&] { return failed != 0 || !(host[3] <= 1e4 * host[2]); };
+    auto solve = [&](int ncoef, int nrint_, int n8, bool smoothing, double pinv) {
+      for (int attempt = 0; attempt < 2; ++attempt) {
+        if (!precise) {
+          if (!smoothing) fit_lsq_pass<double>(cb.st, w1, (long long)m, first, q, dX, ncoef, nrint_, cd, out, fail);
+          else fit_smooth_pass<double>(cb.st, w1, ncoef, n8, bd, pinv, cd, out, fail);
+        } else {
+          w2.alloc(cb, (size_t)nest);
+          if (lsq_dd_n != n) { fit_lsq_pass<dd>(cb.st, w2, (long long)m, first, q, dX, ncoef, nrint_, cd, out, fail); lsq_dd_n = n; }
+          if (smoothing) fit_smooth_pass<dd>(cb.st, w2, ncoef, n8, bd, pinv, cd, out, fail);
+        }
+        residual(ncoef, !smoothing, nrint_);
+        if (std::getenv("MVUS_DEBUG")) std::fprintf(stderr, "spline_smooth: n=%d %s %s  diag(L) %.3e..%.3e  fp %.6e  fail %d\n", n, smoothing ? "smooth" : "lsq",
+                                                    precise ? "dd" : "fp64", host[2], host[3], host[1], failed);
+        if (precise) {                                    // floored pivots are accepted here (see k_band_solve)
+          if (!std::isfinite(host[1])) throw HipError{"spline_smooth: a banded system is not positive definite"};
+          MVUS_HIP(hipMemsetAsync(fail, 0, sizeof(int), cb.st));
+          return;
+        }
+        if (!ill()) return;
+        precise = true;
+        MVUS_HIP(hipMemsetAsync(fail, 0, sizeof(int), cb.st));
+      }
+    };
+    int ncoef = 0;
+    for (;;) {                                             // fppara: do 200 iter = 1, m
+      if (n == nmin) ier = -2;
+      nrint = n - nmin + 1;
+      ncoef = n - k1;
+      for (int j = 0; j < k1; ++j) { t[j] = ub; t[n - 1 - j] = ue; }
+      MVUS_HIP(hipMemcpyAsync(td, t.data(), sizeof(double) * n, hipMemcpyHostToDevice, cb.st));
+      MVUS_HIP(hipStreamSynchronize(cb.st));               // t is modified on the host below
+      hipLaunchKernelGGL(k_fit_basis, blocks(m), dim3(256), 0, cb.st, (long long)m, du, td, ncoef, span, q);
+      hipLaunchKernelGGL(k_fit_first, blocks(nrint + 1), dim3(256), 0, cb.st, (long long)m, du, td, nrint, first);
+      solve(ncoef, nrint, 0, false, 0.0);
+      fp = host[1];
+      if (ier == -2) fp0 = fp;
+      double fpms = fp - s;
+      if (std::fabs(fpms) < acc) break;
+      if (fpms < 0.0) {
+        if (ier == -2) break;                              // the least-squares polynomial is acceptable
+        // ---- part 2: the smoothing spline, F(p) = s ----
+        fitpack::fpdisc(t, n, b);
+        const int n8 = n - nmin;
+        MVUS_HIP(hipMemcpyAsync(bd, b.data(), sizeof(double) * b.size(), hipMemcpyHostToDevice, cb.st));
+        double p1 = 0.0, f1 = fp0 - s, p3 = -1.0, f3 = fpms;
+        p = (double)ncoef / host[0];
+        int ich1 = 0, ich3 = 0;
+        for (int iter = 1; iter <= maxit; ++iter) {
+          solve(ncoef, nrint, n8, true, 1.0 / p);
+          fp = host[1];
+          fpms = fp - s;
+          if (std::fabs(fpms) < acc) break;
+          if (iter == maxit) { ier = 3; break; }
+          const double p2 = p, f2 = fpms;
+          if (ich3 == 0) {
+            if (f2 - f3 <= acc) {                          // the initial choice of p is too large
+              p3 = p2; f3 = f2;
+              p = p * 0.04;
+              if (p <= p1) p = p1 * 0.9 + p2 * 0.1;
+              continue;
+            }
+            if (f2 < 0.0) ich3 = 1;
+          }
+          if (ich1 == 0) {
+            if (f1 - f2 <= acc) {                          // the initial choice of p is too small
+              p1 = p2; f1 = f2;
+              p = p / 0.04;
+              if (p3 < 0.0) continue;
+              if (p >= p3) p = p2 * 0.1 + p3 * 0.9;
+              continue;
+            }
+            if (f2 > 0.0) ich1 = 1;
+          }
+          if (f2 >= f1 || f2 <= f3) { ier = 2; break; }
+          p = fitpack::fprati(p1, f1, p2, f2, p3, f3);
+        }
+        if (ier < 0) ier = 0;
+        break;
+      }
+      if (n == nmax) { ier = -1; break; }
+      if (n == nest) { ier = 1; break; }
+      // ---- more knots ----
+      if (ier == 0) {
+        int npl1 = nplus * 2;
+        const double rn = nplus;
+        if (fpold - fp > acc) npl1 = (int)(rn * fpms / (fpold - fp));
+        nplus = std::min(nplus * 2, std::max(std::max(npl1, nplus / 2), 1));
+      } else {
+        nplus = 1;
+        ier = 0;
+      }
+      fpold = fp;
+      for (int j = 0; j < nrint; ++j) fpint[j] = host[4 + j];
+      for (int l = 0; l < nplus; ++l) {
+        fitpack::fpknot(u, t, n, fpint, nrdata, nrint);
+        if (n == nmax || n == nest) break;
+      }
+      if (n == nmax) {                                      // fppara label 10: the knots of the interpolating spline
+        int i = k2, j = k / 2 + 2;
+        for (int l = 0; l < (int)m - k1; ++l) { t[i - 1] = u[j - 1]; ++i; ++j; }
+      }
+    }
+    std::vector<double> ch(3 * (size_t)ncoef);
+    MVUS_HIP(hipMemcpyAsync(ch.data(), cd, sizeof(double) * 3 * ncoef, hipMemcpyDeviceToHost, cb.st));
+    MVUS_HIP(hipStreamSynchronize(cb.st));
+    for (int d = 0; d < 3; ++d) for (int j = 0; j < ncoef; ++j) c_out[(size_t)d * nest + j] = ch[(size_t)d * ncoef + j];
+    for (int j = 0; j < n; ++j) t_out[j] = t[j];
+    *n_out = n;
+    if (fp_out) *fp_out = fp;
+    if (ier_out) *ier_out = ier;
+  } catch (const HipError& e) {
+    g_create_error = e.msg;
+    return e.msg.find("positive definite") != std::string::npos ? MVUS_E_NUMERIC : MVUS_E_HIP;
   }
   return MVUS_OK;
 }

@@ -1,0 +1,426 @@
+// Smoothing-spline fit of a 3-D trajectory on the GPU: Scene.traj_to_spline's scipy.interpolate.splprep(X, u=t, s=s, k=3)
+// (reference common.py:247, 267), i.e. FITPACK parcur / fppara (Dierckx) with iopt = 0, w = 1, nest = m + 2k.
+//
+// Same algorithm, different linear algebra.  fppara's control flow runs on the host (fit_smoothing_spline below: knots are
+// added where the residual of the least-squares spline is largest until f(p = inf) <= s, then the smoothing parameter p with
+// F(p) = s is found by rational interpolation -- fpknot, fprati and fpdisc are restated line by line, they are O(knots) integer
+// / scalar work).  Everything that touches the m samples or solves a system runs on the device:
+//   k_fit_basis      knot span + the four cubic B-splines of every sample (the fpbspl recurrence of ba_math.h)
+//   k_fit_blocks     per knot span: sum of h h^T and h x^T over its samples (fixed-order tree per workgroup)
+//   k_fit_band       banded normal equations A^T A (half-bandwidth 3) and A^T X from <= 4 span blocks per entry
+//   k_fit_penalty    B^T B of fpdisc's discontinuity-jump matrix (half-bandwidth 4);  k_fit_combine: A^T A + B^T B / p^2 (fppara rotates the rows of B in with weight 1/p)
+//   k_band_solve     banded Cholesky + both substitutions, one wavefront, the previous rows in registers; in fp64, and again in
+//                    double-double when a pivot is lost to rounding (knot sets close to interpolation: cond(A) ~ 1e10)
+//   k_fit_residual   per-sample squared residual;  k_fit_fpint: per-span sums with FITPACK's half/half rule for the sample
+//                    that sits on a knot, and the total f_p
+// FITPACK rotates every observation row (and, in the p iteration, every row of B all the way down the band: O(n^2)) into a
+// triangle with Givens rotations, one after the other; the normal equations give the same splines (same knots on every fixture
+// and seeded case of tests/test_traj_to_spline.py, coefficients to ~1e-9 relative) in O(m + n) parallel work per pass.
+#pragma once
+#include <cmath>
+#include <vector>
+
+#include "ba_math.h"
+
+namespace mvus {
+
+// Double-double arithmetic (~32 digits) for the passes whose normal equations are too ill conditioned for fp64: a knot set
+// with almost as many knots as samples can push cond(A) to 1e10 (cond(A^T A) = 1e20); FITPACK's Givens rotations work on A
+// itself.  Products of doubles are exact (FMA), sums carry their rounding error.
+// The error-free transformations below are only error free when every operation rounds on its own: no fusing of a product
+// with a neighbouring sum (hipcc contracts by default).
+#if defined(__clang__)
+#define MVUS_NO_CONTRACT _Pragma("clang fp contract(off)")
+#else
+#define MVUS_NO_CONTRACT
+#endif
+struct dd {
+  double hi, lo;
+  dd() = default;
+  MVUS_HD dd(double h) : hi(h), lo(0.0) {}
+  MVUS_HD dd(double h, double l) : hi(h), lo(l) {}
+};
+MVUS_HD dd dd_quick(double a, double b) { MVUS_NO_CONTRACT const double s = a + b; return dd(s, b - (s - a)); }
+MVUS_HD dd dd_two_sum(double a, double b) { MVUS_NO_CONTRACT const double s = a + b, bb = s - a; return dd(s, (a - (s - bb)) + (b - bb)); }
+MVUS_HD dd dd_two_prod(double a, double b) { MVUS_NO_CONTRACT const double p = a * b; return dd(p, fma(a, b, -p)); }
+MVUS_HD dd operator+(dd a, dd b) { MVUS_NO_CONTRACT dd s = dd_two_sum(a.hi, b.hi); s.lo += a.lo + b.lo; return dd_quick(s.hi, s.lo); }
+MVUS_HD dd operator-(dd a) { return dd(-a.hi, -a.lo); }
+MVUS_HD dd operator-(dd a, dd b) { return a + (-b); }
+MVUS_HD dd operator*(dd a, dd b) { MVUS_NO_CONTRACT dd p = dd_two_prod(a.hi, b.hi); p.lo += a.hi * b.lo + a.lo * b.hi; return dd_quick(p.hi, p.lo); }
+MVUS_HD dd operator/(dd a, dd b) {
+  MVUS_NO_CONTRACT
+  const double q1 = a.hi / b.hi;
+  dd r = a - b * dd(q1);
+  const double q2 = r.hi / b.hi;
+  r = r - b * dd(q2);
+  const double q3 = r.hi / b.hi;
+  return dd_quick(q1, q2) + dd(q3);
+}
+MVUS_HD dd& operator+=(dd& a, dd b) { a = a + b; return a; }
+MVUS_HD dd& operator-=(dd& a, dd b) { a = a - b; return a; }
+MVUS_HD dd& operator/=(dd& a, dd b) { a = a / b; return a; }
+MVUS_HD dd num_sqrt(dd a) {                        // Karp / Markstein: one correction of the fp64 square root
+  MVUS_NO_CONTRACT
+  const double x = 1.0 / sqrt(a.hi), ax = a.hi * x;
+  const dd r = a - dd_two_prod(ax, ax);
+  return dd_two_sum(ax, r.hi * (x * 0.5));
+}
+MVUS_HD double num_sqrt(double a) { return sqrt(a); }
+MVUS_HD double to_double(double a) { return a; }
+MVUS_HD double to_double(dd a) { return a.hi + a.lo; }
+MVUS_HD bool is_positive(double a) { return a > 0.0; }
+MVUS_HD bool is_positive(dd a) { return a.hi > 0.0; }
+MVUS_HD double pivot_floor(double) { return 1e-12; }       // a Cholesky pivot below this fraction of its diagonal entry is lost to rounding
+MVUS_HD double pivot_floor(dd) { return 1e-24; }
+MVUS_HD double num_prod(double a, double b, double) { return a * b; }          // a * b in the precision of the third argument
+MVUS_HD dd num_prod(double a, double b, dd) { return dd_two_prod(a, b); }
+
+#if defined(__HIPCC__)
+constexpr int kFitBlk = 22;      // per span: 10 products h_a h_b (a >= b) + 12 products h_a x_d
+
+
+__global__ __launch_bounds__(256) void k_fit_basis(long long m, const double* __restrict__ u, const double* __restrict__ t, int ncoef,
+                                                   int32_t* __restrict__ span, double* __restrict__ q) {
+  const long long i = blockIdx.x * 256ll + threadIdx.x;
+  if (i >= m) return;
+  const double x = u[i];
+  const int l = find_span(t, ncoef, x);
+  double h[4], dh[4];
+  bspline_basis<false>(t, l, x, h, dh);
+  span[i] = l - 3;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) q[4 * i + a] = h[a];
+}
+
+// first sample of every span (samples are sorted): first[sp] = lower_bound(u, t[3 + sp]), first[nspan] = m
+__global__ __launch_bounds__(256) void k_fit_first(long long m, const double* __restrict__ u, const double* __restrict__ t, int nspan,
+                                                   long long* __restrict__ first) {
+  const int sp = blockIdx.x * 256 + threadIdx.x;
+  if (sp > nspan) return;
+  if (sp == nspan) { first[sp] = m; return; }
+  if (sp == 0) { first[0] = 0; return; }
+  const double knot = t[3 + sp];
+  long long lo = 0, hi = m;                          // first index with u >= knot
+  while (lo < hi) { const long long mid = (lo + hi) >> 1; if (u[mid] < knot) lo = mid + 1; else hi = mid; }
+  first[sp] = lo;
+}
+
+// fixed-order sum of NV values per thread over one workgroup of NT -> thread 0 holds the result in v[]
+template <int NV, int NT = 256, class T = double>
+__device__ __forceinline__ void block_sum(T (&v)[NV], T* lds) {
+  const int tid = threadIdx.x;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < NV; ++k) lds[k * NT + tid] = v[k];
+  __syncthreads();
+  for (int off = NT / 2; off > 0; off >>= 1) {
+    if (tid < off) {
+#pragma unroll
+      for (int k = 0; k < NV; ++k) lds[k * NT + tid] = lds[k * NT + tid] + lds[k * NT + tid + off];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int k = 0; k < NV; ++k) v[k] = lds[k * NT];
+}
+
+template <class T, int NT>
+__global__ __launch_bounds__(NT) void k_fit_blocks(long long m, const long long* __restrict__ first, const double* __restrict__ q,
+                                                   const double* __restrict__ X, T* __restrict__ SB) {
+  __shared__ T lds[kFitBlk * NT];
+  const int sp = blockIdx.x;
+  T v[kFitBlk];
+#pragma unroll
+  for (int k = 0; k < kFitBlk; ++k) v[k] = T(0.0);
+  for (long long i = first[sp] + threadIdx.x; i < first[sp + 1]; i += NT) {
+    double h[4], x[3];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) h[a] = q[4 * i + a];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) x[d] = X[(long long)d * m + i];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+#pragma unroll
+      for (int b = 0; b <= a; ++b) v[a * (a + 1) / 2 + b] += num_prod(h[a], h[b], T());
+#pragma unroll
+      for (int d = 0; d < 3; ++d) v[10 + 3 * a + d] += num_prod(h[a], x[d], T());
+    }
+  }
+  block_sum<kFitBlk, NT, T>(v, lds);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < kFitBlk; ++k) SB[(long long)sp * kFitBlk + k] = v[k];
+  }
+}
+
+// lower banded storage, width W = HB + 1: G[j * W + w] = M(j, j - w).  Here the normal equations in a width-5 array (w = 4
+// zero) so that the penalty can be added in place, and rhs[d * ncoef + j].
+template <class T>
+__global__ __launch_bounds__(256) void k_fit_band(int ncoef, int nspan, const T* __restrict__ SB, T* __restrict__ G5, T* __restrict__ rhs) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= ncoef) return;
+  T g[5] = {T(0.0), T(0.0), T(0.0), T(0.0), T(0.0)}, r[3] = {T(0.0), T(0.0), T(0.0)};
+  for (int sp = max(0, j - 3); sp <= min(nspan - 1, j); ++sp) {          // spans whose four coefficients include j
+    const int a = j - sp;
+    const T* blk = SB + (long long)sp * kFitBlk;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) if (a - w >= 0) g[w] += blk[a * (a + 1) / 2 + (a - w)];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) r[d] += blk[10 + 3 * a + d];
+  }
+#pragma unroll
+  for (int w = 0; w < 5; ++w) G5[5 * (long long)j + w] = g[w];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) rhs[(long long)d * ncoef + j] = r[d];
+}
+
+// BtB[j * 5 + w] = (B^T B)(j, j - w) for the n8 x ncoef jump matrix B whose row `it` holds b[it * 5 + c] in column it + c
+template <class T>
+__global__ __launch_bounds__(256) void k_fit_penalty(int ncoef, int n8, const double* __restrict__ b, T* __restrict__ BtB) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= ncoef) return;
+  T g[5] = {T(0.0), T(0.0), T(0.0), T(0.0), T(0.0)};
+  for (int it = max(0, j - 4); it <= min(n8 - 1, j); ++it) {
+    const int cj = j - it;
+#pragma unroll
+    for (int w = 0; w < 5; ++w) if (cj - w >= 0) g[w] += num_prod(b[5 * (long long)it + cj], b[5 * (long long)it + cj - w], T());
+  }
+#pragma unroll
+  for (int w = 0; w < 5; ++w) BtB[5 * (long long)j + w] = g[w];
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void k_fit_combine(long long count, const T* __restrict__ G5, const T* __restrict__ BtB, double pinv, T* __restrict__ M) {
+  const long long e = blockIdx.x * 256ll + threadIdx.x;
+  if (e < count) M[e] = G5[e] + (T(pinv) * T(pinv)) * BtB[e];        // fppara rotates the rows of B in with weight 1/p
+}
+
+// Banded Cholesky M = L L^T (lower band, row stride 5, HB = 3 or 4 sub-diagonals used) and the solves for the three
+// right-hand sides, ONE wavefront: every lane runs the factor recurrence (no exchange between lanes), the previous HB rows
+// of L stay in registers, the next row of M is fetched while the current one is processed; lanes 0..2 carry one right-hand
+// side each.  L (stride 5) and the solution go to Lout / c; out[0] = sum of the diagonal of L (FITPACK's sum of a(i,1)).
+template <int HB, class T>
+__global__ __launch_bounds__(64) void k_band_solve(int n, const T* __restrict__ M, const T* __restrict__ rhs, T* __restrict__ Lout, T* __restrict__ ywork,
+                                                   double* __restrict__ c, double* __restrict__ out, int* __restrict__ fail) {
+  const int lane = threadIdx.x;
+  const int d = lane < 3 ? lane : 0;
+  const T* bvec = rhs + (long long)d * n;
+  T* yv = ywork + (long long)d * n;
+  double* cv = c + (long long)d * n;
+  T Lp[HB + 1][HB + 1];               // Lp[u][w] = L(j-u, j-u-w), u = 1..HB
+  T yp[HB + 1];                       // yp[u] = y(j-u)
+#pragma unroll
+  for (int u2 = 0; u2 <= HB; ++u2) {
+    yp[u2] = T(0.0);
+#pragma unroll
+    for (int w = 0; w <= HB; ++w) Lp[u2][w] = (w == 0) ? T(1.0) : T(0.0);
+  }
+  T nxt[HB + 1], nb = T(0.0);
+#pragma unroll
+  for (int w = 0; w <= HB; ++w) nxt[w] = n > 0 ? M[w] : T(0.0);
+  nb = n > 0 ? bvec[0] : T(0.0);
+  double dsum = 0.0, dmin = 1e300, dmax = 0.0;
+  bool bad = false;
+  for (int j = 0; j < n; ++j) {
+    T row[HB + 1];
+#pragma unroll
+    for (int w = 0; w <= HB; ++w) row[w] = nxt[w];
+    const T bj = nb;
+    if (j + 1 < n) {
+#pragma unroll
+      for (int w = 0; w <= HB; ++w) nxt[w] = M[5 * (long long)(j + 1) + w];
+      nb = bvec[j + 1];
+    }
+#pragma unroll
+    for (int w = HB; w >= 1; --w) {                 // L(j, j-w)
+      T v = row[w];
+#pragma unroll
+      for (int u2 = w + 1; u2 <= HB; ++u2) v -= row[u2] * Lp[w][u2 - w];
+      row[w] = (j - w >= 0) ? v / Lp[w][0] : T(0.0);
+    }
+    // A pivot that cancels to (almost) nothing means a direction the samples do not determine: FITPACK's knot search does
+    // produce such knot sets close to interpolation, its Givens triangle then holds a rounding-noise diagonal entry.  The
+    // residual does not depend on how that direction is resolved (the normal equations are consistent), so the pivot is
+    // floored instead of failing; the caller repeats an fp64 pass with floored pivots in double-double.
+    const T floor_ = T(pivot_floor(T()) * to_double(row[0]));
+    T dg = row[0];
+#pragma unroll
+    for (int u2 = 1; u2 <= HB; ++u2) dg -= row[u2] * row[u2];
+    const bool lost = !(to_double(dg) > to_double(floor_));
+    bad |= lost;
+    dg = lost ? (is_positive(floor_) ? floor_ : T(1.0)) : dg;
+    row[0] = num_sqrt(dg);
+    const double dl = to_double(row[0]);
+    dsum += dl; dmin = fmin(dmin, dl); dmax = fmax(dmax, dl);
+    T y = bj;
+#pragma unroll
+    for (int u2 = 1; u2 <= HB; ++u2) y -= row[u2] * yp[u2];
+    y /= row[0];
+    if (lane == 0) {
+#pragma unroll
+      for (int w = 0; w <= HB; ++w) Lout[5 * (long long)j + w] = row[w];
+    }
+    if (lane < 3) yv[j] = y;
+#pragma unroll
+    for (int u2 = HB; u2 >= 2; --u2) {
+      yp[u2] = yp[u2 - 1];
+#pragma unroll
+      for (int w = 0; w <= HB; ++w) Lp[u2][w] = Lp[u2 - 1][w];
+    }
+    yp[1] = y;
+#pragma unroll
+    for (int w = 0; w <= HB; ++w) Lp[1][w] = row[w];
+  }
+  if (lane == 0) { out[0] = dsum; out[2] = dmin; out[3] = dmax; if (bad) fail[0] = 1; }
+  __syncthreads();                                   // Lout / y written by this wavefront are read back below
+  __threadfence_block();
+  // L^T c = y: c(j) = (y(j) - sum_u L(j+u, j) c(j+u)) / L(j,j)
+  T Ln[HB + 1][HB + 1];               // Ln[u][w] = L(j+u, j+u-w)
+  T cn[HB + 1];
+#pragma unroll
+  for (int u2 = 0; u2 <= HB; ++u2) {
+    cn[u2] = T(0.0);
+#pragma unroll
+    for (int w = 0; w <= HB; ++w) Ln[u2][w] = T(0.0);
+  }
+  for (int j = n - 1; j >= 0; --j) {
+    T row[HB + 1];
+#pragma unroll
+    for (int w = 0; w <= HB; ++w) row[w] = Lout[5 * (long long)j + w];
+    T v = lane < 3 ? yv[j] : T(0.0);
+#pragma unroll
+    for (int u2 = 1; u2 <= HB; ++u2) v -= Ln[u2][u2] * cn[u2];
+    v /= row[0];
+    if (lane < 3) cv[j] = to_double(v);
+#pragma unroll
+    for (int u2 = HB; u2 >= 2; --u2) {
+      cn[u2] = cn[u2 - 1];
+#pragma unroll
+      for (int w = 0; w <= HB; ++w) Ln[u2][w] = Ln[u2 - 1][w];
+    }
+    cn[1] = v;
+#pragma unroll
+    for (int w = 0; w <= HB; ++w) Ln[1][w] = row[w];
+  }
+}
+
+// squared residual of every sample, in fppara's order of operations (fac = sum_j c(j) q(it, j); term += (fac - x)^2)
+__global__ __launch_bounds__(256) void k_fit_residual(long long m, int ncoef, const int32_t* __restrict__ span, const double* __restrict__ q,
+                                                      const double* __restrict__ X, const double* __restrict__ c, double* __restrict__ term) {
+  const long long i = blockIdx.x * 256ll + threadIdx.x;
+  if (i >= m) return;
+  const int sp = span[i];
+  double tsum = 0.0;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    double fac = 0.0;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) fac = fac + c[(long long)d * ncoef + sp + a] * q[4 * i + a];
+    const double r = fac - X[(long long)d * m + i];
+    tsum = tsum + r * r;
+  }
+  term[i] = tsum;
+}
+
+// per-span residual: the first sample of a span (it is the first with u >= the knot that opens the span) is shared half / half
+// with the span before, like fppara's `new` / `store` bookkeeping
+__global__ __launch_bounds__(256) void k_fit_fpint(int nspan, const long long* __restrict__ first, const double* __restrict__ term, double* __restrict__ fpint) {
+  __shared__ double lds[256];
+  const int sp = blockIdx.x;
+  const long long a = first[sp], b = first[sp + 1];
+  double v[1] = {0.0};
+  for (long long i = a + (sp > 0 ? 1 : 0) + threadIdx.x; i < b; i += 256) v[0] += term[i];
+  block_sum<1>(v, lds);
+  if (threadIdx.x == 0) {
+    double s = v[0];
+    if (sp > 0 && a < b) s += 0.5 * term[a];
+    if (sp + 1 < nspan && first[sp + 1] < first[sp + 2]) s += 0.5 * term[b];
+    fpint[sp] = s;
+  }
+}
+
+// total of `count` values, one workgroup, fixed order
+__global__ __launch_bounds__(256) void k_fit_total(long long count, const double* __restrict__ v_in, double* __restrict__ out) {
+  __shared__ double lds[256];
+  double v[1] = {0.0};
+  for (long long i = threadIdx.x; i < count; i += 256) v[0] += v_in[i];
+  block_sum<1>(v, lds);
+  if (threadIdx.x == 0) out[0] = v[0];
+}
+#endif
+
+// ---- host side of fppara ------------------------------------------------------------------------------------------------
+namespace fitpack {
+
+// fpdisc.f for k = 3 (k2 = 5): b[(n - 8) * 5], 0-based row l - k2 for l = k2..nk1
+inline void fpdisc(const std::vector<double>& t, int n, std::vector<double>& b) {
+  const int k2 = 5, k1 = 4, k = 3, nk1 = n - k1, nrint = nk1 - k;
+  const double an = nrint, fac = an / (t[nk1] - t[k1 - 1]);
+  b.assign((size_t)std::max(0, n - 2 * k1) * k2, 0.0);
+  double h[8];
+  for (int l = k2; l <= nk1; ++l) {
+    const int lmk = l - k1;
+    for (int j = 1; j <= k1; ++j) {
+      const int ik = j + k1, lj = l + j, lk = lj - k2;
+      h[j - 1] = t[l - 1] - t[lk - 1];
+      h[ik - 1] = t[l - 1] - t[lj - 1];
+    }
+    int lp = lmk;
+    for (int j = 1; j <= k2; ++j) {
+      int jk = j;
+      double prod = h[j - 1];
+      for (int i = 1; i <= k; ++i) { jk = jk + 1; prod = prod * h[jk - 1] * fac; }
+      const int lk = lp + k1;
+      b[(size_t)(lmk - 1) * k2 + (j - 1)] = (t[lk - 1] - t[lp - 1]) / prod;
+      lp = lp + 1;
+    }
+  }
+}
+
+// fpknot.f: one more knot, in the interval with the largest residual that still holds samples (1-based bookkeeping kept)
+inline void fpknot(const double* x, std::vector<double>& t, int& n, std::vector<double>& fpint, std::vector<int>& nrdata, int& nrint) {
+  const int k = (n - nrint - 1) / 2;
+  double fpmax = 0.0;
+  int jbegin = 1, number = 0, maxpt = 0, maxbeg = 0;
+  for (int j = 1; j <= nrint; ++j) {
+    const int jpoint = nrdata[j - 1];
+    if (!(fpmax >= fpint[j - 1] || jpoint == 0)) { fpmax = fpint[j - 1]; number = j; maxpt = jpoint; maxbeg = jbegin; }
+    jbegin = jbegin + jpoint + 1;
+  }
+  const int ihalf = maxpt / 2 + 1, nrx = maxbeg + ihalf, next = number + 1;
+  if (next <= nrint) {
+    for (int j = next; j <= nrint; ++j) {
+      const int jj = next + nrint - j;
+      fpint[jj] = fpint[jj - 1];
+      nrdata[jj] = nrdata[jj - 1];
+      const int jk = jj + k;
+      t[jk] = t[jk - 1];
+    }
+  }
+  nrdata[number - 1] = ihalf - 1;
+  nrdata[next - 1] = maxpt - ihalf;
+  const double am = maxpt;
+  double an = nrdata[number - 1];
+  fpint[number - 1] = fpmax * an / am;
+  an = nrdata[next - 1];
+  fpint[next - 1] = fpmax * an / am;
+  const int jk = next + k;
+  t[jk - 1] = x[nrx - 1];
+  n = n + 1;
+  nrint = nrint + 1;
+}
+
+inline double fprati(double& p1, double& f1, double p2, double f2, double& p3, double& f3) {
+  double p;
+  if (p3 > 0.0) {
+    const double h1 = f1 * (f2 - f3), h2 = f2 * (f3 - f1), h3 = f3 * (f1 - f2);
+    p = -(p1 * p2 * h3 + p2 * p3 * h1 + p3 * p1 * h2) / (p1 * h1 + p2 * h2 + p3 * h3);
+  } else {
+    p = (p1 * (f1 - f3) * f2 - p2 * (f2 - f3) * f1) / ((f1 - f2) * f3);
+  }
+  if (f2 < 0.0) { p3 = p2; f3 = f2; } else { p1 = p2; f1 = f2; }
+  return p;
+}
+
+}  // namespace fitpack
+}  // namespace mvus

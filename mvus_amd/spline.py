@@ -3,8 +3,10 @@
 ``evaluate``   = the evaluation inside ``Scene.spline_to_traj`` (reference common.py:273-301; scipy ``splev``)
 ``lsq_fit``    = least-squares coefficients on a fixed knot vector (the refit step of ``traj_to_spline`` once the knots are
                  placed; scipy ``make_lsq_spline``)
-FITPACK's adaptive knot placement inside the reference's smooth_factor loop (common.py:224-270) stays on the host
-(``Scene.traj_to_spline``).  No CPU fallback: without libmvusba.so / a GPU these raise."""
+``smooth_fit``  = ``scipy.interpolate.splprep(X, u=t, s=s, k=3)``: FITPACK's adaptive knot placement and smoothing-parameter search
+                 with the sample passes and banded solves on the GPU (``mvus_spline_smooth``)
+``traj_fit``    = the reference's smooth_factor loop around it (common.py:241-262): one interval of ``Scene.traj_to_spline``
+No CPU fallback: without libmvusba.so / a GPU these raise."""
 import ctypes
 
 import numpy as np
@@ -52,3 +54,49 @@ def lsq_fit(knots, t, X, device=0):
     if rc != 0:
         _err(lib, rc, 'mvus_spline_lsq')
     return [c[0].copy(), c[1].copy(), c[2].copy()]
+
+
+def smooth_fit(t, X, s, device=0, full_output=False):
+    """``scipy.interpolate.splprep(X, u=t, s=s, k=3)[0]``: the tck ``[knots, [cx, cy, cz], 3]`` of the smoothing cubic spline
+    through X[3, m] at the strictly increasing timestamps t[m].  ``full_output``: also (fp, ier) as FITPACK reports them."""
+    lib = _lib.load()
+    t = np.ascontiguousarray(t, dtype=np.float64)
+    X = np.ascontiguousarray(np.asarray(X, dtype=np.float64))
+    if t.ndim != 1 or X.shape != (3, t.size):
+        raise ValueError('X must be 3 x len(t)')
+    nest = t.size + 6
+    n = ctypes.c_int32(0)
+    ier = ctypes.c_int32(0)
+    fp = ctypes.c_double(0.0)
+    knots = np.zeros(nest)
+    c = np.zeros((3, nest))
+    rc = lib.mvus_spline_smooth(int(device), t.size, _lib.dptr(t), _lib.dptr(X), float(s), ctypes.byref(n), _lib.dptr(knots), _lib.dptr(c),
+                                ctypes.byref(fp), ctypes.byref(ier))
+    if rc != 0:
+        _err(lib, rc, 'mvus_spline_smooth')
+    nk = n.value
+    tck = [knots[:nk].copy(), [c[d, :nk - 4].copy() for d in range(3)], 3]
+    return (tck, fp.value, ier.value) if full_output else tck
+
+
+def traj_fit(part, smooth_factor, device=0):
+    """One interval of ``Scene.traj_to_spline`` (reference common.py:236-262): ``part`` = [t; x; y; z] (4, m).  The smoothing
+    factor starts at 1e-6 * duration and is divided by 1.5 / doubled until duration / #coefficients lies between the two
+    ``smooth_factor`` bounds (or the fit is down to 4 coefficients and still too dense).  Returns the tck."""
+    lo, hi = min(smooth_factor), max(smooth_factor)
+    measure = part[0, -1] - part[0, 0]
+    s = (1e-3) ** 2 * measure
+    prev, direction = 0, 0
+    while True:
+        tck = smooth_fit(part[0], part[1:], s, device=device)
+        n = len(tck[0]) - 4
+        if n == prev and n == 4 and direction == 2:
+            break
+        prev = n
+        if measure / n > hi:
+            s, direction = s / 1.5, 1
+        elif measure / n < lo:
+            s, direction = s * 2, 2
+        else:
+            break
+    return tck

@@ -64,23 +64,6 @@ def test_align_gt_input_handling(tmp_path):
         compare_gt.align_gt(scene, 5.0, np.zeros((5, 7)), verbose=False)
 
 
-def test_traj_to_spline_and_back_match_the_reference():
-    """Spline maintenance either side of BA (common.py:224-301) against the reference's own output
-    (tests/golden/traj_spline.npz from tests/golden/make_golden_spline.py): same intervals, knots and coefficients from the
-    smoothing loop, same resampled trajectories."""
-    import os
-    from golden_util import GOLDEN_DIR
-    g = dict(np.load(os.path.join(GOLDEN_DIR, 'traj_spline.npz')))
-    s = common.Scene()
-    s.traj = g['traj'].copy()
-    sp = s.traj_to_spline(smooth_factor=list(g['smooth_factor']))
-    np.testing.assert_array_equal(sp['int'], g['interval'])
-    assert len(sp['tck']) == int(g['n_int'])
-    for i, tck in enumerate(sp['tck']):
-        np.testing.assert_allclose(tck[0], g['knots_%d' % i], rtol=0, atol=1e-12)
-        np.testing.assert_allclose(np.asarray(tck[1]), g['coefs_%d' % i], rtol=0, atol=1e-9)
-
-
 @pytest.mark.gpu
 def test_spline_to_traj_matches_the_reference():
     """Scene.spline_to_traj (common.py:273-301) with the evaluation on the GPU, against the reference's resampled

@@ -1,0 +1,214 @@
+"""Scene.traj_to_spline (reference common.py:224-270) = FITPACK ``splprep`` inside the smooth_factor loop.
+
+* the oracle (oracle/fitpack_oracle.py, a line-by-line restatement of fppara) is pinned against scipy's own splprep and against
+  the golden fixture written by the REAL reference's traj_to_spline (tests/golden/traj_spline.npz, make_golden_spline.py);
+* the GPU path (mvus_spline_smooth behind mvus_amd.spline.smooth_fit / traj_fit and Scene.traj_to_spline) is compared with
+  the oracle, with scipy and with that fixture: identical knot vectors, coefficients to 1e-8 absolute (values ~10).
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+from scipy import interpolate
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from golden_util import GOLDEN_DIR                      # noqa: E402
+from mvus_amd.reconstruction import common              # noqa: E402
+from oracle import fitpack_oracle as fo                 # noqa: E402
+
+COEF_ATOL = 1e-8
+
+
+def _trajectory(seed, m, noise=0.02, speed=1.0):
+    rng = np.random.default_rng(seed)
+    u = np.cumsum(rng.uniform(0.5, 1.5, m))
+    X = np.vstack([10 * np.sin(u / 80 * speed), 10 * np.cos(u / 95), 30 + 3 * np.sin(u / 50)]) + rng.normal(0, noise, (3, m))
+    return u, X
+
+
+def _golden():
+    return dict(np.load(os.path.join(GOLDEN_DIR, 'traj_spline.npz')))
+
+
+def _parts(g):
+    traj = g['traj']
+    for i in range(int(g['n_int'])):
+        keep = (traj[0] >= g['interval'][0, i]) & (traj[0] <= g['interval'][1, i])
+        yield i, traj[:, keep]
+
+
+def _reference_loop(part, smooth_factor, fit):
+    """common.py:236-262 with ``fit(X, u, s) -> tck``; returns (tck, s of the accepted fit, number of fits)."""
+    lo, hi = min(smooth_factor), max(smooth_factor)
+    measure = part[0, -1] - part[0, 0]
+    s = (1e-3) ** 2 * measure
+    prev, direction, calls = 0, 0, 0
+    while True:
+        tck = fit(part[1:], part[0], s)
+        calls += 1
+        n = len(tck[0]) - 4
+        if n == prev and n == 4 and direction == 2:
+            break
+        prev = n
+        if measure / n > hi:
+            s, direction = s / 1.5, 1
+        elif measure / n < lo:
+            s, direction = s * 2, 2
+        else:
+            break
+    return tck, s, calls
+
+
+CASES = [  # seed, samples, s as a multiple of the duration or absolute
+    (0, 120, ('rel', 1e-6)), (1, 90, ('rel', 1e-4)), (2, 150, ('abs', 0.05)), (3, 200, ('abs', 1.0)), (4, 80, ('abs', 50.0)),
+    (5, 60, ('abs', 5e3)),
+]
+
+
+def _s_of(u, spec):
+    return spec[1] * (u[-1] - u[0]) if spec[0] == 'rel' else spec[1]
+
+
+@pytest.mark.parametrize('seed,m,spec', CASES)
+def test_oracle_is_scipy_splprep(seed, m, spec):
+    """The restatement reproduces FITPACK itself: same knots, same ier, coefficients and fp to rounding -- in the interpolating
+    regime (tiny s), with knots added and smoothing, and for a fit that stays the least-squares polynomial (ier = -2)."""
+    u, X = _trajectory(seed, m, speed=1 + seed)
+    s = _s_of(u, spec)
+    ((t0, c0, _), _u), fp0, ier0, _msg = interpolate.splprep(X, u=u, s=s, k=3, full_output=1)
+    (t, c, k), info = fo.splprep(X, u, s)
+    np.testing.assert_array_equal(t, t0)
+    assert info['ier'] == ier0 and k == 3
+    np.testing.assert_allclose(np.asarray(c), np.asarray(c0), rtol=0, atol=COEF_ATOL)
+    assert abs(info['fp'] - fp0) <= 1e-9 * max(fp0, s)
+
+
+def test_oracle_reproduces_the_reference_fixture():
+    """The accepted fit of every interval of the golden trajectory: the smoothing factor the reference's loop ends on is found
+    with scipy (fast), the oracle's fit at that factor equals what the reference stored."""
+    g = _golden()
+    for i, part in _parts(g):
+        tck_s, s, calls = _reference_loop(part, g['smooth_factor'], lambda X, u, s: interpolate.splprep(X, u=u, s=s, k=3)[0])
+        assert calls > 3                                  # the loop really walks through several smoothing factors
+        np.testing.assert_array_equal(tck_s[0], g['knots_%d' % i])
+        (t, c, _), info = fo.splprep(part[1:], part[0], s)
+        np.testing.assert_array_equal(t, g['knots_%d' % i])
+        np.testing.assert_allclose(np.asarray(c), g['coefs_%d' % i], rtol=0, atol=COEF_ATOL)
+
+
+def test_scene_fitpack_setting_matches_the_reference():
+    """settings['spline_fit'] = 'fitpack' (scipy's splprep inside this repo's loop) against the reference's own output."""
+    g = _golden()
+    s = common.Scene()
+    s.settings = {'spline_fit': 'fitpack'}
+    s.traj = g['traj'].copy()
+    sp = s.traj_to_spline(smooth_factor=list(g['smooth_factor']))
+    np.testing.assert_array_equal(sp['int'], g['interval'])
+    for i, tck in enumerate(sp['tck']):
+        np.testing.assert_allclose(tck[0], g['knots_%d' % i], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(np.asarray(tck[1]), g['coefs_%d' % i], rtol=0, atol=1e-9)
+
+
+# ---- GPU ------------------------------------------------------------------------------------------------------------------
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('seed,m,spec', CASES + [(6, 349, ('rel', 1e-6)), (7, 276, ('abs', 0.05)), (8, 5000, ('abs', 1.0))])
+def test_gpu_smooth_fit_matches_fitpack(seed, m, spec):
+    """mvus_spline_smooth against scipy's splprep (and, at sizes it finishes, the oracle): identical knots, ier, coefficients."""
+    from mvus_amd import spline
+    u, X = _trajectory(seed, m, speed=1 + seed % 7)
+    s = _s_of(u, spec)
+    (t0, c0, _), _u = interpolate.splprep(X, u=u, s=s, k=3)
+    full = interpolate.splprep(X, u=u, s=s, k=3, full_output=1)
+    tck, fp, ier = spline.smooth_fit(u, X, s, full_output=True)
+    np.testing.assert_array_equal(tck[0], t0)
+    assert ier == full[2] and tck[2] == 3
+    np.testing.assert_allclose(np.asarray(tck[1]), np.asarray(c0), rtol=0, atol=COEF_ATOL)
+    assert abs(fp - full[1]) <= 1e-8 * max(full[1], s)
+    if m <= 200:
+        (t1, c1, _), info = fo.splprep(X, u, s)
+        np.testing.assert_array_equal(tck[0], t1)
+        np.testing.assert_allclose(np.asarray(tck[1]), np.asarray(c1), rtol=0, atol=COEF_ATOL)
+
+
+@pytest.mark.gpu
+def test_gpu_smooth_fit_ill_conditioned_knot_set():
+    """Close to interpolation FITPACK's knot search can produce a knot set with cond(A) ~ 1e10 (cond of the normal equations
+    1e20): the fp64 Cholesky loses a pivot, the pass is repeated in double-double and still lands on FITPACK's spline."""
+    from mvus_amd import spline
+    rng = np.random.default_rng(0)
+    for case in range(3):                                  # the third draw of this stream (m = 80) is the ill-conditioned one
+        m = int(rng.integers(60, 400))
+        u = np.cumsum(rng.uniform(0.5, 1.5, m))
+        X = np.vstack([10 * np.sin(u / 80 * (1 + case)), 10 * np.cos(u / 95), 30 + 3 * np.sin(u / 50)]) + rng.normal(0, 0.02, (3, m))
+    s = 1e-4 * (u[-1] - u[0])
+    (t0, c0, _), _u = interpolate.splprep(X, u=u, s=s, k=3)
+    A = interpolate.BSpline.design_matrix(u, t0, 3).toarray()
+    sv = np.linalg.svd(A, compute_uv=False)
+    assert sv[0] / sv[-1] > 1e9                            # the premise of this test
+    tck, fp, ier = spline.smooth_fit(u, X, s, full_output=True)
+    np.testing.assert_array_equal(tck[0], t0)
+    np.testing.assert_allclose(np.asarray(tck[1]), np.asarray(c0), rtol=0, atol=1e-6)
+    assert abs(fp - s) < 1e-3 * s and ier == 0
+
+
+@pytest.mark.gpu
+def test_gpu_traj_to_spline_matches_the_reference_fixture():
+    """Scene.traj_to_spline with the fit on the GPU (the default) against the REAL reference's output: two intervals, the whole
+    smooth_factor loop (a dozen fits per interval from the interpolating regime upwards)."""
+    from mvus_amd import spline
+    g = _golden()
+    s = common.Scene()
+    s.settings = {}
+    s.traj = g['traj'].copy()
+    sp = s.traj_to_spline(smooth_factor=list(g['smooth_factor']))
+    np.testing.assert_array_equal(sp['int'], g['interval'])
+    assert len(sp['tck']) == int(g['n_int'])
+    for i, tck in enumerate(sp['tck']):
+        np.testing.assert_array_equal(tck[0], g['knots_%d' % i])
+        np.testing.assert_allclose(np.asarray(tck[1]), g['coefs_%d' % i], rtol=0, atol=COEF_ATOL)
+    # every fit of the loop, not only the accepted one: same knot count as scipy at every smoothing factor it walks through
+    for i, part in _parts(g):
+        seen = []
+        _reference_loop(part, g['smooth_factor'], lambda X, u, s_: (seen.append((s_, len(spline.smooth_fit(u, X, s_)[0]))), interpolate.splprep(X, u=u, s=s_, k=3)[0])[1])
+        for s_, n_gpu in seen:
+            assert n_gpu == len(interpolate.splprep(part[1:], u=part[0], s=s_, k=3)[0][0])
+
+
+@pytest.mark.gpu
+def test_gpu_smooth_fit_rejects_bad_input():
+    from mvus_amd import spline
+    u, X = _trajectory(0, 50)
+    with pytest.raises(ValueError):
+        spline.smooth_fit(u[::-1].copy(), X, 1.0)          # not increasing
+    with pytest.raises(ValueError):
+        spline.smooth_fit(u, X, 0.0)                       # s must be positive (the reference never asks for interpolation)
+    Xn = X.copy(); Xn[1, 7] = np.nan
+    with pytest.raises(ValueError):
+        spline.smooth_fit(u, Xn, 1.0)
+    with pytest.raises(ValueError):
+        spline.smooth_fit(u[:3], X[:, :3], 1.0)            # fewer samples than a cubic needs
+    with pytest.raises(ValueError):
+        spline.smooth_fit(u, X[:2], 1.0)
+
+
+@pytest.mark.gpu
+def test_gpu_smooth_fit_full_size_properties():
+    """A 10-minute flight at 30 fps (18 000 samples; scipy needs minutes here, its smoothing iteration is O(n^2)): properties
+    FITPACK guarantees -- |fp - s| within its tolerance, interior knots are data sites, strictly increasing, clamped ends --
+    and the fit is what scipy's splev evaluates to within the noise."""
+    import time
+    from mvus_amd import spline
+    u, X = _trajectory(11, 18000, noise=0.05)
+    for s in (1e-6 * (u[-1] - u[0]), 18000 * 0.05 ** 2 * 3):
+        t0 = time.time()
+        tck, fp, ier = spline.smooth_fit(u, X, s, full_output=True)
+        elapsed = time.time() - t0
+        t = tck[0]
+        assert ier == 0 and abs(fp - s) <= 1e-3 * s
+        assert np.all(t[:4] == u[0]) and np.all(t[-4:] == u[-1]) and np.all(np.diff(t[3:-3]) > 0)
+        assert np.all(np.isin(t[4:-4], u))
+        fit = np.asarray(interpolate.splev(u, tck))
+        assert abs(np.sum((fit - X) ** 2) - fp) <= 1e-6 * fp
+        assert elapsed < 30.0
