@@ -3,6 +3,7 @@
 // against the oracle without a GPU.  Never linked into libmvusba.so.
 #include "../../mvus_amd/csrc/ba_math.h"
 #include "../../mvus_amd/csrc/triangulate.hip.h"
+#include "../../mvus_amd/csrc/spline_fit.hip.h"
 
 using namespace mvus;
 
@@ -47,4 +48,34 @@ extern "C" int hostcheck_triangulate(long long N, const double* x1, const double
     if (err2) err2[i] = reprojection_distance(P2, Xh, x2[i], x2[N + i]);
   }
   return 0;
+}
+
+// host parts of the smoothing-spline fit (mvus_amd/csrc/spline_fit.hip.h): FITPACK's scalar routines and the double-double
+// arithmetic of the ill-conditioned passes
+extern "C" void hostcheck_fpdisc(int n, const double* t, double* b_out) {
+  std::vector<double> tv(t, t + n), b;
+  fitpack::fpdisc(tv, n, b);
+  for (size_t i = 0; i < b.size(); ++i) b_out[i] = b[i];
+}
+extern "C" double hostcheck_fprati(double* pf /* p1 f1 p2 f2 p3 f3, p1 f1 p3 f3 updated */) {
+  return fitpack::fprati(pf[0], pf[1], pf[2], pf[3], pf[4], pf[5]);
+}
+extern "C" void hostcheck_fpknot(int nest, const double* x, int* n, double* t, double* fpint, int* nrdata, int* nrint) {
+  std::vector<double> tv(t, t + nest), fv(fpint, fpint + nest);
+  std::vector<int> nd(nrdata, nrdata + nest);
+  fitpack::fpknot(x, tv, *n, fv, nd, *nrint);
+  for (int i = 0; i < nest; ++i) { t[i] = tv[i]; fpint[i] = fv[i]; nrdata[i] = nd[i]; }
+}
+// op: 0 a+b, 1 a*b, 2 a/b, 3 sqrt(a), 4 exact product of the two high words;  a, b, out: (hi, lo)
+extern "C" void hostcheck_dd(int op, const double* a, const double* b, double* out) {
+  const dd x(a[0], a[1]), y(b[0], b[1]);
+  dd r;
+  switch (op) {
+    case 0: r = x + y; break;
+    case 1: r = x * y; break;
+    case 2: r = x / y; break;
+    case 3: r = num_sqrt(x); break;
+    default: r = dd_two_prod(a[0], b[0]); break;
+  }
+  out[0] = r.hi; out[1] = r.lo;
 }

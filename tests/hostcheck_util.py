@@ -10,7 +10,7 @@ from mvus_amd import _lib
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SRC = [os.path.join(HERE, 'hostcheck', f) for f in ('hostcheck.cpp', 'host_backend.cpp')]
-DEPS = SRC + [os.path.join(ROOT, 'mvus_amd', 'csrc', f) for f in ('ba_math.h', 'ba_solver.h', 'ba_problem.h', 'ba_schur.h', 'ba_partition.h', 'triangulate.hip.h')] \
+DEPS = SRC + [os.path.join(ROOT, 'mvus_amd', 'csrc', f) for f in ('ba_math.h', 'ba_solver.h', 'ba_problem.h', 'ba_schur.h', 'ba_partition.h', 'triangulate.hip.h', 'spline_fit.hip.h')] \
     + [os.path.join(ROOT, 'include', 'mvus_ba.h')]
 SO = os.path.join(HERE, 'hostcheck', 'libhostcheck.so')
 
@@ -44,6 +44,11 @@ def load():
     lib.hostcheck_solve.argtypes = [ctypes.c_void_p, _lib.c_double_p, ctypes.POINTER(_lib.MvusSolveOpts),
                                     ctypes.POINTER(_lib.MvusResult), _lib.c_double_p]
     lib.hostcheck_triangulate.argtypes = [ctypes.c_longlong] + [_lib.c_double_p] * 7
+    lib.hostcheck_fpdisc.argtypes = [ctypes.c_int, _lib.c_double_p, _lib.c_double_p]
+    lib.hostcheck_fprati.restype = ctypes.c_double
+    lib.hostcheck_fprati.argtypes = [_lib.c_double_p]
+    lib.hostcheck_fpknot.argtypes = [ctypes.c_int, _lib.c_double_p, _lib.c_int32_p, _lib.c_double_p, _lib.c_double_p, _lib.c_int32_p, _lib.c_int32_p]
+    lib.hostcheck_dd.argtypes = [ctypes.c_int, _lib.c_double_p, _lib.c_double_p, _lib.c_double_p]
     _cached = lib
     return lib
 

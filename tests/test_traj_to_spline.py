@@ -110,6 +110,74 @@ def test_scene_fitpack_setting_matches_the_reference():
         np.testing.assert_allclose(np.asarray(tck[1]), g['coefs_%d' % i], rtol=0, atol=1e-9)
 
 
+def test_host_side_of_the_gpu_fit_matches_the_oracle():
+    """The scalar FITPACK routines the GPU path runs on the host (csrc/spline_fit.hip.h: fpdisc, fprati, fpknot), compiled with
+    g++ (tests/hostcheck), against the oracle's restatement -- bit for bit, they are the same arithmetic."""
+    import ctypes
+    from hostcheck_util import load
+    from mvus_amd import _lib
+    lib = load()
+    rng = np.random.default_rng(3)
+    u, X = _trajectory(3, 90)
+    (t, _c, _k), _info = fo.splprep(X, u, 0.05)
+    n = t.size
+    b = np.zeros((n - 8, 5))
+    lib.hostcheck_fpdisc(n, _lib.dptr(np.ascontiguousarray(t)), _lib.dptr(b))
+    np.testing.assert_array_equal(b, fo.fpdisc(t, n, 5))
+    for _ in range(50):
+        p1, p2 = np.sort(rng.uniform(0.1, 10.0, 2))
+        f1, f2 = rng.uniform(0.1, 5.0), rng.uniform(-5.0, 5.0)
+        p3, f3 = (-1.0, rng.uniform(-9.0, -5.0)) if rng.random() < 0.5 else (p2 + rng.uniform(0.1, 5.0), rng.uniform(-9.0, -5.0))
+        pf = np.array([p1, f1, p2, f2, p3, f3])
+        got = lib.hostcheck_fprati(_lib.dptr(pf))
+        want = fo.fprati(p1, f1, p2, f2, p3, f3)
+        assert got == want[0] and tuple(pf[[0, 1, 4, 5]]) == want[1:]
+    # a few knot insertions from the state fppara is in after its first least-squares pass
+    m, nest = u.size, u.size + 6
+    t1 = np.zeros(nest); t1[:4] = u[0]; t1[4:8] = u[-1]
+    t2 = t1.copy()
+    fp1 = np.zeros(nest); fp1[0] = 3.25
+    fp2 = fp1.copy()
+    nr1 = np.zeros(nest, dtype=np.int64); nr1[0] = m - 2
+    nr2 = nr1.astype(np.int32)
+    n1, ri1 = 8, 1
+    n2, ri2 = ctypes.c_int32(8), ctypes.c_int32(1)
+    for step in range(12):
+        n1, ri1 = fo.fpknot(u, t1, n1, fp1, nr1, ri1)
+        lib.hostcheck_fpknot(nest, _lib.dptr(u), ctypes.byref(n2), _lib.dptr(t2), _lib.dptr(fp2), nr2.ctypes.data_as(_lib.c_int32_p), ctypes.byref(ri2))
+        assert (n2.value, ri2.value) == (n1, ri1)
+        np.testing.assert_array_equal(t2, t1)
+        np.testing.assert_array_equal(fp2, fp1)
+        np.testing.assert_array_equal(nr2, nr1)
+        fp1[:ri1] *= rng.uniform(0.5, 1.5, ri1)           # new residuals before the next insertion
+        fp2[:] = fp1
+
+
+def test_double_double_arithmetic_on_the_host():
+    """The double-double primitives of the ill-conditioned passes against exact rational arithmetic: ~1e-31 relative."""
+    from fractions import Fraction
+    from hostcheck_util import load
+    from mvus_amd import _lib
+    lib = load()
+    rng = np.random.default_rng(4)
+
+    def run(op, a, b):
+        out = np.zeros(2)
+        lib.hostcheck_dd(op, _lib.dptr(np.array(a)), _lib.dptr(np.array(b)), _lib.dptr(out))
+        return Fraction(out[0]) + Fraction(out[1])
+
+    for _ in range(200):
+        ah, bh = rng.uniform(-3, 3), rng.uniform(0.5, 3)
+        a, b = (ah, ah * rng.uniform(-1, 1) * 2.0 ** -54), (bh, bh * rng.uniform(-1, 1) * 2.0 ** -54)
+        fa, fb = Fraction(a[0]) + Fraction(a[1]), Fraction(b[0]) + Fraction(b[1])
+        assert run(4, a, b) == Fraction(a[0]) * Fraction(b[0])                       # the product of two doubles is exact
+        for op, exact in ((0, fa + fb), (1, fa * fb), (2, fa / fb)):
+            err = abs(run(op, a, b) - exact)
+            assert err <= abs(exact) * Fraction(1, 2 ** 100) + Fraction(1, 2 ** 150)
+        r = run(3, (abs(a[0]) + 0.1, 0.0), b)
+        assert abs(r * r - (Fraction(abs(a[0]) + 0.1))) <= Fraction(1, 2 ** 98) * r * r
+
+
 # ---- GPU ------------------------------------------------------------------------------------------------------------------
 
 @pytest.mark.gpu
