@@ -209,42 +209,14 @@ class Scene:
     def traj_to_spline(self, smooth_factor):
         """One smoothing cubic spline per contiguous part of ``self.traj`` (reference common.py:224-270): FITPACK's ``splprep``
         inside the reference's knot-density loop, with the sample passes and banded solves on the GPU
-        (``mvus_amd.spline.traj_fit`` -> ``mvus_spline_smooth``).  ``settings['spline_fit'] = 'fitpack'`` keeps scipy's own
-        ``splprep`` (the comparison the tests make)."""
-        assert len(smooth_factor) == 2, 'Smoothness should be defined by two parameters (min, max)'
+        (``mvus_amd.spline.traj_fit`` -> ``mvus_spline_smooth``; no host fallback)."""
         from .. import spline as _spline
+        assert len(smooth_factor) == 2, 'Smoothness should be defined by two parameters (min, max)'
         interval, idx = util.find_intervals(self.traj[0], idx=True)
-        settings = self.settings if isinstance(self.settings, dict) else {}
-        tck = []
-        for i in range(interval.shape[1]):
-            part = self.traj[:, idx[0, i]:idx[1, i] + 1]
-            if settings.get('spline_fit', 'gpu') == 'fitpack':
-                tck.append(self._traj_fit_fitpack(part, smooth_factor))
-            else:
-                tck.append(_spline.traj_fit(part, smooth_factor, device=int(settings.get('device', 0))))
+        device = int(self.settings.get('device', 0)) if isinstance(self.settings, dict) else 0
+        tck = [_spline.traj_fit(self.traj[:, idx[0, i]:idx[1, i] + 1], smooth_factor, device=device) for i in range(interval.shape[1])]
         self.spline['tck'], self.spline['int'] = tck, interval
         return self.spline
-
-    @staticmethod
-    def _traj_fit_fitpack(part, smooth_factor):
-        from scipy import interpolate
-        lo, hi = min(smooth_factor), max(smooth_factor)
-        measure = part[0, -1] - part[0, 0]
-        s = (1e-3) ** 2 * measure
-        prev, direction = 0, 0
-        while True:
-            fit, _ = interpolate.splprep(part[1:], u=part[0], s=s, k=3)
-            n = len(fit[0]) - 4
-            if n == prev and n == 4 and direction == 2:
-                break
-            prev = n
-            if measure / n > hi:
-                s, direction = s / 1.5, 1
-            elif measure / n < lo:
-                s, direction = s * 2, 2
-            else:
-                break
-        return fit
 
     def spline_to_traj(self, sampling_rate=1, t=None):
         """Discrete 3D points of the splines (common.py:273-301): sampled at a constant rate or at the given timestamps,

@@ -97,19 +97,6 @@ def test_oracle_reproduces_the_reference_fixture():
         np.testing.assert_allclose(np.asarray(c), g['coefs_%d' % i], rtol=0, atol=COEF_ATOL)
 
 
-def test_scene_fitpack_setting_matches_the_reference():
-    """settings['spline_fit'] = 'fitpack' (scipy's splprep inside this repo's loop) against the reference's own output."""
-    g = _golden()
-    s = common.Scene()
-    s.settings = {'spline_fit': 'fitpack'}
-    s.traj = g['traj'].copy()
-    sp = s.traj_to_spline(smooth_factor=list(g['smooth_factor']))
-    np.testing.assert_array_equal(sp['int'], g['interval'])
-    for i, tck in enumerate(sp['tck']):
-        np.testing.assert_allclose(tck[0], g['knots_%d' % i], rtol=0, atol=1e-12)
-        np.testing.assert_allclose(np.asarray(tck[1]), g['coefs_%d' % i], rtol=0, atol=1e-9)
-
-
 def test_host_side_of_the_gpu_fit_matches_the_oracle():
     """The scalar FITPACK routines the GPU path runs on the host (csrc/spline_fit.hip.h: fpdisc, fprati, fpknot), compiled with
     g++ (tests/hostcheck), against the oracle's restatement -- bit for bit, they are the same arithmetic."""
