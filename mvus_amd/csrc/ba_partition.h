@@ -6,7 +6,10 @@
 
 namespace mvus {
 
-constexpr int kPartL = 32;                           // control points per interior
+#ifndef MVUS_PART_L
+#define MVUS_PART_L 32
+#endif
+constexpr int kPartL = MVUS_PART_L;                  // control points per interior
 constexpr int kPartRowsMax = 3 * (kPartL + 6);       // scalar rows of the longest interior (merged tails included)
 
 // Partition of a chain of `n` control points starting at local control point `c0`: interiors of kPartL control points
