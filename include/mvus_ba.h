@@ -267,6 +267,17 @@ int mvus_spline_lsq(int32_t device, int32_t num_knots, const double* knots, int6
 int mvus_spline_smooth(int32_t device, int64_t m, const double* u, const double* X, double s, int32_t* n_out, double* t_out, double* c_out,
                        double* fp_out, int32_t* ier_out);
 
+/* Scene.get_camera_pose's cv2.solvePnPRansac(objectPoints, imagePoints, K, d, reprojectionError=error) (common.py:744; OpenCV is
+ * a third-party dependency absent from this image: parity unpinned, see pnp.hip.h).  X[3*N] object points (x(N) y(N) z(N)),
+ * uv[2*N] raw pixels (u(N) v(N)), K = fx fy cx cy, d = k1 k2 p1 p2 k3.  `iterations` hypotheses (OpenCV's iterationsCount,
+ * default 100) from six sampled points each (counter-based sampling from `seed`: deterministic), scored by the number of points
+ * with reprojection error <= reproj_error pixels; the best pose is refined on its inliers by damped Gauss-Newton on the pixel
+ * reprojection error (OpenCV's SOLVEPNP_ITERATIVE refinement minimises the same quantity).  Outputs: rvec[3], tvec[3]
+ * (cv2.Rodrigues convention), inliers[N] (1 = inlier of the best hypothesis; may be NULL), *n_inliers.
+ * MVUS_E_NUMERIC when no hypothesis is supported by six points.  Stateless; no CPU fallback. */
+int mvus_pnp_ransac(int32_t device, int64_t N, const double* X, const double* uv, const double* K, const double* d, double reproj_error,
+                    int32_t iterations, uint64_t seed, double* rvec, double* tvec, uint8_t* inliers, int64_t* n_inliers);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,6 +17,7 @@
 #include "triangulate.hip.h"
 #include "spline_ops.hip.h"
 #include "spline_fit.hip.h"
+#include "pnp.hip.h"
 
 namespace mvus {
 
@@ -1189,6 +1190,110 @@ int mvus_spline_smooth(int32_t device, int64_t m, const double* u, const double*
   } catch (const HipError& e) {
     g_create_error = e.msg;
     return e.msg.find("positive definite") != std::string::npos ? MVUS_E_NUMERIC : MVUS_E_HIP;
+  }
+  return MVUS_OK;
+}
+
+/* cv2.solvePnPRansac(objectPoints, imagePoints, K, d, reprojectionError) as Scene.get_camera_pose calls it (pnp.hip.h) */
+int mvus_pnp_ransac(int32_t device, int64_t N, const double* X, const double* uv, const double* K, const double* d, double reproj_error,
+                    int32_t iterations, uint64_t seed, double* rvec, double* tvec, uint8_t* inliers, int64_t* n_inliers) {
+  if (N < 6 || N > (1ll << 30) || !X || !uv || !K || !d || !rvec || !tvec || !(reproj_error > 0.0) || iterations < 1 || iterations > 65536) {
+    g_create_error = "pnp_ransac: bad arguments (at least 6 points, reprojection error > 0, 1..65536 iterations)";
+    return MVUS_E_INVALID;
+  }
+  for (int64_t i = 0; i < 3 * N; ++i) if (!std::isfinite(X[i])) { g_create_error = "pnp_ransac: non-finite object point"; return MVUS_E_INVALID; }
+  for (int64_t i = 0; i < 2 * N; ++i) if (!std::isfinite(uv[i])) { g_create_error = "pnp_ransac: non-finite image point"; return MVUS_E_INVALID; }
+  // the object points are centred and scaled (the direct linear transform is badly conditioned otherwise); a pose (R, t')
+  // of the scaled points is the pose (R, sigma t' - R m) of the original ones
+  double m[3] = {0.0, 0.0, 0.0}, sigma = 0.0;
+  for (int a = 0; a < 3; ++a) { for (int64_t i = 0; i < N; ++i) m[a] += X[a * N + i]; m[a] /= (double)N; }
+  for (int a = 0; a < 3; ++a) for (int64_t i = 0; i < N; ++i) sigma += (X[a * N + i] - m[a]) * (X[a * N + i] - m[a]);
+  sigma = std::sqrt(sigma / (3.0 * (double)N));
+  if (!(sigma > 0.0)) { g_create_error = "pnp_ransac: all object points coincide"; return MVUS_E_INVALID; }
+  std::vector<double> Xc(3 * (size_t)N);
+  for (int a = 0; a < 3; ++a) for (int64_t i = 0; i < N; ++i) Xc[a * N + i] = (X[a * N + i] - m[a]) / sigma;
+  double Kd[9] = {K[0], K[1], K[2], K[3], d[0], d[1], d[2], d[3], d[4]};
+  try {
+    CallBuffers cb;
+    cb.open(device);
+    const double* dX = cb.put(Xc.data(), Xc.size());
+    const double* duv = cb.put(uv, 2 * (size_t)N);
+    const double* dK = cb.put(Kd, 9);
+    double* xn = cb.get<double>(2 * (size_t)N);
+    double* poses = cb.get<double>(13 * (size_t)iterations);
+    int32_t* counts = cb.get<int32_t>((size_t)iterations);
+    uint8_t* mask = cb.get<uint8_t>((size_t)N);
+    double* pose_d = cb.get<double>(13);
+    double* acc_d = cb.get<double>(29);
+    const double thr2 = reproj_error * reproj_error;
+    hipLaunchKernelGGL(k_pnp_normalise, fit_blocks(N), dim3(256), 0, cb.st, (long long)N, duv, dK, xn);
+    hipLaunchKernelGGL(k_pnp_hypotheses, dim3((iterations + 63) / 64), dim3(64), 0, cb.st, iterations, (unsigned long long)seed, (long long)N, dX, xn, poses);
+    hipLaunchKernelGGL(k_pnp_score, dim3(iterations), dim3(256), 0, cb.st, (long long)N, dX, duv, dK, poses, thr2, counts);
+    MVUS_HIP(hipGetLastError());
+    std::vector<int32_t> cnt((size_t)iterations);
+    MVUS_HIP(hipMemcpyAsync(cnt.data(), counts, sizeof(int32_t) * iterations, hipMemcpyDeviceToHost, cb.st));
+    MVUS_HIP(hipStreamSynchronize(cb.st));
+    int best = 0;
+    for (int h = 1; h < iterations; ++h) if (cnt[h] > cnt[best]) best = h;          // ties: the first hypothesis
+    if (cnt[best] < 6) { g_create_error = "pnp_ransac: no hypothesis is supported by six points (reprojection error too small, or no consistent pose)"; return MVUS_E_NUMERIC; }
+    double pose[13];
+    MVUS_HIP(hipMemcpyAsync(pose, poses + 13ll * best, sizeof(double) * 13, hipMemcpyDeviceToHost, cb.st));
+    hipLaunchKernelGGL(k_pnp_mask, fit_blocks(N), dim3(256), 0, cb.st, (long long)N, dX, duv, dK, poses + 13ll * best, thr2, mask);
+    MVUS_HIP(hipStreamSynchronize(cb.st));
+    // damped Gauss-Newton on the inliers; the normal equations come from the device, the 6x6 solve is done here
+    double acc[29], cand[13], acc2[29];
+    auto evaluate = [&](const double* ps, double* out) {
+      MVUS_HIP(hipMemcpyAsync(pose_d, ps, sizeof(double) * 13, hipMemcpyHostToDevice, cb.st));
+      hipLaunchKernelGGL(k_pnp_normal, dim3(1), dim3(256), 0, cb.st, (long long)N, dX, duv, dK, pose_d, mask, acc_d);
+      MVUS_HIP(hipMemcpyAsync(out, acc_d, sizeof(double) * 29, hipMemcpyDeviceToHost, cb.st));
+      MVUS_HIP(hipStreamSynchronize(cb.st));
+    };
+    evaluate(pose, acc);
+    double lambda = 1e-3;
+    for (int it = 0; it < 100; ++it) {
+      double Hm[6][6], g[6], L[6][6], dlt[6];
+      int e = 0;
+      for (int a = 0; a < 6; ++a) for (int b = 0; b <= a; ++b) { Hm[a][b] = Hm[b][a] = acc[e++]; }
+      for (int a = 0; a < 6; ++a) { g[a] = acc[21 + a]; Hm[a][a] += lambda * (Hm[a][a] > 0.0 ? Hm[a][a] : 1.0); }
+      bool pd = true;
+      for (int j = 0; j < 6 && pd; ++j) {
+        double s = Hm[j][j];
+        for (int k2 = 0; k2 < j; ++k2) s -= L[j][k2] * L[j][k2];
+        if (!(s > 0.0)) { pd = false; break; }
+        L[j][j] = std::sqrt(s);
+        for (int i = j + 1; i < 6; ++i) { double v = Hm[i][j]; for (int k2 = 0; k2 < j; ++k2) v -= L[i][k2] * L[j][k2]; L[i][j] = v / L[j][j]; }
+      }
+      if (!pd) { lambda *= 10.0; if (lambda > 1e10) break; continue; }
+      for (int i = 0; i < 6; ++i) { double v = -g[i]; for (int k2 = 0; k2 < i; ++k2) v -= L[i][k2] * dlt[k2]; dlt[i] = v / L[i][i]; }
+      for (int i = 5; i >= 0; --i) { double v = dlt[i]; for (int k2 = i + 1; k2 < 6; ++k2) v -= L[k2][i] * dlt[k2]; dlt[i] = v / L[i][i]; }
+      double dR[9], W[9];
+      rodrigues(dlt, dR, W);
+      for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) cand[3 * a + b] = dR[3 * a] * pose[b] + dR[3 * a + 1] * pose[3 + b] + dR[3 * a + 2] * pose[6 + b];
+      for (int a = 0; a < 3; ++a) cand[9 + a] = pose[9 + a] + dlt[3 + a];
+      cand[12] = 1.0;
+      evaluate(cand, acc2);
+      double step = 0.0;
+      for (int a = 0; a < 6; ++a) step = std::max(step, std::fabs(dlt[a]));
+      if (acc2[28] == 0.0 && acc2[27] <= acc[27]) {
+        const double gain = acc[27] - acc2[27];
+        std::memcpy(pose, cand, sizeof(pose));
+        std::memcpy(acc, acc2, sizeof(acc));
+        lambda = std::max(lambda * 0.1, 1e-12);
+        if (step < 1e-13 || gain <= 1e-15 * acc[27]) break;
+      } else {
+        lambda *= 10.0;
+        if (lambda > 1e10 || step < 1e-14) break;
+      }
+    }
+    // back to the scale of the original points
+    for (int a = 0; a < 3; ++a) tvec[a] = sigma * pose[9 + a] - (pose[3 * a] * m[0] + pose[3 * a + 1] * m[1] + pose[3 * a + 2] * m[2]);
+    rotation_to_rvec(pose, rvec);
+    if (inliers) MVUS_HIP(hipMemcpyAsync(inliers, mask, (size_t)N, hipMemcpyDeviceToHost, cb.st));
+    MVUS_HIP(hipStreamSynchronize(cb.st));
+    if (n_inliers) *n_inliers = cnt[best];
+  } catch (const HipError& e) {
+    g_create_error = e.msg;
+    return MVUS_E_HIP;
   }
   return MVUS_OK;
 }

@@ -457,12 +457,41 @@ class Scene:
             self.traj_to_spline(smooth_factor=factor_t2s)
         return X_new
 
+    def get_camera_pose(self, cam_id, error=8, verbose=0):
+        """Absolute pose of camera ``cam_id`` from the trajectory (reference common.py:719-750): the spline points at the
+        camera's detection timestamps (GPU: ``mvus_spline_eval``) against the raw detections, PnP + RANSAC on the GPU
+        (``mvus_pnp_ransac`` in place of ``cv2.solvePnPRansac``, reprojectionError = ``error``); sets R, t, P of the camera."""
+        from .. import spline as _spline
+        from .pnp import solve_pnp_ransac
+        tck, interval = self.spline['tck'], self.spline['int']
+        device = int(self.settings.get('device', 0)) if isinstance(self.settings, dict) else 0
+        self.detection_to_global(cam_id)
+        det = self.detections_global[cam_id]
+        _, idx = util.sampling(det, interval, belong=True)
+        detect, point_3D = np.empty([3, 0]), np.empty([3, 0])
+        for i in range(interval.shape[1]):                       # the reference's order: interval by interval
+            part = det[:, idx == i + 1]
+            if part.size:
+                X, which = _spline.evaluate([tck[i]], interval[:, i:i + 1], part[0], device=device)
+                detect = np.hstack((detect, part))
+                point_3D = np.hstack((point_3D, X))
+        N = point_3D.shape[1]
+        cam = self.cameras[cam_id]
+        retval, rvec, tvec, inliers = solve_pnp_ransac(point_3D.T, detect[1:].T, cam.K, cam.d, reprojectionError=error, device=device)
+        if not retval:
+            raise ValueError('get_camera_pose: no pose is supported by six trajectory points within %g px' % error)
+        cam.R = _rodrigues(np.ravel(rvec))
+        cam.t = np.ravel(tvec)
+        cam.compose()
+        if verbose:
+            print('{} out of {} points are inliers for PnP'.format(inliers.shape[0], N))
+
     # ---- outside the hot path -----------------------------------------------------------------------
     def _out_of_scope(self, *a, **k):
         raise NotImplementedError('outside the BA hot path this package accelerates (SURVEY.md section 2); '
-                                  'use the reference implementation for initialisation / PnP / synchronisation search')
+                                  'use the reference implementation for initialisation / synchronisation search')
 
-    init_traj = get_camera_pose = select_most_overlap = plot_reprojection = error_motion = _out_of_scope
+    init_traj = select_most_overlap = plot_reprojection = error_motion = _out_of_scope
 
 
 def create_scene(path_input):

@@ -4,6 +4,7 @@
 #include "../../mvus_amd/csrc/ba_math.h"
 #include "../../mvus_amd/csrc/triangulate.hip.h"
 #include "../../mvus_amd/csrc/spline_fit.hip.h"
+#include "../../mvus_amd/csrc/pnp.hip.h"
 
 using namespace mvus;
 
@@ -79,3 +80,17 @@ extern "C" void hostcheck_dd(int op, const double* a, const double* b, double* o
   }
   out[0] = r.hi; out[1] = r.lo;
 }
+
+// host build of the PnP math (mvus_amd/csrc/pnp.hip.h)
+extern "C" int hostcheck_pnp_dlt6(const double* Xs /* [6][3] */, const double* xn /* [6][2] */, double* R, double* t) {
+  return pnp_dlt6(reinterpret_cast<const double (*)[3]>(Xs), reinterpret_cast<const double (*)[2]>(xn), R, t) ? 1 : 0;
+}
+extern "C" int hostcheck_pnp_project(const double* K, const double* d, const double* R, const double* t, const double* X, double* uv) {
+  return pnp_project(K, d, R, t, X, uv[0], uv[1]) ? 1 : 0;
+}
+extern "C" int hostcheck_pnp_point_normal(const double* K, const double* d, const double* R, const double* t, const double* X, double u, double v, double* acc28) {
+  for (int k = 0; k < 28; ++k) acc28[k] = 0.0;
+  return pnp_point_normal(K, d, R, t, X, u, v, acc28) ? 1 : 0;
+}
+extern "C" void hostcheck_pnp_sample6(unsigned long long seed, int h, long long N, long long* idx) { pnp_sample6(seed, h, N, idx); }
+extern "C" void hostcheck_rotation_to_rvec(const double* R, double* r) { rotation_to_rvec(R, r); }

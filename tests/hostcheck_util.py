@@ -10,7 +10,7 @@ from mvus_amd import _lib
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SRC = [os.path.join(HERE, 'hostcheck', f) for f in ('hostcheck.cpp', 'host_backend.cpp')]
-DEPS = SRC + [os.path.join(ROOT, 'mvus_amd', 'csrc', f) for f in ('ba_math.h', 'ba_solver.h', 'ba_problem.h', 'ba_schur.h', 'ba_partition.h', 'triangulate.hip.h', 'spline_fit.hip.h')] \
+DEPS = SRC + [os.path.join(ROOT, 'mvus_amd', 'csrc', f) for f in ('ba_math.h', 'ba_solver.h', 'ba_problem.h', 'ba_schur.h', 'ba_partition.h', 'triangulate.hip.h', 'spline_fit.hip.h', 'pnp.hip.h')] \
     + [os.path.join(ROOT, 'include', 'mvus_ba.h')]
 SO = os.path.join(HERE, 'hostcheck', 'libhostcheck.so')
 
@@ -49,6 +49,11 @@ def load():
     lib.hostcheck_fprati.argtypes = [_lib.c_double_p]
     lib.hostcheck_fpknot.argtypes = [ctypes.c_int, _lib.c_double_p, _lib.c_int32_p, _lib.c_double_p, _lib.c_double_p, _lib.c_int32_p, _lib.c_int32_p]
     lib.hostcheck_dd.argtypes = [ctypes.c_int, _lib.c_double_p, _lib.c_double_p, _lib.c_double_p]
+    lib.hostcheck_pnp_dlt6.argtypes = [_lib.c_double_p] * 4
+    lib.hostcheck_pnp_project.argtypes = [_lib.c_double_p] * 6
+    lib.hostcheck_pnp_point_normal.argtypes = [_lib.c_double_p] * 5 + [ctypes.c_double, ctypes.c_double, _lib.c_double_p]
+    lib.hostcheck_pnp_sample6.argtypes = [ctypes.c_uint64, ctypes.c_int, ctypes.c_longlong, _lib.c_int64_p]
+    lib.hostcheck_rotation_to_rvec.argtypes = [_lib.c_double_p, _lib.c_double_p]
     _cached = lib
     return lib
 
