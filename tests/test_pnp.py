@@ -182,3 +182,49 @@ def test_gpu_scene_get_camera_pose():
     assert _angle(cam.R, R_true) < 0.1
     assert np.linalg.norm(cam.t - t_true) < 3e-2 * max(1.0, np.linalg.norm(t_true))
     np.testing.assert_allclose(cam.P, cam.K @ np.hstack((cam.R, cam.t.reshape(3, 1))), rtol=0, atol=1e-9)
+
+
+@pytest.mark.gpu
+def test_gpu_incremental_loop_adds_a_camera():
+    """The loop of the reference's main.py:44-83 for one added camera, every step on the GPU: BA on two cameras -> remove_outliers
+    -> BA -> get_camera_pose of the third (its pose unknown) -> triangulate its detections into the trajectory -> BA on three.
+    Ground truth decides: the third camera's pose, and the reprojection error of all three cameras after the last BA."""
+    from mvus_amd import synth
+    from mvus_amd.reconstruction import common
+    sc = synth.make_scene(3, 3000, seed=9, knot_spacing=15.0, perturb=0.3)
+    s = common.Scene()
+    s.numCam = sc.num_cam
+    s.settings = dict(sc.settings)
+    s.settings.update(undist_points=False, sampling_rate=0.02, thres_triangulation=20)
+    for c in sc.cameras:
+        cam = common.Camera(K=c['K'].copy(), d=c['d'].copy(), R=c['R'].copy(), t=c['t'].copy(), fps=c['fps'], resolution=list(c['resolution']))
+        cam.compose()
+        s.addCamera(cam)
+    for det in sc.detections:
+        s.addDetection(det.copy())
+    s.alpha, s.beta, s.rs = sc.alpha.copy(), sc.beta.copy(), sc.rs.copy()
+    s.sequence = list(range(sc.num_cam))
+    s.spline = {'tck': [[t.copy(), [c.copy() for c in cs], 3] for t, cs, _ in sc.tck], 'int': sc.interval.copy()}
+    s.detection_to_global()
+    truth = sc.truth
+    R_true, t_true = truth['cameras'][2]['R'], truth['cameras'][2]['t']
+    s.cameras[2].R, s.cameras[2].t = np.eye(3), np.zeros(3)              # the camera to be added: pose unknown
+    s.cameras[2].compose()
+    s.BA(2, max_iter=20)
+    s.remove_outliers([0, 1], thres=10)
+    s.BA(2, max_iter=20)
+    s.get_camera_pose(2, error=8)
+    assert _angle(s.cameras[2].R, R_true) < 2.0           # the two-camera BA is free to drift in its gauge: truth only bounds the pose
+    s.spline_to_traj(sampling_rate=1)
+    n_before = s.traj.shape[1]
+    s.triangulate(2, [0, 1], factor_t2s=s.settings['smooth_factor'], factor_s2t=s.settings['sampling_rate'], thres=s.settings['thres_triangulation'])
+    assert s.traj.shape[1] >= n_before
+    s.BA(3, max_iter=20)
+    s.remove_outliers([0, 1, 2], thres=10)
+    s.BA(3, max_iter=20)
+    for c in range(3):
+        err = s.error_cam(c, mode='each')
+        m = err.size // 2
+        dist = np.sqrt(err[:m] ** 2 + err[m:] ** 2)
+        assert np.mean(dist[dist > 0]) < 1.5                               # 0.5 px detection noise per axis
+    assert _angle(s.cameras[2].R, R_true) < 2.0
