@@ -486,12 +486,39 @@ class Scene:
         if verbose:
             print('{} out of {} points are inliers for PnP'.format(inliers.shape[0], N))
 
+    def select_most_overlap(self, init=False):
+        """The initial pair of cameras or the next camera with the largest temporal overlap (reference common.py:851-884): host
+        bookkeeping over the detection timestamps; the resampled trajectory of the second branch comes from the GPU."""
+        if not self.find_order:
+            return
+        self.detection_to_global()
+        overlap_max = 0
+        if init:
+            init_pair = None
+            for i in range(self.numCam - 1):
+                for j in range(i + 1, self.numCam):
+                    x, _ = util.match_overlap(self.detections_global[i], self.detections_global[j])
+                    overlap = x.shape[1] / self.cameras[i].fps
+                    if overlap > overlap_max:
+                        overlap_max, init_pair = overlap, [i, j]
+            self.sequence = init_pair
+        else:
+            traj = self.spline_to_traj()
+            next_cam = None
+            for i in [c for c in range(self.numCam) if self.cameras[c].P is None]:
+                interval = util.find_intervals(self.detections_global[i][0])
+                overlap = util.sampling(traj[0], interval)
+                overlap = overlap[0] if isinstance(overlap, tuple) else overlap
+                if len(overlap) > overlap_max:
+                    overlap_max, next_cam = len(overlap), i
+            self.sequence.append(next_cam)
+
     # ---- outside the hot path -----------------------------------------------------------------------
     def _out_of_scope(self, *a, **k):
         raise NotImplementedError('outside the BA hot path this package accelerates (SURVEY.md section 2); '
                                   'use the reference implementation for initialisation / synchronisation search')
 
-    init_traj = select_most_overlap = plot_reprojection = error_motion = _out_of_scope
+    init_traj = plot_reprojection = error_motion = _out_of_scope
 
 
 def create_scene(path_input):

@@ -108,7 +108,7 @@ def test_create_scene_reads_reference_config(tmp_path):
 
 def test_out_of_scope_methods_say_so():
     s = common.Scene()
-    for name in ('init_traj', 'select_most_overlap'):
+    for name in ('init_traj',):
         with pytest.raises(NotImplementedError):
             getattr(s, name)()
 

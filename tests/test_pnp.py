@@ -208,12 +208,14 @@ def test_gpu_incremental_loop_adds_a_camera():
     s.detection_to_global()
     truth = sc.truth
     R_true, t_true = truth['cameras'][2]['R'], truth['cameras'][2]['t']
-    s.cameras[2].R, s.cameras[2].t = np.eye(3), np.zeros(3)              # the camera to be added: pose unknown
-    s.cameras[2].compose()
+    s.cameras[2].R = s.cameras[2].t = s.cameras[2].P = None              # the camera to be added: pose unknown
+    s.sequence, s.find_order = [0, 1], True
     s.BA(2, max_iter=20)
     s.remove_outliers([0, 1], thres=10)
     s.BA(2, max_iter=20)
-    s.get_camera_pose(2, error=8)
+    s.select_most_overlap()
+    assert s.sequence == [0, 1, 2]
+    s.get_camera_pose(s.sequence[2], error=8)
     assert _angle(s.cameras[2].R, R_true) < 2.0           # the two-camera BA is free to drift in its gauge: truth only bounds the pose
     s.spline_to_traj(sampling_rate=1)
     n_before = s.traj.shape[1]
