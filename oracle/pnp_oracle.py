@@ -3,7 +3,9 @@
 CPU checker for ``mvus_pnp_ransac`` (the ``cv2.solvePnPRansac`` call of the reference's ``Scene.get_camera_pose``,
 ``reconstruction/common.py:719-750``).  OpenCV (unpinned, absent from this image) is the reference's implementation of that
 step and none of it lives under /root/reference, so there are no reference outputs, golden vectors or tests to pin this
-oracle against: **parity unpinned**.  What it restates is the published model the call is defined by:
+oracle against: **parity unpinned** for the call as a whole.  The one piece of PnP arithmetic the reference itself carries -- its own
+six-point direct linear transform ``epipolar.solve_PnP`` (epipolar.py:298-308) -- is run by tests/golden/make_golden_pnp.py and
+pins the minimal solver (tests/golden/pnp_dlt.npz).  What this file restates is the published model the call is defined by:
 
 * ``project``       cv2.projectPoints: pinhole projection + the 5-coefficient distortion model (k1 k2 p1 p2 k3);
 * ``dlt_pose``      a direct-linear-transform pose from >= 6 correspondences (SVD), the closed form the GPU hypotheses use;

@@ -230,3 +230,20 @@ def test_gpu_incremental_loop_adds_a_camera():
         dist = np.sqrt(err[:m] ** 2 + err[m:] ** 2)
         assert np.mean(dist[dist > 0]) < 1.5                               # 0.5 px detection noise per axis
     assert _angle(s.cameras[2].R, R_true) < 2.0
+
+
+def test_dlt_pose_against_the_references_own_dlt():
+    """The six-point pose of k_pnp_hypotheses (host build) against the REAL reference's ``epipolar.solve_PnP``
+    (tests/golden/pnp_dlt.npz, make_golden_pnp.py) on exact correspondences: the same projection matrix up to scale."""
+    from golden_util import GOLDEN_DIR
+    from hostcheck_util import load
+    lib = load()
+    g = dict(np.load(os.path.join(GOLDEN_DIR, 'pnp_dlt.npz')))
+    Kg = g['K']
+    for X, x, P_ref in zip(g['X'], g['x'], g['P_ref']):
+        xn = np.vstack(((x[0] - Kg[0, 2]) / Kg[0, 0], (x[1] - Kg[1, 2]) / Kg[1, 1]))
+        Rh, th = np.zeros(9), np.zeros(3)
+        assert lib.hostcheck_pnp_dlt6(_lib.dptr(np.ascontiguousarray(X.T)), _lib.dptr(np.ascontiguousarray(xn.T)), _lib.dptr(Rh), _lib.dptr(th))
+        P = Kg @ np.hstack((Rh.reshape(3, 3), th.reshape(3, 1)))
+        P = P / np.linalg.norm(P)
+        np.testing.assert_allclose(P, P_ref, rtol=0, atol=1e-7)
