@@ -276,12 +276,12 @@ struct HipBackend {
     if (masked && !has_pattern) throw HipError{"MVUS_JAC_PATTERN needs mvus_ba_set_pattern (or solve) first"};
     ensure_cams(x);
     if (dp.n_chunks > 0) {
-      const dim3 g(dp.n_chunks), b(kThreads);
+      const dim3 g(dp.n_chunks), gj(xcd_grid(dp.n_chunks)), b(kThreads);
       if (hp.calib) {
-        if (jac) hipLaunchKernelGGL((k_observations<true, true>), g, b, 0, stream, dp, cams, x, f, J, span, pat0, (int)masked);
+        if (jac) hipLaunchKernelGGL((k_observations<true, true>), gj, b, 0, stream, dp, cams, x, f, J, span, pat0, (int)masked);
         else hipLaunchKernelGGL((k_observations<true, false>), g, b, 0, stream, dp, cams, x, f, J, span, pat0, 0);
       } else {
-        if (jac) hipLaunchKernelGGL((k_observations<false, true>), g, b, 0, stream, dp, cams, x, f, J, span, pat0, (int)masked);
+        if (jac) hipLaunchKernelGGL((k_observations<false, true>), gj, b, 0, stream, dp, cams, x, f, J, span, pat0, (int)masked);
         else hipLaunchKernelGGL((k_observations<false, false>), g, b, 0, stream, dp, cams, x, f, J, span, pat0, 0);
       }
     }
@@ -891,8 +891,9 @@ int mvus_ba_time_kernel(mvus_ba* h, int32_t which, int32_t launches, double* avg
         case 5: {
           const OutSet& o = sets[turn];
           turn = (turn + 1) % (int)sets.size();
-          if (be.hp.calib) hipLaunchKernelGGL((k_observations<true, true>), g, b, 0, be.stream, be.dp, be.cams, be.x_cur, o.f, o.J, o.span, be.pat0, 0);
-          else hipLaunchKernelGGL((k_observations<false, true>), g, b, 0, be.stream, be.dp, be.cams, be.x_cur, o.f, o.J, o.span, be.pat0, 0);
+          const dim3 gj(xcd_grid(be.dp.n_chunks));
+          if (be.hp.calib) hipLaunchKernelGGL((k_observations<true, true>), gj, b, 0, be.stream, be.dp, be.cams, be.x_cur, o.f, o.J, o.span, be.pat0, 0);
+          else hipLaunchKernelGGL((k_observations<false, true>), gj, b, 0, be.stream, be.dp, be.cams, be.x_cur, o.f, o.J, o.span, be.pat0, 0);
           break;
         }
         case 2:
