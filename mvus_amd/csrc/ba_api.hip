@@ -200,7 +200,11 @@ struct HipBackend {
     MVUS_HIP(hipStreamSynchronize(stream));
   }
   void copy(double* d, const double* s, int64_t len) { touch(d); if (d != s) MVUS_HIP(hipMemcpyAsync(d, s, len * sizeof(double), hipMemcpyDeviceToDevice, stream)); }
-  void fill(double* d, double v, int64_t len) { touch(d); if (len > 0) hipLaunchKernelGGL(k_fill, dim3(grid_for(len)), dim3(kThreads), 0, stream, (long long)len, v, d); }
+  void fill(double* d, double v, int64_t len) {
+    touch(d);
+    const int tiles = grid_for(len);
+    if (len > 0) hipLaunchKernelGGL(k_fill, dim3(xcd_grid(tiles)), dim3(kThreads), 0, stream, (long long)len, v, d, tiles);
+  }
   void axpby(int64_t len, double a, const double* x, double b, const double* y, double* out) {
     touch(out);
     if (len > 0) hipLaunchKernelGGL(k_axpby, dim3(grid_for(len)), dim3(kThreads), 0, stream, (long long)len, a, x, b, y, out);

@@ -513,9 +513,12 @@ __global__ void k_mul(long long len, const double* x, const double* y, double* o
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < len; i += (long long)gridDim.x * blockDim.x)
     out[i] = x[i] * y[i];
 }
-__global__ void k_fill(long long len, double v, double* out) {
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < len; i += (long long)gridDim.x * blockDim.x)
-    out[i] = v;
+// grid = xcd_grid(tiles) workgroups; every pass of the grid-stride loop covers tiles * 256 consecutive elements, of which each
+// XCD writes runs of consecutive 2 KB pieces (xcd_tile)
+__global__ void k_fill(long long len, double v, double* out, int tiles) {
+  const int t = xcd_tile(tiles);
+  if (t >= tiles) return;
+  for (long long i = t * (long long)blockDim.x + threadIdx.x; i < len; i += (long long)tiles * blockDim.x) out[i] = v;
 }
 // deterministic two-stage dot product: per-workgroup partials, then one workgroup sums them
 __global__ __launch_bounds__(kThreads) void k_dot_partial(long long len, const double* __restrict__ a, const double* __restrict__ b,

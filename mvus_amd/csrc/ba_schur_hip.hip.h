@@ -1351,8 +1351,8 @@ __global__ __launch_bounds__(64) void k_part_back(PartView pv, int ncols, double
 // The same launch also packs the damped band (band_pack_entry: the two are independent element-wise passes over the assembled
 // blocks, and every launch costs ~4.7 us before it does anything).
 __global__ void k_build_rhs(NEView ne, int ncols, double* __restrict__ Z, double* __restrict__ Erm, double lambda, int BW, double* __restrict__ Lb,
-                            int* __restrict__ fail, DevProblem dp, int with_diag, double* __restrict__ D, double* __restrict__ gx) {
-  const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+                            int* __restrict__ fail, DevProblem dp, int with_diag, double* __restrict__ D, double* __restrict__ gx, int tiles) {
+  const long long idx = xcd_tile(tiles) * (long long)blockDim.x + threadIdx.x;      // XCD-aware order: 31.5 -> 25 us (see xcd_tile)
   band_pack_entry(ne, lambda, BW, Lb, fail, dp, with_diag, D, gx, idx);
   if (idx >= (long long)ne.N3 * ncols) return;
   const int r = (int)(idx / ncols), cidx = (int)(idx % ncols);
@@ -1986,8 +1986,9 @@ struct HipSchur {
   void solve_async(double lambda) {
     const long long nLb = (long long)ne.N3 * (BW + 1);
     const long long nZ = (long long)ne.N3 * ncols;          // >= nLb: one launch covers both passes
-    hipLaunchKernelGGL(k_build_rhs, dim3((unsigned)((std::max(nZ, nLb) + 255) / 256)), dim3(256), 0, be.stream, ne, ncols, Z, Erm, lambda, BW, Lb, fail, be.dp,
-                       (int)diag_pending, D, gx);
+    const int rhs_tiles = (int)((std::max(nZ, nLb) + 255) / 256);
+    hipLaunchKernelGGL(k_build_rhs, dim3((unsigned)xcd_grid(rhs_tiles)), dim3(256), 0, be.stream, ne, ncols, Z, Erm, lambda, BW, Lb, fail, be.dp,
+                       (int)diag_pending, D, gx, rhs_tiles);
     diag_pending = false;
     if (BW == 11) band_chain<11, 9>(); else band_chain<17, 15>();
     const int row_lo = 3 * own_lo, row_hi = 3 * own_hi;
