@@ -439,8 +439,8 @@ struct HipBackend {
 
   void jv(const double* v, double* y) {
     if (dp.n_chunks > 0) {
-      if (hp.calib) hipLaunchKernelGGL(k_jv<30>, dim3(dp.n_chunks), dim3(kThreads), 0, stream, dp, J, span, v, y);
-      else hipLaunchKernelGGL(k_jv<21>, dim3(dp.n_chunks), dim3(kThreads), 0, stream, dp, J, span, v, y);
+      if (hp.calib) hipLaunchKernelGGL(k_jv<30>, dim3(xcd_grid(dp.n_chunks)), dim3(kThreads), 0, stream, dp, J, span, v, y);
+      else hipLaunchKernelGGL(k_jv<21>, dim3(xcd_grid(dp.n_chunks)), dim3(kThreads), 0, stream, dp, J, span, v, y);
     }
     if (hp.T > 0) hipLaunchKernelGGL(k_motion_jv, dim3((hp.T + kThreads - 1) / kThreads), dim3(kThreads), 0, stream, dp, mJ, mctrl, v, y + 2 * hp.M);
     MVUS_HIP(hipGetLastError());
@@ -460,11 +460,11 @@ struct HipBackend {
     const dim3 g2(hp.C + (hp.N + kThreads / 64 - 1) / (kThreads / 64)), b(kThreads);
     const int motion = hp.T > 0 ? 1 : 0;
     if (hp.calib) {
-      if (dp.n_chunks > 0) hipLaunchKernelGGL(k_jtu_partial<30>, dim3(dp.n_chunks), b, 0, stream, dp, J, span, u, z, zc, zs, zg0, jt_nondet);
+      if (dp.n_chunks > 0) hipLaunchKernelGGL(k_jtu_partial<30>, dim3(xcd_grid(dp.n_chunks)), b, 0, stream, dp, J, span, u, z, zc, zs, zg0, jt_nondet);
       hipLaunchKernelGGL(k_jtu_index, dim3(hp.C), dim3(64), 0, stream, dp, zg0, zfill);
       hipLaunchKernelGGL(k_jtu_reduce<30>, g2, b, 0, stream, dp, zc, zs, zg0, zfill, mJ, mctrl, u + 2 * hp.M, motion, z);
     } else {
-      if (dp.n_chunks > 0) hipLaunchKernelGGL(k_jtu_partial<21>, dim3(dp.n_chunks), b, 0, stream, dp, J, span, u, z, zc, zs, zg0, jt_nondet);
+      if (dp.n_chunks > 0) hipLaunchKernelGGL(k_jtu_partial<21>, dim3(xcd_grid(dp.n_chunks)), b, 0, stream, dp, J, span, u, z, zc, zs, zg0, jt_nondet);
       hipLaunchKernelGGL(k_jtu_index, dim3(hp.C), dim3(64), 0, stream, dp, zg0, zfill);
       hipLaunchKernelGGL(k_jtu_reduce<21>, g2, b, 0, stream, dp, zc, zs, zg0, zfill, mJ, mctrl, u + 2 * hp.M, motion, z);
     }
@@ -901,8 +901,8 @@ int mvus_ba_time_kernel(mvus_ba* h, int32_t which, int32_t launches, double* avg
           break;
         }
         case 2:
-          if (be.hp.calib) hipLaunchKernelGGL(k_jv<30>, g, b, 0, be.stream, be.dp, be.J, be.span, vn, ym);
-          else hipLaunchKernelGGL(k_jv<21>, g, b, 0, be.stream, be.dp, be.J, be.span, vn, ym);
+          if (be.hp.calib) hipLaunchKernelGGL(k_jv<30>, dim3(xcd_grid(be.dp.n_chunks)), b, 0, be.stream, be.dp, be.J, be.span, vn, ym);
+          else hipLaunchKernelGGL(k_jv<21>, dim3(xcd_grid(be.dp.n_chunks)), b, 0, be.stream, be.dp, be.J, be.span, vn, ym);
           break;
         case 3:
           be.jtu_local(um, zn);

@@ -247,7 +247,8 @@ __global__ __launch_bounds__(kThreads) void k_jv(DevProblem dp, const double* __
                                                  const double* __restrict__ v, double* __restrict__ y) {
   constexpr int B = NS - 12;
   __shared__ double vc[B];
-  const int chunk = blockIdx.x;
+    const int chunk = xcd_tile(dp.n_chunks);        // grid = xcd_grid(n_chunks): every XCD streams runs of consecutive chunks of J
+  if (chunk >= dp.n_chunks) return;
   const int c = dp.chunk_cam[chunk];
   if (threadIdx.x < B) vc[threadIdx.x] = v[cam_col(dp.C, dp.P, c, threadIdx.x)];
   __syncthreads();
@@ -301,7 +302,8 @@ __global__ __launch_bounds__(kThreads) void k_jtu_partial(DevProblem dp, const d
   __shared__ int lo[kJtWin], hi[kJtWin], skey[kThreads];
   __shared__ int gmin_s[kThreads / 64];
   __shared__ int bad_s, wide_s;
-  const int chunk = blockIdx.x;
+    const int chunk = xcd_tile(dp.n_chunks);        // grid = xcd_grid(n_chunks): every XCD streams runs of consecutive chunks of J
+  if (chunk >= dp.n_chunks) return;
   const ChunkInfo ci = dp.chunks[chunk];
   const bool active = (int)threadIdx.x < ci.count;
   const long long i = ci.start + (active ? threadIdx.x : 0);

@@ -767,9 +767,9 @@ __global__ __launch_bounds__(64) void k_part_cholesky(PartView pv, double* __res
 // cache line, ~1-2 us away).
 constexpr int kPsPf = 16;
 template <int BW, bool COUPLING>
-__device__ __forceinline__ void part_solve_block(const PartView& pv, int ncols, const double* __restrict__ Lb, double* __restrict__ Z, double* Ls) {
+__device__ __forceinline__ void part_solve_block(const PartView& pv, int ncols, const double* __restrict__ Lb, double* __restrict__ Z, double* Ls, int p, int by) {
   constexpr int R = BW + 1, kPf = kPsPf;
-  const int p = blockIdx.x, tid = threadIdx.x;
+  const int tid = threadIdx.x;
   const int s3 = pv.s3;
   const int r0 = pv.i0[p], nr = pv.i1[p] - r0;
   const int nrp = (nr + kPf - 1) / kPf * kPf;                // rows padded to whole batches
@@ -784,10 +784,10 @@ __device__ __forceinline__ void part_solve_block(const PartView& pv, int ncols, 
     live = tid < 2 * s3 && (tid < s3 ? pv.sl[p] >= 0 : pv.sr[p] >= 0);
     if (live) ccol = tid < s3 ? pv.sl[p] + tid : pv.sr[p] + (tid - s3);
   } else {
-    live = (int)(blockIdx.y * 64 + tid) < ncols;
+    live = (int)(by * 64 + tid) < ncols;
   }
   if (!live) return;                                         // no barrier below
-  double* out = COUPLING ? pv.VW + ((long long)p * kPartRowsMax) * (2 * s3) + tid : Z + (long long)r0 * ncols + blockIdx.y * 64 + tid;
+  double* out = COUPLING ? pv.VW + ((long long)p * kPartRowsMax) * (2 * s3) + tid : Z + (long long)r0 * ncols + by * 64 + tid;
   const long long ostride = COUPLING ? 2 * s3 : ncols;
   auto rhs_at = [&](int i) { return i < nr ? (COUPLING ? band_entry<BW>(Lb, r0 + i, ccol) : out[(long long)i * ostride]) : 0.0; };
   double yw[BW];           // yw[0] = newest value
@@ -847,13 +847,18 @@ __device__ __forceinline__ void part_solve_block(const PartView& pv, int ncols, 
   }
 }
 
-// blockIdx.y < gridDim.y - 1: 64 right-hand-side columns; the last block row: the coupling columns (same launch, so
-// that they run beside the others instead of after them)
+// column blocks 0 .. gy-2: 64 right-hand-side columns each; the last one: the coupling columns (same launch, so that they run
+// beside the others instead of after them)
 template <int BW>
-__global__ __launch_bounds__(64) void k_part_solve(PartView pv, int ncols, const double* __restrict__ Lb, double* __restrict__ Z) {
+__global__ __launch_bounds__(64) void k_part_solve(PartView pv, int ncols, const double* __restrict__ Lb, double* __restrict__ Z, int gy) {
   __shared__ double Ls[(kPartRowsMax + 2 * kPsPf) * (BW + 1)];
-  if (blockIdx.y + 1 == gridDim.y) part_solve_block<BW, true>(pv, ncols, Lb, Z, Ls);
-  else part_solve_block<BW, false>(pv, ncols, Lb, Z, Ls);
+  // 1-D grid: the gy column blocks of one interior are consecutive tiles, runs of tiles per XCD (xcd_tile): 48.9 -> 46.6 us
+  const int tiles = pv.P * gy;
+  const int tile = xcd_tile(tiles);
+  if (tile >= tiles) return;
+  const int p = tile / gy, by = tile % gy;
+  if (by + 1 == gy) part_solve_block<BW, true>(pv, ncols, Lb, Z, Ls, p, by);
+  else part_solve_block<BW, false>(pv, ncols, Lb, Z, Ls, p, by);
 }
 
 // separator system: T(q,q), T(q,q+1) and the reduced right-hand sides (in place in the separator rows of Z)
@@ -1313,12 +1318,18 @@ __global__ __launch_bounds__(256) void k_sep_bcr_rhs(PartView pv, int ncols) {
 // costs one coalesced load, 2*S3 FMAs and one store.
 constexpr int kBackRows = 16;      // rows per workgroup: enough workgroups in flight to hide the load latency
 template <int S3>
-__global__ __launch_bounds__(64) void k_part_back(PartView pv, int ncols, double* __restrict__ Z) {
-  const int p = blockIdx.x, col = blockIdx.y * 64 + threadIdx.x;
+__global__ __launch_bounds__(64) void k_part_back(PartView pv, int ncols, double* __restrict__ Z, int gy, int gz) {
+  // 1-D grid, tiles ordered column block fastest, then row block, then interior, handed to the XCDs in runs (xcd_tile):
+  // one XCD reads and writes whole consecutive rows of Z (22.1 -> 20.3 us)
+  const int tiles = pv.P * gy * gz;
+  const int tile = xcd_tile(tiles);
+  if (tile >= tiles) return;
+  const int by = tile % gy, bz = (tile / gy) % gz, p = tile / (gy * gz);
+  const int col = by * 64 + threadIdx.x;
   if (col >= ncols) return;
   constexpr int st = 2 * S3;
   const int r0 = pv.i0[p], n = pv.i1[p] - r0;
-  const int ia = blockIdx.z * kBackRows, ib = min(n, ia + kBackRows);      // rows of this workgroup
+  const int ia = bz * kBackRows, ib = min(n, ia + kBackRows);      // rows of this workgroup
   if (ia >= n) return;
   const bool left = pv.sl[p] >= 0, right = pv.sr[p] >= 0;
   const double* __restrict__ VWp = pv.VW + ((long long)p * kPartRowsMax) * st;
@@ -1328,7 +1339,7 @@ __global__ __launch_bounds__(64) void k_part_back(PartView pv, int ncols, double
     zl[a] = left ? pv.R[((long long)(pv.q_off + p - 1) * S3 + a) * ncols + col] : 0.0;
     zr[a] = right ? pv.R[((long long)(pv.q_off + p) * S3 + a) * ncols + col] : 0.0;
   }
-  if (right && blockIdx.z == 0) {          // the solved separator right of this interior goes back into its rows of Z
+  if (right && bz == 0) {          // the solved separator right of this interior goes back into its rows of Z
 #pragma unroll
     for (int a = 0; a < S3; ++a) Z[(long long)(pv.sr[p] + a) * ncols + col] = zr[a];
   }
@@ -1962,7 +1973,7 @@ struct HipSchur {
   void band_chain() {
     const dim3 gsolve(pv.P, (ncols + 63) / 64 + 1);      // + one block row for the coupling columns
     hipLaunchKernelGGL(k_part_cholesky<BWT>, dim3(pv.P), dim3(64), 0, be.stream, pv, Lb, fail);
-    hipLaunchKernelGGL(k_part_solve<BWT>, gsolve, dim3(64), 0, be.stream, pv, ncols, Lb, Z);
+    hipLaunchKernelGGL(k_part_solve<BWT>, dim3(xcd_grid(pv.P * (int)gsolve.y)), dim3(64), 0, be.stream, pv, ncols, Lb, Z, (int)gsolve.y);
     if (pv.m > 0) {
       if (shard) MVUS_HIP(hipMemsetAsync(sepbuf, 0, sep_count * sizeof(double), be.stream));      // other ranks' separators: zero here
       if (pv.nt > 0) hipLaunchKernelGGL(k_part_reduce<BWT>, dim3(pv.nt, (pv.s3 * ncols + 255) / 256), dim3(256), 0, be.stream, pv, ncols, Lb, Z);
@@ -1978,8 +1989,9 @@ struct HipSchur {
         hipLaunchKernelGGL(k_sep_factor<S3T>, dim3(1), dim3(64), 0, be.stream, pv, fail);
         hipLaunchKernelGGL(k_sep_rhs<S3T>, dim3((ncols + 63) / 64), dim3(64), 0, be.stream, pv, ncols);
       }
-      const dim3 gback(pv.P, (ncols + 63) / 64, (kPartRowsMax + kBackRows - 1) / kBackRows);
-      hipLaunchKernelGGL(k_part_back<S3T>, gback, dim3(64), 0, be.stream, pv, ncols, Z);
+      const int gy = (ncols + 63) / 64, gz = (kPartRowsMax + kBackRows - 1) / kBackRows;
+      const dim3 gback(xcd_grid(pv.P * gy * gz));
+      hipLaunchKernelGGL(k_part_back<S3T>, gback, dim3(64), 0, be.stream, pv, ncols, Z, gy, gz);
     }
   }
 
