@@ -13,6 +13,17 @@ __global__ __launch_bounds__(256) void store8(double* __restrict__ J, long long 
 #pragma unroll
   for (int k = 0; k < NS2; ++k) { v = v * 1.0000001 + 0.5; J[(long long)k * M + i] = v; }
 }
+// the same 8-byte pattern with the workgroups of one XCD (blockIdx % 8) working on runs of RUN consecutive 2 KB tiles
+template <int RUN>
+__global__ __launch_bounds__(256) void store8_xcd(double* __restrict__ J, long long M, double seed) {
+  const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+  const long long tile = ((long long)(q / RUN) * 8 + xcd) * RUN + q % RUN;
+  const long long i = tile * 256ll + threadIdx.x;
+  if (i >= M) return;
+  double v = seed + (double)i;
+#pragma unroll
+  for (int k = 0; k < NS2; ++k) { v = v * 1.0000001 + 0.5; J[(long long)k * M + i] = v; }
+}
 __global__ __launch_bounds__(256) void store16(double* __restrict__ J, long long M, double seed) {
   const long long i = 2 * (blockIdx.x * 256ll + threadIdx.x);
   if (i + 1 >= M) return;
@@ -57,14 +68,21 @@ int main(int argc, char** argv) {
   for (auto& b : bufs) CK(hipMalloc(&b, sizeof(double) * NS2 * M));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   const double bytes = (double)NS2 * M * 8;
-  for (int variant = 0; variant < 3; ++variant) {
+  for (int variant = 0; variant < 6; ++variant) {
     for (int rot = 0; rot < 2; ++rot) {
       const int nb = rot ? NROT : 1;
       auto launch = [&](int it) {
         double* J = bufs[it % nb];
         if (variant == 0) hipLaunchKernelGGL(store8, dim3((M + 255) / 256), dim3(256), 0, 0, J, M, 1.0);
         else if (variant == 1) hipLaunchKernelGGL(store16, dim3((M / 2 + 255) / 256), dim3(256), 0, 0, J, M, 1.0);
-        else hipLaunchKernelGGL(store16x, dim3((M + 255) / 256), dim3(256), 0, 0, J, M, 1.0);
+        else if (variant == 2) hipLaunchKernelGGL(store16x, dim3((M + 255) / 256), dim3(256), 0, 0, J, M, 1.0);
+        else {
+          const int run = variant == 3 ? 8 : variant == 4 ? 64 : 256;
+          const long long tiles = (M + 255) / 256, per = 8 * run, grid = (tiles + per - 1) / per * per;
+          if (variant == 3) hipLaunchKernelGGL(store8_xcd<8>, dim3(grid), dim3(256), 0, 0, J, M, 1.0);
+          else if (variant == 4) hipLaunchKernelGGL(store8_xcd<64>, dim3(grid), dim3(256), 0, 0, J, M, 1.0);
+          else hipLaunchKernelGGL(store8_xcd<256>, dim3(grid), dim3(256), 0, 0, J, M, 1.0);
+        }
       };
       for (int it = 0; it < NROT; ++it) launch(it);
       CK(hipEventRecord(e0, 0));
@@ -73,7 +91,7 @@ int main(int argc, char** argv) {
       CK(hipEventSynchronize(e1));
       float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
       const double us = 1e3 * ms / reps;
-      printf("%-8s %s: %.1f us per launch, %.0f GB/s\n", variant == 0 ? "store8" : variant == 1 ? "store16" : "store16x", rot ? "rotating 6 x 169 MB" : "one buffer        ", us, bytes / us * 1e-3);
+      printf("%-8s %s: %.1f us per launch, %.0f GB/s\n", variant == 0 ? "store8" : variant == 1 ? "store16" : variant == 2 ? "store16x" : variant == 3 ? "xcd8" : variant == 4 ? "xcd64" : "xcd256", rot ? "rotating 6 x 169 MB" : "one buffer        ", us, bytes / us * 1e-3);
     }
   }
   return 0;
