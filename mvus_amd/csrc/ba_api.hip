@@ -273,7 +273,7 @@ struct HipBackend {
   double dot_m(const double* a, const double* b) { dot_to_slot(a, b, hp.m, 1); reduce(scal_dev + 1, 1); return read_slot(1); }
 
   // the slot Jacobian (2*NS*M doubles) is allocated on first use: residual-only handles (Scene.error_cam, outlier masks) never pay for it
-  void ensure_J() { if (!J) J = dalloc<double>((size_t)2 * hp.NS * std::max<int64_t>(hp.M, 1)); }
+  void ensure_J() { if (!J) J = dalloc<double>(j_doubles(hp.NS, dp.n_chunks)); }      // sized at first use; outlier removal only ever shrinks the chunk table
   void eval(const double* x, double* f, bool jac, int jac_mode) {
     if (jac) ensure_J();
     const bool masked = jac && jac_mode == MVUS_JAC_PATTERN;
@@ -619,10 +619,19 @@ int mvus_ba_residual_jacobian(mvus_ba* h, const double* x, int32_t jac_mode, dou
     HipBackend& be = h->be;
     be.upload(be.x_cur, x, be.hp.n);
     // rows that stay invisible are never written by the kernel: clear so the host copy is well defined
-    if (J) { be.ensure_J(); MVUS_HIP(hipMemsetAsync(be.J, 0, sizeof(double) * 2 * be.hp.NS * be.hp.M, be.stream)); }
+    if (J) { be.ensure_J(); MVUS_HIP(hipMemsetAsync(be.J, 0, sizeof(double) * j_doubles(be.hp.NS, be.dp.n_chunks), be.stream)); }
     be.jacobian(be.x_cur, be.f_cur, jac_mode);
     if (f) be.download(f, be.f_cur, be.hp.m);
-    if (J) be.download(J, be.J, (int64_t)2 * be.hp.NS * be.hp.M);
+    if (J) {                                 // the ABI's layout is slot-major (mvus_ba.h); the device keeps J chunk-major
+      PoolGuard<HipBackend> pool(be);
+      double* Jout = pool.get((int64_t)2 * be.hp.NS * std::max<int64_t>(be.hp.M, 1));
+      MVUS_HIP(hipMemsetAsync(Jout, 0, sizeof(double) * 2 * be.hp.NS * be.hp.M, be.stream));
+      if (be.dp.n_chunks > 0) {
+        if (be.hp.calib) hipLaunchKernelGGL(k_j_export<30>, dim3(be.dp.n_chunks), dim3(kThreads), 0, be.stream, be.dp, be.J, Jout);
+        else hipLaunchKernelGGL(k_j_export<21>, dim3(be.dp.n_chunks), dim3(kThreads), 0, be.stream, be.dp, be.J, Jout);
+      }
+      be.download(J, Jout, (int64_t)2 * be.hp.NS * be.hp.M);
+    }
     if (ctrl) {
       MVUS_HIP(hipMemcpyAsync(ctrl, be.span, sizeof(int32_t) * be.hp.M, hipMemcpyDeviceToHost, be.stream));
       MVUS_HIP(hipStreamSynchronize(be.stream));
@@ -871,7 +880,7 @@ int mvus_ba_time_kernel(mvus_ba* h, int32_t which, int32_t launches, double* avg
     std::vector<void*> extra;
     auto free_extra = [&]() { for (void* p : extra) (void)hipFree(p); extra.clear(); };
     if (which == 1) {
-      const size_t jb = sizeof(double) * 2 * (size_t)be.hp.NS * (size_t)std::max<int64_t>(be.hp.M, 1);
+      const size_t jb = sizeof(double) * j_doubles(be.hp.NS, be.dp.n_chunks);
       const size_t want = (size_t)1 << 30;                                   // >= 1 GiB in rotation (4x the Infinity Cache)
       const int nrot = (int)std::min<size_t>(16, std::max<size_t>(3, (want + jb - 1) / jb));
       for (int r = 1; r < nrot; ++r) {

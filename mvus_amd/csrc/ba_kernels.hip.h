@@ -117,6 +117,15 @@ __device__ __forceinline__ int xcd_tile(int tiles) {
 #if !defined(MVUS_JAC_ARRAY) && !defined(MVUS_JAC_DIRECT)
 #define MVUS_JAC_DIRECT 1        // default: values go to memory as they are produced (98 VGPRs; the array form needs 128 + scratch)
 #endif
+// Chunk-major Jacobian: the 2*NS slot rows of one <=256-detection chunk are adjacent in memory,
+//     J[(chunk * 2*NS + r) * kThreads + lane],   r = k (x row of slot k) or NS + k (y row),
+// so a workgroup writes (and J v / J^T u / the assembly read) ONE contiguous 2*NS*2 KB block instead of 2*NS pieces M*8 bytes
+// apart: the bare store pattern gains 8 % at 504k detections and 15 % at 2 M over the slot-major layout even with the XCD-aware
+// order (tools/micro/store_bw.hip).  The C ABI keeps the slot-major layout (k_j_export converts on the way out).
+template <int NS>
+MVUS_HD long long j_chunk_offset(int chunk) { return (long long)chunk * (2 * NS * kThreads); }
+inline size_t j_doubles(int NS, int n_chunks) { return (size_t)2 * NS * kThreads * (size_t)(n_chunks > 0 ? n_chunks : 1); }
+
 #if defined(MVUS_JAC_NT)
 #define MVUS_JSTORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
 #elif defined(MVUS_JAC_SC1)
@@ -166,8 +175,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(JAC ? 
   const double ur = CALIB ? dp.u_raw[i] : 0.0;
 #ifdef MVUS_JAC_DIRECT
   // every Jacobian value goes to memory as soon as it exists: the row never sits in registers as a whole
-  double* __restrict__ Jc = J + ci.start;          // wave-uniform
-  JStoreSink sink{Jc, Jc + (long long)NS * dp.M, dp.M, (JAC && masked) ? pat0[i] : 0, NS - 12, JAC && masked != 0, true, -1, threadIdx.x};
+  double* __restrict__ Jc = J + j_chunk_offset<NS>(chunk);          // wave-uniform
+  JStoreSink sink{Jc, Jc + NS * kThreads, kThreads, (JAC && masked) ? pat0[i] : 0, NS - 12, JAC && masked != 0, true, -1, threadIdx.x};
   ObsResult r = eval_observation_to<CALIB, JAC>(cam, dp.sp, x, dp.undist != 0, dp.rs_free != 0, dp.sync_free != 0, dp.frame[i], ur, dp.v_raw[i], uo, vo, sink);
   f[2 * a + (i - a)] = r.ex;
   f[2 * a + Mc + (i - a)] = r.ey;
@@ -189,13 +198,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(JAC ? 
     if (ctrl >= 0) {
 #pragma unroll
       for (int k = 0; k < NS; ++k) {
-#ifdef MVUS_JAC_SADDR
-        MVUS_JSTORE(&(J + ci.start + (long long)k * dp.M)[threadIdx.x], jx[k]);         // SGPR base + 32-bit lane offset
-        MVUS_JSTORE(&(J + ci.start + (long long)(NS + k) * dp.M)[threadIdx.x], jy[k]);
-#else
-        MVUS_JSTORE(&J[(long long)k * dp.M + i], jx[k]);
-        MVUS_JSTORE(&J[(long long)(NS + k) * dp.M + i], jy[k]);
-#endif
+        MVUS_JSTORE(&(J + j_chunk_offset<NS>(chunk) + k * kThreads)[threadIdx.x], jx[k]);
+        MVUS_JSTORE(&(J + j_chunk_offset<NS>(chunk) + (NS + k) * kThreads)[threadIdx.x], jy[k]);
       }
     }
   }
@@ -241,6 +245,16 @@ __global__ __launch_bounds__(kThreads) void k_motion(DevProblem dp, const double
 
 __device__ __forceinline__ int cam_col(int C, int P, int c, int k) { return k < 3 ? k * C + c : 3 * C + c * P + (k - 3); }
 
+// the C ABI's slot-major copy of the Jacobian, Jout[r * M + i], from the chunk-major device layout (inspection calls only)
+template <int NS>
+__global__ __launch_bounds__(kThreads) void k_j_export(DevProblem dp, const double* __restrict__ J, double* __restrict__ Jout) {
+  const int chunk = blockIdx.x;
+  if ((int)threadIdx.x >= dp.chunk_count[chunk]) return;
+  const long long i = dp.chunk_start[chunk] + threadIdx.x;
+  const double* __restrict__ Jc = J + j_chunk_offset<NS>(chunk) + threadIdx.x;
+  for (int r = 0; r < 2 * NS; ++r) Jout[(long long)r * dp.M + i] = Jc[r * kThreads];
+}
+
 // y = J v on the detection rows.  Camera/sync entries of v are staged in LDS once per workgroup.
 template <int NS>
 __global__ __launch_bounds__(kThreads) void k_jv(DevProblem dp, const double* __restrict__ J, const int32_t* __restrict__ span,
@@ -256,12 +270,13 @@ __global__ __launch_bounds__(kThreads) void k_jv(DevProblem dp, const double* __
   const long long i = dp.chunk_start[chunk] + threadIdx.x;
   const long long a = dp.det_off[c], Mc = dp.det_off[c + 1] - a;
   const int g = span[i];
+  const double* __restrict__ Jc = J + j_chunk_offset<NS>(chunk) + threadIdx.x;
   double sx = 0.0, sy = 0.0;
   if (g >= 0) {
 #pragma unroll
     for (int k = 0; k < B; ++k) {
-      sx += J[(long long)k * dp.M + i] * vc[k];
-      sy += J[(long long)(NS + k) * dp.M + i] * vc[k];
+      sx += Jc[k * kThreads] * vc[k];
+      sy += Jc[(NS + k) * kThreads] * vc[k];
     }
     const int x0 = dp.mv.ctrl_x0[g], st = dp.mv.ctrl_stride[g];
 #pragma unroll
@@ -269,8 +284,8 @@ __global__ __launch_bounds__(kThreads) void k_jv(DevProblem dp, const double* __
 #pragma unroll
       for (int d = 0; d < 3; ++d) {
         const double vv = v[x0 + q + d * st];
-        sx += J[(long long)(B + 3 * q + d) * dp.M + i] * vv;
-        sy += J[(long long)(NS + B + 3 * q + d) * dp.M + i] * vv;
+        sx += Jc[(B + 3 * q + d) * kThreads] * vv;
+        sy += Jc[(NS + B + 3 * q + d) * kThreads] * vv;
       }
   }
   y[2 * a + (i - a)] = sx;
@@ -312,6 +327,7 @@ __global__ __launch_bounds__(kThreads) void k_jtu_partial(DevProblem dp, const d
   const double ux = g >= 0 ? u[2 * a + (i - a)] : 0.0;
   const double uy = g >= 0 ? u[2 * a + Mc + (i - a)] : 0.0;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const double* __restrict__ Jc = J + j_chunk_offset<NS>(chunk) + (active ? threadIdx.x : 0);
   for (int k = threadIdx.x; k < kJtWin; k += kThreads) { lo[k] = 0x7fffffff; hi[k] = 0; }
   if (threadIdx.x == 0) { bad_s = 0; wide_s = 0; }
   skey[threadIdx.x] = g;
@@ -322,7 +338,7 @@ __global__ __launch_bounds__(kThreads) void k_jtu_partial(DevProblem dp, const d
 #pragma unroll
   for (int k = 0; k < B; ++k) {
     double val = 0.0;
-    if (g >= 0) val = J[(long long)k * dp.M + i] * ux + J[(long long)(NS + k) * dp.M + i] * uy;
+    if (g >= 0) val = Jc[k * kThreads] * ux + Jc[(NS + k) * kThreads] * uy;
     val = wave_sum(val);
     if (lane == 0) part[wave][k] = val;
   }
@@ -343,7 +359,7 @@ __global__ __launch_bounds__(kThreads) void k_jtu_partial(DevProblem dp, const d
   double pv[12];
 #pragma unroll
   for (int e = 0; e < 12; ++e) {
-    pv[e] = g >= 0 ? J[(long long)(B + e) * dp.M + i] * ux + J[(long long)(NS + B + e) * dp.M + i] * uy : 0.0;
+    pv[e] = g >= 0 ? Jc[(B + e) * kThreads] * ux + Jc[(NS + B + e) * kThreads] * uy : 0.0;
     prod[e * PS + threadIdx.x] = pv[e];
   }
   if (g >= 0) {
@@ -709,8 +725,8 @@ __global__ __launch_bounds__(kThreads) void k_fd_fill(DevProblem dp, long long m
       jx = (Fg[rx] - fx) / dx[col];
       jy = (Fg[ry] - fy) / dx[col];
     }
-    J[(long long)k * dp.M + i] = jx;
-    J[(long long)(NS + k) * dp.M + i] = jy;
+    J[j_chunk_offset<NS>(chunk) + k * kThreads + threadIdx.x] = jx;
+    J[j_chunk_offset<NS>(chunk) + (NS + k) * kThreads + threadIdx.x] = jy;
   }
 }
 __global__ __launch_bounds__(kThreads) void k_fd_fill_motion(DevProblem dp, long long m, const double* __restrict__ f0, const double* __restrict__ F,

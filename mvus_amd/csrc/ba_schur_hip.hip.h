@@ -151,7 +151,7 @@ __global__ __launch_bounds__(kGaThreads) void k_assemble_spans(DevProblem dp, co
       if (r >= 2 * NS + 2) break;
       double v = 0.0;
       if (g >= 0) {
-        if (r < 2 * NS) v = J[(long long)r * dp.M + i0 + t];
+        if (r < 2 * NS) v = J[j_chunk_offset<NS>(chunk) + r * kThreads + half * kGaObs + t];
         else v = f[2 * a0 + (r - 2 * NS) * Mc + (i0 + t - a0)];
       }
       Js[r * kGaStride + t] = v;
