@@ -126,14 +126,17 @@ template <int NS>
 MVUS_HD long long j_chunk_offset(int chunk) { return (long long)chunk * (2 * NS * kThreads); }
 inline size_t j_doubles(int NS, int n_chunks) { return (size_t)2 * NS * kThreads * (size_t)(n_chunks > 0 ? n_chunks : 1); }
 
-#if defined(MVUS_JAC_NT)
-#define MVUS_JSTORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
+// The Jacobian is written once and read by other kernels later: non-temporal stores.  With the chunk-major layout they take the
+// kernel from 39.4 to 35.2 us when the outputs go to HBM (with the slot-major layout they cost +4 us, with plain stores into a
+// cache-resident buffer they are 1 us slower): measured, tools/micro/ab_kernel.sh.  MVUS_JAC_PLAIN / MVUS_JAC_SC1: the variants.
+#if defined(MVUS_JAC_PLAIN)
+#define MVUS_JSTORE(ptr, val) (*(ptr) = (val))
 #elif defined(MVUS_JAC_SC1)
 #define MVUS_JSTORE(ptr, val) __hip_atomic_store((ptr), (val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #else
-#define MVUS_JSTORE(ptr, val) (*(ptr) = (val))
+#define MVUS_JSTORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
 #endif
-// Sink of eval_observation_to that stores each value of the 2 x NS block straight to the slot-major Jacobian
+// Sink of eval_observation_to that stores each value of the 2 x NS block straight to the chunk-major Jacobian
 // (masked: spline slots outside the pattern become zeros; an all-zero pattern row stores nothing).
 struct JStoreSink {
   double *Jx, *Jy;
