@@ -4,13 +4,14 @@
 //   frame[M] u_raw[M] v_raw[M]            raw detections (common.py:1190)
 //   u_obs[M] v_obs[M]                     observed pixel after the one-time undistortion (fixed calibration)
 //   f[m]                                  residuals in the reference row order (common.py:476-485)
-//   J[(a*NS + k)*M + i]                   Jacobian slot k of row a (0:x, 1:y) of observation i -> every one of
-//                                         the 2*NS stores / loads of a wavefront is one contiguous 512-B segment
+//   J[(chunk*2*NS + a*NS + k)*256 + lane] Jacobian slot k of row a (0:x, 1:y) of the lane-th detection of a chunk (chunk-major:
+//                                         one contiguous 2*NS*2 KB block per workgroup, every store / load of a wavefront
+//                                         one contiguous 512-B segment; see j_chunk_offset)
 //   span[M]                               first active control point (global index), -1 = row is zero
 // Work decomposition: one 256-thread workgroup (4 wavefronts of 64) per chunk of <=256 consecutive
 // detections of ONE camera, so the camera's decoded parameters (R, t, K, d, alpha, beta, rs and the
-// rotation-derivative matrix W) are staged once per workgroup in LDS and every lane reads them as LDS
-// broadcasts; consecutive lanes hold consecutive frames, i.e. neighbouring timestamps, so their knot-span
+// rotation-derivative matrix W) are wave-uniform and come through the scalar cache into SGPRs;
+// consecutive lanes hold consecutive frames, i.e. neighbouring timestamps, so their knot-span
 // searches and control-point gathers hit the same L1/L2 lines.
 #pragma once
 #include <hip/hip_runtime.h>
