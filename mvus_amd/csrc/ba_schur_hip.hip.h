@@ -1106,6 +1106,10 @@ __device__ __forceinline__ void lds_wave_sync() {      // orders the LDS traffic
 // Stored for k_sep_bcr_rhs: Dinv_j, Ha_j, Hc_j of jR (and of jL for the first survivor, whose left neighbour nobody else
 // owns).  s = 0 with no survivor at all is the last level: the one remaining node is inverted.
 // w: 3 * S3 * S3 doubles of LDS private to the wavefront.
+// The blocks read here may have been written by ANOTHER wavefront of the same workgroup one level earlier (k_sep_bcr_tail), and a
+// 128-byte line can straddle two 648-byte blocks: a line fetched into the CU's L1 for one block before a neighbour's store to
+// the other landed would be stale at the next level.  Agent-scope loads go to L2, where the stores are.
+__device__ __forceinline__ double bcr_ld(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 template <int S3>
 __device__ __forceinline__ void bcr_survivor(const PartView& pv, int h, int s, double* __restrict__ w, int* __restrict__ fail) {
   constexpr int SS = S3 * S3, KS = (S3 + 3) / 4;
@@ -1119,18 +1123,18 @@ __device__ __forceinline__ void bcr_survivor(const PartView& pv, int h, int s, d
   const double* Tsrc = pv.T + (long long)(nl == 0 ? jL : (right ? jR : 0)) * SS + a * S3;
   double row[S3];
 #pragma unroll
-  for (int b = 0; b < S3; ++b) row[b] = act ? Tsrc[b] : (a == b ? 1.0 : 0.0);
+  for (int b = 0; b < S3; ++b) row[b] = act ? bcr_ld(Tsrc + b) : (a == b ? 1.0 : 0.0);
   double cL[KS], ci[KS], cR[KS], ti[4];
 #pragma unroll
   for (int s_ = 0; s_ < KS; ++s_) {
     const int k = 4 * s_ + lk;
     const bool ok = lr < S3 && k < S3;
-    cL[s_] = (ok && has_i) ? Cc[(long long)jL * SS + k * S3 + lr] : 0.0;        // C_jL[k][lr]: B operand of Hc_jL, A operand (transposed) of the D update
-    ci[s_] = (ok && right) ? Cc[(long long)i * SS + lr * S3 + k] : 0.0;         // C_i[lr][k]: B operand (transposed) of Ha_jR, A operand of both updates
-    cR[s_] = (ok && right2) ? Cc[(long long)jR * SS + k * S3 + lr] : 0.0;       // C_jR[k][lr]
+    cL[s_] = (ok && has_i) ? bcr_ld(Cc + (long long)jL * SS + k * S3 + lr) : 0.0;        // C_jL[k][lr]: B operand of Hc_jL, A operand (transposed) of the D update
+    ci[s_] = (ok && right) ? bcr_ld(Cc + (long long)i * SS + lr * S3 + k) : 0.0;         // C_i[lr][k]: B operand (transposed) of Ha_jR, A operand of both updates
+    cR[s_] = (ok && right2) ? bcr_ld(Cc + (long long)jR * SS + k * S3 + lr) : 0.0;       // C_jR[k][lr]
   }
 #pragma unroll
-  for (int r = 0; r < 4; ++r) { const int rw = lk + 4 * r; ti[r] = (has_i && rw < S3 && lr < S3) ? pv.T[(long long)i * SS + rw * S3 + lr] : 0.0; }
+  for (int r = 0; r < 4; ++r) { const int rw = lk + 4 * r; ti[r] = (has_i && rw < S3 && lr < S3) ? bcr_ld(pv.T + (long long)i * SS + rw * S3 + lr) : 0.0; }
   // ---- Dinv of both neighbours: a block row per lane, the pivot row of each Gauss-Jordan step broadcast with shuffles ----
   bool bad = false;
 #pragma unroll
