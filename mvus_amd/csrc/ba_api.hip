@@ -1204,6 +1204,9 @@ int mvus_spline_smooth(int32_t device, int64_t m, const double* u, const double*
   } catch (const HipError& e) {
     g_create_error = e.msg;
     return e.msg.find("positive definite") != std::string::npos ? MVUS_E_NUMERIC : MVUS_E_HIP;
+  } catch (const std::exception& e) {          // bad_alloc / length_error on absurd sizes must not cross the C ABI
+    g_create_error = e.what();
+    return MVUS_E_INVALID;
   }
   return MVUS_OK;
 }
@@ -1219,6 +1222,7 @@ int mvus_pnp_ransac(int32_t device, int64_t N, const double* X, const double* uv
   for (int64_t i = 0; i < 2 * N; ++i) if (!std::isfinite(uv[i])) { g_create_error = "pnp_ransac: non-finite image point"; return MVUS_E_INVALID; }
   // the object points are centred and scaled (the direct linear transform is badly conditioned otherwise); a pose (R, t')
   // of the scaled points is the pose (R, sigma t' - R m) of the original ones
+  try {
   double m[3] = {0.0, 0.0, 0.0}, sigma = 0.0;
   for (int a = 0; a < 3; ++a) { for (int64_t i = 0; i < N; ++i) m[a] += X[a * N + i]; m[a] /= (double)N; }
   for (int a = 0; a < 3; ++a) for (int64_t i = 0; i < N; ++i) sigma += (X[a * N + i] - m[a]) * (X[a * N + i] - m[a]);
@@ -1227,7 +1231,7 @@ int mvus_pnp_ransac(int32_t device, int64_t N, const double* X, const double* uv
   std::vector<double> Xc(3 * (size_t)N);
   for (int a = 0; a < 3; ++a) for (int64_t i = 0; i < N; ++i) Xc[a * N + i] = (X[a * N + i] - m[a]) / sigma;
   double Kd[9] = {K[0], K[1], K[2], K[3], d[0], d[1], d[2], d[3], d[4]};
-  try {
+  {
     CallBuffers cb;
     cb.open(device);
     const double* dX = cb.put(Xc.data(), Xc.size());
@@ -1305,9 +1309,13 @@ int mvus_pnp_ransac(int32_t device, int64_t N, const double* X, const double* uv
     if (inliers) MVUS_HIP(hipMemcpyAsync(inliers, mask, (size_t)N, hipMemcpyDeviceToHost, cb.st));
     MVUS_HIP(hipStreamSynchronize(cb.st));
     if (n_inliers) *n_inliers = cnt[best];
+  }
   } catch (const HipError& e) {
     g_create_error = e.msg;
     return MVUS_E_HIP;
+  } catch (const std::exception& e) {
+    g_create_error = e.what();
+    return MVUS_E_INVALID;
   }
   return MVUS_OK;
 }
