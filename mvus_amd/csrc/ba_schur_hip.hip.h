@@ -467,7 +467,10 @@ __global__ __launch_bounds__(1024) void k_cam_block_reduce(DevProblem dp, NEView
   __shared__ double part[kGroups][kLanes];
   const int c = blockIdx.x;
   constexpr int kPer = kGaParts * (kGaThreads / 64);                      // partial blocks per 256-chunk: assembly workgroups x wavefronts
-  const int w0 = dp.cam_chunk_off[c] * kPer, w1 = dp.cam_chunk_off[c + 1] * kPer;
+  // two workgroups per camera (blockIdx.y), each over half of the partial blocks; both add into the zeroed A / gc with atomics --
+  // 0 + a + b has the same bits in either order, so the result stays deterministic
+  const int wa = dp.cam_chunk_off[c] * kPer, wb = dp.cam_chunk_off[c + 1] * kPer, wm = wa + (wb - wa + 1) / 2;
+  const int w0 = blockIdx.y == 0 ? wa : wm, w1 = blockIdx.y == 0 ? wm : wb;
   const int k = threadIdx.x % kLanes, grp = threadIdx.x / kLanes;
   // group grp adds the partial blocks w0 + grp, w0 + grp + kGroups, ... (independent loads, four in flight), then the groups are
   // added in index order: a fixed summation tree
@@ -492,10 +495,10 @@ __global__ __launch_bounds__(1024) void k_cam_block_reduce(DevProblem dp, NEView
     int ra = 0;
     while ((ra + 1) * (ra + 2) / 2 <= kk) ++ra;
     const int rb = kk - ra * (ra + 1) / 2;
-    if (ra == B) { if (rb < B) ne.gc[c * B + rb] += v; }
+    if (ra == B) { if (rb < B) unsafeAtomicAdd(&ne.gc[c * B + rb], v); }
     else {
-      ne.A[((long long)c * B + ra) * B + rb] += v;
-      if (ra != rb) ne.A[((long long)c * B + rb) * B + ra] += v;
+      unsafeAtomicAdd(&ne.A[((long long)c * B + ra) * B + rb], v);
+      if (ra != rb) unsafeAtomicAdd(&ne.A[((long long)c * B + rb) * B + ra], v);
     }
   }
 }
@@ -1917,8 +1920,8 @@ struct HipSchur {
       }
     }
     if (be.dp.n_chunks > 0) {
-      if (be.hp.calib) hipLaunchKernelGGL(k_cam_block_reduce<18>, dim3(be.hp.C), dim3(1024), 0, be.stream, be.dp, ne);
-      else hipLaunchKernelGGL(k_cam_block_reduce<9>, dim3(be.hp.C), dim3(1024), 0, be.stream, be.dp, ne);
+      if (be.hp.calib) hipLaunchKernelGGL(k_cam_block_reduce<18>, dim3(be.hp.C, 2), dim3(1024), 0, be.stream, be.dp, ne);
+      else hipLaunchKernelGGL(k_cam_block_reduce<9>, dim3(be.hp.C, 2), dim3(1024), 0, be.stream, be.dp, ne);
     }
     if (be.hp.T > 0)
       hipLaunchKernelGGL(k_assemble_motion, dim3((be.hp.T + kThreads - 1) / kThreads), dim3(kThreads), 0, be.stream, be.dp, be.mJ, be.mctrl,
