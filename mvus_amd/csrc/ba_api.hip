@@ -42,6 +42,7 @@ struct HipBackend {
   int64_t det_capacity = 0;
   // reductions
   double *partials = nullptr, *scal_dev = nullptr, *scal_host = nullptr;
+  double* scal_map = nullptr;     // device address of scal_host (mapped pinned memory): scalar results a kernel writes there need no copy kernel
   // pinned staging ring for the n-vectors that cross PCIe every solve / iteration (x, gradient, bounds): a copy from pageable
   // memory costs ~30 us of host-side staging per call and a synchronisation; through a pinned slot the upload is asynchronous
   static constexpr int kStageSlots = 4;
@@ -110,7 +111,9 @@ struct HipBackend {
     mJ = dalloc<double>((size_t)36 * hp.T); mctrl = dalloc<int32_t>((size_t)3 * hp.T);
     x_cur = dalloc<double>(hp.n); f_cur = dalloc<double>(hp.m);
     partials = dalloc<double>(2048); scal_dev = dalloc<double>(16);
-    MVUS_HIP(hipHostMalloc(reinterpret_cast<void**>(&scal_host), 16 * sizeof(double), hipHostMallocDefault));
+    MVUS_HIP(hipHostMalloc(reinterpret_cast<void**>(&scal_host), 16 * sizeof(double), hipHostMallocMapped));
+    for (int i = 0; i < 16; ++i) scal_host[i] = 0.0;
+    if (hipHostGetDevicePointer(reinterpret_cast<void**>(&scal_map), scal_host, 0) != hipSuccess) scal_map = nullptr;
     stage_cap = std::max<int64_t>(hp.n, 1024);
     for (int i = 0; i < kStageSlots; ++i) {
       MVUS_HIP(hipHostMalloc(reinterpret_cast<void**>(&stage[i]), stage_cap * sizeof(double), hipHostMallocDefault));
@@ -224,9 +227,14 @@ struct HipBackend {
       MVUS_HIP(hipMemsetAsync(out, 0, sizeof(double), stream));
     }
   }
-  void dot_to_slot(const double* a, const double* b, int64_t len, int slot) { dot_into(a, b, len, scal_dev + slot); }
+  // Where the scalars the host reads after every step are written.  One rank: straight into the mapped pinned mirror (the host
+  // reads it after a stream synchronisation: no device-to-host copy kernel, ~4 us + a launch per fetch).  With an all-reduce
+  // callback the scalars are summed over the ranks in device memory first, so they stay there and are copied.
+  bool scal_direct() const { return scal_map != nullptr && !allreduce; }
+  double* scal_out() { return scal_direct() ? scal_map : scal_dev; }
+  void dot_to_slot(const double* a, const double* b, int64_t len, int slot) { dot_into(a, b, len, scal_out() + slot); }
   double read_slot(int slot) {
-    MVUS_HIP(hipMemcpyAsync(scal_host + slot, scal_dev + slot, sizeof(double), hipMemcpyDeviceToHost, stream));
+    if (!scal_direct()) MVUS_HIP(hipMemcpyAsync(scal_host + slot, scal_dev + slot, sizeof(double), hipMemcpyDeviceToHost, stream));
     MVUS_HIP(hipStreamSynchronize(stream));
     return scal_host[slot];
   }
@@ -248,7 +256,7 @@ struct HipBackend {
   }
   const double* lb_ptr() const { return lb_dev; }
   const double* ub_ptr() const { return ub_dev; }
-  double* lm_scalars() { return scal_dev + 8; }
+  double* lm_scalars() { return scal_out() + 8; }
   void dot_m_into(const double* a, const double* b, double* out) {
     dot_into(a, b, hp.m, out);
     reduce(out, 1);
@@ -263,14 +271,14 @@ struct HipBackend {
     touch(x_new);
     hipLaunchKernelGGL(k_lm_trial, dim3(lm_grid()), dim3(1024), 0, stream, (int)hp.n, x, p, lb, ub, g, D, fail, x_new, out, gnorm_out, partials, lm_counter);
   }
-  void fetch(const double* src, int k, double* host) {       // src inside scal_dev: staged through the pinned mirror
-    const int64_t off = src - scal_dev;
-    MVUS_HIP(hipMemcpyAsync(scal_host + off, src, sizeof(double) * k, hipMemcpyDeviceToHost, stream));
+  void fetch(const double* src, int k, double* host) {       // src inside scal_out(): the pinned mirror itself, or staged through it
+    const int64_t off = src - scal_out();
+    if (!scal_direct()) MVUS_HIP(hipMemcpyAsync(scal_host + off, src, sizeof(double) * k, hipMemcpyDeviceToHost, stream));
     MVUS_HIP(hipStreamSynchronize(stream));
     for (int i = 0; i < k; ++i) host[i] = scal_host[off + i];
   }
   double dot_n(const double* a, const double* b, int64_t len) { dot_to_slot(a, b, len, 0); return read_slot(0); }
-  double dot_m(const double* a, const double* b) { dot_to_slot(a, b, hp.m, 1); reduce(scal_dev + 1, 1); return read_slot(1); }
+  double dot_m(const double* a, const double* b) { dot_to_slot(a, b, hp.m, 1); reduce(scal_out() + 1, 1); return read_slot(1); }
 
   // the slot Jacobian (2*NS*M doubles) is allocated on first use: residual-only handles (Scene.error_cam, outlier masks) never pay for it
   void ensure_J() { if (!J) J = dalloc<double>(j_doubles(hp.NS, dp.n_chunks)); }      // sized at first use; outlier removal only ever shrinks the chunk table
