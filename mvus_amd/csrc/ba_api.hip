@@ -269,6 +269,14 @@ struct HipBackend {
   void lm_trial(const double* x, const double* p, const double* lb, const double* ub, const double* g, const double* D,
                 const int* fail, double* x_new, double* out, double* gnorm_out) {
     touch(x_new);
+    // one workgroup is limited by what one CU can load (six n-vectors: 18 us at n = 15k); a few workgroups and a second, tiny
+    // launch for their partials take 10 us.  Beyond 128k parameters: the one-launch form with the last-workgroup hand-over.
+    const unsigned g2 = hp.n > 2048 && hp.n <= (1 << 17) ? (unsigned)std::min<int64_t>(32, (hp.n + 1023) / 1024) : 0u;
+    if (g2 > 1) {
+      hipLaunchKernelGGL(k_lm_trial, dim3(g2), dim3(1024), 0, stream, (int)hp.n, x, p, lb, ub, g, D, fail, x_new, out, gnorm_out, partials, (unsigned*)nullptr);
+      hipLaunchKernelGGL(k_lm_trial_sum, dim3(1), dim3(64), 0, stream, (int)g2, partials, out, gnorm_out);
+      return;
+    }
     hipLaunchKernelGGL(k_lm_trial, dim3(lm_grid()), dim3(1024), 0, stream, (int)hp.n, x, p, lb, ub, g, D, fail, x_new, out, gnorm_out, partials, lm_counter);
   }
   void fetch(const double* src, int k, double* host) {       // src inside scal_out(): the pinned mirror itself, or staged through it

@@ -60,6 +60,36 @@ __device__ __forceinline__ double wave_sum(double v) {
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
   return v;
 }
+// The same reductions on the DPP data path (VALU lane shifts inside 16-lane rows, then the two row broadcasts): no trip through
+// the LDS crossbar per step.  With 16 wavefronts of one workgroup each reducing five values, the ds_bpermute version of
+// k_lm_trial spent 21-25 k cycles in its reductions (MVUS_TRIAL_PROBE); the summation tree differs from wave_sum's, so these are
+// used by the LM driver's kernels only, not by anything the TRF + LSMR parity path sums.  Result valid in every lane.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_shift(double v, double fill) {
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(fill), __double2loint(v), CTRL, ROW_MASK, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(fill), __double2hiint(v), CTRL, ROW_MASK, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+  v += dpp_shift<0x111, 0xF>(v, 0.0);      // row_shr:1
+  v += dpp_shift<0x112, 0xF>(v, 0.0);      // row_shr:2
+  v += dpp_shift<0x114, 0xF>(v, 0.0);      // row_shr:4
+  v += dpp_shift<0x118, 0xF>(v, 0.0);      // row_shr:8   -> lane 15 of every row holds the row's sum
+  v += dpp_shift<0x142, 0xA>(v, 0.0);      // row_bcast:15 into rows 1 and 3
+  v += dpp_shift<0x143, 0xC>(v, 0.0);      // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_max_dpp(double v) {       // for values >= 0 (fill 0)
+  v = fmax(v, dpp_shift<0x111, 0xF>(v, 0.0));
+  v = fmax(v, dpp_shift<0x112, 0xF>(v, 0.0));
+  v = fmax(v, dpp_shift<0x114, 0xF>(v, 0.0));
+  v = fmax(v, dpp_shift<0x118, 0xF>(v, 0.0));
+  v = fmax(v, dpp_shift<0x142, 0xA>(v, 0.0));
+  v = fmax(v, dpp_shift<0x143, 0xC>(v, 0.0));
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+  return __hiloint2double(hi, lo);
+}
 
 // Decode every camera's parameters once per evaluation (C threads): Rodrigues + derivative matrix.
 __global__ void k_cam_states(DevProblem dp, const double* __restrict__ x, CamState* __restrict__ cams) {
@@ -609,8 +639,7 @@ __global__ __launch_bounds__(1024) void k_lm_gnorm(int n, const double* __restri
       if (!blocked) gn = fmax(gn, fabs(gi[u]));
     }
   }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) gn = fmax(gn, __shfl_down(gn, off, 64));
+  gn = wave_max_dpp(gn);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = gn;
   __syncthreads();
   if (threadIdx.x == 0) { double t = 0.0; for (int w = 0; w < 16; ++w) t = fmax(t, red[w]); part[blockIdx.x] = t; if (gridDim.x == 1) *out = t; }
@@ -657,13 +686,11 @@ __global__ __launch_bounds__(1024) void k_lm_trial(int n, const double* __restri
   }
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const double v = wave_sum(s[k]);
+    const double v = wave_sum_dpp(s[k]);
     if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = v;
   }
   {
-    double v = s[4];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
+    const double v = wave_max_dpp(s[4]);
     if ((threadIdx.x & 63) == 0) red[4][threadIdx.x >> 6] = v;
   }
   __syncthreads();
@@ -673,7 +700,7 @@ __global__ __launch_bounds__(1024) void k_lm_trial(int n, const double* __restri
     part[blockIdx.x * 5 + threadIdx.x] = t;
     if (gridDim.x == 1) { if (threadIdx.x < 4) out[threadIdx.x] = t; else *gnorm_out = t; }
   }
-  if (gridDim.x == 1) return;                              // one workgroup: done, nothing to hand over
+  if (gridDim.x == 1 || counter == nullptr) return;        // one workgroup, or k_lm_trial_sum follows: nothing to hand over
   if (last_block_done(counter) && threadIdx.x < 5) {
     double t = 0.0;
     for (unsigned b = 0; b < gridDim.x; ++b) {
@@ -682,6 +709,17 @@ __global__ __launch_bounds__(1024) void k_lm_trial(int n, const double* __restri
     }
     if (threadIdx.x < 4) out[threadIdx.x] = t; else *gnorm_out = t;
   }
+}
+
+// second stage of k_lm_trial launched over several workgroups with counter == nullptr: the five partials per workgroup -> out
+__global__ __launch_bounds__(64) void k_lm_trial_sum(int nparts, const double* __restrict__ part, double* __restrict__ out, double* __restrict__ gnorm_out) {
+  if (threadIdx.x >= 5) return;
+  double t = 0.0;
+  for (int b = 0; b < nparts; ++b) {
+    const double v = part[b * 5 + threadIdx.x];
+    t = threadIdx.x < 4 ? t + v : fmax(t, v);
+  }
+  if (threadIdx.x < 4) out[threadIdx.x] = t; else *gnorm_out = t;
 }
 
 // ---- MVUS_JAC_FD: scipy's sparse 2-point differences (scipy/optimize/_numdiff.py:628-700) ----------------
