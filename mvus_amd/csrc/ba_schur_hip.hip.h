@@ -1393,7 +1393,10 @@ __global__ void k_build_rhs(NEView ne, int ncols, double* __restrict__ Z, double
 // tiles on or below the block diagonal are computed (k_schur_finish mirrors), plus one 48x16 tile per block row for
 // the right-hand-side column.  Partial sums per slab are written, not atomically added: no memset, deterministic.
 using d4 = __attribute__((ext_vector_type(4))) double;
-constexpr int kGemmT = 48, kGemmWaveK = 256, kGemmSlab = 4 * kGemmWaveK;
+#ifndef MVUS_GEMM_WAVEK
+#define MVUS_GEMM_WAVEK 256
+#endif
+constexpr int kGemmT = 48, kGemmWaveK = MVUS_GEMM_WAVEK, kGemmSlab = 4 * kGemmWaveK;
 
 template <int NJ>   // NJ = 3: 48x48 tile of the symmetric part, NJ = 1: 48x16 tile holding the rhs column
 __device__ __forceinline__ void schur_gemm_tile(const NEView& ne, int ncols, const double* __restrict__ Erm, const double* __restrict__ Z,
