@@ -20,7 +20,7 @@ except Exception as e:
     print('no memory copy table:', e, [t for t in tabs if 'cop' in t.lower()])
 ev.sort()
 # the last complete step: from the last k_lm_trial backwards to the previous one
-idx = [i for i, e in enumerate(ev) if 'k_lm_trial' in e[2]]
+idx = [i for i, e in enumerate(ev) if 'k_lm_trial(' in e[2]]
 a, b = idx[-2] + 1, idx[-1] + 1
 t0 = ev[a][0]
 prev_end = ev[a - 1][1]
