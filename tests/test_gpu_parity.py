@@ -458,3 +458,44 @@ def test_opt_sync_off_freezes_alpha_and_beta(BAHandle):
             r = h.solve(x0, solver=solver, jac_mode=jm, max_nfev=14)      # (LM rejects its first five trials from this start)
             np.testing.assert_array_equal(r.x[:2 * C], x0[:2 * C])
             assert r.cost < r.initial_cost
+
+
+@pytest.mark.parametrize('total_obs', [150, 1900, 16400, 131500])
+def test_chunk_orders_cover_every_chunk(BAHandle, total_obs):
+    """The XCD-aware tile orders pad their grids (to multiples of 8 x run) and skip tiles past the end: with 1, ~8, ~65 and ~515
+    chunks every detection must still be evaluated, stored (chunk-major J, exported slot-major), multiplied (J v, J^T u) and
+    assembled.  Checked through identities that hold for any x: J v against central differences of the residual along v,
+    u.(J v) == (J^T u).v, the normal-equation gradient == J^T f, and all of it against the host build where it is small."""
+    from mvus_amd import synth
+    sc = synth.make_scene(2, total_obs, seed=total_obs % 97, knot_spacing=15.0)
+    prob, x0 = mp.problem_from_scene(sc)
+    rng = np.random.default_rng(1)
+    with BAHandle(prob) as h:
+        f, J, ctrl = h.residual_jacobian(x0, _lib.JAC_ANALYTIC)
+        assert ctrl.shape == (prob.M,) and J.shape[-1] == prob.M
+        visible = ctrl >= 0
+        assert visible.sum() > 0.9 * prob.M                      # every chunk evaluated: no block of untouched rows
+        v, u = rng.normal(size=h.n) * 1e-3, rng.normal(size=h.m)
+        if not prob.rs_free:
+            v[2 * prob.C:3 * prob.C] = 0.0                        # a frozen column: J has no entry for it, the residual still depends on rs
+        Jv = h.jv(v)
+        eps = 1e-4
+        fp, fm = np.abs(h.residual(x0 + eps * v)), np.abs(h.residual(x0 - eps * v))
+        fd = (fp - fm) / (2 * eps)
+        sel = np.concatenate((visible, visible)) if h.T == 0 else np.concatenate((visible, visible, np.ones(h.T, bool)))
+        ok = sel & (np.abs(f) > 1e-3 + 4 * eps * np.abs(Jv)) & (fp > 0) & (fm > 0)   # |r| has a kink at 0 (not to be crossed between the two evaluations); a time stamp may leave its interval
+        assert ok.sum() > 0.9 * sel.sum()
+        assert np.max(np.abs(Jv[ok] - fd[ok])) < 1e-5 * max(1.0, np.abs(Jv).max())
+        JTu = h.jtu(u)
+        assert abs(u @ Jv - JTu @ v) < 1e-9 * max(1.0, abs(u @ Jv))
+        f, J, ctrl = h.residual_jacobian(x0, _lib.JAC_ANALYTIC)    # the residual calls above replaced the f the handle holds
+        g = h.normal_equations()[0]                              # assembled from the J held: gradient == J^T f
+        np.testing.assert_allclose(g, h.jtu(f), rtol=1e-9, atol=1e-9 * np.abs(g).max())
+        if total_obs <= 2000:
+            hh = _host(prob)
+            hh.set_pattern(x0)
+            f_ref, D_ref = hh.dense_jacobian(x0, _lib.JAC_ANALYTIC)
+            np.testing.assert_allclose(Jv, D_ref @ v, rtol=1e-10, atol=1e-12)
+            np.testing.assert_allclose(JTu, D_ref.T @ u, rtol=1e-10, atol=1e-10 * np.abs(JTu).max())
+        r = h.solve(x0, solver=_lib.SOLVER_LM_SCHUR, jac_mode=_lib.JAC_ANALYTIC, max_nfev=4)
+        assert r.cost < r.initial_cost
