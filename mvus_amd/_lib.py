@@ -40,7 +40,7 @@ class MvusSolveOpts(ctypes.Structure):
         ('solver', ctypes.c_int32), ('jac_mode', ctypes.c_int32), ('max_nfev', ctypes.c_int32),
         ('ftol', ctypes.c_double), ('xtol', ctypes.c_double), ('gtol', ctypes.c_double),
         ('lsmr_atol', ctypes.c_double), ('lsmr_btol', ctypes.c_double), ('lsmr_conlim', ctypes.c_double),
-        ('lsmr_maxiter', ctypes.c_int32), ('verbose', ctypes.c_int32),
+        ('lsmr_maxiter', ctypes.c_int32), ('verbose', ctypes.c_int32), ('lm_lambda_min', ctypes.c_double),
     ]
 
 
@@ -161,4 +161,5 @@ def default_opts(solver=SOLVER_TRF_LSMR, jac_mode=JAC_PATTERN, max_nfev=10):
     o.ftol, o.xtol, o.gtol = 1e-8, 1e-12, 1e-8
     o.lsmr_atol, o.lsmr_btol, o.lsmr_conlim, o.lsmr_maxiter = 1e-6, 1e-6, 1e8, 0
     o.verbose = 0
+    o.lm_lambda_min = 1e-2
     return o

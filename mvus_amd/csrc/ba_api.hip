@@ -158,13 +158,15 @@ struct HipBackend {
   double* alloc(int64_t len) {
     const size_t bytes = (size_t)std::max<int64_t>(len, 1) * sizeof(double);
     auto it = pool_free.find(bytes);
-    if (it != pool_free.end() && !it->second.empty()) { double* p = it->second.back(); it->second.pop_back(); return p; }
+    if (it != pool_free.end() && !it->second.empty()) { double* p = it->second.back(); it->second.pop_back(); touch(p); return p; }
     void* p = nullptr;
     MVUS_HIP(hipMalloc(&p, bytes));
     pool_size[static_cast<double*>(p)] = bytes;
     return static_cast<double*>(p);
   }
-  void release(double* p) { if (p) pool_free[pool_size[p]].push_back(p); }   // stream-ordered reuse: one stream per handle
+  // stream-ordered reuse: one stream per handle.  A buffer that leaves or re-enters the pool no longer names an x whose camera
+  // states are cached (not every writer of an n-vector calls touch(): J^T u, the Schur kernels); the invariant is kept HERE
+  void release(double* p) { if (p) { touch(p); pool_free[pool_size[p]].push_back(p); } }
   // decoded camera states are reused while the x buffer they came from is untouched (the accepted point of an LM iteration
   // is the trial point whose states are already there; a 2-evaluation solve evaluates and linearises at the same x)
   void touch(const double* d) { if (d == cams_for) cams_for = nullptr; }
@@ -240,7 +242,7 @@ struct HipBackend {
   }
   void reduce(double* buf, size_t count) {
     if (!allreduce) return;
-    if (allreduce(allreduce_user, buf, count, stream) != 0) throw HipError{"all-reduce callback failed"};
+    if (allreduce(allreduce_user, buf, count, stream) != 0) throw HipError{"all-reduce callback failed", MVUS_E_COMM};
   }
   // device-resident LM driver (ba_schur.h)
   std::vector<double> lb_host, ub_host;
@@ -560,7 +562,7 @@ static int guarded(mvus_ba* h, F&& fn) {
     return fn();
   } catch (const HipError& e) {
     h->be.err = e.msg;
-    return e.msg.find("all-reduce") != std::string::npos ? MVUS_E_COMM : MVUS_E_HIP;
+    return e.code;
   } catch (const std::exception& e) {
     h->be.err = e.what();
     return MVUS_E_INVALID;
@@ -573,7 +575,7 @@ void mvus_default_opts(mvus_solve_opts* o) {
   if (!o) return;
   o->solver = MVUS_SOLVER_TRF_LSMR; o->jac_mode = MVUS_JAC_PATTERN; o->max_nfev = 10;
   o->ftol = 1e-8; o->xtol = 1e-12; o->gtol = 1e-8;
-  o->lsmr_atol = 1e-6; o->lsmr_btol = 1e-6; o->lsmr_conlim = 1e8; o->lsmr_maxiter = 0; o->verbose = 0;
+  o->lsmr_atol = 1e-6; o->lsmr_btol = 1e-6; o->lsmr_conlim = 1e8; o->lsmr_maxiter = 0; o->verbose = 0; o->lm_lambda_min = 1e-2;
 }
 
 int mvus_ba_create(const mvus_problem* p, mvus_ba** out) {
@@ -776,7 +778,7 @@ int mvus_ba_solve(mvus_ba* h, double* x, const mvus_solve_opts* opts, mvus_resul
     SolveOptions so;
     so.jac_mode = opts->jac_mode; so.max_nfev = opts->max_nfev; so.ftol = opts->ftol; so.xtol = opts->xtol; so.gtol = opts->gtol;
     so.lsmr_atol = opts->lsmr_atol; so.lsmr_btol = opts->lsmr_btol; so.lsmr_conlim = opts->lsmr_conlim;
-    so.lsmr_maxiter = opts->lsmr_maxiter; so.verbose = opts->verbose;
+    so.lsmr_maxiter = opts->lsmr_maxiter; so.verbose = opts->verbose; so.lm_lambda_min = opts->lm_lambda_min >= 0 ? opts->lm_lambda_min : 0.0;
     if (so.jac_mode == MVUS_JAC_PATTERN && !be.pattern_uploaded) {
       be.upload(be.x_cur, xv.data(), n);
       be.set_pattern(be.x_cur);
@@ -989,7 +991,11 @@ int mvus_triangulate(int32_t device, int64_t N, const double* x1, const double* 
   } catch (const HipError& e) {
     g_create_error = e.msg;
     cleanup();
-    return MVUS_E_HIP;
+    return e.code;
+  } catch (const std::exception& e) {          // nothing throws across the ABI
+    g_create_error = e.what();
+    cleanup();
+    return MVUS_E_INVALID;
   }
   cleanup();
   return MVUS_OK;
@@ -1021,7 +1027,10 @@ int mvus_spline_eval(int32_t device, int32_t S, const double* interval, const in
     MVUS_HIP(hipStreamSynchronize(cb.st));
   } catch (const HipError& e) {
     g_create_error = e.msg;
-    return MVUS_E_HIP;
+    return e.code;
+  } catch (const std::exception& e) {          // bad_alloc / length_error from the host-side tables: nothing throws across the ABI
+    g_create_error = e.what();
+    return MVUS_E_INVALID;
   }
   return MVUS_OK;
 }
@@ -1053,7 +1062,10 @@ int mvus_spline_lsq(int32_t device, int32_t num_knots, const double* knots, int6
     if (fh) { g_create_error = "spline_lsq: the normal equations are not positive definite (a coefficient without data: Schoenberg-Whitney violated)"; return MVUS_E_NUMERIC; }
   } catch (const HipError& e) {
     g_create_error = e.msg;
-    return MVUS_E_HIP;
+    return e.code;
+  } catch (const std::exception& e) {          // bad_alloc / length_error from the host-side tables: nothing throws across the ABI
+    g_create_error = e.what();
+    return MVUS_E_INVALID;
   }
   return MVUS_OK;
 }
@@ -1121,7 +1133,7 @@ int mvus_spline_smooth(int32_t device, int64_t m, const double* u, const double*
         if (std::getenv("MVUS_DEBUG")) std::fprintf(stderr, "spline_smooth: n=%d %s %s  diag(L) %.3e..%.3e  fp %.6e  fail %d\n", n, smoothing ? "smooth" : "lsq",
                                                     precise ? "dd" : "fp64", host[2], host[3], host[1], failed);
         if (precise) {                                    // floored pivots are accepted here (see k_band_solve)
-          if (!std::isfinite(host[1])) throw HipError{"spline_smooth: a banded system is not positive definite"};
+          if (!std::isfinite(host[1])) throw HipError{"spline_smooth: a banded system is not positive definite", MVUS_E_NUMERIC};
           MVUS_HIP(hipMemsetAsync(fail, 0, sizeof(int), cb.st));
           return;
         }
@@ -1219,7 +1231,7 @@ int mvus_spline_smooth(int32_t device, int64_t m, const double* u, const double*
     if (ier_out) *ier_out = ier;
   } catch (const HipError& e) {
     g_create_error = e.msg;
-    return e.msg.find("positive definite") != std::string::npos ? MVUS_E_NUMERIC : MVUS_E_HIP;
+    return e.code;
   } catch (const std::exception& e) {          // bad_alloc / length_error on absurd sizes must not cross the C ABI
     g_create_error = e.what();
     return MVUS_E_INVALID;

@@ -24,7 +24,7 @@ namespace mvus {
 
 constexpr int kThreads = 256;
 
-struct HipError { std::string msg; };
+struct HipError { std::string msg; int code = -2; };   // code: the MVUS_E_* value the C ABI returns (-2 = MVUS_E_HIP)
 
 #define MVUS_HIP(expr)                                                                              \
   do {                                                                                              \

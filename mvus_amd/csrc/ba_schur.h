@@ -99,7 +99,8 @@ SolveResult lm_schur(B& be, Schur& sc, std::vector<double>& x, const std::vector
     be.dot_m_into(f_new, f_new, S + 6);
   };
 
-  double lambda = opt.lm_lambda0 > 0 ? opt.lm_lambda0 : 1e-4, nu = opt.lm_nu0 > 0 ? opt.lm_nu0 : 2.0;
+  double lambda = std::max(opt.lm_lambda0 > 0 ? opt.lm_lambda0 : 1e-4, opt.lm_lambda_min), nu = opt.lm_nu0 > 0 ? opt.lm_nu0 : 2.0;
+  const double lambda_min = opt.lm_lambda_min;
   double cost = 0;
   bool cost_known = false;
   int status = -1;
@@ -144,6 +145,7 @@ SolveResult lm_schur(B& be, Schur& sc, std::vector<double>& x, const std::vector
       if (actual_reduction > 0) {
         const double t = 2.0 * ratio - 1.0;
         lambda *= std::max(1.0 / 3.0, 1.0 - t * t * t);                 // Nielsen's update
+        lambda = std::max(lambda, lambda_min);
         nu = 2.0;
       } else {
         lambda *= nu; nu *= 2.0;

@@ -1247,6 +1247,10 @@ __global__ __launch_bounds__(bcr_tail_waves(S3) * 64) void k_sep_bcr_tail(PartVi
     const long long p0_ = clock64();
 #endif
     for (int s = wave; s < nt; s += NW) bcr_survivor<S3>(pv, h, s, w + wave * 3 * S3 * S3, fail);
+    // The next level's agent-scope loads (bcr_ld) must see this level's plain stores of the OTHER wavefronts: release at the
+    // scope the loads use.  A workgroup-scope barrier alone need not wait for the stores to reach L2 (vmcnt) before it lets the
+    // other wavefronts go on.
+    __threadfence();
     __syncthreads();
 #ifdef MVUS_BCR_PROBE
     if (threadIdx.x == 0) printf("bcr tail h=%d ns=%d: %lld cycles\n", h, ns, clock64() - p0_);

@@ -44,6 +44,7 @@ struct SolveOptions {
   double lsmr_atol = 1e-6, lsmr_btol = 1e-6, lsmr_conlim = 1e8;
   int lsmr_maxiter = 0;
   int verbose = 0;
+  double lm_lambda_min = 1e-2;   // floor of the LM damping (see mvus_solve_opts)
   double lm_lambda0 = 0;   // > 0: initial LM damping (a handle carries it over from its previous solve)
   double lm_nu0 = 0;       // > 0: initial damping growth factor (carried with it, so that a run of one-trial solves
                            // escalates the damping like one long solve does)

@@ -11,13 +11,20 @@ Out of scope: trajectory initialisation, PnP-RANSAC, synch
 dead ``motion_prior=True`` branch -- those methods raise ``NotImplementedError``.  ``Scene.triangulate`` (SURVEY 8f rank
 4) is here, with its per-point SVD on the GPU.
 
-Extra ``settings`` keys (all optional): ``ba_solver`` ('lm' = Levenberg-Marquardt on device-assembled normal equations
-with the Schur complement, the default -- ~10-20x faster per BA iteration and it converges to a lower value of the same
-objective than the reference's optimiser reaches; 'trf' = scipy's TRF + LSMR restated, the parity mode), ``ba_jacobian``
-('analytic' = full analytic, default with 'lm'; 'pattern' = analytic masked to the reference sparsity pattern, default
-with 'trf'; 'fd' = scipy's grouped 2-point differences on the GPU, the reference's own estimate -- with 'trf' this is the
-reference's algorithm end to end), ``ba_pattern_ties`` ('numpy' = the twin rows of the pattern decided like np.argsort of
-this process decides them, default; 'canonical'), ``opt_sync`` (reference key: False freezes alpha/beta), ``device``.
+Extra ``settings`` keys (all optional; a reference ``config.json`` has none of them):
+
+``ba_solver``  'trf' (DEFAULT) = scipy's TRF + LSMR restated on the GPU -- with ``ba_jacobian`` 'fd' (its default) this is
+               the reference's algorithm end to end: same pattern matrix, same grouped 2-point differences, same trust
+               region, same termination; results agree with the reference's within the reference's own reproducibility.
+               'lm' = Levenberg-Marquardt on device-assembled normal equations with the Schur complement and the analytic
+               Jacobian: ~20x faster per BA iteration, reaches a LOWER value of the same objective, hence another point than
+               the reference's (DESIGN.md section 2 states how far, against the reference and against ground truth).
+``ba_jacobian`` 'fd' (default with 'trf'), 'pattern' = analytic, masked to the reference sparsity pattern, 'analytic' =
+               full analytic (default with 'lm').
+``ba_pattern_ties`` 'numpy' = the twin rows of the pattern decided like np.argsort of this process decides them (default;
+               what the reference would build here), 'canonical'.
+``ba_lambda_min`` floor of the LM damping (default 1e-2, see ``mvus_solve_opts.lm_lambda_min``).
+``opt_sync`` (reference key: False freezes alpha/beta), ``device``.
 """
 import json
 
@@ -362,12 +369,11 @@ class Scene:
         print('Number of BA parameters is {}'.format(len(model)))
         print('Doing BA with {} cameras...\n'.format(numCam))
         st = self.settings
-        solver = _ba.SOLVER_LM_SCHUR if st.get('ba_solver', 'lm') == 'lm' else _ba.SOLVER_TRF_LSMR
-        default_jac = 'analytic' if solver == _ba.SOLVER_LM_SCHUR else 'pattern'
-        jac_mode = {'analytic': _ba.JAC_ANALYTIC, 'pattern': _ba.JAC_PATTERN, 'fd': _ba.JAC_FD}[st.get('ba_jacobian', default_jac)]
+        solver, jac_mode = self.ba_mode()
         h = self._resident_handle(prob, cams)      # stays resident for remove_outliers and the next BA
-        res = h.solve(model, solver=solver, jac_mode=jac_mode, max_nfev=max_iter, ties=st.get('ba_pattern_ties', 'numpy'),
-                      matrix=jac_sparsity)
+        opts = _ba._lib.default_opts(solver, jac_mode, max_iter)
+        opts.lm_lambda_min = float(st.get('ba_lambda_min', opts.lm_lambda_min))
+        res = h.solve(model, opts=opts, ties=st.get('ba_pattern_ties', 'numpy'), matrix=jac_sparsity)
         alpha, beta, rs_new, cam_states, coefs = _problem.unpack_x(prob, res.x)
         self.alpha[cams], self.beta[cams], self.rs[cams] = alpha, beta, rs_new
         for k, i in enumerate(cams):
@@ -383,6 +389,22 @@ class Scene:
             self.all_detect_to_traj(cams)
             self.spline_to_traj()
         return res
+
+    def ba_mode(self):
+        """(solver, Jacobian mode) that ``BA`` runs with the current settings.  Without any ``ba_*`` key -- a reference
+        config.json -- that is the reference's own algorithm: TRF + LSMR over grouped 2-point differences."""
+        from .. import ba as _ba
+        st = self.settings if isinstance(self.settings, dict) else {}
+        name = st.get('ba_solver', 'trf')
+        if name not in ('trf', 'lm'):
+            raise ValueError("settings['ba_solver'] must be 'trf' or 'lm', not %r" % (name,))
+        solver = _ba.SOLVER_LM_SCHUR if name == 'lm' else _ba.SOLVER_TRF_LSMR
+        default_jac = 'analytic' if name == 'lm' else 'fd'
+        modes = {'analytic': _ba.JAC_ANALYTIC, 'pattern': _ba.JAC_PATTERN, 'fd': _ba.JAC_FD}
+        jac = st.get('ba_jacobian', default_jac)
+        if jac not in modes:
+            raise ValueError("settings['ba_jacobian'] must be one of %s, not %r" % (sorted(modes), jac))
+        return solver, modes[jac]
 
     def remove_outliers(self, cams, thres=30, verbose=False):
         """Drop detections whose reprojection error is >= thres (common.py:700-717); the mask is computed by
@@ -518,7 +540,27 @@ class Scene:
         raise NotImplementedError('outside the BA hot path this package accelerates (SURVEY.md section 2); '
                                   'use the reference implementation for initialisation / synchronisation search')
 
-    init_traj = plot_reprojection = error_motion = _out_of_scope
+    init_traj = plot_reprojection = _out_of_scope
+
+    def error_motion(self, cams, mode='dist', norm=False, motion_weights=0, motion_reg=False, motion_prior=False):
+        """The motion-regularisation rows of the BA residual (reference common.py:362-424 with ``motion_reg=True``): one value
+        per sample of ``spline_to_traj()`` (unit steps of the reference camera's frame clock), 'F' or 'KE' by
+        ``settings['motion_type']``, zero at the first/last samples of an interval.  Evaluated by ``k_motion`` on the GPU (the
+        rows ``error_BA`` appends, common.py:462-467).  ``motion_prior=True`` is the reference's dead branch."""
+        if motion_prior:
+            raise NotImplementedError('motion_prior=True is dead code in the reference pipeline (SURVEY.md section 2)')
+        if not motion_reg:
+            raise ValueError('error_motion: motion_reg=True is the only live mode (the reference returns an unbound name otherwise)')
+        cams = [int(cams)] if isinstance(cams, (int, np.integer)) else list(cams)
+        for i in cams:
+            self.detection_to_global(i)
+        self.spline_to_traj()
+        prob = self._ba_problem(cams[:1], motion_reg=True, motion_weights=motion_weights)
+        with self._handle(prob) as tmp:
+            f = tmp.residual(self._pack(prob, cams[:1]))
+        out = f[2 * prob.M:]
+        assert out.size == self.traj.shape[1], 'motion rows and trajectory samples do not correspond'
+        return out
 
 
 def create_scene(path_input):

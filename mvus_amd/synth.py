@@ -101,8 +101,12 @@ def make_scene(num_cam, total_obs, *, seed=0, rolling_shutter=False, distortion=
                opt_calib=False, motion_reg=False, motion_type='F', motion_weights=1.0,
                rs_bounds=False, num_knots=None, knot_spacing=15.0, num_intervals=1,
                noise_px=0.5, outlier_frac=0.02, dropout=0.0, perturb=1.0,
-               fps_choices=(25.0, 30.0, 50.0, 59.94)):
-    """Build a seeded scene with ``num_cam`` cameras and about ``total_obs`` detections."""
+               fps_choices=(25.0, 30.0, 50.0, 59.94), ring_radius=60.0):
+    """Build a seeded scene with ``num_cam`` cameras and about ``total_obs`` detections.
+
+    ``ring_radius`` (m) is the distance of the camera ring from the trajectory's centroid: at the default 60 m the target
+    stays within ~170 px of the image centre (lens distortion is then barely observable -- fine while calibration is fixed);
+    ~22 m makes it sweep most of the image, which is what a scene with ``opt_calib`` needs to be well posed."""
     rng = np.random.default_rng(seed)
     C = num_cam
     fps = np.array([fps_choices[i % len(fps_choices)] for i in range(C)], dtype=np.float64)
@@ -139,7 +143,7 @@ def make_scene(num_cam, total_obs, *, seed=0, rolling_shutter=False, distortion=
     for c in range(C):
         ang = 2 * np.pi * c / C + rng.uniform(-0.1, 0.1)
         elev = rng.uniform(-8.0, 8.0)
-        center = centroid + np.array([60.0 * np.cos(ang), 60.0 * np.sin(ang), elev])
+        center = centroid + np.array([ring_radius * np.cos(ang), ring_radius * np.sin(ang), elev])
         R, tvec = look_at(center, centroid)
         f = 1000.0 + rng.uniform(-50, 50)
         K = np.array([[f, 0, W / 2 + rng.uniform(-10, 10)], [0, f * rng.uniform(0.995, 1.005), H / 2 + rng.uniform(-10, 10)], [0, 0, 1.0]])

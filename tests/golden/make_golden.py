@@ -241,43 +241,17 @@ def run_case(common, name, sc, max_iters=(10,), seed=123, max_iters2=(10,)):
     print('wrote %s (%.1f KiB)' % (path, os.path.getsize(path) / 1024))
 
 
-def integer_intervals(sc):
-    """Snap interval bounds (and the clamped end knots) to integers so that motion samples can land
-    exactly on an interval end -- the closed/half-open corner of common.py:292 vs util.py:105."""
-    for s in range(sc.interval.shape[1]):
-        a, b = np.ceil(sc.interval[0, s]), np.floor(sc.interval[1, s])
-        t = sc.tck[s][0]
-        t[:4], t[-4:] = a, b
-        inner = t[4:-4]
-        t[4:-4] = np.clip(inner, a + 0.5, b - 0.5)
-        sc.interval[0, s], sc.interval[1, s] = a, b
-    return sc
-
-
 def main():
-    from mvus_amd import synth
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import golden_cases
     common = import_reference()
-    cases = {
-        # BASELINE config 1: 2 pinhole cams x 1k detections, global shutter, no motion reg
-        'c1_pinhole_2cam': (synth.make_scene(2, 2000, seed=1, knot_spacing=15.0), (10, 40)),
-        # rolling shutter + motion_reg F over two integer-aligned intervals
-        'rs_F_2int_3cam': (integer_intervals(synth.make_scene(3, 1500, seed=11, rolling_shutter=True, motion_reg=True,
-                                                              motion_type='F', motion_weights=1e4, num_intervals=2,
-                                                              knot_spacing=12.0, dropout=0.05)), (10,)),
-        # full parameter vector: K, dist, beta, RS (bounded), pose, spline; KE regulariser
-        'calib_KE_bounds_3cam': (synth.make_scene(3, 1200, seed=21, rolling_shutter=True, distortion=True,
-                                                  opt_calib=True, rs_bounds=True, motion_reg=True, motion_type='KE',
-                                                  motion_weights=1e2, knot_spacing=14.0), (10,)),
-        # fixed calibration with lens distortion (observation-side undistortion only)
-        'dist_fixed_2cam': (synth.make_scene(2, 800, seed=31, rolling_shutter=True, distortion=True,
-                                             knot_spacing=16.0), (10,)),
-    }
     only = sys.argv[1:]
-    for name, (sc, mis) in cases.items():
+    for name in golden_cases.GENERATORS:
         if only and name not in only:
             continue
+        sc = golden_cases.make(name)
         print('case %s: C=%d M=%d' % (name, sc.num_cam, sc.num_obs))
-        run_case(common, name, sc, mis, max_iters2=(10, 200))
+        run_case(common, name, sc, golden_cases.MAX_ITERS.get(name, (10,)), max_iters2=(10, 200))
 
 
 if __name__ == '__main__':

@@ -308,7 +308,7 @@ int hostcheck_solve(void* h, double* x, const mvus_solve_opts* o, mvus_result* r
   if (be->hp.rs_bounds) for (int c = 0; c < be->hp.C; ++c) { lb[2 * be->hp.C + c] = 0.0; ub[2 * be->hp.C + c] = 1.0; }
   SolveOptions so;
   so.jac_mode = o->jac_mode; so.max_nfev = o->max_nfev; so.ftol = o->ftol; so.xtol = o->xtol; so.gtol = o->gtol;
-  so.lsmr_atol = o->lsmr_atol; so.lsmr_btol = o->lsmr_btol; so.lsmr_conlim = o->lsmr_conlim; so.lsmr_maxiter = o->lsmr_maxiter; so.verbose = o->verbose;
+  so.lsmr_atol = o->lsmr_atol; so.lsmr_btol = o->lsmr_btol; so.lsmr_conlim = o->lsmr_conlim; so.lsmr_maxiter = o->lsmr_maxiter; so.verbose = o->verbose; so.lm_lambda_min = o->lm_lambda_min;
   if (so.jac_mode == MVUS_JAC_PATTERN && !be->pattern_uploaded) be->set_pattern(x);
   std::vector<double> f(be->hp.m);
   SolveResult sr;
