@@ -101,7 +101,7 @@ typedef struct mvus_solve_opts {
   double lsmr_conlim; /* 1e8                                 */
   int32_t lsmr_maxiter; /* 0 -> min(m, n)                    */
   int32_t verbose;
-  double lm_lambda_min; /* MVUS_SOLVER_LM_SCHUR: floor of the Marquardt damping (1e-2; 0 = none).  Directions the data does
+  double lm_lambda_min; /* MVUS_SOLVER_LM_SCHUR: floor of the Marquardt damping (3e-3; 0 = none).  Directions the data does
                            not determine (a control point seen by one camera: depth along its rays; rs against beta when the
                            image row hardly varies) have curvature << lambda * diag(H) and stay where they are instead of
                            following the noise -- the effect the reference gets from LSMR's truncated solves (common.py:670) */

@@ -109,7 +109,7 @@ struct HipBackend {
     cams = dalloc<CamState>(hp.C);
     span = dalloc<int32_t>(hp.M); pat0 = dalloc<int32_t>(hp.M);
     mJ = dalloc<double>((size_t)36 * hp.T); mctrl = dalloc<int32_t>((size_t)3 * hp.T);
-    x_cur = dalloc<double>(hp.n); f_cur = dalloc<double>(hp.m);
+    x_cur = dalloc<double>(hp.n); f_cur = alloc(hp.m);      // (from the pool: an LM solve swaps it with its trial buffer)
     partials = dalloc<double>(2048); scal_dev = dalloc<double>(16);
     MVUS_HIP(hipHostMalloc(reinterpret_cast<void**>(&scal_host), 16 * sizeof(double), hipHostMallocMapped));
     for (int i = 0; i < 16; ++i) scal_host[i] = 0.0;
@@ -140,6 +140,8 @@ struct HipBackend {
     for (void* p : owned) (void)hipFree(p);
     for (auto& kv : pool_size) (void)hipFree(kv.first);
     if (scal_host) (void)hipHostFree(scal_host);
+    if (lsmr_host) (void)hipHostFree(lsmr_host);
+    for (int i = 0; i < 2; ++i) if (xmir_host[i]) (void)hipHostFree(xmir_host[i]);
     for (int i = 0; i < kStageSlots; ++i) {
       if (stage[i]) (void)hipHostFree(stage[i]);
       if (stage_ev[i]) (void)hipEventDestroy(stage_ev[i]);
@@ -268,18 +270,42 @@ struct HipBackend {
   void lm_gnorm(const double* x, const double* lb, const double* ub, const double* g, double* out) {
     hipLaunchKernelGGL(k_lm_gnorm, dim3(lm_grid()), dim3(1024), 0, stream, (int)hp.n, x, lb, ub, g, out, partials, lm_counter);
   }
+  // Two mapped pinned mirrors of the trial point (ping-pong with the accepted / trial roles of the LM driver): the trial kernel
+  // writes x_new there as well, so that the host holds the accepted point after the fetch that decides on it and the solve ends
+  // without a device-to-host copy and its synchronisation.  One rank only (like the mapped scalars); else nullptr -> download.
+  static constexpr bool kSwapResiduals = true;          // f at an accepted point: the trial buffer changes roles with f_cur, no copy
+  double* xmir_host[2] = {nullptr, nullptr};
+  double* xmir_dev[2] = {nullptr, nullptr};
+  int64_t xmir_cap = 0;
+  double* mirror_dev(int k) {
+    if (!scal_direct()) return nullptr;
+    if (xmir_cap < hp.n) {
+      for (int i = 0; i < 2; ++i) {
+        if (xmir_host[i]) { (void)hipHostFree(xmir_host[i]); xmir_host[i] = xmir_dev[i] = nullptr; }
+        MVUS_HIP(hipHostMalloc(reinterpret_cast<void**>(&xmir_host[i]), std::max<int64_t>(hp.n, 1) * sizeof(double), hipHostMallocMapped));
+        if (hipHostGetDevicePointer(reinterpret_cast<void**>(&xmir_dev[i]), xmir_host[i], 0) != hipSuccess) xmir_dev[i] = nullptr;
+      }
+      xmir_cap = hp.n;
+    }
+    return xmir_dev[k];
+  }
+  const double* mirror_host(int k) const { return xmir_host[k]; }
+  void adopt_residual(double*& f_dev, double*& f_new) {       // both are pool buffers of one size class
+    if (f_dev == f_cur) f_cur = f_new;
+    std::swap(f_dev, f_new);
+  }
   void lm_trial(const double* x, const double* p, const double* lb, const double* ub, const double* g, const double* D,
-                const int* fail, double* x_new, double* out, double* gnorm_out) {
+                const int* fail, double* x_new, double* out, double* gnorm_out, double* x_mirror) {
     touch(x_new);
     // one workgroup is limited by what one CU can load (six n-vectors: 18 us at n = 15k); a few workgroups and a second, tiny
     // launch for their partials take 10 us.  Beyond 128k parameters: the one-launch form with the last-workgroup hand-over.
     const unsigned g2 = hp.n > 2048 && hp.n <= (1 << 17) ? (unsigned)std::min<int64_t>(32, (hp.n + 1023) / 1024) : 0u;
     if (g2 > 1) {
-      hipLaunchKernelGGL(k_lm_trial, dim3(g2), dim3(1024), 0, stream, (int)hp.n, x, p, lb, ub, g, D, fail, x_new, out, gnorm_out, partials, (unsigned*)nullptr);
+      hipLaunchKernelGGL(k_lm_trial, dim3(g2), dim3(1024), 0, stream, (int)hp.n, x, p, lb, ub, g, D, fail, x_new, out, gnorm_out, partials, (unsigned*)nullptr, x_mirror);
       hipLaunchKernelGGL(k_lm_trial_sum, dim3(1), dim3(64), 0, stream, (int)g2, partials, out, gnorm_out);
       return;
     }
-    hipLaunchKernelGGL(k_lm_trial, dim3(lm_grid()), dim3(1024), 0, stream, (int)hp.n, x, p, lb, ub, g, D, fail, x_new, out, gnorm_out, partials, lm_counter);
+    hipLaunchKernelGGL(k_lm_trial, dim3(lm_grid()), dim3(1024), 0, stream, (int)hp.n, x, p, lb, ub, g, D, fail, x_new, out, gnorm_out, partials, lm_counter, x_mirror);
   }
   void fetch(const double* src, int k, double* host) {       // src inside scal_out(): the pinned mirror itself, or staged through it
     const int64_t off = src - scal_out();
@@ -489,6 +515,48 @@ struct HipBackend {
     MVUS_HIP(hipGetLastError());
   }
   void jtu(const double* u, double* z) { jtu_local(u, z); reduce(z, (size_t)hp.n); }
+
+  // ---- device-resident LSMR iterations (Lsmr::run of ba_solver.h, unbounded case, one rank) ----
+  static constexpr bool kDeviceLsmr = true;
+  LsmrScalars* lsmr_state = nullptr;       // [2] device
+  LsmrScalars* lsmr_host = nullptr;        // pinned
+  double* lsmr_part = nullptr;             // [3][2048] partial sums (u.u, v.v, x.x) + beta
+  bool lsmr_on_device() const { return !allreduce && std::getenv("MVUS_LSMR_HOST") == nullptr; }
+  void lsmr_iterations(LsmrScalars& sc, double* ut, double* tm, double* v, double* tn, double* h, double* hbar, double* x) {
+    if (!lsmr_state) {
+      lsmr_state = dalloc<LsmrScalars>(2);
+      lsmr_part = dalloc<double>(3 * 2048 + 8);
+      MVUS_HIP(hipHostMalloc(reinterpret_cast<void**>(&lsmr_host), sizeof(LsmrScalars), hipHostMallocDefault));
+    }
+    const long long n = hp.n, m = hp.m;
+    const int gm = grid_for(m), gn = grid_for(n);
+    double *pu = lsmr_part, *pv = lsmr_part + 2048, *px = lsmr_part + 4096, *beta_dev = lsmr_part + 6144;
+    *lsmr_host = sc;
+    MVUS_HIP(hipMemcpyAsync(lsmr_state, lsmr_host, sizeof(LsmrScalars), hipMemcpyHostToDevice, stream));
+    int cur = 0;
+    const int batch = 8;
+    long long launched = 0;
+    while (true) {
+      for (int b = 0; b < batch && launched < sc.maxiter; ++b, ++launched) {
+        const LsmrScalars* c = lsmr_state + cur;
+        LsmrScalars* nx = lsmr_state + (cur ^ 1);
+        jv(v, tm);
+        hipLaunchKernelGGL(k_lsmr_u, dim3(gm), dim3(kThreads), 0, stream, m, tm, ut, c, pu);
+        hipLaunchKernelGGL(k_lsmr_unorm, dim3(gm), dim3(kThreads), 0, stream, m, ut, gm, pu, c, beta_dev);
+        jtu_local(ut, tn);
+        hipLaunchKernelGGL(k_lsmr_v, dim3(gn), dim3(kThreads), 0, stream, n, tn, v, c, beta_dev, pv);
+        hipLaunchKernelGGL(k_lsmr_update, dim3(gn), dim3(kThreads), 0, stream, n, v, h, hbar, x, gn, pv, c, beta_dev, nx, px);
+        hipLaunchKernelGGL(k_lsmr_test, dim3(1), dim3(kThreads), 0, stream, gn, px, c, nx);
+        cur ^= 1;
+      }
+      MVUS_HIP(hipGetLastError());
+      MVUS_HIP(hipMemcpyAsync(lsmr_host, lsmr_state + cur, sizeof(LsmrScalars), hipMemcpyDeviceToHost, stream));
+      MVUS_HIP(hipStreamSynchronize(stream));
+      if (lsmr_host->istop != 0 || launched >= sc.maxiter) break;
+    }
+    sc = *lsmr_host;
+    touch(v); touch(x); touch(h); touch(hbar);
+  }
 };
 
 }  // namespace mvus
@@ -575,7 +643,7 @@ void mvus_default_opts(mvus_solve_opts* o) {
   if (!o) return;
   o->solver = MVUS_SOLVER_TRF_LSMR; o->jac_mode = MVUS_JAC_PATTERN; o->max_nfev = 10;
   o->ftol = 1e-8; o->xtol = 1e-12; o->gtol = 1e-8;
-  o->lsmr_atol = 1e-6; o->lsmr_btol = 1e-6; o->lsmr_conlim = 1e8; o->lsmr_maxiter = 0; o->verbose = 0; o->lm_lambda_min = 1e-2;
+  o->lsmr_atol = 1e-6; o->lsmr_btol = 1e-6; o->lsmr_conlim = 1e8; o->lsmr_maxiter = 0; o->verbose = 0; o->lm_lambda_min = 3e-3;
 }
 
 int mvus_ba_create(const mvus_problem* p, mvus_ba** out) {

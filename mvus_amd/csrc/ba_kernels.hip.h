@@ -19,6 +19,7 @@
 #include <string>
 
 #include "ba_math.h"
+#include "ba_solver.h"
 
 namespace mvus {
 
@@ -602,6 +603,118 @@ __global__ __launch_bounds__(kThreads) void k_dot_final(int nb, const double* __
   }
 }
 
+// ---- device-resident LSMR iteration (ba_solver.h: Lsmr::run, unbounded case) ------------------------------------------------
+// The scalar state lives in device memory (two copies, read `cur` / write `nxt`, flipped per iteration), so a batch of
+// iterations is launched without the three host synchronisations per iteration of the host-driven loop.  Every kernel is a
+// no-op once cur->istop is set: iterations launched past convergence cost their launches only.  The element arithmetic and
+// the summation trees are those of k_axpby / k_dot_partial / k_dot_final (same grids), so the iterates are the same bits.
+__device__ __forceinline__ double dot_final_block(int nb, const double* __restrict__ partials) {     // k_dot_final's tree; blockDim.x == kThreads
+  __shared__ double red_f[kThreads / 64];
+  __shared__ double tot_f;
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nb; i += kThreads) s += partials[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red_f[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int w = 0; w < kThreads / 64; ++w) t += red_f[w];
+    tot_f = t;
+  }
+  __syncthreads();
+  return tot_f;
+}
+__device__ __forceinline__ void dot_partial_store(double s, double* __restrict__ partials) {         // k_dot_partial's tree
+  __shared__ double red_p[kThreads / 64];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red_p[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int w = 0; w < kThreads / 64; ++w) t += red_p[w];
+    partials[blockIdx.x] = t;
+  }
+}
+// u = A v - alpha u (A v is in tm), partial sums of u.u
+__global__ __launch_bounds__(kThreads) void k_lsmr_u(long long m, const double* __restrict__ tm, double* __restrict__ ut,
+                                                     const LsmrScalars* __restrict__ cur, double* __restrict__ partials) {
+  if (cur->istop != 0) return;
+  const double a = 1.0, b = -cur->alpha;
+  double s = 0.0;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < m; i += (long long)gridDim.x * blockDim.x) {
+    const double u = a * tm[i] + b * ut[i];
+    ut[i] = u;
+    s += u * u;
+  }
+  dot_partial_store(s, partials);
+}
+// beta = |u| ; u /= beta.  Every workgroup sums the partials itself (same tree, same result); workgroup 0 records beta.
+__global__ __launch_bounds__(kThreads) void k_lsmr_unorm(long long m, double* __restrict__ ut, int nb, const double* __restrict__ partials,
+                                                         const LsmrScalars* __restrict__ cur, double* __restrict__ beta_out) {
+  if (cur->istop != 0) return;
+  const double beta = sqrt(dot_final_block(nb, partials));
+  if (blockIdx.x == 0 && threadIdx.x == 0) *beta_out = beta;
+  if (!(beta > 0)) return;
+  const double a = 1.0 / beta, b = 0.0;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < m; i += (long long)gridDim.x * blockDim.x)
+    ut[i] = a * ut[i] + b * ut[i];
+}
+// v = A^T u - beta v (A^T u is in tn), partial sums of v.v
+__global__ __launch_bounds__(kThreads) void k_lsmr_v(long long n, const double* __restrict__ tn, double* __restrict__ v,
+                                                     const LsmrScalars* __restrict__ cur, const double* __restrict__ beta_in, double* __restrict__ partials) {
+  if (cur->istop != 0) return;
+  const double beta = *beta_in;
+  if (!(beta > 0)) { if (threadIdx.x == 0) partials[blockIdx.x] = 0.0; return; }
+  const double a = 1.0, b = -beta;
+  double s = 0.0;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const double w = a * tn[i] + b * v[i];
+    v[i] = w;
+    s += w * w;
+  }
+  dot_partial_store(s, partials);
+}
+// alpha = |v| ; v /= alpha ; plane rotations ; hbar, x, h updates ; partial sums of x.x.  Every workgroup evaluates the (cheap)
+// scalar recurrences itself from the same inputs; workgroup 0 writes the new state.
+__global__ __launch_bounds__(kThreads) void k_lsmr_update(long long n, double* __restrict__ v, double* __restrict__ h, double* __restrict__ hbar,
+                                                          double* __restrict__ x, int nb, const double* __restrict__ partials_v,
+                                                          const LsmrScalars* __restrict__ cur, const double* __restrict__ beta_in,
+                                                          LsmrScalars* __restrict__ nxt, double* __restrict__ partials_x) {
+  if (cur->istop != 0) { if (blockIdx.x == 0 && threadIdx.x == 0) *nxt = *cur; return; }
+  LsmrScalars s = *cur;
+  ++s.itn;
+  s.beta = *beta_in;
+  const double vv = dot_final_block(nb, partials_v);
+  bool scale = false;
+  if (s.beta > 0) { s.alpha = sqrt(vv); scale = s.alpha > 0; }
+  detail::lsmr_rotations(s);
+  if (blockIdx.x == 0 && threadIdx.x == 0) *nxt = s;
+  const double inv = scale ? 1.0 / s.alpha : 1.0;
+  const double one = 1.0, zero = 0.0;
+  double acc = 0.0;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    double vi = v[i];
+    if (scale) { vi = inv * vi + zero * vi; v[i] = vi; }
+    const double hb = one * h[i] + s.c_hbar * hbar[i];
+    hbar[i] = hb;
+    const double xi = one * x[i] + s.c_x * hb;
+    x[i] = xi;
+    h[i] = one * vi + s.c_h * h[i];
+    acc += xi * xi;
+  }
+  dot_partial_store(acc, partials_x);
+}
+// |x| and the stopping tests
+__global__ __launch_bounds__(kThreads) void k_lsmr_test(int nb, const double* __restrict__ partials_x, const LsmrScalars* __restrict__ cur, LsmrScalars* __restrict__ nxt) {
+  if (cur->istop != 0) return;                       // (k_lsmr_update has carried the final state over)
+  const double xx = dot_final_block(nb, partials_x);
+  if (threadIdx.x == 0) {
+    LsmrScalars s = *nxt;
+    detail::lsmr_tests(s, sqrt(xx));
+    nxt->istop = s.istop;
+  }
+}
+
 // ---- LM driver (ba_schur.h): the two small vector reductions of an iteration --------------------------------
 // One element per thread; every workgroup leaves its partial result in `part`, the last one to finish (ticket from an
 // atomic counter, which it resets) combines them -- one launch, deterministic, no zero-initialised accumulator.
@@ -656,7 +769,7 @@ __global__ __launch_bounds__(1024) void k_lm_gnorm(int n, const double* __restri
 __global__ __launch_bounds__(1024) void k_lm_trial(int n, const double* __restrict__ x, const double* __restrict__ p, const double* __restrict__ lb,
                                                    const double* __restrict__ ub, const double* __restrict__ g, const double* __restrict__ D,
                                                    const int* __restrict__ fail, double* __restrict__ x_new, double* __restrict__ out,
-                                                   double* __restrict__ gnorm_out, double* part, unsigned* counter) {
+                                                   double* __restrict__ gnorm_out, double* part, unsigned* counter, double* __restrict__ x_mirror) {
   // also delivers the projected gradient norm of k_lm_gnorm (x, g and the bounds are read here anyway): slot 4 = max
   __shared__ double red[5][16];
   const bool dead = fail[0] != 0;
@@ -679,6 +792,7 @@ __global__ __launch_bounds__(1024) void k_lm_trial(int n, const double* __restri
       const double xn = (dead || !ok) ? xi : fmin(fmax(xi + pi, lo[u]), hi[u]);
       const double st = xn - xi;
       x_new[i] = xn;
+      if (x_mirror) x_mirror[i] = xn;                    // mapped pinned host memory: the accepted point needs no download
       s[0] += ok ? gi * st : pi * 0.0; s[1] += st * dv[u] * st; s[2] += st * st; s[3] += xi * xi;
       const bool blocked = (xi <= lo[u] && gi > 0) || (xi >= hi[u] && gi < 0);
       s[4] = fmax(s[4], blocked ? 0.0 : fabs(gi));

@@ -107,7 +107,7 @@ struct HostProblem {
       const int ns = nk - 4;
       const double* t = knots.data() + knot_off[s];
       for (int k = 1; k < nk; ++k) if (t[k] < t[k - 1]) return "knot vector must be non-decreasing";
-      for (int k = 3; k < ns; ++k) if (!(t[k + 1] > t[k])) return "interior knots must be distinct";
+      for (int k = 3; k < ns; ++k) if (!(t[k + 1] > t[k])) return "interior knots must be distinct (a spline piece with repeated interior knots -- e.g. the cubic twin of the reference's k=1 fallback for a three-sample trajectory part -- can be evaluated, but not bundle-adjusted: the reference's jac_BA has no pattern for it either)";
       ctrl_off[s + 1] = ctrl_off[s] + ns;
       xoff[s] = (int32_t)xo;
       xo += 3 * (int64_t)ns;

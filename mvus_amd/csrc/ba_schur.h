@@ -70,7 +70,7 @@ inline void lm_trial_host(int64_t n, const double* x, const double* p, const dou
 
 template <class B, class Schur>
 SolveResult lm_schur(B& be, Schur& sc, std::vector<double>& x, const std::vector<double>& lb, const std::vector<double>& ub,
-                     const SolveOptions& opt, double* f_dev) {
+                     const SolveOptions& opt, double* f_dev) {          // f_dev: the backend's residual buffer (f(x) on return)
   using namespace detail;
   SolveResult res;
   const int64_t n = be.n(), m = be.m_local();
@@ -92,9 +92,16 @@ SolveResult lm_schur(B& be, Schur& sc, std::vector<double>& x, const std::vector
   be.dot_m_into(f_dev, f_dev, S);
   sc.linearize(be, x_dev, f_dev, opt.jac_mode, true);
 
+  // f(x_new) becomes f(x): the two buffers change roles where the backend allows it (the HIP backend's are pool buffers of
+  // one size), else a copy
+  auto accept_residual = [&] {
+    if (B::kSwapResiduals) { double* old = f_new; be.adopt_residual(f_dev, f_new); pool.replace(old, f_new); }
+    else be.copy(f_dev, f_new, m);
+  };
+  int mir_cur = -1, mir_trial = 0;      // host mirrors of the accepted / the trial point (backend permitting)
   auto launch_trial = [&](double lambda) {
     sc.solve_async(lambda);
-    be.lm_trial(x_dev, sc.step_ptr(), lbp, ubp, sc.grad_ptr(), sc.diag_ptr(), sc.fail_ptr(), xt_dev, S + 2, S + 1);
+    be.lm_trial(x_dev, sc.step_ptr(), lbp, ubp, sc.grad_ptr(), sc.diag_ptr(), sc.fail_ptr(), xt_dev, S + 2, S + 1, be.mirror_dev(mir_trial));
     be.residual(xt_dev, f_new);
     be.dot_m_into(f_new, f_new, S + 6);
   };
@@ -154,15 +161,16 @@ SolveResult lm_schur(B& be, Schur& sc, std::vector<double>& x, const std::vector
     }
     if (actual_reduction > 0) {
       std::swap(x_dev, xt_dev);
+      mir_cur = mir_trial; mir_trial ^= 1;
       cost = cost_new;
       if (status == -1 && res.nfev >= opt.max_nfev) {
         // evaluation budget spent: no further step will be taken, so the accepted point is not re-linearised (one
         // Jacobian + assembly saved per call); the reported optimality is then that of the last linearisation
-        be.copy(f_dev, f_new, m);
+        accept_residual();
         res.jac_stale = true;             // J, span and the assembled blocks still belong to the previous point
         break;
       }
-      be.copy(f_dev, f_new, m);                 // f at the accepted point is the trial residual: not evaluated again
+      accept_residual();                        // f at the accepted point is the trial residual: not evaluated again
       ++res.njev;
       sc.linearize(be, x_dev, f_dev, opt.jac_mode, true);
     }
@@ -174,7 +182,9 @@ SolveResult lm_schur(B& be, Schur& sc, std::vector<double>& x, const std::vector
     }
   }
   if (status == -1) status = 0;
-  be.download(x.data(), x_dev, n);
+  if (mir_cur < 0) { /* no step was accepted: x is the caller's x0 */ }
+  else if (be.mirror_host(mir_cur)) std::copy(be.mirror_host(mir_cur), be.mirror_host(mir_cur) + n, x.begin());   // written by the accepted trial's kernel, fetched since
+  else be.download(x.data(), x_dev, n);
   res.status = status;
   res.cost = cost;
   res.optimality = g_norm;

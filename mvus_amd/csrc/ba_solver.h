@@ -44,7 +44,7 @@ struct SolveOptions {
   double lsmr_atol = 1e-6, lsmr_btol = 1e-6, lsmr_conlim = 1e8;
   int lsmr_maxiter = 0;
   int verbose = 0;
-  double lm_lambda_min = 1e-2;   // floor of the LM damping (see mvus_solve_opts)
+  double lm_lambda_min = 3e-3;   // floor of the LM damping (see mvus_solve_opts)
   double lm_lambda0 = 0;   // > 0: initial LM damping (a handle carries it over from its previous solve)
   double lm_nu0 = 0;       // > 0: initial damping growth factor (carried with it, so that a run of one-trial solves
                            // escalates the damping like one long solve does)
@@ -66,6 +66,7 @@ struct PoolGuard {
   std::vector<double*> bufs;
   explicit PoolGuard(B& b) : be(b) {}
   double* get(int64_t len) { double* p = be.alloc(len); bufs.push_back(p); return p; }
+  void replace(double* held, double* now) { for (double*& p : bufs) if (p == held) { p = now; return; } }   // a held buffer changed roles with one outside
   ~PoolGuard() { for (double* p : bufs) be.release(p); }
   PoolGuard(const PoolGuard&) = delete;
   PoolGuard& operator=(const PoolGuard&) = delete;
@@ -261,6 +262,107 @@ inline void intersect_trust_region(const std::vector<double>& x, const std::vect
 }  // namespace detail
 
 // ------------------------------------------------------------------------------------------------
+// Scalar state of one LSMR run (scipy lsmr.py:316-470) and its two per-iteration updates, written once for the host loop
+// and for the HIP backend's device-resident loop (k_lsmr_* in ba_kernels.hip.h), which runs whole batches of iterations
+// without a host round trip.  No FMA contraction in here: host and device then produce the same bits.
+// ------------------------------------------------------------------------------------------------
+#if defined(__HIPCC__)
+#define MVUS_SOLVER_HD __host__ __device__ inline
+#else
+#define MVUS_SOLVER_HD inline
+#endif
+struct LsmrScalars {
+  double alpha = 0, beta = 0, zetabar = 0, alphabar = 0, rho = 1, rhobar = 1, cbar = 1, sbar = 0;
+  double betadd = 0, betad = 0, rhodold = 1, tautildeold = 0, thetatilde = 0, zeta = 0, d = 0;
+  double normA2 = 0, maxrbar = 0, minrbar = 1e+100, normb = 0, damp = 0, atol = 0, btol = 0, ctol = 0;
+  double normr = 0, normar = 0, normA = 0, condA = 1;
+  double c_hbar = 0, c_x = 0, c_h = 0;       // hbar = h + c_hbar hbar ; x += c_x hbar ; h = v + c_h h
+  long long itn = 0, maxiter = 0;
+  int istop = 0, pad = 0;
+};
+namespace detail {
+MVUS_SOLVER_HD double hd_sgn(double a) { return (a > 0) - (a < 0); }
+MVUS_SOLVER_HD void hd_sym_ortho(double a, double b, double& c, double& s, double& r) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+  if (b == 0) { c = hd_sgn(a); s = 0; r = fabs(a); }
+  else if (a == 0) { c = 0; s = hd_sgn(b); r = fabs(b); }
+  else if (fabs(b) > fabs(a)) {
+    const double tau = a / b;
+    s = hd_sgn(b) / sqrt(1 + tau * tau);
+    c = s * tau;
+    r = b / s;
+  } else {
+    const double tau = b / a;
+    c = hd_sgn(a) / sqrt(1 + tau * tau);
+    s = c * tau;
+    r = a / c;
+  }
+}
+// after alpha and beta of this iteration are known (s.alpha, s.beta): rotations, the three vector-update coefficients,
+// norm estimates (lsmr.py:379-440)
+MVUS_SOLVER_HD void lsmr_rotations(LsmrScalars& s) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+  const double alpha = s.alpha, beta = s.beta;
+  double chat, shat, alphahat; hd_sym_ortho(s.alphabar, s.damp, chat, shat, alphahat);
+  const double rhoold = s.rho;
+  double c, sn; hd_sym_ortho(alphahat, beta, c, sn, s.rho);
+  const double thetanew = sn * alpha;
+  s.alphabar = c * alpha;
+  const double rhobarold = s.rhobar, zetaold = s.zeta;
+  const double thetabar = s.sbar * s.rho, rhotemp = s.cbar * s.rho;
+  hd_sym_ortho(s.cbar * s.rho, thetanew, s.cbar, s.sbar, s.rhobar);
+  s.zeta = s.cbar * s.zetabar;
+  s.zetabar = -s.sbar * s.zetabar;
+  s.c_hbar = -(thetabar * s.rho / (rhoold * rhobarold));
+  s.c_x = s.zeta / (s.rho * s.rhobar);
+  s.c_h = -(thetanew / s.rho);
+  const double betaacute = chat * s.betadd, betacheck = -shat * s.betadd;
+  const double betahat = c * betaacute;
+  s.betadd = -sn * betaacute;
+  const double thetatildeold = s.thetatilde;
+  double ctildeold, stildeold, rhotildeold; hd_sym_ortho(s.rhodold, thetabar, ctildeold, stildeold, rhotildeold);
+  s.thetatilde = stildeold * s.rhobar;
+  s.rhodold = ctildeold * s.rhobar;
+  s.betad = -stildeold * s.betad + ctildeold * betahat;
+  s.tautildeold = (zetaold - thetatildeold * s.tautildeold) / rhotildeold;
+  const double taud = (s.zeta - s.thetatilde * s.tautildeold) / s.rhodold;
+  s.d = s.d + betacheck * betacheck;
+  s.normr = sqrt(s.d + (s.betad - taud) * (s.betad - taud) + s.betadd * s.betadd);
+  s.normA2 = s.normA2 + beta * beta;
+  s.normA = sqrt(s.normA2);
+  s.normA2 = s.normA2 + alpha * alpha;
+  s.maxrbar = s.maxrbar > rhobarold ? s.maxrbar : rhobarold;
+  if (s.itn > 1) s.minrbar = s.minrbar < rhobarold ? s.minrbar : rhobarold;
+  s.condA = (s.maxrbar > rhotemp ? s.maxrbar : rhotemp) / (s.minrbar < rhotemp ? s.minrbar : rhotemp);
+  s.normar = fabs(s.zetabar);
+}
+// the stopping tests once |x| is known (lsmr.py:442-470)
+MVUS_SOLVER_HD void lsmr_tests(LsmrScalars& s, double normx) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+  const double test1 = s.normr / s.normb;
+  const double test2 = (s.normA * s.normr) != 0 ? s.normar / (s.normA * s.normr) : 1.0 / 0.0;
+  const double test3 = 1 / s.condA;
+  const double t1 = test1 / (1 + s.normA * normx / s.normb);
+  const double rtol = s.btol + s.atol * s.normA * normx / s.normb;
+  int istop = 0;
+  if (s.itn >= s.maxiter) istop = 7;
+  if (1 + test3 <= 1) istop = 6;
+  if (1 + test2 <= 1) istop = 5;
+  if (1 + t1 <= 1) istop = 4;
+  if (test3 <= s.ctol) istop = 3;
+  if (test2 <= s.atol) istop = 2;
+  if (test1 <= rtol) istop = 1;
+  s.istop = istop;
+}
+}  // namespace detail
+
+// ------------------------------------------------------------------------------------------------
 // LSMR on A = [J diag(D); diag(E)] with right-hand side [b; 0] and scalar damping `damp`.
 // D and E are device n-vectors or nullptr (D = 1, no extra rows).  Result in x_dev (n).
 // ------------------------------------------------------------------------------------------------
@@ -299,91 +401,60 @@ struct Lsmr {
       be.fill(v, 0.0, n);
     }
     if (alpha > 0) be.axpby(n, 1.0 / alpha, v, 0.0, v, v);
-    int64_t itn = 0;
-    double zetabar = alpha * beta, alphabar = alpha, rho = 1, rhobar = 1, cbar = 1, sbar = 0;
+    LsmrScalars sc;
+    sc.alpha = alpha; sc.beta = beta; sc.zetabar = alpha * beta; sc.alphabar = alpha;
     be.copy(h, v, n);
     be.fill(hbar, 0.0, n);
-    double betadd = beta, betad = 0, rhodold = 1, tautildeold = 0, thetatilde = 0, zeta = 0, d = 0;
-    double normA2 = alpha * alpha, maxrbar = 0, minrbar = 1e+100;
-    double normA = std::sqrt(normA2), condA = 1, normx = 0;
-    int istop = 0;
-    const double ctol = conlim > 0 ? 1 / conlim : 0;
-    double normr = beta, normar = alpha * beta;
+    sc.betadd = beta; sc.normA2 = alpha * alpha; sc.normb = normb; sc.damp = damp; sc.atol = atol; sc.btol = btol;
+    sc.ctol = conlim > 0 ? 1 / conlim : 0;
+    sc.normr = beta; sc.normar = alpha * beta; sc.normA = std::sqrt(sc.normA2); sc.maxiter = maxiter;
     if (itn_out) *itn_out = 0;
-    if (normar == 0) return 0;
+    if (sc.normar == 0) return 0;
     if (normb == 0) { be.fill(x, 0.0, n); return 0; }
-    while (itn < maxiter) {
-      ++itn;
+    if constexpr (B::kDeviceLsmr) {
+      // the HIP backend keeps the scalars on the device and runs batches of iterations without a host round trip
+      // (three synchronisations and ~17 launches per iteration otherwise); same kernels' arithmetic, same bits
+      if (!D && !E && !trace && be.lsmr_on_device()) {
+        be.lsmr_iterations(sc, ut, tm, v, tn, h, hbar, x);
+        if (itn_out) *itn_out = (int)sc.itn;
+        return sc.istop;
+      }
+    }
+    while (sc.itn < maxiter) {
+      ++sc.itn;
       // u = A v - alpha u ; beta = |u|
       if (D) { be.mul(n, D, v, tn); be.jv(tn, tm); } else be.jv(v, tm);
-      be.axpby(m, 1.0, tm, -alpha, ut, ut);
+      be.axpby(m, 1.0, tm, -sc.alpha, ut, ut);
       double bsq = be.dot_m(ut, ut);
       if (E) {
         be.mul(n, E, v, tn);
-        be.axpby(n, 1.0, tn, -alpha, ub, ub);
+        be.axpby(n, 1.0, tn, -sc.alpha, ub, ub);
         bsq += be.dot_n(ub, ub, n);
       }
-      beta = std::sqrt(bsq);
-      if (beta > 0) {
-        be.axpby(m, 1.0 / beta, ut, 0.0, ut, ut);
-        if (E) be.axpby(n, 1.0 / beta, ub, 0.0, ub, ub);
+      sc.beta = std::sqrt(bsq);
+      if (sc.beta > 0) {
+        be.axpby(m, 1.0 / sc.beta, ut, 0.0, ut, ut);
+        if (E) be.axpby(n, 1.0 / sc.beta, ub, 0.0, ub, ub);
         // v = A^T u - beta v
         be.jtu(ut, tn);
         if (D) be.mul(n, D, tn, tn);
-        be.axpby(n, 1.0, tn, -beta, v, v);
+        be.axpby(n, 1.0, tn, -sc.beta, v, v);
         if (E) { be.mul(n, E, ub, tn); be.axpby(n, 1.0, v, 1.0, tn, v); }
-        alpha = std::sqrt(be.dot_n(v, v, n));
-        if (alpha > 0) be.axpby(n, 1.0 / alpha, v, 0.0, v, v);
+        sc.alpha = std::sqrt(be.dot_n(v, v, n));
+        if (sc.alpha > 0) be.axpby(n, 1.0 / sc.alpha, v, 0.0, v, v);
       }
-      double chat, shat, alphahat; sym_ortho(alphabar, damp, chat, shat, alphahat);
-      const double rhoold = rho;
-      double c, s; sym_ortho(alphahat, beta, c, s, rho);
-      const double thetanew = s * alpha;
-      alphabar = c * alpha;
-      const double rhobarold = rhobar, zetaold = zeta;
-      const double thetabar = sbar * rho, rhotemp = cbar * rho;
-      sym_ortho(cbar * rho, thetanew, cbar, sbar, rhobar);
-      zeta = cbar * zetabar;
-      zetabar = -sbar * zetabar;
+      detail::lsmr_rotations(sc);
       // hbar = h - (thetabar*rho/(rhoold*rhobarold)) hbar ; x += (zeta/(rho*rhobar)) hbar ; h = v - (thetanew/rho) h
-      be.axpby(n, 1.0, h, -(thetabar * rho / (rhoold * rhobarold)), hbar, hbar);
-      be.axpby(n, 1.0, x, zeta / (rho * rhobar), hbar, x);
-      be.axpby(n, 1.0, v, -(thetanew / rho), h, h);
-      const double betaacute = chat * betadd, betacheck = -shat * betadd;
-      const double betahat = c * betaacute;
-      betadd = -s * betaacute;
-      const double thetatildeold = thetatilde;
-      double ctildeold, stildeold, rhotildeold; sym_ortho(rhodold, thetabar, ctildeold, stildeold, rhotildeold);
-      thetatilde = stildeold * rhobar;
-      rhodold = ctildeold * rhobar;
-      betad = -stildeold * betad + ctildeold * betahat;
-      tautildeold = (zetaold - thetatildeold * tautildeold) / rhotildeold;
-      const double taud = (zeta - thetatilde * tautildeold) / rhodold;
-      d = d + betacheck * betacheck;
-      normr = std::sqrt(d + (betad - taud) * (betad - taud) + betadd * betadd);
-      normA2 = normA2 + beta * beta;
-      normA = std::sqrt(normA2);
-      normA2 = normA2 + alpha * alpha;
-      maxrbar = std::max(maxrbar, rhobarold);
-      if (itn > 1) minrbar = std::min(minrbar, rhobarold);
-      condA = std::max(maxrbar, rhotemp) / std::min(minrbar, rhotemp);
-      normar = std::fabs(zetabar);
-      normx = std::sqrt(be.dot_n(x, x, n));
-      const double test1 = normr / normb;
-      const double test2 = (normA * normr) != 0 ? normar / (normA * normr) : std::numeric_limits<double>::infinity();
-      const double test3 = 1 / condA;
-      const double t1 = test1 / (1 + normA * normx / normb);
-      const double rtol = btol + atol * normA * normx / normb;
-      if (itn >= maxiter) istop = 7;
-      if (1 + test3 <= 1) istop = 6;
-      if (1 + test2 <= 1) istop = 5;
-      if (1 + t1 <= 1) istop = 4;
-      if (test3 <= ctol) istop = 3;
-      if (test2 <= atol) istop = 2;
-      if (test1 <= rtol) istop = 1;
-      if (trace) std::fprintf(stderr, "lsmr %3d alpha=%.10e beta=%.10e normr=%.6e normar=%.6e normA=%.4e condA=%.4e t2=%.3e\n", (int)itn, alpha, beta, normr, normar, normA, condA, test2);
-      if (istop > 0) break;
+      be.axpby(n, 1.0, h, sc.c_hbar, hbar, hbar);
+      be.axpby(n, 1.0, x, sc.c_x, hbar, x);
+      be.axpby(n, 1.0, v, sc.c_h, h, h);
+      const double normx = std::sqrt(be.dot_n(x, x, n));
+      detail::lsmr_tests(sc, normx);
+      if (trace) std::fprintf(stderr, "lsmr %3d alpha=%.10e beta=%.10e normr=%.6e normar=%.6e normA=%.4e condA=%.4e\n", (int)sc.itn, sc.alpha, sc.beta, sc.normr, sc.normar, sc.normA, sc.condA);
+      if (sc.istop > 0) break;
     }
+    const int64_t itn = sc.itn;
+    const int istop = sc.istop;
     if (itn_out) *itn_out = (int)itn;
     return istop;
   }

@@ -23,7 +23,7 @@ Extra ``settings`` keys (all optional; a reference ``config.json`` has none of t
                full analytic (default with 'lm').
 ``ba_pattern_ties`` 'numpy' = the twin rows of the pattern decided like np.argsort of this process decides them (default;
                what the reference would build here), 'canonical'.
-``ba_lambda_min`` floor of the LM damping (default 1e-2, see ``mvus_solve_opts.lm_lambda_min``).
+``ba_lambda_min`` floor of the LM damping (default 3e-3, see ``mvus_solve_opts.lm_lambda_min``).
 ``opt_sync`` (reference key: False freezes alpha/beta), ``device``.
 """
 import json
@@ -373,7 +373,17 @@ class Scene:
         h = self._resident_handle(prob, cams)      # stays resident for remove_outliers and the next BA
         opts = _ba._lib.default_opts(solver, jac_mode, max_iter)
         opts.lm_lambda_min = float(st.get('ba_lambda_min', opts.lm_lambda_min))
-        res = h.solve(model, opts=opts, ties=st.get('ba_pattern_ties', 'numpy'), matrix=jac_sparsity)
+        try:
+            res = h.solve(model, opts=opts, ties=st.get('ba_pattern_ties', 'numpy'), matrix=jac_sparsity)
+        except RuntimeError as e:
+            if solver != _ba.SOLVER_LM_SCHUR or 'unsupported band width' not in str(e):
+                raise
+            # LM + Schur keeps the spline block as a band of at most six 3x3 blocks; FITPACK knots less than one frame apart
+            # (dense triangulated points of a fast camera) make the motion rows reach further.  The other GPU solver has no
+            # such limit: same analytic Jacobian, TRF + LSMR instead of the normal equations.  Said aloud, not silently.
+            print('BA: %s -- solving this problem with ba_solver=trf (analytic Jacobian) instead' % e)
+            opts = _ba._lib.default_opts(_ba.SOLVER_TRF_LSMR, _ba.JAC_ANALYTIC, max_iter)
+            res = h.solve(model, opts=opts, ties='canonical')
         alpha, beta, rs_new, cam_states, coefs = _problem.unpack_x(prob, res.x)
         self.alpha[cams], self.beta[cams], self.rs[cams] = alpha, beta, rs_new
         for k, i in enumerate(cams):

@@ -79,6 +79,101 @@ def smooth_fit(t, X, s, device=0, full_output=False):
     return (tck, fp.value, ier.value) if full_output else tck
 
 
+def _fprati(p1, f1, p2, f2, p3, f3):
+    """FITPACK fprati: the zero of the rational interpolant r(p) = (u p + v) / (p + w) through three points (p3 < 0: p3 = inf)."""
+    if p3 > 0.0:
+        h1, h2, h3 = f1 * (f2 - f3), f2 * (f3 - f1), f3 * (f1 - f2)
+        p = -(p1 * p2 * h3 + p2 * p3 * h1 + p3 * p1 * h2) / (p1 * h1 + p2 * h2 + p3 * h3)
+    else:
+        p = (p1 * (f1 - f3) * f2 - p2 * (f2 - f3) * f1) / ((f1 - f2) * f3)
+    if f2 < 0.0:
+        p3, f3 = p2, f2
+    else:
+        p1, f1 = p2, f2
+    return p, p1, f1, p3, f3
+
+
+def linear_fit_as_cubic(part, s):
+    """The reference's fallback for a part with fewer than four samples (common.py:266-267): ``splprep(k=3)`` raises there
+    (it needs m > k) and the bare ``except`` calls ``splprep(X, u=t, s=s, k=1)`` instead.  Through ``find_intervals`` only
+    m = 3 can occur (two gaps < 5 spanning >= 5 time units).  This is FITPACK's ``fppara`` for k = 1 written out for that
+    size (scipy 1.15.3, third party -- not under /root/reference; same flow, tolerances and iteration as the k = 3 case the
+    GPU runs): the least-squares line if its squared residual is below s; otherwise one knot at the middle sample, and
+    -- the interpolating polyline then has residual 0 < s -- the smoothing spline between the two with residual s, its
+    parameter p found by fppara's own rational iteration (same starting value, brackets and stopping rule, so the same p).
+    With the three linear B-splines being 1 at their own sample the observation matrix is the identity, which makes every
+    step closed form: c(p) = x - b (b.x) / (p^2 + b.b), b = the derivative-jump row of ``fpdisc``.
+
+    The kernels of this library evaluate CUBIC splines only, so the piecewise-linear curve is returned degree-elevated: the
+    same curve, point for point, as a cubic tck (knots [a x4, b x4], or [a x4, u2 x3, b x4] for the bent one).  Documented
+    divergence: ``tck[2]`` is 3 where the reference stores 1, and the knot / coefficient arrays differ accordingly; every
+    evaluation (spline_to_traj, the BA residual) gives the reference's values."""
+    part = np.asarray(part, dtype=np.float64)
+    m = part.shape[1]
+    u, X = part[0], part[1:]
+    if m < 2:
+        raise ValueError('traj_to_spline: a trajectory part with a single sample cannot be fitted (the reference raises too: splprep needs m > k)')
+    a, b = u[0], u[-1]
+    if m == 2:                                                        # nmax == nmin: the interpolating segment
+        P, breaks = [X[:, 0], X[:, 1]], [a, b]
+    elif m == 3:
+        tol, maxit = 0.001, 20
+        acc = tol * s
+        lam = (u - a) / (b - a)
+        A = np.column_stack((1.0 - lam, lam))
+        c, *_ = np.linalg.lstsq(A, X.T, rcond=None)                  # (2, 3): values of the least-squares line at a and b
+        fp0 = float(np.sum((A @ c - X.T) ** 2))
+        if abs(fp0 - s) < acc or fp0 < s:                              # fppara: |fp - s| < acc, or fp < s with no interior knot (ier = -2)
+            P, breaks = [c[0], c[1]], [a, b]
+        else:
+            fac = 2.0 / (b - a)                                        # fpdisc, k = 1, knots [a, a, u2, b, b]
+            bj = np.array([1.0 / ((u[1] - a) * fac), (b - a) / ((u[1] - a) * (u[1] - b) * fac), 1.0 / ((b - u[1]) * fac)])
+            bb, w = float(bj @ bj), X @ bj
+            W = float(w @ w)
+            F = lambda p: bb * W / (p * p + bb) ** 2                   # noqa: E731  residual of the smoothing spline with parameter p
+            p1, f1, p3, f3 = 0.0, fp0 - s, -1.0, -s
+            p = 1.0                                                    # nk1 / sum of the triangle's diagonal (three ones)
+            ich1 = ich3 = 0
+            for iteration in range(1, maxit + 1):
+                f2 = F(p) - s
+                if abs(f2) < acc or iteration == maxit:
+                    break
+                p2 = p
+                if ich3 == 0:
+                    if f2 - f3 <= acc:                                 # the initial choice of p is too large
+                        p3, f3 = p2, f2
+                        p = p * 0.04
+                        if p <= p1:
+                            p = p1 * 0.9 + p2 * 0.1
+                        continue
+                    if f2 < 0.0:
+                        ich3 = 1
+                if ich1 == 0:
+                    if f1 - f2 <= acc:                                 # the initial choice of p is too small
+                        p1, f1 = p2, f2
+                        p = p / 0.04
+                        if p3 >= 0.0 and p >= p3:
+                            p = p2 * 0.1 + p3 * 0.9
+                        continue
+                    if f2 > 0.0:
+                        ich1 = 1
+                if f2 >= f1 or f2 <= f3:
+                    break                                              # (fppara: ier = 2, keeps the current spline)
+                p, p1, f1, p3, f3 = _fprati(p1, f1, p2, f2, p3, f3)
+            Cp = X - np.outer(w, bj) / (p * p + bb)
+            P, breaks = [Cp[:, 0], Cp[:, 1], Cp[:, 2]], [a, u[1], b]
+    else:
+        raise ValueError('linear_fit_as_cubic is the fallback for parts with fewer than four samples')
+    knots = [breaks[0]] * 4
+    coefs = [P[0]]
+    for j in range(1, len(P)):
+        d = P[j] - P[j - 1]
+        coefs += [P[j - 1] + d / 3.0, P[j - 1] + 2.0 * d / 3.0, P[j]]
+        knots += [breaks[j]] * (3 if j < len(P) - 1 else 4)
+    C = np.array(coefs).T
+    return [np.array(knots, dtype=np.float64), [C[0].copy(), C[1].copy(), C[2].copy()], 3]
+
+
 def traj_fit(part, smooth_factor, device=0):
     """One interval of ``Scene.traj_to_spline`` (reference common.py:236-262): ``part`` = [t; x; y; z] (4, m).  The smoothing
     factor starts at 1e-6 * duration and is divided by 1.5 / doubled until duration / #coefficients lies between the two
@@ -86,6 +181,8 @@ def traj_fit(part, smooth_factor, device=0):
     lo, hi = min(smooth_factor), max(smooth_factor)
     measure = part[0, -1] - part[0, 0]
     s = (1e-3) ** 2 * measure
+    if part.shape[1] < 4:                        # splprep(k=3) raises -> the reference's k=1 fallback (common.py:266-267)
+        return linear_fit_as_cubic(part, s)
     prev, direction = 0, 0
     while True:
         tck = smooth_fit(part[0], part[1:], s, device=device)

@@ -6,6 +6,10 @@ import numpy as np
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 CASES = ['c1_pinhole_2cam', 'rs_F_2int_3cam', 'calib_KE_bounds_3cam', 'dist_fixed_2cam']
+# BASELINE configs[4] (opt_calib + rs_bounds + KE) on a WELL-POSED scene: 5 cameras x ~3k detections, the target sweeps the
+# images.  15k detections: used by the tests that need it (residual, mask, pattern, converged parity), not by every sweep.
+CALIB_WP = 'calib_KE_wellposed_5cam'
+CONVERGED_CASES = CASES + [CALIB_WP]
 
 
 def load_case(name):
@@ -34,3 +38,28 @@ def load_case(name):
                             rs=g['rs'].copy(), tck=tck, interval=g['interval'].copy(), settings=settings,
                             num_cam=C, num_obs=int(off[-1]))
     return scene, g
+
+
+def load_ensemble(name):
+    """The reference's own reproducibility (tests/golden/make_golden_ensemble.py): converged parameter vectors of its
+    second BA re-run with last-place noise on the residuals, two noise models x 8 members."""
+    return dict(np.load(os.path.join(GOLDEN_DIR, 'ens_' + name + '.npz'), allow_pickle=False))
+
+
+def reference_spread(oprob, name, x_ref):
+    """Per gauge-invariant metric (tests/gauge.py) and for the final RMSE: the largest deviation of any ensemble member
+    (either noise model) from the reference's unperturbed answer."""
+    import gauge
+    ens = load_ensemble(name)
+    a = gauge.ensemble_spread(oprob, x_ref, ens['ens_x'])
+    b = gauge.ensemble_spread(oprob, x_ref, ens['ensu_x'])
+    return {k: max(a[k], b[k]) for k in a}
+
+
+def ground_truth_x(oprob, name):
+    """The generator's ground truth as a parameter vector of this problem (the fixtures do not store it; mvus_amd.synth is
+    deterministic in its arguments, tests/golden_cases.py has them)."""
+    import golden_cases
+    from oracle import ba_oracle as orc
+    tr = golden_cases.make(name).truth
+    return orc.pack_x(oprob, tr['alpha'], tr['beta'], tr['rs'], tr['cameras'], [t[1] for t in tr['tck']])

@@ -54,7 +54,12 @@ struct HostBackend {
   void dot_m_into(const double* a, const double* b, double* out) { *out = dot_m(a, b); }
   void lm_gnorm(const double* x, const double* lb, const double* ub, const double* g, double* out) { *out = mvus::lm_gnorm_host(hp.n, x, lb, ub, g); }
   void lm_trial(const double* x, const double* p, const double* lb, const double* ub, const double* g, const double* D,
-                const int* fail, double* x_new, double* out, double* gn) { mvus::lm_trial_host(hp.n, x, p, lb, ub, g, D, *fail, x_new, out, gn); }
+                const int* fail, double* x_new, double* out, double* gn, double*) { mvus::lm_trial_host(hp.n, x, p, lb, ub, g, D, *fail, x_new, out, gn); }
+  static constexpr bool kSwapResiduals = false;
+  static constexpr bool kDeviceLsmr = false;
+  double* mirror_dev(int) { return nullptr; }
+  const double* mirror_host(int) const { return nullptr; }
+  void adopt_residual(double*&, double*&) {}
   void fetch(const double* src, int k, double* host) { std::memcpy(host, src, sizeof(double) * k); }
 
   void init() {

@@ -4,7 +4,8 @@ import numpy as np
 import pytest
 
 from oracle import ba_oracle as orc
-from golden_util import CASES, load_case
+import gauge
+from golden_util import CALIB_WP, CASES, CONVERGED_CASES, ground_truth_x, load_case, reference_spread
 from test_fd_mode_host import CONVERGED_RMSE_ATOL, filtered_case, golden_matrix, tie_order_is_the_recorded_one
 from mvus_amd import _lib
 from mvus_amd import problem as mp
@@ -12,7 +13,12 @@ from mvus_amd import problem as mp
 pytestmark = pytest.mark.gpu
 
 RESIDUAL_ATOL = 1e-9        # px, fp64 residuals vs the reference's values
-GPU_CONVERGED_RMSE_ATOL = {'c1_pinhole_2cam': 2.5e-3, 'rs_F_2int_3cam': 2.5e-3, 'calib_KE_bounds_3cam': 1e-1, 'dist_fixed_2cam': 2.5e-3}
+# The converged second BA in the reference's own algorithm is held to SPREAD_FACTOR x what the REFERENCE reproduces of itself
+# when its residuals are perturbed in the last place (tests/golden/ens_*.npz: eight runs each with 1e-15 relative noise and
+# with noise of one ulp of the pixel coordinates; the larger of the two spreads per quantity).  Measured on MI355X, final
+# RMSE minus the reference's / spread: c1 -1.4e-4 / 4.3e-4, rs_F -8.1e-4 / 3.5e-4 (2.3x), calib_KE_bounds -3.1e-3 / 2.5e-2,
+# dist -1.4e-4 / 1.1e-4 (1.3x), calib_KE_wellposed -2.4e-5; gauge-invariant distances of x: <= 2.7x (rs_F), else <= 1x.
+SPREAD_FACTOR = 3.0
 JAC_RTOL = 1e-10            # GPU vs host build of the same analytic formulas (relative to column scale)
 
 
@@ -60,7 +66,7 @@ def slots_to_dense(prob, J, ctrl, mJ=None, mctrl=None):
     return D
 
 
-@pytest.mark.parametrize('name', CASES)
+@pytest.mark.parametrize('name', CONVERGED_CASES)
 def test_residual_vs_reference_golden(BAHandle, name):
     scene, g = load_case(name)
     prob, x0 = mp.problem_from_scene(scene)
@@ -102,7 +108,7 @@ def test_jacobian_operator_vs_host_build(BAHandle, name, mode):
         np.testing.assert_allclose(h.jtu(u), zref, rtol=1e-10, atol=1e-10 * np.abs(zref).max())
 
 
-@pytest.mark.parametrize('name', CASES)
+@pytest.mark.parametrize('name', CONVERGED_CASES)
 def test_pattern_vs_reference_matrix(BAHandle, name):
     """jac_BA + compute_visibility (common.py:427-438,490-610), integer: the codes k_pattern computes, against the matrix
     the reference built (golden), row by row.  Bit-exact in every row that is not a twin tie; the flagged rows differ
@@ -171,7 +177,7 @@ def test_analytic_jacobian_vs_oracle_central_differences(BAHandle, name):
     assert np.max(np.abs(D[ok] - Jfd[ok]) / scale) < 2e-5
 
 
-@pytest.mark.parametrize('name', CASES)
+@pytest.mark.parametrize('name', CONVERGED_CASES)
 def test_outlier_mask_bit_exact(BAHandle, name):
     scene, g = load_case(name)
     prob, _ = mp.problem_from_scene(scene)
@@ -358,39 +364,62 @@ def test_fd_mode_ba_vs_reference_result(BAHandle, name):
     assert flips <= 0.02 * keep.size, flips
 
 
-@pytest.mark.parametrize('name', CASES)
+@pytest.mark.parametrize('name', CONVERGED_CASES)
 def test_converged_second_ba_fd_mode(BAHandle, name):
-    """North-star parity at the one point where it is decidable: the reference's converged second BA (main.py:59 with
-    max_iter=200; status 3 on all four scenes).  The reference's algorithm on the GPU -- TRF + LSMR + grouped forward
-    differences over the reference's matrix -- from the reference's start: same status, final RMSE at the reference's
-    own reproducibility floor (see CONVERGED_RMSE_ATOL), inlier mask at the converged point identical."""
+    """North-star parity at the one point where it is decidable: the reference's second BA (main.py:59) run with max_iter=200
+    (status 3 on the four small scenes; the well-posed calibration scene uses all 200 evaluations, status 0).  The reference's
+    algorithm on the GPU -- TRF + LSMR + grouped forward differences over the reference's matrix -- from the reference's
+    start.  Compared with the reference's result: same status, the ANSWER ITSELF (res.x is all the caller reads,
+    common.py:672-695) in gauge-invariant terms -- trajectory at the detection time stamps and camera centres / orientations
+    after the best similarity, beta differences, alpha ratios, rs, and K, d with opt_calib (tests/gauge.py) -- and the final
+    RMSE, each within SPREAD_FACTOR x the reference's own reproducibility; inlier mask at that point identical."""
     scene, g = filtered_case(name)
     prob, _ = mp.problem_from_scene(scene)
     oprob, _ = orc.problem_from_scene(scene)
     with BAHandle(prob) as h:
         r = h.solve(g['ba2_200_x0'], solver=_lib.SOLVER_TRF_LSMR, jac_mode=_lib.JAC_FD, max_nfev=200, matrix=golden_matrix(g, second=True))
         keep = h.outlier_mask(r.x, float(g['thres_outlier']))
-    d_rmse = orc.reprojection_rmse(oprob, r.x) - float(g['ba2_200_rmse'])
-    print('converged FD %s: rmse %+.2e px, cost %.9g vs %.9g, nfev %d vs %d, status %d' % (name, d_rmse, r.cost, float(g['ba2_200_cost']), r.nfev, int(g['ba2_200_nfev']), r.status))
-    assert r.status == int(g['ba2_200_status']) == 3
+    spread = reference_spread(oprob, name, g['ba2_200_x'])
+    c = gauge.compare(oprob, g['ba2_200_x'], r.x)
+    d_rmse = c['rmse_b'] - float(g['ba2_200_rmse'])
+    print('converged FD %s: rmse %+.2e px (spread %.1e), cost %.9g vs %.9g, nfev %d vs %d, status %d; x vs reference / spread: %s'
+          % (name, d_rmse, spread['rmse'], r.cost, float(g['ba2_200_cost']), r.nfev, int(g['ba2_200_nfev']), r.status,
+             ' '.join('%s %.1e/%.1e' % (k, c[k], spread[k]) for k in spread if k != 'rmse')))
+    assert r.status == int(g['ba2_200_status'])
     assert abs(r.nfev - int(g['ba2_200_nfev'])) <= 6
-    # Measured on MI355X (deterministic J^T u): +4.7e-5 (c1), -7.8e-4 (rs_F), -3.3e-2 (calib+KE+bounds), -1.4e-4 (dist) px; with
-    # round 1's atomic J^T u six runs gave -3.4e-4..+3.9e-4, -8.2e-4..-3.3e-4, -3.9e-2..-3.8e-3, -1.6e-4..+1.7e-5.  The host
-    # build of the same solver lands 1.5e-4 / 1.0e-4 / 4.4e-3 / 5.5e-6 away and scipy's own least_squares on this repo's
-    # residual 1e-5 / 1e-6 / 2e-2 / 6e-5 (tests/test_fd_mode_host.py): it is not the residual arithmetic that separates the
-    # runs but the summation order inside LSMR's J v / J^T u / norms (scipy: sequential CSR loops and OpenBLAS ddot; here:
-    # reduction trees), which LSMR amplifies ~10x per 1-2 iterations -- every change of that order re-rolls the last digits.
-    assert abs(d_rmse) < GPU_CONVERGED_RMSE_ATOL[name]
+    assert abs(c['rmse_a'] - float(g['ba2_200_rmse'])) < 1e-9                    # the oracle reproduces the reference's own figure
+    assert abs(d_rmse) <= SPREAD_FACTOR * spread['rmse']
+    for k in spread:
+        if k != 'rmse':
+            assert c[k] <= SPREAD_FACTOR * spread[k] + 1e-12, (k, c[k], spread[k])
     assert np.array_equal(keep.astype(np.uint8), g['ba2_200_keep'])
 
 
-@pytest.mark.parametrize('name', CASES)
+# LM + Schur (the fast solver, settings['ba_solver'] = 'lm') is ANOTHER estimator of the same scene: it minimises the same
+# objective with the exact Jacobian and reaches a lower value than the reference's stopping point, so its x is not the
+# reference's x.  What can be stated -- and is, here -- is how far apart the two are next to how far each is from the truth the
+# synthetic scene was generated from (two estimates of one truth differ by about their errors).  Bounds = measured on MI355X x 1.5
+# (trajectory RMS in metres after similarity alignment, at the detection time stamps; scene extent ~20 m):
+#                         LM vs reference   reference vs truth   LM vs truth
+#   c1_pinhole_2cam            0.20              0.23               0.13
+#   rs_F_2int_3cam             0.030             0.058              0.076
+#   dist_fixed_2cam            0.16              0.12               0.15
+#   calib_KE_wellposed_5cam    0.0055            0.0059             0.0051      K within 4.5e-3 relative, d within 0.043 of the reference's
+# calib_KE_bounds_3cam is ill posed (the distortion coefficients are unobservable: the reference's own first BA takes k1 from
+# -0.03 to 27.7 and its converged K, d do not reproduce): no exact-Jacobian solver has a meaningful answer there, LM's k3 reaches
+# 3e4.  Scene.BA therefore never picks LM by itself (test_scene_default_is_the_reference_algorithm).
+LM_TRAJ_RMS_VS_REF = {'c1_pinhole_2cam': 0.30, 'rs_F_2int_3cam': 0.045, 'dist_fixed_2cam': 0.24, CALIB_WP: 0.0085}
+LM_TRAJ_RMS_VS_TRUTH_FACTOR = 1.5          # LM's distance to the truth <= this x the reference's distance to the truth
+
+
+@pytest.mark.parametrize('name', CONVERGED_CASES)
 @pytest.mark.parametrize('mode', ['trf_pattern', 'lm_schur'])
 def test_converged_second_ba_analytic_modes(BAHandle, name, mode):
     """The analytic-Jacobian solvers from the same start: they do not stop where the reference's trust region collapses
     (its Jacobian lumps the dropped control point into the kept ones) but go on to a LOWER value of the same objective.
-    Two-sided statement: the cost is below the reference's by the measured margin, the oracle confirms the value, and the
-    inlier mask at the end is compared with the reference's."""
+    Asserted: the oracle confirms the objective value; the cost is not above the reference's; the inlier mask at the end;
+    and for LM the recovered solution itself against the reference's AND against ground truth (table above), the damping
+    floor keeping it out of the directions the data does not determine (without it: 3.9 m on c1)."""
     scene, g = filtered_case(name)
     prob, _ = mp.problem_from_scene(scene)
     oprob, _ = orc.problem_from_scene(scene)
@@ -405,13 +434,25 @@ def test_converged_second_ba_analytic_modes(BAHandle, name, mode):
     assert abs(0.5 * float(fo @ fo) - r.cost) < 1e-9 * r.cost
     rmse = orc.reprojection_rmse(oprob, r.x)
     flips = int(np.sum(keep.astype(np.uint8) != g['ba2_200_keep']))
-    print('converged %s %s: cost %.9g vs ref %.9g (%.2f %%), rmse %.6f vs %.6f, nfev %d status %d, %d mask flips'
-          % (mode, name, r.cost, ref_cost, 100 * (r.cost / ref_cost - 1), rmse, ref_rmse, r.nfev, r.status, flips))
+    c = gauge.compare(oprob, g['ba2_200_x'], r.x)
+    xt = ground_truth_x(oprob, name)
+    ct_ref, ct = gauge.compare(oprob, xt, g['ba2_200_x']), gauge.compare(oprob, xt, r.x)
+    print('converged %s %s: cost %.9g vs ref %.9g (%.2f %%), rmse %.6f vs %.6f, nfev %d status %d, %d mask flips; trajectory rms: vs ref %.2e, '
+          'ref vs truth %.2e, this vs truth %.2e; centres vs truth %.2e (ref %.2e)'
+          % (mode, name, r.cost, ref_cost, 100 * (r.cost / ref_cost - 1), rmse, ref_rmse, r.nfev, r.status, flips, c['traj_rms'],
+             ct_ref['traj_rms'], ct['traj_rms'], ct['centre_max'], ct_ref['centre_max']))
     assert r.cost <= ref_cost * (1 + 1e-6)
-    # measured on the host build (cost vs reference): -2.1/-2.8 % c1, -14/-6 % rs_F, -49/-76 % calib_KE, -0.9/-1.8 % dist
+    # measured (cost vs reference): -2.1/-2.5 % c1, -14/-7.5 % rs_F, -43/-76 % calib_KE_bounds, -0.9/-0.8 % dist, -0.1/-1.1 % calib_KE_wellposed
     if not prob.motion_reg:
         assert rmse <= ref_rmse + 1e-4           # without a regulariser in the objective lower cost IS lower reprojection error
     assert flips <= 3
+    if mode == 'lm_schur' and name in LM_TRAJ_RMS_VS_REF:
+        assert c['traj_rms'] <= LM_TRAJ_RMS_VS_REF[name]
+        assert ct['traj_rms'] <= LM_TRAJ_RMS_VS_TRUTH_FACTOR * ct_ref['traj_rms']
+        assert np.all(np.isfinite(r.x))
+        if prob.opt_calib:                       # K, d stay physical and near the reference's (well-posed scene)
+            assert c['K_rel_max'] <= 1e-2 and c['d_max'] <= 0.1, (c['K_rel_max'], c['d_max'])
+            assert ct['K_rel_max'] <= 1e-2 and ct['d_max'] <= 0.15, (ct['K_rel_max'], ct['d_max'])
 
 
 @pytest.mark.parametrize('name', CASES)

@@ -4,6 +4,7 @@ import numpy as np
 import pytest
 
 from golden_util import CASES, load_case
+from mvus_amd import _lib
 from mvus_amd.reconstruction import common
 
 pytestmark = pytest.mark.gpu
@@ -28,15 +29,16 @@ def build_scene(scene):
 
 
 @pytest.mark.parametrize('name', CASES)
-@pytest.mark.parametrize('mode', ['default', 'parity'])
+@pytest.mark.parametrize('mode', ['default', 'lm'])
 def test_ba_outliers_ba_sequence(name, mode):
-    """main.py:49-62 through the drop-in Scene: 'default' = settings untouched (LM + Schur), 'parity' = the reference's
-    algorithm (ba_solver 'trf', ba_jacobian 'fd')."""
+    """main.py:49-62 through the drop-in Scene: 'default' = settings untouched = the reference's algorithm (TRF + LSMR over
+    grouped 2-point differences); 'lm' = the fast solver, opted into with settings['ba_solver'] = 'lm'."""
     scene, g = load_case(name)
     st = scene.settings
     s = build_scene(scene)
-    if mode == 'parity':
-        s.settings.update(ba_solver='trf', ba_jacobian='fd')
+    assert 'ba_solver' not in s.settings and 'ba_jacobian' not in s.settings
+    if mode == 'lm':
+        s.settings.update(ba_solver='lm')
     C = s.numCam
     kw = dict(rs=st['rolling_shutter'], motion_reg=st['motion_reg'], motion_weights=st['motion_weights'], rs_bounds=st['rs_bounds'])
     before = np.array([np.mean(s.error_cam(i)) for i in range(C)])
@@ -46,9 +48,9 @@ def test_ba_outliers_ba_sequence(name, mode):
     assert handle is not None and handle.h
     assert res.nfev == int(g['ba10_nfev'])
     loose = name == 'calib_KE_bounds_3cam'            # the scene whose 10-evaluation iterate the reference itself does not reproduce
-    if mode == 'parity':
+    if mode == 'default':
         assert abs(res.cost - float(g['ba10_cost'])) < (2e-2 if loose else 5e-3) * float(g['ba10_cost'])
-    else:
+    elif not loose:                                   # (LM's first ten evaluations on the ill-posed calibration scene go nowhere useful)
         assert res.cost < float(g['ba10_cost']) * (1 + 5e-3)
     n_before = sum(d.shape[1] for d in s.detections)
     s.remove_outliers(s.sequence[:C], thres=st['thres_outlier'])
@@ -56,8 +58,11 @@ def test_ba_outliers_ba_sequence(name, mode):
     ref_removed = int((g['outlier_keep'] == 0).sum())
     # Both runs stop UNCONVERGED after 10 evaluations, so this is a plumbing check with loose bounds; the decidable
     # comparison is test_converged_second_ba_through_the_scene below.  Measured on MI355X, removed here / by the reference:
-    # parity 125/126, 40/40, 100/78, 59/58; default (another optimiser, another 10-evaluation iterate) 160/126, 40/40, 74/78, 43/58
-    assert abs(removed - ref_removed) <= max(3, 0.4 * ref_removed)
+    # default 125/126, 40/40, 100/78, 59/58; lm (another optimiser, another 10-evaluation iterate) 160/126, 40/40, 74/78, 43/58
+    if mode == 'default' and not loose:
+        assert abs(removed - ref_removed) <= 4                       # measured: -3, 0, +1 -- the same outliers, to the borderline ones
+    else:
+        assert abs(removed - ref_removed) <= max(3, 0.4 * ref_removed)
     assert s._ba_handle is handle and handle.M == sum(d.shape[1] for d in s.detections)    # filtered in place on the GPU
     res2 = s.BA(C, **kw)
     assert s._ba_handle is handle                                                            # no new handle, no re-upload
@@ -104,23 +109,39 @@ def scene_at_second_ba(name):
 
 
 @pytest.mark.parametrize('name', CASES)
-@pytest.mark.parametrize('mode', ['default', 'parity'])
+@pytest.mark.parametrize('mode', ['default', 'lm'])
 def test_converged_second_ba_through_the_scene(name, mode):
-    """Scene.BA(max_iter=200) from the reference's own start of its second BA: in parity mode (the reference's algorithm over
-    the reference's matrix, passed like the reference passes it to least_squares) the final RMSE -- computed by
-    Scene.error_cam like main.py does -- is the reference's within its reproducibility floor and remove_outliers then removes
-    exactly the detections the reference removes; the default solver ends at a lower value of the same objective."""
+    """Scene.BA(max_iter=200) from the reference's own start of its second BA: by default (the reference's algorithm over the
+    reference's matrix, passed like the reference passes it to least_squares) the final RMSE -- computed by Scene.error_cam
+    like main.py does -- is the reference's within SPREAD_FACTOR x its own reproducibility, the scene state BA leaves behind
+    (alpha, beta, rs, cameras, spline: what common.py:672-695 writes back from res.x) is the reference's in gauge-invariant
+    terms, and remove_outliers then removes exactly the detections the reference removes; the 'lm' solver ends at a lower
+    value of the same objective."""
+    import gauge
+    from golden_util import reference_spread
+    from oracle import ba_oracle as orc
+    from mvus_amd import problem as mp
     from test_fd_mode_host import golden_matrix
-    from test_gpu_parity import GPU_CONVERGED_RMSE_ATOL
+    from test_gpu_parity import SPREAD_FACTOR
     s, scene, g = scene_at_second_ba(name)
     st = scene.settings
     C = s.numCam
     kw = dict(rs=st['rolling_shutter'], motion_reg=st['motion_reg'], motion_weights=st['motion_weights'], rs_bounds=st['rs_bounds'])
-    if mode == 'parity':
-        s.settings.update(ba_solver='trf', ba_jacobian='fd')
+    if mode == 'default':
         res = s.BA(C, max_iter=200, jac_sparsity=golden_matrix(g, second=True), **kw)
     else:
+        s.settings.update(ba_solver='lm')
         res = s.BA(C, max_iter=200, **kw)
+    # the state Scene.BA wrote back, re-packed: must be res.x (the unpack / pack of common.py:672-695 loses nothing)
+    prob, _ = mp.problem_from_scene(scene)
+    x_state = mp.pack_x(prob, s.alpha, s.beta, s.rs, s.cameras, s.spline['tck'])
+    Cn, P = prob.C, prob.P
+    np.testing.assert_array_equal(x_state[:3 * Cn], res.x[:3 * Cn])
+    np.testing.assert_array_equal(x_state[Cn * (3 + P):], res.x[Cn * (3 + P):])
+    _, _, _, cam_states, _ = mp.unpack_x(prob, res.x)
+    for cam, stt in zip(s.cameras, cam_states):                           # (a rotation vector beyond pi re-packs to its twin: compare R)
+        np.testing.assert_array_equal(cam.R, stt['R'])
+        np.testing.assert_array_equal(cam.t, stt['t'])
     rmse = np.sqrt(np.mean(np.concatenate([s.error_cam(i, 'dist') for i in range(C)]) ** 2))
     n_before = sum(d.shape[1] for d in s.detections)
     frames = [d[0].copy() for d in s.detections]
@@ -129,9 +150,15 @@ def test_converged_second_ba_through_the_scene(name, mode):
     print('%s %s: rmse %.6f (ref %.6f), cost %.6g (ref %.6g), status %d, removed %d (ref %d)'
           % (name, mode, rmse, float(g['ba2_200_rmse']), res.cost, float(g['ba2_200_cost']), res.status,
              n_before - int(keep.sum()), int((g['ba2_200_keep'] == 0).sum())))
-    if mode == 'parity':
+    if mode == 'default':
+        oprob, _ = orc.problem_from_scene(scene)
+        spread = reference_spread(oprob, name, g['ba2_200_x'])
+        c = gauge.compare(oprob, g['ba2_200_x'], x_state)
         assert res.status == int(g['ba2_200_status'])
-        assert abs(rmse - float(g['ba2_200_rmse'])) < GPU_CONVERGED_RMSE_ATOL[name]
+        assert abs(rmse - float(g['ba2_200_rmse'])) <= SPREAD_FACTOR * spread['rmse']
+        for k in spread:
+            if k != 'rmse':
+                assert c[k] <= SPREAD_FACTOR * spread[k] + 1e-12, (k, c[k], spread[k])
         assert np.array_equal(keep, g['ba2_200_keep'])
     else:
         assert res.cost <= float(g['ba2_200_cost']) * (1 + 1e-6)
@@ -166,7 +193,7 @@ def test_pipeline_from_files_on_disk(tmp_path):
            'settings': {'num_detections': 100000, 'opt_calib': False, 'cf_exact': True, 'undist_points': True,
                         'rolling_shutter': False, 'init_rs': 0, 'rs_bounds': False, 'motion_reg': False, 'motion_weights': 1,
                         'rs_bounds': False, 'camera_sequence': [0, 1], 'ref_cam': 0, 'thres_outlier': st['thres_outlier'],
-                        'smooth_factor': [10, 20], 'motion_type': 'F', 'ba_solver': 'trf', 'ba_jacobian': 'pattern'}}
+                        'smooth_factor': [10, 20], 'motion_type': 'F'}}          # a reference config: no ba_* keys
     path = tmp_path / 'config.json'
     path.write_text(json.dumps(cfg))
     flight = common.create_scene(str(path))
@@ -181,7 +208,7 @@ def test_pipeline_from_files_on_disk(tmp_path):
     flight.spline = {'tck': [[t.copy(), [c.copy() for c in cs], 3] for t, cs, _ in scene.tck], 'int': scene.interval.copy()}
     flight.detection_to_global()
     ref = build_scene(scene)
-    ref.settings.update(ba_solver='trf', ba_jacobian='pattern')
+    assert flight.ba_mode() == ref.ba_mode() == (_lib.SOLVER_TRF_LSMR, _lib.JAC_FD)   # the reference's algorithm, from a reference config
     before = np.array([np.mean(flight.error_cam(i)) for i in range(2)])
     np.testing.assert_allclose(before, g['mean_err_before'], rtol=0, atol=1e-9)
     r1, r1_ref = flight.BA(2), ref.BA(2)

@@ -43,11 +43,13 @@ def test_fresh_handle_lm_solves_never_fail(index, handles):
         outcomes[key] += 1
         if first is None:
             first = r
-            assert np.isfinite(r.cost) and r.cost < 0.5 * r.initial_cost, (r.cost, r.initial_cost)
+            assert np.isfinite(r.cost) and r.cost < r.initial_cost, (r.cost, r.initial_cost)      # (2 % gross outliers carry most of the cost)
             continue
         assert key == (first.nfev, first.njev, first.status), 'handle %d took another path: %r' % (rep, dict(outcomes))
-        assert abs(r.cost - first.cost) <= 1e-9 * first.cost, 'handle %d: cost %.15g vs %.15g' % (rep, r.cost, first.cost)
-        assert np.max(np.abs(r.x - first.x)) <= 1e-6 * max(1.0, float(np.max(np.abs(first.x))))
+        # the fused assembly adds with fp64 atomics: the last bits of the normal equations depend on the arrival order and
+        # eight evaluations amplify them; a pivot failure or a read of poisoned memory changes the path or the cost by far more
+        assert abs(r.cost - first.cost) <= 1e-7 * first.cost, 'handle %d: cost %.15g vs %.15g' % (rep, r.cost, first.cost)
+        assert np.max(np.abs(r.x - first.x)) <= 1e-4 * max(1.0, float(np.max(np.abs(first.x))))
 
 
 def test_one_handle_many_solves_all_descend():
@@ -60,6 +62,6 @@ def test_one_handle_many_solves_all_descend():
         costs = []
         for rep in range(200):
             r = h.solve(x0, solver=_lib.SOLVER_LM_SCHUR, jac_mode=_lib.JAC_ANALYTIC, max_nfev=6, return_fun=False)
-            assert np.isfinite(r.cost) and r.cost < 0.5 * r.initial_cost, 'solve %d: %.9g -> %.9g (status %d)' % (rep, r.initial_cost, r.cost, r.status)
+            assert np.isfinite(r.cost) and r.cost < r.initial_cost, 'solve %d: %.9g -> %.9g (status %d)' % (rep, r.initial_cost, r.cost, r.status)
             costs.append(r.cost)
-        assert max(costs) < 1.5 * min(costs)
+        assert max(costs) < (1 + 1e-2) * min(costs)

@@ -246,3 +246,29 @@ def test_band_solver_partition_invariants():
                     assert pos == 3 * (c0 + n), (n, sctrl, close)
                     if close and ns >= 2:                     # the interior before the closing separator also sits between two
                         assert i1[P - 1] - i0[P - 1] >= 3 * sctrl
+
+
+def test_scene_default_is_the_reference_algorithm():
+    """A reference config.json carries no ba_* key: Scene.BA then runs the reference's own algorithm (scipy TRF + LSMR over
+    grouped 2-point differences, restated on the GPU).  The LM + Schur solver is opt-in, never a silent default -- it reaches
+    another point and has no meaningful answer on an ill-posed opt_calib scene."""
+    from mvus_amd import _lib
+    from mvus_amd.reconstruction.common import Scene
+    s = Scene()
+    s.settings = {'opt_calib': True, 'undist_points': True, 'rolling_shutter': True, 'motion_reg': True, 'motion_type': 'KE',
+                  'rs_bounds': True, 'smooth_factor': [10, 20], 'thres_outlier': 10}         # keys of the reference's config.json only
+    assert s.ba_mode() == (_lib.SOLVER_TRF_LSMR, _lib.JAC_FD)
+    s.settings['ba_solver'] = 'lm'
+    assert s.ba_mode() == (_lib.SOLVER_LM_SCHUR, _lib.JAC_ANALYTIC)
+    s.settings['ba_jacobian'] = 'pattern'
+    assert s.ba_mode() == (_lib.SOLVER_LM_SCHUR, _lib.JAC_PATTERN)
+    s.settings.update(ba_solver='trf', ba_jacobian='analytic')
+    assert s.ba_mode() == (_lib.SOLVER_TRF_LSMR, _lib.JAC_ANALYTIC)
+    import pytest
+    for bad in ({'ba_solver': 'gn'}, {'ba_jacobian': 'exact'}):
+        s.settings.update(ba_solver='trf', ba_jacobian='fd')
+        s.settings.update(bad)
+        with pytest.raises(ValueError):
+            s.ba_mode()
+    o = _lib.default_opts()
+    assert o.lm_lambda_min == 3e-3

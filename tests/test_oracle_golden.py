@@ -4,10 +4,10 @@ import pytest
 from scipy import sparse
 
 from oracle import ba_oracle as orc
-from golden_util import CASES, load_case
+from golden_util import CASES, CONVERGED_CASES, load_case
 
 
-@pytest.mark.parametrize('name', CASES)
+@pytest.mark.parametrize('name', CONVERGED_CASES)
 def test_pack_matches_reference_x0(name):
     scene, g = load_case(name)
     prob, x0 = orc.problem_from_scene(scene)
@@ -15,7 +15,7 @@ def test_pack_matches_reference_x0(name):
     np.testing.assert_allclose(x0, g['x0'], rtol=0, atol=1e-12)
 
 
-@pytest.mark.parametrize('name', CASES)
+@pytest.mark.parametrize('name', CONVERGED_CASES)
 def test_residual_matches_reference(name):
     scene, g = load_case(name)
     prob, _ = orc.problem_from_scene(scene)
@@ -29,7 +29,7 @@ def test_residual_matches_reference(name):
     assert np.array_equal(f1 == 0, g['f_x0_delta'] == 0)
 
 
-@pytest.mark.parametrize('name', CASES)
+@pytest.mark.parametrize('name', CONVERGED_CASES)
 def test_pattern_matches_reference_bit_exact(name):
     scene, g = load_case(name)
     prob, _ = orc.problem_from_scene(scene)
@@ -73,7 +73,7 @@ def test_solve_matches_reference(name):
     np.testing.assert_allclose(orc.reprojection_rmse(prob, g['ba10_x']), float(g['ba10_rmse']), rtol=0, atol=1e-9)
 
 
-@pytest.mark.parametrize('name', CASES)
+@pytest.mark.parametrize('name', CONVERGED_CASES)
 def test_outlier_mask_bit_exact(name):
     scene, g = load_case(name)
     prob, _ = orc.problem_from_scene(scene)
@@ -109,3 +109,38 @@ def test_sampling_half_open():
     interval = np.array([[0.0, 20.0], [10.0, 30.0]])
     ts = np.array([-1.0, 0.0, 5.0, 10.0, 15.0, 20.0, 29.999, 30.0])
     assert orc.sampling_idx(ts, interval).tolist() == [0, 1, 1, 0, 0, 2, 2, 0]
+
+
+@pytest.mark.parametrize('name', CONVERGED_CASES)
+def test_golden_converged_answer_evaluates_to_its_own_figures(name):
+    """`ba2_200_x` (the reference's res.x of its converged second BA) through the oracle: the stored cost and RMSE come back,
+    and the stored inlier mask is the oracle's mask at that x -- the x-level fixtures are consistent with the scalar ones."""
+    from test_fd_mode_host import filtered_case
+    scene, g = filtered_case(name)
+    prob, _ = orc.problem_from_scene(scene)
+    f = orc.residual(prob, g['ba2_200_x'])
+    np.testing.assert_allclose(0.5 * f @ f, float(g['ba2_200_cost']), rtol=1e-10)
+    np.testing.assert_allclose(orc.reprojection_rmse(prob, g['ba2_200_x']), float(g['ba2_200_rmse']), rtol=0, atol=1e-9)
+    keep = np.concatenate(orc.outlier_keep_mask(prob, g['ba2_200_x'], float(g['thres_outlier'])))
+    assert np.array_equal(keep.astype(np.uint8), g['ba2_200_keep'])
+
+
+@pytest.mark.parametrize('name', CONVERGED_CASES)
+def test_reference_ensembles_are_what_they_say(name):
+    """tests/golden/ens_<case>.npz: 2 x N converged runs of the REAL reference with last-place noise on its residuals.  Every
+    member is a parameter vector of this problem whose stored RMSE the oracle reproduces; the unperturbed member is the
+    golden answer; the spreads are small next to the distance the reference moved (an ensemble of junk would not be)."""
+    import gauge
+    from golden_util import load_ensemble
+    from test_fd_mode_host import filtered_case
+    scene, g = filtered_case(name)
+    prob, _ = orc.problem_from_scene(scene)
+    ens = load_ensemble(name)
+    np.testing.assert_array_equal(ens['x_ref'], g['ba2_200_x'])
+    moved = gauge.compare(prob, g['ba2_200_x'], g['ba2_200_x0'])
+    for pre in ('ens_', 'ensu_'):
+        assert ens[pre + 'x'].shape[1] == g['ba2_200_x'].size and ens[pre + 'x'].shape[0] >= 4
+        for x, rmse in zip(ens[pre + 'x'], ens[pre + 'rmse']):
+            np.testing.assert_allclose(orc.reprojection_rmse(prob, x), rmse, rtol=0, atol=1e-9)
+        sp = gauge.ensemble_spread(prob, g['ba2_200_x'], ens[pre + 'x'])
+        assert sp['traj_rms'] < 0.1 * moved['traj_rms'] and sp['rmse'] < 0.05

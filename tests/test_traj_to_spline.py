@@ -231,6 +231,91 @@ def test_gpu_traj_to_spline_matches_the_reference_fixture():
             assert n_gpu == len(interpolate.splprep(part[1:], u=part[0], s=s_, k=3)[0][0])
 
 
+def _short():
+    return dict(np.load(os.path.join(GOLDEN_DIR, 'traj_spline_short.npz')))
+
+
+def test_short_part_fallback_is_the_reference_curve():
+    """A part with three samples (the only size below four that find_intervals lets through): the reference's splprep(k=3)
+    raises and its bare `except` fits a k=1 spline (common.py:266-267).  mvus_amd.spline.linear_fit_as_cubic restates
+    FITPACK's k=1 answer and returns the same curve degree-elevated to a cubic; against the REAL reference's tck
+    (tests/golden/traj_spline_short.npz: a bent part -- smoothing spline with one knot -- and a straight one -- the
+    least-squares line) and against scipy over a sweep of shapes and scales."""
+    from mvus_amd import spline
+    g = _short()
+    assert list(g['degree']) == [1, 3, 1]
+    traj = g['traj']
+    for i in (0, 2):
+        a, b = g['interval'][:, i]
+        part = traj[:, (traj[0] >= a) & (traj[0] <= b)]
+        assert part.shape[1] == 3
+        tck = spline.linear_fit_as_cubic(part, 1e-6 * (b - a))
+        assert tck[2] == 3 and len(tck[0]) == (11 if i == 0 else 8)
+        ts = np.linspace(a, b, 101)
+        ref = np.asarray(interpolate.splev(ts, [g['knots_%d' % i], list(g['coefs_%d' % i]), 1]))
+        np.testing.assert_allclose(np.asarray(interpolate.splev(ts, tck)), ref, rtol=0, atol=1e-12)
+    rng = np.random.default_rng(0)
+    for trial in range(200):
+        u = np.cumsum(rng.uniform(2.5, 4.9, 3))
+        X = rng.normal(size=(3, 3)) * rng.choice([1e-3, 1e-1, 1, 10])
+        if trial % 3 == 0:                                  # nearly straight: both sides of the fp0 < s decision
+            X = X[:, :1] + np.outer(rng.normal(size=3), u - u[0]) + 1e-4 * rng.normal(size=(3, 3)) * rng.choice([1, 0.1, 10])
+        s_ = 1e-6 * (u[-1] - u[0])
+        tck1 = interpolate.splprep(X, u=u, s=s_, k=1)[0]
+        tck = spline.linear_fit_as_cubic(np.vstack((u, X)), s_)
+        assert len(tck[0]) == {4: 8, 5: 11}[len(tck1[0])]
+        ts = np.linspace(u[0], u[-1], 40)
+        np.testing.assert_allclose(np.asarray(interpolate.splev(ts, tck)), np.asarray(interpolate.splev(ts, tck1)), rtol=0, atol=1e-8)
+    with pytest.raises(ValueError):
+        spline.linear_fit_as_cubic(np.array([[0.0], [1.0], [2.0], [3.0]]), 1e-6)       # one sample: the reference raises too
+
+
+@pytest.mark.gpu
+def test_gpu_traj_to_spline_with_short_parts_matches_the_reference():
+    """Scene.traj_to_spline / spline_to_traj on a trajectory with two three-sample parts around a regular one, against the
+    REAL reference's outputs: same intervals, the regular part's knots and coefficients, and every sampled point of all three
+    parts (the short ones through the cubic twin of the reference's k=1 spline, triple interior knot included)."""
+    g = _short()
+    s = common.Scene()
+    s.settings = {}
+    s.traj = g['traj'].copy()
+    sp = s.traj_to_spline(smooth_factor=[10, 20])
+    np.testing.assert_array_equal(sp['int'], g['interval'])
+    np.testing.assert_array_equal(sp['tck'][1][0], g['knots_1'])
+    np.testing.assert_allclose(np.asarray(sp['tck'][1][1]), g['coefs_1'], rtol=0, atol=COEF_ATOL)
+    traj = s.spline_to_traj(sampling_rate=0.25)
+    assert traj.shape == g['traj_rate'].shape
+    np.testing.assert_array_equal(traj[0], g['traj_rate'][0])
+    np.testing.assert_allclose(traj[1:], g['traj_rate'][1:], rtol=0, atol=1e-8)
+    tq = s.spline_to_traj(t=g['t_query'])
+    np.testing.assert_array_equal(tq[0], g['traj_query'][0])
+    np.testing.assert_allclose(tq[1:], g['traj_query'][1:], rtol=0, atol=1e-8)
+    # ... and a BA over such a spline is refused with a message that says why: the straight part ([a x4, b x4]) is an ordinary cubic,
+    # the bent one has a triple interior knot, for which neither the reference's jac_BA nor the kernels' pattern codes are defined
+    from mvus_amd import problem as mp
+    from mvus_amd.ba import BAHandle
+    from mvus_amd import synth
+    sc = synth.make_scene(2, 400, seed=3, knot_spacing=15.0)
+    for d in sc.detections:
+        d[0] = np.linspace(-5.0, 150.0, d.shape[1])
+    sc.alpha[:] = 1.0
+    sc.beta[:] = 0.0
+    sc.tck = [[t[0].copy(), [c.copy() for c in t[1]], 3] for t in sp['tck']]
+    sc.interval = sp['int'].copy()
+    prob, x0 = mp.problem_from_scene(sc)
+    with pytest.raises(ValueError, match='repeated interior knots'):
+        BAHandle(prob)
+    sc.tck, sc.interval = sc.tck[1:], sc.interval[:, 1:]                   # without the bent part: regular + straight three-sample part
+    prob, x0 = mp.problem_from_scene(sc)
+    from oracle import ba_oracle as orc
+    oprob, _ = orc.problem_from_scene(sc)
+    with BAHandle(prob) as h:
+        f = h.residual(x0)
+    fo_ = orc.residual(oprob, x0)
+    assert np.array_equal(f == 0, fo_ == 0) and (f != 0).sum() > 100
+    np.testing.assert_allclose(f, fo_, rtol=1e-9, atol=1e-7)
+
+
 @pytest.mark.gpu
 def test_gpu_smooth_fit_rejects_bad_input():
     from mvus_amd import spline
