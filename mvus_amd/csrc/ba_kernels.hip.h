@@ -639,7 +639,7 @@ __device__ __forceinline__ void dot_partial_store(double s, double* __restrict__
 __global__ __launch_bounds__(kThreads) void k_lsmr_u(long long m, const double* __restrict__ tm, double* __restrict__ ut,
                                                      const LsmrScalars* __restrict__ cur, double* __restrict__ partials) {
   if (cur->istop != 0) return;
-  const double a = 1.0, b = -cur->alpha;
+  const double a = cur->one, b = -cur->alpha;
   double s = 0.0;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < m; i += (long long)gridDim.x * blockDim.x) {
     const double u = a * tm[i] + b * ut[i];
@@ -655,7 +655,7 @@ __global__ __launch_bounds__(kThreads) void k_lsmr_unorm(long long m, double* __
   const double beta = sqrt(dot_final_block(nb, partials));
   if (blockIdx.x == 0 && threadIdx.x == 0) *beta_out = beta;
   if (!(beta > 0)) return;
-  const double a = 1.0 / beta, b = 0.0;
+  const double a = 1.0 / beta, b = cur->zero;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < m; i += (long long)gridDim.x * blockDim.x)
     ut[i] = a * ut[i] + b * ut[i];
 }
@@ -665,7 +665,7 @@ __global__ __launch_bounds__(kThreads) void k_lsmr_v(long long n, const double* 
   if (cur->istop != 0) return;
   const double beta = *beta_in;
   if (!(beta > 0)) { if (threadIdx.x == 0) partials[blockIdx.x] = 0.0; return; }
-  const double a = 1.0, b = -beta;
+  const double a = cur->one, b = -beta;
   double s = 0.0;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
     const double w = a * tn[i] + b * v[i];
@@ -690,7 +690,7 @@ __global__ __launch_bounds__(kThreads) void k_lsmr_update(long long n, double* _
   detail::lsmr_rotations(s);
   if (blockIdx.x == 0 && threadIdx.x == 0) *nxt = s;
   const double inv = scale ? 1.0 / s.alpha : 1.0;
-  const double one = 1.0, zero = 0.0;
+  const double one = cur->one, zero = cur->zero;
   double acc = 0.0;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
     double vi = v[i];

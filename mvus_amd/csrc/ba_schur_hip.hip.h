@@ -1247,10 +1247,12 @@ __global__ __launch_bounds__(bcr_tail_waves(S3) * 64) void k_sep_bcr_tail(PartVi
     const long long p0_ = clock64();
 #endif
     for (int s = wave; s < nt; s += NW) bcr_survivor<S3>(pv, h, s, w + wave * 3 * S3 * S3, fail);
-    // The next level's agent-scope loads (bcr_ld) must see this level's plain stores of the OTHER wavefronts: release at the
-    // scope the loads use.  A workgroup-scope barrier alone need not wait for the stores to reach L2 (vmcnt) before it lets the
-    // other wavefronts go on.
-    __threadfence();
+    // The next level's loads (bcr_ld: agent scope, they bypass the CU's L1 and read L2) must see this level's plain stores of the
+    // OTHER wavefronts of this workgroup.  All of them run on one CU, hence behind one L2: what is needed is that the stores have
+    // ARRIVED there before anybody passes the barrier, i.e. that their acknowledgements are in (vmcnt = 0) -- a workgroup-scope
+    // barrier by itself does not wait for that.  (A full agent-scope release, __threadfence(), also writes the XCD's L2 back for the
+    // benefit of other XCDs -- `buffer_wbl2 sc1` -- which nothing here needs: measured +15 us per solve.)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 #ifdef MVUS_BCR_PROBE
     if (threadIdx.x == 0) printf("bcr tail h=%d ns=%d: %lld cycles\n", h, ns, clock64() - p0_);

@@ -279,6 +279,7 @@ struct LsmrScalars {
   double c_hbar = 0, c_x = 0, c_h = 0;       // hbar = h + c_hbar hbar ; x += c_x hbar ; h = v + c_h h
   long long itn = 0, maxiter = 0;
   int istop = 0, pad = 0;
+  double one = 1.0, zero = 0.0;               // read at run time by the device kernels: `a * x + b * y` with a = 1 must round like k_axpby's
 };
 namespace detail {
 MVUS_SOLVER_HD double hd_sgn(double a) { return (a > 0) - (a < 0); }

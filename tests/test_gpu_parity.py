@@ -16,8 +16,9 @@ RESIDUAL_ATOL = 1e-9        # px, fp64 residuals vs the reference's values
 # The converged second BA in the reference's own algorithm is held to SPREAD_FACTOR x what the REFERENCE reproduces of itself
 # when its residuals are perturbed in the last place (tests/golden/ens_*.npz: eight runs each with 1e-15 relative noise and
 # with noise of one ulp of the pixel coordinates; the larger of the two spreads per quantity).  Measured on MI355X, final
-# RMSE minus the reference's / spread: c1 -1.4e-4 / 4.3e-4, rs_F -8.1e-4 / 3.5e-4 (2.3x), calib_KE_bounds -3.1e-3 / 2.5e-2,
-# dist -1.4e-4 / 1.1e-4 (1.3x), calib_KE_wellposed -2.4e-5; gauge-invariant distances of x: <= 2.7x (rs_F), else <= 1x.
+# RMSE minus the reference's / spread: c1 -1.4e-4 / 7.0e-4, rs_F -8.1e-4 / 3.5e-4 (2.3x), calib_KE_bounds -3.1e-3 / 4.3e-2,
+# dist -1.4e-4 / 1.1e-4 (1.3x), calib_KE_wellposed -2.4e-5 / 6.2e-4; gauge-invariant distances of x: <= 2.8x (rs_F), else <= 1x.
+# (24 ensemble members per noise model on the four small scenes, 4 on the well-posed calibration scene: ~20 min per run there.)
 SPREAD_FACTOR = 3.0
 JAC_RTOL = 1e-10            # GPU vs host build of the same analytic formulas (relative to column scale)
 
@@ -399,16 +400,17 @@ def test_converged_second_ba_fd_mode(BAHandle, name):
 # objective with the exact Jacobian and reaches a lower value than the reference's stopping point, so its x is not the
 # reference's x.  What can be stated -- and is, here -- is how far apart the two are next to how far each is from the truth the
 # synthetic scene was generated from (two estimates of one truth differ by about their errors).  Bounds = measured on MI355X x 1.5
-# (trajectory RMS in metres after similarity alignment, at the detection time stamps; scene extent ~20 m):
+# (trajectory RMS in metres after similarity alignment, at the detection time stamps; scene extent ~20 m; 200 evaluations,
+# damping floor 3e-3):
 #                         LM vs reference   reference vs truth   LM vs truth
-#   c1_pinhole_2cam            0.20              0.23               0.13
-#   rs_F_2int_3cam             0.030             0.058              0.076
-#   dist_fixed_2cam            0.16              0.12               0.15
-#   calib_KE_wellposed_5cam    0.0055            0.0059             0.0051      K within 4.5e-3 relative, d within 0.043 of the reference's
+#   c1_pinhole_2cam            0.33              0.23               0.20        (without the damping floor: 3.9 / 3.8)
+#   rs_F_2int_3cam             0.032             0.058              0.079
+#   dist_fixed_2cam            0.10              0.12               0.095
+#   calib_KE_wellposed_5cam    0.0080            0.0059             0.0078      K within 9.1e-3 relative, d within 0.059 of the reference's
 # calib_KE_bounds_3cam is ill posed (the distortion coefficients are unobservable: the reference's own first BA takes k1 from
 # -0.03 to 27.7 and its converged K, d do not reproduce): no exact-Jacobian solver has a meaningful answer there, LM's k3 reaches
-# 3e4.  Scene.BA therefore never picks LM by itself (test_scene_default_is_the_reference_algorithm).
-LM_TRAJ_RMS_VS_REF = {'c1_pinhole_2cam': 0.30, 'rs_F_2int_3cam': 0.045, 'dist_fixed_2cam': 0.24, CALIB_WP: 0.0085}
+# 5e4.  Scene.BA therefore never picks LM by itself (tests/test_host_logic.py::test_scene_default_is_the_reference_algorithm).
+LM_TRAJ_RMS_VS_REF = {'c1_pinhole_2cam': 0.50, 'rs_F_2int_3cam': 0.048, 'dist_fixed_2cam': 0.15, CALIB_WP: 0.012}
 LM_TRAJ_RMS_VS_TRUTH_FACTOR = 1.5          # LM's distance to the truth <= this x the reference's distance to the truth
 
 
@@ -451,8 +453,8 @@ def test_converged_second_ba_analytic_modes(BAHandle, name, mode):
         assert ct['traj_rms'] <= LM_TRAJ_RMS_VS_TRUTH_FACTOR * ct_ref['traj_rms']
         assert np.all(np.isfinite(r.x))
         if prob.opt_calib:                       # K, d stay physical and near the reference's (well-posed scene)
-            assert c['K_rel_max'] <= 1e-2 and c['d_max'] <= 0.1, (c['K_rel_max'], c['d_max'])
-            assert ct['K_rel_max'] <= 1e-2 and ct['d_max'] <= 0.15, (ct['K_rel_max'], ct['d_max'])
+            assert c['K_rel_max'] <= 2e-2 and c['d_max'] <= 0.1, (c['K_rel_max'], c['d_max'])
+            assert ct['K_rel_max'] <= 2e-2 and ct['d_max'] <= 0.15, (ct['K_rel_max'], ct['d_max'])
 
 
 @pytest.mark.parametrize('name', CASES)
