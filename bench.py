@@ -45,9 +45,10 @@ def algorithmic_bytes(prob):
     return per_obs, once
 
 
-def cpu_baseline(config_index):
+def cpu_baseline(config_index, full_scene=None):
     """The reference's CPU path restated (oracle: numpy residual + scipy least_squares with the sparsity
-    pattern, exactly the call of common.py:670), single core, on a 1/32-scale sample of the workload."""
+    pattern, exactly the call of common.py:670), single core, on a 1/32-scale sample of the workload; plus -- the anchor for that
+    sample -- ONE evaluation of the oracle's residual (error_BA) on the full-size workload."""
     import numpy as np
     from mvus_amd import synth
     from oracle import ba_oracle as orc
@@ -65,11 +66,23 @@ def cpu_baseline(config_index):
         dt = time.perf_counter() - t0
     M = sum(d.shape[1] for d in oprob.detections)
     iters = max(res.nfev - 1, 1)
+    full = None
+    if full_scene is not None:
+        fprob, fx0 = orc.problem_from_scene(full_scene)
+        with threadpool_limits(limits=1):
+            orc.residual(fprob, fx0)                      # (first call: page faults, imports)
+            t1 = time.perf_counter()
+            orc.residual(fprob, fx0)
+            dtf = time.perf_counter() - t1
+        Mf = sum(d.shape[1] for d in fprob.detections)
+        full = {'value': Mf / dtf, 'unit': 'residuals/s', 'seconds_per_evaluation': dtf, 'obs': Mf,
+                'what': 'one evaluation of the oracle residual (error_BA restated, numpy, 1 core) on the FULL workload; a BA iteration of '
+                        'the reference costs (column groups + 1) such evaluations for its 2-point Jacobian plus the LSMR solve'}
     import numpy, scipy
     blas = [(d.get('internal_api'), d.get('version'), d.get('num_threads')) for d in __import__('threadpoolctl').threadpool_info()]
     return {'value': M * iters / dt, 'unit': 'residuals/s', 'cores': 1, 'kind': 'port',
             'ba_iters_per_s': iters / dt, 'os_cpu_count': os.cpu_count(), 'numpy': numpy.__version__, 'scipy': scipy.__version__,
-            'blas': blas, 'blas_threads_during_timing': 1,
+            'blas': blas, 'blas_threads_during_timing': 1, 'residual_only_full_size': full,
             'sample': '%d cams x %d obs (%d params), 1/%d-scale sample of the workload from the same generator; '
                       'oracle restatement of Scene.BA: scipy least_squares(jac_sparsity, lsmr, 2-point FD), '
                       '%d trial steps in %.1f s' % (oprob.C, M, x0.size, scale, iters, dt)}
@@ -84,6 +97,7 @@ def main():
     ap.add_argument('--solver', choices=['trf', 'lm'], default=os.environ.get('MVUS_BENCH_SOLVER', 'lm'))
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-parity-solver', action='store_true', help='skip the extra timing of the scipy-TRF+LSMR restatement')
+    ap.add_argument('--obs', type=int, default=None, help='override the detection count of the config (kernel studies at other sizes; the workload string says so)')
     ap.add_argument('--shard', choices=['time', 'obs'], default=None, help='N>1: how observations are cut over the ranks (default: time for lm, obs for trf)')
     args = ap.parse_args()
 
@@ -116,6 +130,8 @@ def main():
     from mvus_amd.dist import sharded_handle
 
     kw = dict(synth.BASELINE_CONFIGS[args.config])
+    if args.obs:
+        kw['total_obs'] = args.obs
     per_gpu_obs = kw['total_obs']
     # configs[3] IS a multi-GPU configuration (64 cams x 2M obs sharded over the node): the fixed problem is cut over the
     # ranks (strong scaling).  Every other config scales weakly: fixed observations per GPU, cameras and knots as configured.
@@ -201,9 +217,9 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
             'higher_is_better': True, 'scaling': 'strong' if strong else 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'ba_iters_per_sec': args.steps / dt,
-            'config': {'workload': 'BASELINE configs[%d]: %d cams x %d obs (%d per GPU), rolling shutter %s, %d spline '
-                                   'control points, %d params, %d residual rows; step = 1 trust-region trial '
-                                   '(residual+Jacobian, %s, trial residual)'
+            'config': {'workload': ('BASELINE configs[%d]' + (' RESIZED with --obs' if args.obs else '') + ': %d cams x %d obs (%d per GPU), rolling shutter %s, %d spline '
+                                    'control points, %d params, %d residual rows; step = 1 trust-region trial '
+                                    '(residual+Jacobian, %s, trial residual)')
                                    % (args.config, prob.C, M_total, handle.prob.M, 'on' if prob.rs_free else 'off',
                                       int(prob.n_coef.sum()), prob.n_params, prob.n_residuals,
                                       'LM normal equations + Schur solve' if args.solver == 'lm'
@@ -223,7 +239,7 @@ def main():
                            'fused_jacobian_normal_eq_assembly': t_fused},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(args.config)
+            out['cpu_baseline'] = cpu_baseline(args.config, scene)
         print(json.dumps(out))
     handle.close()
     if world > 1:

@@ -493,23 +493,25 @@ struct HipBackend {
   double *zc = nullptr, *zs = nullptr;
   int32_t *zg0 = nullptr, *zfill = nullptr;
   int* jt_nondet = nullptr;
-  void jtu_local(const double* u, double* z) {
+  // z_is_zero: the caller guarantees z == 0 on entry (the device-resident LSMR loop clears it while consuming it);
+  // reuse_index: zfill of the previous call is still valid (same Jacobian, hence the same window starts)
+  void jtu_local(const double* u, double* z, bool z_is_zero = false, bool reuse_index = false) {
     if (!zc) {
       const size_t nc = std::max<size_t>(hp.chunks.size(), 1);
       zc = dalloc<double>(nc * (size_t)(hp.NS - 12)); zs = dalloc<double>(nc * 3 * (size_t)kJtWin); zg0 = dalloc<int32_t>(nc); zfill = dalloc<int32_t>(nc);
       jt_nondet = dalloc<int>(1);
       MVUS_HIP(hipMemsetAsync(jt_nondet, 0, sizeof(int), stream));
     }
-    MVUS_HIP(hipMemsetAsync(z, 0, sizeof(double) * hp.n, stream));
+    if (!z_is_zero) MVUS_HIP(hipMemsetAsync(z, 0, sizeof(double) * hp.n, stream));
     const dim3 g2(hp.C + (hp.N + kThreads / 64 - 1) / (kThreads / 64)), b(kThreads);
     const int motion = hp.T > 0 ? 1 : 0;
     if (hp.calib) {
       if (dp.n_chunks > 0) hipLaunchKernelGGL(k_jtu_partial<30>, dim3(xcd_grid(dp.n_chunks)), b, 0, stream, dp, J, span, u, z, zc, zs, zg0, jt_nondet);
-      hipLaunchKernelGGL(k_jtu_index, dim3(hp.C), dim3(64), 0, stream, dp, zg0, zfill);
+      if (!reuse_index) hipLaunchKernelGGL(k_jtu_index, dim3(hp.C), dim3(64), 0, stream, dp, zg0, zfill);
       hipLaunchKernelGGL(k_jtu_reduce<30>, g2, b, 0, stream, dp, zc, zs, zg0, zfill, mJ, mctrl, u + 2 * hp.M, motion, z);
     } else {
       if (dp.n_chunks > 0) hipLaunchKernelGGL(k_jtu_partial<21>, dim3(xcd_grid(dp.n_chunks)), b, 0, stream, dp, J, span, u, z, zc, zs, zg0, jt_nondet);
-      hipLaunchKernelGGL(k_jtu_index, dim3(hp.C), dim3(64), 0, stream, dp, zg0, zfill);
+      if (!reuse_index) hipLaunchKernelGGL(k_jtu_index, dim3(hp.C), dim3(64), 0, stream, dp, zg0, zfill);
       hipLaunchKernelGGL(k_jtu_reduce<21>, g2, b, 0, stream, dp, zc, zs, zg0, zfill, mJ, mctrl, u + 2 * hp.M, motion, z);
     }
     MVUS_HIP(hipGetLastError());
@@ -536,6 +538,7 @@ struct HipBackend {
     int cur = 0;
     const int batch = 8;
     long long launched = 0;
+    MVUS_HIP(hipMemsetAsync(tn, 0, sizeof(double) * n, stream));        // J^T u adds into a zeroed vector; k_lsmr_v clears it again while reading it
     while (true) {
       for (int b = 0; b < batch && launched < sc.maxiter; ++b, ++launched) {
         const LsmrScalars* c = lsmr_state + cur;
@@ -543,7 +546,7 @@ struct HipBackend {
         jv(v, tm);
         hipLaunchKernelGGL(k_lsmr_u, dim3(gm), dim3(kThreads), 0, stream, m, tm, ut, c, pu);
         hipLaunchKernelGGL(k_lsmr_unorm, dim3(gm), dim3(kThreads), 0, stream, m, ut, gm, pu, c, beta_dev);
-        jtu_local(ut, tn);
+        jtu_local(ut, tn, true, launched > 0);
         hipLaunchKernelGGL(k_lsmr_v, dim3(gn), dim3(kThreads), 0, stream, n, tn, v, c, beta_dev, pv);
         hipLaunchKernelGGL(k_lsmr_update, dim3(gn), dim3(kThreads), 0, stream, n, v, h, hbar, x, gn, pv, c, beta_dev, nx, px);
         hipLaunchKernelGGL(k_lsmr_test, dim3(1), dim3(kThreads), 0, stream, gn, px, c, nx);

@@ -146,6 +146,9 @@ __device__ __forceinline__ int xcd_tile(int tiles) {
 #ifndef MVUS_JAC_WAVES
 #define MVUS_JAC_WAVES 4
 #endif
+#ifndef MVUS_JAC_WAVES_CALIB
+#define MVUS_JAC_WAVES_CALIB 3        // opt_calib (2 x 30 slots + the K, d tangents): at 4 wavefronts per SIMD (128 VGPRs) it spills 40 B per lane
+#endif
 #if !defined(MVUS_JAC_ARRAY) && !defined(MVUS_JAC_DIRECT)
 #define MVUS_JAC_DIRECT 1        // default: values go to memory as they are produced (98 VGPRs; the array form needs 128 + scratch)
 #endif
@@ -189,7 +192,7 @@ struct JStoreSink {
 };
 
 template <bool CALIB, bool JAC>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(JAC ? MVUS_JAC_WAVES : 4, 8))) void k_observations(DevProblem dp, const CamState* __restrict__ cams,
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(JAC ? (CALIB ? MVUS_JAC_WAVES_CALIB : MVUS_JAC_WAVES) : 4, 8))) void k_observations(DevProblem dp, const CamState* __restrict__ cams,
                                                            const double* __restrict__ x, double* __restrict__ f,
                                                            double* __restrict__ J, int32_t* __restrict__ span,
                                                            const int32_t* __restrict__ pat0, int masked) {
@@ -660,15 +663,20 @@ __global__ __launch_bounds__(kThreads) void k_lsmr_unorm(long long m, double* __
     ut[i] = a * ut[i] + b * ut[i];
 }
 // v = A^T u - beta v (A^T u is in tn), partial sums of v.v
-__global__ __launch_bounds__(kThreads) void k_lsmr_v(long long n, const double* __restrict__ tn, double* __restrict__ v,
+// (tn is cleared as it is consumed: the next J^T u adds into it without a memset of its own)
+__global__ __launch_bounds__(kThreads) void k_lsmr_v(long long n, double* __restrict__ tn, double* __restrict__ v,
                                                      const LsmrScalars* __restrict__ cur, const double* __restrict__ beta_in, double* __restrict__ partials) {
-  if (cur->istop != 0) return;
   const double beta = *beta_in;
-  if (!(beta > 0)) { if (threadIdx.x == 0) partials[blockIdx.x] = 0.0; return; }
+  if (cur->istop != 0 || !(beta > 0)) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) tn[i] = 0.0;
+    if (cur->istop == 0 && threadIdx.x == 0) partials[blockIdx.x] = 0.0;
+    return;
+  }
   const double a = cur->one, b = -beta;
   double s = 0.0;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
     const double w = a * tn[i] + b * v[i];
+    tn[i] = 0.0;
     v[i] = w;
     s += w * w;
   }

@@ -5,13 +5,15 @@
 # the program after `--` is python3 itself (no wrapper that re-execs).
 set -x
 export TMPDIR=/tmp
-R=${1:-r02}
+R=${1:-r03}
 O=gpurun_out/refresh; mkdir -p $O
 python bench.py --steps 20 --warmup 5 > $O/${R}_bench_config2_lm.json 2> $O/bench_config2_lm.err
 python bench.py --solver trf --steps 5 --warmup 1 --no-cpu-baseline --no-parity-solver > $O/${R}_bench_config2_trf.json 2>> $O/bench.err
 python bench.py --config 1 --no-cpu-baseline > $O/${R}_bench_config1_lm.json 2>> $O/bench.err
 python bench.py --config 4 --no-cpu-baseline > $O/${R}_bench_config4_calib_lm.json 2>> $O/bench.err
 python bench.py --config 3 --no-cpu-baseline --no-parity-solver > $O/${R}_bench_config3_one_gpu_lm.json 2>> $O/bench.err
+# the opt_calib residual+Jacobian kernel (524 B/obs) at a size where a launch is not latency: configs[4]'s 7 cameras with 2M detections (1 GiB per launch)
+python bench.py --config 4 --obs 2000000 --steps 3 --warmup 1 --no-cpu-baseline --no-parity-solver > $O/${R}_bench_config4_calib_2M_obs.json 2>> $O/bench.err
 rocprofv3 --kernel-trace --stats -d $O/stats_lm -o r -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-parity-solver > $O/stats_lm.log 2>&1
 python3 tools/rocprof_summary.py stats $O/stats_lm/r_results.db > $O/${R}_kernel_stats_config2_lm.txt
 rocprofv3 --kernel-trace --stats -d $O/stats_trf -o r -- python3 bench.py --solver trf --steps 5 --warmup 1 --no-cpu-baseline --no-parity-solver > $O/stats_trf.log 2>&1
@@ -22,6 +24,22 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_fetch -o r -- python3 bench.
 python3 tools/rocprof_summary.py pmc $O/pmc_fetch/r_results.db > $O/${R}_pmc_FETCH_SIZE_config2.txt
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pmc_write -o r -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-parity-solver > $O/pmc_write.log 2>&1
 python3 tools/rocprof_summary.py pmc $O/pmc_write/r_results.db > $O/${R}_pmc_WRITE_SIZE_config2.txt
-python3 tools/rocprof_summary.py traffic $O/${R}_pmc_FETCH_SIZE_config2.txt $O/${R}_pmc_WRITE_SIZE_config2.txt > $O/pmc_traffic.json
-rm -rf $O/stats_lm $O/stats_trf $O/stats_c3 $O/pmc_fetch $O/pmc_write
+python3 tools/rocprof_summary.py traffic $O/${R}_pmc_FETCH_SIZE_config2.txt $O/${R}_pmc_WRITE_SIZE_config2.txt config2_calib0 > $O/pmc_traffic_c2.json
+# configs[3] on one GPU (779 MB per launch of the judged kernel) and configs[4] (opt_calib: k_observations<true,true>)
+for C in 3 4; do
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_fetch$C -o r -- python3 bench.py --config $C --steps 3 --warmup 1 --no-cpu-baseline --no-parity-solver > $O/pmc_fetch$C.log 2>&1
+  python3 tools/rocprof_summary.py pmc $O/pmc_fetch$C/r_results.db > $O/${R}_pmc_FETCH_SIZE_config$C.txt
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pmc_write$C -o r -- python3 bench.py --config $C --steps 3 --warmup 1 --no-cpu-baseline --no-parity-solver > $O/pmc_write$C.log 2>&1
+  python3 tools/rocprof_summary.py pmc $O/pmc_write$C/r_results.db > $O/${R}_pmc_WRITE_SIZE_config$C.txt
+done
+python3 tools/rocprof_summary.py traffic $O/${R}_pmc_FETCH_SIZE_config3.txt $O/${R}_pmc_WRITE_SIZE_config3.txt config3_calib0 $O/pmc_traffic_c2.json > $O/pmc_traffic_c23.json
+python3 tools/rocprof_summary.py traffic $O/${R}_pmc_FETCH_SIZE_config4.txt $O/${R}_pmc_WRITE_SIZE_config4.txt config4_calib1 $O/pmc_traffic_c23.json > $O/pmc_traffic.json
+# the bare store stream the judged kernel is compared with, built on the box
+/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -o /tmp/store_bw tools/micro/store_bw.hip && /tmp/store_bw > $O/${R}_store_bw.txt 2>&1
+bash tools/step_timeline.sh 2 > $O/${R}_step_timeline_config2.txt 2>&1
+python3 tools/incremental_loop.py --solver trf --cpu-sample 2>&1 | grep -v "^Number\|^Doing\|^$" > $O/${R}_incremental_loop_trf.txt
+python3 tools/incremental_loop.py --solver lm 2>&1 | grep -v "^Number\|^Doing\|^$" > $O/${R}_incremental_loop_lm.txt
+python3 tools/xlevel_table.py > $O/${R}_xlevel_parity.txt 2>&1
+python3 tools/time_neighbours.py > $O/${R}_neighbour_steps.txt 2>&1
+rm -rf $O/stats_lm $O/stats_trf $O/stats_c3 $O/pmc_fetch* $O/pmc_write* $O/pmc_traffic_c2.json $O/pmc_traffic_c23.json
 ls -la $O

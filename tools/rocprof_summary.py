@@ -28,26 +28,33 @@ def pmc(db):
         print('%-100s %-12s %6d %14.3f %14.3f %14.3f %12.0f' % (name[:100], cname, n, avg, mn, mx, dur))
 
 
-def traffic(fetch_txt, write_txt):
+def traffic(fetch_txt, write_txt, key='config2_calib0', merge_into=None):
     """profiles/pmc_traffic.json: HBM bytes per launch of the residual+Jacobian kernel from the two PMC summaries, corrected as
     /opt/skills/guides/MI355X_MICROARCH.md (HBM section) prescribes for gfx950: FETCH_SIZE doubled (128-B read requests are
-    tallied at 64 B), WRITE_SIZE as reported; both are KiB per dispatch in the summaries."""
+    tallied at 64 B), WRITE_SIZE as reported; both are KiB per dispatch in the summaries.  `key` names the workload
+    (config<i>_calib<0|1>, what bench.py looks up); `merge_into`: an existing json whose other keys are kept."""
     import json
+    import os
+    kname = 'k_observations<true, true>' if key.endswith('calib1') else 'k_observations<false, true>'
 
     def avg(path, counter):
         for line in open(path):
-            if 'k_observations<false, true>' in line and counter in line:
+            if kname in line and counter in line:
                 parts = line.split(counter)[1].split()
                 return int(parts[0]), float(parts[1]) * 1024.0
         raise SystemExit('kernel not found in ' + path)
     nf, fb = avg(fetch_txt, 'FETCH_SIZE')
     nw, wb = avg(write_txt, 'WRITE_SIZE')
-    print(json.dumps({'config2_calib0': {
-        'kernel': 'k_observations<calib=false,jac=true>', 'dispatches': nw,
+    out = {}
+    if merge_into and os.path.exists(merge_into):
+        out = json.load(open(merge_into))
+    out[key] = {
+        'kernel': kname, 'dispatches': nw,
         'WRITE_SIZE_bytes': wb, 'FETCH_SIZE_bytes_reported': fb, 'bytes_per_launch': wb + 2.0 * fb,
-        'note': 'rocprofv3 --pmc WRITE_SIZE and --pmc FETCH_SIZE in separate passes of `python3 bench.py` (profiles/r02_pmc_*_config2.txt); '
+        'note': 'rocprofv3 --pmc WRITE_SIZE and --pmc FETCH_SIZE in separate passes of `python3 bench.py` (%s, %s); '
                 'the dispatches are the 100 launches with rotating outputs (>= 1 GiB in rotation) plus 20 into one buffer set; FETCH_SIZE '
-                'doubled per the gfx950 correction of the guide, WRITE_SIZE as reported'}}, indent=1))
+                'doubled per the gfx950 correction of the guide, WRITE_SIZE as reported' % (os.path.basename(fetch_txt), os.path.basename(write_txt))}
+    print(json.dumps(out, indent=1))
 
 
 if __name__ == '__main__':
