@@ -143,3 +143,25 @@ def test_all_detect_to_traj_vs_reference(name):
     np.testing.assert_array_equal(s.global_traj[:3], g['adt_global_traj'][:3])          # order index, camera id, frame id: integers
     np.testing.assert_allclose(s.global_traj[3:], g['adt_global_traj'][3:], rtol=0, atol=1e-8)
     np.testing.assert_allclose(s.traj, g['adt_traj'], rtol=0, atol=1e-8)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', ['rs_F_2int_3cam', 'calib_KE_bounds_3cam'])
+def test_error_motion_is_the_tail_of_the_reference_residual(name):
+    """Scene.error_motion(motion_reg=True) (common.py:362-424) at the fixture's x0: the values the reference's error_BA
+    appends to its residual vector (common.py:462-467; golden `f_x0`, rows 2M..), F and KE, one per sample of
+    spline_to_traj(), zeros at the interval ends included."""
+    from test_gpu_scene import build_scene
+    scene, g = load_case(name)
+    s = build_scene(scene)
+    st = scene.settings
+    M = sum(d.shape[1] for d in scene.detections)
+    ref = g['f_x0'][2 * M:]
+    em = s.error_motion(list(range(s.numCam)), motion_weights=st['motion_weights'], motion_reg=True)
+    assert em.shape == ref.shape == (s.traj.shape[1],)
+    assert np.array_equal(em == 0, ref == 0)
+    np.testing.assert_allclose(em, ref, rtol=1e-9, atol=1e-9)
+    with pytest.raises(NotImplementedError):
+        s.error_motion([0], motion_prior=True)
+    with pytest.raises(ValueError):
+        s.error_motion([0])
