@@ -348,6 +348,26 @@ struct HipBackend {
     if (jac) has_jacobian = true;
   }
   void residual(const double* x, double* f) { eval(x, f, false, 0); }
+  // f = f(x) and out = |f|^2 (summed over the ranks): on one rank the residual kernels leave their workgroups' sums of squares
+  // behind and one small launch adds them -- no separate pass over f
+  double* sq_part = nullptr;
+  size_t sq_cap = 0;
+  void residual_sq(const double* x, double* f, double* out) {
+    if (allreduce) { residual(x, f); dot_m_into(f, f, out); return; }
+    const int mb = hp.T > 0 ? (int)((hp.T + kThreads - 1) / kThreads) : 0;
+    const size_t need = (size_t)dp.n_chunks + mb + 1;
+    if (need > sq_cap) { sq_part = dalloc<double>(need); sq_cap = need; }
+    ensure_cams(x);
+    if (dp.n_chunks > 0) {
+      const dim3 g(dp.n_chunks), b(kThreads);
+      if (hp.calib) hipLaunchKernelGGL((k_observations<true, false>), g, b, 0, stream, dp, cams, x, f, J, span, pat0, 0, sq_part);
+      else hipLaunchKernelGGL((k_observations<false, false>), g, b, 0, stream, dp, cams, x, f, J, span, pat0, 0, sq_part);
+    }
+    if (mb > 0) hipLaunchKernelGGL(k_motion<false>, dim3(mb), dim3(kThreads), 0, stream, dp, x, f + 2 * hp.M, mJ, mctrl, 0, sq_part + dp.n_chunks);
+    if (dp.n_chunks + mb > 0) hipLaunchKernelGGL(k_dot_final, dim3(1), dim3(kThreads), 0, stream, dp.n_chunks + mb, sq_part, out);
+    else MVUS_HIP(hipMemsetAsync(out, 0, sizeof(double), stream));
+    MVUS_HIP(hipGetLastError());
+  }
   // motion rows only: their residuals and Jacobian blocks (the fused LM path evaluates the detection rows elsewhere)
   void motion_jacobian(const double* x, double* f) {
     if (hp.T <= 0) return;

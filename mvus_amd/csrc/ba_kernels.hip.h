@@ -195,7 +195,7 @@ template <bool CALIB, bool JAC>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(JAC ? (CALIB ? MVUS_JAC_WAVES_CALIB : MVUS_JAC_WAVES) : 4, 8))) void k_observations(DevProblem dp, const CamState* __restrict__ cams,
                                                            const double* __restrict__ x, double* __restrict__ f,
                                                            double* __restrict__ J, int32_t* __restrict__ span,
-                                                           const int32_t* __restrict__ pat0, int masked) {
+                                                           const int32_t* __restrict__ pat0, int masked, double* __restrict__ sq_part = nullptr) {
   constexpr int NS = 3 + (CALIB ? 15 : 6) + 12;
   // JAC: the grid is xcd_grid(n_chunks) workgroups and each XCD works on runs of consecutive chunks (xcd_tile): the kernel
   // is bound by its store stream, and an L2 that writes back runs of consecutive lines of each slot row reaches 12-14 %
@@ -206,6 +206,35 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(JAC ? 
   // the camera state is wave-uniform too: it is read through the scalar cache into SGPRs (34 doubles that would occupy
   // 68 VGPRs of every lane as hoisted LDS broadcasts, and no LDS staging + barrier before the first useful load)
   const CamState& cam = cams[ci.cam];
+  if constexpr (!JAC) {
+    // residual-only launches of the LM driver: the chunk's sum of squares is left in sq_part[chunk] (the driver needs |f|^2 of
+    // every trial point; a separate pass over f for it costs a launch and 8 MB of reads).  Every lane stays for the reduction.
+    if (sq_part != nullptr) {
+      __shared__ double sq_red[kThreads / 64];
+      double sq = 0.0;
+      if ((int)threadIdx.x < ci.count) {
+        const long long i = ci.start + threadIdx.x;
+        const long long a = ci.cam_start, Mc = ci.cam_count;
+        const double uo = CALIB ? 0.0 : dp.u_obs[i], vo = CALIB ? 0.0 : dp.v_obs[i];
+        const double ur = CALIB ? dp.u_raw[i] : 0.0;
+        JStoreSink sink{J, J, kThreads, 0, NS - 12, false, true, -1, threadIdx.x};
+        const ObsResult r = eval_observation_to<CALIB, false>(cam, dp.sp, x, dp.undist != 0, dp.rs_free != 0, dp.sync_free != 0, dp.frame[i], ur, dp.v_raw[i], uo, vo, sink);
+        f[2 * a + (i - a)] = r.ex;
+        f[2 * a + Mc + (i - a)] = r.ey;
+        sq = r.ex * r.ex + r.ey * r.ey;
+      }
+      sq = wave_sum(sq);
+      if ((threadIdx.x & 63) == 0) sq_red[threadIdx.x >> 6] = sq;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < kThreads / 64; ++w) t += sq_red[w];
+        sq_part[chunk] = t;
+      }
+      return;
+    }
+  }
   if ((int)threadIdx.x >= ci.count) return;
   const long long i = ci.start + threadIdx.x;
   const long long a = ci.cam_start, Mc = ci.cam_count;
@@ -258,8 +287,29 @@ __global__ __launch_bounds__(kThreads) void k_pattern(DevProblem dp, const CamSt
 // Motion-regulariser rows (error_motion / motion_prior): one thread per sample.
 template <bool JAC>
 __global__ __launch_bounds__(kThreads) void k_motion(DevProblem dp, const double* __restrict__ x, double* __restrict__ fm,
-                                                     double* __restrict__ mJ, int32_t* __restrict__ mctrl, int masked) {
+                                                     double* __restrict__ mJ, int32_t* __restrict__ mctrl, int masked, double* __restrict__ sq_part = nullptr) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if constexpr (!JAC) {
+    if (sq_part != nullptr) {                            // residual-only, with the workgroup's sum of squares (see k_observations)
+      __shared__ double sq_red[kThreads / 64];
+      double v = 0.0;
+      if (j < dp.T) {
+        const int key = dp.mv.ctrl[j];
+        if (key >= dp.mot_lo && key < dp.mot_hi) { double jrow[36]; int32_t cidx[3]; v = eval_motion_row<false>(dp.mv, x, j, false, jrow, cidx); }
+        fm[j] = v;
+      }
+      double sq = wave_sum(v * v);
+      if ((threadIdx.x & 63) == 0) sq_red[threadIdx.x >> 6] = sq;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < kThreads / 64; ++w) t += sq_red[w];
+        sq_part[blockIdx.x] = t;
+      }
+      return;
+    }
+  }
   if (j >= dp.T) return;
   double jrow[36];
   int32_t cidx[3];

@@ -87,9 +87,8 @@ SolveResult lm_schur(B& be, Schur& sc, std::vector<double>& x, const std::vector
   double hs[7] = {0, 0, 0, 0, 0, 0, 0};
 
   be.upload(x_dev, x.data(), n);
-  be.residual(x_dev, f_dev);
+  be.residual_sq(x_dev, f_dev, S);
   res.nfev = 1; res.njev = 1;
-  be.dot_m_into(f_dev, f_dev, S);
   sc.linearize(be, x_dev, f_dev, opt.jac_mode, true);
 
   // f(x_new) becomes f(x): the two buffers change roles where the backend allows it (the HIP backend's are pool buffers of
@@ -102,8 +101,7 @@ SolveResult lm_schur(B& be, Schur& sc, std::vector<double>& x, const std::vector
   auto launch_trial = [&](double lambda) {
     sc.solve_async(lambda);
     be.lm_trial(x_dev, sc.step_ptr(), lbp, ubp, sc.grad_ptr(), sc.diag_ptr(), sc.fail_ptr(), xt_dev, S + 2, S + 1, be.mirror_dev(mir_trial));
-    be.residual(xt_dev, f_new);
-    be.dot_m_into(f_new, f_new, S + 6);
+    be.residual_sq(xt_dev, f_new, S + 6);
   };
 
   double lambda = std::max(opt.lm_lambda0 > 0 ? opt.lm_lambda0 : 1e-4, opt.lm_lambda_min), nu = opt.lm_nu0 > 0 ? opt.lm_nu0 : 2.0;

@@ -1744,9 +1744,12 @@ __global__ __launch_bounds__(kGjThreads) void k_gj_step(int nn, int kb, const do
 
 // p (x order) from p_c and p_s = -(z_g + Z_E p_c)
 __global__ __launch_bounds__(kThreads) void k_back_substitute(DevProblem dp, NEView ne, int ncols, int row_lo, int row_hi, int cams,
-                                                              const double* __restrict__ Z, const double* __restrict__ pc, double* __restrict__ px) {
+                                                              const double* __restrict__ Z, const double* __restrict__ pc, double* __restrict__ px,
+                                                              const int* __restrict__ fail = nullptr, int* __restrict__ fail_mirror = nullptr) {
   // one wavefront per owned spline row: lanes stride over the row of Z (coalesced), then a shuffle reduction
   const int lane = threadIdx.x & 63;
+  // last kernel of a solve: the two failure flags go to the host's mapped copy here (a device-to-host copy of 8 bytes is a launch)
+  if (fail_mirror != nullptr && blockIdx.x == 0 && threadIdx.x < 2) fail_mirror[threadIdx.x] = fail[threadIdx.x];
   const int r = row_lo + blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
   if (blockIdx.x == 0 && cams)
     for (int idx = threadIdx.x; idx < ne.CB; idx += kThreads) px[cam_col(dp.C, dp.P, idx / ne.B, idx % ne.B)] = pc[idx];
@@ -1772,6 +1775,7 @@ struct HipSchur {
          *DG = nullptr, *D = nullptr, *gx = nullptr, *px = nullptr, *sepbuf = nullptr;
   int* fail = nullptr;      // [0] numerical failure of a solve, [1] a row reached outside the slice (assembly)
   int* fail_host = nullptr;
+  int* fail_map = nullptr;  // device address of fail_host (mapped pinned)
   PartView pv{};
   int* part_tables = nullptr;
   int nslab = 1;            // K-slabs of the Schur product (partial sums in G)
@@ -1843,8 +1847,9 @@ struct HipSchur {
     px = be.alloc(hp.n + 2);                         // + the two failure flags of a time shard
     MVUS_HIP(hipMalloc(reinterpret_cast<void**>(&fail), 2 * sizeof(int)));
     MVUS_HIP(hipMemsetAsync(fail, 0, 2 * sizeof(int), be.stream));
-    MVUS_HIP(hipHostMalloc(reinterpret_cast<void**>(&fail_host), 2 * sizeof(int), hipHostMallocDefault));
+    MVUS_HIP(hipHostMalloc(reinterpret_cast<void**>(&fail_host), 2 * sizeof(int), hipHostMallocMapped));
     fail_host[0] = fail_host[1] = 0;
+    if (hipHostGetDevicePointer(reinterpret_cast<void**>(&fail_map), fail_host, 0) != hipSuccess) fail_map = nullptr;
     ne.err = fail + 1;
     // partition of the owned chain; the separators are numbered along the chain of ALL ranks (each rank can compute
     // every other rank's count from the cuts)
@@ -2048,14 +2053,14 @@ struct HipSchur {
     if (shard) MVUS_HIP(hipMemsetAsync(px, 0, be.hp.n * sizeof(double), be.stream));
     const int nrows = row_hi - row_lo, per = kThreads / 64;
     hipLaunchKernelGGL(k_back_substitute, dim3((unsigned)std::max(1, (nrows + per - 1) / per)), dim3(kThreads), 0, be.stream, be.dp, ne, ncols,
-                       row_lo, row_hi, (int)(!shard || be.tshard.rank == 0), Z, pc, px);
+                       row_lo, row_hi, (int)(!shard || be.tshard.rank == 0), Z, pc, px, fail, (!shard && be.scal_direct()) ? fail_map : (int*)nullptr);
     if (shard) {
       hipLaunchKernelGGL(k_fail_pack, dim3(1), dim3(64), 0, be.stream, fail, px + be.hp.n);
       be.reduce(px, (size_t)be.hp.n + 2);             // every rank's part of the step (+ failure flags)
       hipLaunchKernelGGL(k_fail_unpack, dim3(1), dim3(64), 0, be.stream, px + be.hp.n, fail);
     }
     MVUS_HIP(hipGetLastError());
-    MVUS_HIP(hipMemcpyAsync(fail_host, fail, 2 * sizeof(int), hipMemcpyDeviceToHost, be.stream));
+    if (shard || !be.scal_direct() || !fail_map) MVUS_HIP(hipMemcpyAsync(fail_host, fail, 2 * sizeof(int), hipMemcpyDeviceToHost, be.stream));
   }
 };
 

@@ -41,6 +41,9 @@ GENERATORS = {
                                                         opt_calib=True, rs_bounds=True, motion_reg=True, motion_type='KE',
                                                         motion_weights=1e2, knot_spacing=14.0, perturb=0.3, ring_radius=18.0,
                                                         outlier_frac=0.005),
+    # BASELINE configs[1] in SHAPE (7 cameras, rolling shutter, motion_reg F with the README's weight 1e4, two intervals) at 1/14 of
+    # its size, so that the real reference converges in minutes: the same generator arguments as synth.BASELINE_CONFIGS[1]
+    'config1_shape_7cam': lambda: integer_intervals(synth.make_scene(**dict(synth.BASELINE_CONFIGS[1], total_obs=7000))),
 }
 MAX_ITERS = {'c1_pinhole_2cam': (10, 40)}          # first-BA budgets stored per case (default (10,))
 
