@@ -515,7 +515,8 @@ struct HipBackend {
   int* jt_nondet = nullptr;
   // z_is_zero: the caller guarantees z == 0 on entry (the device-resident LSMR loop clears it while consuming it);
   // reuse_index: zfill of the previous call is still valid (same Jacobian, hence the same window starts)
-  void jtu_local(const double* u, double* z, bool z_is_zero = false, bool reuse_index = false) {
+  int32_t* jt_first = nullptr;            // [N][C] first covering chunk per (control point, camera): valid while reuse_index calls follow one another
+  void jtu_local(const double* u, double* z, bool z_is_zero = false, bool reuse_index = false, bool build_first = false) {
     if (!zc) {
       const size_t nc = std::max<size_t>(hp.chunks.size(), 1);
       zc = dalloc<double>(nc * (size_t)(hp.NS - 12)); zs = dalloc<double>(nc * 3 * (size_t)kJtWin); zg0 = dalloc<int32_t>(nc); zfill = dalloc<int32_t>(nc);
@@ -528,13 +529,20 @@ struct HipBackend {
     if (hp.calib) {
       if (dp.n_chunks > 0) hipLaunchKernelGGL(k_jtu_partial<30>, dim3(xcd_grid(dp.n_chunks)), b, 0, stream, dp, J, span, u, z, zc, zs, zg0, jt_nondet);
       if (!reuse_index) hipLaunchKernelGGL(k_jtu_index, dim3(hp.C), dim3(64), 0, stream, dp, zg0, zfill);
-      hipLaunchKernelGGL(k_jtu_reduce<30>, g2, b, 0, stream, dp, zc, zs, zg0, zfill, mJ, mctrl, u + 2 * hp.M, motion, z);
+      if (build_first) build_jt_first();
+      hipLaunchKernelGGL(k_jtu_reduce<30>, g2, b, 0, stream, dp, zc, zs, zg0, zfill, mJ, mctrl, u + 2 * hp.M, motion, z, (reuse_index || build_first) ? jt_first : (int32_t*)nullptr);
     } else {
       if (dp.n_chunks > 0) hipLaunchKernelGGL(k_jtu_partial<21>, dim3(xcd_grid(dp.n_chunks)), b, 0, stream, dp, J, span, u, z, zc, zs, zg0, jt_nondet);
       if (!reuse_index) hipLaunchKernelGGL(k_jtu_index, dim3(hp.C), dim3(64), 0, stream, dp, zg0, zfill);
-      hipLaunchKernelGGL(k_jtu_reduce<21>, g2, b, 0, stream, dp, zc, zs, zg0, zfill, mJ, mctrl, u + 2 * hp.M, motion, z);
+      if (build_first) build_jt_first();
+      hipLaunchKernelGGL(k_jtu_reduce<21>, g2, b, 0, stream, dp, zc, zs, zg0, zfill, mJ, mctrl, u + 2 * hp.M, motion, z, (reuse_index || build_first) ? jt_first : (int32_t*)nullptr);
     }
     MVUS_HIP(hipGetLastError());
+  }
+  void build_jt_first() {
+    if (!jt_first) jt_first = dalloc<int32_t>((size_t)std::max<int64_t>(hp.N, 1) * hp.C);
+    const long long e = (long long)hp.N * hp.C;
+    if (e > 0) hipLaunchKernelGGL(k_jtu_first, dim3((unsigned)((e + kThreads - 1) / kThreads)), dim3(kThreads), 0, stream, dp, zfill, jt_first);
   }
   void jtu(const double* u, double* z) { jtu_local(u, z); reduce(z, (size_t)hp.n); }
 
@@ -566,7 +574,7 @@ struct HipBackend {
         jv(v, tm);
         hipLaunchKernelGGL(k_lsmr_u, dim3(gm), dim3(kThreads), 0, stream, m, tm, ut, c, pu);
         hipLaunchKernelGGL(k_lsmr_unorm, dim3(gm), dim3(kThreads), 0, stream, m, ut, gm, pu, c, beta_dev);
-        jtu_local(ut, tn, true, launched > 0);
+        jtu_local(ut, tn, true, launched > 0, launched == 0);
         hipLaunchKernelGGL(k_lsmr_v, dim3(gn), dim3(kThreads), 0, stream, n, tn, v, c, beta_dev, pv);
         hipLaunchKernelGGL(k_lsmr_update, dim3(gn), dim3(kThreads), 0, stream, n, v, h, hbar, x, gn, pv, c, beta_dev, nx, px);
         hipLaunchKernelGGL(k_lsmr_test, dim3(1), dim3(kThreads), 0, stream, gn, px, c, nx);

@@ -61,6 +61,9 @@ __device__ __forceinline__ double wave_sum(double v) {
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
   return v;
 }
+// wave_sum's tree for callers that read the total from lane 0 only: the two steps that cross 16-lane rows go through the LDS
+// crossbar like __shfl_down, the four inside row 0 are DPP row shifts (no LDS trip).  Lane 0 holds the same bits as wave_sum's.
+__device__ __forceinline__ double wave_sum_lane0(double v);
 // The same reductions on the DPP data path (VALU lane shifts inside 16-lane rows, then the two row broadcasts): no trip through
 // the LDS crossbar per step.  With 16 wavefronts of one workgroup each reducing five values, the ds_bpermute version of
 // k_lm_trial spent 21-25 k cycles in its reductions (MVUS_TRIAL_PROBE); the summation tree differs from wave_sum's, so these are
@@ -70,6 +73,15 @@ __device__ __forceinline__ double dpp_shift(double v, double fill) {
   const int lo = __builtin_amdgcn_update_dpp(__double2loint(fill), __double2loint(v), CTRL, ROW_MASK, 0xF, false);
   const int hi = __builtin_amdgcn_update_dpp(__double2hiint(fill), __double2hiint(v), CTRL, ROW_MASK, 0xF, false);
   return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_lane0(double v) {
+  v += __shfl_down(v, 32, 64);
+  v += __shfl_down(v, 16, 64);
+  v += dpp_shift<0x108, 0xF>(v, 0.0);      // row_shl:8
+  v += dpp_shift<0x104, 0xF>(v, 0.0);      // row_shl:4
+  v += dpp_shift<0x102, 0xF>(v, 0.0);      // row_shl:2
+  v += dpp_shift<0x101, 0xF>(v, 0.0);      // row_shl:1
+  return v;
 }
 __device__ __forceinline__ double wave_sum_dpp(double v) {
   v += dpp_shift<0x111, 0xF>(v, 0.0);      // row_shr:1
@@ -404,7 +416,7 @@ __global__ __launch_bounds__(kThreads) void k_jtu_partial(DevProblem dp, const d
   __shared__ double prod[12 * PS];
   __shared__ int lo[kJtWin], hi[kJtWin], skey[kThreads];
   __shared__ int gmin_s[kThreads / 64];
-  __shared__ int bad_s, wide_s;
+  __shared__ int bad_s, wide_s, lmax_s;
     const int chunk = xcd_tile(dp.n_chunks);        // grid = xcd_grid(n_chunks): every XCD streams runs of consecutive chunks of J
   if (chunk >= dp.n_chunks) return;
   const ChunkInfo ci = dp.chunks[chunk];
@@ -417,7 +429,7 @@ __global__ __launch_bounds__(kThreads) void k_jtu_partial(DevProblem dp, const d
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const double* __restrict__ Jc = J + j_chunk_offset<NS>(chunk) + (active ? threadIdx.x : 0);
   for (int k = threadIdx.x; k < kJtWin; k += kThreads) { lo[k] = 0x7fffffff; hi[k] = 0; }
-  if (threadIdx.x == 0) { bad_s = 0; wide_s = 0; }
+  if (threadIdx.x == 0) { bad_s = 0; wide_s = 0; lmax_s = -1; }
   skey[threadIdx.x] = g;
   int gm = g >= 0 ? g : 0x7fffffff;
 #pragma unroll
@@ -427,7 +439,7 @@ __global__ __launch_bounds__(kThreads) void k_jtu_partial(DevProblem dp, const d
   for (int k = 0; k < B; ++k) {
     double val = 0.0;
     if (g >= 0) val = Jc[k * kThreads] * ux + Jc[(NS + k) * kThreads] * uy;
-    val = wave_sum(val);
+    val = wave_sum_lane0(val);
     if (lane == 0) part[wave][k] = val;
   }
   __syncthreads();
@@ -452,11 +464,21 @@ __global__ __launch_bounds__(kThreads) void k_jtu_partial(DevProblem dp, const d
   }
   if (g >= 0) {
     if (l + 3 >= kJtWin) atomicOr(&wide_s, 1);
-    else { atomicMin(&lo[l], (int)threadIdx.x); atomicMax(&hi[l], (int)threadIdx.x + 1); }
+    else {
+      // only the ends of a run of equal span can set the minimum / maximum of their span's index range (LDS atomics serialise
+      // per address: a run of r detections cost 2 r of them, now 2)
+      const int tid = threadIdx.x;
+      if (tid == 0 || skey[tid - 1] != g) atomicMin(&lo[l], tid);
+      if (tid == kThreads - 1 || skey[tid + 1] != g) { atomicMax(&hi[l], tid + 1); atomicMax(&lmax_s, l); }
+    }
   }
   __syncthreads();
+  // do the index ranges of consecutive non-empty spans overlap (detections not in span order)?  Each non-empty span looks for the
+  // next one -- up to the last span in use only: scanning the empty tail of the 144-wide window took the last span's thread
+  // ~60 dependent LDS reads, 15 of the kernel's 49 us
   if (threadIdx.x < kJtWin && hi[threadIdx.x] > 0) {
-    for (int t = threadIdx.x + 1; t < kJtWin; ++t)
+    const int last = lmax_s;
+    for (int t = threadIdx.x + 1; t <= last; ++t)
       if (hi[t] > 0) { if (lo[t] < hi[threadIdx.x]) atomicOr(&bad_s, 1); break; }
   }
   __syncthreads();
@@ -515,11 +537,26 @@ __global__ __launch_bounds__(64) void k_jtu_index(DevProblem dp, const int32_t* 
 // Blocks [C, ..): one wavefront per control point, lane = camera (cameras lane, lane + 64, ...): every lane adds, chunk by
 // chunk, the window entries of its camera that cover the control point; the lanes are then combined by a butterfly whose
 // pairing is fixed (the same bits every run), lane 0 adds the motion rows (a contiguous, precomputed row range) and writes z.
+// first chunk of camera c whose running-max window start is within reach of control point g: what pass 2 finds by binary
+// search.  It depends on the Jacobian's spans only, so a run of products with one Jacobian (LSMR) looks it up once.
+__device__ __forceinline__ int jtu_first_chunk(const DevProblem& dp, const int32_t* __restrict__ zfill, int c, int g) {
+  int lo = dp.cam_chunk_off[c], hi = dp.cam_chunk_off[c + 1];
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (zfill[mid] + kJtWin > g) hi = mid; else lo = mid + 1;
+  }
+  return lo;
+}
+__global__ __launch_bounds__(kThreads) void k_jtu_first(DevProblem dp, const int32_t* __restrict__ zfill, int32_t* __restrict__ first) {
+  const long long e = blockIdx.x * (long long)kThreads + threadIdx.x;
+  if (e >= (long long)dp.N * dp.C) return;
+  first[e] = jtu_first_chunk(dp, zfill, (int)(e % dp.C), (int)(e / dp.C));
+}
 template <int NS>
 __global__ __launch_bounds__(kThreads) void k_jtu_reduce(DevProblem dp, const double* __restrict__ zc, const double* __restrict__ zs,
                                                          const int32_t* __restrict__ zg0, const int32_t* __restrict__ zfill, const double* __restrict__ mJ,
                                                          const int32_t* __restrict__ mctrl, const double* __restrict__ um, int motion,
-                                                         double* __restrict__ z) {
+                                                         double* __restrict__ z, const int32_t* __restrict__ first = nullptr) {
   constexpr int B = NS - 12;
   if ((int)blockIdx.x < dp.C) {
     const int c = blockIdx.x, k = threadIdx.x;
@@ -535,12 +572,8 @@ __global__ __launch_bounds__(kThreads) void k_jtu_reduce(DevProblem dp, const do
   double acc[3] = {0.0, 0.0, 0.0};
   for (int c = lane; c < dp.C; c += 64) {
     // first chunk whose running-max window start is within reach of g (everything before ends left of g) ...
-    int lo = dp.cam_chunk_off[c], hi = dp.cam_chunk_off[c + 1];
-    const int end = hi;
-    while (lo < hi) {
-      const int mid = (lo + hi) >> 1;
-      if (zfill[mid] + kJtWin > g) hi = mid; else lo = mid + 1;
-    }
+    const int end = dp.cam_chunk_off[c + 1];
+    const int lo = first ? first[(long long)g * dp.C + c] : jtu_first_chunk(dp, zfill, c, g);
     // ... then forward until the running maximum is a whole window past g (a later chunk's own start is never that far
     // below the running maximum), adding the covering windows in chunk order
     for (int ch = lo; ch < end && zfill[ch] <= g + kJtWin; ++ch) {

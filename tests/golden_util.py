@@ -9,7 +9,9 @@ CASES = ['c1_pinhole_2cam', 'rs_F_2int_3cam', 'calib_KE_bounds_3cam', 'dist_fixe
 # BASELINE configs[4] (opt_calib + rs_bounds + KE) on a WELL-POSED scene: 5 cameras x ~3k detections, the target sweeps the
 # images.  15k detections: used by the tests that need it (residual, mask, pattern, converged parity), not by every sweep.
 CALIB_WP = 'calib_KE_wellposed_5cam'
-CONVERGED_CASES = CASES + [CALIB_WP]
+# BASELINE configs[1] in shape (7 cameras, rolling shutter, motion_reg F, weight 1e4, two intervals) at 1/14 of its size
+CONFIG1_SHAPE = 'config1_shape_7cam'
+CONVERGED_CASES = CASES + [CALIB_WP, CONFIG1_SHAPE]
 
 
 def load_case(name):
