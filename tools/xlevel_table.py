@@ -25,7 +25,7 @@ from oracle import ba_oracle as orc
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith('--')]
     host = '--host' in sys.argv
-    cases = args or ['c1_pinhole_2cam', 'rs_F_2int_3cam', 'dist_fixed_2cam', 'calib_KE_bounds_3cam', 'calib_KE_wellposed_5cam']
+    cases = args or ['c1_pinhole_2cam', 'rs_F_2int_3cam', 'dist_fixed_2cam', 'calib_KE_bounds_3cam', 'calib_KE_wellposed_5cam', 'config1_shape_7cam']
     for name in cases:
         scene, g = filtered_case(name)
         prob, _ = mp.problem_from_scene(scene)
