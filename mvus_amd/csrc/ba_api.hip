@@ -1187,20 +1187,33 @@ int mvus_spline_smooth(int32_t device, int64_t m, const double* u, const double*
     int32_t* span = cb.get<int32_t>((size_t)m);
     double* q = cb.get<double>(4 * (size_t)m);
     double* term = cb.get<double>((size_t)m);
-    long long* first = cb.get<long long>((size_t)nest + 1);
-    double* cd = cb.get<double>(3 * (size_t)nest);
-    double* td = cb.get<double>((size_t)nest);
-    double* bd = cb.get<double>(5 * (size_t)nest);
-    double* out = cb.get<double>((size_t)nest + 4);       // [0] sum diag(L), [1] f_p, [2] min diag(L), [3] max diag(L), [4..] residual per span
+    // Everything indexed by knots is sized by a CAPACITY that grows with the knot count (x4, up to FITPACK's nest = m + 6), not
+    // by nest: the trajectories traj_to_spline fits are 50x oversampled (560k samples for ~600 knots), and allocating and
+    // freeing ~40 arrays of nest doubles (430 MB with the double-double set) cost 70 of the 77 ms of such a fit
+    long long* first = nullptr;
+    double *cd = nullptr, *td = nullptr, *bd = nullptr, *out = nullptr;   // out: [0] sum diag(L), [1] f_p, [2] min diag(L), [3] max diag(L), [4..] residual per span
     int* fail = cb.get<int>(1);
     FitWork<double> w1;
     FitWork<dd> w2;
-    w1.alloc(cb, (size_t)nest);
     bool precise = false;                                  // double-double from the first ill-conditioned pass on
     int lsq_dd_n = -1;                                     // knot count whose normal equations w2 holds
     MVUS_HIP(hipMemsetAsync(fail, 0, sizeof(int), cb.st));
-    std::vector<double> t((size_t)nest, 0.0), fpint((size_t)nest, 0.0), host((size_t)nest + 4, 0.0), b;
-    std::vector<int> nrdata((size_t)nest, 0);
+    std::vector<double> t, fpint, host, b;
+    std::vector<int> nrdata;
+    size_t cap = 0;
+    auto ensure = [&](size_t need) {                      // between passes only: the device arrays hold nothing that outlives a pass
+      if (need <= cap) return;
+      size_t c = std::max<size_t>(cap, 1024);
+      while (c < need) c *= 4;
+      cap = std::min<size_t>(c, (size_t)nest);
+      first = cb.get<long long>(cap + 1); cd = cb.get<double>(3 * cap); td = cb.get<double>(cap); bd = cb.get<double>(5 * cap);
+      out = cb.get<double>(cap + 4);
+      w1 = FitWork<double>(); w2 = FitWork<dd>(); lsq_dd_n = -1;
+      w1.alloc(cb, cap);
+      if (t.size() < cap) { t.resize(cap, 0.0); fpint.resize(cap, 0.0); nrdata.resize(cap, 0); }
+      if (host.size() < cap + 4) host.resize(cap + 4, 0.0);
+    };
+    ensure(nmin + 16);
     const double ub = u[0], ue = u[m - 1], acc = tol * s;
     int n = nmin, nplus = 0, ier = 0, nrint = 1, failed = 0;
     double fpold = 0.0, fp0 = 0.0, fp = 0.0, p = -1.0;
@@ -1224,7 +1237,7 @@ int mvus_spline_smooth(int32_t device, int64_t m, const double* u, const double*
           if (!smoothing) fit_lsq_pass<double>(cb.st, w1, (long long)m, first, q, dX, ncoef, nrint_, cd, out, fail);
           else fit_smooth_pass<double>(cb.st, w1, ncoef, n8, bd, pinv, cd, out, fail);
         } else {
-          w2.alloc(cb, (size_t)nest);
+          w2.alloc(cb, cap);
           if (lsq_dd_n != n) { fit_lsq_pass<dd>(cb.st, w2, (long long)m, first, q, dX, ncoef, nrint_, cd, out, fail); lsq_dd_n = n; }
           if (smoothing) fit_smooth_pass<dd>(cb.st, w2, ncoef, n8, bd, pinv, cd, out, fail);
         }
@@ -1243,6 +1256,7 @@ int mvus_spline_smooth(int32_t device, int64_t m, const double* u, const double*
     };
     int ncoef = 0;
     for (;;) {                                             // fppara: do 200 iter = 1, m
+      ensure((size_t)n + 16);
       if (n == nmin) ier = -2;
       nrint = n - nmin + 1;
       ncoef = n - k1;
@@ -1310,12 +1324,17 @@ int mvus_spline_smooth(int32_t device, int64_t m, const double* u, const double*
         ier = 0;
       }
       fpold = fp;
+      {                                                    // room for the knots about to be added (host arrays; the device side follows at the top of the loop)
+        const size_t need = std::min<size_t>((size_t)nest, (size_t)n + (size_t)nplus + 16);
+        if (need > t.size()) { t.resize(need, 0.0); fpint.resize(need, 0.0); nrdata.resize(need, 0); }
+      }
       for (int j = 0; j < nrint; ++j) fpint[j] = host[4 + j];
       for (int l = 0; l < nplus; ++l) {
         fitpack::fpknot(u, t, n, fpint, nrdata, nrint);
         if (n == nmax || n == nest) break;
       }
       if (n == nmax) {                                      // fppara label 10: the knots of the interpolating spline
+        if (t.size() < (size_t)nest) { t.resize((size_t)nest, 0.0); fpint.resize((size_t)nest, 0.0); nrdata.resize((size_t)nest, 0); }
         int i = k2, j = k / 2 + 2;
         for (int l = 0; l < (int)m - k1; ++l) { t[i - 1] = u[j - 1]; ++i; ++j; }
       }
