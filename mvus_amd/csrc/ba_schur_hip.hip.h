@@ -717,11 +717,16 @@ __device__ __forceinline__ double band_entry(const double* __restrict__ Lb, int 
   return d <= BW ? Lb[(long long)hi * (BW + 1) + d] : 0.0;
 }
 
+// banded Cholesky of interior p by ONE wavefront (lane = threadIdx.x & 63); T: kPartRowsMax * (BW + 1) doubles of LDS private to it.
+// (Only this wavefront touches T: the synchronisation is the wavefront-level one.)
+__device__ __forceinline__ void part_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+}
 template <int BW>
-__global__ __launch_bounds__(64) void k_part_cholesky(PartView pv, double* __restrict__ Lb, int* __restrict__ fail) {
+__device__ __forceinline__ void part_cholesky_body(const PartView& pv, double* __restrict__ Lb, int* __restrict__ fail, double* __restrict__ T, int p, int lane) {
   constexpr int R = BW + 1;
-  __shared__ double T[kPartRowsMax * R];
-  const int p = blockIdx.x, lane = threadIdx.x;
   const int r0 = pv.i0[p], n = pv.i1[p] - r0;
   for (int e = lane; e < n * R; e += 64) T[e] = Lb[(long long)r0 * R + e];
   // trailing-update pairs (rr >= ss >= 1) owned by this lane, as offsets from the pivot row: fixed for all columns
@@ -736,7 +741,7 @@ __global__ __launch_bounds__(64) void k_part_cholesky(PartView pv, double* __res
     prr[sl] = e < kPairs ? rr : BW + 1;
     offA[sl] = rr * R + (rr - ss); offB[sl] = rr * R + rr; offC[sl] = ss * R + ss;
   }
-  __syncthreads();
+  part_lds_sync();
   for (int k = 0; k < n; ++k) {
     double piv = T[k * R];
     if (!(piv > 0.0)) { if (lane == 0) fail[0] = 1; piv = 1.0; }
@@ -745,19 +750,24 @@ __global__ __launch_bounds__(64) void k_part_cholesky(PartView pv, double* __res
     inv = inv * (1.5 - 0.5 * piv * inv * inv);
     const int nb = min(BW, n - 1 - k);
     if (lane >= 1 && lane <= nb) T[(k + lane) * R + lane] *= inv;
-    __syncthreads();
+    part_lds_sync();
     double* Tk = T + k * R;
 #pragma unroll
     for (int sl = 0; sl < kSlots; ++sl)
       if (prr[sl] <= nb) Tk[offA[sl]] -= Tk[offB[sl]] * Tk[offC[sl]];
     if (lane == 0) T[k * R] = inv;      // reciprocal of L(k,k)
-    __syncthreads();
+    part_lds_sync();
   }
   // write back only entries whose column lies inside the interior (j <= row - r0); couplings stay original
   for (int e = lane; e < n * R; e += 64) {
     const int row = e / R, j = e % R;
     if (j <= row) Lb[(long long)r0 * R + e] = T[e];
   }
+}
+template <int BW>
+__global__ __launch_bounds__(64) void k_part_cholesky(PartView pv, double* __restrict__ Lb, int* __restrict__ fail) {
+  __shared__ double T[kPartRowsMax * (BW + 1)];
+  part_cholesky_body<BW>(pv, Lb, fail, T, (int)blockIdx.x, (int)threadIdx.x);
 }
 
 // interior solves, one thread per column, one wavefront per (interior, 64 columns).  COUPLING = false: right-hand-side
@@ -1390,6 +1400,38 @@ __global__ void k_build_rhs(NEView ne, int ncols, double* __restrict__ Z, double
   }
 }
 
+// The same work as two launches that OVERLAP: k_band_pack (the damped band, 0.2 M entries) first, then ONE launch whose first
+// pad8(P) workgroups factorise the interiors (a lone wavefront each, ~37 us of dependent LDS round trips on 155 of 256 CUs)
+// while all the others stream the right-hand-side copies (72 MB, bandwidth bound, ~22 us) -- the factorisation needs the
+// band only, the copies need nothing from the factorisation.  25 + 37 us in sequence become ~40.
+__global__ void k_band_pack(NEView ne, double lambda, int BW, double* __restrict__ Lb, int* __restrict__ fail, DevProblem dp, int with_diag,
+                            double* __restrict__ D, double* __restrict__ gx) {
+  band_pack_entry(ne, lambda, BW, Lb, fail, dp, with_diag, D, gx, blockIdx.x * (long long)blockDim.x + threadIdx.x);
+}
+template <int BW>
+__global__ __launch_bounds__(256) void k_cholesky_and_rhs(PartView pv, double* __restrict__ Lb, int* __restrict__ fail, int chol_blocks,
+                                                          NEView ne, int ncols, double* __restrict__ Z, double* __restrict__ Erm, int tiles) {
+  __shared__ double T[kPartRowsMax * (BW + 1)];
+  if ((int)blockIdx.x < chol_blocks) {                    // chol_blocks is a multiple of 8: the copy tiles keep their XCD mapping
+    if ((int)blockIdx.x < pv.P && threadIdx.x < 64) part_cholesky_body<BW>(pv, Lb, fail, T, (int)blockIdx.x, (int)threadIdx.x);
+    return;
+  }
+  const int b = (int)blockIdx.x - chol_blocks;
+  const int run = xcd_run_for(tiles);
+  const int xcd = b & 7, qq = b >> 3;
+  const long long idx = (long long)(((qq / run) * 8 + xcd) * run + qq % run) * blockDim.x + threadIdx.x;     // xcd_tile for the shifted index
+  if (idx >= (long long)ne.N3 * ncols) return;
+  const int r = (int)(idx / ncols), cidx = (int)(idx % ncols);
+  if (cidx < ne.CB) {
+    const int c = cidx / ne.B, k = cidx % ne.B;
+    const double v = ne.Et[((long long)c * ne.N3 + r) * ne.B + k];
+    Z[idx] = v;
+    Erm[(long long)r * ne.CB + cidx] = v;
+  } else {
+    Z[idx] = ne.gs[r];
+  }
+}
+
 // Gp[slab][CB][ncols] = Et^T Z over one K-slab: the one dense contraction of the solve (2 * CB^2 * 3N flops), on the
 // fp64 matrix cores (v_mfma_f64_16x16x4_f64).  Both operands are stored K-major ([3N][CB] and [3N][ncols]), which is
 // exactly the MFMA operand layout (lane l: A[l&15][k = l>>4], B[k = l>>4][l&15]; every 16-lane group reads 128
@@ -1788,6 +1830,8 @@ struct HipSchur {
   size_t sep_count = 0, halo_count = 0, nAg = 0, n_apart = 0;
   int nbound = 0;
   bool diag_pending = false;                   // D / g in x order still to be written (folded into the next k_build_rhs)
+  bool overlap_chol = true;                    // interiors factorised beside the right-hand-side copies (k_cholesky_and_rhs)
+  int rhs_tiles_z = 0;
   int* halo_tables = nullptr;                  // [nbound] cut, [nbound] index in the packed buffer
 
   explicit HipSchur(BE& b) : be(b) {
@@ -1993,7 +2037,12 @@ struct HipSchur {
   template <int BWT, int S3T>
   void band_chain() {
     const dim3 gsolve(pv.P, (ncols + 63) / 64 + 1);      // + one block row for the coupling columns
-    hipLaunchKernelGGL(k_part_cholesky<BWT>, dim3(pv.P), dim3(64), 0, be.stream, pv, Lb, fail);
+    if (overlap_chol) {
+      const int cb = (pv.P + 7) / 8 * 8;
+      hipLaunchKernelGGL(k_cholesky_and_rhs<BWT>, dim3((unsigned)(cb + xcd_grid(rhs_tiles_z))), dim3(256), 0, be.stream, pv, Lb, fail, cb, ne, ncols, Z, Erm, rhs_tiles_z);
+    } else {
+      hipLaunchKernelGGL(k_part_cholesky<BWT>, dim3(pv.P), dim3(64), 0, be.stream, pv, Lb, fail);
+    }
     hipLaunchKernelGGL(k_part_solve<BWT>, dim3(xcd_grid(pv.P * (int)gsolve.y)), dim3(64), 0, be.stream, pv, ncols, Lb, Z, (int)gsolve.y);
     if (pv.m > 0) {
       if (shard) MVUS_HIP(hipMemsetAsync(sepbuf, 0, sep_count * sizeof(double), be.stream));      // other ranks' separators: zero here
@@ -2020,8 +2069,15 @@ struct HipSchur {
     const long long nLb = (long long)ne.N3 * (BW + 1);
     const long long nZ = (long long)ne.N3 * ncols;          // >= nLb: one launch covers both passes
     const int rhs_tiles = (int)((std::max(nZ, nLb) + 255) / 256);
-    hipLaunchKernelGGL(k_build_rhs, dim3((unsigned)xcd_grid(rhs_tiles)), dim3(256), 0, be.stream, ne, ncols, Z, Erm, lambda, BW, Lb, fail, be.dp,
-                       (int)diag_pending, D, gx, rhs_tiles);
+    overlap_chol = std::getenv("MVUS_NO_OVERLAP") == nullptr;
+    if (overlap_chol) {
+      const long long nband = std::max<long long>(nLb, (long long)ne.CB + ne.N3);
+      hipLaunchKernelGGL(k_band_pack, dim3((unsigned)((nband + 255) / 256)), dim3(256), 0, be.stream, ne, lambda, BW, Lb, fail, be.dp, (int)diag_pending, D, gx);
+      rhs_tiles_z = (int)((nZ + 255) / 256);
+    } else {
+      hipLaunchKernelGGL(k_build_rhs, dim3((unsigned)xcd_grid(rhs_tiles)), dim3(256), 0, be.stream, ne, ncols, Z, Erm, lambda, BW, Lb, fail, be.dp,
+                         (int)diag_pending, D, gx, rhs_tiles);
+    }
     diag_pending = false;
     if (BW == 11) band_chain<11, 9>(); else band_chain<17, 15>();
     const int row_lo = 3 * own_lo, row_hi = 3 * own_hi;
