@@ -352,21 +352,27 @@ struct HipBackend {
   // behind and one small launch adds them -- no separate pass over f
   double* sq_part = nullptr;
   size_t sq_cap = 0;
-  void residual_sq(const double* x, double* f, double* out) {
-    if (allreduce) { residual(x, f); dot_m_into(f, f, out); return; }
+  // clr / clr_len: storage to zero beside the evaluation (HipSchur's normal-equation blocks); returns false if it was not done
+  bool residual_sq(const double* x, double* f, double* out, double* clr = nullptr, int64_t clr_len = 0) {
+    if (allreduce) { residual(x, f); dot_m_into(f, f, out); return false; }
     const int mb = hp.T > 0 ? (int)((hp.T + kThreads - 1) / kThreads) : 0;
     const size_t need = (size_t)dp.n_chunks + mb + 1;
     if (need > sq_cap) { sq_part = dalloc<double>(need); sq_cap = need; }
     ensure_cams(x);
+    bool cleared = false;
     if (dp.n_chunks > 0) {
-      const dim3 g(dp.n_chunks), b(kThreads);
-      if (hp.calib) hipLaunchKernelGGL((k_observations<true, false>), g, b, 0, stream, dp, cams, x, f, J, span, pat0, 0, sq_part);
-      else hipLaunchKernelGGL((k_observations<false, false>), g, b, 0, stream, dp, cams, x, f, J, span, pat0, 0, sq_part);
+      const int fb = (clr && clr_len > 0) ? (int)std::min<int64_t>(2048, (clr_len + kThreads - 1) / kThreads) : 0;
+      const dim3 g(dp.n_chunks + fb), b(kThreads);
+      double* c = fb > 0 ? clr : (double*)nullptr;
+      if (hp.calib) hipLaunchKernelGGL((k_observations<true, false>), g, b, 0, stream, dp, cams, x, f, J, span, pat0, 0, sq_part, c, (long long)clr_len);
+      else hipLaunchKernelGGL((k_observations<false, false>), g, b, 0, stream, dp, cams, x, f, J, span, pat0, 0, sq_part, c, (long long)clr_len);
+      cleared = fb > 0;
     }
     if (mb > 0) hipLaunchKernelGGL(k_motion<false>, dim3(mb), dim3(kThreads), 0, stream, dp, x, f + 2 * hp.M, mJ, mctrl, 0, sq_part + dp.n_chunks);
     if (dp.n_chunks + mb > 0) hipLaunchKernelGGL(k_dot_final, dim3(1), dim3(kThreads), 0, stream, dp.n_chunks + mb, sq_part, out);
     else MVUS_HIP(hipMemsetAsync(out, 0, sizeof(double), stream));
     MVUS_HIP(hipGetLastError());
+    return cleared;
   }
   // motion rows only: their residuals and Jacobian blocks (the fused LM path evaluates the detection rows elsewhere)
   void motion_jacobian(const double* x, double* f) {

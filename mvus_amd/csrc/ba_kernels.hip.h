@@ -207,12 +207,22 @@ template <bool CALIB, bool JAC>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(JAC ? (CALIB ? MVUS_JAC_WAVES_CALIB : MVUS_JAC_WAVES) : 4, 8))) void k_observations(DevProblem dp, const CamState* __restrict__ cams,
                                                            const double* __restrict__ x, double* __restrict__ f,
                                                            double* __restrict__ J, int32_t* __restrict__ span,
-                                                           const int32_t* __restrict__ pat0, int masked, double* __restrict__ sq_part = nullptr) {
+                                                           const int32_t* __restrict__ pat0, int masked, double* __restrict__ sq_part = nullptr,
+                                                           double* __restrict__ clr = nullptr, long long clr_len = 0) {
   constexpr int NS = 3 + (CALIB ? 15 : 6) + 12;
   // JAC: the grid is xcd_grid(n_chunks) workgroups and each XCD works on runs of consecutive chunks (xcd_tile): the kernel
   // is bound by its store stream, and an L2 that writes back runs of consecutive lines of each slot row reaches 12-14 %
   // more of the HBM write bandwidth than eight L2s interleaving 2 KB segments (50.6 -> 44.5 us at 504k detections)
   const int chunk = JAC ? xcd_tile(dp.n_chunks) : (int)blockIdx.x;
+  if constexpr (!JAC) {
+    // workgroups past the chunks (the LM driver's first evaluation of a solve): they zero the normal-equation storage the
+    // linearisation that follows adds into -- a bandwidth-bound pass riding beside a latency-bound kernel instead of a launch of its own
+    if (clr != nullptr && chunk >= dp.n_chunks) {
+      const long long nb = (long long)gridDim.x - dp.n_chunks;
+      for (long long i = (chunk - dp.n_chunks) * (long long)kThreads + threadIdx.x; i < clr_len; i += nb * kThreads) clr[i] = 0.0;
+      return;
+    }
+  }
   if (chunk >= dp.n_chunks) return;
   const ChunkInfo ci = dp.chunks[chunk];                 // wave-uniform: one scalar load
   // the camera state is wave-uniform too: it is read through the scalar cache into SGPRs (34 doubles that would occupy

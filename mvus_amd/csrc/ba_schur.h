@@ -87,7 +87,8 @@ SolveResult lm_schur(B& be, Schur& sc, std::vector<double>& x, const std::vector
   double hs[7] = {0, 0, 0, 0, 0, 0, 0};
 
   be.upload(x_dev, x.data(), n);
-  be.residual_sq(x_dev, f_dev, S);
+  // (the first linearisation follows at once: its storage is zeroed beside this evaluation where the backend can do that)
+  if (be.residual_sq(x_dev, f_dev, S, sc.clear_ptr(), sc.clear_len())) sc.mark_cleared();
   res.nfev = 1; res.njev = 1;
   sc.linearize(be, x_dev, f_dev, opt.jac_mode, true);
 
@@ -222,6 +223,9 @@ struct HostSchur {
   }
   std::vector<double> Dd, pstep;
   int fail = 0;
+  double* clear_ptr() { return nullptr; }
+  int64_t clear_len() const { return 0; }
+  void mark_cleared() {}
   const double* grad_ptr() const { return g.data(); }
   const double* diag_ptr() const { return Dd.data(); }
   const double* step_ptr() const { return pstep.data(); }

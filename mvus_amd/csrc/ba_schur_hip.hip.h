@@ -875,8 +875,33 @@ __global__ __launch_bounds__(64) void k_part_solve(PartView pv, int ncols, const
 }
 
 // separator system: T(q,q), T(q,q+1) and the reduced right-hand sides (in place in the separator rows of Z)
+// right-hand sides of separator task t: entries e0, e0 + estride, ... of its s3 x ncols block
 template <int BW>
-__global__ __launch_bounds__(256) void k_part_reduce(PartView pv, int ncols, const double* __restrict__ Lb, const double* __restrict__ Z) {
+__device__ __forceinline__ void part_reduce_rhs(const PartView& pv, int ncols, const double* __restrict__ Lb, const double* __restrict__ Z, int t, int e0, int estride) {
+  const int s3 = pv.s3;
+  const int c0 = pv.tc0[t], pl = pv.tpl[t], pr = pv.tpr[t], gq = pv.tgq[t];
+  const bool own = pv.town[t] != 0;
+  const int a0 = pl >= 0 ? pv.i0[pl] : 0, a1 = pl >= 0 ? pv.i1[pl] : 0;
+  const int b0 = pr >= 0 ? pv.i0[pr] : 0, b1 = pr >= 0 ? pv.i1[pr] : 0;
+  for (int e = e0; e < s3 * ncols; e += estride) {
+    const int a = e / ncols, col = e % ncols;
+    double r = own ? Z[(long long)(c0 + a) * ncols + col] : 0.0;
+#pragma unroll
+    for (int jj = 0; jj < BW; ++jj) {
+      const int i = a1 - BW + jj;
+      if (pl >= 0 && i >= a0) r -= band_entry<BW>(Lb, i, c0 + a) * Z[(long long)i * ncols + col];
+    }
+#pragma unroll
+    for (int jj = 0; jj < BW; ++jj) {
+      const int i = b0 + jj;
+      if (pr >= 0 && i < b1) r -= band_entry<BW>(Lb, i, c0 + a) * Z[(long long)i * ncols + col];
+    }
+    pv.R[((long long)gq * s3 + a) * ncols + col] = r;
+  }
+}
+// what: 1 = the matrix blocks T, U (workgroups with blockIdx.y == 0), 2 = the right-hand sides, 3 = both
+template <int BW>
+__global__ __launch_bounds__(256) void k_part_reduce(PartView pv, int ncols, const double* __restrict__ Lb, const double* __restrict__ Z, int what = 3) {
   const int t = blockIdx.x, s3 = pv.s3, st = 2 * s3;
   const int c0 = pv.tc0[t], pl = pv.tpl[t], pr = pv.tpr[t], gq = pv.tgq[t];
   const bool own = pv.town[t] != 0;
@@ -886,7 +911,7 @@ __global__ __launch_bounds__(256) void k_part_reduce(PartView pv, int ncols, con
   // loops run over exactly BW rows with the out-of-range ones masked, so that all their loads are issued together
   const double* VWa = pv.VW + ((long long)(pl >= 0 ? pl : 0) * kPartRowsMax) * st;
   const double* VWb = pv.VW + ((long long)(pr >= 0 ? pr : 0) * kPartRowsMax) * st;
-  for (int e = threadIdx.x; blockIdx.y == 0 && e < s3 * s3; e += blockDim.x) {
+  for (int e = threadIdx.x; (what & 1) && blockIdx.y == 0 && e < s3 * s3; e += blockDim.x) {
     const int a = e / s3, b = e % s3;
     double tt = own ? band_entry<BW>(Lb, c0 + a, c0 + b) : 0.0, u = 0.0;
 #pragma unroll
@@ -907,21 +932,7 @@ __global__ __launch_bounds__(256) void k_part_reduce(PartView pv, int ncols, con
     pv.U[((long long)gq * s3 + a) * s3 + b] = (gq + 1 < pv.m) ? u : 0.0;
   }
   // the right-hand sides: gridDim.y workgroups per separator share the entries (few dependent load rounds each)
-  for (int e = blockIdx.y * blockDim.x + threadIdx.x; e < s3 * ncols; e += gridDim.y * blockDim.x) {
-    const int a = e / ncols, col = e % ncols;
-    double r = own ? Z[(long long)(c0 + a) * ncols + col] : 0.0;
-#pragma unroll
-    for (int jj = 0; jj < BW; ++jj) {
-      const int i = a1 - BW + jj;
-      if (pl >= 0 && i >= a0) r -= band_entry<BW>(Lb, i, c0 + a) * Z[(long long)i * ncols + col];
-    }
-#pragma unroll
-    for (int jj = 0; jj < BW; ++jj) {
-      const int i = b0 + jj;
-      if (pr >= 0 && i < b1) r -= band_entry<BW>(Lb, i, c0 + a) * Z[(long long)i * ncols + col];
-    }
-    pv.R[((long long)gq * s3 + a) * ncols + col] = r;
-  }
+  if (what & 2) part_reduce_rhs<BW>(pv, ncols, Lb, Z, t, (int)(blockIdx.y * blockDim.x + threadIdx.x), (int)(gridDim.y * blockDim.x));
 }
 
 // block-tridiagonal Cholesky of the separator system by ONE wavefront (no workgroup barriers needed between
@@ -1247,9 +1258,8 @@ __global__ __launch_bounds__(64) void k_sep_bcr_level(PartView pv, int h, int* _
 // the remaining levels from stride h0 on, one workgroup: a wavefront per survivor, one barrier per level
 constexpr int bcr_tail_waves(int s3) { return s3 > 9 ? kBcrWaves / 2 : kBcrWaves; }
 template <int S3>
-__global__ __launch_bounds__(bcr_tail_waves(S3) * 64) void k_sep_bcr_tail(PartView pv, int h0, int* __restrict__ fail) {
+__device__ __forceinline__ void bcr_tail_body(const PartView& pv, int h0, int* __restrict__ fail, double* __restrict__ w) {
   constexpr int NW = bcr_tail_waves(S3);
-  __shared__ double w[NW * 3 * S3 * S3];
   const int wave = threadIdx.x >> 6;
   for (int h = h0; h <= pv.m; h <<= 1) {
     const int ns = pv.m / (2 * h), nt = ns > 0 ? ns : 1;
@@ -1268,6 +1278,21 @@ __global__ __launch_bounds__(bcr_tail_waves(S3) * 64) void k_sep_bcr_tail(PartVi
     if (threadIdx.x == 0) printf("bcr tail h=%d ns=%d: %lld cycles\n", h, ns, clock64() - p0_);
 #endif
   }
+}
+template <int S3>
+__global__ __launch_bounds__(bcr_tail_waves(S3) * 64) void k_sep_bcr_tail(PartView pv, int h0, int* __restrict__ fail) {
+  __shared__ double w[bcr_tail_waves(S3) * 3 * S3 * S3];
+  bcr_tail_body<S3>(pv, h0, fail, w);
+}
+// The last levels of the cyclic reduction run in ONE workgroup (29 us of barriers); the right-hand sides of the separator system
+// (k_part_reduce's second half, ~12 us over ~460 workgroups) need nothing from it: same launch, workgroup 0 = the tail.
+template <int BW, int S3>
+__global__ __launch_bounds__(bcr_tail_waves(S3) * 64) void k_bcr_tail_and_reduce_rhs(PartView pv, int h0, int run_tail, int* __restrict__ fail, int ncols,
+                                                                                    const double* __restrict__ Lb, const double* __restrict__ Z, int ny) {
+  __shared__ double w[bcr_tail_waves(S3) * 3 * S3 * S3];
+  if (blockIdx.x == 0) { if (run_tail) bcr_tail_body<S3>(pv, h0, fail, w); return; }
+  const int idx = (int)blockIdx.x - 1, t = idx / ny, by = idx % ny;
+  part_reduce_rhs<BW>(pv, ncols, Lb, Z, t, (int)(by * blockDim.x + threadIdx.x), (int)(ny * blockDim.x));
 }
 
 constexpr int kBcrCols = 1;       // columns per workgroup (one: more workgroups, fewer items per level and thread)
@@ -1963,8 +1988,14 @@ struct HipSchur {
 
   // x_fused != nullptr: the detection rows' Jacobian is evaluated inside the assembly kernel at x_fused (no J in memory);
   // the motion rows (O(T), tiny) still go through k_motion
+  // the storage the assembly adds into; the LM driver has it zeroed beside its first residual evaluation (mark_cleared)
+  bool ne_cleared = false;
+  double* clear_ptr() { return NE; }
+  int64_t clear_len() const { return (int64_t)(ne_count + n_apart); }
+  void mark_cleared() { ne_cleared = true; }
   void assemble_local(const double* f_dev, const double* x_fused = nullptr) {
-    be.fill(NE, 0.0, (int64_t)(ne_count + n_apart));      // one launch (hipMemsetAsync splits 36 MB into two fill kernels)
+    if (!ne_cleared) be.fill(NE, 0.0, (int64_t)(ne_count + n_apart));      // one launch (hipMemsetAsync splits 36 MB into two fill kernels)
+    ne_cleared = false;
     if (be.dp.n_chunks > 0) {
       const int nc = be.dp.n_chunks;
       const dim3 g(kGaParts * nc), b(kGaThreads);
@@ -2046,13 +2077,18 @@ struct HipSchur {
     hipLaunchKernelGGL(k_part_solve<BWT>, dim3(xcd_grid(pv.P * (int)gsolve.y)), dim3(64), 0, be.stream, pv, ncols, Lb, Z, (int)gsolve.y);
     if (pv.m > 0) {
       if (shard) MVUS_HIP(hipMemsetAsync(sepbuf, 0, sep_count * sizeof(double), be.stream));      // other ranks' separators: zero here
-      if (pv.nt > 0) hipLaunchKernelGGL(k_part_reduce<BWT>, dim3(pv.nt, (pv.s3 * ncols + 255) / 256), dim3(256), 0, be.stream, pv, ncols, Lb, Z);
+      // one rank, cyclic reduction: only the matrix blocks first; the right-hand sides ride beside the one-workgroup tail
+      const bool split = overlap_chol && !shard && use_bcr && pv.nt > 0;
+      if (pv.nt > 0) hipLaunchKernelGGL(k_part_reduce<BWT>, dim3(pv.nt, split ? 1 : (pv.s3 * ncols + 255) / 256), dim3(256), 0, be.stream, pv, ncols, Lb, Z, split ? 1 : 3);
       if (shard) be.reduce(sepbuf, sep_count);        // every rank now holds the whole separator system
       if (use_bcr) {
         int h = 1;                                        // wide levels: a launch each; the rest in one workgroup
         for (; h <= pv.m && pv.m / (2 * h) > kBcrTailNs; h <<= 1)
           hipLaunchKernelGGL(k_sep_bcr_level<S3T>, dim3(pv.m / (2 * h)), dim3(64), 0, be.stream, pv, h, fail);
-        if (h <= pv.m) hipLaunchKernelGGL(k_sep_bcr_tail<S3T>, dim3(1), dim3(bcr_tail_waves(S3T) * 64), 0, be.stream, pv, h, fail);
+        if (split) {
+          const int tb = bcr_tail_waves(S3T) * 64, ny = (pv.s3 * ncols + tb - 1) / tb;
+          hipLaunchKernelGGL((k_bcr_tail_and_reduce_rhs<BWT, S3T>), dim3(1 + pv.nt * ny), dim3(tb), 0, be.stream, pv, h, (int)(h <= pv.m), fail, ncols, Lb, Z, ny);
+        } else if (h <= pv.m) hipLaunchKernelGGL(k_sep_bcr_tail<S3T>, dim3(1), dim3(bcr_tail_waves(S3T) * 64), 0, be.stream, pv, h, fail);
         if (bcr_cols == kBcrCols) hipLaunchKernelGGL((k_sep_bcr_rhs<S3T, kBcrCols>), dim3((ncols + kBcrCols - 1) / kBcrCols), dim3(256), bcr_lds, be.stream, pv, ncols);
         else hipLaunchKernelGGL((k_sep_bcr_rhs<S3T, 1>), dim3(ncols), dim3(256), bcr_lds, be.stream, pv, ncols);
       } else {

@@ -52,7 +52,7 @@ struct HostBackend {
   const double* ub_ptr() const { return ubv.data(); }
   double* lm_scalars() { return lm_s; }
   void dot_m_into(const double* a, const double* b, double* out) { *out = dot_m(a, b); }
-  void residual_sq(const double* x, double* f, double* out) { residual(x, f); dot_m_into(f, f, out); }
+  bool residual_sq(const double* x, double* f, double* out, double* = nullptr, int64_t = 0) { residual(x, f); dot_m_into(f, f, out); return false; }
   void lm_gnorm(const double* x, const double* lb, const double* ub, const double* g, double* out) { *out = mvus::lm_gnorm_host(hp.n, x, lb, ub, g); }
   void lm_trial(const double* x, const double* p, const double* lb, const double* ub, const double* g, const double* D,
                 const int* fail, double* x_new, double* out, double* gn, double*) { mvus::lm_trial_host(hp.n, x, p, lb, ub, g, D, *fail, x_new, out, gn); }
