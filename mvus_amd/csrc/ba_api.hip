@@ -302,7 +302,8 @@ struct HipBackend {
     const unsigned g2 = hp.n > 2048 && hp.n <= (1 << 17) ? (unsigned)std::min<int64_t>(32, (hp.n + 1023) / 1024) : 0u;
     if (g2 > 1) {
       hipLaunchKernelGGL(k_lm_trial, dim3(g2), dim3(1024), 0, stream, (int)hp.n, x, p, lb, ub, g, D, fail, x_new, out, gnorm_out, partials, (unsigned*)nullptr, x_mirror);
-      hipLaunchKernelGGL(k_lm_trial_sum, dim3(1), dim3(64), 0, stream, (int)g2, partials, out, gnorm_out);
+      hipLaunchKernelGGL(k_lm_trial_sum, dim3(1), dim3(64), 0, stream, (int)g2, partials, out, gnorm_out, dp, (const double*)x_new, cams);
+      cams_for = x_new;                      // decoded by that launch: the trial residual needs no k_cam_states
       return;
     }
     hipLaunchKernelGGL(k_lm_trial, dim3(lm_grid()), dim3(1024), 0, stream, (int)hp.n, x, p, lb, ub, g, D, fail, x_new, out, gnorm_out, partials, lm_counter, x_mirror);

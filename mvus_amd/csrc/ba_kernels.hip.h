@@ -927,7 +927,16 @@ __global__ __launch_bounds__(1024) void k_lm_trial(int n, const double* __restri
 }
 
 // second stage of k_lm_trial launched over several workgroups with counter == nullptr: the five partials per workgroup -> out
-__global__ __launch_bounds__(64) void k_lm_trial_sum(int nparts, const double* __restrict__ part, double* __restrict__ out, double* __restrict__ gnorm_out) {
+// cams != nullptr: the workgroup also decodes the camera states of the trial point (complete in memory by now) for the residual
+// evaluation that follows -- k_cam_states' work without its launch
+__global__ __launch_bounds__(64) void k_lm_trial_sum(int nparts, const double* __restrict__ part, double* __restrict__ out, double* __restrict__ gnorm_out,
+                                                     DevProblem dp, const double* __restrict__ x_new, CamState* __restrict__ cams) {
+  if (cams != nullptr)
+    for (int c = threadIdx.x; c < dp.C; c += 64) {
+      CamState s;
+      load_cam_state(x_new, dp.C, c, dp.calib != 0, dp.Kfix, dp.dfix, dp.H[c], s);
+      cams[c] = s;
+    }
   if (threadIdx.x >= 5) return;
   double t = 0.0;
   for (int b = 0; b < nparts; ++b) {
