@@ -357,12 +357,16 @@ def test_fd_mode_ba_vs_reference_result(BAHandle, name):
     flips = int(np.sum(keep.astype(np.uint8) != g['outlier_keep']))
     print('FD 10 evaluations %s: cost rel %.2e, rmse %.2e px, %d mask flips' % (name, d_cost, d_rmse, flips))
     # The unconverged 10-evaluation iterate is chaotic in the last bits of LSMR's sums (run to run it is reproducible here:
-    # J^T u is summed in a fixed order, k_jtu_partial / k_jtu_reduce).  Measured on MI355X: cost 3e-5 / 1e-5 / 2e-3 / 6e-4
-    # relative, RMSE 3e-4 / 2e-5 / 1e-2 / 1e-2 px, 12 / 0 / 22 / 1 mask flips of 1000-2200 detections; with atomics in
+    # J^T u is summed in a fixed order, k_jtu_partial / k_jtu_reduce).  Measured on MI355X: cost 2e-5 / 1e-5 / 1.5e-3 / 4e-4
+    # relative, RMSE 2e-4 / 2e-5 / 9e-3 / 1e-2 px, 13 / 0 / 29 / 1 mask flips of 1000-2200 detections; with atomics in
     # J^T u (round 1) the same quantities moved by that much from run to run.  The decidable comparison is the converged one.
-    assert d_cost < 5e-3
-    assert d_rmse < 3e-2
-    assert flips <= 0.02 * keep.size, flips
+    # bars = those measured values x ~3 (the iterate is deterministic on the GPU; the margin is for changes of summation order)
+    cost_tol = {'c1_pinhole_2cam': 1e-4, 'rs_F_2int_3cam': 5e-5, 'calib_KE_bounds_3cam': 5e-3, 'dist_fixed_2cam': 1.5e-3}[name]
+    rmse_tol = {'c1_pinhole_2cam': 1e-3, 'rs_F_2int_3cam': 1e-4, 'calib_KE_bounds_3cam': 3e-2, 'dist_fixed_2cam': 3e-2}[name]
+    flip_tol = {'c1_pinhole_2cam': 30, 'rs_F_2int_3cam': 2, 'calib_KE_bounds_3cam': 60, 'dist_fixed_2cam': 4}[name]
+    assert d_cost < cost_tol
+    assert d_rmse < rmse_tol
+    assert flips <= flip_tol, flips
 
 
 @pytest.mark.parametrize('name', CONVERGED_CASES)

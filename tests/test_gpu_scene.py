@@ -56,11 +56,13 @@ def test_ba_outliers_ba_sequence(name, mode):
     s.remove_outliers(s.sequence[:C], thres=st['thres_outlier'])
     removed = n_before - sum(d.shape[1] for d in s.detections)
     ref_removed = int((g['outlier_keep'] == 0).sum())
-    # Both runs stop UNCONVERGED after 10 evaluations, so this is a plumbing check with loose bounds; the decidable
-    # comparison is test_converged_second_ba_through_the_scene below.  Measured on MI355X, removed here / by the reference:
-    # default 125/126, 40/40, 100/78, 59/58; lm (another optimiser, another 10-evaluation iterate) 160/126, 40/40, 74/78, 43/58
-    if mode == 'default' and not loose:
-        assert abs(removed - ref_removed) <= 4                       # measured: -3, 0, +1 -- the same outliers, to the borderline ones
+    # Both runs stop UNCONVERGED after 10 evaluations (the decidable comparison is test_converged_second_ba_through_the_scene below),
+    # so the bars are the values measured on MI355X plus the chaos margin of an unconverged iterate, per scene.  Removed here /
+    # by the reference -- default (the reference's algorithm): 123/126, 40/40, 87/78, 60/58; lm (another optimiser, another
+    # 10-evaluation iterate): 156/126, 40/40, 90/78, 64/58
+    removed_tol = {'c1_pinhole_2cam': 5, 'rs_F_2int_3cam': 1, 'calib_KE_bounds_3cam': 14, 'dist_fixed_2cam': 4}[name]
+    if mode == 'default':
+        assert abs(removed - ref_removed) <= removed_tol
     else:
         assert abs(removed - ref_removed) <= max(3, 0.4 * ref_removed)
     assert s._ba_handle is handle and handle.M == sum(d.shape[1] for d in s.detections)    # filtered in place on the GPU
@@ -74,12 +76,16 @@ def test_ba_outliers_ba_sequence(name, mode):
     # Final answer of the pipeline after 10 + 10 evaluations, on (slightly) different inlier sets.  With motion_reg the cost
     # trades reprojection error against the heavily weighted motion term, so the RMSE bound is one-sided and loose there.
     assert res2.cost < res2.initial_cost
-    # measured second-BA cost / reference: parity 0.996, 1.000, (calib) ..., 1.17; default <= 1.09
-    # (the calib + KE + bounds scene is the one whose 10-evaluation iterate the reference itself does not reproduce:
-    # 2.2x the reference's cost in parity mode here, 1.09x in default mode; no bound beyond "it descends" is meaningful)
-    if not loose:
-        assert res2.cost < float(g['ba2_10_cost']) * 1.4
-        assert rmse < float(g['ba2_10_rmse']) * (2.0 if st['motion_reg'] else 1.15) + 1e-3
+    # measured, second-BA cost / reference and RMSE - reference: default 0.9998 / -6e-4, 1.0001 / +1e-3, 1.119 / +0.13 (the ill-posed
+    # calibration scene, whose 10-evaluation iterate the reference itself does not reproduce), 1.062 / +0.019; lm 0.94, 0.93, 1.07, 0.99
+    cost_ratio = {'c1_pinhole_2cam': 1.005, 'rs_F_2int_3cam': 1.005, 'calib_KE_bounds_3cam': 1.25, 'dist_fixed_2cam': 1.1}[name]
+    rmse_margin = {'c1_pinhole_2cam': 5e-3, 'rs_F_2int_3cam': 5e-3, 'calib_KE_bounds_3cam': 0.25, 'dist_fixed_2cam': 0.04}[name]
+    if mode == 'default':
+        assert res2.cost < float(g['ba2_10_cost']) * cost_ratio
+        assert rmse < float(g['ba2_10_rmse']) + rmse_margin
+    else:
+        assert res2.cost < float(g['ba2_10_cost']) * 1.15
+        assert rmse < float(g['ba2_10_rmse']) * (1.15 if st['motion_reg'] else 1.02) + 1e-3
     assert np.all(np.isfinite(s.alpha)) and len(s.detections_global) == C
     if st['motion_reg']:
         assert s.global_traj.shape[0] == 7 and s.traj.shape[0] == 4                 # attributes the pickle carries
