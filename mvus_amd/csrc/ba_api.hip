@@ -1194,6 +1194,7 @@ int mvus_spline_smooth(int32_t device, int64_t m, const double* u, const double*
     int32_t* span = cb.get<int32_t>((size_t)m);
     double* q = cb.get<double>(4 * (size_t)m);
     double* term = cb.get<double>((size_t)m);
+    double* tot_part = cb.get<double>(1024);
     // Everything indexed by knots is sized by a CAPACITY that grows with the knot count (x4, up to FITPACK's nest = m + 6), not
     // by nest: the trajectories traj_to_spline fits are 50x oversampled (560k samples for ~600 knots), and allocating and
     // freeing ~40 arrays of nest doubles (430 MB with the double-double set) cost 70 of the 77 ms of such a fit
@@ -1228,7 +1229,13 @@ int mvus_spline_smooth(int32_t device, int64_t m, const double* u, const double*
     auto blocks = fit_blocks;
     auto residual = [&](int ncoef, bool spans, int nspan) {            // c -> f_p (and the per-span residuals), fetched
       hipLaunchKernelGGL(k_fit_residual, blocks(m), dim3(256), 0, cb.st, (long long)m, ncoef, span, q, dX, cd, term);
-      hipLaunchKernelGGL(k_fit_total, dim3(1), dim3(256), 0, cb.st, (long long)m, term, out + 1);
+      if (m > 8192) {                                                 // two stages (still one fixed order)
+        const int nbt = (int)std::min<long long>(1024, (m + 2047) / 2048);
+        hipLaunchKernelGGL(k_fit_total_partial, dim3(nbt), dim3(256), 0, cb.st, (long long)m, term, tot_part);
+        hipLaunchKernelGGL(k_fit_total, dim3(1), dim3(256), 0, cb.st, (long long)nbt, tot_part, out + 1);
+      } else {
+        hipLaunchKernelGGL(k_fit_total, dim3(1), dim3(256), 0, cb.st, (long long)m, term, out + 1);
+      }
       if (spans) hipLaunchKernelGGL(k_fit_fpint, dim3(nspan), dim3(256), 0, cb.st, nspan, first, term, out + 4);
       MVUS_HIP(hipGetLastError());
       MVUS_HIP(hipMemcpyAsync(host.data(), out, sizeof(double) * (4 + (spans ? nspan : 0)), hipMemcpyDeviceToHost, cb.st));

@@ -339,7 +339,15 @@ __global__ __launch_bounds__(256) void k_fit_fpint(int nspan, const long long* _
   }
 }
 
-// total of `count` values, one workgroup, fixed order
+// total of `count` values in a fixed order: per-workgroup partial sums (grid-stride), then one workgroup over the partials
+// (k_fit_total with `count` = the number of partials).  One workgroup over 550k samples took 517 us a pass -- 65 % of a fit.
+__global__ __launch_bounds__(256) void k_fit_total_partial(long long count, const double* __restrict__ v_in, double* __restrict__ part) {
+  __shared__ double lds[256];
+  double v[1] = {0.0};
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < count; i += (long long)gridDim.x * 256) v[0] += v_in[i];
+  block_sum<1>(v, lds);
+  if (threadIdx.x == 0) part[blockIdx.x] = v[0];
+}
 __global__ __launch_bounds__(256) void k_fit_total(long long count, const double* __restrict__ v_in, double* __restrict__ out) {
   __shared__ double lds[256];
   double v[1] = {0.0};
