@@ -632,32 +632,54 @@ struct CallBuffers {
 // device work arrays of the smoothing fit in one precision (double, or double-double for ill-conditioned knot sets)
 template <class T>
 struct FitWork {
-  T *SB = nullptr, *G5 = nullptr, *BtB = nullptr, *Mx = nullptr, *Lf = nullptr, *rhs = nullptr, *yw = nullptr;
+  T *SB = nullptr, *G5 = nullptr, *BtB = nullptr, *Mx = nullptr, *Lf = nullptr, *rhs = nullptr, *yw = nullptr, *YL = nullptr, *parts = nullptr;
   bool ready = false, penalty = false;
   void alloc(CallBuffers& cb, size_t nest) {
     if (ready) return;
     SB = cb.get<T>((size_t)kFitBlk * nest); G5 = cb.get<T>(5 * nest); BtB = cb.get<T>(5 * nest); Mx = cb.get<T>(5 * nest);
     Lf = cb.get<T>(5 * nest); rhs = cb.get<T>(3 * nest); yw = cb.get<T>(3 * nest);
+    YL = cb.get<T>(4 * nest); parts = cb.get<T>((size_t)kBandPartsWork);
     ready = true;
   }
 };
+// systems of at least this many rows go to k_band_solve_parts (MVUS_BAND_PARTS_MIN: the tests push the small fixtures through it too)
+static int band_parts_min() {
+  static const int v = [] { const char* e = std::getenv("MVUS_BAND_PARTS_MIN"); return e ? std::max(16, std::atoi(e)) : 192; }();
+  return v;
+}
+// banded solve of the pass; returns true when the factor's diagonal in out[0] is FITPACK's (one chain in the natural order)
+template <int HB, class T>
+static bool fit_band_solve(hipStream_t st, FitWork<T>& w, int ncoef, const T* Mband, double* cd, double* out, int* fail) {
+  const BandParts bp = band_parts(ncoef, HB, band_parts_min());
+  if (bp.P < 2) {
+    hipLaunchKernelGGL((k_band_solve<HB, T>), dim3(1), dim3(64), 0, st, ncoef, Mband, w.rhs, w.Lf, w.yw, cd, out, fail);
+    return true;
+  }
+  hipLaunchKernelGGL((k_band_solve_parts<HB, T>), dim3(1), dim3(64 * ((bp.P + 63) / 64)), 0, st, ncoef, bp, Mband, w.rhs, w.Lf, w.yw, w.YL, w.parts, cd, out, fail);
+  return false;
+}
 static dim3 fit_blocks(long long cnt) { return dim3((unsigned)((cnt + 255) / 256)); }
 // least-squares spline on the current knots: normal equations from the span blocks, banded Cholesky, coefficients -> cd
 template <class T>
-static void fit_lsq_pass(hipStream_t st, FitWork<T>& w, long long m, const long long* first, const double* q, const double* dX, int ncoef, int nrint,
+static bool fit_lsq_pass(hipStream_t st, FitWork<T>& w, long long m, const long long* first, const double* q, const double* dX, int ncoef, int nrint,
                          double* cd, double* out, int* fail) {
   constexpr int NT = sizeof(T) == sizeof(double) ? 256 : 64;
   hipLaunchKernelGGL((k_fit_blocks<T, NT>), dim3(nrint), dim3(NT), 0, st, m, first, q, dX, w.SB);
   hipLaunchKernelGGL(k_fit_band<T>, fit_blocks(ncoef), dim3(256), 0, st, ncoef, nrint, w.SB, w.G5, w.rhs);
-  hipLaunchKernelGGL((k_band_solve<3, T>), dim3(1), dim3(64), 0, st, ncoef, w.G5, w.rhs, w.Lf, w.yw, cd, out, fail);
   w.penalty = false;
+  return fit_band_solve<3, T>(st, w, ncoef, w.G5, cd, out, fail);
+}
+// the sum of the factor's diagonal in the natural elimination order (fppara's initial p) when the last pass was partitioned
+template <class T>
+static void fit_lsq_diag(hipStream_t st, FitWork<T>& w, int ncoef, double* cd, double* out, int* fail) {
+  hipLaunchKernelGGL((k_band_solve<3, T>), dim3(1), dim3(64), 0, st, ncoef, w.G5, w.rhs, w.Lf, w.yw, cd, out, fail);
 }
 // smoothing spline for one value of p on the same knots (fit_lsq_pass has run in this precision)
 template <class T>
 static void fit_smooth_pass(hipStream_t st, FitWork<T>& w, int ncoef, int n8, const double* bd, double pinv, double* cd, double* out, int* fail) {
   if (!w.penalty) { hipLaunchKernelGGL(k_fit_penalty<T>, fit_blocks(ncoef), dim3(256), 0, st, ncoef, n8, bd, w.BtB); w.penalty = true; }
   hipLaunchKernelGGL(k_fit_combine<T>, fit_blocks(5ll * ncoef), dim3(256), 0, st, 5ll * ncoef, w.G5, w.BtB, pinv, w.Mx);
-  hipLaunchKernelGGL((k_band_solve<4, T>), dim3(1), dim3(64), 0, st, ncoef, w.Mx, w.rhs, w.Lf, w.yw, cd, out, fail);
+  fit_band_solve<4, T>(st, w, ncoef, w.Mx, cd, out, fail);
 }
 
 template <class F>
@@ -1204,6 +1226,7 @@ int mvus_spline_smooth(int32_t device, int64_t m, const double* u, const double*
     FitWork<double> w1;
     FitWork<dd> w2;
     bool precise = false;                                  // double-double from the first ill-conditioned pass on
+    bool diag_natural = true;                              // out[0] of the last least-squares pass is the sum FITPACK forms (see fit_band_solve)
     int lsq_dd_n = -1;                                     // knot count whose normal equations w2 holds
     MVUS_HIP(hipMemsetAsync(fail, 0, sizeof(int), cb.st));
     std::vector<double> t, fpint, host, b;
@@ -1248,11 +1271,11 @@ int mvus_spline_smooth(int32_t device, int64_t m, const double* u, const double*
     auto solve = [&](int ncoef, int nrint_, int n8, bool smoothing, double pinv) {
       for (int attempt = 0; attempt < 2; ++attempt) {
         if (!precise) {
-          if (!smoothing) fit_lsq_pass<double>(cb.st, w1, (long long)m, first, q, dX, ncoef, nrint_, cd, out, fail);
+          if (!smoothing) diag_natural = fit_lsq_pass<double>(cb.st, w1, (long long)m, first, q, dX, ncoef, nrint_, cd, out, fail);
           else fit_smooth_pass<double>(cb.st, w1, ncoef, n8, bd, pinv, cd, out, fail);
         } else {
           w2.alloc(cb, cap);
-          if (lsq_dd_n != n) { fit_lsq_pass<dd>(cb.st, w2, (long long)m, first, q, dX, ncoef, nrint_, cd, out, fail); lsq_dd_n = n; }
+          if (lsq_dd_n != n) { diag_natural = fit_lsq_pass<dd>(cb.st, w2, (long long)m, first, q, dX, ncoef, nrint_, cd, out, fail); lsq_dd_n = n; }
           if (smoothing) fit_smooth_pass<dd>(cb.st, w2, ncoef, n8, bd, pinv, cd, out, fail);
         }
         residual(ncoef, !smoothing, nrint_);
@@ -1291,6 +1314,13 @@ int mvus_spline_smooth(int32_t device, int64_t m, const double* u, const double*
         const int n8 = n - nmin;
         MVUS_HIP(hipMemcpyAsync(bd, b.data(), sizeof(double) * b.size(), hipMemcpyHostToDevice, cb.st));
         double p1 = 0.0, f1 = fp0 - s, p3 = -1.0, f3 = fpms;
+        if (!diag_natural) {                               // the pass above was partitioned: one chain over the same normal equations for sum a(i,1)
+          if (precise) fit_lsq_diag<dd>(cb.st, w2, ncoef, cd, out, fail); else fit_lsq_diag<double>(cb.st, w1, ncoef, cd, out, fail);
+          MVUS_HIP(hipGetLastError());
+          MVUS_HIP(hipMemcpyAsync(host.data(), out, sizeof(double), hipMemcpyDeviceToHost, cb.st));
+          MVUS_HIP(hipMemsetAsync(fail, 0, sizeof(int), cb.st));
+          MVUS_HIP(hipStreamSynchronize(cb.st));
+        }
         p = (double)ncoef / host[0];
         int ich1 = 0, ich3 = 0;
         for (int iter = 1; iter <= maxit; ++iter) {

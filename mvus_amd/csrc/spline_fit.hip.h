@@ -304,6 +304,441 @@ __global__ __launch_bounds__(64) void k_band_solve(int n, const T* __restrict__ 
   }
 }
 
+#endif
+// ---- the same systems, partitioned --------------------------------------------------------------------------------------
+// k_band_solve is one dependent chain of n rows (0.4 us a row in fp64, 4.8 us in double-double: 31 ms for the 6 500 coefficients
+// of a 3.3 M-sample trajectory, and ~50 such solves per fit).  k_band_solve_parts cuts the rows into P interiors separated by
+// P - 1 separators of HB rows (interiors do not couple: half-bandwidth <= HB), one LANE per interior:
+//   phase 1  every lane factors its interior A_p = L L^T and forward-solves the coupling columns to the separator on its left
+//            (Y_L, dense), to the one on its right (Y_R, last HB rows only) and the three right-hand sides (y); what the
+//            interior contributes to the separator system (Y^T Y, Y^T y) goes to a record per interior
+//   phase 2  one lane: block-tridiagonal Cholesky of the separator system (HB x HB blocks), both substitutions
+//   phase 3  every lane: L^T x = y - Y_L x_left - Y_R x_right
+// One workgroup (P <= 256 lanes), __syncthreads between the phases.  The elimination ORDER differs from k_band_solve's, so
+// the factor's diagonal is not FITPACK's a(i,1): out[0] is not written; the caller runs k_band_solve once per fit where
+// fppara needs that sum (the initial p).  out[2], out[3] = smallest / largest pivot of all the factors (same use as before).
+struct BandParts {
+  int P = 1, len = 0, rem = 0, HB = 3;       // interior p: rows [first(p), first(p) + length(p)), then HB separator rows
+  MVUS_HD int length(int p) const { return len + (p < rem ? 1 : 0); }
+  MVUS_HD int first(int p) const { return p * (len + HB) + (p < rem ? p : rem); }
+};
+inline BandParts band_parts(int n, int HB, int min_rows) {
+  BandParts bp;
+  bp.HB = HB;
+  if (n < min_rows) return bp;
+  int P = (int)std::sqrt((double)n / 2.5);
+  P = std::max(2, std::min(256, P));
+  while (P > 1 && (n - (P - 1) * HB) / P < 2 * HB) --P;
+  if (P < 2) return bp;
+  bp.P = P;
+  bp.len = (n - (P - 1) * HB) / P;
+  bp.rem = (n - (P - 1) * HB) - bp.len * P;
+  return bp;
+}
+MVUS_HD double num_recip(double a) { return 1.0 / a; }
+MVUS_HD dd num_recip(dd a) {                        // one Newton step on the fp64 reciprocal: r0 + r0 (1 - a r0)
+  MVUS_NO_CONTRACT
+  const double r0 = 1.0 / a.hi;
+  dd p = dd_two_prod(a.hi, r0);
+  p.lo += a.lo * r0;
+  const dd e = dd(1.0) - dd_quick(p.hi, p.lo);
+  return dd_two_sum(r0, r0 * (e.hi + e.lo));
+}
+
+#if defined(__HIPCC__)
+template <int HB> struct BandRec {                  // per interior (T units)
+  static constexpr int GLL = 0, GRR = HB * HB, C = 2 * HB * HB, YR = 3 * HB * HB, GL = 4 * HB * HB, GR = 4 * HB * HB + 3 * HB, SIZE = 4 * HB * HB + 6 * HB;
+};
+template <int HB> struct BandSep {                  // per separator (T units): its Cholesky block, the coupling W to the next one, z, x
+  static constexpr int LT = 0, W = HB * HB, Z = 2 * HB * HB, X = 2 * HB * HB + 3 * HB, SIZE = 2 * HB * HB + 6 * HB;
+};
+constexpr int kBandPartsMax = 256;
+constexpr int kBandPartsWork = kBandPartsMax * (BandRec<4>::SIZE + BandSep<4>::SIZE);        // T units of `work`
+
+template <class T>
+struct PivotStats {
+  double dsum = 0.0, dmin = 1e300, dmax = 0.0;
+  bool bad = false;
+  // dg = what is left of the diagonal entry `full` after the eliminations: the pivot (floored when lost to rounding, see k_band_solve)
+  __device__ __forceinline__ T pivot(T dg, T full) {
+    const T floor_ = T(pivot_floor(T()) * to_double(full));
+    const bool lost = !(to_double(dg) > to_double(floor_));
+    bad |= lost;
+    dg = lost ? (is_positive(floor_) ? floor_ : T(1.0)) : dg;
+    const T l = num_sqrt(dg);
+    const double dl = to_double(l);
+    dsum += dl; dmin = fmin(dmin, dl); dmax = fmax(dmax, dl);
+    return l;
+  }
+};
+
+template <int HB, class T>
+__global__ __launch_bounds__(kBandPartsMax) void k_band_solve_parts(int n, BandParts bp, const T* __restrict__ M, const T* __restrict__ rhs, T* __restrict__ Lout,
+                                                                    T* __restrict__ ywork, T* __restrict__ YL, T* __restrict__ work, double* __restrict__ c,
+                                                                    double* __restrict__ out, int* __restrict__ fail) {
+  using R = BandRec<HB>;
+  using S = BandSep<HB>;
+  constexpr int NC = HB + 3;                          // forward columns of an interior: HB couplings to the left, 3 right-hand sides
+  const int p = threadIdx.x, P = bp.P;
+  T* rec = work;
+  T* sep = work + (long long)kBandPartsMax * R::SIZE;
+  __shared__ double s_min[kBandPartsMax], s_max[kBandPartsMax];
+  __shared__ int s_bad[kBandPartsMax];
+  PivotStats<T> ps;
+  const int r0 = p < P ? bp.first(p) : 0, lp = p < P ? bp.length(p) : 0;
+  // ---- phase 1 ----
+  if (p < P) {
+    T Lp[HB + 1][HB + 1];                             // Lp[u][w] = L(i-u, i-u-w)
+    T ip[HB + 1];                                     // ip[u] = 1 / L(i-u, i-u)
+    T Yp[HB + 1][NC];                                 // Yp[u][col] = Y(i-u, col)
+    T gll[HB][HB], gl[HB][3];
+#pragma unroll
+    for (int u = 0; u <= HB; ++u) {
+      ip[u] = T(1.0);
+#pragma unroll
+      for (int w = 0; w <= HB; ++w) Lp[u][w] = (w == 0) ? T(1.0) : T(0.0);
+#pragma unroll
+      for (int col = 0; col < NC; ++col) Yp[u][col] = T(0.0);
+    }
+#pragma unroll
+    for (int a = 0; a < HB; ++a) {
+#pragma unroll
+      for (int b = 0; b < HB; ++b) gll[a][b] = T(0.0);
+#pragma unroll
+      for (int d = 0; d < 3; ++d) gl[a][d] = T(0.0);
+    }
+    T nxt[HB + 1], nb[3];
+#pragma unroll
+    for (int w = 0; w <= HB; ++w) nxt[w] = M[5 * (long long)r0 + w];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) nb[d] = rhs[(long long)d * n + r0];
+    for (int i = 0; i < lp; ++i) {
+      const long long j = r0 + i;
+      T row[HB + 1], b[NC];
+#pragma unroll
+      for (int w = 0; w <= HB; ++w) row[w] = nxt[w];
+#pragma unroll
+      for (int col = 0; col < HB; ++col) b[col] = T(0.0);
+#pragma unroll
+      for (int d = 0; d < 3; ++d) b[HB + d] = nb[d];
+      if (i + 1 < lp) {
+#pragma unroll
+        for (int w = 0; w <= HB; ++w) nxt[w] = M[5 * (j + 1) + w];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) nb[d] = rhs[(long long)d * n + j + 1];
+      }
+      if (i < HB) {                                   // M(j, j-w) with i - w < 0 couples to the separator on the left: column i + HB - w of it
+#pragma unroll
+        for (int w = 1; w <= HB; ++w) {
+          if (w > i) {
+#pragma unroll
+            for (int col = 0; col < HB; ++col) if (col == i + HB - w) b[col] = row[w];
+            row[w] = T(0.0);
+          }
+        }
+      }
+#pragma unroll
+      for (int w = HB; w >= 1; --w) {                 // L(i, i-w)
+        T v = row[w];
+#pragma unroll
+        for (int u2 = w + 1; u2 <= HB; ++u2) v -= row[u2] * Lp[w][u2 - w];
+        row[w] = v * ip[w];
+      }
+      const T full = row[0];
+      T dg = row[0];
+#pragma unroll
+      for (int u2 = 1; u2 <= HB; ++u2) dg -= row[u2] * row[u2];
+      row[0] = ps.pivot(dg, full);
+      const T inv = num_recip(row[0]);
+      T y[NC];
+#pragma unroll
+      for (int col = 0; col < NC; ++col) {
+        T v = b[col];
+#pragma unroll
+        for (int u2 = 1; u2 <= HB; ++u2) v -= row[u2] * Yp[u2][col];
+        y[col] = v * inv;
+      }
+#pragma unroll
+      for (int a = 0; a < HB; ++a) {
+#pragma unroll
+        for (int b2 = 0; b2 <= a; ++b2) gll[a][b2] += y[a] * y[b2];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) gl[a][d] += y[a] * y[HB + d];
+      }
+#pragma unroll
+      for (int w = 0; w <= HB; ++w) Lout[5 * j + w] = row[w];
+#pragma unroll
+      for (int col = 0; col < HB; ++col) YL[(long long)HB * j + col] = y[col];
+#pragma unroll
+      for (int d = 0; d < 3; ++d) ywork[(long long)d * n + j] = y[HB + d];
+#pragma unroll
+      for (int u2 = HB; u2 >= 2; --u2) {
+        ip[u2] = ip[u2 - 1];
+#pragma unroll
+        for (int w = 0; w <= HB; ++w) Lp[u2][w] = Lp[u2 - 1][w];
+#pragma unroll
+        for (int col = 0; col < NC; ++col) Yp[u2][col] = Yp[u2 - 1][col];
+      }
+      ip[1] = inv;
+#pragma unroll
+      for (int w = 0; w <= HB; ++w) Lp[1][w] = row[w];
+#pragma unroll
+      for (int col = 0; col < NC; ++col) Yp[1][col] = y[col];
+    }
+    T* rc = rec + (long long)p * R::SIZE;
+#pragma unroll
+    for (int a = 0; a < HB; ++a) {
+#pragma unroll
+      for (int b2 = 0; b2 < HB; ++b2) rc[R::GLL + a * HB + b2] = b2 <= a ? gll[a][b2] : gll[b2][a];
+#pragma unroll
+      for (int d = 0; d < 3; ++d) rc[R::GL + a * 3 + d] = gl[a][d];
+    }
+    if (p + 1 < P) {
+      // separator row r0 + lp + cq couples to the interior row lp - HB + r (window index u = HB - r) through M(., w = HB - r + cq):
+      // Y_R(r, cq), lower triangular in (r, cq)
+      const long long s0 = (long long)r0 + lp;
+      T yr[HB][HB];
+#pragma unroll
+      for (int r = 0; r < HB; ++r) {
+#pragma unroll
+        for (int cq = 0; cq < HB; ++cq) {
+          if (cq <= r) {
+            T v = M[5 * (s0 + cq) + (HB - r + cq)];
+#pragma unroll
+            for (int r2 = 0; r2 < HB; ++r2) if (r2 >= cq && r2 < r) v -= Lp[HB - r][r - r2] * yr[r2][cq];
+            yr[r][cq] = v * ip[HB - r];
+          } else {
+            yr[r][cq] = T(0.0);
+          }
+        }
+      }
+#pragma unroll
+      for (int a = 0; a < HB; ++a) {
+#pragma unroll
+        for (int b2 = 0; b2 < HB; ++b2) {
+          T grr = T(0.0), cc = T(0.0);
+#pragma unroll
+          for (int r = 0; r < HB; ++r) { grr += yr[r][a] * yr[r][b2]; cc += Yp[HB - r][a] * yr[r][b2]; }
+          rc[R::GRR + a * HB + b2] = grr;
+          rc[R::C + a * HB + b2] = cc;                // C(a, b2) = sum_i Y_L(i, a) Y_R(i, b2)
+          rc[R::YR + a * HB + b2] = yr[a][b2];
+        }
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          T g = T(0.0);
+#pragma unroll
+          for (int r = 0; r < HB; ++r) g += yr[r][a] * Yp[HB - r][HB + d];
+          rc[R::GR + a * 3 + d] = g;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  __threadfence_block();
+  // ---- phase 2: the separator system, one lane ----
+  if (p == 0) {
+    T W[HB][HB], z[HB][3];
+    for (int q = 0; q + 1 < P; ++q) {
+      const long long s0 = (long long)bp.first(q) + bp.length(q);
+      const T* ra = rec + (long long)q * R::SIZE;
+      const T* rb = rec + (long long)(q + 1) * R::SIZE;
+      T D[HB][HB], full[HB], r[HB][3];
+#pragma unroll
+      for (int a = 0; a < HB; ++a) {
+#pragma unroll
+        for (int b2 = 0; b2 <= a; ++b2) {
+          T v = M[5 * (s0 + a) + (a - b2)] - ra[R::GRR + a * HB + b2] - rb[R::GLL + a * HB + b2];
+          if (b2 == a) full[a] = M[5 * (s0 + a)];
+          if (q > 0) {
+#pragma unroll
+            for (int k = 0; k < HB; ++k) v -= W[a][k] * W[b2][k];
+          }
+          D[a][b2] = v;
+        }
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          T v = rhs[(long long)d * n + s0 + a] - ra[R::GR + a * 3 + d] - rb[R::GL + a * 3 + d];
+          if (q > 0) {
+#pragma unroll
+            for (int k = 0; k < HB; ++k) v -= W[a][k] * z[k][d];
+          }
+          r[a][d] = v;
+        }
+      }
+      T Lt[HB][HB], il[HB];
+#pragma unroll
+      for (int a = 0; a < HB; ++a) {
+#pragma unroll
+        for (int b2 = 0; b2 < a; ++b2) {
+          T v = D[a][b2];
+#pragma unroll
+          for (int k = 0; k < HB; ++k) if (k < b2) v -= Lt[a][k] * Lt[b2][k];
+          Lt[a][b2] = v * il[b2];
+        }
+        T dg = D[a][a];
+#pragma unroll
+        for (int k = 0; k < HB; ++k) if (k < a) dg -= Lt[a][k] * Lt[a][k];
+        Lt[a][a] = ps.pivot(dg, full[a]);
+        il[a] = num_recip(Lt[a][a]);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          T v = r[a][d];
+#pragma unroll
+          for (int k = 0; k < HB; ++k) if (k < a) v -= Lt[a][k] * z[k][d];
+          z[a][d] = v * il[a];
+        }
+      }
+      T* sq = sep + (long long)q * S::SIZE;
+#pragma unroll
+      for (int a = 0; a < HB; ++a) {
+#pragma unroll
+        for (int b2 = 0; b2 < HB; ++b2) sq[S::LT + a * HB + b2] = b2 < a ? Lt[a][b2] : (b2 == a ? il[a] : T(0.0));    // the diagonal holds 1 / L
+#pragma unroll
+        for (int d = 0; d < 3; ++d) sq[S::Z + a * 3 + d] = z[a][d];
+      }
+      if (q + 2 < P) {                                // W = O Lt^-T, O(cq, cc) = -C_{q+1}(cc, cq): rows = the next separator
+#pragma unroll
+        for (int a = 0; a < HB; ++a) {
+#pragma unroll
+          for (int k = 0; k < HB; ++k) {
+            T v = -rb[R::C + k * HB + a];
+#pragma unroll
+            for (int m2 = 0; m2 < HB; ++m2) if (m2 < k) v -= W[a][m2] * Lt[k][m2];
+            W[a][k] = v * il[k];
+          }
+        }
+#pragma unroll
+        for (int a = 0; a < HB; ++a) {
+#pragma unroll
+          for (int k = 0; k < HB; ++k) sq[S::W + a * HB + k] = W[a][k];
+        }
+      }
+    }
+    T x[HB][3];
+    for (int q = P - 2; q >= 0; --q) {                // x_q = Lt^-T (z_q - W_q^T x_{q+1})
+      T* sq = sep + (long long)q * S::SIZE;
+      T v[HB][3];
+#pragma unroll
+      for (int a = 0; a < HB; ++a) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          T t = sq[S::Z + a * 3 + d];
+          if (q + 2 < P) {
+#pragma unroll
+            for (int k = 0; k < HB; ++k) t -= sq[S::W + k * HB + a] * x[k][d];
+          }
+          v[a][d] = t;
+        }
+      }
+#pragma unroll
+      for (int a = HB - 1; a >= 0; --a) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          T t = v[a][d];
+#pragma unroll
+          for (int k = 0; k < HB; ++k) if (k > a) t -= sq[S::LT + k * HB + a] * x[k][d];
+          x[a][d] = t * sq[S::LT + a * HB + a];
+        }
+      }
+      const long long s0 = (long long)bp.first(q) + bp.length(q);
+#pragma unroll
+      for (int a = 0; a < HB; ++a) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { sq[S::X + a * 3 + d] = x[a][d]; c[(long long)d * n + s0 + a] = to_double(x[a][d]); }
+      }
+    }
+  }
+  __syncthreads();
+  __threadfence_block();
+  // ---- phase 3 ----
+  if (p < P) {
+    T xl[HB][3], xr[HB][3], yr[HB][HB];
+#pragma unroll
+    for (int a = 0; a < HB; ++a) {
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        xl[a][d] = p > 0 ? sep[(long long)(p - 1) * S::SIZE + S::X + a * 3 + d] : T(0.0);
+        xr[a][d] = p + 1 < P ? sep[(long long)p * S::SIZE + S::X + a * 3 + d] : T(0.0);
+      }
+#pragma unroll
+      for (int b2 = 0; b2 < HB; ++b2) yr[a][b2] = p + 1 < P ? rec[(long long)p * R::SIZE + R::YR + a * HB + b2] : T(0.0);
+    }
+    T Ln[HB + 1][HB + 1], cn[HB + 1][3];              // Ln[u][w] = L(i+u, i+u-w), cn[u] = x(i+u)
+#pragma unroll
+    for (int u = 0; u <= HB; ++u) {
+#pragma unroll
+      for (int w = 0; w <= HB; ++w) Ln[u][w] = T(0.0);
+#pragma unroll
+      for (int d = 0; d < 3; ++d) cn[u][d] = T(0.0);
+    }
+    T nrow[HB + 1], nyl[HB], ny[3];
+    auto fetch = [&](long long j) {
+#pragma unroll
+      for (int w = 0; w <= HB; ++w) nrow[w] = Lout[5 * j + w];
+#pragma unroll
+      for (int col = 0; col < HB; ++col) nyl[col] = YL[(long long)HB * j + col];
+#pragma unroll
+      for (int d = 0; d < 3; ++d) ny[d] = ywork[(long long)d * n + j];
+    };
+    fetch((long long)r0 + lp - 1);
+    for (int i = lp - 1; i >= 0; --i) {
+      const long long j = r0 + i;
+      T row[HB + 1], yl[HB], v[3];
+#pragma unroll
+      for (int w = 0; w <= HB; ++w) row[w] = nrow[w];
+#pragma unroll
+      for (int col = 0; col < HB; ++col) yl[col] = nyl[col];
+#pragma unroll
+      for (int d = 0; d < 3; ++d) v[d] = ny[d];
+      if (i > 0) fetch(j - 1);
+      const int rr = i - (lp - HB);                   // row of Y_R (>= 0 in the last HB rows of the interior)
+      const T inv = num_recip(row[0]);
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        T t = v[d];
+#pragma unroll
+        for (int col = 0; col < HB; ++col) t -= yl[col] * xl[col][d];
+        if (rr >= 0) {
+#pragma unroll
+          for (int r = 0; r < HB; ++r) {
+            if (r == rr) {
+#pragma unroll
+              for (int cq = 0; cq < HB; ++cq) t -= yr[r][cq] * xr[cq][d];
+            }
+          }
+        }
+#pragma unroll
+        for (int u2 = 1; u2 <= HB; ++u2) t -= Ln[u2][u2] * cn[u2][d];
+        t = t * inv;
+        v[d] = t;
+        c[(long long)d * n + j] = to_double(t);
+      }
+#pragma unroll
+      for (int u2 = HB; u2 >= 2; --u2) {
+#pragma unroll
+        for (int w = 0; w <= HB; ++w) Ln[u2][w] = Ln[u2 - 1][w];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) cn[u2][d] = cn[u2 - 1][d];
+      }
+#pragma unroll
+      for (int w = 0; w <= HB; ++w) Ln[1][w] = row[w];
+#pragma unroll
+      for (int d = 0; d < 3; ++d) cn[1][d] = v[d];
+    }
+  }
+  s_min[p] = ps.dmin; s_max[p] = ps.dmax; s_bad[p] = ps.bad ? 1 : 0;
+  __syncthreads();
+  if (p == 0) {
+    double mn = 1e300, mx = 0.0;
+    int bad = 0;
+    for (int k = 0; k < (int)blockDim.x; ++k) { mn = fmin(mn, s_min[k]); mx = fmax(mx, s_max[k]); bad |= s_bad[k]; }
+    out[2] = mn; out[3] = mx;
+    if (bad) fail[0] = 1;
+  }
+}
+#endif
+
+#if defined(__HIPCC__)
 // squared residual of every sample, in fppara's order of operations (fac = sum_j c(j) q(it, j); term += (fac - x)^2)
 __global__ __launch_bounds__(256) void k_fit_residual(long long m, int ncoef, const int32_t* __restrict__ span, const double* __restrict__ q,
                                                       const double* __restrict__ X, const double* __restrict__ c, double* __restrict__ term) {

@@ -3,7 +3,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from mvus_amd import pipeline, synth, spline
 kw = dict(synth.BASELINE_CONFIGS[1]); kw.pop('seed'); kw.pop('num_cam'); kw.pop('total_obs'); kw.pop('num_intervals', None); kw['motion_weights'] = 100.0
-flight, sc = pipeline.staged_scene(7, 100000, seed=2, settings={'ba_solver': 'lm'}, perturb=0.3, **kw)
+flight, sc = pipeline.staged_scene(7, int(sys.argv[1]) if len(sys.argv) > 1 else 100000, seed=2, settings={'ba_solver': 'lm'}, perturb=0.3, **kw)
 orig = spline.smooth_fit
 def traced(t, X, s, device=0, full_output=False):
     t0 = time.perf_counter(); out = orig(t, X, s, device=device, full_output=full_output); dt = time.perf_counter() - t0
