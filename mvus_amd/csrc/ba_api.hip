@@ -636,7 +636,7 @@ struct FitWork {
   bool ready = false, penalty = false;
   void alloc(CallBuffers& cb, size_t nest) {
     if (ready) return;
-    SB = cb.get<T>((size_t)kFitBlk * nest); G5 = cb.get<T>(5 * nest); BtB = cb.get<T>(5 * nest); Mx = cb.get<T>(5 * nest);
+    SB = cb.get<T>((size_t)kFitBlk * (nest + kFitSliceBlocks)); G5 = cb.get<T>(5 * nest); BtB = cb.get<T>(5 * nest); Mx = cb.get<T>(5 * nest);
     Lf = cb.get<T>(5 * nest); rhs = cb.get<T>(3 * nest); yw = cb.get<T>(3 * nest);
     YL = cb.get<T>(4 * nest); parts = cb.get<T>((size_t)kBandPartsWork);
     ready = true;
@@ -664,15 +664,17 @@ template <class T>
 static bool fit_lsq_pass(hipStream_t st, FitWork<T>& w, long long m, const long long* first, const double* q, const double* dX, int ncoef, int nrint,
                          double* cd, double* out, int* fail) {
   constexpr int NT = sizeof(T) == sizeof(double) ? 256 : 64;
-  hipLaunchKernelGGL((k_fit_blocks<T, NT>), dim3(nrint), dim3(NT), 0, st, m, first, q, dX, w.SB);
+  const int nslice = fit_slices(nrint);
+  hipLaunchKernelGGL((k_fit_blocks<T, NT>), dim3(nrint, nslice), dim3(NT), 0, st, m, first, q, dX, w.SB);
+  if (nslice > 1) hipLaunchKernelGGL(k_fit_slice_sum<T>, fit_blocks((long long)nrint * kFitBlk), dim3(256), 0, st, (long long)nrint * kFitBlk, nslice, w.SB);
   hipLaunchKernelGGL(k_fit_band<T>, fit_blocks(ncoef), dim3(256), 0, st, ncoef, nrint, w.SB, w.G5, w.rhs);
   w.penalty = false;
   return fit_band_solve<3, T>(st, w, ncoef, w.G5, cd, out, fail);
 }
 // the sum of the factor's diagonal in the natural elimination order (fppara's initial p) when the last pass was partitioned
 template <class T>
-static void fit_lsq_diag(hipStream_t st, FitWork<T>& w, int ncoef, double* cd, double* out, int* fail) {
-  hipLaunchKernelGGL((k_band_solve<3, T>), dim3(1), dim3(64), 0, st, ncoef, w.G5, w.rhs, w.Lf, w.yw, cd, out, fail);
+static void fit_lsq_diag(hipStream_t st, FitWork<T>& w, int ncoef, double* out) {
+  hipLaunchKernelGGL((k_band_diag_sum<3, T>), dim3(1), dim3(64), 0, st, ncoef, w.G5, out);
 }
 // smoothing spline for one value of p on the same knots (fit_lsq_pass has run in this precision)
 template <class T>
@@ -1205,9 +1207,16 @@ int mvus_spline_smooth(int32_t device, int64_t m, const double* u, const double*
   constexpr int k = 3, k1 = 4, k2 = 5, nmin = 8, maxit = 20;
   constexpr double tol = 0.001;
   if (m <= k || m > (1ll << 30) || !u || !X || !n_out || !t_out || !c_out || !(s > 0.0) || !std::isfinite(s)) { g_create_error = "spline_smooth: bad arguments (m > 3 samples, s > 0)"; return MVUS_E_INVALID; }
+  const bool timing = std::getenv("MVUS_FIT_TIMING") != nullptr;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+  const auto t_begin = now();
+  int passes = 0;
   for (int64_t i = 1; i < m; ++i) if (!(u[i] > u[i - 1])) { g_create_error = "spline_smooth: the timestamps must be strictly increasing"; return MVUS_E_INVALID; }
   for (int64_t i = 0; i < 3 * m; ++i) if (!std::isfinite(X[i])) { g_create_error = "spline_smooth: non-finite sample"; return MVUS_E_INVALID; }
   const int nest = (int)m + 2 * k, nmax = (int)m + k1;
+  const auto t_checked = now();
+  auto t_ready = t_checked, t_fitted = t_checked;
   try {
     CallBuffers cb;
     cb.open(device);
@@ -1217,6 +1226,7 @@ int mvus_spline_smooth(int32_t device, int64_t m, const double* u, const double*
     double* q = cb.get<double>(4 * (size_t)m);
     double* term = cb.get<double>((size_t)m);
     double* tot_part = cb.get<double>(1024);
+    double* fp_part = cb.get<double>(512 + kFitSliceBlocks);
     // Everything indexed by knots is sized by a CAPACITY that grows with the knot count (x4, up to FITPACK's nest = m + 6), not
     // by nest: the trajectories traj_to_spline fits are 50x oversampled (560k samples for ~600 knots), and allocating and
     // freeing ~40 arrays of nest doubles (430 MB with the double-double set) cost 70 of the 77 ms of such a fit
@@ -1245,6 +1255,7 @@ int mvus_spline_smooth(int32_t device, int64_t m, const double* u, const double*
       if (host.size() < cap + 4) host.resize(cap + 4, 0.0);
     };
     ensure(nmin + 16);
+    if (timing) { MVUS_HIP(hipStreamSynchronize(cb.st)); t_ready = now(); }
     const double ub = u[0], ue = u[m - 1], acc = tol * s;
     int n = nmin, nplus = 0, ier = 0, nrint = 1, failed = 0;
     double fpold = 0.0, fp0 = 0.0, fp = 0.0, p = -1.0;
@@ -1259,7 +1270,11 @@ int mvus_spline_smooth(int32_t device, int64_t m, const double* u, const double*
       } else {
         hipLaunchKernelGGL(k_fit_total, dim3(1), dim3(256), 0, cb.st, (long long)m, term, out + 1);
       }
-      if (spans) hipLaunchKernelGGL(k_fit_fpint, dim3(nspan), dim3(256), 0, cb.st, nspan, first, term, out + 4);
+      if (spans) {
+        const int nslice = fit_slices(nspan);
+        hipLaunchKernelGGL(k_fit_fpint, dim3(nspan, nslice), dim3(256), 0, cb.st, nspan, first, term, out + 4, fp_part);
+        if (nslice > 1) hipLaunchKernelGGL(k_fit_fpint_final, blocks(nspan), dim3(256), 0, cb.st, nspan, nslice, first, term, fp_part, out + 4);
+      }
       MVUS_HIP(hipGetLastError());
       MVUS_HIP(hipMemcpyAsync(host.data(), out, sizeof(double) * (4 + (spans ? nspan : 0)), hipMemcpyDeviceToHost, cb.st));
       MVUS_HIP(hipMemcpyAsync(&failed, fail, sizeof(int), hipMemcpyDeviceToHost, cb.st));
@@ -1279,6 +1294,7 @@ int mvus_spline_smooth(int32_t device, int64_t m, const double* u, const double*
           if (smoothing) fit_smooth_pass<dd>(cb.st, w2, ncoef, n8, bd, pinv, cd, out, fail);
         }
         residual(ncoef, !smoothing, nrint_);
+        ++passes;
         if (std::getenv("MVUS_DEBUG")) std::fprintf(stderr, "spline_smooth: n=%d %s %s  diag(L) %.3e..%.3e  fp %.6e  fail %d\n", n, smoothing ? "smooth" : "lsq",
                                                     precise ? "dd" : "fp64", host[2], host[3], host[1], failed);
         if (precise) {                                    // floored pivots are accepted here (see k_band_solve)
@@ -1315,10 +1331,9 @@ int mvus_spline_smooth(int32_t device, int64_t m, const double* u, const double*
         MVUS_HIP(hipMemcpyAsync(bd, b.data(), sizeof(double) * b.size(), hipMemcpyHostToDevice, cb.st));
         double p1 = 0.0, f1 = fp0 - s, p3 = -1.0, f3 = fpms;
         if (!diag_natural) {                               // the pass above was partitioned: one chain over the same normal equations for sum a(i,1)
-          if (precise) fit_lsq_diag<dd>(cb.st, w2, ncoef, cd, out, fail); else fit_lsq_diag<double>(cb.st, w1, ncoef, cd, out, fail);
+          if (precise) fit_lsq_diag<dd>(cb.st, w2, ncoef, out); else fit_lsq_diag<double>(cb.st, w1, ncoef, out);
           MVUS_HIP(hipGetLastError());
           MVUS_HIP(hipMemcpyAsync(host.data(), out, sizeof(double), hipMemcpyDeviceToHost, cb.st));
-          MVUS_HIP(hipMemsetAsync(fail, 0, sizeof(int), cb.st));
           MVUS_HIP(hipStreamSynchronize(cb.st));
         }
         p = (double)ncoef / host[0];
@@ -1383,6 +1398,7 @@ int mvus_spline_smooth(int32_t device, int64_t m, const double* u, const double*
         for (int l = 0; l < (int)m - k1; ++l) { t[i - 1] = u[j - 1]; ++i; ++j; }
       }
     }
+    t_fitted = now();
     std::vector<double> ch(3 * (size_t)ncoef);
     MVUS_HIP(hipMemcpyAsync(ch.data(), cd, sizeof(double) * 3 * ncoef, hipMemcpyDeviceToHost, cb.st));
     MVUS_HIP(hipStreamSynchronize(cb.st));
@@ -1391,6 +1407,8 @@ int mvus_spline_smooth(int32_t device, int64_t m, const double* u, const double*
     *n_out = n;
     if (fp_out) *fp_out = fp;
     if (ier_out) *ier_out = ier;
+    if (timing) std::fprintf(stderr, "spline_smooth: m=%lld n=%d passes=%d | input checks %.2f ms, buffers+upload %.2f ms, passes %.2f ms", (long long)m, n, passes,
+                             ms(t_begin, t_checked), ms(t_checked, t_ready), ms(t_ready, t_fitted));
   } catch (const HipError& e) {
     g_create_error = e.msg;
     return e.code;
@@ -1398,6 +1416,7 @@ int mvus_spline_smooth(int32_t device, int64_t m, const double* u, const double*
     g_create_error = e.what();
     return MVUS_E_INVALID;
   }
+  if (timing) std::fprintf(stderr, ", total with release %.2f ms\n", ms(t_begin, now()));
   return MVUS_OK;
 }
 

@@ -18,6 +18,7 @@
 // and seeded case of tests/test_traj_to_spline.py, coefficients to ~1e-9 relative) in O(m + n) parallel work per pass.
 #pragma once
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 #include "ba_math.h"
@@ -124,6 +125,14 @@ __device__ __forceinline__ void block_sum(T (&v)[NV], T* lds) {
   for (int k = 0; k < NV; ++k) v[k] = lds[k * NT];
 }
 
+// A span with many samples (the first passes of a fit: ONE span holds all 3.3 M samples of a long trajectory) is cut into
+// gridDim.y slices, one workgroup each; slice `sl` of span `sp` goes to block sl * nspan + sp of SB and k_fit_slice_sum adds the
+// slices in their order.  fit_slices() picks the count from the number of spans alone, so the order of every sum is fixed.
+inline int fit_slices(int nspan) {
+  static const int cap = [] { const char* e = std::getenv("MVUS_FIT_SLICES_MAX"); return e ? std::max(1, std::min(256, std::atoi(e))) : 256; }();
+  return nspan >= 512 ? 1 : std::min(cap, (1024 + nspan - 1) / nspan);
+}
+constexpr int kFitSliceBlocks = 1536;              // nspan * fit_slices(nspan) - nspan stays below this
 template <class T, int NT>
 __global__ __launch_bounds__(NT) void k_fit_blocks(long long m, const long long* __restrict__ first, const double* __restrict__ q,
                                                    const double* __restrict__ X, T* __restrict__ SB) {
@@ -132,7 +141,10 @@ __global__ __launch_bounds__(NT) void k_fit_blocks(long long m, const long long*
   T v[kFitBlk];
 #pragma unroll
   for (int k = 0; k < kFitBlk; ++k) v[k] = T(0.0);
-  for (long long i = first[sp] + threadIdx.x; i < first[sp + 1]; i += NT) {
+  const long long span_lo = first[sp], span_hi = first[sp + 1];
+  const long long per = (span_hi - span_lo + gridDim.y - 1) / gridDim.y;
+  const long long lo = span_lo + per * blockIdx.y, hi = lo + per < span_hi ? lo + per : span_hi;
+  for (long long i = lo + threadIdx.x; i < hi; i += NT) {
     double h[4], x[3];
 #pragma unroll
     for (int a = 0; a < 4; ++a) h[a] = q[4 * i + a];
@@ -149,8 +161,19 @@ __global__ __launch_bounds__(NT) void k_fit_blocks(long long m, const long long*
   block_sum<kFitBlk, NT, T>(v, lds);
   if (threadIdx.x == 0) {
 #pragma unroll
-    for (int k = 0; k < kFitBlk; ++k) SB[(long long)sp * kFitBlk + k] = v[k];
+    for (int k = 0; k < kFitBlk; ++k) SB[((long long)blockIdx.y * gridDim.x + sp) * kFitBlk + k] = v[k];
   }
+}
+
+// the slices of k_fit_blocks added up in their order, into slice 0 (count = nspan * kFitBlk values per slice)
+template <class T>
+__global__ __launch_bounds__(256) void k_fit_slice_sum(long long count, int nslice, T* __restrict__ SB) {
+  const long long e = blockIdx.x * 256ll + threadIdx.x;
+  if (e >= count) return;
+  T v = SB[e];
+#pragma unroll 8
+  for (int sl = 1; sl < nslice; ++sl) v += SB[(long long)sl * count + e];
+  SB[e] = v;
 }
 
 // lower banded storage, width W = HB + 1: G[j * W + w] = M(j, j - w).  Here the normal equations in a width-5 array (w = 4
@@ -371,6 +394,65 @@ struct PivotStats {
     return l;
   }
 };
+
+// sum of diag(L) of the banded Cholesky in the NATURAL order (FITPACK's sum of a(i,1), the initial p of the smoothing
+// iteration) -- the factor recurrence of k_band_solve alone, with reciprocal pivots; every lane fetches one row of a 64-row
+// chunk (coalesced, the next chunk while this one is processed) and the rows are broadcast from the lanes' registers.
+__device__ __forceinline__ double lane_value(double v, int lane) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+__device__ __forceinline__ dd lane_value(dd v, int lane) { return dd(lane_value(v.hi, lane), lane_value(v.lo, lane)); }
+template <int HB, class T>
+__global__ __launch_bounds__(64) void k_band_diag_sum(int n, const T* __restrict__ M, double* __restrict__ out) {
+  const int lane = threadIdx.x;
+  T Lp[HB + 1][HB + 1], ip[HB + 1];
+#pragma unroll
+  for (int u = 0; u <= HB; ++u) {
+    ip[u] = T(1.0);
+#pragma unroll
+    for (int w = 0; w <= HB; ++w) Lp[u][w] = (w == 0) ? T(1.0) : T(0.0);
+  }
+  PivotStats<T> ps;
+  T cur[HB + 1], nxt[HB + 1];
+#pragma unroll
+  for (int w = 0; w <= HB; ++w) { cur[w] = lane < n ? M[5 * (long long)lane + w] : T(0.0); nxt[w] = T(0.0); }
+  for (int base = 0; base < n; base += 64) {
+    if (base + 64 + lane < n) {
+#pragma unroll
+      for (int w = 0; w <= HB; ++w) nxt[w] = M[5 * (long long)(base + 64 + lane) + w];
+    }
+    const int cnt = n - base < 64 ? n - base : 64;
+    for (int k = 0; k < cnt; ++k) {
+      T row[HB + 1];
+#pragma unroll
+      for (int w = 0; w <= HB; ++w) row[w] = lane_value(cur[w], k);
+#pragma unroll
+      for (int w = HB; w >= 1; --w) {
+        T v = row[w];
+#pragma unroll
+        for (int u2 = w + 1; u2 <= HB; ++u2) v -= row[u2] * Lp[w][u2 - w];
+        row[w] = (base + k - w >= 0) ? v * ip[w] : T(0.0);
+      }
+      const T full = row[0];
+      T dg = row[0];
+#pragma unroll
+      for (int u2 = 1; u2 <= HB; ++u2) dg -= row[u2] * row[u2];
+      row[0] = ps.pivot(dg, full);
+#pragma unroll
+      for (int u2 = HB; u2 >= 2; --u2) {
+        ip[u2] = ip[u2 - 1];
+#pragma unroll
+        for (int w = 0; w <= HB; ++w) Lp[u2][w] = Lp[u2 - 1][w];
+      }
+      ip[1] = num_recip(row[0]);
+#pragma unroll
+      for (int w = 0; w <= HB; ++w) Lp[1][w] = row[w];
+    }
+#pragma unroll
+    for (int w = 0; w <= HB; ++w) cur[w] = nxt[w];
+  }
+  if (lane == 0) out[0] = ps.dsum;
+}
 
 template <int HB, class T>
 __global__ __launch_bounds__(kBandPartsMax) void k_band_solve_parts(int n, BandParts bp, const T* __restrict__ M, const T* __restrict__ rhs, T* __restrict__ Lout,
@@ -759,19 +841,37 @@ __global__ __launch_bounds__(256) void k_fit_residual(long long m, int ncoef, co
 
 // per-span residual: the first sample of a span (it is the first with u >= the knot that opens the span) is shared half / half
 // with the span before, like fppara's `new` / `store` bookkeeping
-__global__ __launch_bounds__(256) void k_fit_fpint(int nspan, const long long* __restrict__ first, const double* __restrict__ term, double* __restrict__ fpint) {
+// (gridDim.y slices per span as in k_fit_blocks: with more than one, the slice sums go to part[sl * nspan + sp] and
+// k_fit_fpint_final adds them in order)
+__global__ __launch_bounds__(256) void k_fit_fpint(int nspan, const long long* __restrict__ first, const double* __restrict__ term, double* __restrict__ fpint,
+                                                   double* __restrict__ part) {
   __shared__ double lds[256];
   const int sp = blockIdx.x;
   const long long a = first[sp], b = first[sp + 1];
+  const long long span_lo = a + (sp > 0 ? 1 : 0);
+  const long long per = (b - span_lo + gridDim.y - 1) / gridDim.y;
+  const long long lo = span_lo + per * blockIdx.y, hi = lo + per < b ? lo + per : b;
   double v[1] = {0.0};
-  for (long long i = a + (sp > 0 ? 1 : 0) + threadIdx.x; i < b; i += 256) v[0] += term[i];
+  for (long long i = lo + threadIdx.x; i < hi; i += 256) v[0] += term[i];
   block_sum<1>(v, lds);
   if (threadIdx.x == 0) {
+    if (gridDim.y > 1) { part[(long long)blockIdx.y * nspan + sp] = v[0]; return; }
     double s = v[0];
     if (sp > 0 && a < b) s += 0.5 * term[a];
     if (sp + 1 < nspan && first[sp + 1] < first[sp + 2]) s += 0.5 * term[b];
     fpint[sp] = s;
   }
+}
+__global__ __launch_bounds__(256) void k_fit_fpint_final(int nspan, int nslice, const long long* __restrict__ first, const double* __restrict__ term,
+                                                         const double* __restrict__ part, double* __restrict__ fpint) {
+  const int sp = blockIdx.x * 256 + threadIdx.x;
+  if (sp >= nspan) return;
+  const long long a = first[sp], b = first[sp + 1];
+  double s = 0.0;
+  for (int sl = 0; sl < nslice; ++sl) s += part[(long long)sl * nspan + sp];
+  if (sp > 0 && a < b) s += 0.5 * term[a];
+  if (sp + 1 < nspan && first[sp + 1] < first[sp + 2]) s += 0.5 * term[b];
+  fpint[sp] = s;
 }
 
 // total of `count` values in a fixed order: per-workgroup partial sums (grid-stride), then one workgroup over the partials
