@@ -188,6 +188,24 @@ def test_gpu_smooth_fit_matches_fitpack(seed, m, spec):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('seed,m,spec', [(9, 20000, ('abs', 24.0)), (10, 30000, ('abs', 40.0)), (11, 12000, ('abs', 10.0))])
+def test_gpu_smooth_fit_partitioned_band_solver(seed, m, spec):
+    """Several hundred knots: the banded systems go through k_band_solve_parts (interiors in parallel, separator system,
+    back-substitution; from 192 coefficients on) and the initial p through k_band_diag_sum -- still FITPACK's knots and spline.
+    (MVUS_BAND_PARTS_MIN=16 pushes every case of this file through the same kernels.)"""
+    from mvus_amd import spline
+    u, X = _trajectory(seed, m, speed=1 + seed % 7)
+    s = _s_of(u, spec)
+    (tck0, _u), fp0, ier0, _msg = interpolate.splprep(X, u=u, s=s, k=3, full_output=1)
+    assert len(tck0[0]) > 300
+    tck, fp, ier = spline.smooth_fit(u, X, s, full_output=True)
+    np.testing.assert_array_equal(tck[0], tck0[0])
+    assert ier == ier0
+    np.testing.assert_allclose(np.asarray(tck[1]), np.asarray(tck0[1]), rtol=0, atol=1e-7)
+    assert abs(fp - fp0) <= 1e-7 * max(fp0, s)
+
+
+@pytest.mark.gpu
 def test_gpu_smooth_fit_ill_conditioned_knot_set():
     """Close to interpolation FITPACK's knot search can produce a knot set with cond(A) ~ 1e10 (cond of the normal equations
     1e20): the fp64 Cholesky loses a pivot, the pass is repeated in double-double and still lands on FITPACK's spline."""
