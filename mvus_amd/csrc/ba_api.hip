@@ -637,8 +637,9 @@ struct FitWork {
   void alloc(CallBuffers& cb, size_t nest) {
     if (ready) return;
     SB = cb.get<T>((size_t)kFitBlk * (nest + kFitSliceBlocks)); G5 = cb.get<T>(5 * nest); BtB = cb.get<T>(5 * nest); Mx = cb.get<T>(5 * nest);
-    Lf = cb.get<T>(5 * nest); rhs = cb.get<T>(3 * nest); yw = cb.get<T>(3 * nest);
-    YL = cb.get<T>(4 * nest); parts = cb.get<T>((size_t)kBandPartsWork);
+    const size_t rows = nest + kBandPartsMax;            // the transposed copies hold length(0) rows for EVERY interior
+    Lf = cb.get<T>(5 * rows); rhs = cb.get<T>(3 * nest); yw = cb.get<T>(3 * rows);
+    YL = cb.get<T>(4 * rows); parts = cb.get<T>((size_t)kBandPartsWork);
     ready = true;
   }
 };
@@ -667,7 +668,7 @@ static bool fit_lsq_pass(hipStream_t st, FitWork<T>& w, long long m, const long 
   const int nslice = fit_slices(nrint);
   hipLaunchKernelGGL((k_fit_blocks<T, NT>), dim3(nrint, nslice), dim3(NT), 0, st, m, first, q, dX, w.SB);
   if (nslice > 1) hipLaunchKernelGGL(k_fit_slice_sum<T>, fit_blocks((long long)nrint * kFitBlk), dim3(256), 0, st, (long long)nrint * kFitBlk, nslice, w.SB);
-  hipLaunchKernelGGL(k_fit_band<T>, fit_blocks(ncoef), dim3(256), 0, st, ncoef, nrint, w.SB, w.G5, w.rhs);
+  hipLaunchKernelGGL(k_fit_band<T>, fit_blocks(ncoef), dim3(256), 0, st, ncoef, nrint, w.SB, w.G5, w.rhs, band_parts(ncoef, 3, band_parts_min()), w.Lf, w.yw);
   w.penalty = false;
   return fit_band_solve<3, T>(st, w, ncoef, w.G5, cd, out, fail);
 }
@@ -680,7 +681,8 @@ static void fit_lsq_diag(hipStream_t st, FitWork<T>& w, int ncoef, double* out) 
 template <class T>
 static void fit_smooth_pass(hipStream_t st, FitWork<T>& w, int ncoef, int n8, const double* bd, double pinv, double* cd, double* out, int* fail) {
   if (!w.penalty) { hipLaunchKernelGGL(k_fit_penalty<T>, fit_blocks(ncoef), dim3(256), 0, st, ncoef, n8, bd, w.BtB); w.penalty = true; }
-  hipLaunchKernelGGL(k_fit_combine<T>, fit_blocks(5ll * ncoef), dim3(256), 0, st, 5ll * ncoef, w.G5, w.BtB, pinv, w.Mx);
+  hipLaunchKernelGGL(k_fit_combine<T>, fit_blocks(5ll * ncoef), dim3(256), 0, st, 5ll * ncoef, w.G5, w.BtB, pinv, w.Mx, ncoef, w.rhs,
+                     band_parts(ncoef, 4, band_parts_min()), w.Lf, w.yw);
   fit_band_solve<4, T>(st, w, ncoef, w.Mx, cd, out, fail);
 }
 

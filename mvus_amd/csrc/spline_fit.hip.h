@@ -76,6 +76,33 @@ MVUS_HD double pivot_floor(dd) { return 1e-24; }
 MVUS_HD double num_prod(double a, double b, double) { return a * b; }          // a * b in the precision of the third argument
 MVUS_HD dd num_prod(double a, double b, dd) { return dd_two_prod(a, b); }
 
+struct BandParts {
+  int P = 1, len = 0, rem = 0, HB = 3;       // interior p: rows [first(p), first(p) + length(p)), then HB separator rows
+  MVUS_HD int length(int p) const { return len + (p < rem ? 1 : 0); }
+  MVUS_HD int first(int p) const { return p * (len + HB) + (p < rem ? p : rem); }
+  // row j -> its interior p and the row i inside it (i >= length(p): a separator row)
+  MVUS_HD void locate(int j, int& p, int& i) const {
+    const int big = len + 1 + HB;
+    if (j < rem * big) { p = j / big; i = j - p * big; }
+    else { const int j2 = j - rem * big; p = rem + j2 / (len + HB); i = j2 - (p - rem) * (len + HB); }
+  }
+  // the interiors' rows are also kept TRANSPOSED for the solver: value k of K per row, row i of interior p at ((i K + k) P + p),
+  // so that the P lanes of k_band_solve_parts (one interior each) read and write consecutive addresses
+  MVUS_HD long long at(int p, int i, int k, int K) const { return ((long long)i * K + k) * P + p; }
+};
+inline BandParts band_parts(int n, int HB, int min_rows) {
+  BandParts bp;
+  bp.HB = HB;
+  if (n < min_rows) return bp;
+  int P = (int)std::sqrt((double)n / 2.5);
+  P = std::max(2, std::min(256, P));
+  while (P > 1 && (n - (P - 1) * HB) / P < 2 * HB) --P;
+  if (P < 2) return bp;
+  bp.P = P;
+  bp.len = (n - (P - 1) * HB) / P;
+  bp.rem = (n - (P - 1) * HB) - bp.len * P;
+  return bp;
+}
 #if defined(__HIPCC__)
 constexpr int kFitBlk = 22;      // per span: 10 products h_a h_b (a >= b) + 12 products h_a x_d
 
@@ -179,7 +206,8 @@ __global__ __launch_bounds__(256) void k_fit_slice_sum(long long count, int nsli
 // lower banded storage, width W = HB + 1: G[j * W + w] = M(j, j - w).  Here the normal equations in a width-5 array (w = 4
 // zero) so that the penalty can be added in place, and rhs[d * ncoef + j].
 template <class T>
-__global__ __launch_bounds__(256) void k_fit_band(int ncoef, int nspan, const T* __restrict__ SB, T* __restrict__ G5, T* __restrict__ rhs) {
+__global__ __launch_bounds__(256) void k_fit_band(int ncoef, int nspan, const T* __restrict__ SB, T* __restrict__ G5, T* __restrict__ rhs, BandParts bp,
+                                                  T* __restrict__ Mt, T* __restrict__ rt) {
   const int j = blockIdx.x * 256 + threadIdx.x;
   if (j >= ncoef) return;
   T g[5] = {T(0.0), T(0.0), T(0.0), T(0.0), T(0.0)}, r[3] = {T(0.0), T(0.0), T(0.0)};
@@ -195,6 +223,16 @@ __global__ __launch_bounds__(256) void k_fit_band(int ncoef, int nspan, const T*
   for (int w = 0; w < 5; ++w) G5[5 * (long long)j + w] = g[w];
 #pragma unroll
   for (int d = 0; d < 3; ++d) rhs[(long long)d * ncoef + j] = r[d];
+  if (bp.P > 1) {                                    // the copy k_band_solve_parts<3> reads (see BandParts::at)
+    int p, i;
+    bp.locate(j, p, i);
+    if (i < bp.length(p)) {
+#pragma unroll
+      for (int w = 0; w < 4; ++w) Mt[bp.at(p, i, w, 4)] = g[w];
+#pragma unroll
+      for (int d = 0; d < 3; ++d) rt[bp.at(p, i, d, 3)] = r[d];
+    }
+  }
 }
 
 // BtB[j * 5 + w] = (B^T B)(j, j - w) for the n8 x ncoef jump matrix B whose row `it` holds b[it * 5 + c] in column it + c
@@ -213,9 +251,21 @@ __global__ __launch_bounds__(256) void k_fit_penalty(int ncoef, int n8, const do
 }
 
 template <class T>
-__global__ __launch_bounds__(256) void k_fit_combine(long long count, const T* __restrict__ G5, const T* __restrict__ BtB, double pinv, T* __restrict__ M) {
+__global__ __launch_bounds__(256) void k_fit_combine(long long count, const T* __restrict__ G5, const T* __restrict__ BtB, double pinv, T* __restrict__ M,
+                                                     int ncoef, const T* __restrict__ rhs, BandParts bp, T* __restrict__ Mt, T* __restrict__ rt) {
   const long long e = blockIdx.x * 256ll + threadIdx.x;
-  if (e < count) M[e] = G5[e] + (T(pinv) * T(pinv)) * BtB[e];        // fppara rotates the rows of B in with weight 1/p
+  if (e >= count) return;
+  const T v = G5[e] + (T(pinv) * T(pinv)) * BtB[e];                  // fppara rotates the rows of B in with weight 1/p
+  M[e] = v;
+  if (bp.P > 1) {                                    // the copy k_band_solve_parts<4> reads, and the right-hand sides in ITS partition
+    const int j = (int)(e / 5), w = (int)(e - 5ll * j);
+    int p, i;
+    bp.locate(j, p, i);
+    if (i < bp.length(p)) {
+      Mt[bp.at(p, i, w, 5)] = v;
+      if (w < 3) rt[bp.at(p, i, w, 3)] = rhs[(long long)w * ncoef + j];
+    }
+  }
 }
 
 // Banded Cholesky M = L L^T (lower band, row stride 5, HB = 3 or 4 sub-diagonals used) and the solves for the three
@@ -340,24 +390,6 @@ __global__ __launch_bounds__(64) void k_band_solve(int n, const T* __restrict__ 
 // One workgroup (P <= 256 lanes), __syncthreads between the phases.  The elimination ORDER differs from k_band_solve's, so
 // the factor's diagonal is not FITPACK's a(i,1): out[0] is not written; the caller runs k_band_solve once per fit where
 // fppara needs that sum (the initial p).  out[2], out[3] = smallest / largest pivot of all the factors (same use as before).
-struct BandParts {
-  int P = 1, len = 0, rem = 0, HB = 3;       // interior p: rows [first(p), first(p) + length(p)), then HB separator rows
-  MVUS_HD int length(int p) const { return len + (p < rem ? 1 : 0); }
-  MVUS_HD int first(int p) const { return p * (len + HB) + (p < rem ? p : rem); }
-};
-inline BandParts band_parts(int n, int HB, int min_rows) {
-  BandParts bp;
-  bp.HB = HB;
-  if (n < min_rows) return bp;
-  int P = (int)std::sqrt((double)n / 2.5);
-  P = std::max(2, std::min(256, P));
-  while (P > 1 && (n - (P - 1) * HB) / P < 2 * HB) --P;
-  if (P < 2) return bp;
-  bp.P = P;
-  bp.len = (n - (P - 1) * HB) / P;
-  bp.rem = (n - (P - 1) * HB) - bp.len * P;
-  return bp;
-}
 MVUS_HD double num_recip(double a) { return 1.0 / a; }
 MVUS_HD dd num_recip(dd a) {                        // one Newton step on the fp64 reciprocal: r0 + r0 (1 - a r0)
   MVUS_NO_CONTRACT
@@ -455,9 +487,12 @@ __global__ __launch_bounds__(64) void k_band_diag_sum(int n, const T* __restrict
 }
 
 template <int HB, class T>
-__global__ __launch_bounds__(kBandPartsMax) void k_band_solve_parts(int n, BandParts bp, const T* __restrict__ M, const T* __restrict__ rhs, T* __restrict__ Lout,
-                                                                    T* __restrict__ ywork, T* __restrict__ YL, T* __restrict__ work, double* __restrict__ c,
+__global__ __launch_bounds__(kBandPartsMax) void k_band_solve_parts(int n, BandParts bp, const T* __restrict__ M, const T* __restrict__ rhs, T* __restrict__ Mt,
+                                                                    T* __restrict__ rt, T* __restrict__ YL, T* __restrict__ work, double* __restrict__ c,
                                                                     double* __restrict__ out, int* __restrict__ fail) {
+  // M, rhs: the system as the other kernels hold it (separator rows are read from there); Mt, rt: the interiors' rows transposed
+  // (written by k_fit_band / k_fit_combine) -- overwritten in place by L and y, then by nothing: x goes straight to c
+  constexpr int NW = HB + 1;
   using R = BandRec<HB>;
   using S = BandSep<HB>;
   constexpr int NC = HB + 3;                          // forward columns of an interior: HB couplings to the left, 3 right-hand sides
@@ -491,9 +526,9 @@ __global__ __launch_bounds__(kBandPartsMax) void k_band_solve_parts(int n, BandP
     }
     T nxt[HB + 1], nb[3];
 #pragma unroll
-    for (int w = 0; w <= HB; ++w) nxt[w] = M[5 * (long long)r0 + w];
+    for (int w = 0; w <= HB; ++w) nxt[w] = Mt[bp.at(p, 0, w, NW)];
 #pragma unroll
-    for (int d = 0; d < 3; ++d) nb[d] = rhs[(long long)d * n + r0];
+    for (int d = 0; d < 3; ++d) nb[d] = rt[bp.at(p, 0, d, 3)];
     for (int i = 0; i < lp; ++i) {
       const long long j = r0 + i;
       T row[HB + 1], b[NC];
@@ -505,9 +540,9 @@ __global__ __launch_bounds__(kBandPartsMax) void k_band_solve_parts(int n, BandP
       for (int d = 0; d < 3; ++d) b[HB + d] = nb[d];
       if (i + 1 < lp) {
 #pragma unroll
-        for (int w = 0; w <= HB; ++w) nxt[w] = M[5 * (j + 1) + w];
+        for (int w = 0; w <= HB; ++w) nxt[w] = Mt[bp.at(p, i + 1, w, NW)];
 #pragma unroll
-        for (int d = 0; d < 3; ++d) nb[d] = rhs[(long long)d * n + j + 1];
+        for (int d = 0; d < 3; ++d) nb[d] = rt[bp.at(p, i + 1, d, 3)];
       }
       if (i < HB) {                                   // M(j, j-w) with i - w < 0 couples to the separator on the left: column i + HB - w of it
 #pragma unroll
@@ -548,11 +583,11 @@ __global__ __launch_bounds__(kBandPartsMax) void k_band_solve_parts(int n, BandP
         for (int d = 0; d < 3; ++d) gl[a][d] += y[a] * y[HB + d];
       }
 #pragma unroll
-      for (int w = 0; w <= HB; ++w) Lout[5 * j + w] = row[w];
+      for (int w = 0; w <= HB; ++w) Mt[bp.at(p, i, w, NW)] = row[w];
 #pragma unroll
-      for (int col = 0; col < HB; ++col) YL[(long long)HB * j + col] = y[col];
+      for (int col = 0; col < HB; ++col) YL[bp.at(p, i, col, HB)] = y[col];
 #pragma unroll
-      for (int d = 0; d < 3; ++d) ywork[(long long)d * n + j] = y[HB + d];
+      for (int d = 0; d < 3; ++d) rt[bp.at(p, i, d, 3)] = y[HB + d];
 #pragma unroll
       for (int u2 = HB; u2 >= 2; --u2) {
         ip[u2] = ip[u2 - 1];
@@ -754,15 +789,15 @@ __global__ __launch_bounds__(kBandPartsMax) void k_band_solve_parts(int n, BandP
       for (int d = 0; d < 3; ++d) cn[u][d] = T(0.0);
     }
     T nrow[HB + 1], nyl[HB], ny[3];
-    auto fetch = [&](long long j) {
+    auto fetch = [&](int i) {
 #pragma unroll
-      for (int w = 0; w <= HB; ++w) nrow[w] = Lout[5 * j + w];
+      for (int w = 0; w <= HB; ++w) nrow[w] = Mt[bp.at(p, i, w, NW)];
 #pragma unroll
-      for (int col = 0; col < HB; ++col) nyl[col] = YL[(long long)HB * j + col];
+      for (int col = 0; col < HB; ++col) nyl[col] = YL[bp.at(p, i, col, HB)];
 #pragma unroll
-      for (int d = 0; d < 3; ++d) ny[d] = ywork[(long long)d * n + j];
+      for (int d = 0; d < 3; ++d) ny[d] = rt[bp.at(p, i, d, 3)];
     };
-    fetch((long long)r0 + lp - 1);
+    fetch(lp - 1);
     for (int i = lp - 1; i >= 0; --i) {
       const long long j = r0 + i;
       T row[HB + 1], yl[HB], v[3];
@@ -772,7 +807,7 @@ __global__ __launch_bounds__(kBandPartsMax) void k_band_solve_parts(int n, BandP
       for (int col = 0; col < HB; ++col) yl[col] = nyl[col];
 #pragma unroll
       for (int d = 0; d < 3; ++d) v[d] = ny[d];
-      if (i > 0) fetch(j - 1);
+      if (i > 0) fetch(i - 1);
       const int rr = i - (lp - HB);                   // row of Y_R (>= 0 in the last HB rows of the interior)
       const T inv = num_recip(row[0]);
 #pragma unroll

@@ -179,6 +179,7 @@ def traj_fit(part, smooth_factor, device=0):
     factor starts at 1e-6 * duration and is divided by 1.5 / doubled until duration / #coefficients lies between the two
     ``smooth_factor`` bounds (or the fit is down to 4 coefficients and still too dense).  Returns the tck."""
     lo, hi = min(smooth_factor), max(smooth_factor)
+    part = np.ascontiguousarray(part, dtype=np.float64)     # once, not in each of the dozen fits below (a column slice of the trajectory is strided)
     measure = part[0, -1] - part[0, 0]
     s = (1e-3) ** 2 * measure
     if part.shape[1] < 4:                        # splprep(k=3) raises -> the reference's k=1 fallback (common.py:266-267)
