@@ -175,6 +175,14 @@ int mvus_ba_upload_pattern(mvus_ba* h, const int32_t* pat, const int32_t* motion
  * reference pattern contains both (scipy.optimize._numdiff.group_columns on jac_BA's matrix). */
 int mvus_ba_set_fd_groups(mvus_ba* h, const int32_t* groups, int32_t num_groups);
 
+/* scipy.optimize._numdiff.group_columns(A, order) -- what least_squares runs on jac_sparsity (the reference passes
+ * jac_BA's matrix, common.py:665-670) -- on the HOST, from the pattern's entries instead of a scipy.sparse matrix:
+ * entries (rows[k], cols[k]), k < nnz, of an m x n pattern in any order, duplicates allowed; order[n] = the column
+ * permutation (scipy: numpy.random.RandomState(0).permutation(n)); groups[n] out.  Same greedy pass as scipy's
+ * group_sparse over the permuted columns, hence the same groups.  Returns the number of groups, or a negative MVUS_E_*.
+ * Stateless; no device is touched. */
+int32_t mvus_group_columns(int64_t m, int64_t n, int64_t nnz, const int64_t* rows, const int64_t* cols, const int64_t* order, int32_t* groups);
+
 /* y[m] = J v (v[n]);  z[n] = J^T u (u[m]) with the Jacobian currently held by the handle
  * (after mvus_ba_residual_jacobian / inside solve).  Test and integration hooks for the operator. */
 int mvus_ba_jv(mvus_ba* h, const double* v, double* y);

@@ -850,6 +850,55 @@ int mvus_ba_set_fd_groups(mvus_ba* h, const int32_t* groups, int32_t num_groups)
   });
 }
 
+int32_t mvus_group_columns(int64_t m, int64_t n, int64_t nnz, const int64_t* rows, const int64_t* cols, const int64_t* order, int32_t* groups) {
+  if (m < 0 || n < 1 || nnz < 0 || n > (1ll << 31) - 2 || (nnz > 0 && (!rows || !cols)) || !order || !groups) { g_create_error = "group_columns: bad arguments"; return MVUS_E_INVALID; }
+  try {
+    // A[:, order]: permuted column j is original column order[j]; CSC of the permuted matrix by a counting sort of the entries
+    std::vector<int64_t> where((size_t)n, -1);
+    for (int64_t j = 0; j < n; ++j) {
+      if (order[j] < 0 || order[j] >= n || where[(size_t)order[j]] >= 0) { g_create_error = "group_columns: order is not a permutation"; return MVUS_E_INVALID; }
+      where[(size_t)order[j]] = j;
+    }
+    std::vector<int64_t> indptr((size_t)n + 1, 0);
+    for (int64_t k = 0; k < nnz; ++k) {
+      if (rows[k] < 0 || rows[k] >= m || cols[k] < 0 || cols[k] >= n) { g_create_error = "group_columns: entry outside the matrix"; return MVUS_E_INVALID; }
+      ++indptr[(size_t)where[(size_t)cols[k]] + 1];
+    }
+    for (int64_t j = 0; j < n; ++j) indptr[(size_t)j + 1] += indptr[(size_t)j];
+    std::vector<int64_t> fill(indptr.begin(), indptr.end() - 1), indices((size_t)nnz);
+    for (int64_t k = 0; k < nnz; ++k) indices[(size_t)fill[(size_t)where[(size_t)cols[k]]]++] = rows[k];
+    // scipy/optimize/_group_columns.pyx: group_sparse
+    std::vector<int32_t> gp((size_t)n, -1);
+    std::vector<unsigned char> in_union((size_t)m);
+    int32_t current = 0;
+    for (int64_t i = 0; i < n; ++i) {
+      if (gp[(size_t)i] >= 0) continue;
+      gp[(size_t)i] = current;
+      bool all_grouped = true;
+      std::fill(in_union.begin(), in_union.end(), (unsigned char)0);
+      for (int64_t k = indptr[(size_t)i]; k < indptr[(size_t)i + 1]; ++k) in_union[(size_t)indices[(size_t)k]] = 1;
+      for (int64_t j = 0; j < n; ++j) {
+        if (gp[(size_t)j] >= 0) continue;
+        all_grouped = false;
+        bool intersect = false;
+        for (int64_t k = indptr[(size_t)j]; k < indptr[(size_t)j + 1]; ++k) if (in_union[(size_t)indices[(size_t)k]]) { intersect = true; break; }
+        if (!intersect) {
+          for (int64_t k = indptr[(size_t)j]; k < indptr[(size_t)j + 1]; ++k) in_union[(size_t)indices[(size_t)k]] = 1;
+          gp[(size_t)j] = current;
+        }
+      }
+      if (all_grouped) break;
+      ++current;
+    }
+    int32_t ng = 0;
+    for (int64_t j = 0; j < n; ++j) { groups[(size_t)order[j]] = gp[(size_t)j]; ng = std::max(ng, gp[(size_t)j] + 1); }      // groups[order] = groups.copy()
+    return ng;
+  } catch (const std::exception& e) {
+    g_create_error = e.what();
+    return MVUS_E_INVALID;
+  }
+}
+
 int mvus_ba_jv(mvus_ba* h, const double* v, double* y) {
   return guarded(h, [&] {
     HipBackend& be = h->be;

@@ -134,9 +134,8 @@ def codes_from_matrix(prob, A):
     return pat, mpat
 
 
-def reference_pattern(prob, pat0, motion_pat=None):
-    """scipy.sparse CSR matrix (m x n) of ones: the matrix ``jac_BA`` hands to ``least_squares``, from pattern codes."""
-    from scipy import sparse
+def pattern_entries(prob, pat0, motion_pat=None):
+    """(rows, cols) int64 of the ones of ``jac_BA``'s matrix (unordered; a (row, col) pair can occur twice), from pattern codes."""
     C, P, n = prob.C, prob.P, prob.n_params
     coff = prob.ctrl_offsets
     xoff = prob.spline_x_offsets
@@ -178,14 +177,40 @@ def reference_pattern(prob, pat0, motion_pat=None):
         cols.append(sc)
     rows = np.concatenate(rows) if rows else np.zeros(0, dtype=np.int64)
     cols = np.concatenate(cols) if cols else np.zeros(0, dtype=np.int64)
-    A = sparse.csr_matrix((np.ones(rows.size, dtype=np.int8), (rows, cols)), shape=(prob.n_residuals, n))
+    return np.ascontiguousarray(rows, dtype=np.int64), np.ascontiguousarray(cols, dtype=np.int64)
+
+
+def reference_pattern(prob, pat0, motion_pat=None):
+    """scipy.sparse CSR matrix (m x n) of ones: the matrix ``jac_BA`` hands to ``least_squares``, from pattern codes."""
+    from scipy import sparse
+    rows, cols = pattern_entries(prob, pat0, motion_pat)
+    A = sparse.csr_matrix((np.ones(rows.size, dtype=np.int8), (rows, cols)), shape=(prob.n_residuals, prob.n_params))
     A.sum_duplicates()
     A.data[:] = 1
     return A
 
 
-def fd_groups(prob, pat0, motion_pat=None):
-    """Column groups for sparse 2-point differences: (groups int32[n], number of groups)."""
+def fd_groups_scipy(prob, pat0, motion_pat=None):
+    """``scipy.optimize._numdiff.group_columns`` itself on the reference pattern -- what ``least_squares`` does with
+    ``jac_sparsity`` (reference common.py:665-670); the check of ``fd_groups``."""
     from scipy.optimize._numdiff import group_columns
     groups = np.asarray(group_columns(reference_pattern(prob, pat0, motion_pat)), dtype=np.int32)
     return groups, int(groups.max()) + 1
+
+
+def fd_groups(prob, pat0, motion_pat=None):
+    """Column groups for sparse 2-point differences: (groups int32[n], number of groups) -- scipy's ``group_columns`` (same
+    column permutation ``RandomState(0).permutation(n)``, same greedy pass) run by ``mvus_group_columns`` on the pattern's
+    entries: building the scipy.sparse matrix, converting it to CSC and permuting its columns was 2/3 of a default
+    ``Scene.BA`` call's host time at 600 k detections."""
+    from . import _lib
+    lib = _lib.load()
+    rows, cols = pattern_entries(prob, pat0, motion_pat)
+    n = int(prob.n_params)
+    order = np.ascontiguousarray(np.random.RandomState(0).permutation(n), dtype=np.int64)
+    groups = np.empty(n, dtype=np.int32)
+    ng = lib.mvus_group_columns(int(prob.n_residuals), n, int(rows.size), rows.ctypes.data_as(_lib.c_int64_p), cols.ctypes.data_as(_lib.c_int64_p),
+                                order.ctypes.data_as(_lib.c_int64_p), groups.ctypes.data_as(_lib.c_int32_p))
+    if ng < 0:
+        raise RuntimeError('mvus_group_columns failed (%d): %s' % (ng, lib.mvus_last_error(None).decode()))
+    return groups, int(ng)

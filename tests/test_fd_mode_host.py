@@ -57,6 +57,9 @@ def test_full_pattern_matches_reference(name):
     if tie_order_is_the_recorded_one():
         assert (A != ref).nnz == 0
     groups, ng = pattern.fd_groups(prob, pn, mn if h.T else None)
+    # mvus_group_columns (the entries, no scipy.sparse matrix) finds scipy's own groups
+    gs, ngs = pattern.fd_groups_scipy(prob, pn, mn if h.T else None)
+    assert ng == ngs and np.array_equal(groups, gs)
     # a valid colouring: no row contains two columns of one group
     G = sparse.csr_matrix((np.ones(groups.size), (np.arange(groups.size), groups)), shape=(groups.size, ng))
     assert (A @ G).max() == 1

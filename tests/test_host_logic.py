@@ -272,3 +272,37 @@ def test_scene_default_is_the_reference_algorithm():
             s.ba_mode()
     o = _lib.default_opts()
     assert o.lm_lambda_min == 3e-3
+
+
+def test_group_columns_rejects_bad_input_and_matches_scipy_on_a_random_pattern():
+    """mvus_group_columns (host side of the FD mode: scipy's group_columns without a scipy.sparse matrix): scipy's groups on a
+    random pattern with duplicate entries in random order; a non-permutation and an entry outside the matrix are refused."""
+    import ctypes
+    from scipy import sparse
+    from scipy.optimize._numdiff import group_columns
+    from mvus_amd import _lib
+    lib = _lib.load()
+    m, n = 3000, 400
+    A = sparse.random(m, n, density=0.006, random_state=5, format='csr')
+    A.data[:] = 1
+    coo = A.tocoo()
+    rng = np.random.default_rng(5)
+    rows = np.concatenate([coo.row, coo.row[:50]]).astype(np.int64)
+    cols = np.concatenate([coo.col, coo.col[:50]]).astype(np.int64)
+    p = rng.permutation(rows.size)
+    rows, cols = np.ascontiguousarray(rows[p]), np.ascontiguousarray(cols[p])
+    order = np.ascontiguousarray(np.random.RandomState(0).permutation(n), dtype=np.int64)
+
+    def run(rows, cols, order):
+        g = np.full(n, -7, dtype=np.int32)
+        ng = lib.mvus_group_columns(m, n, rows.size, rows.ctypes.data_as(_lib.c_int64_p), cols.ctypes.data_as(_lib.c_int64_p),
+                                    order.ctypes.data_as(_lib.c_int64_p), g.ctypes.data_as(_lib.c_int32_p))
+        return ng, g
+
+    ng, g = run(rows, cols, order)
+    gs = group_columns(A)
+    assert ng == int(gs.max()) + 1 and np.array_equal(g, gs)
+    bad = order.copy(); bad[3] = bad[4]
+    assert run(rows, cols, bad)[0] == _lib.MVUS_E_INVALID and b'permutation' in lib.mvus_last_error(None)
+    r2 = rows.copy(); r2[7] = m
+    assert run(r2, cols, order)[0] == _lib.MVUS_E_INVALID and b'outside' in lib.mvus_last_error(None)
