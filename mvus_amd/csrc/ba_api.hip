@@ -1439,10 +1439,7 @@ int mvus_spline_smooth(int32_t device, int64_t m, const double* u, const double*
         if (need > t.size()) { t.resize(need, 0.0); fpint.resize(need, 0.0); nrdata.resize(need, 0); }
       }
       for (int j = 0; j < nrint; ++j) fpint[j] = host[4 + j];
-      for (int l = 0; l < nplus; ++l) {
-        fitpack::fpknot(u, t, n, fpint, nrdata, nrint);
-        if (n == nmax || n == nest) break;
-      }
+      fitpack::fpknot_batch(u, t, n, fpint, nrdata, nrint, nplus, nmax, nest);
       if (n == nmax) {                                      // fppara label 10: the knots of the interpolating spline
         if (t.size() < (size_t)nest) { t.resize((size_t)nest, 0.0); fpint.resize((size_t)nest, 0.0); nrdata.resize((size_t)nest, 0); }
         int i = k2, j = k / 2 + 2;

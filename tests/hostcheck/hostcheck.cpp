@@ -67,6 +67,12 @@ extern "C" void hostcheck_fpknot(int nest, const double* x, int* n, double* t, d
   fitpack::fpknot(x, tv, *n, fv, nd, *nrint);
   for (int i = 0; i < nest; ++i) { t[i] = tv[i]; fpint[i] = fv[i]; nrdata[i] = nd[i]; }
 }
+extern "C" void hostcheck_fpknot_batch(int nest, const double* x, int* n, double* t, double* fpint, int* nrdata, int* nrint, int nplus, int nmax) {
+  std::vector<double> tv(t, t + nest), fv(fpint, fpint + nest);
+  std::vector<int> nd(nrdata, nrdata + nest);
+  fitpack::fpknot_batch(x, tv, *n, fv, nd, *nrint, nplus, nmax, nest);
+  for (int i = 0; i < nest; ++i) { t[i] = tv[i]; fpint[i] = fv[i]; nrdata[i] = nd[i]; }
+}
 // op: 0 a+b, 1 a*b, 2 a/b, 3 sqrt(a), 4 exact product of the two high words;  a, b, out: (hi, lo)
 extern "C" void hostcheck_dd(int op, const double* a, const double* b, double* out) {
   const dd x(a[0], a[1]), y(b[0], b[1]);

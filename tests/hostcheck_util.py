@@ -48,6 +48,7 @@ def load():
     lib.hostcheck_fprati.restype = ctypes.c_double
     lib.hostcheck_fprati.argtypes = [_lib.c_double_p]
     lib.hostcheck_fpknot.argtypes = [ctypes.c_int, _lib.c_double_p, _lib.c_int32_p, _lib.c_double_p, _lib.c_double_p, _lib.c_int32_p, _lib.c_int32_p]
+    lib.hostcheck_fpknot_batch.argtypes = lib.hostcheck_fpknot.argtypes + [ctypes.c_int, ctypes.c_int]
     lib.hostcheck_dd.argtypes = [ctypes.c_int, _lib.c_double_p, _lib.c_double_p, _lib.c_double_p]
     lib.hostcheck_pnp_dlt6.argtypes = [_lib.c_double_p] * 4
     lib.hostcheck_pnp_project.argtypes = [_lib.c_double_p] * 6

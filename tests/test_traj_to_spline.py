@@ -140,6 +140,59 @@ def test_host_side_of_the_gpu_fit_matches_the_oracle():
         fp2[:] = fp1
 
 
+def test_batched_knot_insertion_is_fpknot_repeated():
+    """fpknot_batch (heap of candidate intervals + linked list, what the GPU path runs between passes) against `nplus` plain
+    fpknot calls from the same state: knots, residual estimates, sample counts, n and nrint identical -- on random states with
+    many exactly tied residuals (fpknot gives both halves of a split interval fp * n1 / n and fp * n2 / n: ties are the rule),
+    intervals without samples, and the stop at nest."""
+    import ctypes
+    from hostcheck_util import load
+    from mvus_amd import _lib
+    lib = load()
+    rng = np.random.default_rng(11)
+    for trial in range(30):
+        m = int(rng.integers(400, 3000))
+        u = np.cumsum(rng.uniform(0.5, 1.5, m))
+        nest = m + 6
+        # a state as after some passes: nrint intervals with random sample counts that add up (every interior knot is a sample)
+        nrint = int(rng.integers(64, 200))
+        cuts = np.sort(rng.choice(np.arange(2, m - 1), nrint - 1, replace=trial % 3 == 0))       # (replace: empty intervals cannot occur; adjacent cuts give nr = 0)
+        cuts = np.unique(cuts)
+        nrint = cuts.size + 1
+        t = np.zeros(nest); t[:4] = u[0]
+        t[4:4 + cuts.size] = u[cuts - 1]                   # knot at sample index cuts (1-based)
+        n = 8 + cuts.size
+        t[n - 4:n] = u[-1]
+        edges = np.concatenate([[1], cuts, [m]])
+        nr = np.zeros(nest, dtype=np.int32)
+        nr[:nrint] = np.diff(edges) - 1
+        nr[0] = cuts[0] - 2 if cuts.size else m - 2
+        fp = np.zeros(nest)
+        vals = rng.uniform(0.0, 5.0, nrint)
+        vals[rng.random(nrint) < 0.3] = 2.5                # exact ties between computed residuals too
+        vals[rng.random(nrint) < 0.05] = 0.0
+        fp[:nrint] = vals
+        nplus = int(rng.integers(8, 150))
+        nmax = m + 4
+        nest_stop = n + nplus - 3 if trial % 5 == 4 else nest          # some trials run into "n == nest"
+        t1, f1, r1 = t.copy(), fp.copy(), nr.copy()
+        n1, ri1 = ctypes.c_int32(n), ctypes.c_int32(nrint)
+        for _ in range(nplus):
+            lib.hostcheck_fpknot(nest, _lib.dptr(u), ctypes.byref(n1), _lib.dptr(t1), _lib.dptr(f1), r1.ctypes.data_as(_lib.c_int32_p), ctypes.byref(ri1))
+            if n1.value == nmax or n1.value == nest_stop:
+                break
+        t2, f2, r2 = t.copy(), fp.copy(), nr.copy()
+        n2, ri2 = ctypes.c_int32(n), ctypes.c_int32(nrint)
+        t2s, f2s, r2s = t2[:nest_stop].copy(), f2[:nest_stop].copy(), r2[:nest_stop].copy()
+        lib.hostcheck_fpknot_batch(nest_stop, _lib.dptr(u), ctypes.byref(n2), _lib.dptr(t2s), _lib.dptr(f2s), r2s.ctypes.data_as(_lib.c_int32_p), ctypes.byref(ri2),
+                                   nplus, nmax)
+        assert (n2.value, ri2.value) == (n1.value, ri1.value)
+        k = ri1.value
+        np.testing.assert_array_equal(t2s[4:4 + k - 1], t1[4:4 + k - 1])
+        np.testing.assert_array_equal(f2s[:k], f1[:k])
+        np.testing.assert_array_equal(r2s[:k], r1[:k])
+
+
 def test_double_double_arithmetic_on_the_host():
     """The double-double primitives of the ill-conditioned passes against exact rational arithmetic: ~1e-31 relative."""
     from fractions import Fraction
