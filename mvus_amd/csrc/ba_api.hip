@@ -509,11 +509,14 @@ struct HipBackend {
   }
 
   void jv(const double* v, double* y) {
+    const bool fused = dp.n_chunks > 0 && hp.T > 0;        // the motion rows in extra workgroups of k_jv
     if (dp.n_chunks > 0) {
-      if (hp.calib) hipLaunchKernelGGL(k_jv<30>, dim3(xcd_grid(dp.n_chunks)), dim3(kThreads), 0, stream, dp, J, span, v, y);
-      else hipLaunchKernelGGL(k_jv<21>, dim3(xcd_grid(dp.n_chunks)), dim3(kThreads), 0, stream, dp, J, span, v, y);
+      const unsigned grid = (unsigned)(xcd_grid(dp.n_chunks) + (fused ? (hp.T + kThreads - 1) / kThreads : 0));
+      const double* mj = fused ? mJ : nullptr;
+      if (hp.calib) hipLaunchKernelGGL(k_jv<30>, dim3(grid), dim3(kThreads), 0, stream, dp, J, span, v, y, mj, mctrl, y + 2 * hp.M);
+      else hipLaunchKernelGGL(k_jv<21>, dim3(grid), dim3(kThreads), 0, stream, dp, J, span, v, y, mj, mctrl, y + 2 * hp.M);
     }
-    if (hp.T > 0) hipLaunchKernelGGL(k_motion_jv, dim3((hp.T + kThreads - 1) / kThreads), dim3(kThreads), 0, stream, dp, mJ, mctrl, v, y + 2 * hp.M);
+    if (hp.T > 0 && !fused) hipLaunchKernelGGL(k_motion_jv, dim3((hp.T + kThreads - 1) / kThreads), dim3(kThreads), 0, stream, dp, mJ, mctrl, v, y + 2 * hp.M);
     MVUS_HIP(hipGetLastError());
   }
   // z = J^T u of this rank's rows: deterministic two-pass form (k_jtu_partial / k_jtu_reduce)

@@ -143,7 +143,7 @@ __global__ void k_undistort_fixed(DevProblem dp, double* __restrict__ u_obs, dou
 #endif
 constexpr int kXcdRun = MVUS_XCD_RUN;
 MVUS_HD int xcd_run_for(int tiles) { const int r = (tiles + 7) / 8; return r < kXcdRun ? (r > 0 ? r : 1) : kXcdRun; }
-inline int xcd_grid(int tiles) { const int per = 8 * xcd_run_for(tiles); return (tiles + per - 1) / per * per; }
+MVUS_HD int xcd_grid(int tiles) { const int per = 8 * xcd_run_for(tiles); return (tiles + per - 1) / per * per; }
 #if defined(__HIPCC__)
 __device__ __forceinline__ int xcd_tile(int tiles) {
   const int run = xcd_run_for(tiles);
@@ -366,11 +366,33 @@ __global__ __launch_bounds__(kThreads) void k_j_export(DevProblem dp, const doub
 }
 
 // y = J v on the detection rows.  Camera/sync entries of v are staged in LDS once per workgroup.
+// row j of the motion regulariser times v
+__device__ __forceinline__ double motion_row_times(const DevProblem& dp, const double* __restrict__ mJ, const int32_t* __restrict__ mctrl,
+                                                   const double* __restrict__ v, int j) {
+  double s = 0.0;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int g = mctrl[(long long)k * dp.T + j];
+    if (g < 0) continue;
+    const int x0 = dp.mv.ctrl_x0[g], st = dp.mv.ctrl_stride[g];
+    for (int q = 0; q < 4; ++q)
+      for (int d = 0; d < 3; ++d) s += mJ[(long long)(12 * k + 3 * q + d) * dp.T + j] * v[x0 + q + d * st];
+  }
+  return s;
+}
+// (workgroups past xcd_grid(n_chunks), when mJ is given: the motion rows -- k_motion_jv beside the detection rows instead of
+// after them: one launch less in every LSMR iteration of the default solver, which is launch bound at the reference's sizes)
 template <int NS>
 __global__ __launch_bounds__(kThreads) void k_jv(DevProblem dp, const double* __restrict__ J, const int32_t* __restrict__ span,
-                                                 const double* __restrict__ v, double* __restrict__ y) {
+                                                 const double* __restrict__ v, double* __restrict__ y, const double* __restrict__ mJ = nullptr,
+                                                 const int32_t* __restrict__ mctrl = nullptr, double* __restrict__ ym = nullptr) {
   constexpr int B = NS - 12;
   __shared__ double vc[B];
+  if (mJ != nullptr && (int)blockIdx.x >= xcd_grid(dp.n_chunks)) {
+    const int j = ((int)blockIdx.x - xcd_grid(dp.n_chunks)) * kThreads + threadIdx.x;
+    if (j < dp.T) ym[j] = motion_row_times(dp, mJ, mctrl, v, j);
+    return;
+  }
     const int chunk = xcd_tile(dp.n_chunks);        // grid = xcd_grid(n_chunks): every XCD streams runs of consecutive chunks of J
   if (chunk >= dp.n_chunks) return;
   const int c = dp.chunk_cam[chunk];
@@ -627,16 +649,7 @@ __global__ __launch_bounds__(kThreads) void k_motion_jv(DevProblem dp, const dou
                                                         const double* __restrict__ v, double* __restrict__ ym) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= dp.T) return;
-  double s = 0.0;
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const int g = mctrl[(long long)k * dp.T + j];
-    if (g < 0) continue;
-    const int x0 = dp.mv.ctrl_x0[g], st = dp.mv.ctrl_stride[g];
-    for (int q = 0; q < 4; ++q)
-      for (int d = 0; d < 3; ++d) s += mJ[(long long)(12 * k + 3 * q + d) * dp.T + j] * v[x0 + q + d * st];
-  }
-  ym[j] = s;
+  ym[j] = motion_row_times(dp, mJ, mctrl, v, j);
 }
 
 // Scene.remove_outliers (common.py:709-713): keep = sqrt(ex^2 + ey^2) < thres.  Explicit round-to-nearest
