@@ -6,6 +6,7 @@
 Everything is computed by libmvusba.so on the GPU; there is no CPU fallback.
 """
 import ctypes
+import sys
 from types import SimpleNamespace
 
 import numpy as np
@@ -40,6 +41,11 @@ class BAHandle:
             self.h = None
 
     def __del__(self):
+        # not while the interpreter shuts down: modules (and torch's own HIP state) are torn down in no particular order then, and
+        # a handle that dies with the process needs no hipFree -- one GPU-suite run in eleven ended with a fatal signal after its
+        # summary line before this guard
+        if sys.is_finalizing():
+            return
         try:
             self.close()
         except Exception:
