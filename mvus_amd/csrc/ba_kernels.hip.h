@@ -594,7 +594,15 @@ __global__ __launch_bounds__(kThreads) void k_jtu_reduce(DevProblem dp, const do
     const int c = blockIdx.x, k = threadIdx.x;
     if (k >= B) return;
     double acc = 0.0;
-    for (int ch = dp.cam_chunk_off[c]; ch < dp.cam_chunk_off[c + 1]; ++ch) acc += zc[(long long)ch * B + k];
+    // (sixteen loads in flight, then their adds in chunk order: the same sum, a sixteenth of the memory round trips)
+    const int ch1 = dp.cam_chunk_off[c + 1];
+    for (int ch0 = dp.cam_chunk_off[c]; ch0 < ch1; ch0 += 16) {
+      double t[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) t[q] = ch0 + q < ch1 ? zc[(long long)(ch0 + q) * B + k] : 0.0;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) if (ch0 + q < ch1) acc += t[q];
+    }
     z[cam_col(dp.C, dp.P, c, k)] += acc;
     return;
   }
@@ -602,19 +610,37 @@ __global__ __launch_bounds__(kThreads) void k_jtu_reduce(DevProblem dp, const do
   const int g = ((int)blockIdx.x - dp.C) * (kThreads / 64) + (threadIdx.x >> 6);
   if (g >= dp.N) return;
   double acc[3] = {0.0, 0.0, 0.0};
+  const int mrow_lo = motion ? dp.mv.row_lo[g] : 0, mrow_hi = motion ? dp.mv.row_hi[g] : 0;      // (fetched beside the cameras' first loads)
   for (int c = lane; c < dp.C; c += 64) {
     // first chunk whose running-max window start is within reach of g (everything before ends left of g) ...
     const int end = dp.cam_chunk_off[c + 1];
     const int lo = first ? first[(long long)g * dp.C + c] : jtu_first_chunk(dp, zfill, c, g);
     // ... then forward until the running maximum is a whole window past g (a later chunk's own start is never that far
     // below the running maximum), adding the covering windows in chunk order
-    for (int ch = lo; ch < end && zfill[ch] <= g + kJtWin; ++ch) {
-      const int g0 = zg0[ch];
-      const int lc = g - g0;
-      if (g0 != 0x7fffffff && lc >= 0 && lc < kJtWin) {
-        const double* w = zs + (long long)ch * (3 * kJtWin) + 3 * lc;
-        acc[0] += w[0]; acc[1] += w[1]; acc[2] += w[2];
+    // (four chunks at a time: their window starts together, then the entries of the covering ones together, then the adds in
+    // chunk order -- the same sums as the one-chunk-at-a-time loop with a third of its dependent memory round trips; zfill is
+    // non-decreasing, so "the loop has not stopped before chunk ch" is zfill[ch] <= g + kJtWin by itself)
+    for (int ch0 = lo; ch0 < end; ch0 += 4) {
+      int fill[4], g0[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const bool in = ch0 + q < end;
+        fill[q] = in ? zfill[ch0 + q] : 0x7fffffff;
+        g0[q] = in ? zg0[ch0 + q] : 0x7fffffff;
       }
+      double w[4][3];
+      bool use[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int lc = g - g0[q];
+        use[q] = fill[q] <= g + kJtWin && g0[q] != 0x7fffffff && lc >= 0 && lc < kJtWin;
+        const double* wp = zs + (long long)(ch0 + q) * (3 * kJtWin) + 3 * (use[q] ? lc : 0);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) w[q][d] = use[q] ? wp[d] : 0.0;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) if (use[q]) { acc[0] += w[q][0]; acc[1] += w[q][1]; acc[2] += w[q][2]; }
+      if (!(fill[3] <= g + kJtWin)) break;
     }
   }
 #pragma unroll
@@ -624,7 +650,7 @@ __global__ __launch_bounds__(kThreads) void k_jtu_reduce(DevProblem dp, const do
   if (motion) {
     // motion rows: lanes take rows row_lo + lane, + 64, ...; same butterfly
     double ma[3] = {0.0, 0.0, 0.0};
-    for (int j = dp.mv.row_lo[g] + lane; j < dp.mv.row_hi[g]; j += 64) {
+    for (int j = mrow_lo + lane; j < mrow_hi; j += 64) {
       const double uj = um[j];
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
