@@ -505,6 +505,9 @@ __global__ __launch_bounds__(kBandPartsMax) void k_band_solve_parts(int n, BandP
   __shared__ int s_bad[kBandPartsMax];
   PivotStats<T> ps;
   const int r0 = p < P ? bp.first(p) : 0, lp = p < P ? bp.length(p) : 0;
+#ifdef MVUS_PARTS_PROBE
+  const long long tq0_ = wall_clock64();
+#endif
   // ---- phase 1 ----
   if (p < P) {
     T Lp[HB + 1][HB + 1];                             // Lp[u][w] = L(i-u, i-u-w)
@@ -526,26 +529,30 @@ __global__ __launch_bounds__(kBandPartsMax) void k_band_solve_parts(int n, BandP
 #pragma unroll
       for (int d = 0; d < 3; ++d) gl[a][d] = T(0.0);
     }
-    T nxt[HB + 1], nb[3];
+    // rows are fetched RB at a time (all loads of a batch in flight together): with one row ahead every row waited a full memory
+    // round trip (~0.7 us against ~0.15 us of fp64 arithmetic)
+    constexpr int RB = sizeof(T) == sizeof(double) ? 8 : 2;
+    for (int i0 = 0; i0 < lp; i0 += RB) {
+     T cm[RB][HB + 1], cb[RB][3];
 #pragma unroll
-    for (int w = 0; w <= HB; ++w) nxt[w] = Mt[bp.at(p, 0, w, NW)];
+     for (int r = 0; r < RB; ++r) {
+       const int ii = i0 + r < lp ? i0 + r : lp - 1;
 #pragma unroll
-    for (int d = 0; d < 3; ++d) nb[d] = rt[bp.at(p, 0, d, 3)];
-    for (int i = 0; i < lp; ++i) {
-      const long long j = r0 + i;
+       for (int w = 0; w <= HB; ++w) cm[r][w] = Mt[bp.at(p, ii, w, NW)];
+#pragma unroll
+       for (int d = 0; d < 3; ++d) cb[r][d] = rt[bp.at(p, ii, d, 3)];
+     }
+#pragma unroll
+     for (int r = 0; r < RB; ++r) {
+      const int i = i0 + r;
+      if (i >= lp) break;
       T row[HB + 1], b[NC];
 #pragma unroll
-      for (int w = 0; w <= HB; ++w) row[w] = nxt[w];
+      for (int w = 0; w <= HB; ++w) row[w] = cm[r][w];
 #pragma unroll
       for (int col = 0; col < HB; ++col) b[col] = T(0.0);
 #pragma unroll
-      for (int d = 0; d < 3; ++d) b[HB + d] = nb[d];
-      if (i + 1 < lp) {
-#pragma unroll
-        for (int w = 0; w <= HB; ++w) nxt[w] = Mt[bp.at(p, i + 1, w, NW)];
-#pragma unroll
-        for (int d = 0; d < 3; ++d) nb[d] = rt[bp.at(p, i + 1, d, 3)];
-      }
+      for (int d = 0; d < 3; ++d) b[HB + d] = cb[r][d];
       if (i < HB) {                                   // M(j, j-w) with i - w < 0 couples to the separator on the left: column i + HB - w of it
 #pragma unroll
         for (int w = 1; w <= HB; ++w) {
@@ -603,6 +610,7 @@ __global__ __launch_bounds__(kBandPartsMax) void k_band_solve_parts(int n, BandP
       for (int w = 0; w <= HB; ++w) Lp[1][w] = row[w];
 #pragma unroll
       for (int col = 0; col < NC; ++col) Yp[1][col] = y[col];
+     }
     }
     T* rc = rec + (long long)p * R::SIZE;
 #pragma unroll
@@ -654,35 +662,59 @@ __global__ __launch_bounds__(kBandPartsMax) void k_band_solve_parts(int n, BandP
   }
   __syncthreads();
   __threadfence_block();
-  // ---- phase 2: the separator system, one lane ----
-  if (p == 0) {
-    T W[HB][HB], z[HB][3];
-    for (int q = 0; q + 1 < P; ++q) {
+#ifdef MVUS_PARTS_PROBE
+  const long long tq1_ = wall_clock64();
+#endif
+  // ---- phase 2: the separator system: lanes 0..2 of the first wavefront, one right-hand side each (the matrix part is the same
+  // arithmetic in all three; lane 0 stores it).  The inputs of separator q + 1 are fetched while separator q is processed: a step
+  // was 2.6 us (fp64), one memory round trip of it waiting for ~60 loads.
+  if (p < 3) {
+    const int dcol = p;
+    struct SepIn { T grr[HB][HB], gll[HB][HB], cm[HB][HB], m[HB][HB], gr[HB], gl[HB], rh[HB]; };
+    auto load_sep = [&](int q, SepIn& in) {
       const long long s0 = (long long)bp.first(q) + bp.length(q);
       const T* ra = rec + (long long)q * R::SIZE;
       const T* rb = rec + (long long)(q + 1) * R::SIZE;
-      T D[HB][HB], full[HB], r[HB][3];
+#pragma unroll
+      for (int a = 0; a < HB; ++a) {
+#pragma unroll
+        for (int b2 = 0; b2 < HB; ++b2) {
+          in.grr[a][b2] = b2 <= a ? ra[R::GRR + a * HB + b2] : T(0.0);
+          in.gll[a][b2] = b2 <= a ? rb[R::GLL + a * HB + b2] : T(0.0);
+          in.cm[a][b2] = rb[R::C + a * HB + b2];
+          in.m[a][b2] = b2 <= a ? M[5 * (s0 + a) + (a - b2)] : T(0.0);
+        }
+        in.gr[a] = ra[R::GR + a * 3 + dcol];
+        in.gl[a] = rb[R::GL + a * 3 + dcol];
+        in.rh[a] = rhs[(long long)dcol * n + s0 + a];
+      }
+    };
+    T W[HB][HB], z[HB];
+    PivotStats<T> ps2;                                // the separator pivots (lane 0 adds them to its statistics)
+    SepIn nxt_in;
+    if (P > 1) load_sep(0, nxt_in);
+    for (int q = 0; q + 1 < P; ++q) {
+      const SepIn in = nxt_in;
+      if (q + 2 < P) load_sep(q + 1, nxt_in);
+      T D[HB][HB], full[HB], r[HB];
 #pragma unroll
       for (int a = 0; a < HB; ++a) {
 #pragma unroll
         for (int b2 = 0; b2 <= a; ++b2) {
-          T v = M[5 * (s0 + a) + (a - b2)] - ra[R::GRR + a * HB + b2] - rb[R::GLL + a * HB + b2];
-          if (b2 == a) full[a] = M[5 * (s0 + a)];
+          T v = in.m[a][b2] - in.grr[a][b2] - in.gll[a][b2];
+          if (b2 == a) full[a] = in.m[a][a];
           if (q > 0) {
 #pragma unroll
             for (int k = 0; k < HB; ++k) v -= W[a][k] * W[b2][k];
           }
           D[a][b2] = v;
         }
+        T v = in.rh[a] - in.gr[a] - in.gl[a];
+        if (q > 0) {
 #pragma unroll
-        for (int d = 0; d < 3; ++d) {
-          T v = rhs[(long long)d * n + s0 + a] - ra[R::GR + a * 3 + d] - rb[R::GL + a * 3 + d];
-          if (q > 0) {
-#pragma unroll
-            for (int k = 0; k < HB; ++k) v -= W[a][k] * z[k][d];
-          }
-          r[a][d] = v;
+          for (int k = 0; k < HB; ++k) v -= W[a][k] * z[k];
         }
+        r[a] = v;
       }
       T Lt[HB][HB], il[HB];
 #pragma unroll
@@ -697,78 +729,89 @@ __global__ __launch_bounds__(kBandPartsMax) void k_band_solve_parts(int n, BandP
         T dg = D[a][a];
 #pragma unroll
         for (int k = 0; k < HB; ++k) if (k < a) dg -= Lt[a][k] * Lt[a][k];
-        Lt[a][a] = ps.pivot(dg, full[a]);
+        Lt[a][a] = ps2.pivot(dg, full[a]);
         il[a] = num_recip(Lt[a][a]);
+        T v = r[a];
 #pragma unroll
-        for (int d = 0; d < 3; ++d) {
-          T v = r[a][d];
-#pragma unroll
-          for (int k = 0; k < HB; ++k) if (k < a) v -= Lt[a][k] * z[k][d];
-          z[a][d] = v * il[a];
-        }
+        for (int k = 0; k < HB; ++k) if (k < a) v -= Lt[a][k] * z[k];
+        z[a] = v * il[a];
       }
       T* sq = sep + (long long)q * S::SIZE;
 #pragma unroll
       for (int a = 0; a < HB; ++a) {
+        if (dcol == 0) {
 #pragma unroll
-        for (int b2 = 0; b2 < HB; ++b2) sq[S::LT + a * HB + b2] = b2 < a ? Lt[a][b2] : (b2 == a ? il[a] : T(0.0));    // the diagonal holds 1 / L
-#pragma unroll
-        for (int d = 0; d < 3; ++d) sq[S::Z + a * 3 + d] = z[a][d];
+          for (int b2 = 0; b2 < HB; ++b2) sq[S::LT + a * HB + b2] = b2 < a ? Lt[a][b2] : (b2 == a ? il[a] : T(0.0));    // the diagonal holds 1 / L
+        }
+        sq[S::Z + a * 3 + dcol] = z[a];
       }
       if (q + 2 < P) {                                // W = O Lt^-T, O(cq, cc) = -C_{q+1}(cc, cq): rows = the next separator
 #pragma unroll
         for (int a = 0; a < HB; ++a) {
 #pragma unroll
           for (int k = 0; k < HB; ++k) {
-            T v = -rb[R::C + k * HB + a];
+            T v = -in.cm[k][a];
 #pragma unroll
             for (int m2 = 0; m2 < HB; ++m2) if (m2 < k) v -= W[a][m2] * Lt[k][m2];
             W[a][k] = v * il[k];
           }
         }
+        if (dcol == 0) {
 #pragma unroll
-        for (int a = 0; a < HB; ++a) {
+          for (int a = 0; a < HB; ++a) {
 #pragma unroll
-          for (int k = 0; k < HB; ++k) sq[S::W + a * HB + k] = W[a][k];
+            for (int k = 0; k < HB; ++k) sq[S::W + a * HB + k] = W[a][k];
+          }
         }
       }
     }
-    T x[HB][3];
-    for (int q = P - 2; q >= 0; --q) {                // x_q = Lt^-T (z_q - W_q^T x_{q+1})
-      T* sq = sep + (long long)q * S::SIZE;
-      T v[HB][3];
+    if (dcol == 0) { ps.dsum += ps2.dsum; ps.dmin = fmin(ps.dmin, ps2.dmin); ps.dmax = fmax(ps.dmax, ps2.dmax); ps.bad |= ps2.bad; }
+    // lanes 1, 2 read what lane 0 stored (Lt, W): same wavefront, program order + the memory fence below
+    __threadfence_block();
+    T x[HB];
+    struct SepBack { T lt[HB][HB], w[HB][HB], z[HB]; };
+    auto load_back = [&](int q, SepBack& in) {
+      const T* sq = sep + (long long)q * S::SIZE;
 #pragma unroll
       for (int a = 0; a < HB; ++a) {
 #pragma unroll
-        for (int d = 0; d < 3; ++d) {
-          T t = sq[S::Z + a * 3 + d];
-          if (q + 2 < P) {
+        for (int k = 0; k < HB; ++k) { in.lt[a][k] = sq[S::LT + a * HB + k]; in.w[a][k] = q + 2 < P ? sq[S::W + a * HB + k] : T(0.0); }
+        in.z[a] = sq[S::Z + a * 3 + dcol];
+      }
+    };
+    SepBack nxt_b;
+    if (P > 1) load_back(P - 2, nxt_b);
+    for (int q = P - 2; q >= 0; --q) {                // x_q = Lt^-T (z_q - W_q^T x_{q+1}); the blocks of q - 1 are fetched meanwhile
+      T* sq = sep + (long long)q * S::SIZE;
+      const SepBack in = nxt_b;
+      if (q > 0) load_back(q - 1, nxt_b);
+      T v[HB];
 #pragma unroll
-            for (int k = 0; k < HB; ++k) t -= sq[S::W + k * HB + a] * x[k][d];
-          }
-          v[a][d] = t;
+      for (int a = 0; a < HB; ++a) {
+        T t = in.z[a];
+        if (q + 2 < P) {
+#pragma unroll
+          for (int k = 0; k < HB; ++k) t -= in.w[k][a] * x[k];
         }
+        v[a] = t;
       }
 #pragma unroll
       for (int a = HB - 1; a >= 0; --a) {
+        T t = v[a];
 #pragma unroll
-        for (int d = 0; d < 3; ++d) {
-          T t = v[a][d];
-#pragma unroll
-          for (int k = 0; k < HB; ++k) if (k > a) t -= sq[S::LT + k * HB + a] * x[k][d];
-          x[a][d] = t * sq[S::LT + a * HB + a];
-        }
+        for (int k = 0; k < HB; ++k) if (k > a) t -= in.lt[k][a] * x[k];
+        x[a] = t * in.lt[a][a];
       }
       const long long s0 = (long long)bp.first(q) + bp.length(q);
 #pragma unroll
-      for (int a = 0; a < HB; ++a) {
-#pragma unroll
-        for (int d = 0; d < 3; ++d) { sq[S::X + a * 3 + d] = x[a][d]; c[(long long)d * n + s0 + a] = to_double(x[a][d]); }
-      }
+      for (int a = 0; a < HB; ++a) { sq[S::X + a * 3 + dcol] = x[a]; c[(long long)dcol * n + s0 + a] = to_double(x[a]); }
     }
   }
   __syncthreads();
   __threadfence_block();
+#ifdef MVUS_PARTS_PROBE
+  const long long tq2_ = wall_clock64();
+#endif
   // ---- phase 3 ----
   if (p < P) {
     T xl[HB][3], xr[HB][3], yr[HB][HB];
@@ -790,26 +833,31 @@ __global__ __launch_bounds__(kBandPartsMax) void k_band_solve_parts(int n, BandP
 #pragma unroll
       for (int d = 0; d < 3; ++d) cn[u][d] = T(0.0);
     }
-    T nrow[HB + 1], nyl[HB], ny[3];
-    auto fetch = [&](int i) {
+    constexpr int RB = sizeof(T) == sizeof(double) ? 8 : 2;            // rows per batch of loads, as in phase 1
+    for (int i1 = lp - 1; i1 >= 0; i1 -= RB) {
+     T cm[RB][HB + 1], cyl[RB][HB], cy[RB][3];
 #pragma unroll
-      for (int w = 0; w <= HB; ++w) nrow[w] = Mt[bp.at(p, i, w, NW)];
+     for (int r = 0; r < RB; ++r) {
+       const int ii = i1 - r >= 0 ? i1 - r : 0;
 #pragma unroll
-      for (int col = 0; col < HB; ++col) nyl[col] = YL[bp.at(p, i, col, HB)];
+       for (int w = 0; w <= HB; ++w) cm[r][w] = Mt[bp.at(p, ii, w, NW)];
 #pragma unroll
-      for (int d = 0; d < 3; ++d) ny[d] = rt[bp.at(p, i, d, 3)];
-    };
-    fetch(lp - 1);
-    for (int i = lp - 1; i >= 0; --i) {
+       for (int col = 0; col < HB; ++col) cyl[r][col] = YL[bp.at(p, ii, col, HB)];
+#pragma unroll
+       for (int d = 0; d < 3; ++d) cy[r][d] = rt[bp.at(p, ii, d, 3)];
+     }
+#pragma unroll
+     for (int r = 0; r < RB; ++r) {
+      const int i = i1 - r;
+      if (i < 0) break;
       const long long j = r0 + i;
       T row[HB + 1], yl[HB], v[3];
 #pragma unroll
-      for (int w = 0; w <= HB; ++w) row[w] = nrow[w];
+      for (int w = 0; w <= HB; ++w) row[w] = cm[r][w];
 #pragma unroll
-      for (int col = 0; col < HB; ++col) yl[col] = nyl[col];
+      for (int col = 0; col < HB; ++col) yl[col] = cyl[r][col];
 #pragma unroll
-      for (int d = 0; d < 3; ++d) v[d] = ny[d];
-      if (i > 0) fetch(i - 1);
+      for (int d = 0; d < 3; ++d) v[d] = cy[r][d];
       const int rr = i - (lp - HB);                   // row of Y_R (>= 0 in the last HB rows of the interior)
       const T inv = num_recip(row[0]);
 #pragma unroll
@@ -843,6 +891,7 @@ __global__ __launch_bounds__(kBandPartsMax) void k_band_solve_parts(int n, BandP
       for (int w = 0; w <= HB; ++w) Ln[1][w] = row[w];
 #pragma unroll
       for (int d = 0; d < 3; ++d) cn[1][d] = v[d];
+     }
     }
   }
   s_min[p] = ps.dmin; s_max[p] = ps.dmax; s_bad[p] = ps.bad ? 1 : 0;
@@ -853,6 +902,10 @@ __global__ __launch_bounds__(kBandPartsMax) void k_band_solve_parts(int n, BandP
     for (int k = 0; k < (int)blockDim.x; ++k) { mn = fmin(mn, s_min[k]); mx = fmax(mx, s_max[k]); bad |= s_bad[k]; }
     out[2] = mn; out[3] = mx;
     if (bad) fail[0] = 1;
+#ifdef MVUS_PARTS_PROBE
+    if (n > 3000 && n < 3400) printf("parts HB=%d %s n=%d P=%d: phase 1 %lld, phase 2 %lld, phase 3 %lld (10 ns ticks)\n", HB, sizeof(T) == 8 ? "fp64" : "dd", n, P,
+                                     tq1_ - tq0_, tq2_ - tq1_, wall_clock64() - tq2_);
+#endif
   }
 }
 #endif
