@@ -79,7 +79,13 @@ class HostHandle:
             self.h = None
 
     def __del__(self):
-        self.close()
+        import sys
+        if sys is None or sys.is_finalizing():             # module globals may be gone at interpreter shutdown
+            return
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def residual(self, x):
         x = np.ascontiguousarray(x, dtype=np.float64)
