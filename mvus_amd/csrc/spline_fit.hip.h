@@ -691,11 +691,15 @@ __global__ __launch_bounds__(kBandPartsMax) void k_band_solve_parts(int n, BandP
     };
     T W[HB][HB], z[HB];
     PivotStats<T> ps2;                                // the separator pivots (lane 0 adds them to its statistics)
+    // (fp64 only: in double-double the second set of blocks does not fit the register file -- 312 B of scratch per lane -- and the
+    // arithmetic of a step, ~12 us, hides nothing worth hiding)
+    constexpr bool kAhead = sizeof(T) == sizeof(double);
     SepIn nxt_in;
-    if (P > 1) load_sep(0, nxt_in);
+    if (kAhead && P > 1) load_sep(0, nxt_in);
     for (int q = 0; q + 1 < P; ++q) {
-      const SepIn in = nxt_in;
-      if (q + 2 < P) load_sep(q + 1, nxt_in);
+      SepIn in;
+      if (kAhead) { in = nxt_in; if (q + 2 < P) load_sep(q + 1, nxt_in); }
+      else load_sep(q, in);
       T D[HB][HB], full[HB], r[HB];
 #pragma unroll
       for (int a = 0; a < HB; ++a) {
@@ -780,11 +784,12 @@ __global__ __launch_bounds__(kBandPartsMax) void k_band_solve_parts(int n, BandP
       }
     };
     SepBack nxt_b;
-    if (P > 1) load_back(P - 2, nxt_b);
+    if (kAhead && P > 1) load_back(P - 2, nxt_b);
     for (int q = P - 2; q >= 0; --q) {                // x_q = Lt^-T (z_q - W_q^T x_{q+1}); the blocks of q - 1 are fetched meanwhile
       T* sq = sep + (long long)q * S::SIZE;
-      const SepBack in = nxt_b;
-      if (q > 0) load_back(q - 1, nxt_b);
+      SepBack in;
+      if (kAhead) { in = nxt_b; if (q > 0) load_back(q - 1, nxt_b); }
+      else load_back(q, in);
       T v[HB];
 #pragma unroll
       for (int a = 0; a < HB; ++a) {
