@@ -279,6 +279,15 @@ int mvus_spline_lsq(int32_t device, int32_t num_knots, const double* knots, int6
 int mvus_spline_smooth(int32_t device, int64_t m, const double* u, const double* X, double s, int32_t* n_out, double* t_out, double* c_out,
                        double* fp_out, int32_t* ier_out);
 
+/* The same fit as a session: the samples are checked and uploaded once, the work arrays stay allocated, and every call of
+ * mvus_spline_fit_smooth is one splprep(X, u=u, s=s, k=3) on them -- Scene.traj_to_spline's smooth_factor loop
+ * (common.py:241-262) calls splprep about a dozen times on the same part with s doubled or divided by 1.5.  Same results
+ * as mvus_spline_smooth (which is open + smooth + close).  t_out[m + 6], c_out[3][m + 6] as there. */
+typedef struct mvus_spline_fit mvus_spline_fit;
+int mvus_spline_fit_open(int32_t device, int64_t m, const double* u, const double* X, mvus_spline_fit** out);
+int mvus_spline_fit_smooth(mvus_spline_fit* fit, double s, int32_t* n_out, double* t_out, double* c_out, double* fp_out, int32_t* ier_out);
+void mvus_spline_fit_close(mvus_spline_fit* fit);
+
 /* Scene.get_camera_pose's cv2.solvePnPRansac(objectPoints, imagePoints, K, d, reprojectionError=error) (common.py:744; OpenCV is
  * a third-party dependency absent from this image: parity unpinned, see pnp.hip.h).  X[3*N] object points (x(N) y(N) z(N)),
  * uv[2*N] raw pixels (u(N) v(N)), K = fx fy cx cy, d = k1 k2 p1 p2 k3.  `iterations` hypotheses (OpenCV's iterationsCount,

@@ -87,6 +87,10 @@ API = [
     ('mvus_spline_lsq', ctypes.c_int, [ctypes.c_int32, ctypes.c_int32, c_double_p, ctypes.c_int64, c_double_p, c_double_p, c_double_p]),
     ('mvus_spline_smooth', ctypes.c_int, [ctypes.c_int32, ctypes.c_int64, c_double_p, c_double_p, ctypes.c_double, c_int32_p, c_double_p, c_double_p,
                                           c_double_p, c_int32_p]),
+    ('mvus_spline_fit_open', ctypes.c_int, [ctypes.c_int32, ctypes.c_int64, c_double_p, c_double_p, ctypes.POINTER(ctypes.c_void_p)]),
+    ('mvus_spline_fit_smooth', ctypes.c_int, [ctypes.c_void_p, ctypes.c_double, ctypes.POINTER(ctypes.c_int32), c_double_p, c_double_p,
+                                              ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int32)]),
+    ('mvus_spline_fit_close', None, [ctypes.c_void_p]),
     ('mvus_pnp_ransac', ctypes.c_int, [ctypes.c_int32, ctypes.c_int64, c_double_p, c_double_p, c_double_p, c_double_p, ctypes.c_double, ctypes.c_int32,
                                        ctypes.c_uint64, c_double_p, c_double_p, c_uint8_p, c_int64_p]),
     ('mvus_triangulate', ctypes.c_int, [ctypes.c_int32, ctypes.c_int64, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]),

@@ -1255,47 +1255,89 @@ int mvus_spline_lsq(int32_t device, int32_t num_knots, const double* knots, int6
 }
 
 /* scipy.interpolate.splprep(X, u=u, s=s, k=3) on the GPU (spline_fit.hip.h): fppara's control flow here, every pass over the
- * samples and every banded solve on the device. */
-int mvus_spline_smooth(int32_t device, int64_t m, const double* u, const double* X, double s, int32_t* n_out, double* t_out, double* c_out,
-                       double* fp_out, int32_t* ier_out) {
+ * samples and every banded solve on the device.  A SESSION holds the samples (checked and uploaded once) and the work arrays:
+ * traj_to_spline's smooth_factor loop fits the same samples a dozen times with different s. */
+struct mvus_spline_fit {
+  CallBuffers cb;
+  int64_t m = 0;
+  std::vector<double> hu;                                  // the timestamps on the host (fpknot places knots at samples)
+  const double *du = nullptr, *dX = nullptr;
+  int32_t* span = nullptr;
+  double *q = nullptr, *term = nullptr, *tot_part = nullptr, *fp_part = nullptr;
+  int* fail = nullptr;
+  long long* first = nullptr;
+  double *cd = nullptr, *td = nullptr, *bd = nullptr, *out = nullptr;
+  FitWork<double> w1;
+  FitWork<dd> w2;
+  size_t cap = 0;
+};
+static int spline_fit_open_impl(mvus_spline_fit& S, int32_t device, int64_t m, const double* u, const double* X) {
+  constexpr int k = 3;
+  if (m <= k || m > (1ll << 30) || !u || !X) { g_create_error = "spline_smooth: bad arguments (m > 3 samples, s > 0)"; return MVUS_E_INVALID; }
+  for (int64_t i = 1; i < m; ++i) if (!(u[i] > u[i - 1])) { g_create_error = "spline_smooth: the timestamps must be strictly increasing"; return MVUS_E_INVALID; }
+  for (int64_t i = 0; i < 3 * m; ++i) if (!std::isfinite(X[i])) { g_create_error = "spline_smooth: non-finite sample"; return MVUS_E_INVALID; }
+  try {
+    S.m = m;
+    S.hu.assign(u, u + m);
+    CallBuffers& cb = S.cb;
+    cb.open(device);
+    S.du = cb.put(u, (size_t)m);
+    S.dX = cb.put(X, 3 * (size_t)m);
+    S.span = cb.get<int32_t>((size_t)m);
+    S.q = cb.get<double>(4 * (size_t)m);
+    S.term = cb.get<double>((size_t)m);
+    S.tot_part = cb.get<double>(1024);
+    S.fp_part = cb.get<double>(512 + kFitSliceBlocks);
+    S.fail = cb.get<int>(1);
+    MVUS_HIP(hipStreamSynchronize(cb.st));                 // u and X may go away after this call
+  } catch (const HipError& e) {
+    g_create_error = e.msg;
+    return e.code;
+  } catch (const std::exception& e) {
+    g_create_error = e.what();
+    return MVUS_E_INVALID;
+  }
+  return MVUS_OK;
+}
+static int spline_fit_run(mvus_spline_fit& S, double s, int32_t* n_out, double* t_out, double* c_out, double* fp_out, int32_t* ier_out) {
   constexpr int k = 3, k1 = 4, k2 = 5, nmin = 8, maxit = 20;
   constexpr double tol = 0.001;
-  if (m <= k || m > (1ll << 30) || !u || !X || !n_out || !t_out || !c_out || !(s > 0.0) || !std::isfinite(s)) { g_create_error = "spline_smooth: bad arguments (m > 3 samples, s > 0)"; return MVUS_E_INVALID; }
+  const int64_t m = S.m;
+  const double* u = S.hu.data();
+  if (!n_out || !t_out || !c_out || !(s > 0.0) || !std::isfinite(s)) { g_create_error = "spline_smooth: bad arguments (m > 3 samples, s > 0)"; return MVUS_E_INVALID; }
   const bool timing = std::getenv("MVUS_FIT_TIMING") != nullptr;
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
   const auto t_begin = now();
   int passes = 0;
-  for (int64_t i = 1; i < m; ++i) if (!(u[i] > u[i - 1])) { g_create_error = "spline_smooth: the timestamps must be strictly increasing"; return MVUS_E_INVALID; }
-  for (int64_t i = 0; i < 3 * m; ++i) if (!std::isfinite(X[i])) { g_create_error = "spline_smooth: non-finite sample"; return MVUS_E_INVALID; }
   const int nest = (int)m + 2 * k, nmax = (int)m + k1;
   const auto t_checked = now();
   auto t_ready = t_checked, t_fitted = t_checked;
   try {
-    CallBuffers cb;
-    cb.open(device);
-    const double* du = cb.put(u, (size_t)m);
-    const double* dX = cb.put(X, 3 * (size_t)m);
-    int32_t* span = cb.get<int32_t>((size_t)m);
-    double* q = cb.get<double>(4 * (size_t)m);
-    double* term = cb.get<double>((size_t)m);
-    double* tot_part = cb.get<double>(1024);
-    double* fp_part = cb.get<double>(512 + kFitSliceBlocks);
+    CallBuffers& cb = S.cb;
+    const double* du = S.du;
+    const double* dX = S.dX;
+    int32_t* span = S.span;
+    double* q = S.q;
+    double* term = S.term;
+    double* tot_part = S.tot_part;
+    double* fp_part = S.fp_part;
     // Everything indexed by knots is sized by a CAPACITY that grows with the knot count (x4, up to FITPACK's nest = m + 6), not
     // by nest: the trajectories traj_to_spline fits are 50x oversampled (560k samples for ~600 knots), and allocating and
     // freeing ~40 arrays of nest doubles (430 MB with the double-double set) cost 70 of the 77 ms of such a fit
-    long long* first = nullptr;
-    double *cd = nullptr, *td = nullptr, *bd = nullptr, *out = nullptr;   // out: [0] sum diag(L), [1] f_p, [2] min diag(L), [3] max diag(L), [4..] residual per span
-    int* fail = cb.get<int>(1);
-    FitWork<double> w1;
-    FitWork<dd> w2;
+    long long*& first = S.first;
+    double *&cd = S.cd, *&td = S.td, *&bd = S.bd, *&out = S.out;          // out: [0] sum diag(L), [1] f_p, [2] min diag(L), [3] max diag(L), [4..] residual per span
+    int* fail = S.fail;
+    FitWork<double>& w1 = S.w1;
+    FitWork<dd>& w2 = S.w2;
+    w1.penalty = false; w2.penalty = false;              // (the work arrays outlive a fit; what they hold does not)
     bool precise = false;                                  // double-double from the first ill-conditioned pass on
     bool diag_natural = true;                              // out[0] of the last least-squares pass is the sum FITPACK forms (see fit_band_solve)
     int lsq_dd_n = -1;                                     // knot count whose normal equations w2 holds
     MVUS_HIP(hipMemsetAsync(fail, 0, sizeof(int), cb.st));
     std::vector<double> t, fpint, host, b;
     std::vector<int> nrdata;
-    size_t cap = 0;
+    size_t& cap = S.cap;
     auto ensure = [&](size_t need) {                      // between passes only: the device arrays hold nothing that outlives a pass
       if (need <= cap) return;
       size_t c = std::max<size_t>(cap, 1024);
@@ -1309,6 +1351,8 @@ int mvus_spline_smooth(int32_t device, int64_t m, const double* u, const double*
       if (host.size() < cap + 4) host.resize(cap + 4, 0.0);
     };
     ensure(nmin + 16);
+    if (t.size() < cap) { t.resize(cap, 0.0); fpint.resize(cap, 0.0); nrdata.resize(cap, 0); }      // (capacity kept from an earlier fit of this session)
+    if (host.size() < cap + 4) host.resize(cap + 4, 0.0);
     if (timing) { MVUS_HIP(hipStreamSynchronize(cb.st)); t_ready = now(); }
     const double ub = u[0], ue = u[m - 1], acc = tol * s;
     int n = nmin, nplus = 0, ier = 0, nrint = 1, failed = 0;
@@ -1467,8 +1511,33 @@ int mvus_spline_smooth(int32_t device, int64_t m, const double* u, const double*
     g_create_error = e.what();
     return MVUS_E_INVALID;
   }
-  if (timing) std::fprintf(stderr, ", total with release %.2f ms\n", ms(t_begin, now()));
+  if (timing) std::fprintf(stderr, ", total %.2f ms\n", ms(t_begin, now()));
   return MVUS_OK;
+}
+
+int mvus_spline_fit_open(int32_t device, int64_t m, const double* u, const double* X, mvus_spline_fit** out) {
+  if (!out) { g_create_error = "spline_fit_open: bad arguments"; return MVUS_E_INVALID; }
+  *out = nullptr;
+  mvus_spline_fit* S = nullptr;
+  try { S = new mvus_spline_fit(); } catch (const std::exception& e) { g_create_error = e.what(); return MVUS_E_INVALID; }
+  const int rc = spline_fit_open_impl(*S, device, m, u, X);
+  if (rc != MVUS_OK) { delete S; return rc; }
+  *out = S;
+  return MVUS_OK;
+}
+int mvus_spline_fit_smooth(mvus_spline_fit* S, double s, int32_t* n_out, double* t_out, double* c_out, double* fp_out, int32_t* ier_out) {
+  if (!S) { g_create_error = "spline_fit_smooth: no session"; return MVUS_E_INVALID; }
+  return spline_fit_run(*S, s, n_out, t_out, c_out, fp_out, ier_out);
+}
+void mvus_spline_fit_close(mvus_spline_fit* S) { delete S; }
+
+int mvus_spline_smooth(int32_t device, int64_t m, const double* u, const double* X, double s, int32_t* n_out, double* t_out, double* c_out,
+                       double* fp_out, int32_t* ier_out) {
+  if (!n_out || !t_out || !c_out || !(s > 0.0) || !std::isfinite(s)) { g_create_error = "spline_smooth: bad arguments (m > 3 samples, s > 0)"; return MVUS_E_INVALID; }
+  mvus_spline_fit S;
+  const int rc = spline_fit_open_impl(S, device, m, u, X);
+  if (rc != MVUS_OK) return rc;
+  return spline_fit_run(S, s, n_out, t_out, c_out, fp_out, ier_out);
 }
 
 /* cv2.solvePnPRansac(objectPoints, imagePoints, K, d, reprojectionError) as Scene.get_camera_pose calls it (pnp.hip.h) */

@@ -79,6 +79,64 @@ def smooth_fit(t, X, s, device=0, full_output=False):
     return (tck, fp.value, ier.value) if full_output else tck
 
 
+class SmoothFit:
+    """``smooth_fit`` for several smoothing factors on ONE set of samples: the samples are checked and uploaded once and the
+    device work arrays are kept (``mvus_spline_fit_open`` / ``_smooth`` / ``_close``) -- what ``traj_fit``'s loop needs.
+
+        with SmoothFit(t, X) as fit:
+            tck = fit(s)
+    """
+
+    def __init__(self, t, X, device=0):
+        self.lib = _lib.load()
+        t = np.ascontiguousarray(t, dtype=np.float64)
+        X = np.ascontiguousarray(np.asarray(X, dtype=np.float64))
+        if t.ndim != 1 or X.shape != (3, t.size):
+            raise ValueError('X must be 3 x len(t)')
+        self.m = t.size
+        self.h = ctypes.c_void_p()
+        rc = self.lib.mvus_spline_fit_open(int(device), t.size, _lib.dptr(t), _lib.dptr(X), ctypes.byref(self.h))
+        if rc != 0:
+            self.h = None
+            _err(self.lib, rc, 'mvus_spline_fit_open')
+        nest = self.m + 6
+        self._knots = np.zeros(nest)
+        self._c = np.zeros((3, nest))
+
+    def __call__(self, s, full_output=False):
+        if not self.h:
+            raise ValueError('the fit session is closed')
+        n = ctypes.c_int32(0)
+        ier = ctypes.c_int32(0)
+        fp = ctypes.c_double(0.0)
+        rc = self.lib.mvus_spline_fit_smooth(self.h, float(s), ctypes.byref(n), _lib.dptr(self._knots), _lib.dptr(self._c), ctypes.byref(fp), ctypes.byref(ier))
+        if rc != 0:
+            _err(self.lib, rc, 'mvus_spline_fit_smooth')
+        nk = n.value
+        tck = [self._knots[:nk].copy(), [self._c[d, :nk - 4].copy() for d in range(3)], 3]
+        return (tck, fp.value, ier.value) if full_output else tck
+
+    def close(self):
+        if getattr(self, 'h', None):
+            self.lib.mvus_spline_fit_close(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        import sys
+        if sys is None or sys.is_finalizing():
+            return
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def _fprati(p1, f1, p2, f2, p3, f3):
     """FITPACK fprati: the zero of the rational interpolant r(p) = (u p + v) / (p + w) through three points (p3 < 0: p3 = inf)."""
     if p3 > 0.0:
@@ -185,16 +243,17 @@ def traj_fit(part, smooth_factor, device=0):
     if part.shape[1] < 4:                        # splprep(k=3) raises -> the reference's k=1 fallback (common.py:266-267)
         return linear_fit_as_cubic(part, s)
     prev, direction = 0, 0
-    while True:
-        tck = smooth_fit(part[0], part[1:], s, device=device)
-        n = len(tck[0]) - 4
-        if n == prev and n == 4 and direction == 2:
-            break
-        prev = n
-        if measure / n > hi:
-            s, direction = s / 1.5, 1
-        elif measure / n < lo:
-            s, direction = s * 2, 2
-        else:
-            break
+    with SmoothFit(part[0], part[1:], device=device) as fit:       # one upload for the dozen fits of the loop
+        while True:
+            tck = fit(s)
+            n = len(tck[0]) - 4
+            if n == prev and n == 4 and direction == 2:
+                break
+            prev = n
+            if measure / n > hi:
+                s, direction = s / 1.5, 1
+            elif measure / n < lo:
+                s, direction = s * 2, 2
+            else:
+                break
     return tck

@@ -259,6 +259,26 @@ def test_gpu_smooth_fit_partitioned_band_solver(seed, m, spec):
 
 
 @pytest.mark.gpu
+def test_gpu_smooth_fit_session_is_the_one_shot_fit():
+    """mvus_spline_fit_open / _smooth / _close (the samples uploaded once, work arrays kept: what traj_fit's smooth_factor loop
+    uses) gives, for every s and in any order of s, exactly what one-shot mvus_spline_smooth gives."""
+    from mvus_amd import spline
+    u, X = _trajectory(12, 6000, speed=3)
+    ss = [40.0, 5.0, 800.0, 7.2, 0.5, 40.0]                 # knot counts up and down: the work arrays grow, are reused, hold stale data
+    with spline.SmoothFit(u, X) as fit:
+        for s in ss:
+            tck, fp, ier = fit(s, full_output=True)
+            tck1, fp1, ier1 = spline.smooth_fit(u, X, s, full_output=True)
+            np.testing.assert_array_equal(tck[0], tck1[0])
+            np.testing.assert_array_equal(np.asarray(tck[1]), np.asarray(tck1[1]))
+            assert (fp, ier) == (fp1, ier1)
+    with pytest.raises(ValueError):
+        fit(1.0)                                           # closed
+    with pytest.raises(ValueError):
+        spline.SmoothFit(u[::-1].copy(), X)                # the checks of the one-shot call happen at open
+
+
+@pytest.mark.gpu
 def test_gpu_smooth_fit_ill_conditioned_knot_set():
     """Close to interpolation FITPACK's knot search can produce a knot set with cond(A) ~ 1e10 (cond of the normal equations
     1e20): the fp64 Cholesky loses a pivot, the pass is repeated in double-double and still lands on FITPACK's spline."""
