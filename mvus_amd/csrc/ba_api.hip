@@ -521,7 +521,8 @@ struct HipBackend {
   }
   // z = J^T u of this rank's rows: deterministic two-pass form (k_jtu_partial / k_jtu_reduce)
   double *zc = nullptr, *zs = nullptr;
-  int32_t *zg0 = nullptr, *zfill = nullptr;
+  int32_t *zg0 = nullptr, *zfill = nullptr, *zext = nullptr;
+  int* jt_bounds = nullptr;               // [2] measured by k_jtu_index: how far a chunk starts below the running maximum, how far a chunk reaches
   int* jt_nondet = nullptr;
   // z_is_zero: the caller guarantees z == 0 on entry (the device-resident LSMR loop clears it while consuming it);
   // reuse_index: zfill of the previous call is still valid (same Jacobian, hence the same window starts)
@@ -530,29 +531,31 @@ struct HipBackend {
     if (!zc) {
       const size_t nc = std::max<size_t>(hp.chunks.size(), 1);
       zc = dalloc<double>(nc * (size_t)(hp.NS - 12)); zs = dalloc<double>(nc * 3 * (size_t)kJtWin); zg0 = dalloc<int32_t>(nc); zfill = dalloc<int32_t>(nc);
+      zext = dalloc<int32_t>(nc); jt_bounds = dalloc<int>(2);
       jt_nondet = dalloc<int>(1);
       MVUS_HIP(hipMemsetAsync(jt_nondet, 0, sizeof(int), stream));
     }
     if (!z_is_zero) MVUS_HIP(hipMemsetAsync(z, 0, sizeof(double) * hp.n, stream));
+    if (!reuse_index) MVUS_HIP(hipMemsetAsync(jt_bounds, 0, 2 * sizeof(int), stream));
     const dim3 g2(hp.C + (hp.N + kThreads / 64 - 1) / (kThreads / 64)), b(kThreads);
     const int motion = hp.T > 0 ? 1 : 0;
     if (hp.calib) {
-      if (dp.n_chunks > 0) hipLaunchKernelGGL(k_jtu_partial<30>, dim3(xcd_grid(dp.n_chunks)), b, 0, stream, dp, J, span, u, z, zc, zs, zg0, jt_nondet);
-      if (!reuse_index) hipLaunchKernelGGL(k_jtu_index, dim3(hp.C), dim3(64), 0, stream, dp, zg0, zfill);
+      if (dp.n_chunks > 0) hipLaunchKernelGGL(k_jtu_partial<30>, dim3(xcd_grid(dp.n_chunks)), b, 0, stream, dp, J, span, u, z, zc, zs, zg0, jt_nondet, zext);
+      if (!reuse_index) hipLaunchKernelGGL(k_jtu_index, dim3(hp.C), dim3(64), 0, stream, dp, zg0, zfill, zext, jt_bounds);
       if (build_first) build_jt_first();
-      hipLaunchKernelGGL(k_jtu_reduce<30>, g2, b, 0, stream, dp, zc, zs, zg0, zfill, mJ, mctrl, u + 2 * hp.M, motion, z, (reuse_index || build_first) ? jt_first : (int32_t*)nullptr);
+      hipLaunchKernelGGL(k_jtu_reduce<30>, g2, b, 0, stream, dp, zc, zs, zg0, zfill, mJ, mctrl, u + 2 * hp.M, motion, z, (reuse_index || build_first) ? jt_first : (int32_t*)nullptr, jt_bounds);
     } else {
-      if (dp.n_chunks > 0) hipLaunchKernelGGL(k_jtu_partial<21>, dim3(xcd_grid(dp.n_chunks)), b, 0, stream, dp, J, span, u, z, zc, zs, zg0, jt_nondet);
-      if (!reuse_index) hipLaunchKernelGGL(k_jtu_index, dim3(hp.C), dim3(64), 0, stream, dp, zg0, zfill);
+      if (dp.n_chunks > 0) hipLaunchKernelGGL(k_jtu_partial<21>, dim3(xcd_grid(dp.n_chunks)), b, 0, stream, dp, J, span, u, z, zc, zs, zg0, jt_nondet, zext);
+      if (!reuse_index) hipLaunchKernelGGL(k_jtu_index, dim3(hp.C), dim3(64), 0, stream, dp, zg0, zfill, zext, jt_bounds);
       if (build_first) build_jt_first();
-      hipLaunchKernelGGL(k_jtu_reduce<21>, g2, b, 0, stream, dp, zc, zs, zg0, zfill, mJ, mctrl, u + 2 * hp.M, motion, z, (reuse_index || build_first) ? jt_first : (int32_t*)nullptr);
+      hipLaunchKernelGGL(k_jtu_reduce<21>, g2, b, 0, stream, dp, zc, zs, zg0, zfill, mJ, mctrl, u + 2 * hp.M, motion, z, (reuse_index || build_first) ? jt_first : (int32_t*)nullptr, jt_bounds);
     }
     MVUS_HIP(hipGetLastError());
   }
   void build_jt_first() {
     if (!jt_first) jt_first = dalloc<int32_t>((size_t)std::max<int64_t>(hp.N, 1) * hp.C);
     const long long e = (long long)hp.N * hp.C;
-    if (e > 0) hipLaunchKernelGGL(k_jtu_first, dim3((unsigned)((e + kThreads - 1) / kThreads)), dim3(kThreads), 0, stream, dp, zfill, jt_first);
+    if (e > 0) hipLaunchKernelGGL(k_jtu_first, dim3((unsigned)((e + kThreads - 1) / kThreads)), dim3(kThreads), 0, stream, dp, zfill, jt_first, jt_bounds);
   }
   void jtu(const double* u, double* z) { jtu_local(u, z); reduce(z, (size_t)hp.n); }
 

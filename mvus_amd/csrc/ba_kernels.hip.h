@@ -441,7 +441,8 @@ constexpr int kJtWin = 144;     // control points per chunk window of the J^T u 
 template <int NS>
 __global__ __launch_bounds__(kThreads) void k_jtu_partial(DevProblem dp, const double* __restrict__ J, const int32_t* __restrict__ span,
                                                           const double* __restrict__ u, double* __restrict__ z, double* __restrict__ zc,
-                                                          double* __restrict__ zs, int32_t* __restrict__ zg0, int* __restrict__ nondet) {
+                                                          double* __restrict__ zs, int32_t* __restrict__ zg0, int* __restrict__ nondet,
+                                                          int32_t* __restrict__ zext = nullptr) {
   constexpr int B = NS - 12;
   constexpr int PS = kThreads + 1;
   __shared__ double part[kThreads / 64][B];
@@ -484,7 +485,7 @@ __global__ __launch_bounds__(kThreads) void k_jtu_partial(DevProblem dp, const d
     for (int w = 0; w < kThreads / 64; ++w) sacc += part[w][threadIdx.x];
     zc[(long long)chunk * B + threadIdx.x] = sacc;
   }
-  if (threadIdx.x == 0) zg0[chunk] = g0;
+  if (threadIdx.x == 0) { zg0[chunk] = g0; if (zext != nullptr && g0 == 0x7fffffff) zext[chunk] = 0; }
   double* zw = zs + (long long)chunk * (3 * kJtWin);
   if (g0 == 0x7fffffff) return;                       // nothing visible (uniform): pass 2 skips the chunk
   const int l = g - g0;
@@ -514,6 +515,9 @@ __global__ __launch_bounds__(kThreads) void k_jtu_partial(DevProblem dp, const d
       if (hi[t] > 0) { if (lo[t] < hi[threadIdx.x]) atomicOr(&bad_s, 1); break; }
   }
   __syncthreads();
+  // how many control points of the window this chunk really reaches (k_jtu_index takes the maximum over the chunks: pass 2 then
+  // looks only at chunks that can cover its control point instead of at all whose 144-wide window does)
+  if (threadIdx.x == 0 && zext != nullptr) zext[chunk] = wide_s ? 0 : lmax_s + 4;
   if (wide_s) {                                        // detections spread over more control points than the window holds
     if (threadIdx.x == 0) { zg0[chunk] = 0x7fffffff; atomicAdd(nondet, 1); }
     if (g >= 0) {
@@ -549,9 +553,12 @@ __global__ __launch_bounds__(kThreads) void k_jtu_partial(DevProblem dp, const d
 // between the passes (one wavefront per camera): zfill[chunk] = running maximum of the window starts of the camera's chunks
 // -- non-decreasing whatever the data, so pass 2 can binary-search it; chunks are time ordered, so zfill exceeds a
 // chunk's own start by at most the few spans a rolling-shutter shift can reorder
-__global__ __launch_bounds__(64) void k_jtu_index(DevProblem dp, const int32_t* __restrict__ zg0, int32_t* __restrict__ zfill) {
+// bounds[0] = max over the chunks of (running maximum - own window start): how far behind the running maximum a chunk can start;
+// bounds[1] = max extent of a chunk's window in control points (zext).  Both zeroed by the caller before the launch.
+__global__ __launch_bounds__(64) void k_jtu_index(DevProblem dp, const int32_t* __restrict__ zg0, int32_t* __restrict__ zfill,
+                                                  const int32_t* __restrict__ zext = nullptr, int* __restrict__ bounds = nullptr) {
   const int c = blockIdx.x, lane = threadIdx.x;
-  int carry = -0x7fffffff;
+  int carry = -0x7fffffff, slack = 0, ext = 0;
   for (int base = dp.cam_chunk_off[c]; base < dp.cam_chunk_off[c + 1]; base += 64) {
     const int ch = base + lane;
     const bool in = ch < dp.cam_chunk_off[c + 1];
@@ -561,7 +568,13 @@ __global__ __launch_bounds__(64) void k_jtu_index(DevProblem dp, const int32_t* 
     for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(v, off, 64); if (lane >= off) v = max(v, o); }
     v = max(v, carry);
     if (in) zfill[ch] = v;
+    if (in && g0 != 0x7fffffff) { slack = max(slack, v - g0); if (zext != nullptr) ext = max(ext, zext[ch]); }
     carry = __shfl(v, 63, 64);
+  }
+  if (bounds != nullptr) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { slack = max(slack, __shfl_xor(slack, off, 64)); ext = max(ext, __shfl_xor(ext, off, 64)); }
+    if (lane == 0) { atomicMax(&bounds[0], slack); atomicMax(&bounds[1], ext); }
   }
 }
 
@@ -571,24 +584,28 @@ __global__ __launch_bounds__(64) void k_jtu_index(DevProblem dp, const int32_t* 
 // pairing is fixed (the same bits every run), lane 0 adds the motion rows (a contiguous, precomputed row range) and writes z.
 // first chunk of camera c whose running-max window start is within reach of control point g: what pass 2 finds by binary
 // search.  It depends on the Jacobian's spans only, so a run of products with one Jacobian (LSMR) looks it up once.
-__device__ __forceinline__ int jtu_first_chunk(const DevProblem& dp, const int32_t* __restrict__ zfill, int c, int g) {
+// (win: no chunk reaches further than win control points past its window start -- kJtWin, or the measured bounds[1])
+__device__ __forceinline__ int jtu_first_chunk(const DevProblem& dp, const int32_t* __restrict__ zfill, int c, int g, int win = kJtWin) {
   int lo = dp.cam_chunk_off[c], hi = dp.cam_chunk_off[c + 1];
   while (lo < hi) {
     const int mid = (lo + hi) >> 1;
-    if (zfill[mid] + kJtWin > g) hi = mid; else lo = mid + 1;
+    if (zfill[mid] + win > g) hi = mid; else lo = mid + 1;
   }
   return lo;
 }
-__global__ __launch_bounds__(kThreads) void k_jtu_first(DevProblem dp, const int32_t* __restrict__ zfill, int32_t* __restrict__ first) {
+__device__ __forceinline__ int jtu_window(const int* __restrict__ bounds) { return bounds != nullptr ? min(kJtWin, max(1, bounds[1])) : kJtWin; }
+__global__ __launch_bounds__(kThreads) void k_jtu_first(DevProblem dp, const int32_t* __restrict__ zfill, int32_t* __restrict__ first,
+                                                        const int* __restrict__ bounds = nullptr) {
   const long long e = blockIdx.x * (long long)kThreads + threadIdx.x;
   if (e >= (long long)dp.N * dp.C) return;
-  first[e] = jtu_first_chunk(dp, zfill, (int)(e % dp.C), (int)(e / dp.C));
+  first[e] = jtu_first_chunk(dp, zfill, (int)(e % dp.C), (int)(e / dp.C), jtu_window(bounds));
 }
 template <int NS>
 __global__ __launch_bounds__(kThreads) void k_jtu_reduce(DevProblem dp, const double* __restrict__ zc, const double* __restrict__ zs,
                                                          const int32_t* __restrict__ zg0, const int32_t* __restrict__ zfill, const double* __restrict__ mJ,
                                                          const int32_t* __restrict__ mctrl, const double* __restrict__ um, int motion,
-                                                         double* __restrict__ z, const int32_t* __restrict__ first = nullptr) {
+                                                         double* __restrict__ z, const int32_t* __restrict__ first = nullptr,
+                                                         const int* __restrict__ bounds = nullptr) {
   constexpr int B = NS - 12;
   if ((int)blockIdx.x < dp.C) {
     const int c = blockIdx.x, k = threadIdx.x;
@@ -611,10 +628,13 @@ __global__ __launch_bounds__(kThreads) void k_jtu_reduce(DevProblem dp, const do
   if (g >= dp.N) return;
   double acc[3] = {0.0, 0.0, 0.0};
   const int mrow_lo = motion ? dp.mv.row_lo[g] : 0, mrow_hi = motion ? dp.mv.row_hi[g] : 0;      // (fetched beside the cameras' first loads)
+  // a chunk starts at most bounds[0] control points below the running maximum of the starts: once that maximum is more than
+  // bounds[0] past g, no later chunk starts at or before g (without the measured bound: a whole window)
+  const int reach = bounds != nullptr ? min(kJtWin, bounds[0]) : kJtWin;
   for (int c = lane; c < dp.C; c += 64) {
     // first chunk whose running-max window start is within reach of g (everything before ends left of g) ...
     const int end = dp.cam_chunk_off[c + 1];
-    const int lo = first ? first[(long long)g * dp.C + c] : jtu_first_chunk(dp, zfill, c, g);
+    const int lo = first ? first[(long long)g * dp.C + c] : jtu_first_chunk(dp, zfill, c, g, jtu_window(bounds));
     // ... then forward until the running maximum is a whole window past g (a later chunk's own start is never that far
     // below the running maximum), adding the covering windows in chunk order
     // (four chunks at a time: their window starts together, then the entries of the covering ones together, then the adds in
@@ -633,14 +653,14 @@ __global__ __launch_bounds__(kThreads) void k_jtu_reduce(DevProblem dp, const do
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int lc = g - g0[q];
-        use[q] = fill[q] <= g + kJtWin && g0[q] != 0x7fffffff && lc >= 0 && lc < kJtWin;
+        use[q] = fill[q] <= g + reach && g0[q] != 0x7fffffff && lc >= 0 && lc < kJtWin;
         const double* wp = zs + (long long)(ch0 + q) * (3 * kJtWin) + 3 * (use[q] ? lc : 0);
 #pragma unroll
         for (int d = 0; d < 3; ++d) w[q][d] = use[q] ? wp[d] : 0.0;
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q) if (use[q]) { acc[0] += w[q][0]; acc[1] += w[q][1]; acc[2] += w[q][2]; }
-      if (!(fill[3] <= g + kJtWin)) break;
+      if (!(fill[3] <= g + reach)) break;
     }
   }
 #pragma unroll
