@@ -183,6 +183,12 @@ int mvus_ba_set_fd_groups(mvus_ba* h, const int32_t* groups, int32_t num_groups)
  * Stateless; no device is touched. */
 int32_t mvus_group_columns(int64_t m, int64_t n, int64_t nnz, const int64_t* rows, const int64_t* cols, const int64_t* order, int32_t* groups);
 
+/* The same grouping straight from the pattern CODES of a problem (pat[M] as mvus_ba_set_pattern / mvus_ba_upload_pattern use them,
+ * motion_pat[T] or NULL without motion rows): the entries of jac_BA's matrix (common.py:559-610 -- per detection row alpha, beta
+ * [, rs], the camera's parameters and the three nearest control points' coordinates; per motion row its control points) are
+ * generated here instead of being handed over as two nnz-long arrays.  Host only; p as for mvus_ba_create. */
+int32_t mvus_fd_groups(const mvus_problem* p, const int32_t* pat, const int32_t* motion_pat, const int64_t* order, int32_t* groups);
+
 /* y[m] = J v (v[n]);  z[n] = J^T u (u[m]) with the Jacobian currently held by the handle
  * (after mvus_ba_residual_jacobian / inside solve).  Test and integration hooks for the operator. */
 int mvus_ba_jv(mvus_ba* h, const double* v, double* y);

@@ -856,48 +856,118 @@ int mvus_ba_set_fd_groups(mvus_ba* h, const int32_t* groups, int32_t num_groups)
   });
 }
 
+}  // extern "C" (the two helpers below are C++)
+
+// scipy/optimize/_group_columns.pyx: group_sparse over the CSC arrays of the permuted pattern; groups[order] = result
+static int32_t group_sparse_permuted(int64_t m, int64_t n, const std::vector<int64_t>& indptr, const std::vector<int64_t>& indices, const int64_t* order, int32_t* groups) {
+  std::vector<int32_t> gp((size_t)n, -1);
+  std::vector<unsigned char> in_union((size_t)m);
+  int32_t current = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    if (gp[(size_t)i] >= 0) continue;
+    gp[(size_t)i] = current;
+    bool all_grouped = true;
+    std::fill(in_union.begin(), in_union.end(), (unsigned char)0);
+    for (int64_t k = indptr[(size_t)i]; k < indptr[(size_t)i + 1]; ++k) in_union[(size_t)indices[(size_t)k]] = 1;
+    for (int64_t j = 0; j < n; ++j) {
+      if (gp[(size_t)j] >= 0) continue;
+      all_grouped = false;
+      bool intersect = false;
+      for (int64_t k = indptr[(size_t)j]; k < indptr[(size_t)j + 1]; ++k) if (in_union[(size_t)indices[(size_t)k]]) { intersect = true; break; }
+      if (!intersect) {
+        for (int64_t k = indptr[(size_t)j]; k < indptr[(size_t)j + 1]; ++k) in_union[(size_t)indices[(size_t)k]] = 1;
+        gp[(size_t)j] = current;
+      }
+    }
+    if (all_grouped) break;
+    ++current;
+  }
+  int32_t ng = 0;
+  for (int64_t j = 0; j < n; ++j) { groups[(size_t)order[j]] = gp[(size_t)j]; ng = std::max(ng, gp[(size_t)j] + 1); }      // groups[order] = groups.copy()
+  return ng;
+}
+// A[:, order] in CSC from a generator of entries: for_each(emit) calls emit(row, col) for every entry, the same sequence every time it is called
+template <class ForEach>
+static int32_t group_columns_of(int64_t m, int64_t n, const int64_t* order, int32_t* groups, ForEach&& for_each) {
+  std::vector<int64_t> where((size_t)n, -1);
+  for (int64_t j = 0; j < n; ++j) {
+    if (order[j] < 0 || order[j] >= n || where[(size_t)order[j]] >= 0) { g_create_error = "group_columns: order is not a permutation"; return MVUS_E_INVALID; }
+    where[(size_t)order[j]] = j;
+  }
+  std::vector<int64_t> indptr((size_t)n + 1, 0);
+  bool bad = false;
+  int64_t nnz = 0;
+  for_each([&](int64_t r, int64_t c) { if (r < 0 || r >= m || c < 0 || c >= n) { bad = true; return; } ++indptr[(size_t)where[(size_t)c] + 1]; ++nnz; });
+  if (bad) { g_create_error = "group_columns: entry outside the matrix"; return MVUS_E_INVALID; }
+  for (int64_t j = 0; j < n; ++j) indptr[(size_t)j + 1] += indptr[(size_t)j];
+  std::vector<int64_t> fill(indptr.begin(), indptr.end() - 1), indices((size_t)nnz);
+  for_each([&](int64_t r, int64_t c) { indices[(size_t)fill[(size_t)where[(size_t)c]]++] = r; });
+  return group_sparse_permuted(m, n, indptr, indices, order, groups);
+}
+
+extern "C" {
+
 int32_t mvus_group_columns(int64_t m, int64_t n, int64_t nnz, const int64_t* rows, const int64_t* cols, const int64_t* order, int32_t* groups) {
   if (m < 0 || n < 1 || nnz < 0 || n > (1ll << 31) - 2 || (nnz > 0 && (!rows || !cols)) || !order || !groups) { g_create_error = "group_columns: bad arguments"; return MVUS_E_INVALID; }
   try {
-    // A[:, order]: permuted column j is original column order[j]; CSC of the permuted matrix by a counting sort of the entries
-    std::vector<int64_t> where((size_t)n, -1);
-    for (int64_t j = 0; j < n; ++j) {
-      if (order[j] < 0 || order[j] >= n || where[(size_t)order[j]] >= 0) { g_create_error = "group_columns: order is not a permutation"; return MVUS_E_INVALID; }
-      where[(size_t)order[j]] = j;
+    return group_columns_of(m, n, order, groups, [&](auto&& emit) { for (int64_t k = 0; k < nnz; ++k) emit(rows[k], cols[k]); });
+  } catch (const std::exception& e) {
+    g_create_error = e.what();
+    return MVUS_E_INVALID;
+  }
+}
+
+int32_t mvus_fd_groups(const mvus_problem* p, const int32_t* pat, const int32_t* motion_pat, const int64_t* order, int32_t* groups) {
+  if (!p || !pat || !order || !groups) { g_create_error = "fd_groups: bad arguments"; return MVUS_E_INVALID; }
+  try {
+    HostProblem hp;
+    const std::string msg = hp.build(p);
+    if (!msg.empty()) { g_create_error = msg; return MVUS_E_INVALID; }
+    if (hp.T > 0 && !motion_pat) { g_create_error = "fd_groups: motion_reg needs the motion-row codes (mvus_ba_motion_pattern)"; return MVUS_E_INVALID; }
+    const int C = hp.C, P = hp.P;
+    const bool opt_sync = p->opt_sync != 0, rs_free = p->rs_free != 0;
+    // control point p of the concatenated list -> its spline s, column of its x coefficient, stride between coordinates
+    std::vector<int64_t> coff((size_t)p->num_splines + 1, 0), xoff((size_t)p->num_splines, 0), ncoef((size_t)p->num_splines, 0);
+    {
+      int64_t base = (int64_t)C * (3 + P);
+      for (int s = 0; s < p->num_splines; ++s) {
+        ncoef[(size_t)s] = p->knot_offsets[s + 1] - p->knot_offsets[s] - 4;
+        coff[(size_t)s + 1] = coff[(size_t)s] + ncoef[(size_t)s];
+        xoff[(size_t)s] = base;
+        base += 3 * ncoef[(size_t)s];
+      }
     }
-    std::vector<int64_t> indptr((size_t)n + 1, 0);
-    for (int64_t k = 0; k < nnz; ++k) {
-      if (rows[k] < 0 || rows[k] >= m || cols[k] < 0 || cols[k] >= n) { g_create_error = "group_columns: entry outside the matrix"; return MVUS_E_INVALID; }
-      ++indptr[(size_t)where[(size_t)cols[k]] + 1];
-    }
-    for (int64_t j = 0; j < n; ++j) indptr[(size_t)j + 1] += indptr[(size_t)j];
-    std::vector<int64_t> fill(indptr.begin(), indptr.end() - 1), indices((size_t)nnz);
-    for (int64_t k = 0; k < nnz; ++k) indices[(size_t)fill[(size_t)where[(size_t)cols[k]]]++] = rows[k];
-    // scipy/optimize/_group_columns.pyx: group_sparse
-    std::vector<int32_t> gp((size_t)n, -1);
-    std::vector<unsigned char> in_union((size_t)m);
-    int32_t current = 0;
-    for (int64_t i = 0; i < n; ++i) {
-      if (gp[(size_t)i] >= 0) continue;
-      gp[(size_t)i] = current;
-      bool all_grouped = true;
-      std::fill(in_union.begin(), in_union.end(), (unsigned char)0);
-      for (int64_t k = indptr[(size_t)i]; k < indptr[(size_t)i + 1]; ++k) in_union[(size_t)indices[(size_t)k]] = 1;
-      for (int64_t j = 0; j < n; ++j) {
-        if (gp[(size_t)j] >= 0) continue;
-        all_grouped = false;
-        bool intersect = false;
-        for (int64_t k = indptr[(size_t)j]; k < indptr[(size_t)j + 1]; ++k) if (in_union[(size_t)indices[(size_t)k]]) { intersect = true; break; }
-        if (!intersect) {
-          for (int64_t k = indptr[(size_t)j]; k < indptr[(size_t)j + 1]; ++k) in_union[(size_t)indices[(size_t)k]] = 1;
-          gp[(size_t)j] = current;
+    auto spline_cols = [&](int32_t code, auto&& emit_col) {          // the (<= 12) spline columns of a row with this pattern code
+      const int32_t pc = pattern_index(code), mk = pattern_mask(code);
+      const int s = (int)(std::upper_bound(coff.begin(), coff.end(), (int64_t)pc) - coff.begin()) - 1;
+      if (s < 0 || s >= p->num_splines) return false;
+      const int64_t base = xoff[(size_t)s] + (pc - coff[(size_t)s]);
+      for (int k = 0; k < 4; ++k) if ((mk >> k) & 1) for (int d = 0; d < 3; ++d) emit_col(base + k + d * ncoef[(size_t)s]);
+      return true;
+    };
+    bool bad_code = false;
+    const int64_t M = hp.M;
+    auto for_each = [&](auto&& emit) {
+      for (int c = 0; c < C; ++c) {
+        const int64_t a = p->det_offsets[c], b = p->det_offsets[c + 1];
+        for (int64_t i = a; i < b; ++i) {
+          if (pat[i] < 0) continue;
+          for (int xy = 0; xy < 2; ++xy) {
+            const int64_t row = 2 * a + xy * (b - a) + (i - a);
+            if (opt_sync) { emit(row, (int64_t)c); emit(row, (int64_t)C + c); }
+            if (rs_free) emit(row, 2 * (int64_t)C + c);
+            for (int k = 0; k < P; ++k) emit(row, 3 * (int64_t)C + (int64_t)c * P + k);
+            if (!spline_cols(pat[i], [&](int64_t col) { emit(row, col); })) bad_code = true;
+          }
         }
       }
-      if (all_grouped) break;
-      ++current;
-    }
-    int32_t ng = 0;
-    for (int64_t j = 0; j < n; ++j) { groups[(size_t)order[j]] = gp[(size_t)j]; ng = std::max(ng, gp[(size_t)j] + 1); }      // groups[order] = groups.copy()
+      for (int64_t j = 0; j < hp.T; ++j) {
+        if (motion_pat[j] < 0) continue;
+        if (!spline_cols(motion_pat[j], [&](int64_t col) { emit(2 * M + j, col); })) bad_code = true;
+      }
+    };
+    const int32_t ng = group_columns_of((int64_t)hp.m, (int64_t)hp.n, order, groups, for_each);
+    if (bad_code) { g_create_error = "fd_groups: a pattern code points outside the control points"; return MVUS_E_INVALID; }
     return ng;
   } catch (const std::exception& e) {
     g_create_error = e.what();

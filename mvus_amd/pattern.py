@@ -19,6 +19,8 @@ The grouping is scipy's ``group_columns`` (greedy colouring in the column order 
 ``RandomState(0).permutation(n)``, scipy/optimize/_numdiff.py:216) -- the same call ``least_squares`` makes on the
 reference's matrix.
 """
+import ctypes
+
 import numpy as np
 
 from ._lib import PAT_SHIFT, PAT_TIE
@@ -203,6 +205,28 @@ def fd_groups(prob, pat0, motion_pat=None):
     column permutation ``RandomState(0).permutation(n)``, same greedy pass) run by ``mvus_group_columns`` on the pattern's
     entries: building the scipy.sparse matrix, converting it to CSC and permuting its columns was 2/3 of a default
     ``Scene.BA`` call's host time at 600 k detections."""
+    from . import _lib
+    lib = _lib.load()
+    n = int(prob.n_params)
+    order = np.ascontiguousarray(np.random.RandomState(0).permutation(n), dtype=np.int64)
+    groups = np.empty(n, dtype=np.int32)
+    # the entries are generated from the codes inside the library (mvus_fd_groups); pattern_entries + mvus_group_columns is the same
+    # computation with the entries as arrays (tests/test_fd_mode_host.py compares the three)
+    struct, keep = _lib.make_problem_struct(prob)
+    pat = np.ascontiguousarray(pat0, dtype=np.int32)
+    mp = np.ascontiguousarray(motion_pat, dtype=np.int32) if (prob.motion_reg and motion_pat is not None) else None
+    if prob.motion_reg and mp is None:
+        raise ValueError('motion_reg: pass the motion-row codes (mvus_ba_motion_pattern)')
+    ng = lib.mvus_fd_groups(ctypes.byref(struct), pat.ctypes.data_as(_lib.c_int32_p), mp.ctypes.data_as(_lib.c_int32_p) if mp is not None else None,
+                            order.ctypes.data_as(_lib.c_int64_p), groups.ctypes.data_as(_lib.c_int32_p))
+    del keep
+    if ng < 0:
+        raise RuntimeError('mvus_fd_groups failed (%d): %s' % (ng, lib.mvus_last_error(None).decode()))
+    return groups, int(ng)
+
+
+def fd_groups_from_entries(prob, pat0, motion_pat=None):
+    """``fd_groups`` with the entries built here (``pattern_entries``) and handed to ``mvus_group_columns``."""
     from . import _lib
     lib = _lib.load()
     rows, cols = pattern_entries(prob, pat0, motion_pat)

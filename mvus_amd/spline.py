@@ -128,10 +128,10 @@ class SmoothFit:
         self.close()
 
     def __del__(self):
-        import sys
-        if sys is None or sys.is_finalizing():
-            return
-        try:
+        try:                                               # (at interpreter shutdown even `import sys` can fail)
+            import sys
+            if sys.is_finalizing():
+                return
             self.close()
         except Exception:
             pass

@@ -79,10 +79,10 @@ class HostHandle:
             self.h = None
 
     def __del__(self):
-        import sys
-        if sys is None or sys.is_finalizing():             # module globals may be gone at interpreter shutdown
-            return
-        try:
+        try:                                               # (at interpreter shutdown even `import sys` can fail)
+            import sys
+            if sys.is_finalizing():
+                return
             self.close()
         except Exception:
             pass

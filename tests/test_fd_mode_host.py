@@ -60,6 +60,8 @@ def test_full_pattern_matches_reference(name):
     # mvus_group_columns (the entries, no scipy.sparse matrix) finds scipy's own groups
     gs, ngs = pattern.fd_groups_scipy(prob, pn, mn if h.T else None)
     assert ng == ngs and np.array_equal(groups, gs)
+    ge, nge = pattern.fd_groups_from_entries(prob, pn, mn if h.T else None)
+    assert nge == ngs and np.array_equal(ge, gs)
     # a valid colouring: no row contains two columns of one group
     G = sparse.csr_matrix((np.ones(groups.size), (np.arange(groups.size), groups)), shape=(groups.size, ng))
     assert (A @ G).max() == 1
