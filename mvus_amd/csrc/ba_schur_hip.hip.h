@@ -41,7 +41,19 @@ struct NEView {
   int C, B, CB, N, N3, W;
   int row0;
   int* err;              // set when a row reaches outside the slice
+  // deterministic assembly (MVUS_DET_ASSEMBLY=1, one rank): instead of adding into Et / gs / Cb with fp64 atomics every assembly
+  // workgroup leaves the sums of its flush ROUND (<= 2 rounds) in a window of its own -- block 2 * workgroup + round: the first
+  // control point (dctrl0), a bit per control point it wrote (dmask) and kDetWin x (3B + 3 + 36) entries (dwin) -- and
+  // k_det_gather adds the windows up per control point in a fixed order (camera by camera, workgroup by workgroup)
+  double* dwin = nullptr;
+  int* dctrl0 = nullptr;
+  unsigned long long* dmask = nullptr;
+  int* dnondet = nullptr;  // raised when a workgroup had to fall back to atomics (sparse tracks: slow path, window too wide, > 2 rounds)
+  int det = 0;
 };
+constexpr int kDetWin = 64;
+constexpr int kDetEmpty = 0x7f000000;                    // dctrl0 of a block nobody wrote (the array is memset to 0x7f bytes)
+MVUS_HD int det_entries(int B) { return 3 * B + 3 + 36; }
 
 __device__ __forceinline__ int wave_min_i(int v) {
 #pragma unroll
@@ -316,6 +328,7 @@ __global__ __launch_bounds__(kGaThreads) void k_assemble_spans(DevProblem dp, co
       }
     }
     if (!fast) {                                         // slow path: too many ranges to keep one per thread
+      if (ne.det && tid == 0) *ne.dnondet = 1;
       const int gq = rg[r];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -378,6 +391,33 @@ __global__ __launch_bounds__(kGaThreads) void k_assemble_spans(DevProblem dp, co
     }
     lds_barrier();
   }
+  // deterministic mode: per round the window start, whether the round fits a window, and the bit mask of the points it owns
+  __shared__ int det_c0[8], det_ok[8];
+  __shared__ unsigned long long det_mask[2];
+  if (ne.det) {
+    const int rounds = (nr + kRb - 1) / kRb;
+    if (tid < 8) {
+      det_ok[tid] = 0; det_c0[tid] = 0;
+      if (tid < rounds) {
+        const int p0 = round_off[tid], p1 = round_off[tid + 1];
+        det_c0[tid] = pt_ctrl[p0];
+        det_ok[tid] = tid < 2 && p1 > p0 && pt_ctrl[p1 - 1] - pt_ctrl[p0] < kDetWin;
+        if (!det_ok[tid]) *ne.dnondet = 1;
+      }
+      if (tid < 2) det_mask[tid] = 0ull;
+    }
+    lds_barrier();
+    for (int rho = 0; rho < 2 && rho < rounds; ++rho) {
+      if (!det_ok[rho]) continue;
+      const int p0 = round_off[rho], nown = round_off[rho + 1] - p0;
+      for (int i = tid; i < nown; i += kGaThreads) atomicOr(&det_mask[rho], 1ull << (pt_ctrl[p0 + i] - det_c0[rho]));
+    }
+    lds_barrier();
+    if (tid < 2 && tid < rounds && det_ok[tid]) {
+      ne.dctrl0[2 * (long long)blockIdx.x + tid] = det_c0[tid];
+      ne.dmask[2 * (long long)blockIdx.x + tid] = det_mask[tid];
+    }
+  }
   // ---- flush of the cross block + gradient: Ep[rl][q][3][B], Gp[rl][q][3] ----
   for (int r0 = 0, rho = 0; r0 < nr; r0 += kRb, ++rho) {
     const int nb = min(kRb, nr - r0);
@@ -407,7 +447,9 @@ __global__ __launch_bounds__(kGaThreads) void k_assemble_spans(DevProblem dp, co
         const int q2 = ctrl - rg[r0 + rl + j];
         acc += grad ? Gp[((rl + j) * 4 + q2) * 3 + dk - 3 * B] : Ep[((rl + j) * 4 + q2) * 3 * B + dk];
       }
-      if (acc != 0.0) {
+      if (ne.det && det_ok[rho]) {                        // this round's own window: one writer per entry, zeros included
+        ne.dwin[((2 * (long long)blockIdx.x + rho) * kDetWin + (ctrl - det_c0[rho])) * (3 * B + 39) + dk] = acc;
+      } else if (acc != 0.0) {
         if (grad) unsafeAtomicAdd(&ne.gs[3 * ctrl + dk - 3 * B], acc);
         else unsafeAtomicAdd(&ne.Et[((long long)c * ne.N3 + 3 * ctrl) * B + dk], acc);
       }
@@ -444,7 +486,8 @@ __global__ __launch_bounds__(kGaThreads) void k_assemble_spans(DevProblem dp, co
         const int q2 = ctrl - rg[r0 + rl + j];
         if (q2 + w < 4) acc += Cp[((rl + j) * 10 + 4 * q2 - q2 * (q2 - 1) / 2 + w) * 9 + dd];
       }
-      if (acc != 0.0) unsafeAtomicAdd(&ne.Cb[((long long)ctrl * ne.W) * 9 + wd], acc);
+      if (ne.det && det_ok[rho]) ne.dwin[((2 * (long long)blockIdx.x + rho) * kDetWin + (ctrl - det_c0[rho])) * (3 * B + 39) + 3 * B + 3 + wd] = acc;
+      else if (acc != 0.0) unsafeAtomicAdd(&ne.Cb[((long long)ctrl * ne.W) * 9 + wd], acc);
     }
     lds_barrier();
   }
@@ -455,6 +498,142 @@ __global__ __launch_bounds__(kGaThreads) void k_assemble_spans(DevProblem dp, co
   if ((blockIdx.x % 997) == 5 && (tid == 0 || tid == 64 || tid == 300 || tid == kGaThreads - 64))
     printf("blk %d tid %d nr %d: staged %lld ranges %lld accum %lld wait %lld Eflush %lld Cflush %lld | E round 0: write %lld owners %lld loop %lld barrier %lld\n", (int)blockIdx.x, tid, nr, tp[1] - tp[0], tp[2] - tp[1], tp[3] - tp[2], tp[4] - tp[3], tp[5] - tp[4], tp[6] - tp[5], te[0] - tp[4], te[1] - te[0], te[2] - te[1], te[3] - te[2]);
 #endif
+}
+
+__device__ __forceinline__ void lds_wave_sync() {      // orders the LDS traffic of ONE wavefront (writes of some lanes read by others)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+}
+// ---- deterministic assembly: the gather --------------------------------------------------------------------------------
+// per camera (one wavefront): dfill[block] = running maximum of the window starts of the camera's blocks (non-decreasing, so the
+// gather can binary-search it), bounds[0] = the largest (running maximum - own start): how far below it a block can start
+__global__ __launch_bounds__(64) void k_det_index(DevProblem dp, int N, const int* __restrict__ dctrl0, int* __restrict__ dfill, int* __restrict__ bounds,
+                                                  int* __restrict__ dfirst) {
+  // dfirst[c * N + g] = the first block of camera c whose running maximum + kDetWin exceeds g (what a binary search over dfill finds):
+  // block b is that block for g in [dfill[b-1] + kDetWin, dfill[b] + kDetWin) -- every lane fills the range of its block
+  const int c = blockIdx.x, lane = threadIdx.x;
+  const int b0 = dp.cam_chunk_off[c] * kGaParts * 2, b1 = dp.cam_chunk_off[c + 1] * kGaParts * 2;
+  int carry = -0x7fffffff, slack = 0;
+  int* first = dfirst + (long long)c * N;
+  for (int base = b0; base < b1; base += 64) {
+    const int b = base + lane;
+    const bool in = b < b1;
+    const int c0 = in ? dctrl0[b] : kDetEmpty;
+    int v = c0 >= kDetEmpty ? -0x7fffffff : c0;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(v, off, 64); if (lane >= off) v = max(v, o); }
+    v = max(v, carry);
+    int prev = __shfl_up(v, 1, 64);
+    if (lane == 0) prev = carry;
+    if (in) {
+      dfill[b] = v;
+      if (c0 < kDetEmpty) slack = max(slack, v - c0);
+      if (v > prev) {                                   // (v == prev: an empty block or one that starts below the maximum -- never "the first")
+        const int g_lo = prev == -0x7fffffff ? 0 : min(N, max(0, prev + kDetWin)), g_hi = min(N, max(0, v + kDetWin));
+        for (int g = g_lo; g < g_hi; ++g) first[g] = b;
+      }
+    }
+    carry = __shfl(v, 63, 64);
+  }
+  const int tail = carry == -0x7fffffff ? 0 : min(N, max(0, carry + kDetWin));
+  for (int g = tail + lane; g < N; g += 64) first[g] = b1;      // past every window
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) slack = max(slack, __shfl_xor(slack, off, 64));
+  if (lane == 0) atomicMax(&bounds[0], slack);
+}
+// One wavefront per control point g, two steps.  (1) lane = camera: every lane finds the window rows of g among its camera's blocks
+// (first block from the table, four block headers in flight at a time) and leaves (block, row) in LDS, in block order.  (2) lane =
+// ENTRY of a window row (coalesced 8 * (3B + 39)-byte rows): the cameras' rows are added up in camera order, row by row -- the 3B
+// cross-block entries per camera (written to Et when the camera is done), the gradient and band entries across all cameras.  One
+// fixed order of additions, no exchange between lanes.  Everything is ADDED to the (cleared) storage: workgroups that fell back
+// to atomics have already put their part there.
+constexpr int kDetRowsMax = 8;                           // window rows of one camera that can hold one control point (4 spans of detections / 128 per block, x 2 rounds)
+template <int B>
+__global__ __launch_bounds__(kThreads) void k_det_gather(DevProblem dp, NEView ne, const int* __restrict__ dfill, const int* __restrict__ bounds,
+                                                         const int* __restrict__ dfirst) {
+  constexpr int ENT = 3 * B + 39, kWaves = kThreads / 64;
+  __shared__ int cov_row[kWaves][64][kDetRowsMax];        // per camera (lane) of the current group of 64: row = block * kDetWin + local control point
+  __shared__ int flat_row[kWaves][64 * kDetRowsMax];      // the same rows one after the other, camera by camera
+  __shared__ short flat_cam[kWaves][64 * kDetRowsMax];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = (int)blockIdx.x * kWaves + wave;
+  if (g >= ne.N) return;                                // (wave-uniform; no workgroup barrier below)
+  const int reach = min(kDetWin, bounds[0]);
+  const bool clean = *ne.dnondet == 0;
+  const int e0 = lane, e1 = lane + 64;                   // the entries of a row this lane adds up
+  double b0 = 0.0, b1 = 0.0;                             // gradient / band sums over all cameras (entries >= 3B)
+  for (int cbase = 0; cbase < dp.C; cbase += 64) {
+    const int c = cbase + lane;
+    int cnt = 0;
+    if (c < dp.C) {
+      const int lo = dfirst[(long long)c * ne.N + g];
+      const int end = dp.cam_chunk_off[c + 1] * kGaParts * 2;
+      for (int bb = lo; bb < end; bb += 4) {
+        int fl[4], c0[4];
+        unsigned long long mk[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const bool in = bb + q < end;
+          fl[q] = in ? dfill[bb + q] : 0x7fffffff;
+          c0[q] = in ? ne.dctrl0[bb + q] : kDetEmpty;
+          mk[q] = in ? ne.dmask[bb + q] : 0ull;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int lc = g - c0[q];
+          if (!(fl[q] <= g + reach) || c0[q] >= kDetEmpty || lc < 0 || lc >= kDetWin || !((mk[q] >> lc) & 1ull)) continue;
+          if (cnt < kDetRowsMax) cov_row[wave][lane][cnt++] = (bb + q) * kDetWin + lc;
+          else atomicOr(ne.err, 1);
+        }
+        if (!(fl[3] <= g + reach)) break;
+      }
+    }
+    // the cameras' rows one after the other (exclusive scan of the counts over the lanes)
+    int incl = cnt;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(incl, off, 64); if (lane >= off) incl += o; }
+    const int total = __shfl(incl, 63, 64);
+    for (int k = 0; k < cnt; ++k) { flat_row[wave][incl - cnt + k] = cov_row[wave][lane][k]; flat_cam[wave][incl - cnt + k] = (short)lane; }
+    lds_wave_sync();
+    int cur = -1;
+    double s0 = 0.0, s1 = 0.0;                           // the current camera's cross-block entries (entries < 3B)
+    auto flush_cam = [&]() {
+      if (cur < 0) return;
+      double* er = ne.Et + ((long long)(cbase + cur) * ne.N3 + 3 * g) * B;
+      if (clean) {                                       // nobody added to Et with atomics: the (cleared) entries are simply written
+        if (e0 < 3 * B) er[e0] = s0;
+        if (e1 < 3 * B) er[e1] = s1;
+      } else {
+        if (e0 < 3 * B) er[e0] += s0;
+        if (e1 < 3 * B) er[e1] += s1;
+      }
+    };
+    for (int i0 = 0; i0 < total; i0 += 8) {              // eight rows in flight, then their adds in row order
+      double v0[8], v1[8];
+      int cm[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const bool ok = i0 + q < total;
+        const long long off = ok ? (long long)flat_row[wave][i0 + q] * ENT : 0;
+        cm[q] = ok ? (int)flat_cam[wave][i0 + q] : -1;
+        v0[q] = (ok && e0 < ENT) ? ne.dwin[off + e0] : 0.0;
+        v1[q] = (ok && e1 < ENT) ? ne.dwin[off + e1] : 0.0;
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        if (cm[q] < 0) continue;
+        if (cm[q] != cur) { flush_cam(); cur = cm[q]; s0 = 0.0; s1 = 0.0; }
+        if (e0 < 3 * B) s0 += v0[q]; else b0 += v0[q];
+        if (e1 < 3 * B) s1 += v1[q]; else b1 += v1[q];
+      }
+    }
+    flush_cam();
+    lds_wave_sync();
+  }
+  // entry e >= 3B: e - 3B < 3 is the gradient coordinate, else band entry e - 3B - 3
+  if (e0 >= 3 * B && e0 < ENT) { const int r = e0 - 3 * B; if (r < 3) ne.gs[3 * g + r] += b0; else ne.Cb[((long long)g * ne.W) * 9 + r - 3] += b0; }
+  if (e1 >= 3 * B && e1 < ENT) { const int r = e1 - 3 * B; if (r < 3) ne.gs[3 * g + r] += b1; else ne.Cb[((long long)g * ne.W) * 9 + r - 3] += b1; }
 }
 
 // A[c] (both triangles) and gc[c] from the per-workgroup partial blocks of k_assemble_spans: one workgroup per camera, entry e
@@ -589,6 +768,50 @@ __global__ __launch_bounds__(kThreads) void k_assemble_motion(DevProblem dp, con
     const int gg = g0 + k / (kMotW * 9), w = (k / 9) % kMotW;
     const double v = Cw[k];
     if (gg < ne.N && w < ne.W && v != 0.0) unsafeAtomicAdd(&ne.Cb[((long long)gg * ne.W + w) * 9 + (k % 9)], v);
+  }
+}
+
+// The motion rows in the deterministic mode: one thread per (control point g, entry) -- entry < 3: gradient coordinate, else band
+// entry (w, d, d2) -- adds the rows that can touch g (row_lo[g] <= j < row_hi[g], as in k_jtu_reduce) in row order.  A row's
+// coefficient of (control point, coordinate) is the sum of its (<= 3) sample blocks that reach that control point -- what
+// k_assemble_motion compacts into rv[].  Rows it skips (outside the slice, or wider than kMotW control points) are skipped here.
+__global__ __launch_bounds__(kThreads) void k_det_motion(DevProblem dp, const double* __restrict__ mJ, const int32_t* __restrict__ mctrl,
+                                                         const double* __restrict__ fm, NEView ne) {
+  const int per = 3 + ne.W * 9;
+  const long long o = blockIdx.x * (long long)kThreads + threadIdx.x;
+  if (o >= (long long)ne.N * per) return;
+  const int g = (int)(o / per), e = (int)(o % per);
+  const bool grad = e < 3;
+  const int w = grad ? 0 : (e - 3) / 9, d = grad ? e : ((e - 3) % 9) / 3, d2 = grad ? 0 : (e - 3) % 3;
+  if (g + w >= ne.N) return;
+  const int gg = g + ne.row0;                            // row_lo / row_hi are indexed by the global control point
+  double acc = 0.0;
+  for (int j = dp.mv.row_lo[gg]; j < dp.mv.row_hi[gg]; ++j) {
+    int cid[3], lo = 0x7fffffff, hi = -1;
+    bool outside = false;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      cid[k] = mctrl[(long long)k * dp.T + j];
+      if (cid[k] >= 0) {
+        cid[k] -= ne.row0;
+        if (cid[k] < 0 || cid[k] + 3 >= ne.N) outside = true;
+        lo = min(lo, cid[k]); hi = max(hi, cid[k] + 3);
+      }
+    }
+    if (outside || hi < 0 || hi - lo >= kMotW) continue;
+    double va = 0.0, vb = 0.0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      if (cid[k] < 0) continue;
+      const int qa = g - cid[k], qb = g + w - cid[k];
+      if (qa >= 0 && qa < 4) va += mJ[(long long)(12 * k + 3 * qa + d) * dp.T + j];
+      if (!grad && qb >= 0 && qb < 4) vb += mJ[(long long)(12 * k + 3 * qb + d2) * dp.T + j];
+    }
+    acc += grad ? va * fm[j] : va * vb;
+  }
+  if (acc != 0.0) {
+    if (grad) ne.gs[3 * g + e] += acc;
+    else ne.Cb[((long long)g * ne.W) * 9 + (e - 3)] += acc;
   }
 }
 
@@ -1116,11 +1339,6 @@ __device__ __forceinline__ bcr_d4 bcr_mma(const BcrFrag<S3>& f, bcr_d4 acc) {
 constexpr int kBcrWaves = MVUS_BCR_WAVES;      // wavefronts of the one workgroup that runs the last levels (S3 = 15: half, LDS)
 constexpr int kBcrTailNs = MVUS_BCR_TAIL_NS;   // levels with more survivors than this get a launch of their own (one wavefront per survivor)
 
-__device__ __forceinline__ void lds_wave_sync() {      // orders the LDS traffic of ONE wavefront (writes of some lanes read by others)
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
-}
 
 // One survivor of one level, by ONE wavefront and without any exchange with other wavefronts: the survivor i = 2h(s+1)-1
 // inverts the diagonal blocks of BOTH eliminated neighbours jL = i-h and jR = i+h itself (its neighbours two places on
@@ -1984,6 +2202,7 @@ struct HipSchur {
     if (halo_tables) (void)hipFree(halo_tables);
     if (fail) (void)hipFree(fail);
     if (fail_host) (void)hipHostFree(fail_host);
+    for (void* p : {(void*)ne.dwin, (void*)ne.dctrl0, (void*)ne.dmask, (void*)det_fill, (void*)det_bounds, (void*)det_first}) if (p) (void)hipFree(p);
   }
 
   // x_fused != nullptr: the detection rows' Jacobian is evaluated inside the assembly kernel at x_fused (no J in memory);
@@ -1993,9 +2212,36 @@ struct HipSchur {
   double* clear_ptr() { return NE; }
   int64_t clear_len() const { return (int64_t)(ne_count + n_apart); }
   void mark_cleared() { ne_cleared = true; }
+  // deterministic assembly (see NEView): buffers of the windows, built on first use
+  int *det_fill = nullptr, *det_bounds = nullptr, *det_first = nullptr;
+  size_t det_blocks = 0;
+  bool det_wanted() const { return !shard && std::getenv("MVUS_DET_ASSEMBLY") != nullptr; }
+  void det_prepare() {
+    const size_t nblk = (size_t)kGaParts * 2 * std::max<size_t>(be.hp.chunks.size(), 1);
+    if (det_blocks != nblk) {
+      for (void* p : {(void*)ne.dwin, (void*)ne.dctrl0, (void*)ne.dmask, (void*)det_fill, (void*)det_bounds, (void*)det_first}) if (p) (void)hipFree(p);
+      MVUS_HIP(hipMalloc(reinterpret_cast<void**>(&ne.dwin), nblk * kDetWin * (size_t)det_entries(ne.B) * sizeof(double)));
+      MVUS_HIP(hipMalloc(reinterpret_cast<void**>(&ne.dctrl0), nblk * sizeof(int)));
+      MVUS_HIP(hipMalloc(reinterpret_cast<void**>(&ne.dmask), nblk * sizeof(unsigned long long)));
+      MVUS_HIP(hipMalloc(reinterpret_cast<void**>(&det_fill), nblk * sizeof(int)));
+      MVUS_HIP(hipMalloc(reinterpret_cast<void**>(&det_bounds), 2 * sizeof(int)));
+      MVUS_HIP(hipMalloc(reinterpret_cast<void**>(&det_first), (size_t)std::max(1, ne.C) * (size_t)std::max(1, ne.N) * sizeof(int)));
+      ne.dnondet = det_bounds + 1;
+      det_blocks = nblk;
+    }
+    MVUS_HIP(hipMemsetAsync(ne.dctrl0, 0x7f, det_blocks * sizeof(int), be.stream));
+    MVUS_HIP(hipMemsetAsync(det_bounds, 0, 2 * sizeof(int), be.stream));
+  }
+  int det_fallbacks() {                                    // workgroups of the last assembly that had to use atomics (synchronises)
+    int v = 0;
+    if (det_bounds) { MVUS_HIP(hipMemcpyAsync(&v, det_bounds + 1, sizeof(int), hipMemcpyDeviceToHost, be.stream)); MVUS_HIP(hipStreamSynchronize(be.stream)); }
+    return v;
+  }
   void assemble_local(const double* f_dev, const double* x_fused = nullptr) {
     if (!ne_cleared) be.fill(NE, 0.0, (int64_t)(ne_count + n_apart));      // one launch (hipMemsetAsync splits 36 MB into two fill kernels)
     ne_cleared = false;
+    ne.det = det_wanted() && be.dp.n_chunks > 0 ? 1 : 0;
+    if (ne.det) det_prepare();
     if (be.dp.n_chunks > 0) {
       const int nc = be.dp.n_chunks;
       const dim3 g(kGaParts * nc), b(kGaThreads);
@@ -2008,11 +2254,21 @@ struct HipSchur {
         else hipLaunchKernelGGL((k_assemble_spans<21, false>), g, b, 0, be.stream, be.dp, be.J, be.span, f_dev, ne, be.cams, (const double*)nullptr);
       }
     }
+    if (ne.det) {
+      hipLaunchKernelGGL(k_det_index, dim3(be.hp.C), dim3(64), 0, be.stream, be.dp, ne.N, ne.dctrl0, det_fill, det_bounds, det_first);
+      const dim3 gg((unsigned)((ne.N + kThreads / 64 - 1) / (kThreads / 64)));
+      if (be.hp.calib) hipLaunchKernelGGL(k_det_gather<18>, gg, dim3(kThreads), 0, be.stream, be.dp, ne, det_fill, det_bounds, det_first);
+      else hipLaunchKernelGGL(k_det_gather<9>, gg, dim3(kThreads), 0, be.stream, be.dp, ne, det_fill, det_bounds, det_first);
+    }
     if (be.dp.n_chunks > 0) {
       if (be.hp.calib) hipLaunchKernelGGL(k_cam_block_reduce<18>, dim3(be.hp.C, 2), dim3(1024), 0, be.stream, be.dp, ne);
       else hipLaunchKernelGGL(k_cam_block_reduce<9>, dim3(be.hp.C, 2), dim3(1024), 0, be.stream, be.dp, ne);
     }
-    if (be.hp.T > 0)
+    if (be.hp.T > 0 && ne.det) {
+      const long long cnt = (long long)ne.N * (3 + ne.W * 9);
+      hipLaunchKernelGGL(k_det_motion, dim3((unsigned)((cnt + kThreads - 1) / kThreads)), dim3(kThreads), 0, be.stream, be.dp, be.mJ, be.mctrl,
+                         f_dev + 2 * be.hp.M, ne);
+    } else if (be.hp.T > 0)
       hipLaunchKernelGGL(k_assemble_motion, dim3((be.hp.T + kThreads - 1) / kThreads), dim3(kThreads), 0, be.stream, be.dp, be.mJ, be.mctrl,
                          f_dev + 2 * be.hp.M, ne);
     MVUS_HIP(hipGetLastError());
