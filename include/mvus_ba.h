@@ -171,6 +171,13 @@ int mvus_ba_motion_pattern(mvus_ba* h, int32_t* motion_pat_out);
  * the next mvus_ba_set_pattern or mvus_ba_remove_outliers.  Column groups for MVUS_JAC_FD must be set afterwards. */
 int mvus_ba_upload_pattern(mvus_ba* h, const int32_t* pat, const int32_t* motion_pat);
 
+/* MVUS_SOLVER_LM_SCHUR, one rank: on != 0 assembles the normal equations without floating-point atomics -- every assembly
+ * workgroup leaves its sums in a window of its own and a gather adds the windows in a fixed order -- so that a solve gives the
+ * same bits on every run (the default adds with fp64 atomics: last-bit differences from run to run; ~10 % faster).  The
+ * environment variable MVUS_DET_ASSEMBLY=1 does the same for every handle.  No counterpart in the reference (scipy is
+ * deterministic; this restores that property for the opt-in LM solver).  Ignored on a time shard. */
+int mvus_ba_set_deterministic(mvus_ba* h, int32_t on);
+
 /* Column groups for MVUS_JAC_FD: groups[n] in [0, num_groups), two columns share a group only if no row of the
  * reference pattern contains both (scipy.optimize._numdiff.group_columns on jac_BA's matrix). */
 int mvus_ba_set_fd_groups(mvus_ba* h, const int32_t* groups, int32_t num_groups);

@@ -36,6 +36,7 @@ struct HipBackend {
   double *J = nullptr, *mJ = nullptr, *x_cur = nullptr, *f_cur = nullptr;
   int32_t *span = nullptr, *pat0 = nullptr, *mctrl = nullptr;
   bool has_pattern = false, has_jacobian = false;
+  bool det_assembly = false;          // mvus_ba_set_deterministic: the LM normal equations without fp64 atomics (ba_schur_hip.hip.h)
   bool pattern_uploaded = false;     // the caller supplied the reference's pattern (mvus_ba_upload_pattern): solve keeps it
   int32_t* ms_pat_dev = nullptr;
   double* det_alt[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // second set of detection arrays (remove_outliers ping-pong)
@@ -845,6 +846,10 @@ int mvus_ba_motion_pattern(mvus_ba* h, int32_t* motion_pat_out) {
     }
     return MVUS_OK;
   });
+}
+
+int mvus_ba_set_deterministic(mvus_ba* h, int32_t on) {
+  return guarded(h, [&] { h->be.det_assembly = on != 0; return MVUS_OK; });
 }
 
 int mvus_ba_set_fd_groups(mvus_ba* h, const int32_t* groups, int32_t num_groups) {

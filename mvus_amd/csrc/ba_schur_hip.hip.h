@@ -2215,7 +2215,7 @@ struct HipSchur {
   // deterministic assembly (see NEView): buffers of the windows, built on first use
   int *det_fill = nullptr, *det_bounds = nullptr, *det_first = nullptr;
   size_t det_blocks = 0;
-  bool det_wanted() const { return !shard && std::getenv("MVUS_DET_ASSEMBLY") != nullptr; }
+  bool det_wanted() const { return !shard && (be.det_assembly || std::getenv("MVUS_DET_ASSEMBLY") != nullptr); }
   void det_prepare() {
     const size_t nblk = (size_t)kGaParts * 2 * std::max<size_t>(be.hp.chunks.size(), 1);
     if (det_blocks != nblk) {
