@@ -548,7 +548,7 @@ __global__ __launch_bounds__(64) void k_det_index(DevProblem dp, int N, const in
 // cross-block entries per camera (written to Et when the camera is done), the gradient and band entries across all cameras.  One
 // fixed order of additions, no exchange between lanes.  Everything is ADDED to the (cleared) storage: workgroups that fell back
 // to atomics have already put their part there.
-constexpr int kDetRowsMax = 8;                           // window rows of one camera that can hold one control point (4 spans of detections / 128 per block, x 2 rounds)
+constexpr int kDetRowsMax = 8;                           // window rows of one camera handled per pass (more: further passes, a fixed order all the same)
 template <int B>
 __global__ __launch_bounds__(kThreads) void k_det_gather(DevProblem dp, NEView ne, const int* __restrict__ dfill, const int* __restrict__ bounds,
                                                          const int* __restrict__ dfirst) {
@@ -563,9 +563,10 @@ __global__ __launch_bounds__(kThreads) void k_det_gather(DevProblem dp, NEView n
   const bool clean = *ne.dnondet == 0;
   const int e0 = lane, e1 = lane + 64;                   // the entries of a row this lane adds up
   double b0 = 0.0, b1 = 0.0;                             // gradient / band sums over all cameras (entries >= 3B)
-  for (int cbase = 0; cbase < dp.C; cbase += 64) {
+  for (int cbase = 0; cbase < dp.C; cbase += 64)
+  for (int pass = 0, again = 1; again; ++pass) {         // (a second pass only when some camera holds g in more than kDetRowsMax rows)
     const int c = cbase + lane;
-    int cnt = 0;
+    int cnt = 0, ord = 0;
     if (c < dp.C) {
       const int lo = dfirst[(long long)c * ne.N + g];
       const int end = dp.cam_chunk_off[c + 1] * kGaParts * 2;
@@ -583,12 +584,13 @@ __global__ __launch_bounds__(kThreads) void k_det_gather(DevProblem dp, NEView n
         for (int q = 0; q < 4; ++q) {
           const int lc = g - c0[q];
           if (!(fl[q] <= g + reach) || c0[q] >= kDetEmpty || lc < 0 || lc >= kDetWin || !((mk[q] >> lc) & 1ull)) continue;
-          if (cnt < kDetRowsMax) cov_row[wave][lane][cnt++] = (bb + q) * kDetWin + lc;
-          else atomicOr(ne.err, 1);
+          if (ord >= pass * kDetRowsMax && cnt < kDetRowsMax) cov_row[wave][lane][cnt++] = (bb + q) * kDetWin + lc;
+          ++ord;
         }
         if (!(fl[3] <= g + reach)) break;
       }
     }
+    again = __ballot(ord > (pass + 1) * kDetRowsMax) != 0ull;
     // the cameras' rows one after the other (exclusive scan of the counts over the lanes)
     int incl = cnt;
 #pragma unroll
@@ -601,7 +603,7 @@ __global__ __launch_bounds__(kThreads) void k_det_gather(DevProblem dp, NEView n
     auto flush_cam = [&]() {
       if (cur < 0) return;
       double* er = ne.Et + ((long long)(cbase + cur) * ne.N3 + 3 * g) * B;
-      if (clean) {                                       // nobody added to Et with atomics: the (cleared) entries are simply written
+      if (clean && pass == 0) {                          // nobody added to Et with atomics: the (cleared) entries are simply written
         if (e0 < 3 * B) er[e0] = s0;
         if (e1 < 3 * B) er[e1] = s1;
       } else {

@@ -18,6 +18,8 @@ def _scenes():
     yield 'rs_motion_F_dense_7cam', kw
     kw = dict(synth.BASELINE_CONFIGS[4]); kw.update(total_obs=30_000)
     yield 'calib_KE_7cam', kw
+    # 300 detections per knot span and camera: a control point sits in ~10 windows of ONE camera -- the gather's second pass
+    yield 'very_dense_2cam', dict(num_cam=2, total_obs=120_000, seed=7, num_knots=200, rolling_shutter=True)
     yield 'config2_32cam_504k', dict(synth.BASELINE_CONFIGS[2])       # full size: a thinner flight spreads a workgroup's 128 detections over
                                                                         # more than the 64 control points of a window and falls back to atomics
 
