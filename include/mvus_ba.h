@@ -177,6 +177,10 @@ int mvus_ba_upload_pattern(mvus_ba* h, const int32_t* pat, const int32_t* motion
  * environment variable MVUS_DET_ASSEMBLY=1 does the same for every handle.  No counterpart in the reference (scipy is
  * deterministic; this restores that property for the opt-in LM solver).  Ignored on a time shard. */
 int mvus_ba_set_deterministic(mvus_ba* h, int32_t on);
+/* *fell_back = 1 when some workgroup of the handle's LAST deterministic assembly had to keep the atomic path (its 128 consecutive
+ * detections of one camera spread over more than 64 control points, or over more than ~170 knot-span pieces): the result is
+ * correct, but not guaranteed to repeat bit for bit.  0 otherwise (and when no deterministic assembly has run). */
+int mvus_ba_deterministic_fallback(mvus_ba* h, int32_t* fell_back);
 
 /* Column groups for MVUS_JAC_FD: groups[n] in [0, num_groups), two columns share a group only if no row of the
  * reference pattern contains both (scipy.optimize._numdiff.group_columns on jac_BA's matrix). */

@@ -71,6 +71,7 @@ API = [
     ('mvus_ba_motion_pattern', ctypes.c_int, [ctypes.c_void_p, c_int32_p]),
     ('mvus_ba_upload_pattern', ctypes.c_int, [ctypes.c_void_p, c_int32_p, c_int32_p]),
     ('mvus_ba_set_deterministic', ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32]),
+    ('mvus_ba_deterministic_fallback', ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32)]),
     ('mvus_ba_set_fd_groups', ctypes.c_int, [ctypes.c_void_p, c_int32_p, ctypes.c_int32]),
     ('mvus_group_columns', ctypes.c_int32, [ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, c_int64_p, c_int64_p, c_int64_p, c_int32_p]),
     ('mvus_fd_groups', ctypes.c_int32, [ctypes.POINTER(MvusProblem), c_int32_p, c_int32_p, c_int64_p, c_int32_p]),

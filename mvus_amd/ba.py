@@ -124,6 +124,12 @@ class BAHandle:
         """LM + Schur without floating-point atomics in the assembly: the same bits on every run (about 10 % slower)."""
         self._check(self.lib.mvus_ba_set_deterministic(self.h, 1 if on else 0), 'mvus_ba_set_deterministic')
 
+    def deterministic_fallback(self):
+        """True when the last deterministic assembly kept the atomic path somewhere (very sparse tracks): correct, not bit-reproducible."""
+        v = ctypes.c_int32(0)
+        self._check(self.lib.mvus_ba_deterministic_fallback(self.h, ctypes.byref(v)), 'mvus_ba_deterministic_fallback')
+        return bool(v.value)
+
     def set_fd_groups(self, groups, num_groups):
         groups = np.ascontiguousarray(groups, dtype=np.int32)
         if groups.shape != (self.n,):

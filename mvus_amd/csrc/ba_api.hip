@@ -851,6 +851,13 @@ int mvus_ba_motion_pattern(mvus_ba* h, int32_t* motion_pat_out) {
 int mvus_ba_set_deterministic(mvus_ba* h, int32_t on) {
   return guarded(h, [&] { h->be.det_assembly = on != 0; return MVUS_OK; });
 }
+int mvus_ba_deterministic_fallback(mvus_ba* h, int32_t* fell_back) {
+  return guarded(h, [&] {
+    if (!fell_back) { h->be.err = "bad arguments"; return MVUS_E_INVALID; }
+    *fell_back = h->schur ? (h->schur->det_fallbacks() != 0 ? 1 : 0) : 0;
+    return MVUS_OK;
+  });
+}
 
 int mvus_ba_set_fd_groups(mvus_ba* h, const int32_t* groups, int32_t num_groups) {
   return guarded(h, [&] {

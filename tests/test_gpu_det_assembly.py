@@ -50,6 +50,25 @@ def test_deterministic_assembly_matches_and_repeats(name, kw):
     assert abs(runs[0][1] - cost_a) <= 1e-9 * cost_a                            # and the same optimisation as the atomic mode
 
 
+def test_sparse_tracks_fall_back_and_say_so():
+    """configs[2] thinned to 0.75 detections per knot span and camera: 128 consecutive detections of a camera reach over ~170 control
+    points, more than a window holds -- those workgroups keep the atomic path, the handle reports it, the normal equations are the
+    atomic mode's to rounding; the full-size configuration does not fall back."""
+    from mvus_amd import ba, problem as mp, synth
+    for obs, expect in ((120_000, True), (504_399, False)):
+        kw = dict(synth.BASELINE_CONFIGS[2]); kw.update(total_obs=obs)
+        prob, x0 = mp.problem_from_scene(synth.make_scene(**kw))
+        with ba.BAHandle(prob) as h:
+            assert h.deterministic_fallback() is False
+            h.residual_jacobian(x0)
+            ne_a = h.normal_equations()
+            h.set_deterministic(True)
+            ne_d = h.normal_equations()
+            assert h.deterministic_fallback() is expect
+            for a, d in zip(ne_a, ne_d):
+                assert np.max(np.abs(a - d)) <= 1e-12 * np.max(np.abs(a))
+
+
 def test_scene_setting_switches_the_mode():
     """settings['ba_deterministic'] with ba_solver 'lm': two Scene.BA calls from the same state end with identical parameters."""
     from mvus_amd import pipeline, synth
