@@ -773,47 +773,78 @@ __global__ __launch_bounds__(kThreads) void k_assemble_motion(DevProblem dp, con
   }
 }
 
-// The motion rows in the deterministic mode: one thread per (control point g, entry) -- entry < 3: gradient coordinate, else band
-// entry (w, d, d2) -- adds the rows that can touch g (row_lo[g] <= j < row_hi[g], as in k_jtu_reduce) in row order.  A row's
-// coefficient of (control point, coordinate) is the sum of its (<= 3) sample blocks that reach that control point -- what
-// k_assemble_motion compacts into rv[].  Rows it skips (outside the slice, or wider than kMotW control points) are skipped here.
+// The motion rows in the deterministic mode: one wavefront per control point g.  The rows that can touch g (row_lo[g] <= j <
+// row_hi[g], as in k_jtu_reduce) are taken 64 at a time: first lane = ROW -- its coefficients of (g + a, coordinate d), a < W, i.e.
+// the sum of its (<= 3) sample blocks that reach that control point (what k_assemble_motion compacts into rv[]), and its residual,
+// go to LDS; then lane = ENTRY (gradient coordinate, or band entry (w, d, d2)) adds the rows in row order.  One order of additions
+// per entry, no atomics.  Rows k_assemble_motion skips (outside the slice, wider than kMotW control points) are zeros here.
+constexpr int kDetMotW = 6;                              // >= ne.W (the band solver supports at most six 3x3 blocks)
 __global__ __launch_bounds__(kThreads) void k_det_motion(DevProblem dp, const double* __restrict__ mJ, const int32_t* __restrict__ mctrl,
                                                          const double* __restrict__ fm, NEView ne) {
-  const int per = 3 + ne.W * 9;
-  const long long o = blockIdx.x * (long long)kThreads + threadIdx.x;
-  if (o >= (long long)ne.N * per) return;
-  const int g = (int)(o / per), e = (int)(o % per);
-  const bool grad = e < 3;
-  const int w = grad ? 0 : (e - 3) / 9, d = grad ? e : ((e - 3) % 9) / 3, d2 = grad ? 0 : (e - 3) % 3;
-  if (g + w >= ne.N) return;
+  constexpr int kWaves = kThreads / 64, kRv = kDetMotW * 3 + 1;       // per row: W x 3 coefficients + the residual
+  __shared__ double rv[kWaves][64][kRv + 1];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = (int)blockIdx.x * kWaves + wave;
+  if (g >= ne.N) return;                                // (wave-uniform; no workgroup barrier below)
   const int gg = g + ne.row0;                            // row_lo / row_hi are indexed by the global control point
+  const int j0 = dp.mv.row_lo[gg], j1 = dp.mv.row_hi[gg];
+  const int per = 3 + ne.W * 9;
+  const bool grad = lane < 3;
+  const int w = grad ? 0 : (lane - 3) / 9, d = grad ? lane : ((lane - 3) % 9) / 3, d2 = grad ? 0 : (lane - 3) % 3;
+  const bool mine = lane < per && g + w < ne.N;
   double acc = 0.0;
-  for (int j = dp.mv.row_lo[gg]; j < dp.mv.row_hi[gg]; ++j) {
-    int cid[3], lo = 0x7fffffff, hi = -1;
-    bool outside = false;
+  for (int jb = j0; jb < j1; jb += 64) {
+    const int j = jb + lane;
+    double r[kRv];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      cid[k] = mctrl[(long long)k * dp.T + j];
-      if (cid[k] >= 0) {
-        cid[k] -= ne.row0;
-        if (cid[k] < 0 || cid[k] + 3 >= ne.N) outside = true;
-        lo = min(lo, cid[k]); hi = max(hi, cid[k] + 3);
+    for (int e = 0; e < kRv; ++e) r[e] = 0.0;
+    if (j < j1) {
+      int cid[3], lo = 0x7fffffff, hi = -1;
+      bool outside = false;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        cid[k] = mctrl[(long long)k * dp.T + j];
+        if (cid[k] >= 0) {
+          cid[k] -= ne.row0;
+          if (cid[k] < 0 || cid[k] + 3 >= ne.N) outside = true;
+          lo = min(lo, cid[k]); hi = max(hi, cid[k] + 3);
+        }
+      }
+      if (!outside && hi >= 0 && hi - lo < kMotW) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          if (cid[k] < 0) continue;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int a = cid[k] + q - g;                // this block's control point q is g + a
+            if (a < 0 || a >= kDetMotW) continue;
+#pragma unroll
+            for (int dd = 0; dd < 3; ++dd) {
+              const double v = mJ[(long long)(12 * k + 3 * q + dd) * dp.T + j];
+#pragma unroll
+              for (int e = 0; e < kDetMotW * 3; ++e) if (e == 3 * a + dd) r[e] += v;      // static indexing of r: select by comparison
+            }
+          }
+        }
+        r[kDetMotW * 3] = fm[j];
       }
     }
-    if (outside || hi < 0 || hi - lo >= kMotW) continue;
-    double va = 0.0, vb = 0.0;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      if (cid[k] < 0) continue;
-      const int qa = g - cid[k], qb = g + w - cid[k];
-      if (qa >= 0 && qa < 4) va += mJ[(long long)(12 * k + 3 * qa + d) * dp.T + j];
-      if (!grad && qb >= 0 && qb < 4) vb += mJ[(long long)(12 * k + 3 * qb + d2) * dp.T + j];
+    for (int e = 0; e < kRv; ++e) rv[wave][lane][e] = r[e];
+    lds_wave_sync();
+    const int nrow = min(64, j1 - jb);
+    if (mine) {
+      for (int t = 0; t < nrow; ++t) {
+        const double va = rv[wave][t][d];
+        const double vb = grad ? rv[wave][t][kDetMotW * 3] : rv[wave][t][3 * w + d2];
+        acc += va * vb;
+      }
     }
-    acc += grad ? va * fm[j] : va * vb;
+    lds_wave_sync();
   }
-  if (acc != 0.0) {
-    if (grad) ne.gs[3 * g + e] += acc;
-    else ne.Cb[((long long)g * ne.W) * 9 + (e - 3)] += acc;
+  if (mine && acc != 0.0) {
+    if (grad) ne.gs[3 * g + lane] += acc;
+    else ne.Cb[((long long)g * ne.W) * 9 + (lane - 3)] += acc;
   }
 }
 
@@ -2266,9 +2297,10 @@ struct HipSchur {
       if (be.hp.calib) hipLaunchKernelGGL(k_cam_block_reduce<18>, dim3(be.hp.C, 2), dim3(1024), 0, be.stream, be.dp, ne);
       else hipLaunchKernelGGL(k_cam_block_reduce<9>, dim3(be.hp.C, 2), dim3(1024), 0, be.stream, be.dp, ne);
     }
-    if (be.hp.T > 0 && ne.det) {
-      const long long cnt = (long long)ne.N * (3 + ne.W * 9);
-      hipLaunchKernelGGL(k_det_motion, dim3((unsigned)((cnt + kThreads - 1) / kThreads)), dim3(kThreads), 0, be.stream, be.dp, be.mJ, be.mctrl,
+    // (one rank: the row-ordered kernel in both modes -- 22 us against 26 for the LDS-window one at configs[1], and one source of
+    // run-to-run differences less; a time shard keeps k_assemble_motion, which also reports rows that leave the slice)
+    if (be.hp.T > 0 && !shard && ne.W <= kDetMotW) {
+      hipLaunchKernelGGL(k_det_motion, dim3((unsigned)((ne.N + kThreads / 64 - 1) / (kThreads / 64))), dim3(kThreads), 0, be.stream, be.dp, be.mJ, be.mctrl,
                          f_dev + 2 * be.hp.M, ne);
     } else if (be.hp.T > 0)
       hipLaunchKernelGGL(k_assemble_motion, dim3((be.hp.T + kThreads - 1) / kThreads), dim3(kThreads), 0, be.stream, be.dp, be.mJ, be.mctrl,
