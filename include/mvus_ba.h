@@ -173,7 +173,7 @@ int mvus_ba_upload_pattern(mvus_ba* h, const int32_t* pat, const int32_t* motion
 
 /* MVUS_SOLVER_LM_SCHUR, one rank: on != 0 assembles the normal equations without floating-point atomics -- every assembly
  * workgroup leaves its sums in a window of its own and a gather adds the windows in a fixed order -- so that a solve gives the
- * same bits on every run (the default adds with fp64 atomics: last-bit differences from run to run; ~10 % faster).  The
+ * same bits on every run (the default adds with fp64 atomics: last-bit differences from run to run; 7-14 % faster).  The
  * environment variable MVUS_DET_ASSEMBLY=1 does the same for every handle.  No counterpart in the reference (scipy is
  * deterministic; this restores that property for the opt-in LM solver).  Ignored on a time shard. */
 int mvus_ba_set_deterministic(mvus_ba* h, int32_t on);

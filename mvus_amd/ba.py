@@ -121,7 +121,7 @@ class BAHandle:
                                                     mp.ctypes.data_as(_lib.c_int32_p) if mp is not None else None), 'mvus_ba_upload_pattern')
 
     def set_deterministic(self, on=True):
-        """LM + Schur without floating-point atomics in the assembly: the same bits on every run (about 10 % slower)."""
+        """LM + Schur without floating-point atomics in the assembly: the same bits on every run (7-14 % slower)."""
         self._check(self.lib.mvus_ba_set_deterministic(self.h, 1 if on else 0), 'mvus_ba_set_deterministic')
 
     def deterministic_fallback(self):

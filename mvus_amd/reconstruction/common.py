@@ -25,7 +25,7 @@ Extra ``settings`` keys (all optional; a reference ``config.json`` has none of t
                what the reference would build here), 'canonical'.
 ``ba_lambda_min`` floor of the LM damping (default 3e-3, see ``mvus_solve_opts.lm_lambda_min``).
 ``ba_deterministic`` with 'lm': True assembles the normal equations without floating-point atomics -- the same bits on every
-               run, about 10 % slower (``mvus_ba_set_deterministic``; default False).
+               run, 7-14 % slower (``mvus_ba_set_deterministic``; default False).
 ``opt_sync`` (reference key: False freezes alpha/beta), ``device``.
 """
 import json
@@ -376,7 +376,7 @@ class Scene:
         opts = _ba._lib.default_opts(solver, jac_mode, max_iter)
         opts.lm_lambda_min = float(st.get('ba_lambda_min', opts.lm_lambda_min))
         if solver == _ba.SOLVER_LM_SCHUR:
-            h.set_deterministic(bool(st.get('ba_deterministic', False)))       # 'ba_solver': 'lm' only: same bits on every run, ~10 % slower
+            h.set_deterministic(bool(st.get('ba_deterministic', False)))       # 'ba_solver': 'lm' only: same bits on every run, 7-14 % slower
         try:
             res = h.solve(model, opts=opts, ties=st.get('ba_pattern_ties', 'numpy'), matrix=jac_sparsity)
         except RuntimeError as e:
