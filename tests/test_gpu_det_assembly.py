@@ -50,6 +50,23 @@ def test_deterministic_assembly_matches_and_repeats(name, kw):
     assert abs(runs[0][1] - cost_a) <= 1e-9 * cost_a                            # and the same optimisation as the atomic mode
 
 
+def test_forty_fresh_handles_one_outcome():
+    """tools/micro/loop_lm_configs.py as a test: 40 fresh handles, eight-evaluation LM solves on a rolling-shutter scene with motion
+    regulariser -- ONE (cost, x) with the deterministic assembly (with atomics: as many outcomes as handles)."""
+    import hashlib
+    from mvus_amd import ba, problem as mp, synth
+    kw = dict(synth.BASELINE_CONFIGS[1]); kw.update(total_obs=50_000)
+    prob, x0 = mp.problem_from_scene(synth.make_scene(**kw))
+    seen = set()
+    for _ in range(40):
+        with ba.BAHandle(prob) as h:
+            h.set_deterministic(True)
+            r = h.solve(x0, solver=ba.SOLVER_LM_SCHUR, jac_mode=ba.JAC_ANALYTIC, max_nfev=8)
+            assert not h.deterministic_fallback()
+            seen.add((repr(r.cost), hashlib.sha1(np.ascontiguousarray(r.x).tobytes()).hexdigest()))
+    assert len(seen) == 1
+
+
 def test_sparse_tracks_fall_back_and_say_so():
     """configs[2] thinned to 0.75 detections per knot span and camera: 128 consecutive detections of a camera reach over ~170 control
     points, more than a window holds -- those workgroups keep the atomic path, the handle reports it, the normal equations are the
