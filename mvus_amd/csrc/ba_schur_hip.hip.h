@@ -48,8 +48,9 @@ struct NEView {
   double* dwin = nullptr;
   int* dctrl0 = nullptr;
   unsigned long long* dmask = nullptr;
-  int* dnondet = nullptr;  // raised when a workgroup had to fall back to atomics (sparse tracks: slow path, window too wide, > 2 rounds)
+  int* dnondet = nullptr;  // set to dgen when a workgroup had to fall back to atomics (sparse tracks: slow path, window too wide, > 2 rounds)
   int det = 0;
+  int dgen = 0;            // number of this assembly (what "raised in THIS assembly" is compared with: no reset between assemblies)
 };
 constexpr int kDetWin = 64;
 constexpr int kDetEmpty = 0x7f000000;                    // dctrl0 of a block nobody wrote (the array is memset to 0x7f bytes)
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(kGaThreads) void k_assemble_spans(DevProblem dp, co
   const int chunk = blockIdx.x / kGaParts, half = blockIdx.x % kGaParts;
   const int c = dp.chunk_cam[chunk];
   const int cnt = min(kGaObs, dp.chunk_count[chunk] - half * kGaObs);
-  if (cnt <= 0) return;
+  if (cnt <= 0) { if (ne.det && threadIdx.x < 2) ne.dctrl0[2 * (long long)blockIdx.x + threadIdx.x] = kDetEmpty; return; }
   const long long i0 = dp.chunk_start[chunk] + half * kGaObs;
   const long long a0 = dp.det_off[c], Mc = dp.det_off[c + 1] - a0;
   const int tid = threadIdx.x;
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(kGaThreads) void k_assemble_spans(DevProblem dp, co
     if (tid > 0 && kt < key[tid - 1]) sort_s = 1;
   }
   lds_barrier();
-  if (!any_s) return;                                   // nothing visible (uniform)
+  if (!any_s) { if (ne.det && tid < 2) ne.dctrl0[2 * (long long)blockIdx.x + tid] = kDetEmpty; return; }      // nothing visible (uniform)
   if (sort_s) {
     int pos = 0;
     for (int u = 0; u < kGaObs; ++u) { const int ku = key[u]; pos += (ku < kt) || (ku == kt && u < t); }
@@ -328,7 +329,7 @@ __global__ __launch_bounds__(kGaThreads) void k_assemble_spans(DevProblem dp, co
       }
     }
     if (!fast) {                                         // slow path: too many ranges to keep one per thread
-      if (ne.det && tid == 0) *ne.dnondet = 1;
+      if (ne.det && tid == 0) *ne.dnondet = ne.dgen;
       const int gq = rg[r];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -348,7 +349,7 @@ __global__ __launch_bounds__(kGaThreads) void k_assemble_spans(DevProblem dp, co
       }
     }
   }
-  if (!fast) return;
+  if (!fast) { if (ne.det && tid < 2) ne.dctrl0[2 * (long long)blockIdx.x + tid] = kDetEmpty; return; }
 #if defined(MVUS_ASM_STOP) && MVUS_ASM_STOP == 2
   if (acc_[0] != 12345.678) return;      // timing probe: + accumulation, no flush
 #endif
@@ -402,7 +403,7 @@ __global__ __launch_bounds__(kGaThreads) void k_assemble_spans(DevProblem dp, co
         const int p0 = round_off[tid], p1 = round_off[tid + 1];
         det_c0[tid] = pt_ctrl[p0];
         det_ok[tid] = tid < 2 && p1 > p0 && pt_ctrl[p1 - 1] - pt_ctrl[p0] < kDetWin;
-        if (!det_ok[tid]) *ne.dnondet = 1;
+        if (!det_ok[tid]) *ne.dnondet = ne.dgen;
       }
       if (tid < 2) det_mask[tid] = 0ull;
     }
@@ -413,9 +414,10 @@ __global__ __launch_bounds__(kGaThreads) void k_assemble_spans(DevProblem dp, co
       for (int i = tid; i < nown; i += kGaThreads) atomicOr(&det_mask[rho], 1ull << (pt_ctrl[p0 + i] - det_c0[rho]));
     }
     lds_barrier();
-    if (tid < 2 && tid < rounds && det_ok[tid]) {
-      ne.dctrl0[2 * (long long)blockIdx.x + tid] = det_c0[tid];
-      ne.dmask[2 * (long long)blockIdx.x + tid] = det_mask[tid];
+    if (tid < 2) {                                        // (every block header is written by its workgroup in every assembly: no clearing pass)
+      const bool ok = tid < rounds && det_ok[tid];
+      ne.dctrl0[2 * (long long)blockIdx.x + tid] = ok ? det_c0[tid] : kDetEmpty;
+      if (ok) ne.dmask[2 * (long long)blockIdx.x + tid] = det_mask[tid];
     }
   }
   // ---- flush of the cross block + gradient: Ep[rl][q][3][B], Gp[rl][q][3] ----
@@ -540,7 +542,7 @@ __global__ __launch_bounds__(64) void k_det_index(DevProblem dp, int N, const in
   for (int g = tail + lane; g < N; g += 64) first[g] = b1;      // past every window
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) slack = max(slack, __shfl_xor(slack, off, 64));
-  if (lane == 0) atomicMax(&bounds[0], slack);
+  if (lane == 0) bounds[c] = slack;                      // per camera: the gather takes the maximum (nothing to reset between assemblies)
 }
 // One wavefront per control point g, two steps.  (1) lane = camera: every lane finds the window rows of g among its camera's blocks
 // (first block from the table, four block headers in flight at a time) and leaves (block, row) in LDS, in block order.  (2) lane =
@@ -559,8 +561,12 @@ __global__ __launch_bounds__(kThreads) void k_det_gather(DevProblem dp, NEView n
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = (int)blockIdx.x * kWaves + wave;
   if (g >= ne.N) return;                                // (wave-uniform; no workgroup barrier below)
-  const int reach = min(kDetWin, bounds[0]);
-  const bool clean = *ne.dnondet == 0;
+  int reach = 0;
+  for (int c = lane; c < dp.C; c += 64) reach = max(reach, bounds[c]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) reach = max(reach, __shfl_xor(reach, off, 64));
+  reach = min(kDetWin, reach);
+  const bool clean = *ne.dnondet != ne.dgen;
   const int e0 = lane, e1 = lane + 64;                   // the entries of a row this lane adds up
   double b0 = 0.0, b1 = 0.0;                             // gradient / band sums over all cameras (entries >= 3B)
   for (int cbase = 0; cbase < dp.C; cbase += 64)
@@ -2247,6 +2253,8 @@ struct HipSchur {
   void mark_cleared() { ne_cleared = true; }
   // deterministic assembly (see NEView): buffers of the windows, built on first use
   int *det_fill = nullptr, *det_bounds = nullptr, *det_first = nullptr;
+  int det_gen = 0;
+  bool last_det = false;                                   // the last assembly ran in the deterministic mode
   size_t det_blocks = 0;
   bool det_wanted() const { return !shard && (be.det_assembly || std::getenv("MVUS_DET_ASSEMBLY") != nullptr); }
   void det_prepare() {
@@ -2257,23 +2265,25 @@ struct HipSchur {
       MVUS_HIP(hipMalloc(reinterpret_cast<void**>(&ne.dctrl0), nblk * sizeof(int)));
       MVUS_HIP(hipMalloc(reinterpret_cast<void**>(&ne.dmask), nblk * sizeof(unsigned long long)));
       MVUS_HIP(hipMalloc(reinterpret_cast<void**>(&det_fill), nblk * sizeof(int)));
-      MVUS_HIP(hipMalloc(reinterpret_cast<void**>(&det_bounds), 2 * sizeof(int)));
+      MVUS_HIP(hipMalloc(reinterpret_cast<void**>(&det_bounds), ((size_t)std::max(1, ne.C) + 1) * sizeof(int)));
+      MVUS_HIP(hipMemsetAsync(det_bounds, 0, ((size_t)std::max(1, ne.C) + 1) * sizeof(int), be.stream));
       MVUS_HIP(hipMalloc(reinterpret_cast<void**>(&det_first), (size_t)std::max(1, ne.C) * (size_t)std::max(1, ne.N) * sizeof(int)));
-      ne.dnondet = det_bounds + 1;
+      ne.dnondet = det_bounds + std::max(1, ne.C);
       det_blocks = nblk;
+      det_gen = 0;
     }
-    MVUS_HIP(hipMemsetAsync(ne.dctrl0, 0x7f, det_blocks * sizeof(int), be.stream));
-    MVUS_HIP(hipMemsetAsync(det_bounds, 0, 2 * sizeof(int), be.stream));
+    ne.dgen = ++det_gen;                                   // (block headers, slack and the fall-back mark are rewritten / compared per assembly: nothing to clear)
   }
   int det_fallbacks() {                                    // workgroups of the last assembly that had to use atomics (synchronises)
     int v = 0;
-    if (det_bounds) { MVUS_HIP(hipMemcpyAsync(&v, det_bounds + 1, sizeof(int), hipMemcpyDeviceToHost, be.stream)); MVUS_HIP(hipStreamSynchronize(be.stream)); }
-    return v;
+    if (det_bounds && det_gen > 0) { MVUS_HIP(hipMemcpyAsync(&v, ne.dnondet, sizeof(int), hipMemcpyDeviceToHost, be.stream)); MVUS_HIP(hipStreamSynchronize(be.stream)); }
+    return v == det_gen && det_gen > 0 && last_det ? 1 : 0;
   }
   void assemble_local(const double* f_dev, const double* x_fused = nullptr) {
     if (!ne_cleared) be.fill(NE, 0.0, (int64_t)(ne_count + n_apart));      // one launch (hipMemsetAsync splits 36 MB into two fill kernels)
     ne_cleared = false;
     ne.det = det_wanted() && be.dp.n_chunks > 0 ? 1 : 0;
+    last_det = ne.det != 0;
     if (ne.det) det_prepare();
     if (be.dp.n_chunks > 0) {
       const int nc = be.dp.n_chunks;
