@@ -36,6 +36,7 @@ struct HipBackend {
   double *J = nullptr, *mJ = nullptr, *x_cur = nullptr, *f_cur = nullptr;
   int32_t *span = nullptr, *pat0 = nullptr, *mctrl = nullptr;
   bool has_pattern = false, has_jacobian = false;
+  bool held_analytic_at_xcur = false; // the held Jacobian is the analytic one of x_cur (mvus_ba_residual_jacobian): its normal equations can be formed by the fused window-major assembly
   bool det_assembly = false;          // mvus_ba_set_deterministic: the LM normal equations without fp64 atomics (ba_schur_hip.hip.h)
   bool pattern_uploaded = false;     // the caller supplied the reference's pattern (mvus_ba_upload_pattern): solve keeps it
   int32_t* ms_pat_dev = nullptr;
@@ -186,6 +187,7 @@ struct HipBackend {
   }
   void upload(double* d, const double* s, int64_t len) {      // the host buffer may be reused right away
     touch(d);
+    if (d == x_cur) held_analytic_at_xcur = false;
     if (len <= stage_cap) {
       const int slot = stage_slot();
       std::memcpy(stage[slot], s, len * sizeof(double));
@@ -778,6 +780,7 @@ int mvus_ba_residual_jacobian(mvus_ba* h, const double* x, int32_t jac_mode, dou
     // rows that stay invisible are never written by the kernel: clear so the host copy is well defined
     if (J) { be.ensure_J(); MVUS_HIP(hipMemsetAsync(be.J, 0, sizeof(double) * j_doubles(be.hp.NS, be.dp.n_chunks), be.stream)); }
     be.jacobian(be.x_cur, be.f_cur, jac_mode);
+    be.held_analytic_at_xcur = jac_mode == MVUS_JAC_ANALYTIC;
     if (f) be.download(f, be.f_cur, be.hp.m);
     if (J) {                                 // the ABI's layout is slot-major (mvus_ba.h); the device keeps J chunk-major
       PoolGuard<HipBackend> pool(be);
@@ -1028,7 +1031,7 @@ int mvus_ba_lm_step(mvus_ba* h, double lambda, double* p_out) {
     if (be.hp.C * (3 + be.hp.P) > 1152) throw HipError{"LM_SCHUR: reduced camera system larger than 1152 unknowns"};
     if (!h->schur) h->schur.reset(new HipSchur<HipBackend>(be));
     HipSchur<HipBackend>& sc = *h->schur;
-    sc.assemble(be, be.f_cur);
+    sc.assemble_held(be);
     sc.solve_async(lambda);
     be.download(p_out, sc.step_ptr(), be.hp.n);          // synchronises
     if (!sc.solve_ok()) { be.err = "lm_step: the damped normal equations are not positive definite at this lambda"; return MVUS_E_NUMERIC; }
@@ -1057,6 +1060,7 @@ int mvus_ba_solve(mvus_ba* h, double* x, const mvus_solve_opts* opts, mvus_resul
       return MVUS_E_INVALID;
     }
     SolveResult sr;
+    be.held_analytic_at_xcur = false;
     if (opts->solver == MVUS_SOLVER_LM_SCHUR) {
       if (be.hp.C * (3 + be.hp.P) > 1152) throw HipError{"LM_SCHUR: reduced camera system larger than 1152 unknowns"};
       if (!h->schur) h->schur.reset(new HipSchur<HipBackend>(be));

@@ -186,6 +186,7 @@ inline size_t j_doubles(int NS, int n_chunks) { return (size_t)2 * NS * kThreads
 // Sink of eval_observation_to that stores each value of the 2 x NS block straight to the chunk-major Jacobian
 // (masked: spline slots outside the pattern become zeros; an all-zero pattern row stores nothing).
 struct JStoreSink {
+  static constexpr bool kFactored = false;
   double *Jx, *Jy;
   long long stride;
   int32_t pat;

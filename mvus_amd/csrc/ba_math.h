@@ -225,6 +225,18 @@ struct SplineInfo {
   int32_t pad0, pad1;
 };
 
+// Window-major assembly (ba_assemble_win.hip.h): where, among the frame-sorted detections of one camera, a time range can lie.
+// Cell k of the camera's grid covers frames [f0 + k / scale, f0 + (k + 1) / scale); flut[lut_off + k], k = 0 .. ncell, is the first
+// detection (camera-local index) whose frame is >= the left edge of cell k (flut[lut_off + ncell] = M_c).  vmin / vmax bound v_raw over
+// the camera's detections, i.e. the rolling-shutter term rs * v / H of the time stamp.  The grid is laid out once per problem
+// (removing detections only thins the cells out; the table is rebuilt, the grid stays).
+struct CamWin {
+  double f0, scale;
+  double vmin, vmax;
+  int32_t lut_off, ncell;
+  int32_t pad0, pad1;
+};
+
 // Read-only view of the trajectory splines as they sit in device memory.
 struct SplineView {
   int S;                    // number of spline intervals
@@ -424,16 +436,23 @@ MVUS_HD ObsResult eval_observation_to(const CamState& cam, const SplineView& sp,
     for (int k = 0; k < 5; ++k) { sink.x(13 + k, -su * duo[4 + k]); sink.y(13 + k, -sv * dvo[4 + k]); }
   }
   const int b = kSyncSlots + (CALIB ? 15 : 6);
-  for (int q = 0; q < 4; ++q) {
-    sink.x(b + 3 * q + 0, h[q] * gu0); sink.x(b + 3 * q + 1, h[q] * gu1); sink.x(b + 3 * q + 2, h[q] * gu2);
-    sink.y(b + 3 * q + 0, h[q] * gv0); sink.y(b + 3 * q + 1, h[q] * gv1); sink.y(b + 3 * q + 2, h[q] * gv2);
-    MVUS_GROUP_FENCE();
+  if constexpr (Sink::kFactored) {
+    // the twelve spline slots are the Kronecker product h (x) [gu; gv]: a sink that forms J^T J itself takes the factors
+    // (the window-major assembly: band blocks = (h h^T) (x) (g^T g), 46 multiply-adds per row pair instead of 180)
+    sink.factored(h, gu0, gu1, gu2, gv0, gv1, gv2);
+  } else {
+    for (int q = 0; q < 4; ++q) {
+      sink.x(b + 3 * q + 0, h[q] * gu0); sink.x(b + 3 * q + 1, h[q] * gu1); sink.x(b + 3 * q + 2, h[q] * gu2);
+      sink.y(b + 3 * q + 0, h[q] * gv0); sink.y(b + 3 * q + 1, h[q] * gv1); sink.y(b + 3 * q + 2, h[q] * gv2);
+      MVUS_GROUP_FENCE();
+    }
   }
   return out;
 }
 
 // Sink that keeps the 2 x NS values in two arrays (the host harness, and kernels that post-process the row).
 struct ArraySink {
+  static constexpr bool kFactored = false;
   double *jx, *jy;
   MVUS_HD void begin(int32_t) {}
   MVUS_HD void x(int k, double v) { jx[k] = v; }

@@ -33,6 +33,12 @@ struct HostProblem {
   std::vector<double> ms_t, ms_basis;
   std::vector<int32_t> ms_ctrl, ms_part, ms_pat, ms_row_lo, ms_row_hi;
   std::vector<int32_t> cam_chunk_off;
+  // window-major assembly: time range of the detections whose first control point is >= p (win_tlo[p]) / < p (win_thi[p]),
+  // p = 0 .. N; per-camera frame grids (CamWin); frames_sorted: every camera's frames are non-decreasing
+  std::vector<double> win_tlo, win_thi;
+  std::vector<CamWin> cam_win;
+  int64_t flut_len = 0;
+  bool frames_sorted = true;
 
   SplineView spline_view() const {
     return SplineView{S, istart.data(), iend.data(), knots.data(), knot_off.data(), ctrl_off.data(), xoff.data(),
@@ -56,6 +62,52 @@ struct HostProblem {
       }
     }
     cam_chunk_off[C] = (int32_t)chunks.size();
+  }
+
+  // Tables of the window-major assembly.  A visible time stamp tau of interval s lies in knot span l (t[l] <= tau < t[l+1], clamped to
+  // [3, n_s - 1]) and its first control point is g = ctrl_off[s] + l - 3, non-decreasing in tau.  win_tlo[p] <= every visible tau with
+  // g(tau) >= p, win_thi[p] >= every visible tau with g(tau) < p (suffix minimum / prefix maximum of the spans' ends, so the bounds hold
+  // for any knot vector the checks above let through).
+  void build_window_tables() {
+    const double inf = INFINITY;
+    std::vector<double> lo(N + 1, inf), hi(N + 1, -inf);
+    for (int s = 0; s < S; ++s) {
+      const double* t = knots.data() + knot_off[s];
+      const int ns = ctrl_off[s + 1] - ctrl_off[s];
+      for (int j = 0; j + 4 <= ns; ++j) {                  // span l = j + 3 of interval s
+        const int p = ctrl_off[s] + j;
+        lo[p] = j == 0 ? istart[s] : std::max(t[j + 3], istart[s]);
+        hi[p] = j + 4 == ns ? iend[s] : std::min(t[j + 4], iend[s]);
+      }
+    }
+    win_tlo.assign(N + 1, inf); win_thi.assign(N + 1, -inf);
+    double run = inf;
+    for (int p = N; p >= 0; --p) { run = std::min(run, lo[p]); win_tlo[p] = run; }
+    run = -inf;
+    for (int p = 0; p <= N; ++p) { win_thi[p] = run; if (p < N) run = std::max(run, hi[p]); }
+    cam_win.assign(C, CamWin{0.0, 1.0, 0.0, 0.0, 0, 1, 0, 0});
+    frames_sorted = true;
+    int64_t off = 0;
+    for (int c = 0; c < C; ++c) {
+      const int64_t a = det_off[c], b = det_off[c + 1];
+      CamWin& w = cam_win[c];
+      w.lut_off = (int32_t)off;
+      w.ncell = (int32_t)std::max<int64_t>(1, std::min<int64_t>(b - a, 0x3fffffff));
+      if (b > a) {
+        double fmin = frame[a], fmax = frame[a], vmin = v_raw[a], vmax = v_raw[a];
+        for (int64_t i = a; i < b; ++i) {
+          if (i > a && frame[i] < frame[i - 1]) frames_sorted = false;
+          fmin = std::min(fmin, frame[i]); fmax = std::max(fmax, frame[i]);
+          vmin = std::min(vmin, v_raw[i]); vmax = std::max(vmax, v_raw[i]);
+        }
+        if (!(fmin == fmin && fmax == fmax && vmin == vmin && vmax == vmax) || std::isinf(fmin) || std::isinf(fmax)) frames_sorted = false;   // NaN / inf: the ordered search is off
+        w.f0 = fmin; w.vmin = vmin; w.vmax = vmax;
+        w.scale = fmax > fmin ? (double)w.ncell / (fmax - fmin) : 1.0;
+      }
+      off += (int64_t)w.ncell + 1;
+    }
+    flut_len = off;
+    if (off > 0x7fffffff) frames_sorted = false;
   }
 
   // returns "" on success, otherwise what is wrong with the description
@@ -135,6 +187,7 @@ struct HostProblem {
                             lut_off[s], lut_off[s + 1] - lut_off[s], 0, 0};
     }
     build_chunks();
+    build_window_tables();
     // motion samples: ts = arange(int[0,0], int[1,-1], 1) kept where start <= ts <= end (common.py:289-292)
     ms_t.clear(); ms_basis.clear(); ms_ctrl.clear(); ms_part.clear(); ms_pat.clear();
     T = 0;

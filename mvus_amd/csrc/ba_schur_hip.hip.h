@@ -56,6 +56,10 @@ constexpr int kDetWin = 64;
 constexpr int kDetEmpty = 0x7f000000;                    // dctrl0 of a block nobody wrote (the array is memset to 0x7f bytes)
 MVUS_HD int det_entries(int B) { return 3 * B + 3 + 36; }
 
+}  // namespace mvus
+#include "ba_assemble_win.hip.h"
+namespace mvus {
+
 __device__ __forceinline__ int wave_min_i(int v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_down(v, off, 64));
@@ -89,6 +93,7 @@ constexpr int kGaObs = MVUS_GA_OBS, kGaStride = kGaObs + 1, kGaThreads = 4 * kGa
 constexpr int kGaShift = kGaObs == 128 ? 7 : 6, kGaParts = 256 / kGaObs;      // detections per workgroup: 128 or 64 (parts of a 256-chunk)
 static_assert(kGaObs == 128 || kGaObs == 64, "the assembly tile is 128 or 64 detections");
 struct LdsRowSink {          // eval_observation_to sink: slot k of the x / y row of staged column t
+  static constexpr bool kFactored = false;
   double* col;               // Js + t
   int ns;
   __device__ __forceinline__ void begin(int32_t) {}
@@ -2115,6 +2120,11 @@ struct HipSchur {
   bool overlap_chol = true;                    // interiors factorised beside the right-hand-side copies (k_cholesky_and_rhs)
   int rhs_tiles_z = 0;
   int* halo_tables = nullptr;                  // [nbound] cut, [nbound] index in the packed buffer
+  // window-major fused assembly (ba_assemble_win.hip.h): tables and the per-(window, camera) camera-block partials
+  WinView wv{};
+  bool use_win = false;
+  void* win_tables = nullptr;
+  size_t win_lds = 0;
 
   explicit HipSchur(BE& b) : be(b) {
     const HostProblem& hp = be.hp;
@@ -2234,9 +2244,44 @@ struct HipSchur {
     bcr_lds = (size_t)2 * mm * pv.s3 * bcr_cols * sizeof(double);
     if (bcr_lds > 64 * 1024) { bcr_cols = 1; bcr_lds /= kBcrCols; }
     use_bcr = bcr_lds <= 64 * 1024 && !std::getenv("MVUS_SEP_SEQUENTIAL");
+    win_prepare();
+  }
+  // Window-major assembly: needs every camera's frames in non-decreasing order (HostProblem::frames_sorted; anything else keeps the
+  // detection-major kernel with its atomics).  Window length: about one wavefront of detections per (window, camera) -- the
+  // Wn + 3 spans that reach a window hold (Wn + 3) * M / (C * N) detections on average -- within [4, 16] control points.
+  void win_prepare() {
+    const HostProblem& hp = be.hp;
+    use_win = hp.frames_sorted && hp.M > 0 && ne.N > 0 && !std::getenv("MVUS_ASM_ATOMIC");
+    if (!use_win) return;
+    const double rho = (double)hp.M / ((double)hp.C * std::max(1, hp.N));
+    int Wn = (int)std::lround(56.0 / std::max(rho, 1e-9)) - 3;
+    Wn = std::min(16, std::max(4, Wn));
+    if (const char* e = std::getenv("MVUS_WIN")) Wn = std::min(kWinMaxW, std::max(1, std::atoi(e)));
+    if (hp.calib) Wn = std::min(Wn, 12);
+    wv.Wn = Wn; wv.nwin = (ne.N + Wn - 1) / Wn; wv.Ntot = hp.N;
+    const size_t psz = (size_t)(ne.B + 1) * (ne.B + 2) / 2;
+    wv.Apart = be.alloc((size_t)wv.nwin * ne.C * psz);
+    const size_t bytes_cw = sizeof(CamWin) * (size_t)hp.C, bytes_t = sizeof(double) * ((size_t)hp.N + 1), bytes_l = sizeof(int32_t) * (size_t)hp.flut_len;
+    MVUS_HIP(hipMalloc(&win_tables, bytes_cw + 2 * bytes_t + bytes_l));
+    char* base = static_cast<char*>(win_tables);
+    MVUS_HIP(hipMemcpyAsync(base, hp.cam_win.data(), bytes_cw, hipMemcpyHostToDevice, be.stream));
+    MVUS_HIP(hipMemcpyAsync(base + bytes_cw, hp.win_tlo.data(), bytes_t, hipMemcpyHostToDevice, be.stream));
+    MVUS_HIP(hipMemcpyAsync(base + bytes_cw + bytes_t, hp.win_thi.data(), bytes_t, hipMemcpyHostToDevice, be.stream));
+    wv.cw = reinterpret_cast<const CamWin*>(base);
+    wv.tlo = reinterpret_cast<const double*>(base + bytes_cw);
+    wv.thi = reinterpret_cast<const double*>(base + bytes_cw + bytes_t);
+    int32_t* flut = reinterpret_cast<int32_t*>(base + bytes_cw + 2 * bytes_t);
+    wv.flut = flut;
+    hipLaunchKernelGGL(k_frame_lut, dim3((unsigned)((hp.flut_len + 255) / 256)), dim3(256), 0, be.stream, be.dp, wv.cw, flut, (long long)hp.flut_len);
+    MVUS_HIP(hipGetLastError());
+    MVUS_HIP(hipStreamSynchronize(be.stream));
+    win_lds = ((size_t)kWinWaves * win_region_doubles(ne.B)) * sizeof(double) + (size_t)kWinWaves * 24 * sizeof(unsigned long long);
+    if (hp.calib) MVUS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_assemble_windows<18>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)win_lds));
+    else MVUS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_assemble_windows<9>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)win_lds));
   }
   ~HipSchur() {
-    for (double* p : {Erm, NE, Lb, Z, G, G0, S, S2, Linv, rhs, pc, DG, px, pv.VW, sepbuf, pv.U2, pv.Ha, pv.Hc}) if (p) be.release(p);
+    for (double* p : {Erm, NE, Lb, Z, G, G0, S, S2, Linv, rhs, pc, DG, px, pv.VW, sepbuf, pv.U2, pv.Ha, pv.Hc, wv.Apart}) if (p) be.release(p);
+    if (win_tables) (void)hipFree(win_tables);
     if (part_tables) (void)hipFree(part_tables);
     if (halo_tables) (void)hipFree(halo_tables);
     if (fail) (void)hipFree(fail);
@@ -2248,7 +2293,7 @@ struct HipSchur {
   // the motion rows (O(T), tiny) still go through k_motion
   // the storage the assembly adds into; the LM driver has it zeroed beside its first residual evaluation (mark_cleared)
   bool ne_cleared = false;
-  double* clear_ptr() { return NE; }
+  double* clear_ptr() { return use_win ? nullptr : NE; }      // (the window-major assembly writes every entry: nothing to clear)
   int64_t clear_len() const { return (int64_t)(ne_count + n_apart); }
   void mark_cleared() { ne_cleared = true; }
   // deterministic assembly (see NEView): buffers of the windows, built on first use
@@ -2279,7 +2324,32 @@ struct HipSchur {
     if (det_bounds && det_gen > 0) { MVUS_HIP(hipMemcpyAsync(&v, ne.dnondet, sizeof(int), hipMemcpyDeviceToHost, be.stream)); MVUS_HIP(hipStreamSynchronize(be.stream)); }
     return v == det_gen && det_gen > 0 && last_det ? 1 : 0;
   }
+  void motion_rows(const double* f_dev) {
+    // (one rank: the row-ordered kernel in both modes -- 22 us against 26 for the LDS-window one at configs[1], and one source of
+    // run-to-run differences less; a time shard keeps k_assemble_motion, which also reports rows that leave the slice)
+    if (be.hp.T > 0 && !shard && ne.W <= kDetMotW) {
+      hipLaunchKernelGGL(k_det_motion, dim3((unsigned)((ne.N + kThreads / 64 - 1) / (kThreads / 64))), dim3(kThreads), 0, be.stream, be.dp, be.mJ, be.mctrl,
+                         f_dev + 2 * be.hp.M, ne);
+    } else if (be.hp.T > 0)
+      hipLaunchKernelGGL(k_assemble_motion, dim3((be.hp.T + kThreads - 1) / kThreads), dim3(kThreads), 0, be.stream, be.dp, be.mJ, be.mctrl,
+                         f_dev + 2 * be.hp.M, ne);
+  }
   void assemble_local(const double* f_dev, const double* x_fused = nullptr) {
+    if (x_fused && use_win) {
+      // window-major: every entry of A, gc, Cb, gs, Et is written by exactly one thread -- no clearing pass, no atomics
+      ne_cleared = false; ne.det = 0; last_det = false;
+      be.ensure_cams(x_fused);
+      if (be.hp.calib) {
+        hipLaunchKernelGGL(k_assemble_windows<18>, dim3(wv.nwin), dim3(kWinThreads), win_lds, be.stream, be.dp, ne, wv, be.cams, x_fused);
+        hipLaunchKernelGGL(k_cam_block_sum<18>, dim3(be.hp.C), dim3(1024), 0, be.stream, be.hp.C, wv.nwin, wv.Apart, ne);
+      } else {
+        hipLaunchKernelGGL(k_assemble_windows<9>, dim3(wv.nwin), dim3(kWinThreads), win_lds, be.stream, be.dp, ne, wv, be.cams, x_fused);
+        hipLaunchKernelGGL(k_cam_block_sum<9>, dim3(be.hp.C), dim3(1024), 0, be.stream, be.hp.C, wv.nwin, wv.Apart, ne);
+      }
+      motion_rows(f_dev);
+      MVUS_HIP(hipGetLastError());
+      return;
+    }
     if (!ne_cleared) be.fill(NE, 0.0, (int64_t)(ne_count + n_apart));      // one launch (hipMemsetAsync splits 36 MB into two fill kernels)
     ne_cleared = false;
     ne.det = det_wanted() && be.dp.n_chunks > 0 ? 1 : 0;
@@ -2307,14 +2377,7 @@ struct HipSchur {
       if (be.hp.calib) hipLaunchKernelGGL(k_cam_block_reduce<18>, dim3(be.hp.C, 2), dim3(1024), 0, be.stream, be.dp, ne);
       else hipLaunchKernelGGL(k_cam_block_reduce<9>, dim3(be.hp.C, 2), dim3(1024), 0, be.stream, be.dp, ne);
     }
-    // (one rank: the row-ordered kernel in both modes -- 22 us against 26 for the LDS-window one at configs[1], and one source of
-    // run-to-run differences less; a time shard keeps k_assemble_motion, which also reports rows that leave the slice)
-    if (be.hp.T > 0 && !shard && ne.W <= kDetMotW) {
-      hipLaunchKernelGGL(k_det_motion, dim3((unsigned)((ne.N + kThreads / 64 - 1) / (kThreads / 64))), dim3(kThreads), 0, be.stream, be.dp, be.mJ, be.mctrl,
-                         f_dev + 2 * be.hp.M, ne);
-    } else if (be.hp.T > 0)
-      hipLaunchKernelGGL(k_assemble_motion, dim3((be.hp.T + kThreads - 1) / kThreads), dim3(kThreads), 0, be.stream, be.dp, be.mJ, be.mctrl,
-                         f_dev + 2 * be.hp.M, ne);
+    motion_rows(f_dev);
     MVUS_HIP(hipGetLastError());
   }
   // Linearise at x: residual f (unless the caller already holds f(x) in f_dev), Jacobian, normal equations.  With the
@@ -2346,6 +2409,13 @@ struct HipSchur {
       diag_pending = true;              // D and g (x order) are written by the next solve's first kernel, or by flush_diag()
     }
     MVUS_HIP(hipGetLastError());
+  }
+
+  // normal equations of the Jacobian the backend holds: the analytic Jacobian of x_cur goes through the fused window-major assembly
+  // (the LM path's kernel; MVUS_NE_FROM_J=1 forms them from the stored blocks instead), anything else is assembled from J
+  void assemble_held(BE&) {
+    const bool fused = be.held_analytic_at_xcur && use_win && !std::getenv("MVUS_NE_FROM_J");
+    assemble(be, be.f_cur, fused ? be.x_cur : nullptr);
   }
 
   void flush_diag() {
@@ -2463,7 +2533,7 @@ int schur_export(BE& be, HipSchur<BE>& sc, double* g, double* JtJ_cam, double* b
   if (sc.shard) { be.err = "normal_equations: not available on a time shard (every rank holds a slice of the spline blocks)"; return MVUS_E_INVALID; }
   if (W_out) *W_out = sc.ne.W;
   if (!g && !JtJ_cam && !band && !cross) return MVUS_OK;
-  sc.assemble(be, be.f_cur);
+  sc.assemble_held(be);
   sc.flush_diag();
   const NEView& ne = sc.ne;
   if (g) be.download(g, sc.gx, be.hp.n);
