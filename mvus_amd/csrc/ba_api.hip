@@ -35,6 +35,10 @@ struct HipBackend {
   const double* cams_for = nullptr;   // device x buffer whose camera states `cams` holds (nullptr: none); cleared when that buffer is rewritten
   double *J = nullptr, *mJ = nullptr, *x_cur = nullptr, *f_cur = nullptr;
   int32_t *span = nullptr, *pat0 = nullptr, *mctrl = nullptr;
+  // first control point per detection (-1: not visible) at the x of the last residual-only evaluation: the window-major fused
+  // assembly evaluates with a known knot span (`span` belongs to the held Jacobian and must survive residual evaluations)
+  int32_t* rspan = nullptr;
+  const double* rspan_for = nullptr;
   bool has_pattern = false, has_jacobian = false;
   bool held_analytic_at_xcur = false; // the held Jacobian is the analytic one of x_cur (mvus_ba_residual_jacobian): its normal equations can be formed by the fused window-major assembly
   bool det_assembly = false;          // mvus_ba_set_deterministic: the LM normal equations without fp64 atomics (ba_schur_hip.hip.h)
@@ -109,7 +113,7 @@ struct HipBackend {
     double* uo = dalloc<double>(hp.M); double* vo = dalloc<double>(hp.M);
     dp.u_obs = uo; dp.v_obs = vo;
     cams = dalloc<CamState>(hp.C);
-    span = dalloc<int32_t>(hp.M); pat0 = dalloc<int32_t>(hp.M);
+    span = dalloc<int32_t>(hp.M); pat0 = dalloc<int32_t>(hp.M); rspan = dalloc<int32_t>(hp.M);
     mJ = dalloc<double>((size_t)36 * hp.T); mctrl = dalloc<int32_t>((size_t)3 * hp.T);
     x_cur = dalloc<double>(hp.n); f_cur = alloc(hp.m);      // (from the pool: an LM solve swaps it with its trial buffer)
     partials = dalloc<double>(2048); scal_dev = dalloc<double>(16);
@@ -173,7 +177,7 @@ struct HipBackend {
   void release(double* p) { if (p) { touch(p); pool_free[pool_size[p]].push_back(p); } }
   // decoded camera states are reused while the x buffer they came from is untouched (the accepted point of an LM iteration
   // is the trial point whose states are already there; a 2-evaluation solve evaluates and linearises at the same x)
-  void touch(const double* d) { if (d == cams_for) cams_for = nullptr; }
+  void touch(const double* d) { if (d == cams_for) cams_for = nullptr; if (d == rspan_for) rspan_for = nullptr; }
   void ensure_cams(const double* x) {
     if (cams_for == x) return;
     hipLaunchKernelGGL(k_cam_states, dim3((hp.C + 63) / 64), dim3(64), 0, stream, dp, x, cams);
@@ -331,11 +335,12 @@ struct HipBackend {
       const dim3 g(dp.n_chunks), gj(xcd_grid(dp.n_chunks)), b(kThreads);
       if (hp.calib) {
         if (jac) hipLaunchKernelGGL((k_observations<true, true>), gj, b, 0, stream, dp, cams, x, f, J, span, pat0, (int)masked);
-        else hipLaunchKernelGGL((k_observations<true, false>), g, b, 0, stream, dp, cams, x, f, J, span, pat0, 0);
+        else hipLaunchKernelGGL((k_observations<true, false>), g, b, 0, stream, dp, cams, x, f, J, rspan, pat0, 0);
       } else {
         if (jac) hipLaunchKernelGGL((k_observations<false, true>), gj, b, 0, stream, dp, cams, x, f, J, span, pat0, (int)masked);
-        else hipLaunchKernelGGL((k_observations<false, false>), g, b, 0, stream, dp, cams, x, f, J, span, pat0, 0);
+        else hipLaunchKernelGGL((k_observations<false, false>), g, b, 0, stream, dp, cams, x, f, J, rspan, pat0, 0);
       }
+      if (!jac) rspan_for = x;
     }
     if (hp.T > 0) {
       if (is_root || tshard.on) {
@@ -368,8 +373,9 @@ struct HipBackend {
       const int fb = (clr && clr_len > 0) ? (int)std::min<int64_t>(2048, (clr_len + kThreads - 1) / kThreads) : 0;
       const dim3 g(dp.n_chunks + fb), b(kThreads);
       double* c = fb > 0 ? clr : (double*)nullptr;
-      if (hp.calib) hipLaunchKernelGGL((k_observations<true, false>), g, b, 0, stream, dp, cams, x, f, J, span, pat0, 0, sq_part, c, (long long)clr_len);
-      else hipLaunchKernelGGL((k_observations<false, false>), g, b, 0, stream, dp, cams, x, f, J, span, pat0, 0, sq_part, c, (long long)clr_len);
+      if (hp.calib) hipLaunchKernelGGL((k_observations<true, false>), g, b, 0, stream, dp, cams, x, f, J, rspan, pat0, 0, sq_part, c, (long long)clr_len);
+      else hipLaunchKernelGGL((k_observations<false, false>), g, b, 0, stream, dp, cams, x, f, J, rspan, pat0, 0, sq_part, c, (long long)clr_len);
+      rspan_for = x;
       cleared = fb > 0;
     }
     if (mb > 0) hipLaunchKernelGGL(k_motion<false>, dim3(mb), dim3(kThreads), 0, stream, dp, x, f + 2 * hp.M, mJ, mctrl, 0, sq_part + dp.n_chunks);
@@ -476,7 +482,7 @@ struct HipBackend {
       MVUS_HIP(hipMemcpyAsync(const_cast<int32_t*>(dp.cam_chunk_off), hp.cam_chunk_off.data(), hp.cam_chunk_off.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
       dp.n_chunks = (int)nck;
       MVUS_HIP(hipStreamSynchronize(stream));
-      has_pattern = false; has_jacobian = false; fd_ngroups = 0;
+      has_pattern = false; has_jacobian = false; fd_ngroups = 0; rspan_for = nullptr;
       if (pattern_uploaded && hp.T > 0) MVUS_HIP(hipMemcpyAsync(ms_pat_dev, hp.ms_pat.data(), sizeof(int32_t) * hp.T, hipMemcpyHostToDevice, stream));
       pattern_uploaded = false;
       m_glob = hp.m;
@@ -1188,8 +1194,8 @@ int mvus_ba_time_kernel(mvus_ba* h, int32_t which, int32_t launches, double* avg
     auto launch = [&]() {
       switch (which) {
         case 0:
-          if (be.hp.calib) hipLaunchKernelGGL((k_observations<true, false>), g, b, 0, be.stream, be.dp, be.cams, be.x_cur, be.f_cur, be.J, be.span, be.pat0, 0);
-          else hipLaunchKernelGGL((k_observations<false, false>), g, b, 0, be.stream, be.dp, be.cams, be.x_cur, be.f_cur, be.J, be.span, be.pat0, 0);
+          if (be.hp.calib) hipLaunchKernelGGL((k_observations<true, false>), g, b, 0, be.stream, be.dp, be.cams, be.x_cur, be.f_cur, be.J, be.rspan, be.pat0, 0);
+          else hipLaunchKernelGGL((k_observations<false, false>), g, b, 0, be.stream, be.dp, be.cams, be.x_cur, be.f_cur, be.J, be.rspan, be.pat0, 0);
           break;
         case 1:
         case 5: {

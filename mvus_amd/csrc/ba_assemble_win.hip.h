@@ -39,7 +39,8 @@ namespace mvus {
 
 constexpr int kWinWaves = 4, kWinThreads = 64 * kWinWaves;
 constexpr int kWinStr = 65;                     // staging row stride (odd: the matrix-core fragment reads walk the rows)
-constexpr int kWinMaxW = 18, kWinMaxJ = kWinMaxW + 3;      // 3 * (Wn + 3) lane roles must fit a wavefront
+constexpr int kWinMaxW = 16, kWinMaxJ = kWinMaxW + 3;      // 3 * (Wn + 3) lane roles must fit a wavefront (and two workgroups the LDS of a CU)
+constexpr int kWinSpl = 18;                                 // doubles of one span's record in LDS: six knots, 3 x 4 coefficients
 
 struct WinView {
   const CamWin* cw;          // [C]
@@ -47,6 +48,9 @@ struct WinView {
   const double* tlo;         // [Ntot + 1] by GLOBAL control point: <= every visible time stamp whose first control point is >= p
   const double* thi;         // [Ntot + 1]: >= every visible time stamp whose first control point is < p
   double* Apart;             // [nwin][C][(B+1)(B+2)/2] lower triangle of [camera slots; f][..]^T per (window, camera)
+  const int32_t* span;       // [M] first control point (global) of every detection at the x being linearised, -1 = not visible
+  const int4* crec;          // [Ntot] per control point g as a FIRST control point: {x index of coordinate 0, coefficients of its spline
+                             //        (stride between coordinates), index of knot t[l-2] of its span, 1: first span | 2: last span of the interval}
   int Wn, nwin;
   int Ntot;                  // control points of the whole problem (a time shard's slice is shorter)
 };
@@ -98,32 +102,86 @@ __device__ __forceinline__ void win_wave_sync() {      // orders the LDS traffic
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
 }
 
+#ifndef MVUS_WIN_MFMA_UNROLL
+#define MVUS_WIN_MFMA_UNROLL 4
+#endif
+#ifndef MVUS_WIN_WAVES_PER_EU
+#define MVUS_WIN_WAVES_PER_EU 2
+#endif
+MVUS_HD int win_pieces(int Wn) { return 21 / (Wn + 3); }      // pieces a span's detections are dealt into (dense tracks, short windows)
+constexpr __host__ __device__ int win_wave_doubles(int B) { return win_region_doubles(B) + kWinMaxW * 3 * B + 24; }   // + E accumulator + span masks
+constexpr __host__ __device__ int win_lds_doubles(int B) { return kWinWaves * win_wave_doubles(B) + kWinMaxJ * kWinSpl; }   // + the window's span records
+
 template <int B>
-__global__ __launch_bounds__(kWinThreads) void k_assemble_windows(DevProblem dp, NEView ne, WinView wv, const CamState* __restrict__ cams,
-                                                                  const double* __restrict__ x) {
+__global__ __launch_bounds__(kWinThreads) __attribute__((amdgpu_waves_per_eu(B == 9 ? MVUS_WIN_WAVES_PER_EU : 1, B == 9 ? MVUS_WIN_WAVES_PER_EU : 1)))
+void k_assemble_windows(DevProblem dp, NEView ne, WinView wv, const CamState* __restrict__ cams, const double* __restrict__ x) {
   constexpr bool CALIB = B == 18;
   constexpr int NV = 12 + 2 * B;                            // staged values per detection: h[4] gu[3] gv[3] Jx[B] Jy[B] fx fy
   constexpr int kFx = 10 + 2 * B, kFy = 11 + 2 * B;
   constexpr int PSZ = (B + 1) * (B + 2) / 2, TI = (B + 1 + 15) / 16;
-  constexpr int REG = win_region_doubles(B);
+  constexpr int REG = win_region_doubles(B), WAVE = win_wave_doubles(B);
   static_assert(NV * kWinStr <= REG, "staging fits the region");
-  extern __shared__ double win_lds[];                       // [kWinWaves][REG] doubles, then [kWinWaves][24] masks
+  extern __shared__ double win_lds[];                       // per wavefront: [REG] staging / flush region, [kWinMaxW * 3 * B] E accumulator, [24] masks
   using d4v = __attribute__((ext_vector_type(4))) double;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  double* S = win_lds + wave * REG;
-  unsigned long long* mk = reinterpret_cast<unsigned long long*>(win_lds + kWinWaves * REG) + wave * 24;
+  double* S = win_lds + wave * WAVE;
+  double* Eacc = S + REG;
+  unsigned long long* mk = reinterpret_cast<unsigned long long*>(Eacc + kWinMaxW * 3 * B);
+  double* spl = win_lds + kWinWaves * WAVE;                 // [NJ][18]: knots t[l-2 .. l+3] and coefficients (x, y, z) x 4 of every span of the window
   const int win = blockIdx.x;
   const int a = win * wv.Wn;                                // first owned control point (local to the handle's slice)
   const int nown = min(wv.Wn, ne.N - a), NJ = nown + 3;     // spans a - 3 .. a + nown - 1 reach the window
-  const int j = lane / 3, d = lane - 3 * j;
+  const int SP = win_pieces(wv.Wn);                         // lane = (span j, piece s, coordinate d)
+  const int j = lane / (3 * SP), s = (lane / 3) % SP, d = lane % 3;
   const bool role = j < NJ;
+  const int mslot = j * SP + s;
   // the window's time range; the first / last window of a time shard's slice also sees what lies beyond the slice (and flags it)
   const double inf = INFINITY;
   const int ga = a + ne.row0;
   const double T0 = (win == 0 && ne.row0 > 0) ? -inf : wv.tlo[max(ga - 3, 0)];
   const double T1 = (win == wv.nwin - 1 && ne.row0 + ne.N < wv.Ntot) ? inf : wv.thi[ga + nown];
   if (lane < 24) mk[lane] = 0ull;
+  // the window's spline data, once per workgroup: every evaluation below reads knots and coefficients from LDS (no dependent global
+  // loads on the per-detection path); a control point that cannot start a span (the last three of an interval) leaves zeros
+  for (int e = threadIdx.x; e < NJ * kWinSpl; e += kWinThreads) {
+    const int kk = e / kWinSpl, r = e - kk * kWinSpl;
+    const int g = ga - 3 + kk;
+    double v = 0.0;
+    if (g >= 0 && g < wv.Ntot) {
+      const int4 rec = wv.crec[g];
+      if (!(rec.w & 4)) v = r < 6 ? dp.sp.knots[rec.z + r] : x[rec.x + (r - 6) % 4 + ((r - 6) / 4) * rec.y];
+    }
+    spl[e] = v;
+  }
+  unsigned flags = 0u;                                      // per span: 1 first / 2 last span of its interval (lane kk < NJ holds span kk's)
+  if (lane < NJ) { const int g = ga - 3 + lane; if (g >= 0 && g < wv.Ntot) flags = (unsigned)wv.crec[g].w; }
+  __syncthreads();
+
+  // ---- detection range of every camera of this wavefront, all at once (lane i: camera wave + 4 i): frames that can carry a time
+  //      stamp in [T0, T1), tau = alpha (frame + rs v / H) + beta with v in [vmin, vmax], looked up in the camera's frame grid ----
+  const int ncam = (dp.C - wave + kWinWaves - 1) / kWinWaves;       // cameras of this wavefront: <= 64 (the reduced camera system limits C * B to 1152)
+  int p0v = 0, p1v = 0;
+  if (lane < ncam) {
+    const int c = wave + kWinWaves * lane;
+    const CamState* cs = cams + c;
+    const CamWin cw = wv.cw[c];
+    const double alpha = cs->alpha, beta = cs->beta, rs = cs->rs, H = cs->H;
+    const int Mc = (int)(dp.det_off[c + 1] - dp.det_off[c]);
+    int p0 = 0, p1 = Mc;
+    const double ra = rs * cw.vmin / H, rb = rs * cw.vmax / H;
+    const double FL = (T0 - beta) / alpha - fmax(ra, rb), FH = (T1 - beta) / alpha - fmin(ra, rb);
+    if (alpha > 0.0 && FL <= FH) {                          // (anything else -- alpha <= 0, NaN -- : the whole camera, the span test decides)
+      const double kl = fmin(fmax(floor((FL - cw.f0) * cw.scale) - 1.0, 0.0), (double)cw.ncell);
+      const double kh = fmin(fmax(floor((FH - cw.f0) * cw.scale) + 2.0, 0.0), (double)cw.ncell);
+      p0 = wv.flut[cw.lut_off + (int)kl];
+      p1 = wv.flut[cw.lut_off + (int)kh];
+    }
+    p0v = p0; p1v = max(p0, p1);
+  }
+  auto cam_range = [&](int i, int& p0, int& p1) {           // (i wave-uniform)
+    p0 = __builtin_amdgcn_readlane(p0v, i); p1 = __builtin_amdgcn_readlane(p1v, i);
+  };
 
   double CA[30], gq[4];                                    // band blocks (pair (qa, w), column d2), gradient: across the camera walk
 #pragma unroll
@@ -132,28 +190,43 @@ __global__ __launch_bounds__(kWinThreads) void k_assemble_windows(DevProblem dp,
   for (int q = 0; q < 4; ++q) gq[q] = 0.0;
 #define MVUS_WCA(qa, w, d2) CA[(4 * (qa) - (qa) * ((qa) - 1) / 2 + (w)) * 3 + (d2)]
 
-  for (int c = wave; c < dp.C; c += kWinWaves) {
-    const CamState& cam = cams[c];                          // wave-uniform: scalar loads
-    const CamWin cw = wv.cw[c];
-    const long long a0 = dp.det_off[c];
-    const int Mc = (int)(dp.det_off[c + 1] - a0);
-    // frames that can carry a time stamp in [T0, T1):  tau = alpha (frame + rs v / H) + beta, v in [vmin, vmax]
-    int p0 = 0, p1 = Mc;
-    {
-      const double ra = cam.rs * cw.vmin / cam.H, rb = cam.rs * cw.vmax / cam.H;
-      const double FL = (T0 - cam.beta) / cam.alpha - fmax(ra, rb), FH = (T1 - cam.beta) / cam.alpha - fmin(ra, rb);
-      if (cam.alpha > 0.0 && FL <= FH) {                    // (anything else -- alpha <= 0, NaN -- : the whole camera, the span test decides)
-        const double kl = fmin(fmax(floor((FL - cw.f0) * cw.scale) - 1.0, 0.0), (double)cw.ncell);
-        const double kh = fmin(fmax(floor((FH - cw.f0) * cw.scale) + 2.0, 0.0), (double)cw.ncell);
-        p0 = wv.flut[cw.lut_off + (int)kl];
-        p1 = wv.flut[cw.lut_off + (int)kh];
-      }
+  // inputs of one batch (lane = detection), fetched one batch ahead: the detection, its first control point from the span table
+  // (key: its span's number in the window, -1 = not this window's / not visible) and that control point's record
+  struct Inputs { double fr, vr, p, q; int g; };
+  auto fetch = [&](long long a0, int pos, int p1) {
+    Inputs in{0.0, 0.0, 0.0, 0.0, -1};
+    if (pos < p1) {                                         // (five independent loads: nothing here waits for the span)
+      const long long i = a0 + pos;
+      in.g = wv.span[i];
+      in.fr = dp.frame[i]; in.vr = dp.v_raw[i];
+      in.p = CALIB ? dp.u_raw[i] : dp.u_obs[i];
+      in.q = CALIB ? 0.0 : dp.v_obs[i];
     }
-    double E[4][B];
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-      for (int k = 0; k < B; ++k) E[q][k] = 0.0;
+    return in;
+  };
+  auto span_key = [&](int g) {                              // number of the span in the window, -1: not this window's / not visible
+    if (g < 0) return -1;
+    const int gl = g - ne.row0;                             // local first control point; a time shard must hold all four
+    if (gl < 0 || gl + 3 >= ne.N) { atomicOr(ne.err, 1); return -1; }
+    const int kk = gl - (a - 3);
+    return (kk >= 0 && kk < NJ) ? kk : -1;
+  };
+
+#ifdef MVUS_WIN_PROBE
+  long long tpa[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long tprev = clock64(); const long long tstart = tprev; int nbatch = 0;
+#define MVUS_WTP(i) do { const long long t_ = clock64(); tpa[i] += t_ - tprev; tprev = t_; } while (0)
+#else
+#define MVUS_WTP(i) ((void)0)
+#endif
+  int p0 = 0, p1 = 0;
+  if (ncam > 0) cam_range(0, p0, p1);
+  Inputs cur = ncam > 0 ? fetch(dp.det_off[wave], p0 + lane, p1) : Inputs{0.0, 0.0, 0.0, 0.0, -1};
+  for (int ci = 0; ci < ncam; ++ci) {
+    const int c = wave + kWinWaves * ci;
+    const CamState& cam = cams[c];                          // wave-uniform: scalar loads
+    const long long a0 = dp.det_off[c];
+    int np0 = 0, np1 = 0;                                   // the next camera's range
+    if (ci + 1 < ncam) cam_range(ci + 1, np0, np1);
     d4v cacc[2][TI][TI];
 #pragma unroll
     for (int h2 = 0; h2 < 2; ++h2)
@@ -161,59 +234,120 @@ __global__ __launch_bounds__(kWinThreads) void k_assemble_windows(DevProblem dp,
       for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int jj = 0; jj < TI; ++jj) cacc[h2][i][jj] = d4v{0.0, 0.0, 0.0, 0.0};
+    const int PS = nown * 3 * B;
+    double* er = ne.Et + ((long long)c * ne.N3 + 3 * a) * B;
+    if (!(p0 < p1)) {                                       // no detection of this camera near the window: its block of Et is zero
+      for (int o = lane; o < PS; o += 64) er[o] = 0.0;
+      cur = (ci + 1 < ncam) ? fetch(dp.det_off[c + kWinWaves], np0 + lane, np1) : Inputs{0.0, 0.0, 0.0, 0.0, -1};
+    }
 
     for (int base = p0; base < p1; base += 64) {
-      // ---- stage: lane = detection ----
-      const int pos = base + lane;
-      int key = -1;
-      bool owned = false;
-      if (pos < p1) {
-        const long long i = a0 + pos;
-        const double uo = CALIB ? 0.0 : dp.u_obs[i], vo = CALIB ? 0.0 : dp.v_obs[i];
-        const double ur = CALIB ? dp.u_raw[i] : 0.0;
-        WinSink<B> sink{S + lane};
-        const ObsResult r = eval_observation_to<CALIB, true>(cam, dp.sp, x, dp.undist != 0, dp.rs_free != 0, dp.sync_free != 0,
-                                                             dp.frame[i], ur, dp.v_raw[i], uo, vo, sink);
-        if (r.ctrl >= 0) {
-          const int gl = r.ctrl - ne.row0;                  // local first control point; a time shard must hold all four
-          if (gl < 0 || gl + 3 >= ne.N) atomicOr(ne.err, 1);
-          else {
-            const int kk = gl - (a - 3);
-            if (kk >= 0 && kk < NJ) { key = kk; owned = kk >= 3; }
-          }
-          S[kFx * kWinStr + lane] = r.ex; S[kFy * kWinStr + lane] = r.ey;
+      const bool first = base == p0, last = base + 64 >= p1;
+      // the next batch's inputs (this camera's, else the first of the next camera): in flight over this batch's arithmetic
+      Inputs nxt;
+      if (!last) nxt = fetch(a0, base + 64 + lane, p1);
+      else if (ci + 1 < ncam) nxt = fetch(dp.det_off[c + kWinWaves], np0 + lane, np1);
+      else nxt = Inputs{0.0, 0.0, 0.0, 0.0, -1};
+      MVUS_WTP(0);     // camera set-up / previous flush tail
+      // ---- stage: lane = detection; knot span known (span table), its knots and coefficients from LDS ----
+      const int key = span_key(cur.g);
+      // staged column of a detection: its rank among the lanes that hold one of this window's (lane order kept) -- the columns in
+      // use are contiguous, so the matrix-core pass below walks the owned ones only
+      const unsigned long long valid = __ballot(key >= 0);
+      const int slot = __popcll(valid & ((1ull << lane) - 1ull));
+      if (key >= 0) {
+        SpanLoc loc;
+        loc.ctrl = ga - 3 + key; loc.n = 0; loc.xoff = 0;
+        const double* sk = spl + key * kWinSpl;
+#pragma unroll
+        for (int t = 0; t < 6; ++t) loc.tt[t] = sk[t];
+#pragma unroll
+        for (int dd = 0; dd < 3; ++dd)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) loc.c[dd][q] = sk[6 + 4 * dd + q];
+        const double tau = cam.alpha * (cur.fr + cam.rs * cur.vr / cam.H) + cam.beta;
+        // the table must be the one of THIS x (FITPACK rule t[l] <= tau < t[l+1], open at the clamped ends of an interval)
+        const unsigned fl = (unsigned)__shfl((int)flags, key, 64);
+        if (!(((fl & 1u) || loc.tt[2] <= tau) && ((fl & 2u) || tau < loc.tt[3]))) atomicOr(ne.err, 2);
+        WinSink<B> sink{S + slot};
+        const ObsResult r = eval_observation_at<CALIB, true>(cam, tau, loc, dp.undist != 0, dp.rs_free != 0, dp.sync_free != 0,
+                                                             cur.fr, CALIB ? cur.p : 0.0, cur.vr, CALIB ? 0.0 : cur.p, cur.q, sink);
+        S[kFx * kWinStr + slot] = r.ex; S[kFy * kWinStr + slot] = r.ey;
+        atomicOr(&mk[key * SP + slot % SP], 1ull << slot);  // a span's detections are dealt to its pieces in turn
+      }
+      // spans >= a: the detections this window OWNS (camera block), as a mask over the staged columns (which keep the lane order:
+      // the ballot shifted down when the lanes in use are one run -- anything else only with gaps in visibility -- else compressed)
+      unsigned long long own = __ballot(key >= 3);
+      if (own != 0ull) {
+        const int x0 = __ffsll((long long)valid) - 1, nv = __popcll(valid);
+        if ((valid >> x0) == (nv == 64 ? ~0ull : (1ull << nv) - 1ull)) own >>= x0;
+        else {
+          unsigned long long m = 0ull, va = valid;
+          int col = 0;
+          while (va != 0ull) { const int l = __ffsll((long long)va) - 1; va &= va - 1ull; if ((own >> l) & 1ull) m |= 1ull << col; ++col; }
+          own = m;
         }
       }
-      if (key >= 0) atomicOr(&mk[key], 1ull << lane);
-      const unsigned long long own = __ballot(owned);
       win_wave_sync();
+      MVUS_WTP(1);     // evaluation + staging
       unsigned long long mym = 0ull;
-      if (role) { mym = mk[j]; if (d == 0) mk[j] = 0ull; }   // (the three lanes of a span read before lane d = 0 clears: LDS is in order)
+      if (role) { mym = mk[mslot]; if (d == 0) mk[mslot] = 0ull; }   // (the three lanes of a slot read before lane d = 0 clears: LDS is in order)
+#if defined(MVUS_WIN_STOP) && MVUS_WIN_STOP == 1
+      mym = 0ull;                                           // timing probe: evaluation + staging only
+#endif
       // ---- camera block of the owned detections on the matrix cores: two independent accumulation chains (x rows, y rows) ----
+#if defined(MVUS_WIN_STOP) && (MVUS_WIN_STOP == 1 || MVUS_WIN_STOP == 3)
+      if (false) {
+#else
       if (own != 0ull) {
+#endif
         const int lr = lane & 15, lk = lane >> 4;
-#pragma unroll 4
-        for (int kk = 0; kk < 16; ++kk) {
-          const int u = 4 * kk + lk;
-          const bool on = (own >> u) & 1ull;
+        int srcs[2][TI];
+        bool rowok[TI];
 #pragma unroll
-          for (int xy = 0; xy < 2; ++xy) {
-            double av[TI];
+        for (int i = 0; i < TI; ++i) {
+          const int row = 16 * i + lr;
+          rowok[i] = row <= B;
 #pragma unroll
-            for (int i = 0; i < TI; ++i) {
-              const int row = 16 * i + lr;
-              const int src = row < B ? 10 + xy * B + row : kFx + xy;
-              const double v = S[src * kWinStr + u];
-              av[i] = (on && row <= B) ? v : 0.0;
-            }
+          for (int xy = 0; xy < 2; ++xy) srcs[xy][i] = (row < B ? 10 + xy * B + row : kFx + xy) * kWinStr + lk;
+        }
+        double nv[2][TI];                                   // operands of the next step: in flight over this step's matrix instructions
+        const int k_lo = (__ffsll((long long)own) - 1) >> 2, k_hi = ((63 - __clzll((long long)own)) >> 2) + 1;   // steps of four columns that hold owned ones
+#pragma unroll
+        for (int xy = 0; xy < 2; ++xy)
+#pragma unroll
+          for (int i = 0; i < TI; ++i) nv[xy][i] = S[srcs[xy][i] + 4 * k_lo];
+        for (int kk = k_lo; kk < k_hi; ++kk) {
+          const bool on = (own >> (4 * kk + lk)) & 1ull;
+          double av[2][TI];
+#pragma unroll
+          for (int xy = 0; xy < 2; ++xy)
+#pragma unroll
+            for (int i = 0; i < TI; ++i) av[xy][i] = (on && rowok[i]) ? nv[xy][i] : 0.0;
+          if (kk + 1 < k_hi) {
+#pragma unroll
+            for (int xy = 0; xy < 2; ++xy)
+#pragma unroll
+              for (int i = 0; i < TI; ++i) nv[xy][i] = S[srcs[xy][i] + 4 * (kk + 1)];
+          }
+#pragma unroll
+          for (int xy = 0; xy < 2; ++xy)
 #pragma unroll
             for (int i = 0; i < TI; ++i)
 #pragma unroll
-              for (int jj = 0; jj <= i; ++jj) cacc[xy][i][jj] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], av[jj], cacc[xy][i][jj], 0, 0, 0);
-          }
+              for (int jj = 0; jj <= i; ++jj) cacc[xy][i][jj] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[xy][i], av[xy][jj], cacc[xy][i][jj], 0, 0, 0);
         }
       }
-      // ---- accumulate: lane = (span j, coordinate d) ----
+      MVUS_WTP(2);     // camera block on the matrix cores
+      // ---- accumulate: lane = (span j, piece s, coordinate d); the cross-block sums of THIS batch (flushed below) ----
+#if defined(MVUS_WIN_STOP) && MVUS_WIN_STOP == 2
+      mym = 0ull;                                           // timing probe: no accumulation
+#endif
+      double E[4][B];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int k = 0; k < B; ++k) E[q][k] = 0.0;
       while (mym != 0ull) {
         const int u = __ffsll((long long)mym) - 1;
         mym &= mym - 1ull;
@@ -246,26 +380,34 @@ __global__ __launch_bounds__(kWinThreads) void k_assemble_windows(DevProblem dp,
             for (int d2 = 0; d2 < 3; ++d2) MVUS_WCA(qa, w, d2) += bb * mm[d2];
           }
       }
-      win_wave_sync();                                      // the staging region is rewritten by the next batch
-    }
-
-    // ---- the camera's block of Et: spans j = pl + 3 - q, q = 0..3, reach the owned control point pl; added in that order ----
-    constexpr int PS = kWinMaxW * 3 * B;
-    if (role) {
+      MVUS_WTP(3);     // accumulation
+      // ---- the batch's part of the camera's block of Et: spans j = pl + 3 - q, q = 0..3 (and their pieces) reach the owned control
+      //      point pl; the lane of span pl + 3, piece 0 collects them in (q, piece) order with lane shuffles (no trip through
+      //      memory), adds the earlier batches' sum (the wavefront's accumulator: the lane's own nine entries) and the last batch
+      //      stores the row ----
+      {
+        const bool owner = role && s == 0 && j >= 3;        // row (pl, d) = (j - 3, d)
+        const int orow = ((j - 3) * 3 + d) * B;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int pl = j + q - 3;
-        if (pl >= 0 && pl < nown) {
+        for (int k = 0; k < B; ++k) {
+          double acc = (owner && !first) ? Eacc[orow + k] : 0.0;
 #pragma unroll
-          for (int k = 0; k < B; ++k) S[q * PS + (pl * 3 + d) * B + k] = E[q][k];
+          for (int q = 0; q < 4; ++q)
+            for (int sp = 0; sp < SP; ++sp) {
+              const int src = ((j - q) * SP + sp) * 3 + d;
+              acc += __shfl(E[q][k], src & 63, 64);
+            }
+          if (owner) { if (last) er[orow + k] = acc; else Eacc[orow + k] = acc; }
         }
       }
+      win_wave_sync();                                      // the staging region is rewritten by the next batch
+      MVUS_WTP(4);     // E flush
+#ifdef MVUS_WIN_PROBE
+      ++nbatch;
+#endif
+      cur = nxt;
     }
-    win_wave_sync();
-    {
-      double* er = ne.Et + ((long long)c * ne.N3 + 3 * a) * B;
-      for (int o = lane; o < nown * 3 * B; o += 64) er[o] = ((S[o] + S[PS + o]) + S[2 * PS + o]) + S[3 * PS + o];
-    }
+
     // the camera block's partial (C/D layout of the 16x16 tile: row = (lane >> 4) + 4 reg, column = lane & 15)
     {
       double* mine = wv.Apart + ((long long)win * dp.C + c) * PSZ;
@@ -281,11 +423,17 @@ __global__ __launch_bounds__(kWinThreads) void k_assemble_windows(DevProblem dp,
             mine[ra * (ra + 1) / 2 + rb] = cacc[0][i][jj][r] + cacc[1][i][jj][r];
           }
     }
-    win_wave_sync();                                        // the flush region becomes the next camera's staging region
+    p0 = np0; p1 = np1;
   }
 
-  // ---- band and gradient: overlap-add of the spans, then of the four wavefronts, one fixed order ----
-  constexpr int CP = kWinMaxW * 9, GP0 = 10 * CP, GP = kWinMaxW * 3;
+  MVUS_WTP(5);
+#ifdef MVUS_WIN_PROBE
+  if ((blockIdx.x % 97) == 5 && lane == 0)
+    printf("win %d wave %d ncam %d batches %d: total %lld | per batch: setup %lld eval %lld mfma %lld accum %lld eflush %lld | tail %lld\n", win, wave, ncam, nbatch,
+           clock64() - tstart, tpa[0] / max(nbatch, 1), tpa[1] / max(nbatch, 1), tpa[2] / max(nbatch, 1), tpa[3] / max(nbatch, 1), tpa[4] / max(nbatch, 1), tpa[5]);
+#endif
+  // ---- band and gradient: overlap-add of the spans and pieces, then of the four wavefronts, one fixed order ----
+  const int CP = nown * 9, GP = nown * 3, GP0 = 10 * SP * CP;
   if (role) {
 #pragma unroll
     for (int qa = 0; qa < 4; ++qa) {
@@ -294,8 +442,8 @@ __global__ __launch_bounds__(kWinThreads) void k_assemble_windows(DevProblem dp,
 #pragma unroll
         for (int w = 0; qa + w < 4; ++w)
 #pragma unroll
-          for (int d2 = 0; d2 < 3; ++d2) S[(4 * qa - qa * (qa - 1) / 2 + w) * CP + pl * 9 + 3 * d + d2] = MVUS_WCA(qa, w, d2);
-        S[GP0 + qa * GP + pl * 3 + d] = gq[qa];
+          for (int d2 = 0; d2 < 3; ++d2) S[((4 * qa - qa * (qa - 1) / 2 + w) * SP + s) * CP + pl * 9 + 3 * d + d2] = MVUS_WCA(qa, w, d2);
+        S[GP0 + (qa * SP + s) * GP + pl * 3 + d] = gq[qa];
       }
     }
   }
@@ -307,17 +455,20 @@ __global__ __launch_bounds__(kWinThreads) void k_assemble_windows(DevProblem dp,
     double acc = 0.0;
     if (r < 3) {
       for (int v = 0; v < kWinWaves; ++v) {
-        const double* Sv = win_lds + v * REG + GP0 + pl * 3 + r;
-        acc += ((Sv[0] + Sv[GP]) + Sv[2 * GP]) + Sv[3 * GP];
+        const double* Sv = win_lds + v * WAVE + GP0 + pl * 3 + r;
+        double t = 0.0;
+        for (int qs = 0; qs < 4 * SP; ++qs) t += Sv[qs * GP];
+        acc += t;
       }
       ne.gs[3 * (a + pl) + r] = acc;
     } else {
       const int w = (r - 3) / 9, dd = (r - 3) - 9 * w;
       if (w < 4) {
         for (int v = 0; v < kWinWaves; ++v) {
-          const double* Sv = win_lds + v * REG + pl * 9 + dd;
+          const double* Sv = win_lds + v * WAVE + pl * 9 + dd;
           double t = 0.0;
-          for (int qa = 0; qa + w < 4; ++qa) t += Sv[(4 * qa - qa * (qa - 1) / 2 + w) * CP];
+          for (int qa = 0; qa + w < 4; ++qa)
+            for (int sp = 0; sp < SP; ++sp) t += Sv[((4 * qa - qa * (qa - 1) / 2 + w) * SP + sp) * CP];
           acc += t;
         }
       }

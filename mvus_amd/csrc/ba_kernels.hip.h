@@ -244,6 +244,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(JAC ? 
         const ObsResult r = eval_observation_to<CALIB, false>(cam, dp.sp, x, dp.undist != 0, dp.rs_free != 0, dp.sync_free != 0, dp.frame[i], ur, dp.v_raw[i], uo, vo, sink);
         f[2 * a + (i - a)] = r.ex;
         f[2 * a + Mc + (i - a)] = r.ey;
+        if (span != nullptr) span[i] = r.ctrl;           // (residual-only launches: the span table the fused assembly starts from)
         sq = r.ex * r.ex + r.ey * r.ey;
       }
       sq = wave_sum(sq);
@@ -271,6 +272,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(JAC ? 
   f[2 * a + (i - a)] = r.ex;
   f[2 * a + Mc + (i - a)] = r.ey;
   if (JAC) span[i] = (r.ctrl >= 0 && sink.live) ? r.ctrl : -1;
+  else if (span != nullptr) span[i] = r.ctrl;
 #else
   double jx[NS], jy[NS];
   ObsResult r = eval_observation<CALIB, JAC>(cam, dp.sp, x, dp.undist != 0, dp.rs_free != 0, dp.sync_free != 0, dp.frame[i], ur, dp.v_raw[i],

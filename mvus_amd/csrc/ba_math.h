@@ -338,13 +338,22 @@ struct ObsResult {
 //   jx/jy : NS values each (see slot layout above); untouched when the observation is not visible.
 //   u_obs/v_obs: observed pixel when calibration is fixed (undistorted once at create time).
 template <bool CALIB, bool JAC, class Sink>
+MVUS_HD ObsResult eval_observation_at(const CamState& cam, double tau, const SpanLoc& loc, bool undist, bool rs_free, bool sync_free,
+                                      double frame, double u_raw, double v_raw, double u_obs, double v_obs, Sink& sink);
+template <bool CALIB, bool JAC, class Sink>
 MVUS_HD ObsResult eval_observation_to(const CamState& cam, const SplineView& sp, const double* x, bool undist, bool rs_free, bool sync_free,
+                                      double frame, double u_raw, double v_raw, double u_obs, double v_obs, Sink& sink) {
+  const double tau = cam.alpha * (frame + cam.rs * v_raw / cam.H) + cam.beta;
+  SpanLoc loc;
+  if (!locate_span(sp, x, tau, loc)) { ObsResult out; out.ex = 0.0; out.ey = 0.0; out.ctrl = -1; return out; }
+  return eval_observation_at<CALIB, JAC>(cam, tau, loc, undist, rs_free, sync_free, frame, u_raw, v_raw, u_obs, v_obs, sink);
+}
+// the same observation once its knot span is known (loc: the six knots, the twelve coefficients, the first control point)
+template <bool CALIB, bool JAC, class Sink>
+MVUS_HD ObsResult eval_observation_at(const CamState& cam, double tau, const SpanLoc& loc, bool undist, bool rs_free, bool sync_free,
                                       double frame, double u_raw, double v_raw, double u_obs, double v_obs, Sink& sink) {
   ObsResult out;
   out.ex = 0.0; out.ey = 0.0; out.ctrl = -1;
-  const double tau = cam.alpha * (frame + cam.rs * v_raw / cam.H) + cam.beta;
-  SpanLoc loc;
-  if (!locate_span(sp, x, tau, loc)) return out;
   double h[4], dh[4];
   bspline_basis_w<JAC>(loc.tt, tau, h, dh);
   double X[3] = {0.0, 0.0, 0.0}, Xd[3] = {0.0, 0.0, 0.0};

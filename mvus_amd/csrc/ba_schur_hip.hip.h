@@ -2251,18 +2251,36 @@ struct HipSchur {
   // Wn + 3 spans that reach a window hold (Wn + 3) * M / (C * N) detections on average -- within [4, 16] control points.
   void win_prepare() {
     const HostProblem& hp = be.hp;
-    use_win = hp.frames_sorted && hp.M > 0 && ne.N > 0 && !std::getenv("MVUS_ASM_ATOMIC");
+    use_win = hp.frames_sorted && hp.M > 0 && ne.N > 0 && hp.C <= 64 * kWinWaves && !std::getenv("MVUS_ASM_ATOMIC");
     if (!use_win) return;
-    const double rho = (double)hp.M / ((double)hp.C * std::max(1, hp.N));
-    int Wn = (int)std::lround(56.0 / std::max(rho, 1e-9)) - 3;
-    Wn = std::min(16, std::max(4, Wn));
+    // window length: (Wn + 3) spans of the densest camera should fill most of one 64-detection batch (a 65th detection costs a whole
+    // second batch), and the workgroups should come in whole rounds of two per CU
+    double rho = 0.0;
+    for (int c = 0; c < hp.C; ++c) rho = std::max(rho, (double)(hp.det_off[c + 1] - hp.det_off[c]) / std::max(1, hp.N));
+    int Wn = (int)std::floor(52.0 / std::max(rho, 1e-9)) - 3;
+    Wn = std::min(kWinMaxW, std::max(4, Wn));
+    {
+      int ncu = 256;
+      hipDeviceProp_t prop;
+      if (hipGetDeviceProperties(&prop, be.device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
+      const int slots = 2 * ncu;
+      const int rounds = ((ne.N + Wn - 1) / Wn + slots - 1) / slots;          // keep the number of rounds, use its slots: the shortest window that does
+      while (Wn > 4 && ((ne.N + (Wn - 1) - 1) / (Wn - 1) + slots - 1) / slots == rounds) --Wn;
+    }
     if (const char* e = std::getenv("MVUS_WIN")) Wn = std::min(kWinMaxW, std::max(1, std::atoi(e)));
     if (hp.calib) Wn = std::min(Wn, 12);
     wv.Wn = Wn; wv.nwin = (ne.N + Wn - 1) / Wn; wv.Ntot = hp.N;
     const size_t psz = (size_t)(ne.B + 1) * (ne.B + 2) / 2;
     wv.Apart = be.alloc((size_t)wv.nwin * ne.C * psz);
-    const size_t bytes_cw = sizeof(CamWin) * (size_t)hp.C, bytes_t = sizeof(double) * ((size_t)hp.N + 1), bytes_l = sizeof(int32_t) * (size_t)hp.flut_len;
-    MVUS_HIP(hipMalloc(&win_tables, bytes_cw + 2 * bytes_t + bytes_l));
+    const size_t bytes_cw = sizeof(CamWin) * (size_t)hp.C, bytes_t = sizeof(double) * ((size_t)hp.N + 1), bytes_l = sizeof(int32_t) * (((size_t)hp.flut_len + 3) & ~(size_t)3);
+    const size_t bytes_r = sizeof(int4) * (size_t)std::max(1, hp.N);
+    MVUS_HIP(hipMalloc(&win_tables, bytes_cw + 2 * bytes_t + bytes_l + bytes_r));
+    std::vector<int4> crec((size_t)std::max(1, hp.N), int4{0, 0, 0, 0});
+    for (int sI = 0; sI < hp.S; ++sI) {
+      const int ns = hp.ctrl_off[sI + 1] - hp.ctrl_off[sI];
+      for (int jj = 0; jj < ns; ++jj)        // span l = jj + 3: knots t[l-2 .. l+3] start at knot_off + jj + 1
+        crec[(size_t)hp.ctrl_off[sI] + jj] = int4{hp.xoff[sI] + jj, ns, hp.knot_off[sI] + jj + 1, (jj == 0 ? 1 : 0) | (jj + 4 == ns ? 2 : 0) | (jj + 4 > ns ? 4 : 0)};
+    }
     char* base = static_cast<char*>(win_tables);
     MVUS_HIP(hipMemcpyAsync(base, hp.cam_win.data(), bytes_cw, hipMemcpyHostToDevice, be.stream));
     MVUS_HIP(hipMemcpyAsync(base + bytes_cw, hp.win_tlo.data(), bytes_t, hipMemcpyHostToDevice, be.stream));
@@ -2272,10 +2290,12 @@ struct HipSchur {
     wv.thi = reinterpret_cast<const double*>(base + bytes_cw + bytes_t);
     int32_t* flut = reinterpret_cast<int32_t*>(base + bytes_cw + 2 * bytes_t);
     wv.flut = flut;
+    MVUS_HIP(hipMemcpyAsync(base + bytes_cw + 2 * bytes_t + bytes_l, crec.data(), bytes_r, hipMemcpyHostToDevice, be.stream));   // (synchronised below: crec outlives the copy)
+    wv.crec = reinterpret_cast<const int4*>(base + bytes_cw + 2 * bytes_t + bytes_l);
     hipLaunchKernelGGL(k_frame_lut, dim3((unsigned)((hp.flut_len + 255) / 256)), dim3(256), 0, be.stream, be.dp, wv.cw, flut, (long long)hp.flut_len);
     MVUS_HIP(hipGetLastError());
     MVUS_HIP(hipStreamSynchronize(be.stream));
-    win_lds = ((size_t)kWinWaves * win_region_doubles(ne.B)) * sizeof(double) + (size_t)kWinWaves * 24 * sizeof(unsigned long long);
+    win_lds = (size_t)win_lds_doubles(ne.B) * sizeof(double);
     if (hp.calib) MVUS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_assemble_windows<18>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)win_lds));
     else MVUS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_assemble_windows<9>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)win_lds));
   }
@@ -2334,10 +2354,17 @@ struct HipSchur {
       hipLaunchKernelGGL(k_assemble_motion, dim3((be.hp.T + kThreads - 1) / kThreads), dim3(kThreads), 0, be.stream, be.dp, be.mJ, be.mctrl,
                          f_dev + 2 * be.hp.M, ne);
   }
-  void assemble_local(const double* f_dev, const double* x_fused = nullptr) {
+  void assemble_local(const double* f_dev, const double* x_fused = nullptr, const int32_t* span_held = nullptr) {
     if (x_fused && use_win) {
-      // window-major: every entry of A, gc, Cb, gs, Et is written by exactly one thread -- no clearing pass, no atomics
+      // window-major: every entry of A, gc, Cb, gs, Et is written by exactly one thread -- no clearing pass, no atomics.
+      // It starts from the knot span of every detection at x: left behind by the residual evaluation at x that precedes every
+      // linearisation (else evaluated now), or the held analytic Jacobian's own table
       ne_cleared = false; ne.det = 0; last_det = false;
+      if (span_held) wv.span = span_held;
+      else {
+        if (be.rspan_for != x_fused) be.residual(x_fused, const_cast<double*>(f_dev));      // (f_dev holds f(x) already: the same values again)
+        wv.span = be.rspan;
+      }
       be.ensure_cams(x_fused);
       if (be.hp.calib) {
         hipLaunchKernelGGL(k_assemble_windows<18>, dim3(wv.nwin), dim3(kWinThreads), win_lds, be.stream, be.dp, ne, wv, be.cams, x_fused);
@@ -2390,8 +2417,8 @@ struct HipSchur {
     be.has_jacobian = false;                               // no materialised J belongs to this point
     assemble(be, f_dev, x_dev);
   }
-  void assemble(BE&, const double* f_dev, const double* x_fused = nullptr) {
-    assemble_local(f_dev, x_fused);
+  void assemble(BE&, const double* f_dev, const double* x_fused = nullptr, const int32_t* span_held = nullptr) {
+    assemble_local(f_dev, x_fused, span_held);
     const int tot = ne.CB + ne.N3;          // every entry of x is a camera column or a control-point coordinate
     if (shard) {
       // time shard: sum the camera blocks and the blocks of the control points near a cut; the cross block never moves
@@ -2415,7 +2442,7 @@ struct HipSchur {
   // (the LM path's kernel; MVUS_NE_FROM_J=1 forms them from the stored blocks instead), anything else is assembled from J
   void assemble_held(BE&) {
     const bool fused = be.held_analytic_at_xcur && use_win && !std::getenv("MVUS_NE_FROM_J");
-    assemble(be, be.f_cur, fused ? be.x_cur : nullptr);
+    assemble(be, be.f_cur, fused ? be.x_cur : nullptr, fused ? be.span : nullptr);
   }
 
   void flush_diag() {
@@ -2430,6 +2457,7 @@ struct HipSchur {
   const double* step_ptr() const { return px; }
   const int* fail_ptr() const { return fail; }
   bool solve_ok() const {                 // valid after the stream has been synchronised (the driver's fetch)
+    if (fail_host[1] & 2) throw HipError{"fused assembly: the span table does not belong to the point being linearised (internal error)"};
     if (fail_host[1] != 0) throw HipError{"time shard: a detection or motion row reaches control points outside this rank's slice (halo too small for the time-stamp drift)"};
     if (fail_host[0] != 0 && std::getenv("MVUS_DEBUG")) std::fprintf(stderr, "schur solve: fail code %d\n", fail_host[0]);
     return fail_host[0] == 0;
