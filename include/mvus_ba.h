@@ -171,15 +171,15 @@ int mvus_ba_motion_pattern(mvus_ba* h, int32_t* motion_pat_out);
  * the next mvus_ba_set_pattern or mvus_ba_remove_outliers.  Column groups for MVUS_JAC_FD must be set afterwards. */
 int mvus_ba_upload_pattern(mvus_ba* h, const int32_t* pat, const int32_t* motion_pat);
 
-/* MVUS_SOLVER_LM_SCHUR, one rank: on != 0 assembles the normal equations without floating-point atomics -- every assembly
- * workgroup leaves its sums in a window of its own and a gather adds the windows in a fixed order -- so that a solve gives the
- * same bits on every run (the default adds with fp64 atomics: last-bit differences from run to run; 7-14 % faster).  The
- * environment variable MVUS_DET_ASSEMBLY=1 does the same for every handle.  No counterpart in the reference (scipy is
- * deterministic; this restores that property for the opt-in LM solver).  Ignored on a time shard. */
+/* MVUS_SOLVER_LM_SCHUR.  The normal equations of the analytic Jacobian are assembled window-major (ba_assemble_win.hip.h): every
+ * entry has one writer and one order of additions, no floating-point atomics -- a solve gives the same bits on every run, on one
+ * rank and on every rank of a sharded run (the sums over the ranks are the collective's).  This call is kept for the ABI and
+ * changes nothing (round 3 had an opt-in deterministic mode beside an atomic default).  No counterpart in the reference (scipy is
+ * deterministic; the LM solver keeps that property). */
 int mvus_ba_set_deterministic(mvus_ba* h, int32_t on);
-/* *fell_back = 1 when some workgroup of the handle's LAST deterministic assembly had to keep the atomic path (its 128 consecutive
- * detections of one camera spread over more than 64 control points, or over more than ~170 knot-span pieces): the result is
- * correct, but not guaranteed to repeat bit for bit.  0 otherwise (and when no deterministic assembly has run). */
+/* *fell_back = 1 when the handle's LAST assembly went through the detection-major kernel, which adds with fp64 atomics (last-bit
+ * differences from run to run): a camera whose frames are not in non-decreasing order, more than 256 cameras, or normal equations
+ * formed from a stored Jacobian that is not the analytic one (pattern-masked, finite differences).  0 otherwise. */
 int mvus_ba_deterministic_fallback(mvus_ba* h, int32_t* fell_back);
 
 /* Column groups for MVUS_JAC_FD: groups[n] in [0, num_groups), two columns share a group only if no row of the

@@ -121,11 +121,13 @@ class BAHandle:
                                                     mp.ctypes.data_as(_lib.c_int32_p) if mp is not None else None), 'mvus_ba_upload_pattern')
 
     def set_deterministic(self, on=True):
-        """LM + Schur without floating-point atomics in the assembly: the same bits on every run (7-14 % slower)."""
+        """Kept for the ABI: the LM + Schur assembly is window-major (one writer and one order per entry, no atomics) -- the same
+        bits on every run whatever is set here."""
         self._check(self.lib.mvus_ba_set_deterministic(self.h, 1 if on else 0), 'mvus_ba_set_deterministic')
 
     def deterministic_fallback(self):
-        """True when the last deterministic assembly kept the atomic path somewhere (very sparse tracks): correct, not bit-reproducible."""
+        """True when the last assembly went through the detection-major kernel with fp64 atomics (frames of a camera out of order,
+        or normal equations formed from a stored non-analytic Jacobian): correct, not bit-reproducible."""
         v = ctypes.c_int32(0)
         self._check(self.lib.mvus_ba_deterministic_fallback(self.h, ctypes.byref(v)), 'mvus_ba_deterministic_fallback')
         return bool(v.value)

@@ -41,7 +41,7 @@ struct HipBackend {
   const double* rspan_for = nullptr;
   bool has_pattern = false, has_jacobian = false;
   bool held_analytic_at_xcur = false; // the held Jacobian is the analytic one of x_cur (mvus_ba_residual_jacobian): its normal equations can be formed by the fused window-major assembly
-  bool det_assembly = false;          // mvus_ba_set_deterministic: the LM normal equations without fp64 atomics (ba_schur_hip.hip.h)
+  bool det_assembly = false;          // mvus_ba_set_deterministic (kept for the ABI: the window-major assembly is deterministic by construction)
   bool pattern_uploaded = false;     // the caller supplied the reference's pattern (mvus_ba_upload_pattern): solve keeps it
   int32_t* ms_pat_dev = nullptr;
   double* det_alt[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // second set of detection arrays (remove_outliers ping-pong)
@@ -863,7 +863,7 @@ int mvus_ba_set_deterministic(mvus_ba* h, int32_t on) {
 int mvus_ba_deterministic_fallback(mvus_ba* h, int32_t* fell_back) {
   return guarded(h, [&] {
     if (!fell_back) { h->be.err = "bad arguments"; return MVUS_E_INVALID; }
-    *fell_back = h->schur ? (h->schur->det_fallbacks() != 0 ? 1 : 0) : 0;
+    *fell_back = (h->schur && h->schur->last_atomic) ? 1 : 0;
     return MVUS_OK;
   });
 }

@@ -39,7 +39,7 @@ namespace mvus {
 
 constexpr int kWinWaves = 4, kWinThreads = 64 * kWinWaves;
 constexpr int kWinStr = 65;                     // staging row stride (odd: the matrix-core fragment reads walk the rows)
-constexpr int kWinMaxW = 16, kWinMaxJ = kWinMaxW + 3;      // 3 * (Wn + 3) lane roles must fit a wavefront (and two workgroups the LDS of a CU)
+constexpr int kWinMaxW = 21, kWinMaxJ = kWinMaxW + 3;      // 3 * Wn output rows (one lane each) must fit a wavefront
 constexpr int kWinSpl = 18;                                 // doubles of one span's record in LDS: six knots, 3 x 4 coefficients
 
 struct WinView {
@@ -48,6 +48,7 @@ struct WinView {
   const double* tlo;         // [Ntot + 1] by GLOBAL control point: <= every visible time stamp whose first control point is >= p
   const double* thi;         // [Ntot + 1]: >= every visible time stamp whose first control point is < p
   double* Apart;             // [nwin][C][(B+1)(B+2)/2] lower triangle of [camera slots; f][..]^T per (window, camera)
+  const int32_t* cam_perm;   // [C] the order in which the cameras are dealt to the four wavefronts (balanced by detection count)
   const int32_t* span;       // [M] first control point (global) of every detection at the x being linearised, -1 = not visible
   const int4* crec;          // [Ntot] per control point g as a FIRST control point: {x index of coordinate 0, coefficients of its spline
                              //        (stride between coordinates), index of knot t[l-2] of its span, 1: first span | 2: last span of the interval}
@@ -56,7 +57,7 @@ struct WinView {
 };
 
 constexpr __host__ __device__ int win_region_doubles(int B) {       // LDS doubles per wavefront: staging, reused by the flushes
-  const int stage = (12 + 2 * B) * kWinStr, eflush = 4 * kWinMaxW * 3 * B, cflush = kWinMaxW * (10 * 9 + 4 * 3);
+  const int stage = (15 + 2 * B) * kWinStr, eflush = kWinMaxW * 3 * B, cflush = kWinMaxW * 3 * 13;
   return stage > eflush ? (stage > cflush ? stage : cflush) : (eflush > cflush ? eflush : cflush);
 }
 
@@ -81,18 +82,25 @@ __global__ void k_frame_lut(DevProblem dp, const CamWin* __restrict__ cw, int32_
   flut[e] = first;
 }
 
+// staged rows of one detection (column u of the wavefront's region, row stride kWinStr):
+//   gu[3] gv[3] | Jx[B] Jy[B] | fx fy | h[4] | three rows of zeros (h[q + w] with q + w > 3: "no such control point")
+template <int B>
+struct WinRows {
+  static constexpr int kGu = 0, kGv = 3, kJx = 6, kJy = 6 + B, kFx = 6 + 2 * B, kFy = 7 + 2 * B, kH = 8 + 2 * B, kZero = 12 + 2 * B, kRows = 15 + 2 * B;
+};
 template <int B>
 struct WinSink {             // eval_observation_to sink of the window-major assembly: camera slots as they come, the spline slots factored
   static constexpr bool kFactored = true;
-  double* col;               // staging region + lane
+  using R = WinRows<B>;
+  double* col;               // staging region + column
   __device__ __forceinline__ void begin(int32_t) {}
-  __device__ __forceinline__ void x(int k, double v) { if (k < B) col[(10 + k) * kWinStr] = v; }
-  __device__ __forceinline__ void y(int k, double v) { if (k < B) col[(10 + B + k) * kWinStr] = v; }
+  __device__ __forceinline__ void x(int k, double v) { if (k < B) col[(R::kJx + k) * kWinStr] = v; }
+  __device__ __forceinline__ void y(int k, double v) { if (k < B) col[(R::kJy + k) * kWinStr] = v; }
   __device__ __forceinline__ void factored(const double h[4], double gu0, double gu1, double gu2, double gv0, double gv1, double gv2) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) col[q * kWinStr] = h[q];
-    col[4 * kWinStr] = gu0; col[5 * kWinStr] = gu1; col[6 * kWinStr] = gu2;
-    col[7 * kWinStr] = gv0; col[8 * kWinStr] = gv1; col[9 * kWinStr] = gv2;
+    for (int q = 0; q < 4; ++q) col[(R::kH + q) * kWinStr] = h[q];
+    col[(R::kGu + 0) * kWinStr] = gu0; col[(R::kGu + 1) * kWinStr] = gu1; col[(R::kGu + 2) * kWinStr] = gu2;
+    col[(R::kGv + 0) * kWinStr] = gv0; col[(R::kGv + 1) * kWinStr] = gv1; col[(R::kGv + 2) * kWinStr] = gv2;
   }
 };
 
@@ -102,46 +110,44 @@ __device__ __forceinline__ void win_wave_sync() {      // orders the LDS traffic
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
 }
 
-#ifndef MVUS_WIN_MFMA_UNROLL
-#define MVUS_WIN_MFMA_UNROLL 4
-#endif
 #ifndef MVUS_WIN_WAVES_PER_EU
 #define MVUS_WIN_WAVES_PER_EU 2
 #endif
-MVUS_HD int win_pieces(int Wn) { return 21 / (Wn + 3); }      // pieces a span's detections are dealt into (dense tracks, short windows)
-constexpr __host__ __device__ int win_wave_doubles(int B) { return win_region_doubles(B) + kWinMaxW * 3 * B + 24; }   // + E accumulator + span masks
+MVUS_HD int win_pieces(int Wn) { const int a = 21 / Wn, b = 32 / (Wn + 3); return a < b ? a : b; }          // lanes per output row: a span's detections are dealt to them in turn (dense tracks, short windows)
+constexpr __host__ __device__ int win_wave_doubles(int B) { return win_region_doubles(B) + 32; }   // staging / flush region + span masks
 constexpr __host__ __device__ int win_lds_doubles(int B) { return kWinWaves * win_wave_doubles(B) + kWinMaxJ * kWinSpl; }   // + the window's span records
 
 template <int B>
 __global__ __launch_bounds__(kWinThreads) __attribute__((amdgpu_waves_per_eu(B == 9 ? MVUS_WIN_WAVES_PER_EU : 1, B == 9 ? MVUS_WIN_WAVES_PER_EU : 1)))
 void k_assemble_windows(DevProblem dp, NEView ne, WinView wv, const CamState* __restrict__ cams, const double* __restrict__ x) {
   constexpr bool CALIB = B == 18;
-  constexpr int NV = 12 + 2 * B;                            // staged values per detection: h[4] gu[3] gv[3] Jx[B] Jy[B] fx fy
-  constexpr int kFx = 10 + 2 * B, kFy = 11 + 2 * B;
+  using R = WinRows<B>;
+  constexpr int NV = R::kRows;
+  constexpr int kFx = R::kFx, kFy = R::kFy;
   constexpr int PSZ = (B + 1) * (B + 2) / 2, TI = (B + 1 + 15) / 16;
   constexpr int REG = win_region_doubles(B), WAVE = win_wave_doubles(B);
   static_assert(NV * kWinStr <= REG, "staging fits the region");
-  extern __shared__ double win_lds[];                       // per wavefront: [REG] staging / flush region, [kWinMaxW * 3 * B] E accumulator, [24] masks
+  extern __shared__ double win_lds[];                       // per wavefront: [REG] staging / flush region, [32] masks; then the window's span records
   using d4v = __attribute__((ext_vector_type(4))) double;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   double* S = win_lds + wave * WAVE;
-  double* Eacc = S + REG;
-  unsigned long long* mk = reinterpret_cast<unsigned long long*>(Eacc + kWinMaxW * 3 * B);
+  unsigned long long* mk = reinterpret_cast<unsigned long long*>(S + REG);
   double* spl = win_lds + kWinWaves * WAVE;                 // [NJ][18]: knots t[l-2 .. l+3] and coefficients (x, y, z) x 4 of every span of the window
   const int win = blockIdx.x;
   const int a = win * wv.Wn;                                // first owned control point (local to the handle's slice)
   const int nown = min(wv.Wn, ne.N - a), NJ = nown + 3;     // spans a - 3 .. a + nown - 1 reach the window
-  const int SP = win_pieces(wv.Wn);                         // lane = (span j, piece s, coordinate d)
-  const int j = lane / (3 * SP), s = (lane / 3) % SP, d = lane % 3;
-  const bool role = j < NJ;
-  const int mslot = j * SP + s;
+  const int SP = win_pieces(wv.Wn);                         // lane = (control point pl, coordinate d, piece s): an output ROW and a share of its detections (SP <= 5)
+  const int s = lane % SP, pl = (lane / SP) / 3, d = (lane / SP) % 3;
+  const bool role = pl < nown;
   // the window's time range; the first / last window of a time shard's slice also sees what lies beyond the slice (and flags it)
   const double inf = INFINITY;
   const int ga = a + ne.row0;
   const double T0 = (win == 0 && ne.row0 > 0) ? -inf : wv.tlo[max(ga - 3, 0)];
   const double T1 = (win == wv.nwin - 1 && ne.row0 + ne.N < wv.Ntot) ? inf : wv.thi[ga + nown];
-  if (lane < 24) mk[lane] = 0ull;
+  if (lane < 32) mk[lane] = 0ull;
+#pragma unroll
+  for (int t = 0; t < 3; ++t) S[(R::kZero + t) * kWinStr + lane] = 0.0;      // (columns 0..63; never written again)
   // the window's spline data, once per workgroup: every evaluation below reads knots and coefficients from LDS (no dependent global
   // loads on the per-detection path); a control point that cannot start a span (the last three of an interval) leaves zeros
   for (int e = threadIdx.x; e < NJ * kWinSpl; e += kWinThreads) {
@@ -163,7 +169,7 @@ void k_assemble_windows(DevProblem dp, NEView ne, WinView wv, const CamState* __
   const int ncam = (dp.C - wave + kWinWaves - 1) / kWinWaves;       // cameras of this wavefront: <= 64 (the reduced camera system limits C * B to 1152)
   int p0v = 0, p1v = 0;
   if (lane < ncam) {
-    const int c = wave + kWinWaves * lane;
+    const int c = wv.cam_perm[wave + kWinWaves * lane];
     const CamState* cs = cams + c;
     const CamWin cw = wv.cw[c];
     const double alpha = cs->alpha, beta = cs->beta, rs = cs->rs, H = cs->H;
@@ -183,15 +189,14 @@ void k_assemble_windows(DevProblem dp, NEView ne, WinView wv, const CamState* __
     p0 = __builtin_amdgcn_readlane(p0v, i); p1 = __builtin_amdgcn_readlane(p1v, i);
   };
 
-  double CA[30], gq[4];                                    // band blocks (pair (qa, w), column d2), gradient: across the camera walk
+  // this lane's row of the band (blocks (pl, pl + w), w = 0..3, row d) and of the gradient: across the whole camera walk
+  double Cw[4][3], gacc = 0.0;
 #pragma unroll
-  for (int i = 0; i < 30; ++i) CA[i] = 0.0;
+  for (int w = 0; w < 4; ++w)
 #pragma unroll
-  for (int q = 0; q < 4; ++q) gq[q] = 0.0;
-#define MVUS_WCA(qa, w, d2) CA[(4 * (qa) - (qa) * ((qa) - 1) / 2 + (w)) * 3 + (d2)]
+    for (int d2 = 0; d2 < 3; ++d2) Cw[w][d2] = 0.0;
 
-  // inputs of one batch (lane = detection), fetched one batch ahead: the detection, its first control point from the span table
-  // (key: its span's number in the window, -1 = not this window's / not visible) and that control point's record
+  // inputs of one batch (lane = detection), fetched one batch ahead: the detection and its first control point from the span table
   struct Inputs { double fr, vr, p, q; int g; };
   auto fetch = [&](long long a0, int pos, int p1) {
     Inputs in{0.0, 0.0, 0.0, 0.0, -1};
@@ -220,9 +225,11 @@ void k_assemble_windows(DevProblem dp, NEView ne, WinView wv, const CamState* __
 #endif
   int p0 = 0, p1 = 0;
   if (ncam > 0) cam_range(0, p0, p1);
-  Inputs cur = ncam > 0 ? fetch(dp.det_off[wave], p0 + lane, p1) : Inputs{0.0, 0.0, 0.0, 0.0, -1};
+  int cnext = ncam > 0 ? wv.cam_perm[wave] : 0;
+  Inputs cur = ncam > 0 ? fetch(dp.det_off[cnext], p0 + lane, p1) : Inputs{0.0, 0.0, 0.0, 0.0, -1};
   for (int ci = 0; ci < ncam; ++ci) {
-    const int c = wave + kWinWaves * ci;
+    const int c = cnext;
+    if (ci + 1 < ncam) cnext = wv.cam_perm[wave + kWinWaves * (ci + 1)];
     const CamState& cam = cams[c];                          // wave-uniform: scalar loads
     const long long a0 = dp.det_off[c];
     int np0 = 0, np1 = 0;                                   // the next camera's range
@@ -234,21 +241,19 @@ void k_assemble_windows(DevProblem dp, NEView ne, WinView wv, const CamState* __
       for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int jj = 0; jj < TI; ++jj) cacc[h2][i][jj] = d4v{0.0, 0.0, 0.0, 0.0};
-    const int PS = nown * 3 * B;
-    double* er = ne.Et + ((long long)c * ne.N3 + 3 * a) * B;
-    if (!(p0 < p1)) {                                       // no detection of this camera near the window: its block of Et is zero
-      for (int o = lane; o < PS; o += 64) er[o] = 0.0;
-      cur = (ci + 1 < ncam) ? fetch(dp.det_off[c + kWinWaves], np0 + lane, np1) : Inputs{0.0, 0.0, 0.0, 0.0, -1};
-    }
+    double E[B];                                            // this lane's row (pl, d) of the camera's block of Et: across the camera's batches
+#pragma unroll
+    for (int k = 0; k < B; ++k) E[k] = 0.0;
+    if (!(p0 < p1)) cur = (ci + 1 < ncam) ? fetch(dp.det_off[cnext], np0 + lane, np1) : Inputs{0.0, 0.0, 0.0, 0.0, -1};   // (no batch: nothing was fetched ahead)
 
     for (int base = p0; base < p1; base += 64) {
-      const bool first = base == p0, last = base + 64 >= p1;
+      const bool last = base + 64 >= p1;
       // the next batch's inputs (this camera's, else the first of the next camera): in flight over this batch's arithmetic
       Inputs nxt;
       if (!last) nxt = fetch(a0, base + 64 + lane, p1);
-      else if (ci + 1 < ncam) nxt = fetch(dp.det_off[c + kWinWaves], np0 + lane, np1);
+      else if (ci + 1 < ncam) nxt = fetch(dp.det_off[cnext], np0 + lane, np1);
       else nxt = Inputs{0.0, 0.0, 0.0, 0.0, -1};
-      MVUS_WTP(0);     // camera set-up / previous flush tail
+      MVUS_WTP(0);     // camera set-up / previous batch's tail
       // ---- stage: lane = detection; knot span known (span table), its knots and coefficients from LDS ----
       const int key = span_key(cur.g);
       // staged column of a detection: its rank among the lanes that hold one of this window's (lane order kept) -- the columns in
@@ -273,7 +278,7 @@ void k_assemble_windows(DevProblem dp, NEView ne, WinView wv, const CamState* __
         const ObsResult r = eval_observation_at<CALIB, true>(cam, tau, loc, dp.undist != 0, dp.rs_free != 0, dp.sync_free != 0,
                                                              cur.fr, CALIB ? cur.p : 0.0, cur.vr, CALIB ? 0.0 : cur.p, cur.q, sink);
         S[kFx * kWinStr + slot] = r.ex; S[kFy * kWinStr + slot] = r.ey;
-        atomicOr(&mk[key * SP + slot % SP], 1ull << slot);  // a span's detections are dealt to its pieces in turn
+        atomicOr(&mk[key * SP + slot % SP], 1ull << slot);      // a span's detections are dealt to the pieces in turn
       }
       // spans >= a: the detections this window OWNS (camera block), as a mask over the staged columns (which keep the lane order:
       // the ballot shifted down when the lanes in use are one run -- anything else only with gaps in visibility -- else compressed)
@@ -290,10 +295,13 @@ void k_assemble_windows(DevProblem dp, NEView ne, WinView wv, const CamState* __
       }
       win_wave_sync();
       MVUS_WTP(1);     // evaluation + staging
-      unsigned long long mym = 0ull;
-      if (role) { mym = mk[mslot]; if (d == 0) mk[mslot] = 0ull; }   // (the three lanes of a slot read before lane d = 0 clears: LDS is in order)
+      // the masks of the four spans that reach this lane's control point (its piece of each): span pl + 3 - q touches it as ITS control point q
+      unsigned long long mq[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) mq[q] = role ? mk[(pl + 3 - q) * SP + s] : 0ull;
 #if defined(MVUS_WIN_STOP) && MVUS_WIN_STOP == 1
-      mym = 0ull;                                           // timing probe: evaluation + staging only
+#pragma unroll
+      for (int q = 0; q < 4; ++q) mq[q] = 0ull;             // timing probe: evaluation + staging only
 #endif
       // ---- camera block of the owned detections on the matrix cores: two independent accumulation chains (x rows, y rows) ----
 #if defined(MVUS_WIN_STOP) && (MVUS_WIN_STOP == 1 || MVUS_WIN_STOP == 3)
@@ -309,26 +317,27 @@ void k_assemble_windows(DevProblem dp, NEView ne, WinView wv, const CamState* __
           const int row = 16 * i + lr;
           rowok[i] = row <= B;
 #pragma unroll
-          for (int xy = 0; xy < 2; ++xy) srcs[xy][i] = (row < B ? 10 + xy * B + row : kFx + xy) * kWinStr + lk;
+          for (int xy = 0; xy < 2; ++xy) srcs[xy][i] = (row < B ? R::kJx + xy * B + row : kFx + xy) * kWinStr + lk;
         }
-        double nv[2][TI];                                   // operands of the next step: in flight over this step's matrix instructions
+        // operands of the next two steps are in flight over this step's matrix instructions
         const int k_lo = (__ffsll((long long)own) - 1) >> 2, k_hi = ((63 - __clzll((long long)own)) >> 2) + 1;   // steps of four columns that hold owned ones
+        double n1[2][TI], n2[2][TI];
 #pragma unroll
         for (int xy = 0; xy < 2; ++xy)
 #pragma unroll
-          for (int i = 0; i < TI; ++i) nv[xy][i] = S[srcs[xy][i] + 4 * k_lo];
+          for (int i = 0; i < TI; ++i) { n1[xy][i] = S[srcs[xy][i] + 4 * k_lo]; n2[xy][i] = k_lo + 1 < k_hi ? S[srcs[xy][i] + 4 * (k_lo + 1)] : 0.0; }
         for (int kk = k_lo; kk < k_hi; ++kk) {
           const bool on = (own >> (4 * kk + lk)) & 1ull;
           double av[2][TI];
 #pragma unroll
           for (int xy = 0; xy < 2; ++xy)
 #pragma unroll
-            for (int i = 0; i < TI; ++i) av[xy][i] = (on && rowok[i]) ? nv[xy][i] : 0.0;
-          if (kk + 1 < k_hi) {
+            for (int i = 0; i < TI; ++i) { av[xy][i] = (on && rowok[i]) ? n1[xy][i] : 0.0; n1[xy][i] = n2[xy][i]; }
+          if (kk + 2 < k_hi) {
 #pragma unroll
             for (int xy = 0; xy < 2; ++xy)
 #pragma unroll
-              for (int i = 0; i < TI; ++i) nv[xy][i] = S[srcs[xy][i] + 4 * (kk + 1)];
+              for (int i = 0; i < TI; ++i) n2[xy][i] = S[srcs[xy][i] + 4 * (kk + 2)];
           }
 #pragma unroll
           for (int xy = 0; xy < 2; ++xy)
@@ -339,75 +348,87 @@ void k_assemble_windows(DevProblem dp, NEView ne, WinView wv, const CamState* __
         }
       }
       MVUS_WTP(2);     // camera block on the matrix cores
-      // ---- accumulate: lane = (span j, piece s, coordinate d); the cross-block sums of THIS batch (flushed below) ----
+      // ---- accumulate: lane = (control point pl, coordinate d, piece s).  The lane walks the staged detections of the four spans
+      //      that reach its control point (its piece of them, in column = time order); a detection of span pl + 3 - q has the
+      //      control point as ITS q-th, so the lane's spline slot is h[q] (gu_d, gv_d) and the band blocks (pl, pl + w) take
+      //      h[q] h[q + w] (zero rows stand in for q + w > 3).  The sums of an output row never leave the lane: nothing to
+      //      exchange, nothing to flush.  The values of the next detection are in flight while this one is added ----
 #if defined(MVUS_WIN_STOP) && MVUS_WIN_STOP == 2
-      mym = 0ull;                                           // timing probe: no accumulation
+#pragma unroll
+      for (int q = 0; q < 4; ++q) mq[q] = 0ull;             // timing probe: no accumulation
 #endif
-      double E[4][B];
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int k = 0; k < B; ++k) E[q][k] = 0.0;
-      while (mym != 0ull) {
-        const int u = __ffsll((long long)mym) - 1;
-        mym &= mym - 1ull;
-        const double* su = S + u;
-        double hb[4], gu[3], gv[3];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) hb[q] = su[q * kWinStr];
-#pragma unroll
-        for (int e = 0; e < 3; ++e) { gu[e] = su[(4 + e) * kWinStr]; gv[e] = su[(7 + e) * kWinStr]; }
-        const double gud = d == 0 ? gu[0] : (d == 1 ? gu[1] : gu[2]);
-        const double gvd = d == 0 ? gv[0] : (d == 1 ? gv[1] : gv[2]);
-#pragma unroll
-        for (int k = 0; k < B; ++k) {
-          const double V = gud * su[(10 + k) * kWinStr] + gvd * su[(10 + B + k) * kWinStr];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) E[q][k] += hb[q] * V;
-        }
-        const double Vg = gud * su[kFx * kWinStr] + gvd * su[kFy * kWinStr];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) gq[q] += hb[q] * Vg;
-        double mm[3];
-#pragma unroll
-        for (int d2 = 0; d2 < 3; ++d2) mm[d2] = gud * gu[d2] + gvd * gv[d2];
-#pragma unroll
-        for (int qa = 0; qa < 4; ++qa)
-#pragma unroll
-          for (int w = 0; qa + w < 4; ++w) {
-            const double bb = hb[qa] * hb[qa + w];
-#pragma unroll
-            for (int d2 = 0; d2 < 3; ++d2) MVUS_WCA(qa, w, d2) += bb * mm[d2];
-          }
-      }
-      MVUS_WTP(3);     // accumulation
-      // ---- the batch's part of the camera's block of Et: spans j = pl + 3 - q, q = 0..3 (and their pieces) reach the owned control
-      //      point pl; the lane of span pl + 3, piece 0 collects them in (q, piece) order with lane shuffles (no trip through
-      //      memory), adds the earlier batches' sum (the wavefront's accumulator: the lane's own nine entries) and the last batch
-      //      stores the row ----
       {
-        const bool owner = role && s == 0 && j >= 3;        // row (pl, d) = (j - 3, d)
-        const int orow = ((j - 3) * 3 + d) * B;
-#pragma unroll
-        for (int k = 0; k < B; ++k) {
-          double acc = (owner && !first) ? Eacc[orow + k] : 0.0;
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            for (int sp = 0; sp < SP; ++sp) {
-              const int src = ((j - q) * SP + sp) * 3 + d;
-              acc += __shfl(E[q][k], src & 63, 64);
-            }
-          if (owner) { if (last) er[orow + k] = acc; else Eacc[orow + k] = acc; }
+        unsigned long long mall = mq[0] | mq[1] | mq[2] | mq[3];
+        // (two sets of plain locals and macros: value sets passed by reference end up in scratch memory)
+#define MVUS_WIN_TAKE(P)                                                                                                   \
+        do {                                                /* the lowest column of the walk: its values, one burst of reads */ \
+          const int u_ = __ffsll((long long)mall) - 1;                                                                     \
+          mall &= mall - 1ull;                                                                                             \
+          const int q_ = (int)((mq[1] >> u_) & 1ull) + 2 * (int)((mq[2] >> u_) & 1ull) + 3 * (int)((mq[3] >> u_) & 1ull);  \
+          const double* su_ = S + u_;                                                                                      \
+          const double* sh_ = su_ + (R::kH + q_) * kWinStr;                                                                \
+          _Pragma("unroll") for (int t = 0; t < 4; ++t) P##hb[t] = sh_[t * kWinStr];                                       \
+          _Pragma("unroll") for (int e = 0; e < 3; ++e) { P##gu[e] = su_[(R::kGu + e) * kWinStr]; P##gv[e] = su_[(R::kGv + e) * kWinStr]; } \
+          _Pragma("unroll") for (int k = 0; k < B; ++k) { P##jx[k] = su_[(R::kJx + k) * kWinStr]; P##jy[k] = su_[(R::kJy + k) * kWinStr]; } \
+          P##fx = su_[kFx * kWinStr]; P##fy = su_[kFy * kWinStr];                                                          \
+        } while (0)
+#define MVUS_WIN_ADD(P)                                                                                                    \
+        do {                                                                                                               \
+          const double gud_ = d == 0 ? P##gu[0] : (d == 1 ? P##gu[1] : P##gu[2]);                                          \
+          const double gvd_ = d == 0 ? P##gv[0] : (d == 1 ? P##gv[1] : P##gv[2]);                                          \
+          const double hu_ = P##hb[0] * gud_, hv_ = P##hb[0] * gvd_;      /* this control point's spline slot (x row, y row) */ \
+          _Pragma("unroll") for (int k = 0; k < B; ++k) E[k] += hu_ * P##jx[k] + hv_ * P##jy[k];                           \
+          gacc += hu_ * P##fx + hv_ * P##fy;                                                                               \
+          _Pragma("unroll") for (int w = 0; w < 4; ++w) {                                                                  \
+            const double bu_ = hu_ * P##hb[w], bv_ = hv_ * P##hb[w];                                                       \
+            _Pragma("unroll") for (int d2 = 0; d2 < 3; ++d2) Cw[w][d2] += bu_ * P##gu[d2] + bv_ * P##gv[d2];               \
+          }                                                                                                                \
+        } while (0)
+        if (mall != 0ull) {                                 // two value sets in turn: the reads of one are in flight over the adds of the other
+          double a_hb[4], a_gu[3], a_gv[3], a_jx[B], a_jy[B], a_fx, a_fy;
+          double b_hb[4], b_gu[3], b_gv[3], b_jx[B], b_jy[B], b_fx, b_fy;
+          MVUS_WIN_TAKE(a_);
+          while (true) {
+            bool more = mall != 0ull;
+            if (more) MVUS_WIN_TAKE(b_);
+            MVUS_WIN_ADD(a_);
+            if (!more) break;
+            more = mall != 0ull;
+            if (more) MVUS_WIN_TAKE(a_);
+            MVUS_WIN_ADD(b_);
+            if (!more) break;
+          }
         }
+#undef MVUS_WIN_TAKE
+#undef MVUS_WIN_ADD
       }
       win_wave_sync();                                      // the staging region is rewritten by the next batch
-      MVUS_WTP(4);     // E flush
+      if (lane < 32) mk[lane] = 0ull;
+      MVUS_WTP(3);     // accumulation
 #ifdef MVUS_WIN_PROBE
       ++nbatch;
 #endif
       cur = nxt;
     }
 
+    // ---- the camera's block of Et: the rows' pieces added in order, every row stored by its lane (nine plain stores into the
+    //      camera's contiguous nown x 3 x B block; the L2 merges the rows' lines) ----
+    {
+      double* er = ne.Et + ((long long)c * ne.N3 + 3 * a) * B;
+      if (SP > 1) {
+#pragma unroll
+        for (int k = 0; k < B; ++k) {
+          double t = E[k];
+          for (int sp = 1; sp < SP; ++sp) t += __shfl(E[k], (lane - s + sp) & 63, 64);    // (lane - s: piece 0 of the row)
+          E[k] = t;
+        }
+      }
+      if (role && s == 0) {
+        double* row = er + (pl * 3 + d) * B;
+#pragma unroll
+        for (int k = 0; k < B; ++k) row[k] = E[k];
+      }
+    }
     // the camera block's partial (C/D layout of the 16x16 tile: row = (lane >> 4) + 4 reg, column = lane & 15)
     {
       double* mine = wv.Apart + ((long long)win * dp.C + c) * PSZ;
@@ -423,56 +444,52 @@ void k_assemble_windows(DevProblem dp, NEView ne, WinView wv, const CamState* __
             mine[ra * (ra + 1) / 2 + rb] = cacc[0][i][jj][r] + cacc[1][i][jj][r];
           }
     }
+    MVUS_WTP(4);     // the camera's stores
     p0 = np0; p1 = np1;
   }
 
   MVUS_WTP(5);
 #ifdef MVUS_WIN_PROBE
   if ((blockIdx.x % 97) == 5 && lane == 0)
-    printf("win %d wave %d ncam %d batches %d: total %lld | per batch: setup %lld eval %lld mfma %lld accum %lld eflush %lld | tail %lld\n", win, wave, ncam, nbatch,
-           clock64() - tstart, tpa[0] / max(nbatch, 1), tpa[1] / max(nbatch, 1), tpa[2] / max(nbatch, 1), tpa[3] / max(nbatch, 1), tpa[4] / max(nbatch, 1), tpa[5]);
+    printf("win %d wave %d ncam %d batches %d: total %lld | per batch: setup %lld eval %lld mfma %lld accum %lld | per camera: stores %lld | tail %lld\n", win, wave, ncam, nbatch,
+           clock64() - tstart, tpa[0] / max(nbatch, 1), tpa[1] / max(nbatch, 1), tpa[2] / max(nbatch, 1), tpa[3] / max(nbatch, 1), tpa[4] / max(ncam, 1), tpa[5]);
 #endif
-  // ---- band and gradient: overlap-add of the spans and pieces, then of the four wavefronts, one fixed order ----
-  const int CP = nown * 9, GP = nown * 3, GP0 = 10 * SP * CP;
-  if (role) {
+  // ---- band and gradient: the rows' pieces, then the four wavefronts, added in order; every entry stored once ----
+  if (SP > 1) {
 #pragma unroll
-    for (int qa = 0; qa < 4; ++qa) {
-      const int pl = j + qa - 3;
-      if (pl >= 0 && pl < nown) {
+    for (int w = 0; w < 4; ++w)
 #pragma unroll
-        for (int w = 0; qa + w < 4; ++w)
-#pragma unroll
-          for (int d2 = 0; d2 < 3; ++d2) S[((4 * qa - qa * (qa - 1) / 2 + w) * SP + s) * CP + pl * 9 + 3 * d + d2] = MVUS_WCA(qa, w, d2);
-        S[GP0 + (qa * SP + s) * GP + pl * 3 + d] = gq[qa];
+      for (int d2 = 0; d2 < 3; ++d2) {
+        double t = Cw[w][d2];
+        for (int sp = 1; sp < SP; ++sp) t += __shfl(Cw[w][d2], (lane - s + sp) & 63, 64);
+        Cw[w][d2] = t;
       }
-    }
+    double t = gacc;
+    for (int sp = 1; sp < SP; ++sp) t += __shfl(gacc, (lane - s + sp) & 63, 64);
+    gacc = t;
   }
-#undef MVUS_WCA
+  constexpr int kRow = 13;                                  // a row's sums: 4 x 3 band entries + the gradient
+  if (role && s == 0) {
+    double* row = S + (pl * 3 + d) * kRow;
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+#pragma unroll
+      for (int d2 = 0; d2 < 3; ++d2) row[w * 3 + d2] = Cw[w][d2];
+    row[12] = gacc;
+  }
   __syncthreads();
   const int per = 3 + ne.W * 9;
   for (int e = threadIdx.x; e < nown * per; e += kWinThreads) {
-    const int pl = e / per, r = e - pl * per;
+    const int p = e / per, r = e - p * per;
     double acc = 0.0;
     if (r < 3) {
-      for (int v = 0; v < kWinWaves; ++v) {
-        const double* Sv = win_lds + v * WAVE + GP0 + pl * 3 + r;
-        double t = 0.0;
-        for (int qs = 0; qs < 4 * SP; ++qs) t += Sv[qs * GP];
-        acc += t;
-      }
-      ne.gs[3 * (a + pl) + r] = acc;
+      for (int v = 0; v < kWinWaves; ++v) acc += win_lds[v * WAVE + (p * 3 + r) * kRow + 12];
+      ne.gs[3 * (a + p) + r] = acc;
     } else {
-      const int w = (r - 3) / 9, dd = (r - 3) - 9 * w;
-      if (w < 4) {
-        for (int v = 0; v < kWinWaves; ++v) {
-          const double* Sv = win_lds + v * WAVE + pl * 9 + dd;
-          double t = 0.0;
-          for (int qa = 0; qa + w < 4; ++qa)
-            for (int sp = 0; sp < SP; ++sp) t += Sv[((4 * qa - qa * (qa - 1) / 2 + w) * SP + sp) * CP];
-          acc += t;
-        }
-      }
-      ne.Cb[((long long)(a + pl) * ne.W) * 9 + (r - 3)] = acc;       // (w >= 4: the motion rows' blocks start from zero)
+      const int w = (r - 3) / 9, dd = (r - 3) - 9 * w;        // block (p, p + w), entry (row dd / 3, column dd % 3)
+      if (w < 4)
+        for (int v = 0; v < kWinWaves; ++v) acc += win_lds[v * WAVE + (p * 3 + dd / 3) * kRow + w * 3 + dd % 3];
+      ne.Cb[((long long)(a + p) * ne.W) * 9 + (r - 3)] = acc;       // (w >= 4: the motion rows' blocks start from zero)
     }
   }
 }

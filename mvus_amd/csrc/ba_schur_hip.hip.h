@@ -41,20 +41,7 @@ struct NEView {
   int C, B, CB, N, N3, W;
   int row0;
   int* err;              // set when a row reaches outside the slice
-  // deterministic assembly (MVUS_DET_ASSEMBLY=1, one rank): instead of adding into Et / gs / Cb with fp64 atomics every assembly
-  // workgroup leaves the sums of its flush ROUND (<= 2 rounds) in a window of its own -- block 2 * workgroup + round: the first
-  // control point (dctrl0), a bit per control point it wrote (dmask) and kDetWin x (3B + 3 + 36) entries (dwin) -- and
-  // k_det_gather adds the windows up per control point in a fixed order (camera by camera, workgroup by workgroup)
-  double* dwin = nullptr;
-  int* dctrl0 = nullptr;
-  unsigned long long* dmask = nullptr;
-  int* dnondet = nullptr;  // set to dgen when a workgroup had to fall back to atomics (sparse tracks: slow path, window too wide, > 2 rounds)
-  int det = 0;
-  int dgen = 0;            // number of this assembly (what "raised in THIS assembly" is compared with: no reset between assemblies)
 };
-constexpr int kDetWin = 64;
-constexpr int kDetEmpty = 0x7f000000;                    // dctrl0 of a block nobody wrote (the array is memset to 0x7f bytes)
-MVUS_HD int det_entries(int B) { return 3 * B + 3 + 36; }
 
 }  // namespace mvus
 #include "ba_assemble_win.hip.h"
@@ -120,7 +107,7 @@ __global__ __launch_bounds__(kGaThreads) void k_assemble_spans(DevProblem dp, co
   const int chunk = blockIdx.x / kGaParts, half = blockIdx.x % kGaParts;
   const int c = dp.chunk_cam[chunk];
   const int cnt = min(kGaObs, dp.chunk_count[chunk] - half * kGaObs);
-  if (cnt <= 0) { if (ne.det && threadIdx.x < 2) ne.dctrl0[2 * (long long)blockIdx.x + threadIdx.x] = kDetEmpty; return; }
+  if (cnt <= 0) return;
   const long long i0 = dp.chunk_start[chunk] + half * kGaObs;
   const long long a0 = dp.det_off[c], Mc = dp.det_off[c + 1] - a0;
   const int tid = threadIdx.x;
@@ -183,7 +170,7 @@ __global__ __launch_bounds__(kGaThreads) void k_assemble_spans(DevProblem dp, co
     if (tid > 0 && kt < key[tid - 1]) sort_s = 1;
   }
   lds_barrier();
-  if (!any_s) { if (ne.det && tid < 2) ne.dctrl0[2 * (long long)blockIdx.x + tid] = kDetEmpty; return; }      // nothing visible (uniform)
+  if (!any_s) return;      // nothing visible (uniform)
   if (sort_s) {
     int pos = 0;
     for (int u = 0; u < kGaObs; ++u) { const int ku = key[u]; pos += (ku < kt) || (ku == kt && u < t); }
@@ -334,7 +321,6 @@ __global__ __launch_bounds__(kGaThreads) void k_assemble_spans(DevProblem dp, co
       }
     }
     if (!fast) {                                         // slow path: too many ranges to keep one per thread
-      if (ne.det && tid == 0) *ne.dnondet = ne.dgen;
       const int gq = rg[r];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -354,7 +340,7 @@ __global__ __launch_bounds__(kGaThreads) void k_assemble_spans(DevProblem dp, co
       }
     }
   }
-  if (!fast) { if (ne.det && tid < 2) ne.dctrl0[2 * (long long)blockIdx.x + tid] = kDetEmpty; return; }
+  if (!fast) return;
 #if defined(MVUS_ASM_STOP) && MVUS_ASM_STOP == 2
   if (acc_[0] != 12345.678) return;      // timing probe: + accumulation, no flush
 #endif
@@ -397,34 +383,6 @@ __global__ __launch_bounds__(kGaThreads) void k_assemble_spans(DevProblem dp, co
     }
     lds_barrier();
   }
-  // deterministic mode: per round the window start, whether the round fits a window, and the bit mask of the points it owns
-  __shared__ int det_c0[8], det_ok[8];
-  __shared__ unsigned long long det_mask[2];
-  if (ne.det) {
-    const int rounds = (nr + kRb - 1) / kRb;
-    if (tid < 8) {
-      det_ok[tid] = 0; det_c0[tid] = 0;
-      if (tid < rounds) {
-        const int p0 = round_off[tid], p1 = round_off[tid + 1];
-        det_c0[tid] = pt_ctrl[p0];
-        det_ok[tid] = tid < 2 && p1 > p0 && pt_ctrl[p1 - 1] - pt_ctrl[p0] < kDetWin;
-        if (!det_ok[tid]) *ne.dnondet = ne.dgen;
-      }
-      if (tid < 2) det_mask[tid] = 0ull;
-    }
-    lds_barrier();
-    for (int rho = 0; rho < 2 && rho < rounds; ++rho) {
-      if (!det_ok[rho]) continue;
-      const int p0 = round_off[rho], nown = round_off[rho + 1] - p0;
-      for (int i = tid; i < nown; i += kGaThreads) atomicOr(&det_mask[rho], 1ull << (pt_ctrl[p0 + i] - det_c0[rho]));
-    }
-    lds_barrier();
-    if (tid < 2) {                                        // (every block header is written by its workgroup in every assembly: no clearing pass)
-      const bool ok = tid < rounds && det_ok[tid];
-      ne.dctrl0[2 * (long long)blockIdx.x + tid] = ok ? det_c0[tid] : kDetEmpty;
-      if (ok) ne.dmask[2 * (long long)blockIdx.x + tid] = det_mask[tid];
-    }
-  }
   // ---- flush of the cross block + gradient: Ep[rl][q][3][B], Gp[rl][q][3] ----
   for (int r0 = 0, rho = 0; r0 < nr; r0 += kRb, ++rho) {
     const int nb = min(kRb, nr - r0);
@@ -454,9 +412,7 @@ __global__ __launch_bounds__(kGaThreads) void k_assemble_spans(DevProblem dp, co
         const int q2 = ctrl - rg[r0 + rl + j];
         acc += grad ? Gp[((rl + j) * 4 + q2) * 3 + dk - 3 * B] : Ep[((rl + j) * 4 + q2) * 3 * B + dk];
       }
-      if (ne.det && det_ok[rho]) {                        // this round's own window: one writer per entry, zeros included
-        ne.dwin[((2 * (long long)blockIdx.x + rho) * kDetWin + (ctrl - det_c0[rho])) * (3 * B + 39) + dk] = acc;
-      } else if (acc != 0.0) {
+      if (acc != 0.0) {
         if (grad) unsafeAtomicAdd(&ne.gs[3 * ctrl + dk - 3 * B], acc);
         else unsafeAtomicAdd(&ne.Et[((long long)c * ne.N3 + 3 * ctrl) * B + dk], acc);
       }
@@ -493,8 +449,7 @@ __global__ __launch_bounds__(kGaThreads) void k_assemble_spans(DevProblem dp, co
         const int q2 = ctrl - rg[r0 + rl + j];
         if (q2 + w < 4) acc += Cp[((rl + j) * 10 + 4 * q2 - q2 * (q2 - 1) / 2 + w) * 9 + dd];
       }
-      if (ne.det && det_ok[rho]) ne.dwin[((2 * (long long)blockIdx.x + rho) * kDetWin + (ctrl - det_c0[rho])) * (3 * B + 39) + 3 * B + 3 + wd] = acc;
-      else if (acc != 0.0) unsafeAtomicAdd(&ne.Cb[((long long)ctrl * ne.W) * 9 + wd], acc);
+      if (acc != 0.0) unsafeAtomicAdd(&ne.Cb[((long long)ctrl * ne.W) * 9 + wd], acc);
     }
     lds_barrier();
   }
@@ -512,143 +467,6 @@ __device__ __forceinline__ void lds_wave_sync() {      // orders the LDS traffic
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
 }
-// ---- deterministic assembly: the gather --------------------------------------------------------------------------------
-// per camera (one wavefront): dfill[block] = running maximum of the window starts of the camera's blocks (non-decreasing, so the
-// gather can binary-search it), bounds[0] = the largest (running maximum - own start): how far below it a block can start
-__global__ __launch_bounds__(64) void k_det_index(DevProblem dp, int N, const int* __restrict__ dctrl0, int* __restrict__ dfill, int* __restrict__ bounds,
-                                                  int* __restrict__ dfirst) {
-  // dfirst[c * N + g] = the first block of camera c whose running maximum + kDetWin exceeds g (what a binary search over dfill finds):
-  // block b is that block for g in [dfill[b-1] + kDetWin, dfill[b] + kDetWin) -- every lane fills the range of its block
-  const int c = blockIdx.x, lane = threadIdx.x;
-  const int b0 = dp.cam_chunk_off[c] * kGaParts * 2, b1 = dp.cam_chunk_off[c + 1] * kGaParts * 2;
-  int carry = -0x7fffffff, slack = 0;
-  int* first = dfirst + (long long)c * N;
-  for (int base = b0; base < b1; base += 64) {
-    const int b = base + lane;
-    const bool in = b < b1;
-    const int c0 = in ? dctrl0[b] : kDetEmpty;
-    int v = c0 >= kDetEmpty ? -0x7fffffff : c0;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(v, off, 64); if (lane >= off) v = max(v, o); }
-    v = max(v, carry);
-    int prev = __shfl_up(v, 1, 64);
-    if (lane == 0) prev = carry;
-    if (in) {
-      dfill[b] = v;
-      if (c0 < kDetEmpty) slack = max(slack, v - c0);
-      if (v > prev) {                                   // (v == prev: an empty block or one that starts below the maximum -- never "the first")
-        const int g_lo = prev == -0x7fffffff ? 0 : min(N, max(0, prev + kDetWin)), g_hi = min(N, max(0, v + kDetWin));
-        for (int g = g_lo; g < g_hi; ++g) first[g] = b;
-      }
-    }
-    carry = __shfl(v, 63, 64);
-  }
-  const int tail = carry == -0x7fffffff ? 0 : min(N, max(0, carry + kDetWin));
-  for (int g = tail + lane; g < N; g += 64) first[g] = b1;      // past every window
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) slack = max(slack, __shfl_xor(slack, off, 64));
-  if (lane == 0) bounds[c] = slack;                      // per camera: the gather takes the maximum (nothing to reset between assemblies)
-}
-// One wavefront per control point g, two steps.  (1) lane = camera: every lane finds the window rows of g among its camera's blocks
-// (first block from the table, four block headers in flight at a time) and leaves (block, row) in LDS, in block order.  (2) lane =
-// ENTRY of a window row (coalesced 8 * (3B + 39)-byte rows): the cameras' rows are added up in camera order, row by row -- the 3B
-// cross-block entries per camera (written to Et when the camera is done), the gradient and band entries across all cameras.  One
-// fixed order of additions, no exchange between lanes.  Everything is ADDED to the (cleared) storage: workgroups that fell back
-// to atomics have already put their part there.
-constexpr int kDetRowsMax = 8;                           // window rows of one camera handled per pass (more: further passes, a fixed order all the same)
-template <int B>
-__global__ __launch_bounds__(kThreads) void k_det_gather(DevProblem dp, NEView ne, const int* __restrict__ dfill, const int* __restrict__ bounds,
-                                                         const int* __restrict__ dfirst) {
-  constexpr int ENT = 3 * B + 39, kWaves = kThreads / 64;
-  __shared__ int cov_row[kWaves][64][kDetRowsMax];        // per camera (lane) of the current group of 64: row = block * kDetWin + local control point
-  __shared__ int flat_row[kWaves][64 * kDetRowsMax];      // the same rows one after the other, camera by camera
-  __shared__ short flat_cam[kWaves][64 * kDetRowsMax];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int g = (int)blockIdx.x * kWaves + wave;
-  if (g >= ne.N) return;                                // (wave-uniform; no workgroup barrier below)
-  int reach = 0;
-  for (int c = lane; c < dp.C; c += 64) reach = max(reach, bounds[c]);
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) reach = max(reach, __shfl_xor(reach, off, 64));
-  reach = min(kDetWin, reach);
-  const bool clean = *ne.dnondet != ne.dgen;
-  const int e0 = lane, e1 = lane + 64;                   // the entries of a row this lane adds up
-  double b0 = 0.0, b1 = 0.0;                             // gradient / band sums over all cameras (entries >= 3B)
-  for (int cbase = 0; cbase < dp.C; cbase += 64)
-  for (int pass = 0, again = 1; again; ++pass) {         // (a second pass only when some camera holds g in more than kDetRowsMax rows)
-    const int c = cbase + lane;
-    int cnt = 0, ord = 0;
-    if (c < dp.C) {
-      const int lo = dfirst[(long long)c * ne.N + g];
-      const int end = dp.cam_chunk_off[c + 1] * kGaParts * 2;
-      for (int bb = lo; bb < end; bb += 4) {
-        int fl[4], c0[4];
-        unsigned long long mk[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const bool in = bb + q < end;
-          fl[q] = in ? dfill[bb + q] : 0x7fffffff;
-          c0[q] = in ? ne.dctrl0[bb + q] : kDetEmpty;
-          mk[q] = in ? ne.dmask[bb + q] : 0ull;
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int lc = g - c0[q];
-          if (!(fl[q] <= g + reach) || c0[q] >= kDetEmpty || lc < 0 || lc >= kDetWin || !((mk[q] >> lc) & 1ull)) continue;
-          if (ord >= pass * kDetRowsMax && cnt < kDetRowsMax) cov_row[wave][lane][cnt++] = (bb + q) * kDetWin + lc;
-          ++ord;
-        }
-        if (!(fl[3] <= g + reach)) break;
-      }
-    }
-    again = __ballot(ord > (pass + 1) * kDetRowsMax) != 0ull;
-    // the cameras' rows one after the other (exclusive scan of the counts over the lanes)
-    int incl = cnt;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(incl, off, 64); if (lane >= off) incl += o; }
-    const int total = __shfl(incl, 63, 64);
-    for (int k = 0; k < cnt; ++k) { flat_row[wave][incl - cnt + k] = cov_row[wave][lane][k]; flat_cam[wave][incl - cnt + k] = (short)lane; }
-    lds_wave_sync();
-    int cur = -1;
-    double s0 = 0.0, s1 = 0.0;                           // the current camera's cross-block entries (entries < 3B)
-    auto flush_cam = [&]() {
-      if (cur < 0) return;
-      double* er = ne.Et + ((long long)(cbase + cur) * ne.N3 + 3 * g) * B;
-      if (clean && pass == 0) {                          // nobody added to Et with atomics: the (cleared) entries are simply written
-        if (e0 < 3 * B) er[e0] = s0;
-        if (e1 < 3 * B) er[e1] = s1;
-      } else {
-        if (e0 < 3 * B) er[e0] += s0;
-        if (e1 < 3 * B) er[e1] += s1;
-      }
-    };
-    for (int i0 = 0; i0 < total; i0 += 8) {              // eight rows in flight, then their adds in row order
-      double v0[8], v1[8];
-      int cm[8];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const bool ok = i0 + q < total;
-        const long long off = ok ? (long long)flat_row[wave][i0 + q] * ENT : 0;
-        cm[q] = ok ? (int)flat_cam[wave][i0 + q] : -1;
-        v0[q] = (ok && e0 < ENT) ? ne.dwin[off + e0] : 0.0;
-        v1[q] = (ok && e1 < ENT) ? ne.dwin[off + e1] : 0.0;
-      }
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        if (cm[q] < 0) continue;
-        if (cm[q] != cur) { flush_cam(); cur = cm[q]; s0 = 0.0; s1 = 0.0; }
-        if (e0 < 3 * B) s0 += v0[q]; else b0 += v0[q];
-        if (e1 < 3 * B) s1 += v1[q]; else b1 += v1[q];
-      }
-    }
-    flush_cam();
-    lds_wave_sync();
-  }
-  // entry e >= 3B: e - 3B < 3 is the gradient coordinate, else band entry e - 3B - 3
-  if (e0 >= 3 * B && e0 < ENT) { const int r = e0 - 3 * B; if (r < 3) ne.gs[3 * g + r] += b0; else ne.Cb[((long long)g * ne.W) * 9 + r - 3] += b0; }
-  if (e1 >= 3 * B && e1 < ENT) { const int r = e1 - 3 * B; if (r < 3) ne.gs[3 * g + r] += b1; else ne.Cb[((long long)g * ne.W) * 9 + r - 3] += b1; }
-}
-
 // A[c] (both triangles) and gc[c] from the per-workgroup partial blocks of k_assemble_spans: one workgroup per camera, entry e
 // of the packed lower triangle summed over the camera's assembly workgroups in index order by four threads (quarters, then a
 // fixed combine) -- no atomics, the same bits every run.  Workgroups that had nothing to add left zeros (the buffer is
@@ -2253,28 +2071,52 @@ struct HipSchur {
     const HostProblem& hp = be.hp;
     use_win = hp.frames_sorted && hp.M > 0 && ne.N > 0 && hp.C <= 64 * kWinWaves && !std::getenv("MVUS_ASM_ATOMIC");
     if (!use_win) return;
-    // window length: (Wn + 3) spans of the densest camera should fill most of one 64-detection batch (a 65th detection costs a whole
-    // second batch), and the workgroups should come in whole rounds of two per CU
-    double rho = 0.0;
-    for (int c = 0; c < hp.C; ++c) rho = std::max(rho, (double)(hp.det_off[c + 1] - hp.det_off[c]) / std::max(1, hp.N));
-    int Wn = (int)std::floor(52.0 / std::max(rho, 1e-9)) - 3;
-    Wn = std::min(kWinMaxW, std::max(4, Wn));
+    // Window length.  A (window, camera) pair costs its batches of 64 staged detections -- (Wn + 3) spans reach a window, so camera
+    // c brings n_c = (Wn + 3) rho_c + 3 of them, rho_c = detections per knot span -- a fixed part per batch (evaluation, matrix-core
+    // pass) and a part per detection (accumulation); the windows run two workgroups per CU at a time.  Short windows repeat more
+    // evaluations (the three spans below a window) but fill the machine; the model picks the cheapest length, MVUS_WIN overrides.
+    int Wn = 8;
     {
       int ncu = 256;
       hipDeviceProp_t prop;
       if (hipGetDeviceProperties(&prop, be.device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
-      const int slots = 2 * ncu;
-      const int rounds = ((ne.N + Wn - 1) / Wn + slots - 1) / slots;          // keep the number of rounds, use its slots: the shortest window that does
-      while (Wn > 4 && ((ne.N + (Wn - 1) - 1) / (Wn - 1) + slots - 1) / slots == rounds) --Wn;
+      const double slots = 2.0 * ncu;
+      double best = 1e300;
+      for (int w = 3; w <= kWinMaxW; ++w) {
+        double wg = 0.0;
+        for (int c = 0; c < hp.C; ++c) {
+          const double nc = (w + 3) * (double)(hp.det_off[c + 1] - hp.det_off[c]) / std::max(1, hp.N) + 3.0;
+          wg += 0.45 * std::ceil(nc / 64.0) + 0.55 * nc / 64.0 + 0.15;      // + the camera's own set-up and stores
+        }
+        const double nwin = std::ceil((double)ne.N / w);
+        const double t = std::max(1.0, nwin / slots) * wg;
+        if (t < best * 0.999) { best = t; Wn = w; }
+      }
     }
-    if (const char* e = std::getenv("MVUS_WIN")) Wn = std::min(kWinMaxW, std::max(1, std::atoi(e)));
-    if (hp.calib) Wn = std::min(Wn, 12);
+    if (const char* e = std::getenv("MVUS_WIN")) { if (std::atoi(e) > 0) Wn = std::min(kWinMaxW, std::atoi(e)); }
     wv.Wn = Wn; wv.nwin = (ne.N + Wn - 1) / Wn; wv.Ntot = hp.N;
     const size_t psz = (size_t)(ne.B + 1) * (ne.B + 2) / 2;
     wv.Apart = be.alloc((size_t)wv.nwin * ne.C * psz);
     const size_t bytes_cw = sizeof(CamWin) * (size_t)hp.C, bytes_t = sizeof(double) * ((size_t)hp.N + 1), bytes_l = sizeof(int32_t) * (((size_t)hp.flut_len + 3) & ~(size_t)3);
-    const size_t bytes_r = sizeof(int4) * (size_t)std::max(1, hp.N);
-    MVUS_HIP(hipMalloc(&win_tables, bytes_cw + 2 * bytes_t + bytes_l + bytes_r));
+    const size_t bytes_r = sizeof(int4) * (size_t)std::max(1, hp.N), bytes_p = sizeof(int32_t) * (size_t)hp.C;
+    MVUS_HIP(hipMalloc(&win_tables, bytes_cw + 2 * bytes_t + bytes_l + bytes_r + bytes_p));
+    // cameras dealt to the four wavefronts of a window by decreasing detection count, back and forth (0 1 2 3 3 2 1 0 ...): every
+    // wavefront walks about the same number of detections whatever the cameras' frame rates
+    std::vector<int32_t> perm((size_t)hp.C);
+    {
+      std::vector<int32_t> byc((size_t)hp.C);
+      for (int c = 0; c < hp.C; ++c) byc[c] = c;
+      std::stable_sort(byc.begin(), byc.end(), [&](int32_t u, int32_t v) { return hp.det_off[u + 1] - hp.det_off[u] > hp.det_off[v + 1] - hp.det_off[v]; });
+      std::vector<std::vector<int32_t>> of(kWinWaves);
+      for (int i = 0; i < hp.C; ++i) { const int r = i % (2 * kWinWaves); of[r < kWinWaves ? r : 2 * kWinWaves - 1 - r].push_back(byc[i]); }
+      // wavefront v walks perm[v], perm[v + 4], ...: it takes ceil((C - v) / 4) cameras, the first waves one more than the last ones
+      std::vector<int32_t> flat;
+      for (int v = 0; v < kWinWaves; ++v) flat.insert(flat.end(), of[v].begin(), of[v].end());
+      std::vector<size_t> take(kWinWaves);
+      for (int v = 0; v < kWinWaves; ++v) take[v] = (size_t)(hp.C - v + kWinWaves - 1) / kWinWaves;
+      size_t pos = 0;
+      for (int v = 0; v < kWinWaves; ++v) for (size_t i = 0; i < take[v]; ++i) perm[(size_t)v + kWinWaves * i] = flat[pos++];
+    }
     std::vector<int4> crec((size_t)std::max(1, hp.N), int4{0, 0, 0, 0});
     for (int sI = 0; sI < hp.S; ++sI) {
       const int ns = hp.ctrl_off[sI + 1] - hp.ctrl_off[sI];
@@ -2292,6 +2134,8 @@ struct HipSchur {
     wv.flut = flut;
     MVUS_HIP(hipMemcpyAsync(base + bytes_cw + 2 * bytes_t + bytes_l, crec.data(), bytes_r, hipMemcpyHostToDevice, be.stream));   // (synchronised below: crec outlives the copy)
     wv.crec = reinterpret_cast<const int4*>(base + bytes_cw + 2 * bytes_t + bytes_l);
+    MVUS_HIP(hipMemcpyAsync(base + bytes_cw + 2 * bytes_t + bytes_l + bytes_r, perm.data(), bytes_p, hipMemcpyHostToDevice, be.stream));
+    wv.cam_perm = reinterpret_cast<const int32_t*>(base + bytes_cw + 2 * bytes_t + bytes_l + bytes_r);
     hipLaunchKernelGGL(k_frame_lut, dim3((unsigned)((hp.flut_len + 255) / 256)), dim3(256), 0, be.stream, be.dp, wv.cw, flut, (long long)hp.flut_len);
     MVUS_HIP(hipGetLastError());
     MVUS_HIP(hipStreamSynchronize(be.stream));
@@ -2306,7 +2150,6 @@ struct HipSchur {
     if (halo_tables) (void)hipFree(halo_tables);
     if (fail) (void)hipFree(fail);
     if (fail_host) (void)hipHostFree(fail_host);
-    for (void* p : {(void*)ne.dwin, (void*)ne.dctrl0, (void*)ne.dmask, (void*)det_fill, (void*)det_bounds, (void*)det_first}) if (p) (void)hipFree(p);
   }
 
   // x_fused != nullptr: the detection rows' Jacobian is evaluated inside the assembly kernel at x_fused (no J in memory);
@@ -2316,34 +2159,7 @@ struct HipSchur {
   double* clear_ptr() { return use_win ? nullptr : NE; }      // (the window-major assembly writes every entry: nothing to clear)
   int64_t clear_len() const { return (int64_t)(ne_count + n_apart); }
   void mark_cleared() { ne_cleared = true; }
-  // deterministic assembly (see NEView): buffers of the windows, built on first use
-  int *det_fill = nullptr, *det_bounds = nullptr, *det_first = nullptr;
-  int det_gen = 0;
-  bool last_det = false;                                   // the last assembly ran in the deterministic mode
-  size_t det_blocks = 0;
-  bool det_wanted() const { return !shard && (be.det_assembly || std::getenv("MVUS_DET_ASSEMBLY") != nullptr); }
-  void det_prepare() {
-    const size_t nblk = (size_t)kGaParts * 2 * std::max<size_t>(be.hp.chunks.size(), 1);
-    if (det_blocks != nblk) {
-      for (void* p : {(void*)ne.dwin, (void*)ne.dctrl0, (void*)ne.dmask, (void*)det_fill, (void*)det_bounds, (void*)det_first}) if (p) (void)hipFree(p);
-      MVUS_HIP(hipMalloc(reinterpret_cast<void**>(&ne.dwin), nblk * kDetWin * (size_t)det_entries(ne.B) * sizeof(double)));
-      MVUS_HIP(hipMalloc(reinterpret_cast<void**>(&ne.dctrl0), nblk * sizeof(int)));
-      MVUS_HIP(hipMalloc(reinterpret_cast<void**>(&ne.dmask), nblk * sizeof(unsigned long long)));
-      MVUS_HIP(hipMalloc(reinterpret_cast<void**>(&det_fill), nblk * sizeof(int)));
-      MVUS_HIP(hipMalloc(reinterpret_cast<void**>(&det_bounds), ((size_t)std::max(1, ne.C) + 1) * sizeof(int)));
-      MVUS_HIP(hipMemsetAsync(det_bounds, 0, ((size_t)std::max(1, ne.C) + 1) * sizeof(int), be.stream));
-      MVUS_HIP(hipMalloc(reinterpret_cast<void**>(&det_first), (size_t)std::max(1, ne.C) * (size_t)std::max(1, ne.N) * sizeof(int)));
-      ne.dnondet = det_bounds + std::max(1, ne.C);
-      det_blocks = nblk;
-      det_gen = 0;
-    }
-    ne.dgen = ++det_gen;                                   // (block headers, slack and the fall-back mark are rewritten / compared per assembly: nothing to clear)
-  }
-  int det_fallbacks() {                                    // workgroups of the last assembly that had to use atomics (synchronises)
-    int v = 0;
-    if (det_bounds && det_gen > 0) { MVUS_HIP(hipMemcpyAsync(&v, ne.dnondet, sizeof(int), hipMemcpyDeviceToHost, be.stream)); MVUS_HIP(hipStreamSynchronize(be.stream)); }
-    return v == det_gen && det_gen > 0 && last_det ? 1 : 0;
-  }
+  bool last_atomic = false;                                // the last assembly went through the detection-major kernel (fp64 atomics)
   void motion_rows(const double* f_dev) {
     // (one rank: the row-ordered kernel in both modes -- 22 us against 26 for the LDS-window one at configs[1], and one source of
     // run-to-run differences less; a time shard keeps k_assemble_motion, which also reports rows that leave the slice)
@@ -2359,7 +2175,7 @@ struct HipSchur {
       // window-major: every entry of A, gc, Cb, gs, Et is written by exactly one thread -- no clearing pass, no atomics.
       // It starts from the knot span of every detection at x: left behind by the residual evaluation at x that precedes every
       // linearisation (else evaluated now), or the held analytic Jacobian's own table
-      ne_cleared = false; ne.det = 0; last_det = false;
+      ne_cleared = false; last_atomic = false;
       if (span_held) wv.span = span_held;
       else {
         if (be.rspan_for != x_fused) be.residual(x_fused, const_cast<double*>(f_dev));      // (f_dev holds f(x) already: the same values again)
@@ -2379,9 +2195,7 @@ struct HipSchur {
     }
     if (!ne_cleared) be.fill(NE, 0.0, (int64_t)(ne_count + n_apart));      // one launch (hipMemsetAsync splits 36 MB into two fill kernels)
     ne_cleared = false;
-    ne.det = det_wanted() && be.dp.n_chunks > 0 ? 1 : 0;
-    last_det = ne.det != 0;
-    if (ne.det) det_prepare();
+    last_atomic = be.dp.n_chunks > 0;
     if (be.dp.n_chunks > 0) {
       const int nc = be.dp.n_chunks;
       const dim3 g(kGaParts * nc), b(kGaThreads);
@@ -2393,12 +2207,6 @@ struct HipSchur {
         if (be.hp.calib) hipLaunchKernelGGL((k_assemble_spans<30, false>), g, b, 0, be.stream, be.dp, be.J, be.span, f_dev, ne, be.cams, (const double*)nullptr);
         else hipLaunchKernelGGL((k_assemble_spans<21, false>), g, b, 0, be.stream, be.dp, be.J, be.span, f_dev, ne, be.cams, (const double*)nullptr);
       }
-    }
-    if (ne.det) {
-      hipLaunchKernelGGL(k_det_index, dim3(be.hp.C), dim3(64), 0, be.stream, be.dp, ne.N, ne.dctrl0, det_fill, det_bounds, det_first);
-      const dim3 gg((unsigned)((ne.N + kThreads / 64 - 1) / (kThreads / 64)));
-      if (be.hp.calib) hipLaunchKernelGGL(k_det_gather<18>, gg, dim3(kThreads), 0, be.stream, be.dp, ne, det_fill, det_bounds, det_first);
-      else hipLaunchKernelGGL(k_det_gather<9>, gg, dim3(kThreads), 0, be.stream, be.dp, ne, det_fill, det_bounds, det_first);
     }
     if (be.dp.n_chunks > 0) {
       if (be.hp.calib) hipLaunchKernelGGL(k_cam_block_reduce<18>, dim3(be.hp.C, 2), dim3(1024), 0, be.stream, be.dp, ne);

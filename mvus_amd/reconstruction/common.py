@@ -24,8 +24,8 @@ Extra ``settings`` keys (all optional; a reference ``config.json`` has none of t
 ``ba_pattern_ties`` 'numpy' = the twin rows of the pattern decided like np.argsort of this process decides them (default;
                what the reference would build here), 'canonical'.
 ``ba_lambda_min`` floor of the LM damping (default 3e-3, see ``mvus_solve_opts.lm_lambda_min``).
-``ba_deterministic`` with 'lm': True assembles the normal equations without floating-point atomics -- the same bits on every
-               run, 7-14 % slower (``mvus_ba_set_deterministic``; default False).
+``ba_deterministic`` accepted and ignored: the 'lm' solver's normal equations are assembled without floating-point atomics
+               (one writer, one order of additions per entry) -- the same bits on every run by construction.
 ``opt_sync`` (reference key: False freezes alpha/beta), ``device``.
 """
 import json
@@ -375,8 +375,6 @@ class Scene:
         h = self._resident_handle(prob, cams)      # stays resident for remove_outliers and the next BA
         opts = _ba._lib.default_opts(solver, jac_mode, max_iter)
         opts.lm_lambda_min = float(st.get('ba_lambda_min', opts.lm_lambda_min))
-        if solver == _ba.SOLVER_LM_SCHUR:
-            h.set_deterministic(bool(st.get('ba_deterministic', False)))       # 'ba_solver': 'lm' only: same bits on every run, 7-14 % slower
         try:
             res = h.solve(model, opts=opts, ties=st.get('ba_pattern_ties', 'numpy'), matrix=jac_sparsity)
         except RuntimeError as e:
