@@ -633,7 +633,9 @@ __global__ __launch_bounds__(kThreads) void k_jtu_reduce(DevProblem dp, const do
   const int mrow_lo = motion ? dp.mv.row_lo[g] : 0, mrow_hi = motion ? dp.mv.row_hi[g] : 0;      // (fetched beside the cameras' first loads)
   // a chunk starts at most bounds[0] control points below the running maximum of the starts: once that maximum is more than
   // bounds[0] past g, no later chunk starts at or before g (without the measured bound: a whole window)
-  const int reach = bounds != nullptr ? min(kJtWin, bounds[0]) : kJtWin;
+  // (the MEASURED bound, not clipped to a window: a camera whose detections are not in time order -- nothing in the reference
+  // forbids it -- has chunks that start arbitrarily far below the running maximum; the walk is then longer, never wrong)
+  const int reach = bounds != nullptr ? bounds[0] : kJtWin;
   for (int c = lane; c < dp.C; c += 64) {
     // first chunk whose running-max window start is within reach of g (everything before ends left of g) ...
     const int end = dp.cam_chunk_off[c + 1];

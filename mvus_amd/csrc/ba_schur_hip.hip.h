@@ -2176,6 +2176,9 @@ struct HipSchur {
       // It starts from the knot span of every detection at x: left behind by the residual evaluation at x that precedes every
       // linearisation (else evaluated now), or the held analytic Jacobian's own table
       ne_cleared = false; last_atomic = false;
+      // (a time shard: the part of the packed head that is SUMMED over the ranks without being written in full here -- the halo exchange
+      // buffer of the other ranks' cuts, diag(H) and g of the columns outside this slice -- starts from zero: ~1 MB, not the 36 MB of blocks)
+      if (shard) be.fill(NE + nAg, 0.0, (int64_t)(halo_count + 2 * (size_t)be.hp.n));
       if (span_held) wv.span = span_held;
       else {
         if (be.rspan_for != x_fused) be.residual(x_fused, const_cast<double*>(f_dev));      // (f_dev holds f(x) already: the same values again)

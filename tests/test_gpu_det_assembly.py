@@ -1,10 +1,13 @@
-"""LM + Schur with the deterministic assembly (mvus_ba_set_deterministic / MVUS_DET_ASSEMBLY=1): every assembly workgroup leaves its
-sums in a window of its own instead of adding with fp64 atomics, k_det_gather adds the windows per control point in a fixed order,
-the motion rows are added per control point in row order.  Checked here: the normal equations equal the atomic assembly's to
-rounding, and the assembly as well as a whole LM solve give the SAME BITS on every run -- on a pinhole scene, with rolling shutter +
-motion regulariser F (two spline intervals), with opt_calib (P = 15) + KE, and on a dense flight (several windows of one camera
-per control point).  Tracks so sparse that 128 consecutive detections of a camera span more than 64 control points keep the atomic
-path for those workgroups (correct, not reproducible): not the regime of the BASELINE configurations."""
+"""LM + Schur: the normal equations of the analytic Jacobian are assembled window-major (mvus_amd/csrc/ba_assemble_win.hip.h) -- a
+workgroup owns a window of control points and walks the cameras, every entry has one writer and one order of additions, no fp64
+atomics and no clearing pass.  Checked here, in the DEFAULT mode: the normal equations equal those formed from the stored Jacobian
+blocks by the detection-major kernel (MVUS_NE_FROM_J=1, atomics) to rounding; the assembly as well as a whole LM solve give the SAME
+BITS on every run -- on a pinhole scene, with rolling shutter + motion regulariser F (two spline intervals), with opt_calib
+(P = 15) + KE, on dense and on sparse tracks, at every window length; a camera whose detections are not in time order (nothing in
+the reference forbids that: common.py:448-487 never looks at the order) is still solved correctly (detection-major kernel, and the
+handle says so)."""
+import hashlib
+
 import numpy as np
 import pytest
 
@@ -18,92 +21,128 @@ def _scenes():
     yield 'rs_motion_F_dense_7cam', kw
     kw = dict(synth.BASELINE_CONFIGS[4]); kw.update(total_obs=30_000)
     yield 'calib_KE_7cam', kw
-    # 300 detections per knot span and camera: a control point sits in ~10 windows of ONE camera -- the gather's second pass
-    yield 'very_dense_2cam', dict(num_cam=2, total_obs=120_000, seed=7, num_knots=200, rolling_shutter=True)
-    yield 'config2_32cam_504k', dict(synth.BASELINE_CONFIGS[2])       # full size: a thinner flight spreads a workgroup's 128 detections over
-                                                                        # more than the 64 control points of a window and falls back to atomics
+    yield 'very_dense_2cam', dict(num_cam=2, total_obs=120_000, seed=7, num_knots=200, rolling_shutter=True)   # 300 detections per knot span and camera
+    kw = dict(synth.BASELINE_CONFIGS[2]); kw.update(total_obs=120_000)
+    yield 'config2_sparse_0.75_per_span', kw                            # 0.75 detections per knot span and camera
+    yield 'config2_32cam_504k', dict(synth.BASELINE_CONFIGS[2])         # full size
+
+
+def _normal_equations(prob, x, from_j, monkeypatch):
+    from mvus_amd import ba
+    if from_j:
+        monkeypatch.setenv('MVUS_NE_FROM_J', '1')
+    else:
+        monkeypatch.delenv('MVUS_NE_FROM_J', raising=False)
+    with ba.BAHandle(prob) as h:
+        h.residual_jacobian(x)
+        ne = h.normal_equations()
+        fell_back = h.deterministic_fallback()
+    monkeypatch.delenv('MVUS_NE_FROM_J', raising=False)
+    return ne, fell_back
 
 
 @pytest.mark.parametrize('name,kw', list(_scenes()), ids=[n for n, _ in _scenes()])
-def test_deterministic_assembly_matches_and_repeats(name, kw):
+def test_window_assembly_matches_and_repeats(name, kw, monkeypatch):
     from mvus_amd import ba, problem as mp, synth
-    scene = synth.make_scene(**kw)
-    prob, x0 = mp.problem_from_scene(scene)
+    prob, x0 = mp.problem_from_scene(synth.make_scene(**kw))
 
-    def run(det):
+    def solve():
         with ba.BAHandle(prob) as h:
-            h.set_deterministic(det)
-            h.residual_jacobian(x0)
-            ne = h.normal_equations()
             res = h.solve(x0, solver=ba.SOLVER_LM_SCHUR, jac_mode=ba.JAC_ANALYTIC, max_nfev=6)
-            return ne, res.cost, res.x.copy()
+            assert not h.deterministic_fallback()
+            return res.cost, res.x.copy()
 
-    ne_a, cost_a, _ = run(False)
-    runs = [run(True) for _ in range(3)]
-    for part_a, part_d, what in zip(ne_a, runs[0][0], ('gradient', 'camera blocks', 'band', 'cross block')):
-        scale = np.max(np.abs(part_a))
-        assert np.max(np.abs(part_d - part_a)) <= 1e-12 * scale, what          # measured 1e-20 ... 1e-15: summation order only
-    for ne_d, cost_d, x_d in runs[1:]:
-        for p0, p1 in zip(runs[0][0], ne_d):
+    ne_j, fb_j = _normal_equations(prob, x0, True, monkeypatch)
+    assert fb_j                                                               # (the detection-major kernel says what it is)
+    runs = [_normal_equations(prob, x0, False, monkeypatch) for _ in range(3)]
+    for part_j, part_w, what in zip(ne_j, runs[0][0], ('gradient', 'camera blocks', 'band', 'cross block')):
+        scale = np.max(np.abs(part_j))
+        assert np.max(np.abs(part_w - part_j)) <= 1e-12 * scale, what          # measured 1e-16 ... 1e-15: summation order only
+    for ne_w, fb in runs:
+        assert not fb
+        for p0, p1 in zip(runs[0][0], ne_w):
             assert np.array_equal(p0, p1)                                       # the same bits, run to run
-        assert cost_d == runs[0][1] and np.array_equal(x_d, runs[0][2])
-    assert abs(runs[0][1] - cost_a) <= 1e-9 * cost_a                            # and the same optimisation as the atomic mode
+    sols = [solve() for _ in range(3)]
+    for cost, x in sols[1:]:
+        assert cost == sols[0][0] and np.array_equal(x, sols[0][1])
+    monkeypatch.setenv('MVUS_ASM_ATOMIC', '1')                                 # the round-3 kernel: the same optimisation
+    with ba.BAHandle(prob) as h:
+        cost_a = h.solve(x0, solver=ba.SOLVER_LM_SCHUR, jac_mode=ba.JAC_ANALYTIC, max_nfev=6).cost
+        assert h.deterministic_fallback()
+    assert abs(sols[0][0] - cost_a) <= 1e-9 * cost_a
+
+
+@pytest.mark.parametrize('win', [1, 2, 3, 5, 7, 11, 16, 21])
+def test_every_window_length(win, monkeypatch):
+    """Window lengths from one control point (21 lanes per output row) to 21 (one lane per row): the same normal equations."""
+    from mvus_amd import problem as mp, synth
+    kw = dict(synth.BASELINE_CONFIGS[1]); kw.update(total_obs=30_000)
+    prob, x0 = mp.problem_from_scene(synth.make_scene(**kw))
+    ne_j, _ = _normal_equations(prob, x0, True, monkeypatch)
+    monkeypatch.setenv('MVUS_WIN', str(win))
+    ne_w, fb = _normal_equations(prob, x0, False, monkeypatch)
+    assert not fb
+    for part_j, part_w in zip(ne_j, ne_w):
+        assert np.max(np.abs(part_w - part_j)) <= 1e-12 * np.max(np.abs(part_j))
 
 
 def test_forty_fresh_handles_one_outcome():
     """tools/micro/loop_lm_configs.py as a test: 40 fresh handles, eight-evaluation LM solves on a rolling-shutter scene with motion
-    regulariser -- ONE (cost, x) with the deterministic assembly (with atomics: as many outcomes as handles)."""
-    import hashlib
+    regulariser -- ONE (cost, x) (round 3's default assembly with atomics: as many outcomes as handles)."""
     from mvus_amd import ba, problem as mp, synth
     kw = dict(synth.BASELINE_CONFIGS[1]); kw.update(total_obs=50_000)
     prob, x0 = mp.problem_from_scene(synth.make_scene(**kw))
     seen = set()
     for _ in range(40):
         with ba.BAHandle(prob) as h:
-            h.set_deterministic(True)
             r = h.solve(x0, solver=ba.SOLVER_LM_SCHUR, jac_mode=ba.JAC_ANALYTIC, max_nfev=8)
             assert not h.deterministic_fallback()
             seen.add((repr(r.cost), hashlib.sha1(np.ascontiguousarray(r.x).tobytes()).hexdigest()))
     assert len(seen) == 1
 
 
-def test_sparse_tracks_fall_back_and_say_so():
-    """configs[2] thinned to 0.75 detections per knot span and camera: 128 consecutive detections of a camera reach over ~170 control
-    points, more than a window holds -- those workgroups keep the atomic path, the handle reports it, the normal equations are the
-    atomic mode's to rounding; the full-size configuration does not fall back."""
+def _reverse_camera(prob, cam):
+    """The same problem with the detections of one camera in reverse (descending frame) order; returns it and the row permutation
+    that maps its residual vector onto the original's."""
+    import dataclasses
+    p = dataclasses.replace(prob)
+    off = prob.det_offsets
+    a, b = int(off[cam]), int(off[cam + 1])
+    idx = np.arange(prob.M)
+    idx[a:b] = idx[a:b][::-1]
+    p.frame, p.u_raw, p.v_raw = prob.frame[idx].copy(), prob.u_raw[idx].copy(), prob.v_raw[idx].copy()
+    rows = np.arange(prob.n_residuals)
+    Mc = b - a
+    rows[2 * a:2 * a + Mc] = rows[2 * a:2 * a + Mc][::-1]
+    rows[2 * a + Mc:2 * a + 2 * Mc] = rows[2 * a + Mc:2 * a + 2 * Mc][::-1]
+    return p, rows
+
+
+@pytest.mark.parametrize('cfg', [0, 1])
+def test_detections_out_of_time_order(cfg, monkeypatch):
+    """One camera's detections in descending frame order: residuals, J^T u (the TRF path's deterministic two-pass product whose
+    window walk used to be clipped), the normal equations and both solvers agree with the time-ordered problem."""
     from mvus_amd import ba, problem as mp, synth
-    for obs, expect in ((120_000, True), (504_399, False)):
-        kw = dict(synth.BASELINE_CONFIGS[2]); kw.update(total_obs=obs)
-        prob, x0 = mp.problem_from_scene(synth.make_scene(**kw))
-        with ba.BAHandle(prob) as h:
-            assert h.deterministic_fallback() is False
-            h.residual_jacobian(x0)
-            ne_a = h.normal_equations()
-            h.set_deterministic(True)
-            ne_d = h.normal_equations()
-            assert h.deterministic_fallback() is expect
-            for a, d in zip(ne_a, ne_d):
-                assert np.max(np.abs(a - d)) <= 1e-12 * np.max(np.abs(a))
-
-
-def test_scene_setting_switches_the_mode():
-    """settings['ba_deterministic'] with ba_solver 'lm': two Scene.BA calls from the same state end with identical parameters."""
-    from mvus_amd import pipeline, synth
-    kw = dict(synth.BASELINE_CONFIGS[1])
-    for k in ('seed', 'num_cam', 'total_obs', 'num_intervals'):
-        kw.pop(k, None)
-    kw['motion_weights'] = 1e2
-    ends = []
-    for _ in range(2):
-        flight, _sc = pipeline.staged_scene(4, 30_000, seed=4, settings={'ba_solver': 'lm', 'ba_deterministic': True}, perturb=0.3, **kw)
-        flight.BA(2, max_iter=6, rs=True, motion_reg=True, motion_weights=1e2)
-        ends.append(flight)
-    for i in flights_cams(ends[0]):
-        a, b = ends[0].cameras[i], ends[1].cameras[i]
-        assert np.array_equal(a.R, b.R) and np.array_equal(a.t, b.t)
-    assert all(np.array_equal(a[1], b[1]) for a, b in zip(ends[0].spline['tck'], ends[1].spline['tck']))
-    assert np.array_equal(ends[0].alpha, ends[1].alpha) and np.array_equal(ends[0].beta, ends[1].beta)
-
-
-def flights_cams(flight):
-    return list(flight.sequence[:2])
+    kw = dict(synth.BASELINE_CONFIGS[cfg])
+    if cfg == 1:
+        kw.update(total_obs=20_000)
+    prob, x0 = mp.problem_from_scene(synth.make_scene(**kw))
+    rprob, rows = _reverse_camera(prob, 1)
+    rng = np.random.default_rng(3)
+    u = rng.standard_normal(prob.n_residuals)
+    with ba.BAHandle(prob) as h, ba.BAHandle(rprob) as hr:
+        f = h.residual(x0)
+        fr = hr.residual(x0)
+        assert np.array_equal(fr, f[rows])
+        h.residual_jacobian(x0); hr.residual_jacobian(x0)
+        z, zr = h.jtu(u), hr.jtu(u[rows])
+        assert np.max(np.abs(z - zr)) <= 1e-12 * np.max(np.abs(z))
+        ne, ner = h.normal_equations(), hr.normal_equations()
+        assert not h.deterministic_fallback() and hr.deterministic_fallback()
+        for p0, p1 in zip(ne, ner):
+            assert np.max(np.abs(p0 - p1)) <= 1e-12 * np.max(np.abs(p0))
+        # (LM: the same steps to rounding.  TRF + LSMR: the residual vector is a permutation of the other problem's, so every dot
+        # product rounds differently and LSMR amplifies that by ~10x per iteration or two -- the same optimisation, not the same digits)
+        for solver, jac, tol in ((ba.SOLVER_LM_SCHUR, ba.JAC_ANALYTIC, 1e-9), (ba.SOLVER_TRF_LSMR, ba.JAC_PATTERN, 1e-4)):
+            r, rr = h.solve(x0, solver=solver, jac_mode=jac, max_nfev=6), hr.solve(x0, solver=solver, jac_mode=jac, max_nfev=6)
+            assert abs(r.cost - rr.cost) <= tol * r.cost
