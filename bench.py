@@ -99,6 +99,9 @@ def main():
     ap.add_argument('--no-parity-solver', action='store_true', help='skip the extra timing of the scipy-TRF+LSMR restatement')
     ap.add_argument('--obs', type=int, default=None, help='override the detection count of the config (kernel studies at other sizes; the workload string says so)')
     ap.add_argument('--shard', choices=['time', 'obs'], default=None, help='N>1: how observations are cut over the ranks (default: time for lm, obs for trf)')
+    ap.add_argument('--collective', choices=['rccl', 'torch'], default=None,
+                    help='N>1: rccl = ncclAllReduce called by the library on its own communicator (default on a multi-GPU node), '
+                         'torch = the callback through torch.distributed (the only route of the one-device gloo flow test)')
     args = ap.parse_args()
 
     import numpy as np
@@ -142,7 +145,8 @@ def main():
     prob, x0 = mp.problem_from_scene(scene)
     shard_mode = args.shard or ('time' if args.solver == 'lm' else 'obs')
     if world > 1:
-        handle, _ = sharded_handle(prob, rank, world, local_rank, time_x=x0 if shard_mode == 'time' else None)
+        collective = args.collective or ('torch' if one_device else 'rccl')
+        handle, _ = sharded_handle(prob, rank, world, local_rank, time_x=x0 if shard_mode == 'time' else None, collective=collective)
     else:
         handle = ba.BAHandle(prob, device=local_rank)
     solver = ba.SOLVER_LM_SCHUR if args.solver == 'lm' else ba.SOLVER_TRF_LSMR
@@ -187,22 +191,38 @@ def main():
     bytes_launch = handle.prob.M * per_obs + once
     achieved = bytes_launch / (t_rj * 1e-3) / 1e9
 
-    # the reference-faithful solver (scipy TRF + LSMR restated) on the same workload, a few steps, for the record
+    # the reference-faithful solver (scipy TRF + LSMR restated) on the same workload, a few steps, for the record: with the
+    # Jacobian `Scene.BA` uses BY DEFAULT (scipy's grouped 2-point finite differences, MVUS_JAC_FD: what a user of an unmodified
+    # config.json gets) and with the analytic Jacobian masked to the reference's pattern (MVUS_JAC_PATTERN)
     parity = None
     if world == 1 and not args.no_parity_solver and args.solver == 'lm':      # (an N=1 report, like the CPU baseline)
-        xs = x0.copy()
-        handle.solve(xs, solver=ba.SOLVER_TRF_LSMR, jac_mode=ba.JAC_PATTERN, max_nfev=2, return_fun=False, ties='canonical')
-        barrier()
-        tp = time.perf_counter()
-        nsteps, its = 3, 0
-        for _ in range(nsteps):
-            rp = handle.solve(xs, solver=ba.SOLVER_TRF_LSMR, jac_mode=ba.JAC_PATTERN, max_nfev=2, return_fun=False, ties='canonical')
-            xs = rp.x
-            its += rp.lin_iters
-        barrier()
-        dtp = time.perf_counter() - tp
-        parity = {'solver': 'trf_lsmr (scipy restatement, pattern-masked J)', 'ms_per_step': 1e3 * dtp / nsteps,
-                  'ba_iters_per_sec': nsteps / dtp, 'residuals_per_sec': prob.M * nsteps / dtp, 'lsmr_its_per_step': its / nsteps}
+        def timed(jm, prepare, nsteps=3):
+            xs = x0.copy()
+            t_prep = time.perf_counter()
+            prepare(xs)                                  # the pattern at x0 (and the column groups): once, like least_squares' jac_sparsity
+            t_prep = time.perf_counter() - t_prep
+            handle.solve(xs, solver=ba.SOLVER_TRF_LSMR, jac_mode=jm, max_nfev=2, return_fun=False, prepared=True)
+            barrier()
+            tp = time.perf_counter()
+            its = 0
+            for _ in range(nsteps):
+                rp = handle.solve(xs, solver=ba.SOLVER_TRF_LSMR, jac_mode=jm, max_nfev=2, return_fun=False, prepared=True)
+                xs = rp.x
+                its += rp.lin_iters
+            barrier()
+            dtp = time.perf_counter() - tp
+            return {'ms_per_step': 1e3 * dtp / nsteps, 'ba_iters_per_sec': nsteps / dtp, 'residuals_per_sec': prob.M * nsteps / dtp,
+                    'lsmr_its_per_step': its / nsteps, 'one_time_pattern_setup_ms': 1e3 * t_prep}
+        ngroups = [0]
+        def prep_fd(xs):
+            ngroups[0] = handle.prepare_fd(xs, ties='canonical')
+        fd = timed(ba.JAC_FD, prep_fd)
+        fd.update({'solver': 'trf_lsmr, jac = scipy 2-point finite differences with column groups (the DEFAULT of Scene.BA; common.py:670)',
+                   'column_groups': ngroups[0]})
+        pat = timed(ba.JAC_PATTERN, lambda xs: handle.set_pattern(xs, download=False))
+        pat['solver'] = 'trf_lsmr (scipy restatement, analytic J masked to the reference pattern)'
+        parity = dict(pat)
+        parity['default_fd'] = fd
 
     traffic = None
     tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')

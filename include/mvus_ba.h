@@ -236,6 +236,19 @@ int mvus_ba_remove_outliers(mvus_ba* h, const double* x, double thres, uint8_t* 
  * replicated terms (motion rows, damping) exactly once. */
 int mvus_ba_set_allreduce(mvus_ba* h, mvus_allreduce_fn fn, void* user, int32_t is_root);
 
+/* The same sums by RCCL called from the library itself (no host language in the iteration): every collective is one
+ * ncclAllReduce(double, sum, in place) on the handle's stream.  One rank obtains an id with mvus_rccl_unique_id (128 bytes, RCCL's
+ * ncclUniqueId) and hands it to the others by any means (a torch.distributed / MPI broadcast, a file); every rank then calls
+ * mvus_ba_set_rccl, which joins the communicator (ncclCommInitRank: collective, blocks until all `world` ranks have called) on the
+ * handle's device.  librccl.so.1 is opened at run time (the copy the process already holds -- e.g. PyTorch's -- else the loader's):
+ * the library has no link-time dependency on it and MVUS_E_COMM reports its absence.  Replaces a callback set earlier; is_root as
+ * above.  The sums of a given topology are RCCL's: the same bits on every run.  SURVEY 8e's collective; no reference counterpart. */
+int mvus_rccl_unique_id(uint8_t id_out[128]);
+int mvus_ba_set_rccl(mvus_ba* h, const uint8_t id[128], int32_t rank, int32_t world, int32_t is_root);
+/* Measurement hook: `reps` back-to-back sums of `count` doubles (a scratch buffer) through the route installed on the handle (the
+ * callback or RCCL) between two hipEvents; average milliseconds per collective. */
+int mvus_ba_time_allreduce(mvus_ba* h, int64_t count, int32_t reps, double* avg_ms);
+
 /* Time sharding for the LM/Schur solver ("shard by time range"): this handle was created with the
  * detections of ONE time slice and owns the spline control points [ctrl_cuts[rank], ctrl_cuts[rank+1]) (global
  * control-point indices over all splines, ctrl_cuts[0] = 0, ctrl_cuts[world] = N; every rank passes the same array).

@@ -83,6 +83,9 @@ API = [
     ('mvus_ba_outlier_mask', ctypes.c_int, [ctypes.c_void_p, c_double_p, ctypes.c_double, c_uint8_p]),
     ('mvus_ba_remove_outliers', ctypes.c_int, [ctypes.c_void_p, c_double_p, ctypes.c_double, c_uint8_p, c_int64_p]),
     ('mvus_ba_set_allreduce', ctypes.c_int, [ctypes.c_void_p, ALLREDUCE_FN, ctypes.c_void_p, ctypes.c_int32]),
+    ('mvus_rccl_unique_id', ctypes.c_int, [c_uint8_p]),
+    ('mvus_ba_set_rccl', ctypes.c_int, [ctypes.c_void_p, c_uint8_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
+    ('mvus_ba_time_allreduce', ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, c_double_p]),
     ('mvus_ba_set_time_shard', ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, c_int32_p, ctypes.c_int32]),
     ('mvus_ba_time_kernel', ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, c_double_p]),
     ('mvus_ba_set_x', ctypes.c_int, [ctypes.c_void_p, c_double_p]),
@@ -132,6 +135,16 @@ def load(path=None):
 
 def dptr(a):
     return a.ctypes.data_as(c_double_p)
+
+
+def rccl_unique_id():
+    """128 bytes (RCCL's ncclUniqueId) from mvus_rccl_unique_id: obtained by ONE rank, handed to all of them (mvus_ba_set_rccl)."""
+    lib = load()
+    buf = (ctypes.c_uint8 * 128)()
+    rc = lib.mvus_rccl_unique_id(buf)
+    if rc != MVUS_OK:
+        raise RuntimeError('mvus_rccl_unique_id failed (%d): %s' % (rc, lib.mvus_last_error(None).decode()))
+    return bytes(buf)
 
 
 def make_problem_struct(prob, device=0, stream=None):

@@ -44,7 +44,7 @@ class BAHandle:
         # not while the interpreter shuts down: modules (and torch's own HIP state) are torn down in no particular order then, and
         # a handle that dies with the process needs no hipFree -- one GPU-suite run in eleven ended with a fatal signal after its
         # summary line before this guard
-        if sys.is_finalizing():
+        if sys is None or sys.is_finalizing():       # (module globals are already gone late in the shutdown)
             return
         try:
             self.close()
@@ -191,13 +191,16 @@ class BAHandle:
         return p
 
     def solve(self, x0, solver=SOLVER_TRF_LSMR, jac_mode=JAC_PATTERN, max_nfev=10, opts=None, return_fun=True,
-              ties='numpy', matrix=None):
+              ties='numpy', matrix=None, prepared=False):
         """The least_squares call of Scene.BA.  Returns an OptimizeResult-like namespace
         (x, cost, fun, nfev, njev, status, optimality, ...).  ``ties`` / ``matrix``: how the reference pattern of the
-        JAC_PATTERN / JAC_FD modes is fixed at x0 (see prepare_pattern)."""
+        JAC_PATTERN / JAC_FD modes is fixed at x0 (see prepare_pattern); ``prepared``: the pattern (and column groups) set by an
+        earlier prepare_pattern / prepare_fd stay in force (a run of steps with ONE pattern, as least_squares keeps its jac_sparsity)."""
         x = np.array(self._x(x0, self.n))
         o = opts if opts is not None else _lib.default_opts(solver, jac_mode, max_nfev)
-        if o.jac_mode == JAC_FD:
+        if prepared and o.jac_mode in (JAC_FD, JAC_PATTERN):
+            pass
+        elif o.jac_mode == JAC_FD:
             self.prepare_fd(x, ties, matrix)
         elif o.jac_mode == JAC_PATTERN and (matrix is not None or ties != 'canonical'):
             self.prepare_pattern(x, ties, matrix)
@@ -270,6 +273,20 @@ class BAHandle:
                     return 1
             self._cb = _lib.ALLREDUCE_FN(tramp)
         self._check(self.lib.mvus_ba_set_allreduce(self.h, self._cb, None, int(bool(is_root))), 'mvus_ba_set_allreduce')
+
+
+    def set_rccl(self, unique_id, rank, world, is_root=True):
+        """The sums over the ranks by RCCL called from the library (ncclAllReduce on the handle's stream; no Python in the iteration).
+        ``unique_id``: the 128 bytes of _lib.rccl_unique_id() of ONE rank; collective -- returns once all ``world`` ranks have joined."""
+        buf = (ctypes.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
+        self._cb = None
+        self._check(self.lib.mvus_ba_set_rccl(self.h, buf, int(rank), int(world), int(bool(is_root))), 'mvus_ba_set_rccl')
+
+    def time_allreduce(self, count, reps=50):
+        """Average milliseconds per sum of ``count`` doubles through the installed route (callback or RCCL), HIP events on the handle's stream."""
+        ms = ctypes.c_double(0.0)
+        self._check(self.lib.mvus_ba_time_allreduce(self.h, int(count), int(reps), ctypes.byref(ms)), 'mvus_ba_time_allreduce')
+        return ms.value
 
 
 # kernel ids of mvus_ba_time_kernel

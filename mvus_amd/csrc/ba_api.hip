@@ -5,7 +5,9 @@
 
 #include <chrono>
 #include <cstring>
+#include <dlfcn.h>
 #include <map>
+#include <mutex>
 #include <memory>
 #include <string>
 #include <vector>
@@ -616,10 +618,14 @@ struct HipBackend {
 
 using namespace mvus;
 
+struct mvus_rccl_comm;
+struct mvus_rccl_id { char internal[128]; };     // ncclUniqueId of rccl.h (passed by value to ncclCommInitRank)
+struct mvus_rccl_handle { void* comm = nullptr; };
 struct mvus_ba {
   HipBackend be;
   std::unique_ptr<HipSchur<HipBackend>> schur;   // normal-equation workspace, built on first use
-  ~mvus_ba() { schur.reset(); }
+  mvus_rccl_handle rccl;                         // communicator of mvus_ba_set_rccl (destroyed with the handle)
+  ~mvus_ba();
 };
 
 static thread_local std::string g_create_error;
@@ -1132,6 +1138,102 @@ int mvus_ba_set_allreduce(mvus_ba* h, mvus_allreduce_fn fn, void* user, int32_t 
       be.reduce(be.scal_dev + 2, 1);
       be.m_glob = (int64_t)(be.read_slot(2) + 0.5);
     }
+    return MVUS_OK;
+  });
+}
+
+// ---- RCCL from the library: librccl.so.1 opened at run time, five entry points ----
+namespace {
+struct RcclApi {
+  void* lib = nullptr;
+  int (*GetUniqueId)(void*) = nullptr;
+  int (*CommInitRank)(void**, int, mvus_rccl_id, int) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  std::string err;
+  bool load() {
+    if (lib) return true;
+    lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!lib) { err = std::string("librccl.so.1 cannot be opened: ") + dlerror(); return false; }
+    GetUniqueId = reinterpret_cast<decltype(GetUniqueId)>(dlsym(lib, "ncclGetUniqueId"));
+    CommInitRank = reinterpret_cast<decltype(CommInitRank)>(dlsym(lib, "ncclCommInitRank"));
+    AllReduce = reinterpret_cast<decltype(AllReduce)>(dlsym(lib, "ncclAllReduce"));
+    CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
+    GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
+    if (!GetUniqueId || !CommInitRank || !AllReduce || !CommDestroy) { err = "librccl.so.1 lacks ncclGetUniqueId / ncclCommInitRank / ncclAllReduce / ncclCommDestroy"; dlclose(lib); lib = nullptr; return false; }
+    return true;
+  }
+  std::string what(int rc) const { return GetErrorString ? std::string(GetErrorString(rc)) : ("ncclResult " + std::to_string(rc)); }
+};
+RcclApi g_rccl;
+std::mutex g_rccl_mutex;
+constexpr int kNcclFloat64 = 8, kNcclSum = 0;      // ncclDataType_t / ncclRedOp_t of rccl.h
+}  // namespace
+
+static int rccl_allreduce_cb(void* user, void* buf, size_t count, void* stream) {
+  mvus_rccl_handle* c = static_cast<mvus_rccl_handle*>(user);
+  return g_rccl.AllReduce(buf, buf, count, kNcclFloat64, kNcclSum, c->comm, static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"
+mvus_ba::~mvus_ba() {
+  schur.reset();
+  if (rccl.comm && g_rccl.CommDestroy) { (void)hipStreamSynchronize(be.stream); (void)g_rccl.CommDestroy(rccl.comm); }
+}
+extern "C" {
+
+int mvus_rccl_unique_id(uint8_t id_out[128]) {
+  if (!id_out) return MVUS_E_INVALID;
+  std::lock_guard<std::mutex> lock(g_rccl_mutex);
+  if (!g_rccl.load()) { g_create_error = g_rccl.err; return MVUS_E_COMM; }
+  mvus_rccl_id id;
+  const int rc = g_rccl.GetUniqueId(&id);
+  if (rc != 0) { g_create_error = "ncclGetUniqueId: " + g_rccl.what(rc); return MVUS_E_COMM; }
+  std::memcpy(id_out, id.internal, 128);
+  return MVUS_OK;
+}
+
+int mvus_ba_set_rccl(mvus_ba* h, const uint8_t id[128], int32_t rank, int32_t world, int32_t is_root) {
+  return guarded(h, [&] {
+    HipBackend& be = h->be;
+    if (!id || world < 1 || rank < 0 || rank >= world) { be.err = "set_rccl: bad arguments"; return MVUS_E_INVALID; }
+    {
+      std::lock_guard<std::mutex> lock(g_rccl_mutex);
+      if (!g_rccl.load()) { be.err = g_rccl.err; return MVUS_E_COMM; }
+    }
+    if (h->rccl.comm) { g_rccl.CommDestroy(h->rccl.comm); h->rccl.comm = nullptr; }
+    mvus_rccl_id uid;
+    std::memcpy(uid.internal, id, 128);
+    MVUS_HIP(hipStreamSynchronize(be.stream));
+    const int rc = g_rccl.CommInitRank(&h->rccl.comm, world, uid, rank);
+    if (rc != 0) { h->rccl.comm = nullptr; be.err = "ncclCommInitRank: " + g_rccl.what(rc); return MVUS_E_COMM; }
+    return mvus_ba_set_allreduce(h, rccl_allreduce_cb, &h->rccl, is_root);
+  });
+}
+
+int mvus_ba_time_allreduce(mvus_ba* h, int64_t count, int32_t reps, double* avg_ms) {
+  return guarded(h, [&] {
+    HipBackend& be = h->be;
+    if (count < 1 || reps < 1 || !avg_ms) { be.err = "bad arguments"; return MVUS_E_INVALID; }
+    if (!be.allreduce) { be.err = "time_allreduce: no all-reduce route installed"; return MVUS_E_INVALID; }
+    PoolGuard<HipBackend> pool(be);
+    double* buf = pool.get(count);
+    be.fill(buf, 0.0, count);
+    hipEvent_t e0, e1;
+    MVUS_HIP(hipEventCreate(&e0)); MVUS_HIP(hipEventCreate(&e1));
+    float ms = 0;
+    try {
+      for (int i = 0; i < 3; ++i) be.reduce(buf, (size_t)count);
+      MVUS_HIP(hipEventRecord(e0, be.stream));
+      for (int i = 0; i < reps; ++i) be.reduce(buf, (size_t)count);
+      MVUS_HIP(hipEventRecord(e1, be.stream));
+      MVUS_HIP(hipEventSynchronize(e1));
+      MVUS_HIP(hipEventElapsedTime(&ms, e0, e1));
+    } catch (...) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); throw; }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *avg_ms = (double)ms / reps;
     return MVUS_OK;
   });
 }

@@ -49,12 +49,27 @@ def make_gpu_allreduce(device_index, group=None):
     return fn
 
 
-def sharded_handle(prob, rank, world, device_index, group=None, time_x=None, halo=8):
+def join_rccl(handle, rank, world, group=None, is_root=None):
+    """Native route: rank 0 asks the library for an RCCL id, torch.distributed (whatever its backend) hands the 128 bytes to the
+    other ranks -- once -- and every rank joins the library's own communicator; from then on the iteration's sums are
+    ncclAllReduce calls made by the library on the handle's stream."""
+    import torch.distributed as dist
+    from . import _lib
+    box = [_lib.rccl_unique_id() if rank == 0 else None]
+    if world > 1:
+        dist.broadcast_object_list(box, src=0, group=group)
+    handle.set_rccl(box[0], rank, world, is_root=(rank == 0) if is_root is None else is_root)
+
+
+def sharded_handle(prob, rank, world, device_index, group=None, time_x=None, halo=8, collective='torch'):
     """BAHandle over observation shard ``rank`` of ``world`` on ``cuda:device_index``.
 
     ``time_x`` given (the start parameters): shard by TIME (BAProblem.shard_time + mvus_ba_set_time_shard) -- the
     LM/Schur solver then exchanges a few MB per iteration instead of the whole cross block; every rank must pass the
     same ``time_x``.  Without it every camera's detections are cut into ``world`` pieces (any solver).
+
+    ``collective``: 'torch' = the all-reduce callback (torch.distributed on aliased device buffers: any backend, gloo on CPU
+    boxes), 'rccl' = RCCL called from the library on its own communicator (the route bench.py takes on a multi-GPU node).
 
     The handle runs on torch's current stream of that device so that its kernels and the collective are
     ordered without extra events.  Motion-regulariser rows are replicated inputs but must be counted
@@ -72,9 +87,12 @@ def sharded_handle(prob, rank, world, device_index, group=None, time_x=None, hal
     if cuts is not None:
         h.set_time_shard(rank, world, cuts, halo)
     if world > 1 or group is not None:
-        cb = make_gpu_allreduce(device_index, group)
-        h.set_allreduce(cb, is_root=(rank == 0))
-        h.allreduce_stats = cb.stats
+        if collective == 'rccl':       # ncclAllReduce called by the library itself (mvus_ba_set_rccl)
+            join_rccl(h, rank, world, group)
+        else:                          # the callback: torch.distributed on tensors aliasing the library's buffers (any backend)
+            cb = make_gpu_allreduce(device_index, group)
+            h.set_allreduce(cb, is_root=(rank == 0))
+            h.allreduce_stats = cb.stats
     return h, keep
 
 

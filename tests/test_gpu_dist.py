@@ -39,6 +39,32 @@ def test_allreduce_hook_with_rccl_world1():
         dist.destroy_process_group()
 
 
+def test_rccl_called_by_the_library_world1():
+    """mvus_rccl_unique_id / mvus_ba_set_rccl: the library opens librccl.so.1, joins its own communicator (world 1 on these boxes) and
+    every sum of both solvers is an ncclAllReduce on the handle's stream -- no callback, no torch.distributed in the iteration."""
+    from mvus_amd.ba import BAHandle
+    from mvus_amd.dist import join_rccl
+    scene, g = load_case('rs_F_2int_3cam')
+    prob, x0 = mp.problem_from_scene(scene)
+    uid = _lib.rccl_unique_id()
+    assert len(uid) == 128 and any(uid)
+    opts = _lib.default_opts(_lib.SOLVER_TRF_LSMR, _lib.JAC_PATTERN, 6)
+    opts.lsmr_maxiter = 4
+    with BAHandle(prob) as h0, BAHandle(prob) as h:
+        join_rccl(h, 0, 1)
+        assert h.time_allreduce(1000, 5) >= 0.0
+        r0, r1 = h0.solve(g['x0'], opts=opts), h.solve(g['x0'], opts=opts)
+        np.testing.assert_allclose(r1.cost, r0.cost, rtol=1e-12)
+        np.testing.assert_allclose(r1.x, r0.x, rtol=0, atol=1e-10)
+        l0 = h0.solve(g['x0'], solver=_lib.SOLVER_LM_SCHUR, jac_mode=_lib.JAC_ANALYTIC, max_nfev=6)
+        l1 = h.solve(g['x0'], solver=_lib.SOLVER_LM_SCHUR, jac_mode=_lib.JAC_ANALYTIC, max_nfev=6)
+        np.testing.assert_allclose(l1.cost, l0.cost, rtol=1e-12)
+        np.testing.assert_allclose(l1.x, l0.x, rtol=0, atol=1e-10)
+    with BAHandle(prob) as h:                      # bad arguments are an error code, not a crash
+        with pytest.raises(ValueError):
+            h.set_rccl(uid, 3, 2)
+
+
 @pytest.mark.parametrize('solver', ['trf', 'lm'])
 @pytest.mark.parametrize('case', ['rs_F_2int_3cam', 'calib_KE_bounds_3cam'])
 def test_two_shards_on_one_gpu_match_unsharded(solver, case):
