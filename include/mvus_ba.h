@@ -40,6 +40,8 @@ extern "C" {
 #define MVUS_E_HIP (-2)      /* HIP runtime error (no device, allocation, launch) */
 #define MVUS_E_NUMERIC (-3)  /* non-finite residuals at x0, x0 outside bounds (scipy raises ValueError) */
 #define MVUS_E_COMM (-4)     /* the all-reduce callback reported a failure */
+#define MVUS_E_UNSUPPORTED (-5)  /* the problem is outside what this solver handles (MVUS_SOLVER_LM_SCHUR: motion rows that couple control
+                                 * points more than 16 apart, or more than 6 apart on a time shard): the other solver has no such limit */
 
 #define MVUS_MOTION_F 0  /* constant-force prior       common.py:984-998 */
 #define MVUS_MOTION_KE 1 /* constant-kinetic-energy    common.py:976-981 */
@@ -104,7 +106,9 @@ typedef struct mvus_solve_opts {
   double lm_lambda_min; /* MVUS_SOLVER_LM_SCHUR: floor of the Marquardt damping (3e-3; 0 = none).  Directions the data does
                            not determine (a control point seen by one camera: depth along its rays; rs against beta when the
                            image row hardly varies) have curvature << lambda * diag(H) and stay where they are instead of
-                           following the noise -- the effect the reference gets from LSMR's truncated solves (common.py:670) */
+                           following the noise -- the effect the reference gets from LSMR's truncated solves (common.py:670).
+                           Problems whose motion rows reach over more than six control points (knots less than a frame apart: more
+                           control points than detections) use at least 0.3 */
 } mvus_solve_opts;
 
 /* scipy.optimize.OptimizeResult fields Scene.BA returns (common.py:670,697) */

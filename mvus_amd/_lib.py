@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('MVUS_LIB_PATH') or os.path.join(_HERE, 'csrc', 'libmvusba.so')   # override: kernel experiments
 
 MVUS_OK = 0
-MVUS_E_INVALID, MVUS_E_HIP, MVUS_E_NUMERIC, MVUS_E_COMM = -1, -2, -3, -4
+MVUS_E_INVALID, MVUS_E_HIP, MVUS_E_NUMERIC, MVUS_E_COMM, MVUS_E_UNSUPPORTED = -1, -2, -3, -4, -5
 JAC_ANALYTIC, JAC_PATTERN, JAC_FD = 0, 1, 2
 PAT_SHIFT, PAT_TIE = 25, 1 << 30          # pattern codes of mvus_ba_set_pattern (include/mvus_ba.h)
 SOLVER_TRF_LSMR, SOLVER_LM_SCHUR = 0, 1
@@ -182,5 +182,5 @@ def default_opts(solver=SOLVER_TRF_LSMR, jac_mode=JAC_PATTERN, max_nfev=10):
     o.ftol, o.xtol, o.gtol = 1e-8, 1e-12, 1e-8
     o.lsmr_atol, o.lsmr_btol, o.lsmr_conlim, o.lsmr_maxiter = 1e-6, 1e-6, 1e8, 0
     o.verbose = 0
-    o.lm_lambda_min = 3e-3
+    o.lm_lambda_min = float(os.environ.get('MVUS_LM_LAMBDA_MIN', 3e-3))       # (the environment variable: experiments only)
     return o

@@ -14,8 +14,12 @@ import numpy as np
 from . import _lib
 from ._lib import JAC_ANALYTIC, JAC_FD, JAC_PATTERN, SOLVER_LM_SCHUR, SOLVER_TRF_LSMR  # noqa: F401 (re-exported)
 
+class UnsupportedBySolver(RuntimeError):
+    """MVUS_E_UNSUPPORTED: the problem is outside what the chosen solver handles (see include/mvus_ba.h); the other solver has no such limit."""
+
+
 _ERRORS = {_lib.MVUS_E_INVALID: ValueError, _lib.MVUS_E_NUMERIC: ValueError, _lib.MVUS_E_HIP: RuntimeError,
-           _lib.MVUS_E_COMM: RuntimeError}
+           _lib.MVUS_E_COMM: RuntimeError, _lib.MVUS_E_UNSUPPORTED: UnsupportedBySolver}
 
 
 class BAHandle:

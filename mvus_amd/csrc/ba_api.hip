@@ -298,7 +298,9 @@ struct HipBackend {
     }
     return xmir_dev[k];
   }
-  const double* mirror_host(int k) const { return xmir_host[k]; }
+  // (the mirror of slot k holds the trial point only while the trial kernel writes it: not once an all-reduce route was installed on
+  // a handle that had solved on one rank before -- the caller then downloads x)
+  const double* mirror_host(int k) const { return scal_direct() ? xmir_host[k] : nullptr; }
   void adopt_residual(double*& f_dev, double*& f_new) {       // both are pool buffers of one size class
     if (f_dev == f_cur) f_cur = f_new;
     std::swap(f_dev, f_new);
@@ -1077,6 +1079,12 @@ int mvus_ba_solve(mvus_ba* h, double* x, const mvus_solve_opts* opts, mvus_resul
       if (be.hp.C * (3 + be.hp.P) > 1152) throw HipError{"LM_SCHUR: reduced camera system larger than 1152 unknowns"};
       if (!h->schur) h->schur.reset(new HipSchur<HipBackend>(be));
       so.lm_lambda0 = be.lm_lambda; so.lm_nu0 = be.lm_nu;
+      // knots closer than a frame (band wider than six control points): more control points than detections -- the spline is
+      // held by the motion regulariser alone between the data, and a converging LM whose damping falls to 3e-3 diag(H) follows
+      // noise along those directions (the incremental loop then ends 3 m off; with 0.3 it ends where TRF + LSMR ends:
+      // profiles/r04_loop_lm_wide_band_damping.txt).  The floor of such problems is at least kLambdaMinWide.
+      constexpr double kLambdaMinWide = 0.3;
+      if (h->schur->wide) so.lm_lambda_min = std::max(so.lm_lambda_min, kLambdaMinWide);
       sr = lm_schur(be, *h->schur, xv, lb, ub, so, be.f_cur);
       if (!sr.error) { be.lm_lambda = std::min(std::max(sr.lm_lambda, 1e-12), 1e6); be.lm_nu = std::min(sr.lm_nu, 1024.0); }
       if (sr.jac_stale) be.has_jacobian = false;      // mvus_ba_jv / jtu / lm_step must not pair J(x_old) with f(x_new)
@@ -1536,7 +1544,7 @@ static int spline_fit_run(mvus_spline_fit& S, double s, int32_t* n_out, double* 
     std::vector<int> nrdata;
     size_t& cap = S.cap;
     auto ensure = [&](size_t need) {                      // between passes only: the device arrays hold nothing that outlives a pass
-      if (need <= cap) return;
+      if (need <= cap || cap >= (size_t)nest) return;     // (nest = m + 6 knots is all FITPACK can ever ask for: nothing to grow to)
       size_t c = std::max<size_t>(cap, 1024);
       while (c < need) c *= 4;
       cap = std::min<size_t>(c, (size_t)nest);

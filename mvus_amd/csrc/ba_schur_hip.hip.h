@@ -677,6 +677,136 @@ __global__ __launch_bounds__(kThreads) void k_det_motion(DevProblem dp, const do
   }
 }
 
+// The same for motion rows that reach further than six control points (FITPACK knots less than a frame apart: the three samples of
+// a row then span more than three knot spans; the band has W <= kWideW blocks per row): one wavefront per control point, the rows'
+// coefficients built in LDS by the row's own lane, every lane adds up to three entries of the control point's band row.
+constexpr int kWideW = 16;
+__global__ __launch_bounds__(64) void k_det_motion_wide(DevProblem dp, const double* __restrict__ mJ, const int32_t* __restrict__ mctrl,
+                                                        const double* __restrict__ fm, NEView ne) {
+  constexpr int kRv = kWideW * 3 + 1;                      // per row: W x 3 coefficients + the residual
+  __shared__ double rv[64][kRv + 1];
+  const int lane = threadIdx.x, g = blockIdx.x;
+  if (g >= ne.N) return;
+  const int gg = g + ne.row0;
+  const int j0 = dp.mv.row_lo[gg], j1 = dp.mv.row_hi[gg];
+  const int per = 3 + ne.W * 9;
+  double acc[3] = {0.0, 0.0, 0.0};
+  for (int jb = j0; jb < j1; jb += 64) {
+    const int j = jb + lane;
+    for (int e = 0; e < kRv; ++e) rv[lane][e] = 0.0;
+    if (j < j1) {
+      int cid[3], lo = 0x7fffffff, hi = -1;
+      bool outside = false;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        cid[k] = mctrl[(long long)k * dp.T + j];
+        if (cid[k] >= 0) {
+          cid[k] -= ne.row0;
+          if (cid[k] < 0 || cid[k] + 3 >= ne.N) outside = true;
+          lo = min(lo, cid[k]); hi = max(hi, cid[k] + 3);
+        }
+      }
+      if (!outside && hi >= 0 && hi - lo < kWideW) {
+        for (int k = 0; k < 3; ++k) {
+          if (cid[k] < 0) continue;
+          for (int q = 0; q < 4; ++q) {
+            const int a = cid[k] + q - g;                  // this block's control point q is g + a
+            if (a < 0 || a >= kWideW) continue;
+            for (int dd = 0; dd < 3; ++dd) rv[lane][3 * a + dd] += mJ[(long long)(12 * k + 3 * q + dd) * dp.T + j];
+          }
+        }
+        rv[lane][kWideW * 3] = fm[j];
+      }
+    }
+    lds_wave_sync();
+    const int nrow = min(64, j1 - jb);
+#pragma unroll
+    for (int t3 = 0; t3 < 3; ++t3) {
+      const int e = lane + 64 * t3;
+      if (e >= per) continue;
+      const bool grad = e < 3;
+      const int w = grad ? 0 : (e - 3) / 9, d = grad ? e : ((e - 3) % 9) / 3, d2 = grad ? 0 : (e - 3) % 3;
+      if (g + w >= ne.N) continue;
+      double a = 0.0;
+      for (int t = 0; t < nrow; ++t) a += rv[t][d] * (grad ? rv[t][kWideW * 3] : rv[t][3 * w + d2]);
+      acc[t3] += a;
+    }
+    lds_wave_sync();
+  }
+#pragma unroll
+  for (int t3 = 0; t3 < 3; ++t3) {
+    const int e = lane + 64 * t3;
+    if (e >= per || acc[t3] == 0.0) continue;
+    if (e < 3) ne.gs[3 * g + e] += acc[t3];
+    else if (g + (e - 3) / 9 < ne.N) ne.Cb[((long long)g * ne.W) * 9 + (e - 3)] += acc[t3];
+  }
+}
+
+// ---- the spline block as a GENERAL band (W > 6): Cholesky in place, then every right-hand side by substitution ----------------
+// Lb[i][j] = M(i, i - j), j = 0..BW (the damped band of k_band_pack).  One workgroup: a sliding window of BW + 1 rows in LDS (row
+// k + r in slot (k + r) mod (BW + 1)), column by column -- pivot, the column's BW entries, the rank-one update of the window's
+// trailing triangle -- the finished row goes back to memory and the next one comes in.  A fallback for the rare wide band
+// (the partitioned solver below is built for W = 4 and 6): O(n BW^2) work on one CU.
+__global__ __launch_bounds__(256) void k_band_chol_generic(int n, int BW, double* __restrict__ Lb, int* __restrict__ fail) {
+  extern __shared__ double bwin[];                          // [(BW + 1)][(BW + 1)]
+  __shared__ double dsh;
+  const int R = BW + 1, tid = threadIdx.x;
+  for (int e = tid; e < R * R; e += 256) { const int r = e / R, c = e % R; bwin[e] = r < n ? Lb[(long long)r * R + c] : 0.0; }
+  __syncthreads();
+  bool bad = false;
+  for (int k = 0; k < n; ++k) {
+    const int s0 = k % R;
+    double* row0 = bwin + s0 * R;
+    if (tid == 0) { const double p = row0[0]; bad = !(p > 0.0); dsh = sqrt(p > 0.0 ? p : 1.0); }
+    __syncthreads();
+    const double d = dsh;
+    const int rows = min(BW, n - 1 - k);                    // rows k+1 .. k+rows hold column k
+    if (tid == 0) row0[0] = d;
+    for (int r = 1 + tid; r <= rows; r += 256) bwin[((k + r) % R) * R + r] /= d;     // M(k + r, k) sits at entry r of its row
+    __syncthreads();
+    for (int e = tid; e < rows * (rows + 1) / 2; e += 256) {                        // (r, s), 1 <= s <= r <= rows: M(k+r, k+s) -= l_r l_s
+      int r = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
+      while ((r + 1) * (r + 2) / 2 <= e) ++r;
+      while (r * (r + 1) / 2 > e) --r;
+      const int sidx = e - r * (r + 1) / 2 + 1, rr = r + 1;
+      double* rowr = bwin + ((k + rr) % R) * R;
+      rowr[rr - sidx] -= rowr[rr] * bwin[((k + sidx) % R) * R + sidx];
+    }
+    __syncthreads();
+    // row k is final: back to memory; its slot takes row k + R
+    for (int c = tid; c < R; c += 256) {
+      Lb[(long long)k * R + c] = row0[c];
+      const int nr = k + R;
+      row0[c] = nr < n ? Lb[(long long)nr * R + c] : 0.0;
+    }
+    __syncthreads();
+  }
+  if (bad && tid == 0) fail[0] = 3;
+}
+// Z[i][c] <- (L L^T)^-1 Z[i][c]: one lane per right-hand side (64 per workgroup), the last BW solution entries in an LDS ring
+__global__ __launch_bounds__(64) void k_band_solve_generic(int n, int BW, int ncols, const double* __restrict__ Lb, double* __restrict__ Z) {
+  extern __shared__ double ring[];                          // [BW + 1][64]
+  const int R = BW + 1, lane = threadIdx.x, c = blockIdx.x * 64 + lane;
+  const bool on = c < ncols;
+  for (int i = 0; i < n; ++i) {                             // forward: y_i = (b_i - sum_j L(i, i-j) y_{i-j}) / L(i, i)
+    const double* Li = Lb + (long long)i * R;
+    double sacc = on ? Z[(long long)i * ncols + c] : 0.0;
+    const int jm = min(BW, i);
+    for (int j = 1; j <= jm; ++j) sacc -= Li[j] * ring[((i - j) % R) * 64 + lane];
+    const double y = sacc / Li[0];
+    ring[(i % R) * 64 + lane] = y;
+    if (on) Z[(long long)i * ncols + c] = y;
+  }
+  for (int i = n - 1; i >= 0; --i) {                        // backward: x_i = (y_i - sum_j L(i+j, i) x_{i+j}) / L(i, i)
+    double sacc = on ? Z[(long long)i * ncols + c] : 0.0;
+    const int jm = min(BW, n - 1 - i);
+    for (int j = 1; j <= jm; ++j) sacc -= Lb[(long long)(i + j) * R + j] * ring[((i + j) % R) * 64 + lane];
+    const double xv = sacc / Lb[(long long)i * R];
+    ring[(i % R) * 64 + lane] = xv;
+    if (on) Z[(long long)i * ncols + c] = xv;
+  }
+}
+
 // D = diag(H) in x order (0 -> 1 so that unused columns stay put), and g in x order
 __device__ __forceinline__ void ne_diag_grad_entry(const DevProblem& dp, const NEView& ne, int raw, int idx, double* __restrict__ D, double* __restrict__ gx) {
   // raw (time shards): this rank's PARTIAL diagonal, to be summed over the ranks before k_diag_fix replaces zeros by 1
@@ -1941,6 +2071,7 @@ struct HipSchur {
   // window-major fused assembly (ba_assemble_win.hip.h): tables and the per-(window, camera) camera-block partials
   WinView wv{};
   bool use_win = false;
+  bool wide = false;                           // band wider than six control points: the general band kernels instead of the partitioned solver
   void* win_tables = nullptr;
   size_t win_lds = 0;
 
@@ -1963,8 +2094,13 @@ struct HipSchur {
       if (hp.motion_type == MVUS_MOTION_F && hp.ms_part[j + 1] == hp.ms_part[j]) { lo = std::min(lo, hp.ms_ctrl[j + 1]); hi = std::max(hi, hp.ms_ctrl[j + 1]); }
       W = std::max(W, hi + 3 - lo + 1);
     }
-    if (W > 6) throw HipError{"LM_SCHUR: motion rows couple control points more than 6 apart (knot spacing below one frame) - unsupported band width"};
-    W = W <= 4 ? 4 : 6;
+    // W <= 6: the partitioned band solver (templates for W = 4 and 6).  Wider -- FITPACK knots less than a frame apart, the motion
+    // rows then reach over more than three knot spans -- : the band as it is, factorised and solved by the general kernels
+    // (k_band_chol_generic / k_band_solve_generic: one CU, for the small problems of the incremental loop where this happens)
+    if (W > kWideW) throw HipError{"LM_SCHUR: motion rows couple control points " + std::to_string(W) + " apart (knots far below one frame) - unsupported band width (at most " + std::to_string(kWideW) + ")", MVUS_E_UNSUPPORTED};
+    wide = W > 6;
+    if (wide && shard) throw HipError{"LM_SCHUR: a band wider than six control points is not supported on a time shard", MVUS_E_UNSUPPORTED};
+    if (!wide) W = W <= 4 ? 4 : 6;
     ne.W = W;
     BW = 3 * W - 1;
     ncols = ne.CB + 1;
@@ -2163,7 +2299,9 @@ struct HipSchur {
   void motion_rows(const double* f_dev) {
     // (one rank: the row-ordered kernel in both modes -- 22 us against 26 for the LDS-window one at configs[1], and one source of
     // run-to-run differences less; a time shard keeps k_assemble_motion, which also reports rows that leave the slice)
-    if (be.hp.T > 0 && !shard && ne.W <= kDetMotW) {
+    if (be.hp.T > 0 && wide) {
+      hipLaunchKernelGGL(k_det_motion_wide, dim3((unsigned)ne.N), dim3(64), 0, be.stream, be.dp, be.mJ, be.mctrl, f_dev + 2 * be.hp.M, ne);
+    } else if (be.hp.T > 0 && !shard && ne.W <= kDetMotW) {
       hipLaunchKernelGGL(k_det_motion, dim3((unsigned)((ne.N + kThreads / 64 - 1) / (kThreads / 64))), dim3(kThreads), 0, be.stream, be.dp, be.mJ, be.mctrl,
                          f_dev + 2 * be.hp.M, ne);
     } else if (be.hp.T > 0)
@@ -2314,7 +2452,7 @@ struct HipSchur {
     const long long nLb = (long long)ne.N3 * (BW + 1);
     const long long nZ = (long long)ne.N3 * ncols;          // >= nLb: one launch covers both passes
     const int rhs_tiles = (int)((std::max(nZ, nLb) + 255) / 256);
-    overlap_chol = std::getenv("MVUS_NO_OVERLAP") == nullptr;
+    overlap_chol = std::getenv("MVUS_NO_OVERLAP") == nullptr && !wide;
     if (overlap_chol) {
       const long long nband = std::max<long long>(nLb, (long long)ne.CB + ne.N3);
       hipLaunchKernelGGL(k_band_pack, dim3((unsigned)((nband + 255) / 256)), dim3(256), 0, be.stream, ne, lambda, BW, Lb, fail, be.dp, (int)diag_pending, D, gx);
@@ -2324,7 +2462,11 @@ struct HipSchur {
                          (int)diag_pending, D, gx, rhs_tiles);
     }
     diag_pending = false;
-    if (BW == 11) band_chain<11, 9>(); else band_chain<17, 15>();
+    if (wide) {
+      const size_t lds_c = (size_t)(BW + 1) * (BW + 1) * sizeof(double), lds_s = (size_t)(BW + 1) * 64 * sizeof(double);
+      hipLaunchKernelGGL(k_band_chol_generic, dim3(1), dim3(256), lds_c, be.stream, ne.N3, BW, Lb, fail);
+      hipLaunchKernelGGL(k_band_solve_generic, dim3((unsigned)((ncols + 63) / 64)), dim3(64), lds_s, be.stream, ne.N3, BW, ncols, Lb, Z);
+    } else if (BW == 11) band_chain<11, 9>(); else band_chain<17, 15>();
     const int row_lo = 3 * own_lo, row_hi = 3 * own_hi;
     {
       const int nbk = (ne.CB + kGemmT - 1) / kGemmT;

@@ -24,6 +24,9 @@ Extra ``settings`` keys (all optional; a reference ``config.json`` has none of t
 ``ba_pattern_ties`` 'numpy' = the twin rows of the pattern decided like np.argsort of this process decides them (default;
                what the reference would build here), 'canonical'.
 ``ba_lambda_min`` floor of the LM damping (default 3e-3, see ``mvus_solve_opts.lm_lambda_min``).
+``ba_lm_wide_band`` with 'lm': what to do when the motion rows reach over more than six control points (knots less than a frame
+               apart, i.e. more control points than detections): 'trf' (default) solves THAT problem with TRF + LSMR on the analytic
+               Jacobian and says so, 'lm' keeps LM + Schur (general band solver, damping floor 0.3).
 ``ba_deterministic`` accepted and ignored: the 'lm' solver's normal equations are assembled without floating-point atomics
                (one writer, one order of additions per entry) -- the same bits on every run by construction.
 ``opt_sync`` (reference key: False freezes alpha/beta), ``device``.
@@ -355,6 +358,27 @@ class Scene:
             _, vis = util.sampling(self.detections_global[cam_id], self.spline['int'], belong=True)
             self.visible.append(vis)
 
+    @staticmethod
+    def _motion_band_width(prob):
+        """Control points a motion row couples (common.py:959-1001: samples j-1, j, j+1, four control points each), i.e. the block
+        band width W of the spline part of J^T J; 4 without the regulariser."""
+        if not prob.motion_reg:
+            return 4
+        ts, sid = prob.motion_sample_times()
+        coff = prob.ctrl_offsets
+        first = np.empty(ts.size, dtype=np.int64)
+        for s in range(prob.S):
+            t = prob.knots[int(prob.knot_offsets[s]):int(prob.knot_offsets[s + 1])]
+            sel = sid == s
+            first[sel] = coff[s] + np.clip(np.searchsorted(t, ts[sel], side='right') - 1, 3, t.size - 5) - 3
+        W = 4
+        step = 2 if prob.motion_type == 0 else 1            # 'F' rows use three samples, 'KE' two
+        for d in range(1, step + 1):
+            same = sid[d:] == sid[:-d]
+            if same.any():
+                W = max(W, int(np.max(np.abs(first[d:] - first[:-d])[same])) + 4)
+        return W
+
     def BA(self, numCam, max_iter=10, rs=False, motion_prior=False, motion_reg=False, motion_weights=1, norm=False,
            rs_bounds=False, jac_sparsity=None):
         """Bundle adjustment over ``self.sequence[:numCam]`` (common.py:441-697): same arguments, same side effects,
@@ -376,16 +400,23 @@ class Scene:
         opts = _ba._lib.default_opts(solver, jac_mode, max_iter)
         opts.lm_lambda_min = float(st.get('ba_lambda_min', opts.lm_lambda_min))
         try:
+            if solver == _ba.SOLVER_LM_SCHUR and st.get('ba_lm_wide_band', 'trf') != 'lm' and self._motion_band_width(prob) > 6:
+                # POLICY, not a limit of the library (it solves bands of up to sixteen control points, tests/test_gpu_schur.py): knots less
+                # than a frame apart mean more control points than detections -- what traj_to_spline returns after a dense triangulate
+                # inside the incremental loop -- and there an exact Newton-type step follows the regulariser-only directions: three
+                # seeds of the loop end 2.6 - 8 m from the truth with LM on those problems, 0.2 - 0.35 m with the truncated solver
+                # (profiles/r04_loop_lm_wide_band.txt).  settings['ba_lm_wide_band'] = 'lm' keeps LM (damping floor 0.3).
+                raise _ba.UnsupportedBySolver("settings['ba_lm_wide_band'] = 'trf': the motion rows reach over more than six control points (knots less than a frame apart)")
             res = h.solve(model, opts=opts, ties=st.get('ba_pattern_ties', 'numpy'), matrix=jac_sparsity)
-        except RuntimeError as e:
-            if solver != _ba.SOLVER_LM_SCHUR or 'unsupported band width' not in str(e):
-                raise
-            # LM + Schur keeps the spline block as a band of at most six 3x3 blocks; FITPACK knots less than one frame apart
-            # (dense triangulated points of a fast camera) make the motion rows reach further.  The other GPU solver has no
-            # such limit: same analytic Jacobian, TRF + LSMR instead of the normal equations.  Said aloud, not silently.
+            res.solver_used = 'lm' if solver == _ba.SOLVER_LM_SCHUR else 'trf'
+        except _ba.UnsupportedBySolver as e:
+            # LM + Schur keeps the spline block as a band of at most sixteen 3x3 blocks (MVUS_E_UNSUPPORTED beyond; FITPACK knots far
+            # below one frame apart make the motion rows reach further).  The other GPU solver has no such limit: same analytic
+            # Jacobian, TRF + LSMR instead of the normal equations.  Said aloud and recorded in the result, not silently.
             print('BA: %s -- solving this problem with ba_solver=trf (analytic Jacobian) instead' % e)
             opts = _ba._lib.default_opts(_ba.SOLVER_TRF_LSMR, _ba.JAC_ANALYTIC, max_iter)
             res = h.solve(model, opts=opts, ties='canonical')
+            res.solver_used = 'trf (fallback from lm: %s)' % e
         alpha, beta, rs_new, cam_states, coefs = _problem.unpack_x(prob, res.x)
         self.alpha[cams], self.beta[cams], self.rs[cams] = alpha, beta, rs_new
         for k, i in enumerate(cams):

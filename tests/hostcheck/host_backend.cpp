@@ -6,6 +6,7 @@
 // the oracle without a GPU.  It is compiled into tests/hostcheck/libhostcheck.so only -- the
 // product library libmvusba.so has no CPU path.
 #include "../../mvus_amd/csrc/ba_partition.h"
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -42,7 +43,13 @@ struct HostBackend {
     for (int64_t i = 0; i < len; ++i) out[i] = a * x[i] + b * y[i];
   }
   void mul(int64_t len, const double* x, const double* y, double* out) { for (int64_t i = 0; i < len; ++i) out[i] = x[i] * y[i]; }
-  double dot_n(const double* a, const double* b, int64_t len) { double s = 0; for (int64_t i = 0; i < len; ++i) s += a[i] * b[i]; return s; }
+  // MVUS_HOST_EXACT_SUMS=1 (an experiment of tools/micro/rsf_clusters.py): every long sum of the solver -- dot
+  // products, J v, J^T u -- accumulated in 80-bit long double (x87: 64-bit mantissa, products exact) and rounded once
+  const bool exact_sums = std::getenv("MVUS_HOST_EXACT_SUMS") != nullptr;
+  double dot_n(const double* a, const double* b, int64_t len) {
+    if (exact_sums) { long double s = 0; for (int64_t i = 0; i < len; ++i) s += (long double)a[i] * (long double)b[i]; return (double)s; }
+    double s = 0; for (int64_t i = 0; i < len; ++i) s += a[i] * b[i]; return s;
+  }
   double dot_m(const double* a, const double* b) { return dot_n(a, b, hp.m); }
   // device-resident LM driver (ba_schur.h): host memory plays the role of device memory
   std::vector<double> lbv, ubv;
@@ -190,7 +197,66 @@ struct HostBackend {
 
   int col_of(int c, int k) const { return k < 3 ? k * hp.C + c : 3 * hp.C + c * hp.P + (k - 3); }
 
+  template <class T>
+  void jv_t(const double* v, double* y) {
+    const int NS = hp.NS, B = 3 + hp.P;
+    for (int c = 0; c < hp.C; ++c) {
+      const int64_t a = hp.det_off[c], Mc = hp.det_off[c + 1] - a;
+      for (int64_t i = a; i < a + Mc; ++i) {
+        T sx = 0, sy = 0;
+        const int g = span[i];
+        if (g >= 0) {
+          for (int k = 0; k < B; ++k) { const T vv = v[col_of(c, k)]; sx += (T)J[(size_t)k * hp.M + i] * vv; sy += (T)J[(size_t)(NS + k) * hp.M + i] * vv; }
+          const int x0 = hp.ctrl_x0[g], st = hp.ctrl_stride[g];
+          for (int q = 0; q < 4; ++q)
+            for (int d = 0; d < 3; ++d) {
+              const T vv = v[x0 + q + d * st];
+              sx += (T)J[(size_t)(B + 3 * q + d) * hp.M + i] * vv; sy += (T)J[(size_t)(NS + B + 3 * q + d) * hp.M + i] * vv;
+            }
+        }
+        y[2 * a + (i - a)] = (double)sx; y[2 * a + Mc + (i - a)] = (double)sy;
+      }
+    }
+    for (int j = 0; j < hp.T; ++j) {
+      T s = 0;
+      for (int k = 0; k < 3; ++k) {
+        const int g = mctrl[(size_t)k * hp.T + j];
+        if (g < 0) continue;
+        const int x0 = hp.ctrl_x0[g], st = hp.ctrl_stride[g];
+        for (int q = 0; q < 4; ++q) for (int d = 0; d < 3; ++d) s += (T)mJ[(size_t)(12 * k + 3 * q + d) * hp.T + j] * (T)v[x0 + q + d * st];
+      }
+      y[2 * hp.M + j] = (double)s;
+    }
+  }
+  template <class T>
+  void jtu_t(const double* u, double* zout) {
+    const int NS = hp.NS, B = 3 + hp.P;
+    std::vector<T> z((size_t)hp.n, (T)0);
+    for (int c = 0; c < hp.C; ++c) {
+      const int64_t a = hp.det_off[c], Mc = hp.det_off[c + 1] - a;
+      for (int64_t i = a; i < a + Mc; ++i) {
+        const int g = span[i];
+        if (g < 0) continue;
+        const T ux = u[2 * a + (i - a)], uy = u[2 * a + Mc + (i - a)];
+        for (int k = 0; k < B; ++k) z[col_of(c, k)] += (T)J[(size_t)k * hp.M + i] * ux + (T)J[(size_t)(NS + k) * hp.M + i] * uy;
+        const int x0 = hp.ctrl_x0[g], st = hp.ctrl_stride[g];
+        for (int q = 0; q < 4; ++q)
+          for (int d = 0; d < 3; ++d)
+            z[x0 + q + d * st] += (T)J[(size_t)(B + 3 * q + d) * hp.M + i] * ux + (T)J[(size_t)(NS + B + 3 * q + d) * hp.M + i] * uy;
+      }
+    }
+    for (int j = 0; j < hp.T; ++j)
+      for (int k = 0; k < 3; ++k) {
+        const int g = mctrl[(size_t)k * hp.T + j];
+        if (g < 0) continue;
+        const int x0 = hp.ctrl_x0[g], st = hp.ctrl_stride[g];
+        for (int q = 0; q < 4; ++q) for (int d = 0; d < 3; ++d) z[x0 + q + d * st] += (T)mJ[(size_t)(12 * k + 3 * q + d) * hp.T + j] * (T)u[2 * hp.M + j];
+      }
+    for (int64_t i = 0; i < hp.n; ++i) zout[i] = (double)z[i];
+  }
+
   void jv(const double* v, double* y) {
+    if (exact_sums) { jv_t<long double>(v, y); return; }
     const int NS = hp.NS, B = 3 + hp.P;
     for (int c = 0; c < hp.C; ++c) {
       const int64_t a = hp.det_off[c], Mc = hp.det_off[c + 1] - a;
@@ -222,6 +288,7 @@ struct HostBackend {
   }
 
   void jtu(const double* u, double* z) {
+    if (exact_sums) { jtu_t<long double>(u, z); return; }
     const int NS = hp.NS, B = 3 + hp.P;
     for (int64_t i = 0; i < hp.n; ++i) z[i] = 0;
     for (int c = 0; c < hp.C; ++c) {

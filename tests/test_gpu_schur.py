@@ -108,6 +108,63 @@ def test_partitioned_band_solver_many_partitions(motion):
     np.testing.assert_allclose(r.x, xh, rtol=0, atol=1e-5 * max(1.0, np.abs(xh).max()))
 
 
+@pytest.mark.parametrize('spacing,motion_type', [(0.8, 'F'), (0.45, 'F'), (0.3, 'KE'), (0.22, 'F')])
+def test_wide_band_knots_closer_than_a_frame(spacing, motion_type):
+    """FITPACK knots less than one frame apart (what traj_to_spline returns after a dense triangulate, common.py:224-270): the three
+    samples of a motion row (common.py:959-1001) then span more than three knot spans and the spline block has more than six 3x3
+    blocks per row.  The LM solver keeps the band as it is (general band Cholesky instead of the partitioned solver): normal equations
+    against the dense J^T J, LM steps against the dense host LM."""
+    from mvus_amd import synth
+    from mvus_amd.ba import BAHandle
+    sc = synth.make_scene(3, 420, seed=61, rolling_shutter=True, knot_spacing=spacing, motion_reg=True, motion_type=motion_type, motion_weights=40.0)
+    prob, x0 = mp.problem_from_scene(sc)
+    f, D = _host(prob).dense_jacobian(x0, _lib.JAC_ANALYTIC)
+    H, grad = D.T @ D, D.T @ f
+    cam_idx, spl_idx = internal_index(prob)
+    with BAHandle(prob) as h:
+        h.residual_jacobian(x0, _lib.JAC_ANALYTIC)
+        gg, A, band, cross = h.normal_equations()
+        N, W = band.shape[0], band.shape[1]
+        assert W > 6 or spacing >= 0.8
+        scale = np.abs(H).max()
+        np.testing.assert_allclose(gg, grad, rtol=0, atol=1e-11 * np.abs(grad).max())
+        Hs = H[np.ix_(spl_idx, spl_idx)]
+        covered = np.zeros_like(Hs, dtype=bool)
+        for gi in range(N):
+            for w in range(W):
+                if gi + w < N:
+                    np.testing.assert_allclose(band[gi, w], Hs[3 * gi:3 * gi + 3, 3 * (gi + w):3 * (gi + w) + 3], rtol=0, atol=1e-12 * scale)
+                    covered[3 * gi:3 * gi + 3, 3 * (gi + w):3 * (gi + w) + 3] = True
+                    covered[3 * (gi + w):3 * (gi + w) + 3, 3 * gi:3 * gi + 3] = True
+        assert not Hs[~covered].any()                                   # nothing outside the band
+        p = h.lm_step(0.1)
+    Hd = H + 0.1 * np.diag(np.where(np.diag(H) > 0, np.diag(H), 1.0))
+    p_ref = -np.linalg.solve(Hd, grad)
+    np.testing.assert_allclose(p, p_ref, rtol=0, atol=1e-7 * np.abs(p_ref).max())
+    if spacing < 0.3:
+        return                                                          # (the dense host LM below is O(n^3) per step)
+    opts = _lib.default_opts(_lib.SOLVER_LM_SCHUR, _lib.JAC_ANALYTIC, 5)
+    opts.lm_lambda_min = 0.3               # (the library's floor for bands wider than six control points; the host harness takes it from here)
+    xh, rh, fh = _host(prob).solve(x0, opts)
+    with BAHandle(prob) as h:
+        r = h.solve(x0, opts=opts)
+    assert (r.nfev, r.njev, r.status) == (rh.nfev, rh.njev, rh.status)
+    np.testing.assert_allclose(r.cost, rh.cost, rtol=1e-7)
+    np.testing.assert_allclose(r.x, xh, rtol=0, atol=1e-5 * max(1.0, np.abs(xh).max()))
+
+
+def test_band_beyond_sixteen_control_points_is_an_error_code():
+    from mvus_amd import synth
+    from mvus_amd.ba import BAHandle, UnsupportedBySolver
+    sc = synth.make_scene(2, 300, seed=62, knot_spacing=0.08, motion_reg=True, motion_type='F', motion_weights=40.0)
+    prob, x0 = mp.problem_from_scene(sc)
+    with BAHandle(prob) as h:
+        with pytest.raises(UnsupportedBySolver):
+            h.solve(x0, solver=_lib.SOLVER_LM_SCHUR, jac_mode=_lib.JAC_ANALYTIC, max_nfev=3)
+        r = h.solve(x0, solver=_lib.SOLVER_TRF_LSMR, jac_mode=_lib.JAC_ANALYTIC, max_nfev=3)      # the other solver has no such limit
+        assert np.isfinite(r.cost)
+
+
 @pytest.mark.parametrize('num_knots', [75, 140, 210, 280, 420, 560])
 @pytest.mark.parametrize('sequential', [False, True])
 def test_separator_chain_lengths(num_knots, sequential, monkeypatch):

@@ -30,15 +30,21 @@ def main():
     ap.add_argument('--max-iter', type=int, default=10)
     ap.add_argument('--motion-weights', type=float, default=1e2, help='configs[1] quotes 1e4 (README); on this synthetic flight that lets the regulariser outweigh the data 100:1')
     ap.add_argument('--cpu-sample', action='store_true')
+    ap.add_argument('--seed', type=int, default=None)
+    ap.add_argument('--lambda-min', type=float, default=None, help="settings['ba_lambda_min'] (floor of the LM damping)")
+    ap.add_argument('--lm-wide', choices=['lm', 'trf'], default=None, help="settings['ba_lm_wide_band']: what ba_solver=lm does when the motion rows reach over more than six control points")
     args = ap.parse_args()
     from mvus_amd import pipeline, synth
     kw = dict(synth.BASELINE_CONFIGS[1])
     kw.update(num_cam=args.cams, total_obs=args.obs, motion_weights=args.motion_weights)
-    seed = kw.pop('seed')
+    seed = kw.pop('seed') if args.seed is None else (kw.pop('seed'), args.seed)[1]
     nc, nobs = kw.pop('num_cam'), kw.pop('total_obs')
     kw.pop('num_intervals', None)
     t0 = time.perf_counter()
-    flight, sc = pipeline.staged_scene(nc, nobs, seed=seed, settings={'ba_solver': args.solver}, perturb=0.3, **kw)
+    st_extra = {'ba_solver': args.solver}
+    if args.lambda_min is not None: st_extra['ba_lambda_min'] = args.lambda_min
+    if args.lm_wide is not None: st_extra['ba_lm_wide_band'] = args.lm_wide
+    flight, sc = pipeline.staged_scene(nc, nobs, seed=seed, settings=st_extra, perturb=0.3, **kw)
     print('scene: %d cameras, %d detections (%s), start trajectory %.0f..%.0f of 0..%.0f, %d control points; set-up %.2f s'
           % (nc, sum(d.shape[1] for d in flight.detections), [d.shape[1] for d in flight.detections], flight.spline['int'][0, 0],
              flight.spline['int'][1, -1], sc.interval[1, -1], sum(len(t[0]) - 4 for t in flight.spline['tck']), time.perf_counter() - t0))
