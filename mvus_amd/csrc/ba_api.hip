@@ -253,6 +253,7 @@ struct HipBackend {
   }
   void reduce(double* buf, size_t count) {
     if (!allreduce) return;
+    RoctxRange range("mvus all-reduce");
     if (allreduce(allreduce_user, buf, count, stream) != 0) throw HipError{"all-reduce callback failed", MVUS_E_COMM};
   }
   // device-resident LM driver (ba_schur.h)
@@ -331,6 +332,7 @@ struct HipBackend {
   // the slot Jacobian (2*NS*M doubles) is allocated on first use: residual-only handles (Scene.error_cam, outlier masks) never pay for it
   void ensure_J() { if (!J) J = dalloc<double>(j_doubles(hp.NS, dp.n_chunks)); }      // sized at first use; outlier removal only ever shrinks the chunk table
   void eval(const double* x, double* f, bool jac, int jac_mode) {
+    RoctxRange range(jac ? "mvus residual+jacobian" : "mvus residual");
     if (jac) ensure_J();
     const bool masked = jac && jac_mode == MVUS_JAC_PATTERN;
     if (masked && !has_pattern) throw HipError{"MVUS_JAC_PATTERN needs mvus_ba_set_pattern (or solve) first"};
@@ -368,6 +370,7 @@ struct HipBackend {
   // clr / clr_len: storage to zero beside the evaluation (HipSchur's normal-equation blocks); returns false if it was not done
   bool residual_sq(const double* x, double* f, double* out, double* clr = nullptr, int64_t clr_len = 0) {
     if (allreduce) { residual(x, f); dot_m_into(f, f, out); return false; }
+    RoctxRange range("mvus residual");
     const int mb = hp.T > 0 ? (int)((hp.T + kThreads - 1) / kThreads) : 0;
     const size_t need = (size_t)dp.n_chunks + mb + 1;
     if (need > sq_cap) { sq_part = dalloc<double>(need); sq_cap = need; }

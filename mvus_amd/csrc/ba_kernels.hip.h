@@ -16,6 +16,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
+#include <cstdlib>
 #include <string>
 
 #include "ba_math.h"
@@ -32,6 +35,30 @@ struct HipError { std::string msg; int code = -2; };   // code: the MVUS_E_* val
     hipError_t e_ = (expr);                                                                         \
     if (e_ != hipSuccess) throw ::mvus::HipError{std::string(#expr) + ": " + hipGetErrorString(e_)}; \
   } while (0)
+
+// roctx ranges around the stages of a BA iteration (residual / linearise / solve / all-reduce) for rocprofv3 --marker-trace and the
+// ROCm timeline tools: libroctx64.so is opened at run time when MVUS_ROCTX=1 (no link-time dependency, no cost otherwise)
+struct RoctxApi {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+  RoctxApi() {
+    if (!std::getenv("MVUS_ROCTX")) return;
+    void* lib = dlopen("libroctx64.so", RTLD_NOW | RTLD_LOCAL);
+    if (!lib) lib = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_LOCAL);
+    if (!lib) return;
+    push = reinterpret_cast<int (*)(const char*)>(dlsym(lib, "roctxRangePushA"));
+    pop = reinterpret_cast<int (*)()>(dlsym(lib, "roctxRangePop"));
+    if (!push || !pop) { push = nullptr; pop = nullptr; }
+  }
+};
+inline RoctxApi& roctx_api() { static RoctxApi a; return a; }
+struct RoctxRange {
+  bool on;
+  explicit RoctxRange(const char* name) : on(roctx_api().push != nullptr) { if (on) roctx_api().push(name); }
+  ~RoctxRange() { if (on) roctx_api().pop(); }
+  RoctxRange(const RoctxRange&) = delete;
+  RoctxRange& operator=(const RoctxRange&) = delete;
+};
 
 struct DevProblem {  // trivially copyable: passed to kernels by value
   int C, P, NS, S, calib, undist, rs_free, sync_free, T, N;
@@ -336,7 +363,6 @@ __global__ __launch_bounds__(kThreads) void k_motion(DevProblem dp, const double
     }
   }
   if (j >= dp.T) return;
-  double jrow[36];
   int32_t cidx[3];
   const int key = dp.mv.ctrl[j];
   if (key < dp.mot_lo || key >= dp.mot_hi) {          // owned by another time shard: a row of zeros here
@@ -347,12 +373,19 @@ __global__ __launch_bounds__(kThreads) void k_motion(DevProblem dp, const double
     }
     return;
   }
-  fm[j] = eval_motion_row<JAC>(dp.mv, x, j, masked != 0, jrow, cidx);
   if (JAC) {
+    // every entry goes to memory as it is produced (zeros first: the row function hands over the non-zero ones) -- the row never
+    // sits in a local array (36 doubles + index arithmetic were 304 bytes of scratch per lane)
 #pragma unroll
-    for (int k = 0; k < 36; ++k) mJ[(long long)k * dp.T + j] = jrow[k];
+    for (int k = 0; k < 36; ++k) mJ[(long long)k * dp.T + j] = 0.0;
+    double* mj = mJ + j;
+    const long long T = dp.T;
+    fm[j] = eval_motion_row_to<true>(dp.mv, x, j, masked != 0, [&](int k, int q, int d, double v) { mj[(long long)(12 * k + 3 * q + d) * T] = v; }, cidx);
 #pragma unroll
     for (int k = 0; k < 3; ++k) mctrl[(long long)k * dp.T + j] = cidx[k];
+  } else {
+    double jrow[1];
+    fm[j] = eval_motion_row<false>(dp.mv, x, j, false, jrow, cidx);
   }
 }
 

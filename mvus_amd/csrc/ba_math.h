@@ -169,10 +169,18 @@ MVUS_HD void undistort5(double x0, double y0, const double d[5], double& xo, dou
     for (int k = 0; k < 7; ++k) { dx[k] = 0.0; dy[k] = 0.0; }
     dx[0] = 1.0; dy[1] = 1.0;
   }
+  bool stopped = false;        // OpenCV >= 4.1.1 (cvUndistortPointsInternal, regression_14583): a negative 1 / (1 + k1 r^2 + ...) ends
+                               // the iteration with the point reset to its start (x0, y0) -- restated here, in the oracle and in the shim
   for (int it = 0; it < 5; ++it) {
     const double r2 = x * x + y * y;
     const double qd = 1.0 + ((k3 * r2 + k2) * r2 + k1) * r2;
     const double icd = 1.0 / qd;
+    if (!stopped && icd < 0.0) {
+      stopped = true;
+      x = x0; y = y0;
+      if (TANGENT) { for (int k = 0; k < 7; ++k) { dx[k] = 0.0; dy[k] = 0.0; } dx[0] = 1.0; dy[1] = 1.0; }
+    }
+    if (stopped) continue;
     const double ddx = 2.0 * p1 * x * y + p2 * (r2 + 2.0 * x * x);
     const double ddy = p1 * (r2 + 2.0 * y * y) + 2.0 * p2 * x * y;
     const double nx = x0 - ddx, ny = y0 - ddy;
@@ -578,21 +586,21 @@ MVUS_HD void motion_point(const MotionView& mv, const double* x, int j, double X
   }
 }
 
-// Row j of the motion block.  jrow: 36 values, jrow[12*k + 3*q + d] for sample k (0: j-1, 1: j, 2: j+1),
-// cidx[3]: first control point of each sample (-1 unused).  masked: keep only the reference pattern.
-template <bool JAC>
-MVUS_HD double eval_motion_row(const MotionView& mv, const double* x, int j, bool masked, double* jrow, int32_t cidx[3]) {
+// Row j of the motion block, its Jacobian entries handed to `sink(k, q, d, value)` as they are produced (sample k = 0: j-1, 1: j,
+// 2: j+1; control point q, coordinate d; entries never handed over are zero).  cidx[3]: first control point of each sample
+// (-1 unused).  masked: keep only the reference pattern.
+template <bool JAC, class Emit>
+MVUS_HD double eval_motion_row_to(const MotionView& mv, const double* x, int j, bool masked, Emit&& emit, int32_t cidx[3]) {
   const double eps = 1e-20;
-  if (JAC) { for (int k = 0; k < 36; ++k) jrow[k] = 0.0; cidx[0] = cidx[1] = cidx[2] = -1; }
+  if (JAC) { cidx[0] = cidx[1] = cidx[2] = -1; }
   const int p = mv.part[j];
   if (p < 0 || j < 1 || mv.part[j - 1] != p) return 0.0;
   double Xm[3], X0[3];
   motion_point(mv, x, j - 1, Xm);
   motion_point(mv, x, j, X0);
   double row = 0.0;
-  double coef[3] = {0.0, 0.0, 0.0};   // d r_d / d X_{sample,d} before the sign, per sample
   double sgn[3];
-  int ns = 2;
+  const int32_t pc = (JAC && masked) ? mv.pat[j] : 0;
   if (mv.type == 1) {                                    // 'KE'  common.py:976-981
     const double dt = mv.t[j] - mv.t[j - 1];
     double dcoef[3];
@@ -605,11 +613,13 @@ MVUS_HD double eval_motion_row(const MotionView& mv, const double* x, int j, boo
     }
     if (JAC) {
       cidx[0] = mv.ctrl[j - 1]; cidx[1] = mv.ctrl[j];
-      for (int q = 0; q < 4; ++q)
+      for (int q = 0; q < 4; ++q) {
+        const bool k0 = !masked || pattern_has(pc, cidx[0] + q), k1 = !masked || pattern_has(pc, cidx[1] + q);
         for (int d = 0; d < 3; ++d) {
-          jrow[3 * q + d] = -sgn[d] * dcoef[d] * mv.basis[4 * (j - 1) + q];
-          jrow[12 + 3 * q + d] = sgn[d] * dcoef[d] * mv.basis[4 * j + q];
+          if (k0) emit(0, q, d, -sgn[d] * dcoef[d] * mv.basis[4 * (j - 1) + q]);
+          if (k1) emit(1, q, d, sgn[d] * dcoef[d] * mv.basis[4 * j + q]);
         }
+      }
     }
   } else {                                               // 'F'   common.py:984-998
     if (j + 1 >= mv.T || mv.part[j + 1] != p) return 0.0;
@@ -624,27 +634,28 @@ MVUS_HD double eval_motion_row(const MotionView& mv, const double* x, int j, boo
       row += fabs(r);
       sgn[d] = (r < 0.0) ? -1.0 : 1.0;
     }
-    ns = 3;
     if (JAC) {
       const double k3 = mv.w * dt3 / (dt3 + eps);
+      double coef[3];
       coef[0] = k3 / (dt1 + eps);
       coef[1] = -k3 * (1.0 / (dt2 + eps) + 1.0 / (dt1 + eps));
       coef[2] = k3 / (dt2 + eps);
       for (int k = 0; k < 3; ++k) {
         cidx[k] = mv.ctrl[j - 1 + k];
-        for (int q = 0; q < 4; ++q)
-          for (int d = 0; d < 3; ++d) jrow[12 * k + 3 * q + d] = sgn[d] * coef[k] * mv.basis[4 * (j - 1 + k) + q];
+        for (int q = 0; q < 4; ++q) {
+          if (masked && !pattern_has(pc, cidx[k] + q)) continue;
+          for (int d = 0; d < 3; ++d) emit(k, q, d, sgn[d] * coef[k] * mv.basis[4 * (j - 1 + k) + q]);
+        }
       }
     }
   }
-  if (JAC && masked) {
-    const int32_t pc = mv.pat[j];
-    for (int k = 0; k < ns; ++k)
-      for (int q = 0; q < 4; ++q) {
-        if (!pattern_has(pc, cidx[k] + q)) { jrow[12 * k + 3 * q] = 0.0; jrow[12 * k + 3 * q + 1] = 0.0; jrow[12 * k + 3 * q + 2] = 0.0; }
-      }
-  }
   return row;
+}
+// the same with the 36 entries in an array: jrow[12*k + 3*q + d]
+template <bool JAC>
+MVUS_HD double eval_motion_row(const MotionView& mv, const double* x, int j, bool masked, double* jrow, int32_t cidx[3]) {
+  if (JAC) { for (int k = 0; k < 36; ++k) jrow[k] = 0.0; }
+  return eval_motion_row_to<JAC>(mv, x, j, masked, [&](int k, int q, int d, double v) { jrow[12 * k + 3 * q + d] = v; }, cidx);
 }
 
 // scipy 2-point step for one variable (scipy/optimize/_numdiff.py:146-192, :13-90 with scheme '1-sided', num_steps 1):

@@ -2359,6 +2359,7 @@ struct HipSchur {
   // Linearise at x: residual f (unless the caller already holds f(x) in f_dev), Jacobian, normal equations.  With the
   // analytic Jacobian the detection rows are fused (assemble_local above); other Jacobian modes materialise J first.
   void linearize(BE&, const double* x_dev, double* f_dev, int jac_mode, bool f_valid) {
+    RoctxRange range("mvus linearise");
     const bool fused = jac_mode == MVUS_JAC_ANALYTIC && !std::getenv("MVUS_LM_MATERIALIZE_J");
     if (!fused) { be.jacobian(x_dev, f_dev, jac_mode); assemble(be, f_dev); return; }
     if (!f_valid) be.residual(x_dev, f_dev);
@@ -2449,6 +2450,7 @@ struct HipSchur {
   }
 
   void solve_async(double lambda) {
+    RoctxRange range("mvus schur solve");
     const long long nLb = (long long)ne.N3 * (BW + 1);
     const long long nZ = (long long)ne.N3 * ncols;          // >= nLb: one launch covers both passes
     const int rhs_tiles = (int)((std::max(nZ, nLb) + 255) / 256);

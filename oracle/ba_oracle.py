@@ -71,13 +71,16 @@ def undistort_normalized(uv, K, d, iters=5):
     x0 = (uv[0] - cx) / fx
     y0 = (uv[1] - cy) / fy
     x, y = x0.copy(), y0.copy()
+    stopped = np.zeros(np.shape(x), dtype=bool)       # OpenCV >= 4.1.1: icdist < 0 ends the iteration with the point back at (x0, y0)
     for _ in range(iters):
         r2 = x * x + y * y
-        icdist = 1.0 / (1.0 + ((k3 * r2 + k2) * r2 + k1) * r2)
+        with np.errstate(divide='ignore', invalid='ignore'):
+            icdist = 1.0 / (1.0 + ((k3 * r2 + k2) * r2 + k1) * r2)
+        stopped = stopped | (icdist < 0)
         dx = 2.0 * p1 * x * y + p2 * (r2 + 2.0 * x * x)
         dy = p1 * (r2 + 2.0 * y * y) + 2.0 * p2 * x * y
-        x = (x0 - dx) * icdist
-        y = (y0 - dy) * icdist
+        x = np.where(stopped, x0, (x0 - dx) * icdist)
+        y = np.where(stopped, y0, (y0 - dy) * icdist)
     return np.vstack((x, y))
 
 

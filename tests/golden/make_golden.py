@@ -44,13 +44,16 @@ def install_cv2_standin():
         x0 = (src[:, 0] - K[0, 2]) / K[0, 0]
         y0 = (src[:, 1] - K[1, 2]) / K[1, 1]
         x, y = x0.copy(), y0.copy()
+        stopped = np.zeros(x.shape, dtype=bool)      # OpenCV >= 4.1.1: a negative icdist ends the iteration with the point back at its start
         for _ in range(5):
             r2 = x * x + y * y
-            icd = 1.0 / (1.0 + ((k3 * r2 + k2) * r2 + k1) * r2)
+            with np.errstate(divide='ignore', invalid='ignore'):
+                icd = 1.0 / (1.0 + ((k3 * r2 + k2) * r2 + k1) * r2)
+            stopped = stopped | (icd < 0)
             dx = 2 * p1 * x * y + p2 * (r2 + 2 * x * x)
             dy = p1 * (r2 + 2 * y * y) + 2 * p2 * x * y
-            x = (x0 - dx) * icd
-            y = (y0 - dy) * icd
+            x = np.where(stopped, x0, (x0 - dx) * icd)
+            y = np.where(stopped, y0, (y0 - dy) * icd)
         return np.stack((x, y), axis=1).reshape(-1, 1, 2)
 
     cv2.Rodrigues = Rodrigues

@@ -16,12 +16,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 @pytest.fixture(scope='module')
 def hostlib():
-    src = os.path.join(HERE, 'hostcheck', 'hostcheck.cpp')
-    so = os.path.join(HERE, 'hostcheck', 'libhostcheck.so')
-    hdr = os.path.join(os.path.dirname(HERE), 'mvus_amd', 'csrc', 'ba_math.h')
-    if (not os.path.exists(so)) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
-        subprocess.check_call(['g++', '-O2', '-std=c++17', '-shared', '-fPIC', '-o', so, src])
-    return ctypes.CDLL(so)
+    import hostcheck_util
+    return hostcheck_util.load()           # ONE build recipe for tests/hostcheck/libhostcheck.so (both sources; rebuilt when a header is newer)
 
 
 def host_eval(lib, prob, x):
@@ -118,3 +114,25 @@ def test_host_analytic_jacobian_vs_central_differences(hostlib, name):
     assert err.max() < 2e-5, (err.max(), np.unravel_index(err.argmax(), err.shape))
     # rows of invisible detections carry no derivative at all
     assert not Jdense[f == 0].any()
+
+
+def test_undistort_negative_icdist_resets_the_point():
+    """cv2.undistortPoints of OpenCV >= 4.1.1 (behind Camera.undist_point, common.py:1147-1157) leaves a point at its normalised
+    start when 1 / (1 + k1 r^2 + k2 r^4 + k3 r^6) turns negative during the fixed-point iteration (cvUndistortPointsInternal,
+    regression_14583).  The device math, the oracle and the golden generator's shim restate that: a camera with k1 = -0.9 and
+    detections far from the principal point -- host build of the device math == oracle, and the affected observed pixels equal the
+    raw ones."""
+    from hostcheck_util import HostHandle
+    from mvus_amd import synth
+    sc = synth.make_scene(2, 600, seed=71, distortion=True)
+    sc.cameras[0]['d'] = np.array([-0.9, 0.0, 0.0, 0.0, 0.0])
+    K = sc.cameras[0]['K']
+    d0 = sc.detections[0]
+    d0[1] = K[0, 2] + 1.6 * K[0, 0] * np.sign(d0[1] - K[0, 2] + 0.5)      # |x0| = 1.6: 1 - 0.9 r^2 < 0
+    prob, x0 = mp.problem_from_scene(sc)
+    oprob, ox0 = orc.problem_from_scene(sc)
+    und = orc.undist_point(d0[1:3], K, sc.cameras[0]['d'])
+    assert np.allclose(und, d0[1:3], rtol=0, atol=1e-9)            # reset to the start: K * normalised(raw) = raw
+    f_host = HostHandle(prob).residual(x0)
+    f_orc = orc.residual(oprob, ox0)
+    assert np.all(np.isfinite(f_host)) and np.max(np.abs(f_host - f_orc)) < 1e-9
