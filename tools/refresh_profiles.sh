@@ -5,7 +5,7 @@
 # the program after `--` is python3 itself (no wrapper that re-execs).
 set -x
 export TMPDIR=/tmp
-R=${1:-r03}
+R=${1:-r04}
 O=gpurun_out/refresh; mkdir -p $O
 python bench.py --steps 20 --warmup 5 > $O/${R}_bench_config2_lm.json 2> $O/bench_config2_lm.err
 python bench.py --solver trf --steps 5 --warmup 1 --no-cpu-baseline --no-parity-solver > $O/${R}_bench_config2_trf.json 2>> $O/bench.err
@@ -41,5 +41,11 @@ python3 tools/incremental_loop.py --solver trf --cpu-sample 2>&1 | grep -v "^Num
 python3 tools/incremental_loop.py --solver lm 2>&1 | grep -v "^Number\|^Doing\|^$" > $O/${R}_incremental_loop_lm.txt
 python3 tools/xlevel_table.py > $O/${R}_xlevel_parity.txt 2>&1
 python3 tools/time_neighbours.py > $O/${R}_neighbour_steps.txt 2>&1
+# round 4: the window-major assembly against the detection-major one, per configuration and window length; its SQ counters; cycle probes
+python3 tools/micro/check_win_assembly.py 2>&1 | grep -v amdgpu > $O/${R}_window_assembly_check.txt
+MVUS_WIN_LIST=0,3,4,6,8,10,12,16,20 python3 tools/micro/time_win.py 2 1 3 4 2>&1 | grep -v amdgpu > $O/${R}_window_length_sweep.txt
+bash tools/micro/pmc_win.sh 2 > $O/${R}_window_assembly_sq_counters_config2.txt 2>&1
+python3 tools/micro/collective_latency.py 1 2>&1 | grep -v "amdgpu\|socket.cpp\|^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" > $O/${R}_collective_latency_world1.txt
+python3 tools/micro/time_scene_ba.py > $O/${R}_scene_ba_default_config1.txt 2>&1
 rm -rf $O/stats_lm $O/stats_trf $O/stats_c3 $O/pmc_fetch* $O/pmc_write* $O/pmc_traffic_c2.json $O/pmc_traffic_c23.json
 ls -la $O
