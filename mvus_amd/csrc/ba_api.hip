@@ -982,15 +982,18 @@ int32_t mvus_fd_groups(const mvus_problem* p, const int32_t* pat, const int32_t*
     auto for_each = [&](auto&& emit) {
       for (int c = 0; c < C; ++c) {
         const int64_t a = p->det_offsets[c], b = p->det_offsets[c + 1];
+        // Rows with the same set of columns are interchangeable for group_sparse (it only asks whether two columns share a row),
+        // so ONE row stands for a run of them: the v row of a detection repeats its u row, and time-ordered detections of one
+        // camera repeat the code of their neighbour for a whole knot span (200 k rows -> a few thousand at configs[1]; same groups).
+        int32_t prev = -1;
         for (int64_t i = a; i < b; ++i) {
-          if (pat[i] < 0) continue;
-          for (int xy = 0; xy < 2; ++xy) {
-            const int64_t row = 2 * a + xy * (b - a) + (i - a);
-            if (opt_sync) { emit(row, (int64_t)c); emit(row, (int64_t)C + c); }
-            if (rs_free) emit(row, 2 * (int64_t)C + c);
-            for (int k = 0; k < P; ++k) emit(row, 3 * (int64_t)C + (int64_t)c * P + k);
-            if (!spline_cols(pat[i], [&](int64_t col) { emit(row, col); })) bad_code = true;
-          }
+          if (pat[i] < 0 || pat[i] == prev) continue;
+          prev = pat[i];
+          const int64_t row = 2 * a + (i - a);
+          if (opt_sync) { emit(row, (int64_t)c); emit(row, (int64_t)C + c); }
+          if (rs_free) emit(row, 2 * (int64_t)C + c);
+          for (int k = 0; k < P; ++k) emit(row, 3 * (int64_t)C + (int64_t)c * P + k);
+          if (!spline_cols(pat[i], [&](int64_t col) { emit(row, col); })) bad_code = true;
         }
       }
       for (int64_t j = 0; j < hp.T; ++j) {

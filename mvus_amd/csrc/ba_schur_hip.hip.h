@@ -1671,19 +1671,63 @@ __global__ __launch_bounds__(256) void k_cholesky_and_rhs(PartView pv, double* _
 // fp64 matrix cores (v_mfma_f64_16x16x4_f64).  Both operands are stored K-major ([3N][CB] and [3N][ncols]), which is
 // exactly the MFMA operand layout (lane l: A[l&15][k = l>>4], B[k = l>>4][l&15]; every 16-lane group reads 128
 // contiguous bytes), so fragments go from global memory straight to registers -- no LDS staging.  One wavefront owns a
-// 48x48 output tile (3x3 MFMA tiles, 36 accumulator registers) over kGemmWaveK rows of K; the four wavefronts of a
+// 48x48 output tile (3x3 MFMA tiles, 36 accumulator registers) over wave_k rows of K; the four wavefronts of a
 // workgroup take consecutive K ranges of the same tile and are summed through LDS.  Et^T C^-1 Et is symmetric: only
 // tiles on or below the block diagonal are computed (k_schur_finish mirrors), plus one 48x16 tile per block row for
 // the right-hand-side column.  Partial sums per slab are written, not atomically added: no memset, deterministic.
 using d4 = __attribute__((ext_vector_type(4))) double;
-#ifndef MVUS_GEMM_WAVEK
-#define MVUS_GEMM_WAVEK 256
-#endif
-constexpr int kGemmT = 48, kGemmWaveK = MVUS_GEMM_WAVEK, kGemmSlab = 4 * kGemmWaveK;
+constexpr int kGemmT = 48;
+constexpr int kGemmUn = 4;                                 // k-steps (of 4 rows) per operand set
+constexpr int kGemmSetRows = 4 * kGemmUn;
 
+// Operand sets of the Schur product: kGemmUn k-steps of a 48-wide A strip and a 16 NJ-wide B strip, one double per lane and
+// 16 x 4 fragment.  Two sets are alive: the loads of set k+1 are issued before the matrix-core instructions of set k
+// (a lone wavefront per SIMD otherwise waits out the full memory latency once per set: 58 us instead of 27 at configs[2]).
+template <int NJ>
+struct GemmSet {
+  double a[kGemmUn][3], b[kGemmUn][NJ];
+  // ap / bp point at this lane's row (k + lane / 16) and first column; every address is inside the arrays (columns beyond the
+  // matrix are clamped by the caller: they only feed output rows / columns that are never stored), so the loads carry no
+  // predicate and no branch -- the steady-state loop below is one basic block and s_waitcnt can count the younger set's loads.
+  __device__ __forceinline__ void load(const double* __restrict__ ap, const double* __restrict__ bp, long long lda, long long ldb,
+                                       const int (&ao)[3], const int (&bo)[NJ]) {
+#pragma unroll
+    for (int u = 0; u < kGemmUn; ++u) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) a[u][i] = ap[(long long)(4 * u) * lda + ao[i]];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) b[u][j] = bp[(long long)(4 * u) * ldb + bo[j]];
+    }
+  }
+  // the last, possibly partial set of the whole product: rows clamped to the last one, their values replaced by zero
+  __device__ __forceinline__ void load_tail(const double* __restrict__ A, const double* __restrict__ B, long long lda, long long ldb,
+                                            const int (&ao)[3], const int (&bo)[NJ], int k, int k1, int lk) {
+#pragma unroll
+    for (int u = 0; u < kGemmUn; ++u) {
+      const int row = k + 4 * u + lk;
+      const bool kv = row < k1;
+      const long long rc = kv ? row : k1 - 1;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { const double v = A[rc * lda + ao[i]]; a[u][i] = kv ? v : 0.0; }
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) { const double v = B[rc * ldb + bo[j]]; b[u][j] = kv ? v : 0.0; }
+    }
+  }
+  __device__ __forceinline__ void multiply(d4 (&acc)[3][NJ]) const {
+#pragma unroll
+    for (int u = 0; u < kGemmUn; ++u)
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][i], b[u][j], acc[i][j], 0, 0, 0);
+  }
+};
+
+// The product's rows [row_lo, row_hi) are cut into sets of 16; wavefront g of nslab * 4 takes sets [g q + min(g, r), ...) with
+// q, r = nsets / nwaves, nsets % nwaves -- every wavefront within one set of the others; only the very last set can be partial.
 template <int NJ>   // NJ = 3: 48x48 tile of the symmetric part, NJ = 1: 48x16 tile holding the rhs column
 __device__ __forceinline__ void schur_gemm_tile(const NEView& ne, int ncols, const double* __restrict__ Erm, const double* __restrict__ Z,
-                                                double* __restrict__ Gp, int a0, int b0, int kbeg, int kend, double* red) {
+                                                double* __restrict__ Gp, int a0, int b0, int row_lo, int row_hi, int slab, int nslab, double* red) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int lr = lane & 15, lk = lane >> 4;
   d4 acc[3][NJ];
@@ -1691,32 +1735,43 @@ __device__ __forceinline__ void schur_gemm_tile(const NEView& ne, int ncols, con
   for (int i = 0; i < 3; ++i)
 #pragma unroll
     for (int j = 0; j < NJ; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
-  bool av[3], bv[NJ];
+  int ao[3], bo[NJ];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) av[i] = a0 + 16 * i + lr < ne.CB;
+  for (int i = 0; i < 3; ++i) ao[i] = min(a0 + 16 * i + lr, ne.CB - 1);
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) bv[j] = NJ == 3 ? (b0 + 16 * j + lr < ne.CB) : (lr == 0);
-  const int k0 = kbeg + wave * kGemmWaveK, k1 = min(k0 + kGemmWaveK, kend);
-  const double* ap = Erm + (long long)(k0 + lk) * ne.CB + a0 + lr;
-  const double* bp = Z + (long long)(k0 + lk) * ncols + b0 + lr;
-  constexpr int kUn = 4;                                   // k-steps whose operand loads are issued together
-  for (int k = k0; k < k1; k += 4 * kUn) {
-    double a[kUn][3], b[kUn][NJ];
-#pragma unroll
-    for (int u = 0; u < kUn; ++u) {
-      const bool kv = k + 4 * u + lk < k1;
-#pragma unroll
-      for (int i = 0; i < 3; ++i) a[u][i] = (kv && av[i]) ? ap[(long long)(4 * u) * ne.CB + 16 * i] : 0.0;
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) b[u][j] = (kv && bv[j]) ? bp[(long long)(4 * u) * ncols + 16 * j] : 0.0;
+  for (int j = 0; j < NJ; ++j) bo[j] = NJ == 3 ? min(b0 + 16 * j + lr, ne.CB - 1) : ne.CB;
+  const int nsets = (row_hi - row_lo + kGemmSetRows - 1) / kGemmSetRows, nwaves = nslab * 4, g = slab * 4 + wave;
+  const int q = nsets / nwaves, r = nsets % nwaves;
+  const int s_lo = g * q + min(g, r), s_hi = s_lo + q + (g < r ? 1 : 0);
+  const bool tail = s_hi == nsets && s_hi > s_lo && (row_hi - row_lo) % kGemmSetRows != 0;
+  const int nfull = s_hi - s_lo - (tail ? 1 : 0);
+  const long long lda = ne.CB, ldb = ncols;
+  const int k0 = row_lo + s_lo * kGemmSetRows;
+  const double* ap = Erm + (long long)(k0 + lk) * lda;
+  const double* bp = Z + (long long)(k0 + lk) * ldb;
+  const long long sa = kGemmSetRows * lda, sb = kGemmSetRows * ldb;
+  GemmSet<NJ> s0, s1;
+  if (nfull > 0) {
+    s0.load(ap, bp, lda, ldb, ao, bo);
+    int si = 0;
+    for (; si + 2 < nfull; si += 2) {                    // steady state: one basic block, every load unconditional
+      s1.load(ap + sa, bp + sb, lda, ldb, ao, bo);
+      s0.multiply(acc);
+      ap += 2 * sa; bp += 2 * sb;
+      s0.load(ap, bp, lda, ldb, ao, bo);
+      s1.multiply(acc);
     }
-    ap += 4 * kUn * (long long)ne.CB; bp += 4 * kUn * (long long)ncols;
-#pragma unroll
-    for (int u = 0; u < kUn; ++u)
-#pragma unroll
-      for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][i], b[u][j], acc[i][j], 0, 0, 0);
+    if (si + 1 < nfull) {
+      s1.load(ap + sa, bp + sb, lda, ldb, ao, bo);
+      s0.multiply(acc);
+      s1.multiply(acc);
+    } else {
+      s0.multiply(acc);
+    }
+  }
+  if (tail) {
+    s0.load_tail(Erm, Z, lda, ldb, ao, bo, row_lo + (s_hi - 1) * kGemmSetRows, row_hi, lk);
+    s0.multiply(acc);
   }
   // sum the four wavefronts through LDS, then store: element (i, j, reg) of lane l is row 16i + (l>>4) + 4 reg, col 16j + (l&15)
   for (int w = 0; w < 4; ++w) {
@@ -1740,20 +1795,27 @@ __device__ __forceinline__ void schur_gemm_tile(const NEView& ne, int ncols, con
   }
 }
 
-__global__ __launch_bounds__(256) void k_schur_gemm(NEView ne, int ncols, int row_lo, int row_hi, const double* __restrict__ Erm, const double* __restrict__ Z, double* __restrict__ Gp) {
+// Two workgroups per CU (<= 256 registers).  Every tile of a slab reads rows of the same K range, 12 tiles share each 48-column
+// strip: all workgroups of a slab go to ONE XCD (workgroup L runs on XCD L % 8: slab = L % 8 + 8 * (L / 8 / tiles)), so a strip
+// comes from HBM once and from that XCD's L2 afterwards (with the slabs dealt over all XCDs every XCD fetched every strip:
+// 154 - 308 MB for 55 MB of operands, and the kernel ran at the fabric's rate, not the matrix cores').  Grid: 8 * tiles *
+// ceil(nslab / 8) workgroups; the slab count is chosen by the host (HipSchur::plan_gemm) to fill whole rounds of the XCD's slots.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void k_schur_gemm(NEView ne, int ncols, int row_lo, int row_hi, int nslab, const double* __restrict__ Erm, const double* __restrict__ Z, double* __restrict__ Gp) {
   __shared__ double red[9 * 4 * 64];
-  const int nbk = (ne.CB + kGemmT - 1) / kGemmT, nsym = nbk * (nbk + 1) / 2;
-  const int t = blockIdx.x;
-  const int kbeg = row_lo + blockIdx.y * kGemmSlab, kend = min(kbeg + kGemmSlab, row_hi);      // rows this slice owns
-  double* G = Gp + (long long)blockIdx.y * ne.CB * ncols;
+  const int nbk = (ne.CB + kGemmT - 1) / kGemmT, nsym = nbk * (nbk + 1) / 2, tiles = nsym + nbk;
+  const int L = blockIdx.x, j = L >> 3;
+  const int slab = (L & 7) + 8 * (j / tiles), t = j % tiles;
+  if (slab >= nslab) return;
+  double* G = Gp + (long long)slab * ne.CB * ncols;
   if (t < nsym) {
     int bi = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
     while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
     while (bi * (bi + 1) / 2 > t) --bi;
     const int bj = t - bi * (bi + 1) / 2;
-    schur_gemm_tile<3>(ne, ncols, Erm, Z, G, bi * kGemmT, bj * kGemmT, kbeg, kend, red);
+    schur_gemm_tile<3>(ne, ncols, Erm, Z, G, bi * kGemmT, bj * kGemmT, row_lo, row_hi, slab, nslab, red);
   } else {
-    schur_gemm_tile<1>(ne, ncols, Erm, Z, G, (t - nsym) * kGemmT, ne.CB, kbeg, kend, red);
+    schur_gemm_tile<1>(ne, ncols, Erm, Z, G, (t - nsym) * kGemmT, ne.CB, row_lo, row_hi, slab, nslab, red);
   }
 }
 
@@ -2055,7 +2117,7 @@ struct HipSchur {
   int* fail_map = nullptr;  // device address of fail_host (mapped pinned)
   PartView pv{};
   int* part_tables = nullptr;
-  int nslab = 1;            // K-slabs of the Schur product (partial sums in G)
+  int nslab = 1;            // K-slabs of the Schur product (partial sums in G): HipSchur::plan_gemm
   int bcr_cols = kBcrCols;
   size_t bcr_lds = 0;       // dynamic LDS of k_sep_bcr_rhs; the sequential separator kernels remain for chains too long for it
   bool use_bcr = false;
@@ -2074,6 +2136,27 @@ struct HipSchur {
   bool wide = false;                           // band wider than six control points: the general band kernels instead of the partitioned solver
   void* win_tables = nullptr;
   size_t win_lds = 0;
+
+  // K-slabs of the Schur product: a slab's tiles run on one XCD, two workgroups per CU, so the time is (rounds of the busiest XCD's
+  // slots) x (row sets per wavefront); the slab count with the least of that (ties: fewer slabs = fewer partial sums for k_schur_finish)
+  void plan_gemm(int rows) {
+    const int nbk = (ne.CB + kGemmT - 1) / kGemmT, tiles = nbk * (nbk + 1) / 2 + nbk;
+    int cus = 256;
+    { int dev = 0; hipDeviceProp_t pr{}; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) cus = pr.multiProcessorCount; }
+    const int slots = 2 * cus, nsets = std::max(1, (rows + kGemmSetRows - 1) / kGemmSetRows);
+    nslab = 1;
+    const char* e = std::getenv("MVUS_GEMM_SLABS");
+    if (e && std::atoi(e) > 0) { nslab = std::atoi(e); }
+    else {
+      double best = 1e300;
+      for (int s = 1; s <= 128 && 4 * s <= nsets; ++s) {
+        const int per_wave = (nsets + 4 * s - 1) / (4 * s);                       // sets of the busiest wavefront
+        const int on_xcd = tiles * ((s + 7) / 8);                                 // workgroups of the busiest XCD
+        const double cost = (double)((on_xcd + slots / 8 - 1) / (slots / 8)) * (per_wave + 1.5) + 0.002 * s;
+        if (cost < best * 0.995) { best = cost; nslab = s; }
+      }
+    }
+  }
 
   explicit HipSchur(BE& b) : be(b) {
     const HostProblem& hp = be.hp;
@@ -2125,7 +2208,7 @@ struct HipSchur {
     Lb = be.alloc((size_t)ne.N3 * (BW + 1));
     Z = be.alloc((size_t)ne.N3 * ncols);
     Erm = be.alloc((size_t)ne.N3 * ne.CB);
-    nslab = (3 * (own_hi - own_lo) + kGemmSlab - 1) / kGemmSlab;
+    plan_gemm(3 * (own_hi - own_lo));
     G = be.alloc((size_t)nslab * ne.CB * ncols);
     G0 = be.alloc((size_t)ne.CB * ncols);
     S = be.alloc((size_t)(ne.CB + 1) * ne.CB);
@@ -2472,7 +2555,7 @@ struct HipSchur {
     const int row_lo = 3 * own_lo, row_hi = 3 * own_hi;
     {
       const int nbk = (ne.CB + kGemmT - 1) / kGemmT;
-      hipLaunchKernelGGL(k_schur_gemm, dim3(nbk * (nbk + 1) / 2 + nbk, nslab), dim3(256), 0, be.stream, ne, ncols, row_lo, row_hi, Erm, Z, G);
+      hipLaunchKernelGGL(k_schur_gemm, dim3(8 * (nbk * (nbk + 1) / 2 + nbk) * ((nslab + 7) / 8)), dim3(256), 0, be.stream, ne, ncols, row_lo, row_hi, nslab, Erm, Z, G);
     }
     const int ntile = (ne.CB + kNB - 1) / kNB;
     if (shard) {

@@ -30,6 +30,7 @@ def main():
     ap.add_argument('--max-iter', type=int, default=10)
     ap.add_argument('--motion-weights', type=float, default=1e2, help='configs[1] quotes 1e4 (README); on this synthetic flight that lets the regulariser outweigh the data 100:1')
     ap.add_argument('--cpu-sample', action='store_true')
+    ap.add_argument('--cpu-all', action='store_true', help="time the oracle (scipy least_squares, one core) on EVERY BA of the loop, on the state the GPU BA starts from -- use a down-scaled flight (--obs 20000)")
     ap.add_argument('--seed', type=int, default=None)
     ap.add_argument('--lambda-min', type=float, default=None, help="settings['ba_lambda_min'] (floor of the LM damping)")
     ap.add_argument('--lm-wide', choices=['lm', 'trf'], default=None, help="settings['ba_lm_wide_band']: what ba_solver=lm does when the motion rows reach over more than six control points")
@@ -63,6 +64,34 @@ def main():
             t1 = time.perf_counter()
             r = orc.solve(oprob, ox0, max_iter=args.max_iter)
             oracle_ba = (time.perf_counter() - t1, r.nfev, sum(d.shape[1] for d in oprob.detections), ox0.size)
+    cpu_rows = []
+    if args.cpu_all:
+        # the reference's loop calls Scene.BA twelve times (main.py:49-62); before each GPU call the same problem -- cameras
+        # sequence[:numCam], their detections, the current spline -- goes to the oracle's restatement of the reference's BA
+        from oracle import ba_oracle as orc
+        from types import SimpleNamespace
+        from threadpoolctl import threadpool_limits
+        gpu_ba = flight.BA
+
+        def ba_with_cpu_clock(numCam, **kw):
+            cams = list(flight.sequence[:numCam])
+            view = SimpleNamespace(cameras=[dict(K=flight.cameras[i].K, d=flight.cameras[i].d, R=flight.cameras[i].R, t=flight.cameras[i].t,
+                                                 resolution=flight.cameras[i].resolution) for i in cams],
+                                   detections=[flight.detections[i] for i in cams], alpha=np.asarray(flight.alpha)[cams],
+                                   beta=np.asarray(flight.beta)[cams], rs=np.asarray(flight.rs)[cams], tck=flight.spline['tck'],
+                                   interval=flight.spline['int'], settings=flight.settings, num_cam=numCam)
+            oprob, ox0 = orc.problem_from_scene(view, num_cam=numCam, rs=kw.get('rs', False), motion_reg=kw.get('motion_reg', False),
+                                                motion_weights=kw.get('motion_weights', 1), rs_bounds=kw.get('rs_bounds', False))
+            with threadpool_limits(limits=1):
+                t1 = time.perf_counter()
+                r = orc.solve(oprob, ox0, max_iter=kw.get('max_iter', 10))
+                cpu = time.perf_counter() - t1
+            t1 = time.perf_counter()
+            res = gpu_ba(numCam, **kw)
+            gpu = time.perf_counter() - t1
+            cpu_rows.append((numCam, sum(d.shape[1] for d in oprob.detections), ox0.size, r.nfev, cpu, r.cost, gpu, res.cost, getattr(res, 'solver_used', '?')))
+            return res
+        flight.BA = ba_with_cpu_clock
     t0 = time.perf_counter()
     timer = pipeline.incremental_reconstruction(flight, max_iter=args.max_iter, verbose=False)
     total = time.perf_counter() - t0
@@ -77,6 +106,14 @@ def main():
     if oracle_ba:
         print('CPU (oracle restatement of the reference BA, scipy least_squares, 1 core): first 2-camera BA, %d detections, %d '
               'parameters, %d evaluations: %.1f s' % (oracle_ba[2], oracle_ba[3], oracle_ba[1], oracle_ba[0]))
+    if cpu_rows:
+        print('every BA of the loop: the oracle (scipy least_squares as the reference calls it, ONE core of this host) and the GPU on the same start')
+        print('%3s %5s %9s %7s | %5s %9s %14s | %9s %14s  %s' % ('BA', 'cams', 'detect.', 'params', 'nfev', 'CPU s', 'CPU cost', 'GPU s', 'GPU cost', 'GPU solver'))
+        for k, (nc_, m_, n_, nfev, cpu, ccost, gpu, gcost, used) in enumerate(cpu_rows):
+            print('%3d %5d %9d %7d | %5d %9.2f %14.6g | %9.3f %14.6g  %s' % (k + 1, nc_, m_, n_, nfev, cpu, ccost, gpu, gcost, used[:40]))
+        print('sum over the %d BAs: CPU %.1f s, GPU %.2f s (ratio %.0f)' % (len(cpu_rows), sum(r[4] for r in cpu_rows), sum(r[6] for r in cpu_rows),
+                                                                          sum(r[4] for r in cpu_rows) / max(sum(r[6] for r in cpu_rows), 1e-9)))
+        print('(loop total above includes the CPU clock; GPU stages alone: %.2f s)' % (total - sum(r[4] for r in cpu_rows)))
     ev = pipeline.evaluate_against_truth(flight, sc)
     print('mean reprojection error per camera (px):', np.round(ev['mean_err'], 3))
     print('detections kept / clean by the generator / kept although not clean:', list(zip(ev['kept'], ev['clean'], ev['kept_dirty'])))
