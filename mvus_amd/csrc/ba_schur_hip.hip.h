@@ -1024,7 +1024,10 @@ __device__ __forceinline__ void part_solve_block(const PartView& pv, int ncols, 
   double cur[kPf], nxt[kPf];
 #pragma unroll
   for (int k = 0; k < kPf; ++k) nxt[k] = rhs_at(k);
-  for (int ib = 0; ib < nrp; ib += kPf) {
+#ifndef MVUS_PS_EXP
+#define MVUS_PS_EXP 0
+#endif
+  for (int ib = 0; ib < (MVUS_PS_EXP == 1 ? 0 : nrp); ib += kPf) {
 #pragma unroll
     for (int k = 0; k < kPf; ++k) cur[k] = nxt[k];
     if (ib + kPf < nrp) {
@@ -1041,7 +1044,9 @@ __device__ __forceinline__ void part_solve_block(const PartView& pv, int ncols, 
 #pragma unroll
       for (int j = BW; j >= 1; --j) acc -= Lr[k * R + j] * yw[j - 1];
       const double y = acc * Lr[k * R];
+#if MVUS_PS_EXP != 3
       if (ib + k < nr) yo[(long long)k * ostride] = y;
+#endif
 #pragma unroll
       for (int j = BW - 1; j >= 1; --j) yw[j] = yw[j - 1];
       yw[0] = y;
@@ -1053,7 +1058,7 @@ __device__ __forceinline__ void part_solve_block(const PartView& pv, int ncols, 
   auto y_at = [&](int i) { return i < nr ? out[(long long)i * ostride] : 0.0; };
 #pragma unroll
   for (int k = 0; k < kPf; ++k) nxt[k] = y_at(nrp - kPf + k);
-  for (int ib = nrp - kPf; ib >= 0; ib -= kPf) {
+  for (int ib = (MVUS_PS_EXP == 2 ? -1 : nrp - kPf); ib >= 0; ib -= kPf) {
 #pragma unroll
     for (int k = 0; k < kPf; ++k) cur[k] = nxt[k];
     if (ib > 0) {
@@ -1825,35 +1830,67 @@ void k_schur_gemm(NEView ne, int ncols, int row_lo, int row_hi, int nslab, const
 constexpr int kNB = 32;
 __device__ __forceinline__ void pivot_inverse_wave(double (*Dm)[kNB + 1], double* __restrict__ W, double* __restrict__ Pout, int* __restrict__ fail);
 constexpr int kPivScratch = 5 * 16 * 17;      // doubles of LDS scratch pivot_inverse_wave needs
-__global__ __launch_bounds__(kNB * kNB) void k_schur_finish(NEView ne, int ncols, int nslab, double lambda, const double* __restrict__ Gp, double* __restrict__ S,
-                                                            double* __restrict__ Linv, int* __restrict__ fail) {
+constexpr int kFinThreads = 256;            // 32x32 tile, four rows per thread (256 threads: the pivot inverse needs > 128 registers)
+__global__ __launch_bounds__(kFinThreads) void k_schur_finish(NEView ne, int ncols, int nslab, double lambda, const double* __restrict__ Gp, double* __restrict__ S,
+                                                             double* __restrict__ Linv, int* __restrict__ fail) {
   __shared__ double Dm[kNB][kNB + 1];
   __shared__ double Wp[kPivScratch];
-  const int r = threadIdx.x / kNB, c = threadIdx.x % kNB;
-  const int a = blockIdx.y * kNB + r, b = blockIdx.x * kNB + c;
+  constexpr int kRowsPer = kNB * kNB / kFinThreads, kRowStep = kFinThreads / kNB;
+  const int r0 = threadIdx.x / kNB, c = threadIdx.x % kNB;
+  const int b = blockIdx.x * kNB + c;
   const long long stride = (long long)ne.CB * ncols;
-  double v = 0.0;
-  if (a < ne.CB && b < ne.CB) {
+  const bool first = blockIdx.x == 0 && blockIdx.y == 0;
+  const int nb = min(kNB, ne.CB);
+  // the slabs' partial sums: every load of a thread is independent of the others -- eight slabs x four rows in flight, added in
+  // slab order (a loop of load, add, load ... is a chain of nslab memory round trips: 19 us of this kernel at 16 slabs)
+  double gsum[kRowsPer];
+  long long goff[kRowsPer];
+#pragma unroll
+  for (int q = 0; q < kRowsPer; ++q) {
+    const int a = blockIdx.y * kNB + r0 + kRowStep * q;
     const int hi = a / kGemmT >= b / kGemmT ? a : b, lo = a / kGemmT >= b / kGemmT ? b : a;
-    double g = 0.0;
-    for (int sl = 0; sl < nslab; ++sl) g += Gp[sl * stride + (long long)hi * ncols + lo];
-    v = -g;
-    if (a / ne.B == b / ne.B) {
-      const int cam = a / ne.B;
-      double h = ne.A[((long long)cam * ne.B + a % ne.B) * ne.B + b % ne.B];
-      if (a == b) h += lambda * (h > 0.0 ? h : 1.0);
-      v += h;
-    }
-    S[(long long)a * ne.CB + b] = v;
+    goff[q] = (a < ne.CB && b < ne.CB) ? (long long)hi * ncols + lo : -1;
+    gsum[q] = 0.0;
   }
-  if (blockIdx.y == 0 && r == 0 && b < ne.CB) {               // rhs rides as row CB
+  for (int sl = 0; sl < nslab; sl += 8) {
+    double t[8][kRowsPer];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int q = 0; q < kRowsPer; ++q) t[u][q] = (sl + u < nslab && goff[q] >= 0) ? Gp[(sl + u) * stride + goff[q]] : 0.0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int q = 0; q < kRowsPer; ++q) gsum[q] += t[u][q];
+  }
+#pragma unroll
+  for (int q = 0; q < kRowsPer; ++q) {
+    const int r = r0 + kRowStep * q, a = blockIdx.y * kNB + r;
+    double v = 0.0;
+    if (a < ne.CB && b < ne.CB) {
+      v = -gsum[q];
+      if (a / ne.B == b / ne.B) {
+        const int cam = a / ne.B;
+        double h = ne.A[((long long)cam * ne.B + a % ne.B) * ne.B + b % ne.B];
+        if (a == b) h += lambda * (h > 0.0 ? h : 1.0);
+        v += h;
+      }
+      S[(long long)a * ne.CB + b] = v;
+    }
+    if (first) Dm[r][c] = (r < nb && c < nb && c <= r) ? v : ((r < nb && c < nb) ? 0.0 : (r == c ? 1.0 : 0.0));
+  }
+  if (blockIdx.y == 0 && r0 == 0 && b < ne.CB) {               // rhs rides as row CB
     double gr = 0.0;
-    for (int sl = 0; sl < nslab; ++sl) gr += Gp[sl * stride + (long long)b * ncols + ne.CB];
+    for (int sl = 0; sl < nslab; sl += 8) {
+      double t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = sl + u < nslab ? Gp[(sl + u) * stride + (long long)b * ncols + ne.CB] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) gr += t[u];
+    }
     S[(long long)ne.CB * ne.CB + b] = ne.gc[b] - gr;
   }
-  if (blockIdx.x != 0 || blockIdx.y != 0) return;
-  const int nb = min(kNB, ne.CB);
-  Dm[r][c] = (r < nb && c < nb && c <= r) ? v : ((r < nb && c < nb) ? 0.0 : (r == c ? 1.0 : 0.0));
+  if (!first) return;
   __syncthreads();
   if (threadIdx.x < 64) pivot_inverse_wave(Dm, Wp, Linv, fail);
 }
@@ -1870,8 +1907,7 @@ __global__ __launch_bounds__(kNB * kNB) void k_schur_finish(NEView ne, int ncols
 //
 // The critical path per panel is the inverse of the 32x32 pivot block, done by ONE wavefront of the workgroup that
 // produced that block (pivot_inverse_wave): 2x2 blocks of 16 -- Cholesky + inverse factor of a 16x16 block in registers
-// (row per lane, pivot column by v_readlane, 1/sqrt by v_rsq_f64 + 2 Newton steps; 16 more lanes carry the identity and
-// end up holding L^-T), the Schur complement, the off-diagonal block of L^-1 and P = L^-T L^-1 on the fp64 matrix cores.
+// (row of the block and of the identity per lane, multipliers by DPP row broadcast, 1/d by v_rcp_f64 + 2 Newton steps), the Schur complement, the off-diagonal block of L^-1 and P = L^-T L^-1 on the fp64 matrix cores.
 // Round 2 history (cycle counters, MVUS_GJ_PROBE): a 32-step register Cholesky took 22k cycles and the tile update 13k
 // (three 32-deep LDS dot products per thread: LDS-bandwidth bound); now 16-step halves + matrix-core tile products.
 
@@ -1881,27 +1917,39 @@ __device__ __forceinline__ double bcast_lane(double v, int src) {
   return __hiloint2double(hi, lo);
 }
 
-// L D L^T of a 16x16 SPD block by half a wavefront: lanes 0..15 hold its rows (lower triangle), lanes 16..31 the identity.
-// Column operations col_j -= col_k * (a_jk / d_k): on return lane 16+c holds X[k][c] = (L^-1)[k][c] (unit lower, zero
-// above) and rd[k] = 1 / d_k in every lane, so that block^-1 = X^T diag(rd) X.  No square root, and the broadcast of the
-// raw column (v_readlane) does not wait for the reciprocal: the dependent chain per column is pivot -> rcp + 2 Newton
-// steps -> one multiply -> the first trailing FMA.  No branch inside the loop (one basic block: the scheduler runs the
-// reciprocal of column k+1 under the trailing update of column k).
-__device__ __forceinline__ void ldl_inv16(double (&a)[16], double (&rd)[16], int lane, int* __restrict__ fail) {
-  bool bad = false;
-#pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    double d = bcast_lane(a[k], k);
+// L D L^T of a 16x16 SPD block, every row of 16 lanes on its own copy: lane i of the row holds row i of the block (a, lower
+// triangle) and row i of the identity (x).  Column operations col_j -= col_k * (a_jk / d_k) on both: on return x[k] of lane c is
+// X[k][c] = (L^-1)[k][c] (unit lower, zero above) and rd[k] = 1 / d_k in every lane, so that block^-1 = X^T diag(rd) X.  No square
+// root.  The multiplier A[j][k] comes from lane j by DPP (v_mov_b64_dpp row_newbcast:j -- the one DPP control 64-bit operands have
+// on this part): a vector move per multiplier instead of two v_readlane through an SGPR pair with its wait states, which is what
+// the 16-column chain was made of (tools/micro/ldl16_bench.hip: cycles of the two forms on one wavefront).  One basic block.
+template <int J> __device__ __forceinline__ double row_bcast(double v) { return __builtin_amdgcn_update_dpp(v, v, 0x150 + J, 0xf, 0xf, false); }
+template <int K, int J> struct LdlColOps {
+  static __device__ __forceinline__ void run(double (&a)[16], double (&x)[16], double ta, double tx) {
+    const double m = row_bcast<J>(a[K]);
+    a[J] -= ta * m;
+    x[J] -= tx * m;
+    LdlColOps<K, J + 1>::run(a, x, ta, tx);
+  }
+};
+template <int K> struct LdlColOps<K, 16> { static __device__ __forceinline__ void run(double (&)[16], double (&)[16], double, double) {} };
+template <int K> struct LdlCols {
+  static __device__ __forceinline__ void run(double (&a)[16], double (&x)[16], double (&rd)[16], bool& bad) {
+    double d = row_bcast<K>(a[K]);
     bad |= !(d > 0.0);
     d = d > 0.0 ? d : 1.0;
     double r = __builtin_amdgcn_rcp(d);
     r = r * (2.0 - d * r);
     r = r * (2.0 - d * r);
-    rd[k] = r;
-    const double t = a[k] * r;
-#pragma unroll
-    for (int j = k + 1; j < 16; ++j) a[j] -= t * bcast_lane(a[k], j);
+    rd[K] = r;
+    LdlColOps<K, K + 1>::run(a, x, a[K] * r, x[K] * r);
+    LdlCols<K + 1>::run(a, x, rd, bad);
   }
+};
+template <> struct LdlCols<16> { static __device__ __forceinline__ void run(double (&)[16], double (&)[16], double (&)[16], bool&) {} };
+__device__ __forceinline__ void ldl_inv16(double (&a)[16], double (&x)[16], double (&rd)[16], int lane, int* __restrict__ fail) {
+  bool bad = false;
+  LdlCols<0>::run(a, x, rd, bad);
   if (bad && lane == 0) fail[0] = 2;
 }
 
@@ -1935,19 +1983,21 @@ __device__ __forceinline__ void pivot_inverse_wave(double (*Dm)[kNB + 1], double
   double* M3 = W + 2 * 16 * LD;   // A11^-1
   double* M4 = W + 3 * 16 * LD;   // T, later P21
   double* M5 = W + 4 * 16 * LD;   // S, later P22
-  double a[16], rd[16];
+  double a[16], x[16], rd[16];
 #ifdef MVUS_GJ_PROBE
   const long long q0_ = clock64();
 #endif
 #pragma unroll
-  for (int k = 0; k < 16; ++k) {          // unconditional LDS reads, then selects: no branch per element
+  for (int k = 0; k < 16; ++k) {          // unconditional LDS reads, then selects: no branch per element (every row of 16 lanes the same)
     const double t = Dm[row][k];
-    a[k] = lane < 16 ? (k <= row ? t : 0.0) : (lane < 32 && k == row ? 1.0 : 0.0);
+    a[k] = k <= row ? t : 0.0;
+    x[k] = k == row ? 1.0 : 0.0;
   }
-  ldl_inv16(a, rd, lane, fail);
-  if (lane >= 16 && lane < 32) {
+  ldl_inv16(a, x, rd, lane, fail);
+  if (lane < 32) {                        // lanes 0..15 store X, lanes 16..31 (the same values) D^-1 X
+    double* dst = (lane < 16 ? M1 : M2) + row;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) { M1[k * LD + row] = a[k]; M2[k * LD + row] = rd[k] * a[k]; }
+    for (int k = 0; k < 16; ++k) dst[k * LD] = lane < 16 ? x[k] : rd[k] * x[k];
   }
   lds_wave_sync();
 #ifdef MVUS_GJ_PROBE
@@ -1969,12 +2019,14 @@ __device__ __forceinline__ void pivot_inverse_wave(double (*Dm)[kNB + 1], double
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
     const double t = M5[row * LD + k];
-    a[k] = lane < 16 ? (k <= row ? t : 0.0) : (lane < 32 && k == row ? 1.0 : 0.0);
+    a[k] = k <= row ? t : 0.0;
+    x[k] = k == row ? 1.0 : 0.0;
   }
-  ldl_inv16(a, rd, lane, fail);
-  if (lane >= 16 && lane < 32) {
+  ldl_inv16(a, x, rd, lane, fail);
+  if (lane < 32) {
+    double* dst = (lane < 16 ? M1 : M2) + row;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) { M1[k * LD + row] = a[k]; M2[k * LD + row] = rd[k] * a[k]; }
+    for (int k = 0; k < 16; ++k) dst[k * LD] = lane < 16 ? x[k] : rd[k] * x[k];
   }
   lds_wave_sync();
 #ifdef MVUS_GJ_PROBE
@@ -2562,9 +2614,9 @@ struct HipSchur {
       const long long cnt = (long long)ne.CB * ncols;
       hipLaunchKernelGGL(k_sum_slabs, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, be.stream, cnt, nslab, G, G0);
       be.reduce(G0, (size_t)cnt);                   // the Schur complement contributions of all time slices
-      hipLaunchKernelGGL(k_schur_finish, dim3(ntile, ntile), dim3(kNB * kNB), 0, be.stream, ne, ncols, 1, lambda, G0, S, Linv, fail);
+      hipLaunchKernelGGL(k_schur_finish, dim3(ntile, ntile), dim3(kFinThreads), 0, be.stream, ne, ncols, 1, lambda, G0, S, Linv, fail);
     } else {
-      hipLaunchKernelGGL(k_schur_finish, dim3(ntile, ntile), dim3(kNB * kNB), 0, be.stream, ne, ncols, nslab, lambda, G, S, Linv, fail);
+      hipLaunchKernelGGL(k_schur_finish, dim3(ntile, ntile), dim3(kFinThreads), 0, be.stream, ne, ncols, nslab, lambda, G, S, Linv, fail);
     }
     {
       const int nn = ne.CB;
