@@ -1024,10 +1024,7 @@ __device__ __forceinline__ void part_solve_block(const PartView& pv, int ncols, 
   double cur[kPf], nxt[kPf];
 #pragma unroll
   for (int k = 0; k < kPf; ++k) nxt[k] = rhs_at(k);
-#ifndef MVUS_PS_EXP
-#define MVUS_PS_EXP 0
-#endif
-  for (int ib = 0; ib < (MVUS_PS_EXP == 1 ? 0 : nrp); ib += kPf) {
+  for (int ib = 0; ib < nrp; ib += kPf) {
 #pragma unroll
     for (int k = 0; k < kPf; ++k) cur[k] = nxt[k];
     if (ib + kPf < nrp) {
@@ -1044,9 +1041,7 @@ __device__ __forceinline__ void part_solve_block(const PartView& pv, int ncols, 
 #pragma unroll
       for (int j = BW; j >= 1; --j) acc -= Lr[k * R + j] * yw[j - 1];
       const double y = acc * Lr[k * R];
-#if MVUS_PS_EXP != 3
       if (ib + k < nr) yo[(long long)k * ostride] = y;
-#endif
 #pragma unroll
       for (int j = BW - 1; j >= 1; --j) yw[j] = yw[j - 1];
       yw[0] = y;
@@ -1058,7 +1053,7 @@ __device__ __forceinline__ void part_solve_block(const PartView& pv, int ncols, 
   auto y_at = [&](int i) { return i < nr ? out[(long long)i * ostride] : 0.0; };
 #pragma unroll
   for (int k = 0; k < kPf; ++k) nxt[k] = y_at(nrp - kPf + k);
-  for (int ib = (MVUS_PS_EXP == 2 ? -1 : nrp - kPf); ib >= 0; ib -= kPf) {
+  for (int ib = nrp - kPf; ib >= 0; ib -= kPf) {
 #pragma unroll
     for (int k = 0; k < kPf; ++k) cur[k] = nxt[k];
     if (ib > 0) {
