@@ -47,5 +47,12 @@ MVUS_WIN_LIST=0,3,4,6,8,10,12,16,20 python3 tools/micro/time_win.py 2 1 3 4 2>&1
 bash tools/micro/pmc_win.sh 2 > $O/${R}_window_assembly_sq_counters_config2.txt 2>&1
 python3 tools/micro/collective_latency.py 1 2>&1 | grep -v "amdgpu\|socket.cpp\|^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" > $O/${R}_collective_latency_world1.txt
 python3 tools/micro/time_scene_ba.py > $O/${R}_scene_ba_default_config1.txt 2>&1
+# the Schur product's counters (MFMA busy, L2 hits, HBM fetch), the 16x16 pivot chain in isolation, the loop with the oracle's clock on
+# every BA (down-scaled flight; at the loop's 1e2 and at configs[1]'s 1e4), the loop at 1e4 at full size
+bash tools/micro/pmc_gemm.sh 2 > $O/${R}_schur_gemm_counters_config2.txt 2>&1
+/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -o /tmp/ldl16_bench tools/micro/ldl16_bench.hip 2>/dev/null && /tmp/ldl16_bench > $O/${R}_ldl16_pivot_chain.txt 2>&1
+python3 tools/incremental_loop.py --solver trf --obs 20000 --cpu-all 2>&1 | grep -v "^Number\|^Doing\|^$\|amdgpu" > $O/${R}_loop_oracle_clock_every_ba.txt
+python3 tools/incremental_loop.py --solver trf --obs 20000 --cpu-all --motion-weights 1e4 2>&1 | grep -v "^Number\|^Doing\|^$\|amdgpu" > $O/${R}_loop_oracle_clock_every_ba_mw1e4.txt
+for seed in 1 2 3; do echo "== seed $seed trf motion_weights 1e4"; python3 tools/incremental_loop.py --solver trf --motion-weights 1e4 --seed $seed 2>&1 | grep -v "^Number\|^Doing\|^$\|amdgpu" | tail -9; done > $O/${R}_loop_motion_weights_1e4.txt 2>&1
 rm -rf $O/stats_lm $O/stats_trf $O/stats_c3 $O/pmc_fetch* $O/pmc_write* $O/pmc_traffic_c2.json $O/pmc_traffic_c23.json
 ls -la $O
