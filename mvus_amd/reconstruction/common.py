@@ -47,12 +47,15 @@ def _undistort_normalized(points, K, d):
     x0 = (points[0] - K[0, 2]) / K[0, 0]
     y0 = (points[1] - K[1, 2]) / K[1, 1]
     x, y = x0.copy(), y0.copy()
+    reset = np.zeros(np.shape(x), dtype=bool)        # OpenCV >= 4.1.1: a negative 1/(1 + k1 r^2 + ...) puts the point back at its start for good
     for _ in range(5):
         r2 = x * x + y * y
-        icd = 1.0 / (1.0 + ((k3 * r2 + k2) * r2 + k1) * r2)
+        with np.errstate(divide='ignore', invalid='ignore'):
+            icd = 1.0 / (1.0 + ((k3 * r2 + k2) * r2 + k1) * r2)
+        reset = reset | (icd < 0)
         dx = 2.0 * p1 * x * y + p2 * (r2 + 2.0 * x * x)
         dy = p1 * (r2 + 2.0 * y * y) + 2.0 * p2 * x * y
-        x, y = (x0 - dx) * icd, (y0 - dy) * icd
+        x, y = np.where(reset, x0, (x0 - dx) * icd), np.where(reset, y0, (y0 - dy) * icd)
     return np.vstack((x, y))
 
 
@@ -488,36 +491,38 @@ class Scene:
         the per-point linear triangulation and both reprojection distances come from one GPU kernel
         (``mvus_triangulate``) instead of a Python loop of 4x4 SVDs."""
         from . import epipolar as ep
-        assert self.cameras[cam_id].P is not None, 'The camera pose must be computed first'
-        interval = self.spline['int']
-        self.detection_to_global(cam_id)
-        _, idx_ex = util.sampling(self.detections_global[cam_id], interval)
-        detect_new = self.detections_global[cam_id][:, np.logical_not(idx_ex)]
+        new_cam = self.cameras[cam_id]
+        assert new_cam.P is not None, 'The camera pose must be computed first'
+        covered = self.spline['int']
         device = int(self.settings.get('device', 0)) if isinstance(self.settings, dict) else 0
-        X_new = np.empty([4, 0])
-        for i in cams:
-            self.detection_to_global(i)
-            detect_ex = self.detections_global[i]
+        self.detection_to_global(cam_id)
+        mine = self.detections_global[cam_id]
+        mine = mine[:, ~np.asarray(util.sampling(mine, covered)[1], dtype=bool)]      # only what the spline does not cover yet
+
+        def against(other):
+            """[t; X] of this camera's uncovered detections paired in time with camera ``other`` (one GPU launch per pair of cameras)."""
+            self.detection_to_global(other)
             try:
-                x1, x2 = util.match_overlap(detect_new, detect_ex)
+                a, b = util.match_overlap(mine, self.detections_global[other])
             except Exception:                       # no temporal overlap with this camera (the reference's bare except)
-                continue
-            X_h, err_1, err_2 = ep.triangulate_with_errors(x1[1:], x2[1:], self.cameras[cam_id].P, self.cameras[i].P, device=device)
-            X_i = np.vstack((x1[0], X_h[:-1]))
+                return None
+            Xh, d_new, d_other = ep.triangulate_with_errors(a[1:], b[1:], new_cam.P, self.cameras[other].P, device=device)
+            pts = np.vstack((a[0], Xh[:3]))
             if thres:
-                mask = np.logical_and(err_1 < thres, err_2 < thres)
-                X_i = X_i[:, mask]
+                ok = (d_new < thres) & (d_other < thres)
                 if verbose:
-                    print('{} out of {} points are triangulated'.format(sum(mask), len(err_1)))
-            X_new = np.hstack((X_new, X_i))
+                    print('{} out of {} points are triangulated'.format(sum(ok), len(d_new)))
+                pts = pts[:, ok]
             if verbose:
-                print('{} points are triangulated into the 3D spline'.format(X_i.shape[1]))
-        _, idx_empty = util.sampling(X_new, interval)
-        assert sum(idx_empty) == 0, 'Points should not be triangulated into the existing part of the 3D spline'
+                print('{} points are triangulated into the 3D spline'.format(pts.shape[1]))
+            return pts
+
+        found = [pts for pts in map(against, cams) if pts is not None]
+        X_new = np.hstack([np.empty([4, 0])] + found)
+        assert not np.any(util.sampling(X_new, covered)[1]), 'Points should not be triangulated into the existing part of the 3D spline'
         self.spline_to_traj(sampling_rate=factor_s2t)
-        self.traj = np.hstack((self.traj, X_new))
-        _, idx = np.unique(self.traj[0], return_index=True)
-        self.traj = self.traj[:, idx]
+        merged = np.hstack((self.traj, X_new))
+        self.traj = merged[:, np.unique(merged[0], return_index=True)[1]]      # time ordered, one sample per timestamp (the first)
         if refit:
             self.traj_to_spline(smooth_factor=factor_t2s)
         return X_new

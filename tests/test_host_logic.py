@@ -70,6 +70,11 @@ def test_camera_codec_and_projection():
     und = cam.undist_point(raw)
     np.testing.assert_allclose(und, np.vstack((K[0, 0] * xn[0] + K[0, 2], K[1, 1] * xn[1] + K[1, 2])), atol=2e-3)
     np.testing.assert_allclose(und, orc.undist_point(raw, K, cam.d), atol=1e-12)
+    # OpenCV's early-out (negative 1 / (1 + k1 r^2 + ...): the point stays where it started) -- host copy == oracle
+    cam.d = np.array([-0.9, 0.0, 0.0, 0.0, 0.0])
+    far = np.vstack((K[0, 2] + 1.6 * K[0, 0] * np.ones(3), K[1, 2] + np.array([-0.2, 0.0, 0.3]) * K[1, 1]))
+    np.testing.assert_allclose(cam.undist_point(far), orc.undist_point(far, K, cam.d), atol=1e-12)
+    np.testing.assert_allclose(cam.undist_point(far), far, atol=1e-9)
 
 
 def test_create_scene_reads_reference_config(tmp_path):
