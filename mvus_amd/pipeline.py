@@ -34,10 +34,16 @@ def incremental_reconstruction(flight, max_iter=10, verbose=False, timer=None):
     """main.py:43-82.  ``flight``: a ``Scene`` whose first two cameras of ``sequence`` (or of ``select_most_overlap``) have
     poses and whose ``spline`` holds the first trajectory; the remaining cameras have ``P is None``.  Uses the settings keys
     of the reference's config.json: rolling_shutter, motion_reg, motion_weights, rs_bounds, thres_outlier,
-    thres_triangulation, smooth_factor, sampling_rate, thres_PnP (optional, default 8 as in get_camera_pose).
+    thres_triangulation, smooth_factor, sampling_rate, thres_PnP (optional, default 8 as in get_camera_pose).  With the opt-in
+    ``ba_solver: 'lm'`` and no ``ba_lambda_min`` the loop sets its own damping floor (0.3) in ``flight.settings``.
     Returns the StageTimer."""
     timer = timer or StageTimer()
     st = flight.settings
+    if st.get('ba_solver') == 'lm' and 'ba_lambda_min' not in st:
+        # the staged, gauge-free BAs of the loop need more damping than one large BA (reconstruction/common.py: LOOP_LM_LAMBDA_MIN)
+        from .reconstruction.common import LOOP_LM_LAMBDA_MIN
+        st['ba_lambda_min'] = LOOP_LM_LAMBDA_MIN
+        print("incremental_reconstruction: ba_solver = 'lm' without ba_lambda_min -- using the loop's damping floor %g" % LOOP_LM_LAMBDA_MIN)
     kw = dict(rs=st['rolling_shutter'], motion_reg=st['motion_reg'], motion_weights=st['motion_weights'], rs_bounds=st['rs_bounds'])
     cam_temp = 2
     while True:

@@ -23,7 +23,8 @@ Extra ``settings`` keys (all optional; a reference ``config.json`` has none of t
                full analytic (default with 'lm').
 ``ba_pattern_ties`` 'numpy' = the twin rows of the pattern decided like np.argsort of this process decides them (default;
                what the reference would build here), 'canonical'.
-``ba_lambda_min`` floor of the LM damping (default 3e-3, see ``mvus_solve_opts.lm_lambda_min``).
+``ba_lambda_min`` floor of the LM damping (default 3e-3, see ``mvus_solve_opts.lm_lambda_min``; the incremental loop of
+               ``mvus_amd.pipeline`` sets 0.3 for its staged BAs unless told otherwise: ``LOOP_LM_LAMBDA_MIN`` below).
 ``ba_lm_wide_band`` with 'lm': what to do when the motion rows reach over more than six control points (knots less than a frame
                apart, i.e. more control points than detections): 'trf' (default) solves THAT problem with TRF + LSMR on the analytic
                Jacobian and says so, 'lm' keeps LM + Schur (general band solver, damping floor 0.3).
@@ -57,6 +58,16 @@ def _undistort_normalized(points, K, d):
         dy = p1 * (r2 + 2.0 * y * y) + 2.0 * p2 * x * y
         x, y = np.where(reset, x0, (x0 - dx) * icd), np.where(reset, y0, (y0 - dy) * icd)
     return np.vstack((x, y))
+
+
+# Floor of the LM damping that mvus_amd.pipeline.incremental_reconstruction sets (settings['ba_lambda_min']) when the loop runs with
+# ba_solver = 'lm' and the caller gave none.  The staged BAs of the loop -- two or three cameras, similarity gauge free, a motion
+# regulariser that is not scale invariant -- slope towards a smaller scene; a nearly undamped Newton step (the library's floor, 3e-3,
+# chosen for single large BAs) follows that slope where the reference's ten truncated LSMR solves barely move.  Eleven seeds of the
+# loop: with 0.3 every seed ends 0.21 - 0.43 m from the truth (the reference's algorithm: 0.23 - 0.51 m), with 3e-3 one seed in
+# three ends metres away (profiles/r04_loop_lm_damping_floors.txt).  A single Scene.BA keeps the library's floor: with 0.3 its last
+# steps get short enough for xtol to end a 200-evaluation solve above the minimum (dist_fixed_2cam: cost 252.9 against 238.0).
+LOOP_LM_LAMBDA_MIN = 0.3
 
 
 class Camera:
