@@ -932,7 +932,12 @@ __device__ __forceinline__ double band_entry(const double* __restrict__ Lb, int 
   return d <= BW ? Lb[(long long)hi * (BW + 1) + d] : 0.0;
 }
 
-// banded Cholesky of interior p by ONE wavefront (lane = threadIdx.x & 63); T: kPartRowsMax * (BW + 1) doubles of LDS private to it.
+__device__ __forceinline__ double bcast_lane(double v, int src) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+// banded Cholesky of interior p by ONE wavefront (lane = threadIdx.x & 63); T: (kPartRowsMax + 1) * (BW + 1) doubles of LDS private to it.
 // (Only this wavefront touches T: the synchronisation is the wavefront-level one.)
 __device__ __forceinline__ void part_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
@@ -957,22 +962,47 @@ __device__ __forceinline__ void part_cholesky_body(const PartView& pv, double* _
     offA[sl] = rr * R + (rr - ss); offB[sl] = rr * R + rr; offC[sl] = ss * R + ss;
   }
   part_lds_sync();
+  // One LDS round trip per column (round 4; it was four: pivot, scaled column, its read-back, trailing update).  The trailing
+  // update reads the UNSCALED column, A(k+r, k+s) -= T_r T_s / piv, so it does not wait for the scaled column; the next pivot is
+  // the updated (1, 1) entry, which lane 0 holds in a register (pair 0) -- a v_readlane instead of an LDS read, and its
+  // reciprocal square root runs under the latency of the next column's reads.
+  // The loop body has no branch: a lane without work in a column reads the pivot's slot and writes to a spare slot behind the
+  // matrix (T holds one more row than the interior can have), so the reads carry no exec-mask joins for s_waitcnt to stop at.
+  constexpr int kSpare = kPartRowsMax * R;
+  bool bad = false;
+  double piv = T[0];
   for (int k = 0; k < n; ++k) {
-    double piv = T[k * R];
-    if (!(piv > 0.0)) { if (lane == 0) fail[0] = 1; piv = 1.0; }
-    double inv = __builtin_amdgcn_rsq(piv);              // two Newton steps on v_rsq_f64: the pivot chain is the critical path
-    inv = inv * (1.5 - 0.5 * piv * inv * inv);
-    inv = inv * (1.5 - 0.5 * piv * inv * inv);
     const int nb = min(BW, n - 1 - k);
-    if (lane >= 1 && lane <= nb) T[(k + lane) * R + lane] *= inv;
-    part_lds_sync();
-    double* Tk = T + k * R;
+    const int base = k * R;
+    double a[kSlots], b[kSlots], c[kSlots];
+    bool on[kSlots];
 #pragma unroll
-    for (int sl = 0; sl < kSlots; ++sl)
-      if (prr[sl] <= nb) Tk[offA[sl]] -= Tk[offB[sl]] * Tk[offC[sl]];
-    if (lane == 0) T[k * R] = inv;      // reciprocal of L(k,k)
+    for (int sl = 0; sl < kSlots; ++sl) {
+      on[sl] = prr[sl] <= nb;
+      a[sl] = T[base + (on[sl] ? offA[sl] : 0)]; b[sl] = T[base + (on[sl] ? offB[sl] : 0)]; c[sl] = T[base + (on[sl] ? offC[sl] : 0)];
+    }
+    const bool incol = lane >= 1 && lane <= nb;
+    const int icol = incol ? lane * R + lane : 0;
+    const double colv = T[base + icol];
+    bad |= !(piv > 0.0);
+    piv = piv > 0.0 ? piv : 1.0;
+    double inv = __builtin_amdgcn_rsq(piv);              // two Newton steps on v_rsq_f64
+    inv = inv * (1.5 - 0.5 * piv * inv * inv);
+    inv = inv * (1.5 - 0.5 * piv * inv * inv);
+    const double invp = inv * inv;
+    double first = 0.0;
+#pragma unroll
+    for (int sl = 0; sl < kSlots; ++sl) {
+      const double v = a[sl] - (b[sl] * invp) * c[sl];
+      T[on[sl] ? base + offA[sl] : kSpare] = v;
+      if (sl == 0) first = v;
+    }
+    T[incol ? base + icol : kSpare + 1] = colv * inv;     // the column of L (every read of it above precedes this store in program order)
+    T[lane == 0 ? base : kSpare + 2] = inv;               // reciprocal of L(k,k)
+    piv = bcast_lane(first, 0);                           // A(k+1, k+1) after this column's update (pair 0 = (1, 1)); unused when nb = 0
     part_lds_sync();
   }
+  if (bad && lane == 0) fail[0] = 1;
   // write back only entries whose column lies inside the interior (j <= row - r0); couplings stay original
   for (int e = lane; e < n * R; e += 64) {
     const int row = e / R, j = e % R;
@@ -981,7 +1011,7 @@ __device__ __forceinline__ void part_cholesky_body(const PartView& pv, double* _
 }
 template <int BW>
 __global__ __launch_bounds__(64) void k_part_cholesky(PartView pv, double* __restrict__ Lb, int* __restrict__ fail) {
-  __shared__ double T[kPartRowsMax * (BW + 1)];
+  __shared__ double T[(kPartRowsMax + 1) * (BW + 1)];
   part_cholesky_body<BW>(pv, Lb, fail, T, (int)blockIdx.x, (int)threadIdx.x);
 }
 
@@ -1646,7 +1676,7 @@ __global__ void k_band_pack(NEView ne, double lambda, int BW, double* __restrict
 template <int BW>
 __global__ __launch_bounds__(256) void k_cholesky_and_rhs(PartView pv, double* __restrict__ Lb, int* __restrict__ fail, int chol_blocks,
                                                           NEView ne, int ncols, double* __restrict__ Z, double* __restrict__ Erm, int tiles) {
-  __shared__ double T[kPartRowsMax * (BW + 1)];
+  __shared__ double T[(kPartRowsMax + 1) * (BW + 1)];
   if ((int)blockIdx.x < chol_blocks) {                    // chol_blocks is a multiple of 8: the copy tiles keep their XCD mapping
     if ((int)blockIdx.x < pv.P && threadIdx.x < 64) part_cholesky_body<BW>(pv, Lb, fail, T, (int)blockIdx.x, (int)threadIdx.x);
     return;
@@ -1906,11 +1936,6 @@ __global__ __launch_bounds__(kFinThreads) void k_schur_finish(NEView ne, int nco
 // Round 2 history (cycle counters, MVUS_GJ_PROBE): a 32-step register Cholesky took 22k cycles and the tile update 13k
 // (three 32-deep LDS dot products per thread: LDS-bandwidth bound); now 16-step halves + matrix-core tile products.
 
-__device__ __forceinline__ double bcast_lane(double v, int src) {
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
-  return __hiloint2double(hi, lo);
-}
 
 // L D L^T of a 16x16 SPD block, every row of 16 lanes on its own copy: lane i of the row holds row i of the block (a, lower
 // triangle) and row i of the identity (x).  Column operations col_j -= col_k * (a_jk / d_k) on both: on return x[k] of lane c is
