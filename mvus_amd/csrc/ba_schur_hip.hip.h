@@ -19,6 +19,7 @@
 // on the fp64 matrix cores (k_schur_gemm, k_schur_finish) -> block Gauss-Jordan on the reduced camera system (k_gj_step)
 // -> k_back_substitute.
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -931,6 +932,13 @@ __device__ __forceinline__ double band_entry(const double* __restrict__ Lb, int 
   const int hi = i > c ? i : c, d = i > c ? i - c : c - i;
   return d <= BW ? Lb[(long long)hi * (BW + 1) + d] : 0.0;
 }
+// the same without a conditional load (the row is always inside the band array): for the unconditioned batches of part_solve_block
+template <int BW>
+__device__ __forceinline__ double band_entry_nc(const double* __restrict__ Lb, int i, int c) {
+  const int hi = i > c ? i : c, d = i > c ? i - c : c - i;
+  const double v = Lb[(long long)hi * (BW + 1) + (d <= BW ? d : BW)];
+  return d <= BW ? v : 0.0;
+}
 
 __device__ __forceinline__ double bcast_lane(double v, int src) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
@@ -1047,20 +1055,35 @@ __device__ __forceinline__ void part_solve_block(const PartView& pv, int ncols, 
   if (!live) return;                                         // no barrier below
   double* out = COUPLING ? pv.VW + ((long long)p * kPartRowsMax) * (2 * s3) + tid : Z + (long long)r0 * ncols + by * 64 + tid;
   const long long ostride = COUPLING ? 2 * s3 : ncols;
-  auto rhs_at = [&](int i) { return i < nr ? (COUPLING ? band_entry<BW>(Lb, r0 + i, ccol) : out[(long long)i * ostride]) : 0.0; };
-  double yw[BW];           // yw[0] = newest value
+  // Batches of kPf rows.  A FULL batch (all its rows inside the interior) is loaded, solved and stored without a single condition:
+  // with a condition per row (`i < nr ? load : 0`) every load and store sat in its own scalar branch and the compiler closed each
+  // batch of prefetches with s_waitcnt vmcnt(0) -- the wavefront then waited out the memory latency once per batch in both passes
+  // (round 4: 45 -> see DESIGN section 5).  Only the last, partial batch keeps the conditions.
+  using Full = std::true_type;
+  using Part = std::false_type;
+  auto load_rhs = [&](auto full, double (&dst)[kPf], int ib) {
 #pragma unroll
-  for (int j = 0; j < BW; ++j) yw[j] = 0.0;
-  double cur[kPf], nxt[kPf];
-#pragma unroll
-  for (int k = 0; k < kPf; ++k) nxt[k] = rhs_at(k);
-  for (int ib = 0; ib < nrp; ib += kPf) {
-#pragma unroll
-    for (int k = 0; k < kPf; ++k) cur[k] = nxt[k];
-    if (ib + kPf < nrp) {
-#pragma unroll
-      for (int k = 0; k < kPf; ++k) nxt[k] = rhs_at(ib + kPf + k);
+    for (int k = 0; k < kPf; ++k) {
+      const int i = ib + k;
+      if constexpr (decltype(full)::value) dst[k] = COUPLING ? band_entry_nc<BW>(Lb, r0 + i, ccol) : out[(long long)i * ostride];
+      else dst[k] = i < nr ? (COUPLING ? band_entry<BW>(Lb, r0 + i, ccol) : out[(long long)i * ostride]) : 0.0;
     }
+  };
+  auto load_y = [&](auto full, double (&dst)[kPf], int ib) {
+#pragma unroll
+    for (int k = 0; k < kPf; ++k) {
+      const int i = ib + k;
+      if constexpr (decltype(full)::value) dst[k] = out[(long long)i * ostride];
+      else dst[k] = i < nr ? out[(long long)i * ostride] : 0.0;
+    }
+  };
+  auto take = [&](double (&dst)[kPf], const double (&src)[kPf]) {
+#pragma unroll
+    for (int k = 0; k < kPf; ++k) dst[k] = src[k];
+  };
+  double yw[BW];           // yw[0] = newest value
+  // forward: y(i) = (b(i) - sum_j L(i, i-j) y(i-j)) / L(i,i)
+  auto forward = [&](auto full, const double (&cur)[kPf], int ib) {
     const double* Lr = Ls + ib * R;
     double* yo = out + (long long)ib * ostride;
 #pragma unroll
@@ -1071,25 +1094,15 @@ __device__ __forceinline__ void part_solve_block(const PartView& pv, int ncols, 
 #pragma unroll
       for (int j = BW; j >= 1; --j) acc -= Lr[k * R + j] * yw[j - 1];
       const double y = acc * Lr[k * R];
-      if (ib + k < nr) yo[(long long)k * ostride] = y;
+      if constexpr (decltype(full)::value) yo[(long long)k * ostride] = y;
+      else if (ib + k < nr) yo[(long long)k * ostride] = y;
 #pragma unroll
       for (int j = BW - 1; j >= 1; --j) yw[j] = yw[j - 1];
       yw[0] = y;
     }
-  }
+  };
   // backward: x(i) = (y(i) - sum_j L(i+j, i) x(i+j)) / L(i,i); the padded rows give x = 0
-#pragma unroll
-  for (int j = 0; j < BW; ++j) yw[j] = 0.0;
-  auto y_at = [&](int i) { return i < nr ? out[(long long)i * ostride] : 0.0; };
-#pragma unroll
-  for (int k = 0; k < kPf; ++k) nxt[k] = y_at(nrp - kPf + k);
-  for (int ib = nrp - kPf; ib >= 0; ib -= kPf) {
-#pragma unroll
-    for (int k = 0; k < kPf; ++k) cur[k] = nxt[k];
-    if (ib > 0) {
-#pragma unroll
-      for (int k = 0; k < kPf; ++k) nxt[k] = y_at(ib - kPf + k);
-    }
+  auto backward = [&](auto full, const double (&cur)[kPf], int ib) {
 #pragma unroll
     for (int k = kPf - 1; k >= 0; --k) {
       const int i = ib + k;
@@ -1097,12 +1110,47 @@ __device__ __forceinline__ void part_solve_block(const PartView& pv, int ncols, 
 #pragma unroll
       for (int j = BW; j >= 1; --j) acc -= Ls[(i + j) * R + j] * yw[j - 1];     // rows up to nrp + BW - 1 are staged
       const double xv = acc * Ls[i * R];
-      if (i < nr) out[(long long)i * ostride] = xv;
+      if constexpr (decltype(full)::value) out[(long long)i * ostride] = xv;
+      else if (i < nr) out[(long long)i * ostride] = xv;
 #pragma unroll
       for (int j = BW - 1; j >= 1; --j) yw[j] = yw[j - 1];
       yw[0] = xv;
     }
+  };
+  const int nfull = nr / kPf, tail0 = nfull * kPf;
+  const bool has_tail = tail0 < nr;
+  double cur[kPf], nxt[kPf];
+#pragma unroll
+  for (int j = 0; j < BW; ++j) yw[j] = 0.0;
+  if (nfull > 0) {
+    load_rhs(Full{}, nxt, 0);
+    for (int bt = 0; bt + 1 < nfull; ++bt) {               // the rows of the next batch are fetched while this one is solved
+      take(cur, nxt);
+      load_rhs(Full{}, nxt, (bt + 1) * kPf);
+      forward(Full{}, cur, bt * kPf);
+    }
+    take(cur, nxt);
+    if (has_tail) load_rhs(Part{}, nxt, tail0);
+    forward(Full{}, cur, tail0 - kPf);
+  } else if (has_tail) {
+    load_rhs(Part{}, nxt, 0);
   }
+  if (has_tail) { take(cur, nxt); forward(Part{}, cur, tail0); }
+#pragma unroll
+  for (int j = 0; j < BW; ++j) yw[j] = 0.0;
+  if (has_tail) {
+    load_y(Part{}, cur, tail0);
+    if (nfull > 0) load_y(Full{}, nxt, tail0 - kPf);
+    backward(Part{}, cur, tail0);
+  } else if (nfull > 0) {
+    load_y(Full{}, nxt, tail0 - kPf);
+  }
+  for (int bt = nfull - 1; bt >= 1; --bt) {
+    take(cur, nxt);
+    load_y(Full{}, nxt, (bt - 1) * kPf);
+    backward(Full{}, cur, bt * kPf);
+  }
+  if (nfull > 0) { take(cur, nxt); backward(Full{}, cur, 0); }
 }
 
 // column blocks 0 .. gy-2: 64 right-hand-side columns each; the last one: the coupling columns (same launch, so that they run
