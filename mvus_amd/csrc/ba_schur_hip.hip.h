@@ -1179,15 +1179,27 @@ __device__ __forceinline__ void part_reduce_rhs(const PartView& pv, int ncols, c
   for (int e = e0; e < s3 * ncols; e += estride) {
     const int a = e / ncols, col = e % ncols;
     double r = own ? Z[(long long)(c0 + a) * ncols + col] : 0.0;
+    if (pl >= 0) {                                       // (clamped rows, dropped products: every load unconditional, as in k_part_reduce)
+      double f[BW], z[BW];
 #pragma unroll
-    for (int jj = 0; jj < BW; ++jj) {
-      const int i = a1 - BW + jj;
-      if (pl >= 0 && i >= a0) r -= band_entry<BW>(Lb, i, c0 + a) * Z[(long long)i * ncols + col];
+      for (int jj = 0; jj < BW; ++jj) {
+        const int ic = max(a1 - BW + jj, a0);
+        f[jj] = band_entry_nc<BW>(Lb, ic, c0 + a);
+        z[jj] = Z[(long long)ic * ncols + col];
+      }
+#pragma unroll
+      for (int jj = 0; jj < BW; ++jj) r -= (a1 - BW + jj >= a0) ? f[jj] * z[jj] : 0.0;
     }
+    if (pr >= 0) {
+      double f[BW], z[BW];
 #pragma unroll
-    for (int jj = 0; jj < BW; ++jj) {
-      const int i = b0 + jj;
-      if (pr >= 0 && i < b1) r -= band_entry<BW>(Lb, i, c0 + a) * Z[(long long)i * ncols + col];
+      for (int jj = 0; jj < BW; ++jj) {
+        const int ic = min(b0 + jj, b1 - 1);
+        f[jj] = band_entry_nc<BW>(Lb, ic, c0 + a);
+        z[jj] = Z[(long long)ic * ncols + col];
+      }
+#pragma unroll
+      for (int jj = 0; jj < BW; ++jj) r -= (b0 + jj < b1) ? f[jj] * z[jj] : 0.0;
     }
     pv.R[((long long)gq * s3 + a) * ncols + col] = r;
   }
@@ -1206,19 +1218,34 @@ __global__ __launch_bounds__(256) void k_part_reduce(PartView pv, int ncols, con
   const double* VWb = pv.VW + ((long long)(pr >= 0 ? pr : 0) * kPartRowsMax) * st;
   for (int e = threadIdx.x; (what & 1) && blockIdx.y == 0 && e < s3 * s3; e += blockDim.x) {
     const int a = e / s3, b = e % s3;
+    // (rows outside the interior are clamped to its edge and their products dropped: no load sits behind a condition, all 2 x BW
+    // x 2 - 3 of them are in flight together -- with a branch per row this loop was a chain of ~30 memory round trips, 12 us)
     double tt = own ? band_entry<BW>(Lb, c0 + a, c0 + b) : 0.0, u = 0.0;
+    if (pl >= 0) {
+      double f[BW], w[BW];
 #pragma unroll
-    for (int jj = 0; jj < BW; ++jj) {
-      const int i = a1 - BW + jj;
-      if (pl >= 0 && i >= a0) tt -= band_entry<BW>(Lb, i, c0 + a) * VWa[(long long)(i - a0) * st + s3 + b];          // F_right(q)^T W_q
+      for (int jj = 0; jj < BW; ++jj) {
+        const int ic = max(a1 - BW + jj, a0);
+        f[jj] = band_entry_nc<BW>(Lb, ic, c0 + a);
+        w[jj] = VWa[(long long)(ic - a0) * st + s3 + b];
+      }
+#pragma unroll
+      for (int jj = 0; jj < BW; ++jj) tt -= (a1 - BW + jj >= a0) ? f[jj] * w[jj] : 0.0;                             // F_right(q)^T W_q
     }
+    if (pr >= 0) {
+      double f[BW], wv[BW], ww[BW];
 #pragma unroll
-    for (int jj = 0; jj < BW; ++jj) {
-      const int i = b0 + jj;
-      if (pr >= 0 && i < b1) {
-        const double fl = band_entry<BW>(Lb, i, c0 + a);
-        tt -= fl * VWb[(long long)(i - b0) * st + b];                                                                // F_left(q+1)^T V_{q+1}
-        u -= fl * VWb[(long long)(i - b0) * st + s3 + b];                                                            // F_left(q+1)^T W_{q+1}
+      for (int jj = 0; jj < BW; ++jj) {
+        const int ic = min(b0 + jj, b1 - 1);
+        f[jj] = band_entry_nc<BW>(Lb, ic, c0 + a);
+        wv[jj] = VWb[(long long)(ic - b0) * st + b];
+        ww[jj] = VWb[(long long)(ic - b0) * st + s3 + b];
+      }
+#pragma unroll
+      for (int jj = 0; jj < BW; ++jj) {
+        const bool in = b0 + jj < b1;
+        tt -= in ? f[jj] * wv[jj] : 0.0;                                                                             // F_left(q+1)^T V_{q+1}
+        u -= in ? f[jj] * ww[jj] : 0.0;                                                                              // F_left(q+1)^T W_{q+1}
       }
     }
     pv.T[((long long)gq * s3 + a) * s3 + b] = tt;
