@@ -2173,15 +2173,20 @@ __global__ __launch_bounds__(kGjThreads) void k_gj_step(int nn, int kb, const do
 #pragma unroll
   for (int q = 0; q < kNB * kNB / kGjThreads; ++q) {
     const int e = threadIdx.x + kGjThreads * q, r = e / kNB, c = e % kNB;
-    Ai[r][c] = (i0 + r <= nn && c < nb) ? src[(long long)(i0 + r) * nn + kb + c] : 0.0;
+    // (indices clamped into the (nn + 1) x nn array, values outside the tile replaced afterwards: sixteen unconditional loads in
+    // flight together instead of a branch around each -- the tile update is on the chain of every panel)
+    const double ai = src[(long long)min(i0 + r, nn) * nn + min(kb + c, nn - 1)];
+    const double bk = src[(long long)min(kb + r, nn) * nn + min(j0 + c, nn - 1)];
+    Ai[r][c] = (i0 + r <= nn && c < nb) ? ai : 0.0;
     Pk[r][c] = Pinv[(long long)(kb / kNB) * kNB * kNB + e];
-    Bk[r][c] = (r < nb && j0 + c < nn) ? src[(long long)(kb + r) * nn + j0 + c] : 0.0;
+    Bk[r][c] = (r < nb && j0 + c < nn) ? bk : 0.0;
   }
   double v[4];                                               // the tile itself, in the accumulator layout
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int i = i0 + br + lk + 4 * r, j = j0 + bc + lr;
-    v[r] = (i <= nn && j < nn && !pivcol) ? src[(long long)i * nn + j] : 0.0;
+    const double t = src[(long long)min(i, nn) * nn + min(j, nn - 1)];
+    v[r] = (i <= nn && j < nn && !pivcol) ? t : 0.0;
   }
   __syncthreads();
   bcr_d4 acc{0.0, 0.0, 0.0, 0.0};
