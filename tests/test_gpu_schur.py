@@ -372,3 +372,41 @@ def test_assembly_randomised_layouts(seed):
         for w in range(band.shape[1]):
             if gi + w < band.shape[0]:
                 np.testing.assert_allclose(band[gi, w], Hs[3 * gi:3 * gi + 3, 3 * (gi + w):3 * (gi + w) + 3], rtol=0, atol=1e-12 * scale)
+
+
+@pytest.mark.parametrize('slabs', [None, 1, 3, 8, 11, 24])
+def test_schur_product_slab_plans(slabs, monkeypatch):
+    """k_schur_gemm deals the K-slabs of E^T Z to the XCDs (slab s -> XCD s mod 8) and every wavefront takes a share of the 16-row
+    sets of the product; the slab count is planned per problem (HipSchur::plan_gemm).  Forced counts -- one slab, fewer than the
+    XCDs, not a multiple of eight, more slabs than whole sets per wavefront -- on 17 cameras (153 columns: four 48-wide tiles, the last
+    one ragged) and a row count that is not a multiple of 16: the damped step must match a dense solve of the exported normal equations."""
+    from mvus_amd import synth
+    from mvus_amd.ba import BAHandle
+    if slabs is None:
+        monkeypatch.delenv('MVUS_GEMM_SLABS', raising=False)
+    else:
+        monkeypatch.setenv('MVUS_GEMM_SLABS', str(slabs))
+    sc = synth.make_scene(17, 9000, seed=61, rolling_shutter=True, num_knots=171)
+    prob, x0 = mp.problem_from_scene(sc)
+    N = int(prob.n_coef.sum())
+    assert (3 * N) % 16 != 0
+    cam_idx, spl_idx = internal_index(prob)
+    with BAHandle(prob) as h:
+        h.residual_jacobian(x0, _lib.JAC_ANALYTIC)
+        g, A, band, cross = h.normal_equations()
+        p = h.lm_step(0.05)
+    n, C, B, W = prob.n_params, prob.C, 3 + prob.P, band.shape[1]
+    H = np.zeros((n, n))
+    for c in range(C):
+        H[np.ix_(cam_idx[c], cam_idx[c])] = A[c]
+    E = cross.reshape(C * B, 3 * N)
+    H[np.ix_(cam_idx.ravel(), spl_idx)] = E
+    H[np.ix_(spl_idx, cam_idx.ravel())] = E.T
+    for w in range(W):
+        for gi in range(N - w):
+            ri, cj = spl_idx[3 * gi:3 * gi + 3], spl_idx[3 * (gi + w):3 * (gi + w) + 3]
+            H[np.ix_(ri, cj)] = band[gi, w]
+            H[np.ix_(cj, ri)] = band[gi, w].T
+    d = np.diag(H).copy()
+    p_ref = np.linalg.solve(H + 0.05 * np.diag(np.where(d > 0, d, 1.0)), -g)
+    assert float(np.abs(p - p_ref).max() / np.abs(p_ref).max()) < 1e-8
