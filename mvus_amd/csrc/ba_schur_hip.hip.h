@@ -1449,6 +1449,36 @@ constexpr int kBcrTailNs = MVUS_BCR_TAIL_NS;   // levels with more survivors tha
 // 128-byte line can straddle two 648-byte blocks: a line fetched into the CU's L1 for one block before a neighbour's store to
 // the other landed would be stale at the next level.  Agent-scope loads go to L2, where the stores are.
 __device__ __forceinline__ double bcr_ld(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// lane J of every row of 16 lanes, to all lanes of that row (v_mov_b64_dpp row_newbcast:J -- the one DPP control 64-bit operands have here)
+template <int J> __device__ __forceinline__ double row_bcast(double v) { return __builtin_amdgcn_update_dpp(v, v, 0x150 + J, 0xf, 0xf, false); }
+// Gauss-Jordan inverse of an S3 x S3 SPD block held a row per lane (lane a of a row of 16 lanes: block row a; lanes >= S3 carry
+// zeros): step K broadcasts the pivot row with DPP row_newbcast:K.  Template recursion: the DPP control is an immediate.
+template <int S3, int K>
+struct BcrGaussJordan {
+  static __device__ __forceinline__ void run(double (&row)[S3], int a, bool& bad) {
+    double pr[S3];
+#pragma unroll
+    for (int b = 0; b < S3; ++b) pr[b] = row_bcast<K>(row[b]);
+    double piv = pr[K];
+    bad |= !(piv > 0.0);
+    piv = piv > 0.0 ? piv : 1.0;
+    double ip = __builtin_amdgcn_rcp(piv);
+    ip = ip * (2.0 - piv * ip);
+    ip = ip * (2.0 - piv * ip);
+    if (a == K) {
+#pragma unroll
+      for (int b = 0; b < S3; ++b) row[b] = (b == K) ? ip : row[b] * ip;
+    } else {
+      const double f = row[K] * ip;
+#pragma unroll
+      for (int b = 0; b < S3; ++b) row[b] = (b == K) ? -f : row[b] - f * pr[b];
+    }
+    BcrGaussJordan<S3, K + 1>::run(row, a, bad);
+  }
+};
+template <int S3>
+struct BcrGaussJordan<S3, S3> { static __device__ __forceinline__ void run(double (&)[S3], int, bool&) {} };
+
 template <int S3>
 __device__ __forceinline__ void bcr_survivor(const PartView& pv, int h, int s, double* __restrict__ w, int* __restrict__ fail) {
   constexpr int SS = S3 * S3, KS = (S3 + 3) / 4;
@@ -1457,9 +1487,12 @@ __device__ __forceinline__ void bcr_survivor(const PartView& pv, int h, int s, d
   const bool has_i = i < m, right = jR < m, right2 = jR + h < m;
   double* __restrict__ Cc = pv.U;
   // ---- all global operands, issued together ----
-  const int nl = lane / S3, a = lane % S3;
-  const bool act = nl == 0 || (nl == 1 && right);
-  const double* Tsrc = pv.T + (long long)(nl == 0 ? jL : (right ? jR : 0)) * SS + a * S3;
+  // (block row a of neighbour nl in lane 16 nl + a: each neighbour's rows inside one row of 16 lanes, so that the pivot row of the
+  // elimination below is a DPP row broadcast -- v_mov_b64_dpp row_newbcast -- instead of two ds_bpermute per entry)
+  static_assert(S3 <= 16, "a block row per lane inside one DPP row");
+  const int nl = lane >> 4, a = lane & 15;
+  const bool act = a < S3 && (nl == 0 || (nl == 1 && right));
+  const double* Tsrc = pv.T + (long long)(nl == 0 ? jL : (right ? jR : 0)) * SS + (a < S3 ? a : 0) * S3;
   double row[S3];
 #pragma unroll
   for (int b = 0; b < S3; ++b) row[b] = act ? bcr_ld(Tsrc + b) : (a == b ? 1.0 : 0.0);
@@ -1476,29 +1509,9 @@ __device__ __forceinline__ void bcr_survivor(const PartView& pv, int h, int s, d
   for (int r = 0; r < 4; ++r) { const int rw = lk + 4 * r; ti[r] = (has_i && rw < S3 && lr < S3) ? bcr_ld(pv.T + (long long)i * SS + rw * S3 + lr) : 0.0; }
   // ---- Dinv of both neighbours: a block row per lane, the pivot row of each Gauss-Jordan step broadcast with shuffles ----
   bool bad = false;
-#pragma unroll
-  for (int k = 0; k < S3; ++k) {
-    const int src = (nl < 2 ? nl : 0) * S3 + k;
-    double pr[S3];
-#pragma unroll
-    for (int b = 0; b < S3; ++b) pr[b] = __shfl(row[b], src, 64);
-    double piv = pr[k];
-    bad |= !(piv > 0.0);
-    piv = piv > 0.0 ? piv : 1.0;
-    double ip = __builtin_amdgcn_rcp(piv);
-    ip = ip * (2.0 - piv * ip);
-    ip = ip * (2.0 - piv * ip);
-    if (a == k) {
-#pragma unroll
-      for (int b = 0; b < S3; ++b) row[b] = (b == k) ? ip : row[b] * ip;
-    } else {
-      const double f = row[k] * ip;
-#pragma unroll
-      for (int b = 0; b < S3; ++b) row[b] = (b == k) ? -f : row[b] - f * pr[b];
-    }
-  }
+  BcrGaussJordan<S3, 0>::run(row, a, bad);
   if (bad && act) fail[0] = 3;
-  if (nl < 2) {
+  if (nl < 2 && a < S3) {
 #pragma unroll
     for (int b = 0; b < S3; ++b) w[nl * SS + a * S3 + b] = row[b];
     if (nl == 0 ? s == 0 : right) {
@@ -2018,7 +2031,6 @@ __global__ __launch_bounds__(kFinThreads) void k_schur_finish(NEView ne, int nco
 // root.  The multiplier A[j][k] comes from lane j by DPP (v_mov_b64_dpp row_newbcast:j -- the one DPP control 64-bit operands have
 // on this part): a vector move per multiplier instead of two v_readlane through an SGPR pair with its wait states, which is what
 // the 16-column chain was made of (tools/micro/ldl16_bench.hip: cycles of the two forms on one wavefront).  One basic block.
-template <int J> __device__ __forceinline__ double row_bcast(double v) { return __builtin_amdgcn_update_dpp(v, v, 0x150 + J, 0xf, 0xf, false); }
 template <int K, int J> struct LdlColOps {
   static __device__ __forceinline__ void run(double (&a)[16], double (&x)[16], double ta, double tx) {
     const double m = row_bcast<J>(a[K]);

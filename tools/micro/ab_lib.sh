@@ -7,7 +7,7 @@ import json,sys; d=json.loads(sys.stdin.read()); print('$v config $c', round(d['
   python3 - <<PY
 import sqlite3
 cur=sqlite3.connect('gpurun_out/prof_ab/r_results.db').cursor()
-for r in cur.execute("select name,total_calls,average from top_kernels where name like '%k_cholesky_and_rhs%' or name like '%k_part_solve%' or name like '%k_part_back%' or name like '%k_sep_bcr_rhs%' or name like '%k_bcr_tail%' or name like '%k_part_reduce%' or name like '%k_gj_step%' or name like '%k_schur_finish%'"):
+for r in cur.execute("select name,total_calls,average from top_kernels where name like '%k_cholesky_and_rhs%' or name like '%k_part_solve%' or name like '%k_part_back%' or name like '%k_sep_bcr_rhs%' or name like '%k_bcr_tail%' or name like '%k_part_reduce%' or name like '%k_sep_bcr_level%'"):
     print('$v', r[0][:50], r[1], '%.1f us' % r[2])
 PY
 done; rm -rf gpurun_out/prof_ab
