@@ -956,7 +956,13 @@ template <int BW>
 __device__ __forceinline__ void part_cholesky_body(const PartView& pv, double* __restrict__ Lb, int* __restrict__ fail, double* __restrict__ T, int p, int lane) {
   constexpr int R = BW + 1;
   const int r0 = pv.i0[p], n = pv.i1[p] - r0;
-  for (int e = lane; e < n * R; e += 64) T[e] = Lb[(long long)r0 * R + e];
+  for (int e0 = lane; e0 < n * R; e0 += 64 * 8) {          // eight loads in flight per lane
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = Lb[(long long)r0 * R + min(e0 + 64 * u, n * R - 1)];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) if (e0 + 64 * u < n * R) T[e0 + 64 * u] = v[u];
+  }
   // trailing-update pairs (rr >= ss >= 1) owned by this lane, as offsets from the pivot row: fixed for all columns
   constexpr int kPairs = BW * (BW + 1) / 2, kSlots = (kPairs + 63) / 64;
   int prr[kSlots], offA[kSlots], offB[kSlots], offC[kSlots];
@@ -1039,9 +1045,21 @@ __device__ __forceinline__ void part_solve_block(const PartView& pv, int ncols, 
   const int s3 = pv.s3;
   const int r0 = pv.i0[p], nr = pv.i1[p] - r0;
   const int nrp = (nr + kPf - 1) / kPf * kPf;                // rows padded to whole batches
-  for (int e = tid; e < (nrp + kPf) * R; e += 64) {
-    const int row = e / R, jj = e % R;
-    Ls[e] = row < nr ? ((jj <= row) ? Lb[(long long)r0 * R + e] : 0.0) : (jj == 0 ? 1.0 : 0.0);   // column row-jj inside the interior
+  // (eight loads in flight per lane, none behind a condition: rows past the interior repeat its last row and are replaced afterwards)
+  constexpr int kStage = 8;
+  const int total = (nrp + kPf) * R;
+  for (int e0 = tid; e0 < total; e0 += 64 * kStage) {
+    double v[kStage];
+#pragma unroll
+    for (int u = 0; u < kStage; ++u) {
+      const int e = min(e0 + 64 * u, total - 1), row = e / R, jj = e - row * R;
+      v[u] = Lb[(long long)(r0 + min(row, nr - 1)) * R + jj];
+    }
+#pragma unroll
+    for (int u = 0; u < kStage; ++u) {
+      const int e = e0 + 64 * u, row = e / R, jj = e - row * R;
+      if (e < total) Ls[e] = row < nr ? ((jj <= row) ? v[u] : 0.0) : (jj == 0 ? 1.0 : 0.0);   // column row-jj inside the interior
+    }
   }
   __syncthreads();
   int ccol = 0;
