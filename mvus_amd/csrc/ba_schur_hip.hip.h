@@ -1710,7 +1710,10 @@ __global__ __launch_bounds__(256) void k_sep_bcr_rhs(PartView pv, int ncols) {
 // interiors: X = Y - V X_{S_{p-1}} - W X_{S_p}.  One thread per right-hand-side column: the 2*S3 separator values of
 // its column stay in registers, the rows of V|W are the same for every lane (scalar loads), so each interior entry
 // costs one coalesced load, 2*S3 FMAs and one store.
-constexpr int kBackRows = 16;      // rows per workgroup: enough workgroups in flight to hide the load latency
+#ifndef MVUS_BACK_ROWS
+#define MVUS_BACK_ROWS 16
+#endif
+constexpr int kBackRows = MVUS_BACK_ROWS;      // rows per workgroup: enough workgroups in flight to hide the load latency
 template <int S3>
 __global__ __launch_bounds__(64) void k_part_back(PartView pv, int ncols, double* __restrict__ Z, int gy, int gz) {
   // 1-D grid, tiles ordered column block fastest, then row block, then interior, handed to the XCDs in runs (xcd_tile):
