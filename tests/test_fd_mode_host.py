@@ -228,3 +228,28 @@ def test_opt_sync_off_freezes_alpha_and_beta():
     assert res.cost < res.initial_cost and not np.array_equal(x, x0)
     ref = orc.solve(oprob, x0, max_iter=6)                       # the reference's scipy call: alpha, beta stay put too
     np.testing.assert_array_equal(ref.x[:2 * C], x0[:2 * C])
+
+
+@pytest.mark.parametrize('name', ['rs_F_2int_3cam', 'config1_shape_7cam'])
+def test_column_groups_with_detections_out_of_time_order(name):
+    """mvus_fd_groups hands scipy's greedy grouping ONE row per run of equal pattern codes (rows with the same columns are
+    interchangeable for it).  With a camera's detections in reverse and in shuffled order the runs are short or gone -- the groups
+    must still be scipy's own on the full matrix."""
+    import dataclasses
+    from hostcheck_util import HostHandle
+    scene, g = load_case(name)
+    prob, x0 = mp.problem_from_scene(scene)
+    rng = np.random.default_rng(5)
+    for how in ('reversed', 'shuffled'):
+        p = dataclasses.replace(prob)
+        idx = np.arange(prob.M)
+        a, b = int(prob.det_offsets[1]), int(prob.det_offsets[2])
+        idx[a:b] = idx[a:b][::-1] if how == 'reversed' else rng.permutation(idx[a:b])
+        p.frame, p.u_raw, p.v_raw = prob.frame[idx].copy(), prob.u_raw[idx].copy(), prob.v_raw[idx].copy()
+        h = HostHandle(p)
+        pat = h.set_pattern(x0)
+        mpat = h.motion_pattern() if h.T else None
+        pn, mn = pattern.resolve_ties(p, x0, pat, mpat, how='canonical')
+        groups, ng = pattern.fd_groups(p, pn, mn if h.T else None)
+        gs, ngs = pattern.fd_groups_scipy(p, pn, mn if h.T else None)
+        assert ng == ngs and np.array_equal(groups, gs), how
