@@ -1641,7 +1641,10 @@ __global__ __launch_bounds__(bcr_tail_waves(S3) * 64) void k_bcr_tail_and_reduce
   part_reduce_rhs<BW>(pv, ncols, Lb, Z, t, (int)(by * blockDim.x + threadIdx.x), (int)(ny * blockDim.x));
 }
 
-constexpr int kBcrCols = 1;       // columns per workgroup (one: more workgroups, fewer items per level and thread)
+#ifndef MVUS_BCR_COLS
+#define MVUS_BCR_COLS 1
+#endif
+constexpr int kBcrCols = MVUS_BCR_COLS;       // columns per workgroup (one: more workgroups, fewer items per level and thread)
 template <int S3, int TC>
 __global__ __launch_bounds__(256) void k_sep_bcr_rhs(PartView pv, int ncols) {
   double* __restrict__ Rr = pv.R;
