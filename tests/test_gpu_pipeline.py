@@ -19,8 +19,8 @@ def test_incremental_loop_seven_cameras(solver):
     # makes the regulariser 100x the data term and BA -- the reference's objective, any solver -- flattens the curve at the
     # price of 3 px of reprojection error, after which a 10 px outlier threshold eats the inliers.  1e2 keeps it a regulariser.
     kw['motion_weights'] = 1e2
-    # 60k detections: on a sparse flight (21k) the loop amplifies last-bit differences into different outcomes -- LM + Schur
-    # assembles with fp64 atomics, and the smoothing fit of either solver breaks FITPACK's knot ties by rounding (fpknot gives the
+    # 60k detections: on a sparse flight (21k) the loop amplifies last-bit differences into different outcomes -- the smoothing
+    # fit of either solver breaks FITPACK's knot ties by rounding (fpknot gives the
     # two halves of a split interval residuals fp * n1 / n and fp * n2 / n: the quarters of an interval tie mathematically and the
     # winner is decided by the last bit of fp; scipy itself lands on other knots than this library on such a trajectory, see
     # tools/micro/loop_fits_vs_scipy.py and DESIGN.md section 2).  Eight seeds at 21k: worst camera centre 0.2-0.7 m with one summation
@@ -41,7 +41,7 @@ def test_incremental_loop_seven_cameras(solver):
     assert ev['trajectory_extent'][1] > start_extent[1] + 0.2 * ev['trajectory_extent'][2]
     assert ev['trajectory_extent'][1] > 0.95 * ev['trajectory_extent'][2]
     # 0.5 px noise per axis -> mean distance ~0.63 px for a perfect fit; measured after 12 ten-evaluation BAs: 0.85-1.15 (trf, 60k, eight seeds),
-    # 0.62-0.66 (lm, 60k, three runs -- it is not bit-reproducible)
+    # 0.62-0.97 (lm, 60k; bit-reproducible since the window-major assembly of round 4, and run with the loop's damping floor)
     assert max(ev['mean_err']) < 1.3
     for kept, clean, dirty in zip(ev['kept'], ev['clean'], ev['kept_dirty']):
         assert kept >= 0.95 * clean                  # the inliers survive six outlier passes ...
