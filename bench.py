@@ -99,8 +99,8 @@ def main():
     ap.add_argument('--no-parity-solver', action='store_true', help='skip the extra timing of the scipy-TRF+LSMR restatement')
     ap.add_argument('--obs', type=int, default=None, help='override the detection count of the config (kernel studies at other sizes; the workload string says so)')
     ap.add_argument('--shard', choices=['time', 'obs'], default=None, help='N>1: how observations are cut over the ranks (default: time for lm, obs for trf)')
-    ap.add_argument('--collective', choices=['rccl', 'torch'], default=None,
-                    help='N>1: rccl = ncclAllReduce called by the library on its own communicator (default on a multi-GPU node), '
+    ap.add_argument('--collective', choices=['rccl', 'torch', 'auto'], default=None,
+                    help='N>1: rccl = ncclAllReduce called by the library on its own communicator; auto (default on a multi-GPU node) = rccl, or the callback if the library cannot open RCCL; '
                          'torch = the callback through torch.distributed (the only route of the one-device gloo flow test)')
     args = ap.parse_args()
 
@@ -145,7 +145,7 @@ def main():
     prob, x0 = mp.problem_from_scene(scene)
     shard_mode = args.shard or ('time' if args.solver == 'lm' else 'obs')
     if world > 1:
-        collective = args.collective or ('torch' if one_device else 'rccl')
+        collective = args.collective or ('torch' if one_device else 'auto')
         handle, _ = sharded_handle(prob, rank, world, local_rank, time_x=x0 if shard_mode == 'time' else None, collective=collective)
     else:
         handle = ba.BAHandle(prob, device=local_rank)
@@ -245,6 +245,7 @@ def main():
                                       'LM normal equations + Schur solve' if args.solver == 'lm'
                                       else 'scipy-TRF restatement with LSMR on the block-sparse J (%.0f LSMR its/step)' % (lin_iters / max(args.steps, 1))),
                        'solver': args.solver, 'parallelism': '%s-shard x%d' % (shard_mode, world),
+                       'collective': getattr(handle, 'collective_used', None),      # 'rccl' = ncclAllReduce called by the library, 'torch' = callback
                        'cost_first': cost0, 'cost_last': r.cost},
             'roofline': {'bound': 'hbm', 'kernel': 'k_observations<calib=%s,jac=true>' % ('true' if prob.opt_calib else 'false'),
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,

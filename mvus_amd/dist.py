@@ -68,7 +68,7 @@ def sharded_handle(prob, rank, world, device_index, group=None, time_x=None, hal
     LM/Schur solver then exchanges a few MB per iteration instead of the whole cross block; every rank must pass the
     same ``time_x``.  Without it every camera's detections are cut into ``world`` pieces (any solver).
 
-    ``collective``: 'torch' = the all-reduce callback (torch.distributed on aliased device buffers: any backend, gloo on CPU
+    ``collective``: 'auto' = 'rccl' if the library can open and initialise RCCL, else 'torch'; 'torch' = the all-reduce callback (torch.distributed on aliased device buffers: any backend, gloo on CPU
     boxes), 'rccl' = RCCL called from the library on its own communicator (the route bench.py takes on a multi-GPU node).
 
     The handle runs on torch's current stream of that device so that its kernels and the collective are
@@ -87,12 +87,20 @@ def sharded_handle(prob, rank, world, device_index, group=None, time_x=None, hal
     if cuts is not None:
         h.set_time_shard(rank, world, cuts, halo)
     if world > 1 or group is not None:
-        if collective == 'rccl':       # ncclAllReduce called by the library itself (mvus_ba_set_rccl)
-            join_rccl(h, rank, world, group)
-        else:                          # the callback: torch.distributed on tensors aliasing the library's buffers (any backend)
+        use_rccl = collective in ('rccl', 'auto')
+        if use_rccl:                   # ncclAllReduce called by the library itself (mvus_ba_set_rccl)
+            try:
+                join_rccl(h, rank, world, group)
+            except Exception as e:     # a librccl the library cannot open / initialise fails the same way on every rank
+                if collective == 'rccl':
+                    raise
+                print('sharded_handle: RCCL from the library is not available (%s) -- using the torch.distributed callback' % e, flush=True)
+                use_rccl = False
+        if not use_rccl:               # the callback: torch.distributed on tensors aliasing the library's buffers (any backend)
             cb = make_gpu_allreduce(device_index, group)
             h.set_allreduce(cb, is_root=(rank == 0))
             h.allreduce_stats = cb.stats
+        h.collective_used = 'rccl' if use_rccl else 'torch'
     return h, keep
 
 
