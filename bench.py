@@ -219,7 +219,7 @@ def main():
         fd = timed(ba.JAC_FD, prep_fd)
         fd.update({'solver': 'trf_lsmr, jac = scipy 2-point finite differences with column groups (the DEFAULT of Scene.BA; common.py:670)',
                    'column_groups': ngroups[0]})
-        pat = timed(ba.JAC_PATTERN, lambda xs: handle.set_pattern(xs, download=False))
+        pat = timed(ba.JAC_PATTERN, lambda xs: handle.prepare_pattern(xs, ties='canonical'))
         pat['solver'] = 'trf_lsmr (scipy restatement, analytic J masked to the reference pattern)'
         parity = dict(pat)
         parity['default_fd'] = fd

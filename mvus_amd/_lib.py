@@ -182,5 +182,5 @@ def default_opts(solver=SOLVER_TRF_LSMR, jac_mode=JAC_PATTERN, max_nfev=10):
     o.ftol, o.xtol, o.gtol = 1e-8, 1e-12, 1e-8
     o.lsmr_atol, o.lsmr_btol, o.lsmr_conlim, o.lsmr_maxiter = 1e-6, 1e-6, 1e8, 0
     o.verbose = 0
-    o.lm_lambda_min = float(os.environ.get('MVUS_LM_LAMBDA_MIN', 3e-3))       # (the environment variable: experiments only)
+    o.lm_lambda_min = 3e-3
     return o

@@ -103,6 +103,7 @@ class BAHandle:
         x0 = self._x(x0, self.n)
         pat = np.empty(self.M, dtype=np.int32) if download else None
         self._check(self.lib.mvus_ba_set_pattern(self.h, _lib.dptr(x0), pat.ctypes.data_as(_lib.c_int32_p) if download else None), 'mvus_ba_set_pattern')
+        self._pattern_fixed = False      # (a pattern computed on the device is re-computed at the x0 of every JAC_PATTERN solve)
         return pat
 
     def motion_pattern(self):
@@ -123,6 +124,7 @@ class BAHandle:
                 raise ValueError('motion_pat has shape %s, expected (%d,)' % (mp.shape, self.T))
         self._check(self.lib.mvus_ba_upload_pattern(self.h, pat.ctypes.data_as(_lib.c_int32_p),
                                                     mp.ctypes.data_as(_lib.c_int32_p) if mp is not None else None), 'mvus_ba_upload_pattern')
+        self._pattern_fixed = True       # an uploaded pattern stays in force over every solve that follows (mvus_ba_solve keeps it)
 
     def set_deterministic(self, on=True):
         """Kept for the ABI: the LM + Schur assembly is window-major (one writer and one order per entry, no atomics) -- the same
@@ -198,12 +200,15 @@ class BAHandle:
               ties='numpy', matrix=None, prepared=False):
         """The least_squares call of Scene.BA.  Returns an OptimizeResult-like namespace
         (x, cost, fun, nfev, njev, status, optimality, ...).  ``ties`` / ``matrix``: how the reference pattern of the
-        JAC_PATTERN / JAC_FD modes is fixed at x0 (see prepare_pattern); ``prepared``: the pattern (and column groups) set by an
-        earlier prepare_pattern / prepare_fd stay in force (a run of steps with ONE pattern, as least_squares keeps its jac_sparsity)."""
+        JAC_PATTERN / JAC_FD modes is fixed at x0 (see prepare_pattern); ``prepared``: the pattern (and column groups) UPLOADED by an
+        earlier prepare_pattern / prepare_fd stay in force (a run of steps with ONE pattern, as least_squares keeps its
+        jac_sparsity) -- a pattern that only exists on the device (set_pattern) would be recomputed at every call's x0, so that is
+        refused here."""
         x = np.array(self._x(x0, self.n))
         o = opts if opts is not None else _lib.default_opts(solver, jac_mode, max_nfev)
         if prepared and o.jac_mode in (JAC_FD, JAC_PATTERN):
-            pass
+            if not getattr(self, '_pattern_fixed', False):
+                raise ValueError('solve(prepared=True): call prepare_pattern / prepare_fd (or upload_pattern) first')
         elif o.jac_mode == JAC_FD:
             self.prepare_fd(x, ties, matrix)
         elif o.jac_mode == JAC_PATTERN and (matrix is not None or ties != 'canonical'):

@@ -1140,22 +1140,6 @@ int mvus_ba_remove_outliers(mvus_ba* h, const double* x, double thres, uint8_t* 
   });
 }
 
-int mvus_ba_set_allreduce(mvus_ba* h, mvus_allreduce_fn fn, void* user, int32_t is_root) {
-  return guarded(h, [&] {
-    HipBackend& be = h->be;
-    be.allreduce = fn; be.allreduce_user = user; be.is_root = is_root;
-    be.m_glob = be.hp.m;
-    if (fn) {   // global row count = sum of the shards' detection rows + the motion rows once
-      const bool counts_motion = be.tshard.on ? be.tshard.rank == 0 : is_root != 0;
-      be.scal_host[2] = (double)(2 * be.hp.M + (counts_motion ? be.hp.T : 0));
-      MVUS_HIP(hipMemcpyAsync(be.scal_dev + 2, be.scal_host + 2, sizeof(double), hipMemcpyHostToDevice, be.stream));
-      be.reduce(be.scal_dev + 2, 1);
-      be.m_glob = (int64_t)(be.read_slot(2) + 0.5);
-    }
-    return MVUS_OK;
-  });
-}
-
 // ---- RCCL from the library: librccl.so.1 opened at run time, five entry points ----
 namespace {
 struct RcclApi {
@@ -1191,6 +1175,27 @@ static int rccl_allreduce_cb(void* user, void* buf, size_t count, void* stream) 
   return g_rccl.AllReduce(buf, buf, count, kNcclFloat64, kNcclSum, c->comm, static_cast<hipStream_t>(stream));
 }
 
+int mvus_ba_set_allreduce(mvus_ba* h, mvus_allreduce_fn fn, void* user, int32_t is_root) {
+  return guarded(h, [&] {
+    HipBackend& be = h->be;
+    if (fn != rccl_allreduce_cb && h->rccl.comm) {      // another route (or none) replaces the library's own communicator: tear it down
+      MVUS_HIP(hipStreamSynchronize(be.stream));
+      if (g_rccl.CommDestroy) (void)g_rccl.CommDestroy(h->rccl.comm);
+      h->rccl.comm = nullptr;
+    }
+    be.allreduce = fn; be.allreduce_user = user; be.is_root = is_root;
+    be.m_glob = be.hp.m;
+    if (fn) {   // global row count = sum of the shards' detection rows + the motion rows once
+      const bool counts_motion = be.tshard.on ? be.tshard.rank == 0 : is_root != 0;
+      be.scal_host[2] = (double)(2 * be.hp.M + (counts_motion ? be.hp.T : 0));
+      MVUS_HIP(hipMemcpyAsync(be.scal_dev + 2, be.scal_host + 2, sizeof(double), hipMemcpyHostToDevice, be.stream));
+      be.reduce(be.scal_dev + 2, 1);
+      be.m_glob = (int64_t)(be.read_slot(2) + 0.5);
+    }
+    return MVUS_OK;
+  });
+}
+
 }  // extern "C"
 mvus_ba::~mvus_ba() {
   schur.reset();
@@ -1217,10 +1222,13 @@ int mvus_ba_set_rccl(mvus_ba* h, const uint8_t id[128], int32_t rank, int32_t wo
       std::lock_guard<std::mutex> lock(g_rccl_mutex);
       if (!g_rccl.load()) { be.err = g_rccl.err; return MVUS_E_COMM; }
     }
-    if (h->rccl.comm) { g_rccl.CommDestroy(h->rccl.comm); h->rccl.comm = nullptr; }
+    // the route is torn down BEFORE anything can fail: a failed call leaves the handle without a collective route (sums of one
+    // rank), never with a callback that points at a destroyed or half-initialised communicator
+    MVUS_HIP(hipStreamSynchronize(be.stream));
+    if (be.allreduce == rccl_allreduce_cb) { be.allreduce = nullptr; be.allreduce_user = nullptr; }
+    if (h->rccl.comm) { (void)g_rccl.CommDestroy(h->rccl.comm); h->rccl.comm = nullptr; }
     mvus_rccl_id uid;
     std::memcpy(uid.internal, id, 128);
-    MVUS_HIP(hipStreamSynchronize(be.stream));
     const int rc = g_rccl.CommInitRank(&h->rccl.comm, world, uid, rank);
     if (rc != 0) { h->rccl.comm = nullptr; be.err = "ncclCommInitRank: " + g_rccl.what(rc); return MVUS_E_COMM; }
     return mvus_ba_set_allreduce(h, rccl_allreduce_cb, &h->rccl, is_root);

@@ -217,12 +217,7 @@ void k_assemble_windows(DevProblem dp, NEView ne, WinView wv, const CamState* __
     return (kk >= 0 && kk < NJ) ? kk : -1;
   };
 
-#ifdef MVUS_WIN_PROBE
-  long long tpa[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long tprev = clock64(); const long long tstart = tprev; int nbatch = 0;
-#define MVUS_WTP(i) do { const long long t_ = clock64(); tpa[i] += t_ - tprev; tprev = t_; } while (0)
-#else
 #define MVUS_WTP(i) ((void)0)
-#endif
   int p0 = 0, p1 = 0;
   if (ncam > 0) cam_range(0, p0, p1);
   int cnext = ncam > 0 ? wv.cam_perm[wave] : 0;
@@ -405,9 +400,6 @@ void k_assemble_windows(DevProblem dp, NEView ne, WinView wv, const CamState* __
       win_wave_sync();                                      // the staging region is rewritten by the next batch
       if (lane < 32) mk[lane] = 0ull;
       MVUS_WTP(3);     // accumulation
-#ifdef MVUS_WIN_PROBE
-      ++nbatch;
-#endif
       cur = nxt;
     }
 
@@ -449,11 +441,6 @@ void k_assemble_windows(DevProblem dp, NEView ne, WinView wv, const CamState* __
   }
 
   MVUS_WTP(5);
-#ifdef MVUS_WIN_PROBE
-  if ((blockIdx.x % 97) == 5 && lane == 0)
-    printf("win %d wave %d ncam %d batches %d: total %lld | per batch: setup %lld eval %lld mfma %lld accum %lld | per camera: stores %lld | tail %lld\n", win, wave, ncam, nbatch,
-           clock64() - tstart, tpa[0] / max(nbatch, 1), tpa[1] / max(nbatch, 1), tpa[2] / max(nbatch, 1), tpa[3] / max(nbatch, 1), tpa[4] / max(ncam, 1), tpa[5]);
-#endif
   // ---- band and gradient: the rows' pieces, then the four wavefronts, added in order; every entry stored once ----
   if (SP > 1) {
 #pragma unroll

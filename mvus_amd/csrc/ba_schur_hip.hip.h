@@ -112,12 +112,7 @@ __global__ __launch_bounds__(kGaThreads) void k_assemble_spans(DevProblem dp, co
   const long long i0 = dp.chunk_start[chunk] + half * kGaObs;
   const long long a0 = dp.det_off[c], Mc = dp.det_off[c + 1] - a0;
   const int tid = threadIdx.x;
-#ifdef MVUS_ASM_PROBE
-  long long tp[8]; int np_ = 0; long long te[4] = {0, 0, 0, 0};
-#define MVUS_TP() do { if (np_ < 8) tp[np_++] = clock64(); } while (0)
-#else
 #define MVUS_TP() ((void)0)
-#endif
   MVUS_TP();
   if (tid == 0) { any_s = 0; sort_s = 0; nr_s = 0; }
   const int t = tid & (kGaObs - 1);                    // detection handled while staging
@@ -211,9 +206,6 @@ __global__ __launch_bounds__(kGaThreads) void k_assemble_spans(DevProblem dp, co
   const int nr = nr_s;
   const double* fxs = Js + (2 * NS) * kGaStride;
   const double* fys = fxs + kGaStride;
-#if defined(MVUS_ASM_STOP) && MVUS_ASM_STOP == 1
-  if (nr >= 0) return;      // timing probe: staging + ranges only
-#endif
   // camera block (lower triangle) and camera gradient on the fp64 matrix cores: G = R R^T with R = [camera slots; f]
   // ((B+1) x 2*128, x rows then y rows).  For v_mfma_f64_16x16x4 the A fragment (lane l: R[l&15][k0 + (l>>4)]) IS the
   // B fragment of R^T, so one LDS read feeds both operands.  The LAST wavefront does all of it (64 MFMAs per tile pair)
@@ -342,9 +334,6 @@ __global__ __launch_bounds__(kGaThreads) void k_assemble_spans(DevProblem dp, co
     }
   }
   if (!fast) return;
-#if defined(MVUS_ASM_STOP) && MVUS_ASM_STOP == 2
-  if (acc_[0] != 12345.678) return;      // timing probe: + accumulation, no flush
-#endif
   MVUS_TP();   // 3: accumulated
   lds_barrier();                                        // every thread holds its partials in registers: Js is dead
   MVUS_TP();   // 4: everybody accumulated
@@ -421,9 +410,6 @@ __global__ __launch_bounds__(kGaThreads) void k_assemble_spans(DevProblem dp, co
     lds_barrier();
   }
   MVUS_TP();   // 5: cross block flushed
-#if defined(MVUS_ASM_STOP) && MVUS_ASM_STOP == 3
-  if (nr >= 0) return;      // timing probe: + cross-block flush
-#endif
   // ---- flush of the spline band: Cp[rl][pair (qa, w)][3][3], pair = 4 qa - qa (qa - 1) / 2 + w ----
   for (int r0 = 0, rho = 0; r0 < nr; r0 += kRb, ++rho) {
     const int nb = min(kRb, nr - r0);
@@ -457,10 +443,6 @@ __global__ __launch_bounds__(kGaThreads) void k_assemble_spans(DevProblem dp, co
 #undef EA
 #undef CA
   MVUS_TP();   // 6: band flushed
-#ifdef MVUS_ASM_PROBE
-  if ((blockIdx.x % 997) == 5 && (tid == 0 || tid == 64 || tid == 300 || tid == kGaThreads - 64))
-    printf("blk %d tid %d nr %d: staged %lld ranges %lld accum %lld wait %lld Eflush %lld Cflush %lld | E round 0: write %lld owners %lld loop %lld barrier %lld\n", (int)blockIdx.x, tid, nr, tp[1] - tp[0], tp[2] - tp[1], tp[3] - tp[2], tp[4] - tp[3], tp[5] - tp[4], tp[6] - tp[5], te[0] - tp[4], te[1] - te[0], te[2] - te[1], te[3] - te[2]);
-#endif
 }
 
 __device__ __forceinline__ void lds_wave_sync() {      // orders the LDS traffic of ONE wavefront (writes of some lanes read by others)
@@ -1609,9 +1591,6 @@ __device__ __forceinline__ void bcr_tail_body(const PartView& pv, int h0, int* _
   const int wave = threadIdx.x >> 6;
   for (int h = h0; h <= pv.m; h <<= 1) {
     const int ns = pv.m / (2 * h), nt = ns > 0 ? ns : 1;
-#ifdef MVUS_BCR_PROBE
-    const long long p0_ = clock64();
-#endif
     for (int s = wave; s < nt; s += NW) bcr_survivor<S3>(pv, h, s, w + wave * 3 * S3 * S3, fail);
     // The next level's loads (bcr_ld: agent scope, they bypass the CU's L1 and read L2) must see this level's plain stores of the
     // OTHER wavefronts of this workgroup.  All of them run on one CU, hence behind one L2: what is needed is that the stores have
@@ -1620,9 +1599,6 @@ __device__ __forceinline__ void bcr_tail_body(const PartView& pv, int h0, int* _
     // benefit of other XCDs -- `buffer_wbl2 sc1` -- which nothing here needs: measured +15 us per solve.)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-#ifdef MVUS_BCR_PROBE
-    if (threadIdx.x == 0) printf("bcr tail h=%d ns=%d: %lld cycles\n", h, ns, clock64() - p0_);
-#endif
   }
 }
 template <int S3>
@@ -2115,9 +2091,6 @@ __device__ __forceinline__ void pivot_inverse_wave(double (*Dm)[kNB + 1], double
   double* M4 = W + 3 * 16 * LD;   // T, later P21
   double* M5 = W + 4 * 16 * LD;   // S, later P22
   double a[16], x[16], rd[16];
-#ifdef MVUS_GJ_PROBE
-  const long long q0_ = clock64();
-#endif
 #pragma unroll
   for (int k = 0; k < 16; ++k) {          // unconditional LDS reads, then selects: no branch per element (every row of 16 lanes the same)
     const double t = Dm[row][k];
@@ -2131,9 +2104,6 @@ __device__ __forceinline__ void pivot_inverse_wave(double (*Dm)[kNB + 1], double
     for (int k = 0; k < 16; ++k) dst[k * LD] = lane < 16 ? x[k] : rd[k] * x[k];
   }
   lds_wave_sync();
-#ifdef MVUS_GJ_PROBE
-  const long long q1_ = clock64();
-#endif
   bcr_d4 a11 = mma16(M1, LD, true, M2, LD, false, zero);                 // A11^-1 = X^T (D^-1 X)
   store16(M3, LD, a11, 1.0);
   lds_wave_sync();
@@ -2144,9 +2114,6 @@ __device__ __forceinline__ void pivot_inverse_wave(double (*Dm)[kNB + 1], double
 #pragma unroll
   for (int r = 0; r < 4; ++r) M5[(lk + 4 * r) * LD + lr] = Dm[16 + lk + 4 * r][16 + lr] - acc[r];
   lds_wave_sync();
-#ifdef MVUS_GJ_PROBE
-  const long long q2_ = clock64();
-#endif
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
     const double t = M5[row * LD + k];
@@ -2160,9 +2127,6 @@ __device__ __forceinline__ void pivot_inverse_wave(double (*Dm)[kNB + 1], double
     for (int k = 0; k < 16; ++k) dst[k * LD] = lane < 16 ? x[k] : rd[k] * x[k];
   }
   lds_wave_sync();
-#ifdef MVUS_GJ_PROBE
-  const long long q3_ = clock64();
-#endif
   const bcr_d4 p22 = mma16(M1, LD, true, M2, LD, false, zero);           // S^-1
   store16(M5, LD, p22, 1.0);
   lds_wave_sync();
@@ -2182,9 +2146,6 @@ __device__ __forceinline__ void pivot_inverse_wave(double (*Dm)[kNB + 1], double
     Pout[lr * kNB + 16 + rw] = -p21[r];
     Pout[(16 + rw) * kNB + 16 + lr] = p22[r];
   }
-#ifdef MVUS_GJ_PROBE
-  if (lane == 0 && blockIdx.x == 0) printf("pivot inverse: ldl %lld, A11inv+T+S %lld, ldl %lld, glue+P %lld cycles\n", q1_ - q0_, q2_ - q1_, q3_ - q2_, clock64() - q3_);
-#endif
 }
 
 // one panel step; grid (row tiles below the panel incl. the rhs row, all column tiles); pc != nullptr on the last step.
@@ -2198,9 +2159,6 @@ __global__ __launch_bounds__(kGjThreads) void k_gj_step(int nn, int kb, const do
   double (*Pk)[kNB + 1] = reinterpret_cast<double (*)[kNB + 1]>(lds + kTile);
   double (*Q)[kNB + 1] = reinterpret_cast<double (*)[kNB + 1]>(lds + 2 * kTile);
   double (*Bk)[kNB + 1] = reinterpret_cast<double (*)[kNB + 1]>(lds + 3 * kTile);      // Q and Bk: one contiguous scratch area later
-#ifdef MVUS_GJ_PROBE
-  const long long t0_ = clock64();
-#endif
   const int nb = min(kNB, nn - kb), base = kb + nb;
   const int i0 = base + blockIdx.x * kNB, j0 = blockIdx.y * kNB;
   const bool pivcol = j0 == kb;                              // this tile is column block k: it stores Q_I
@@ -2252,9 +2210,6 @@ __global__ __launch_bounds__(kGjThreads) void k_gj_step(int nn, int kb, const do
   // the tile holding the next pivot block inverts it
   const int nb2 = min(kNB, nn - base);
   if (blockIdx.x != 0 || j0 != base || nb2 <= 0) return;
-#ifdef MVUS_GJ_PROBE
-  const long long t1_ = clock64();
-#endif
   __syncthreads();                                           // Ai is reused as the block to invert, Q and Bk as scratch
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -2264,9 +2219,6 @@ __global__ __launch_bounds__(kGjThreads) void k_gj_step(int nn, int kb, const do
   __syncthreads();
   static_assert(kPivScratch <= 2 * kNB * (kNB + 1), "pivot scratch must fit Q and Bk");
   if (threadIdx.x < 64) pivot_inverse_wave(Ai, &Q[0][0], Pinv + (long long)(base / kNB) * kNB * kNB, fail);
-#ifdef MVUS_GJ_PROBE
-  if (threadIdx.x == 0 && kb == 0) printf("gj panel 0: tile %lld cycles, pivot inverse %lld cycles\n", t1_ - t0_, clock64() - t1_);
-#endif
 }
 
 // p (x order) from p_c and p_s = -(z_g + Z_E p_c)

@@ -505,9 +505,6 @@ __global__ __launch_bounds__(kBandPartsMax) void k_band_solve_parts(int n, BandP
   __shared__ int s_bad[kBandPartsMax];
   PivotStats<T> ps;
   const int r0 = p < P ? bp.first(p) : 0, lp = p < P ? bp.length(p) : 0;
-#ifdef MVUS_PARTS_PROBE
-  const long long tq0_ = wall_clock64();
-#endif
   // ---- phase 1 ----
   if (p < P) {
     T Lp[HB + 1][HB + 1];                             // Lp[u][w] = L(i-u, i-u-w)
@@ -662,9 +659,6 @@ __global__ __launch_bounds__(kBandPartsMax) void k_band_solve_parts(int n, BandP
   }
   __syncthreads();
   __threadfence_block();
-#ifdef MVUS_PARTS_PROBE
-  const long long tq1_ = wall_clock64();
-#endif
   // ---- phase 2: the separator system: lanes 0..2 of the first wavefront, one right-hand side each (the matrix part is the same
   // arithmetic in all three; lane 0 stores it).  The inputs of separator q + 1 are fetched while separator q is processed: a step
   // was 2.6 us (fp64), one memory round trip of it waiting for ~60 loads.
@@ -814,9 +808,6 @@ __global__ __launch_bounds__(kBandPartsMax) void k_band_solve_parts(int n, BandP
   }
   __syncthreads();
   __threadfence_block();
-#ifdef MVUS_PARTS_PROBE
-  const long long tq2_ = wall_clock64();
-#endif
   // ---- phase 3 ----
   if (p < P) {
     T xl[HB][3], xr[HB][3], yr[HB][HB];
@@ -907,10 +898,6 @@ __global__ __launch_bounds__(kBandPartsMax) void k_band_solve_parts(int n, BandP
     for (int k = 0; k < (int)blockDim.x; ++k) { mn = fmin(mn, s_min[k]); mx = fmax(mx, s_max[k]); bad |= s_bad[k]; }
     out[2] = mn; out[3] = mx;
     if (bad) fail[0] = 1;
-#ifdef MVUS_PARTS_PROBE
-    if (n > 3000 && n < 3400) printf("parts HB=%d %s n=%d P=%d: phase 1 %lld, phase 2 %lld, phase 3 %lld (10 ns ticks)\n", HB, sizeof(T) == 8 ? "fp64" : "dd", n, P,
-                                     tq1_ - tq0_, tq2_ - tq1_, wall_clock64() - tq2_);
-#endif
   }
 }
 #endif

@@ -49,16 +49,55 @@ def make_gpu_allreduce(device_index, group=None):
     return fn
 
 
+def agree_on_rccl(rank, world, group, get_id, join, leave):
+    """The route of the sums is a COLLECTIVE decision: every rank returns the same (ok, reason).
+
+    ``get_id()`` (rank 0 only) returns the 128-byte RCCL id or raises; ``join(id)`` makes this rank join the library's communicator
+    or raises; ``leave()`` tears down a communicator that did initialise.  Protocol, every step a collective of ``group`` that all
+    ranks enter whatever happened locally: (1) rank 0 broadcasts (ok, id-or-error) -- it never raises before the broadcast;
+    (2) if there is an id every rank tries to join, then all ranks exchange their outcome (all_gather_object); (3) unless ALL joined,
+    the ranks that did join leave again and everyone reports failure.  No rank can end up in the native route while another one is
+    in the callback route (mismatched collectives = a hang)."""
+    import torch.distributed as dist
+    box = [None]
+    if rank == 0:
+        try:
+            box[0] = (True, bytes(get_id()))
+        except Exception as e:
+            box[0] = (False, '%s: %s' % (type(e).__name__, e))
+    if world > 1:
+        dist.broadcast_object_list(box, src=0, group=group)
+    ok, payload = box[0]
+    if not ok:
+        return False, 'rank 0 could not get an RCCL id (%s)' % payload
+    err = None
+    try:
+        join(payload)
+    except Exception as e:
+        err = '%s: %s' % (type(e).__name__, e)
+    outcomes = [None] * world
+    if world > 1:
+        dist.all_gather_object(outcomes, err, group=group)
+    else:
+        outcomes[0] = err
+    failed = [(r, o) for r, o in enumerate(outcomes) if o is not None]
+    if failed:
+        if err is None:
+            leave()
+        return False, '; '.join('rank %d: %s' % f for f in failed)
+    return True, ''
+
+
 def join_rccl(handle, rank, world, group=None, is_root=None):
     """Native route: rank 0 asks the library for an RCCL id, torch.distributed (whatever its backend) hands the 128 bytes to the
     other ranks -- once -- and every rank joins the library's own communicator; from then on the iteration's sums are
-    ncclAllReduce calls made by the library on the handle's stream."""
-    import torch.distributed as dist
+    ncclAllReduce calls made by the library on the handle's stream.  Returns (ok, reason), the same on every rank
+    (``agree_on_rccl``); on failure the handle is left without a route."""
     from . import _lib
-    box = [_lib.rccl_unique_id() if rank == 0 else None]
-    if world > 1:
-        dist.broadcast_object_list(box, src=0, group=group)
-    handle.set_rccl(box[0], rank, world, is_root=(rank == 0) if is_root is None else is_root)
+    root = (rank == 0) if is_root is None else is_root
+    return agree_on_rccl(rank, world, group, _lib.rccl_unique_id,
+                         lambda uid: handle.set_rccl(uid, rank, world, is_root=root),
+                         lambda: handle.set_allreduce(None, is_root=root))
 
 
 def sharded_handle(prob, rank, world, device_index, group=None, time_x=None, halo=8, collective='torch'):
@@ -88,13 +127,13 @@ def sharded_handle(prob, rank, world, device_index, group=None, time_x=None, hal
         h.set_time_shard(rank, world, cuts, halo)
     if world > 1 or group is not None:
         use_rccl = collective in ('rccl', 'auto')
-        if use_rccl:                   # ncclAllReduce called by the library itself (mvus_ba_set_rccl)
-            try:
-                join_rccl(h, rank, world, group)
-            except Exception as e:     # a librccl the library cannot open / initialise fails the same way on every rank
+        if use_rccl:                   # ncclAllReduce called by the library itself (mvus_ba_set_rccl); all ranks agree on the outcome
+            ok, why = join_rccl(h, rank, world, group)
+            if not ok:
                 if collective == 'rccl':
-                    raise
-                print('sharded_handle: RCCL from the library is not available (%s) -- using the torch.distributed callback' % e, flush=True)
+                    raise RuntimeError('sharded_handle: RCCL from the library is not available: ' + why)
+                if rank == 0:
+                    print('sharded_handle: RCCL from the library is not available (%s) -- every rank uses the torch.distributed callback' % why, flush=True)
                 use_rccl = False
         if not use_rccl:               # the callback: torch.distributed on tensors aliasing the library's buffers (any backend)
             cb = make_gpu_allreduce(device_index, group)

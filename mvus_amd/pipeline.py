@@ -39,11 +39,21 @@ def incremental_reconstruction(flight, max_iter=10, verbose=False, timer=None):
     Returns the StageTimer."""
     timer = timer or StageTimer()
     st = flight.settings
-    if st.get('ba_solver') == 'lm' and 'ba_lambda_min' not in st:
-        # the staged, gauge-free BAs of the loop need more damping than one large BA (reconstruction/common.py: LOOP_LM_LAMBDA_MIN)
+    loop_floor = st.get('ba_solver') == 'lm' and 'ba_lambda_min' not in st
+    if loop_floor:
+        # the staged, gauge-free BAs of the loop need more damping than one large BA (reconstruction/common.py: LOOP_LM_LAMBDA_MIN);
+        # the floor is in force for the loop only: a later stand-alone Scene.BA on this Scene gets the library's own again
         from .reconstruction.common import LOOP_LM_LAMBDA_MIN
         st['ba_lambda_min'] = LOOP_LM_LAMBDA_MIN
         print("incremental_reconstruction: ba_solver = 'lm' without ba_lambda_min -- using the loop's damping floor %g" % LOOP_LM_LAMBDA_MIN)
+    try:
+        return _incremental_loop(flight, st, max_iter, verbose, timer)
+    finally:
+        if loop_floor:
+            st.pop('ba_lambda_min', None)
+
+
+def _incremental_loop(flight, st, max_iter, verbose, timer):
     kw = dict(rs=st['rolling_shutter'], motion_reg=st['motion_reg'], motion_weights=st['motion_weights'], rs_bounds=st['rs_bounds'])
     cam_temp = 2
     while True:

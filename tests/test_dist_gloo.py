@@ -181,3 +181,61 @@ def test_time_sharded_lm_in_two_processes_matches_unsharded(tmp_path):
     assert cost_ref < 0.95 * 0.5 * float(h.residual(x0) @ h.residual(x0))  # the solve did something (2 % gross outliers carry most of the cost)
     np.testing.assert_allclose(float(r[0]['cost']), cost_ref, rtol=1e-9)
     np.testing.assert_allclose(r[0]['x'], x_ref, rtol=0, atol=1e-7 * max(1.0, np.abs(x_ref).max()))
+
+
+def _route_worker(rank, world, port, fail_at, out_dir):
+    """agree_on_rccl with injected failures: get_id raises on rank 0 ('id'), join raises on ONE rank ('join0' / 'join1'), or nothing
+    fails ('none').  Whatever happens locally every rank must come out with the same decision, a rank that did join must have left
+    again, and the collective that follows (here: the callback route's all_reduce) must complete on both ranks."""
+    _setup(rank, world, port)
+    try:
+        from mvus_amd.dist import agree_on_rccl
+        state = {'joined': False, 'left': False}
+
+        def get_id():
+            if fail_at == 'id':
+                raise OSError('librccl.so.1 cannot be opened (injected)')
+            return bytes(range(128))
+
+        def join(uid):
+            assert uid == bytes(range(128))
+            if fail_at == 'join%d' % rank:
+                raise ValueError('ncclCommInitRank failed (injected)')
+            state['joined'] = True
+
+        def leave():
+            state['left'] = True
+
+        ok, why = agree_on_rccl(rank, world, None, get_id, join, leave)
+        total = _sum(np.array([1.0 + rank]))          # the route both ranks fell back to: must not hang
+        np.save(os.path.join(out_dir, 'route%d.npy' % rank),
+                np.array([float(ok), float(state['joined']), float(state['left']), float(total[0])]))
+        with open(os.path.join(out_dir, 'why%d.txt' % rank), 'w') as f:
+            f.write(why)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize('fail_at', ['none', 'id', 'join0', 'join1'])
+def test_rccl_route_is_a_collective_decision(tmp_path, fail_at):
+    """collective='auto' (mvus_amd/dist.py): a librccl the library cannot open on rank 0 only, or a communicator that fails to
+    initialise on one rank only, must send BOTH ranks to the callback route -- not one rank into its first all_reduce while the
+    other one still sits in the id broadcast (the round-4 advisor's finding)."""
+    world, port = 2, _free_port()
+    tmp.spawn(_route_worker, args=(world, port, fail_at, str(tmp_path)), nprocs=world, join=True)
+    r = [np.load(tmp_path / ('route%d.npy' % k)) for k in range(world)]
+    why = [(tmp_path / ('why%d.txt' % k)).read_text() for k in range(world)]
+    assert r[0][0] == r[1][0] == (1.0 if fail_at == 'none' else 0.0)        # the same decision on both ranks
+    assert why[0] == why[1]
+    assert r[0][3] == r[1][3] == 3.0                                            # the next collective completed on both
+    for k in range(world):
+        joined, left = r[k][1], r[k][2]
+        if fail_at == 'none':
+            assert joined == 1.0 and left == 0.0
+        elif fail_at == 'id':
+            assert joined == 0.0 and left == 0.0 and 'rank 0 could not get an RCCL id' in why[k]
+        else:
+            failing = int(fail_at[-1])
+            assert joined == (0.0 if k == failing else 1.0) and left == joined        # who joined has left again
+            assert 'rank %d' % failing in why[k]

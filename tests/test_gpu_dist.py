@@ -51,7 +51,8 @@ def test_rccl_called_by_the_library_world1():
     opts = _lib.default_opts(_lib.SOLVER_TRF_LSMR, _lib.JAC_PATTERN, 6)
     opts.lsmr_maxiter = 4
     with BAHandle(prob) as h0, BAHandle(prob) as h:
-        join_rccl(h, 0, 1)
+        ok, why = join_rccl(h, 0, 1)
+        assert ok, why
         assert h.time_allreduce(1000, 5) >= 0.0
         r0, r1 = h0.solve(g['x0'], opts=opts), h.solve(g['x0'], opts=opts)
         np.testing.assert_allclose(r1.cost, r0.cost, rtol=1e-12)

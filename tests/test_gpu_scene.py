@@ -68,6 +68,8 @@ def test_ba_outliers_ba_sequence(name, mode):
         # of the detections, OpenCV's early-out -- restated since round 4 -- resets those points, and the count of "outliers" at such an
         # iterate means nothing: 90 before the early-out was restated, 29 with it, 78 by the reference at ITS tenth evaluation)
         assert abs(removed - ref_removed) <= max(3, 0.4 * ref_removed)
+    else:                                             # ... but it stays a small part of the scene (the threshold still means something)
+        assert removed <= max(4 * ref_removed, 0.1 * n_before)
     assert s._ba_handle is handle and handle.M == sum(d.shape[1] for d in s.detections)    # filtered in place on the GPU
     res2 = s.BA(C, **kw)
     assert s._ba_handle is handle                                                            # no new handle, no re-upload

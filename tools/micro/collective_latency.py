@@ -26,7 +26,8 @@ for route in ('torch callback', 'rccl native'):
         if route == 'torch callback':
             h.set_allreduce(make_gpu_allreduce(0), is_root=True)
         else:
-            join_rccl(h, 0, 1)
+            ok, why = join_rccl(h, 0, 1)
+            assert ok, why
         for name, cnt in sizes:
             ms = h.time_allreduce(cnt, 200)
             out.setdefault(name, {})[route] = ms
