@@ -1,0 +1,430 @@
+// Reduced camera system S p_c = -rhs (dense, SPD, nn = C * (3 + P) <= 1152 unknowns): blocked L D L^T with the matrix held in the
+// register layout of the fp64 matrix cores.  Included by ba_schur_hip.hip.h (needs NEView, bcr_d4, ldl_inv16, dpp_shift).
+//
+// No counterpart in the reference (Scene.BA hands the whole problem to scipy, reconstruction/common.py:670); this replaces the
+// block Gauss-Jordan of rounds 1-4 (k_gj_step: one launch per 32 columns, 10.1 us each, of which the 32x32 pivot inverse in ONE
+// wavefront was 5.8 us and the rest a kernel boundary plus a round trip of the pivot tile through memory).
+//
+// Storage.  The matrix is cut into 16x16 blocks.  A block M is kept as its IMAGE  img(M)[lane][r] = M[lk + 4r][lr]  (lane = 16 lk +
+// lr, r = 0..3: four doubles = 32 contiguous bytes per lane, 2 KB per block) -- the accumulator layout of v_mfma_f64_16x16x4.  The same
+// four values are at once the B operand of M (step s reads M[4s + lk][lr] = img(M)[s]) and the A operand of M^T (step s reads
+// M^T[lr][4s + lk] = img(M)[s]): a product  D = P^T Q  of two blocks needs img(P) and img(Q) only -- no transposition, no LDS shuffle
+// between the result of one product and the operand of the next.  Block (i, j), i >= j, lives at rcs_blk(i, j); block row nbk is the
+// right-hand side (a block row whose first row is rhs^T).
+//
+// Algebra (right-looking, 16 columns per step).  U_ij = A_ij^T is what is stored.  Step k:  A_kk = L_k Delta_k L_k^T by ldl_inv16 (one
+// wavefront, row per lane, multipliers by DPP) which also returns X_k = L_k^-1;  panel  T_ik = X_k U_ik  (i > k);  trailing update
+// U_ij -= T_jk^T Delta_k^-1 T_ik  (i >= j > k).  The right-hand side rides as block row R = nbk; afterwards column 0 of T_Rk is
+// t_k = (L^-1 rhs)_k and  x_k = X_k^T Delta_k^-1 (t_k - sum_{i>k} T_ik x_i)  descending in k.  The negated, scaled image -Delta_k^-1 T_ik
+// is kept beside the raw one so that every update is a plain multiply-accumulate.
+//
+// Launches.  Super-panels of kRcsSP = 9 block columns (144 unknowns):  k_rcs_factor (ONE workgroup: the diagonal super-block and
+// the right-hand-side row live in the registers of ten wavefronts (one block row each), an eleventh runs the 16-column pivot chain one step ahead of the
+// trailing update: per 16 columns the chain is ldl_inv16 + one panel product + one block update, all inside one CU)  ->  k_rcs_trsm
+// (block rows below: one wavefront per row, operands staged in LDS)  ->  k_rcs_syrk (trailing blocks, one wavefront each)  ->  next
+// super-panel ...  ->  k_rcs_backsub (one workgroup, descending).  nn = 288: 6 launches instead of 1 + 9.
+#pragma once
+
+namespace mvus {
+
+constexpr int kRcsSP = 9;                   // 16-column blocks per super-panel
+constexpr int kRcsFactorThreads = 64 * (kRcsSP + 2);      // ten row-owning wavefronts (nine block rows + the right-hand side) + the pivot wavefront
+constexpr int kRcsTrsmRows = 4;             // block rows (wavefronts) per workgroup of k_rcs_trsm
+
+struct RcsView {
+  double* Simg;      // block images: U_ij, overwritten by T_ik (i > k) and by img(X_k^T) on the diagonal
+  double* Tsc;       // -Delta_k^-1 T_ik images; diagonal block (k, k): 1/d of the 16 pivots in its first 16 doubles
+  int nn, nbk;       // unknowns, 16-blocks (the right-hand side is block row nbk)
+};
+
+__host__ __device__ __forceinline__ long long rcs_blk(int i, int j) { return ((long long)i * (i + 1) / 2 + j) * 256; }
+__host__ __device__ inline size_t rcs_doubles(int nn) { const int nbk = (nn + 15) / 16; return (size_t)rcs_blk(nbk + 1, 0); }
+__device__ __forceinline__ bcr_d4 rcs_load(const double* __restrict__ p) { return *reinterpret_cast<const bcr_d4*>(p); }
+__device__ __forceinline__ void rcs_store(double* __restrict__ p, bcr_d4 v) { *reinterpret_cast<bcr_d4*>(p) = v; }
+// acc + P^T Q from img(P), img(Q)
+__device__ __forceinline__ bcr_d4 rcs_mma(bcr_d4 p, bcr_d4 q, bcr_d4 acc) {
+#pragma unroll
+  for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(p[s], q[s], acc, 0, 0, 0);
+  return acc;
+}
+// y = M w from img(M) and w[lr] (the value of this lane's column): the sums over the 16 lanes of a row by DPP row shifts;
+// lane lr == 15 of row lk ends with y[lk + 4r] in out[r]
+__device__ __forceinline__ bcr_d4 rcs_matvec(bcr_d4 img, double w) {
+  bcr_d4 out;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    double v = img[r] * w;
+    v += dpp_shift<0x111, 0xF>(v, 0.0);      // row_shr:1
+    v += dpp_shift<0x112, 0xF>(v, 0.0);      // row_shr:2
+    v += dpp_shift<0x114, 0xF>(v, 0.0);      // row_shr:4
+    v += dpp_shift<0x118, 0xF>(v, 0.0);      // row_shr:8
+    out[r] = v;
+  }
+  return out;
+}
+
+// L D L^T of a 16x16 block with the inverse factor, as ldl_inv16 (ba_schur_hip.hip.h: row i of the block and of the identity in lane i
+// of every 16-lane row, multipliers by DPP row broadcast; same operations on every entry in the same order), with the instruction
+// order fixed BY HAND.  The unit of work is one (column K, target column J) pair: broadcast of the multiplier, the update of a[J] and
+// of x[J]; a scheduling barrier closes each.  Column K first updates column K + 1; the six dependent steps that turn the next pivot
+// into its reciprocal (broadcast, v_rcp_f64, two Newton steps) are then dealt one per following pair, so that each waits under the
+// ~30 issue cycles of a pair instead of stalling the wavefront.  Left to itself the compiler hoists the broadcasts of several
+// columns, postpones the x updates, and spills the multipliers it keeps for them (256 registers and 300 - 700 bytes of scratch per
+// lane inside the chain).
+struct RcsPivotChain { double d, r, e; bool bad; };
+template <int STAGE, int J> __device__ __forceinline__ void rcs_chain_stage(RcsPivotChain& c, const double (&a)[16]) {
+  if constexpr (STAGE == 0) { double d = row_bcast<J>(a[J]); c.bad |= !(d > 0.0); c.d = d > 0.0 ? d : 1.0; }
+  else if constexpr (STAGE == 1) c.r = __builtin_amdgcn_rcp(c.d);
+  else if constexpr (STAGE == 2 || STAGE == 4) c.e = 2.0 - c.d * c.r;
+  else if constexpr (STAGE == 3 || STAGE == 5) c.r = c.r * c.e;
+}
+template <int FROM, int KN> struct RcsChainRest {      // the stages that found no pair to hide under (the last columns)
+  static __device__ __forceinline__ void run(RcsPivotChain& c, const double (&a)[16]) {
+    if constexpr (FROM <= 5) { rcs_chain_stage<FROM, KN>(c, a); RcsChainRest<FROM + 1, KN>::run(c, a); }
+  }
+};
+template <int K, int J> struct RcsColOps {
+  static __device__ __forceinline__ void run(double (&a)[16], double (&x)[16], double ta, double tx, RcsPivotChain& c) {
+    if constexpr (J < 16) {
+      const double m = row_bcast<J>(a[K]);
+      a[J] -= ta * m;
+      x[J] -= tx * m;
+      rcs_chain_stage<J - (K + 1), K + 1>(c, a);
+      // (scheduling barriers order machine instructions only; the empty asm makes the pair's results exist HERE in the instruction
+      // selector's order too -- without it the x updates sink to the end of the block and their multipliers go to scratch)
+      asm volatile("" : "+v"(a[J]), "+v"(x[J]), "+v"(c.d), "+v"(c.r), "+v"(c.e));
+      __builtin_amdgcn_sched_barrier(0);
+      RcsColOps<K, J + 1>::run(a, x, ta, tx, c);
+    }
+  }
+};
+template <int K> struct RcsCols {
+  static __device__ __forceinline__ void run(double (&a)[16], double (&x)[16], double (&rd)[16], RcsPivotChain& c) {
+    const double r = c.r;
+    rd[K] = r;
+    if constexpr (K + 1 < 16) {
+      const double ta = a[K] * r, tx = x[K] * r;
+      RcsColOps<K, K + 1>::run(a, x, ta, tx, c);
+      RcsChainRest<(15 - K < 6 ? 15 - K : 6), K + 1>::run(c, a);
+      __builtin_amdgcn_sched_barrier(0);
+      RcsCols<K + 1>::run(a, x, rd, c);
+    }
+  }
+};
+__device__ __forceinline__ void rcs_ldl16(double (&a)[16], double (&x)[16], double (&rd)[16], int lane, int* __restrict__ fail) {
+  RcsPivotChain c{0.0, 0.0, 0.0, false};
+  RcsChainRest<0, 0>::run(c, a);
+  RcsCols<0>::run(a, x, rd, c);
+  if (c.bad && lane == 0) fail[0] = 2;
+}
+
+// S = (A + lambda D_c) - sum_slabs Gp[:, :CB] and rhs = gc - sum_slabs Gp[:, CB] (k_schur_finish's sums), written as block images:
+// lower block triangle, identity on the padding of the last block, the right-hand side as block row nbk.
+// Grid (ntile, ntile + 1) of 32x32 tiles, the last row of the grid writes the right-hand side.
+__global__ __launch_bounds__(256) void k_rcs_finish(NEView ne, int ncols, int nslab, double lambda, const double* __restrict__ Gp, RcsView rv) {
+  constexpr int kT = 32, kRowsPer = 4, kRowStep = 8;
+  const int r0 = threadIdx.x / kT, c = threadIdx.x % kT;
+  const int b = blockIdx.x * kT + c;
+  const long long stride = (long long)ne.CB * ncols;
+  const int nn = ne.CB, npad = rv.nbk * 16;
+  if (blockIdx.y == gridDim.y - 1) {
+    if (r0 != 0 || b >= npad) return;
+    double gr = 0.0;
+    if (b < nn) {
+      for (int sl = 0; sl < nslab; sl += 8) {
+        double t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = sl + u < nslab ? Gp[(sl + u) * stride + (long long)b * ncols + ne.CB] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) gr += t[u];
+      }
+    }
+    const double val = b < nn ? ne.gc[b] - gr : 0.0;
+    double* blk = rv.Simg + rcs_blk(rv.nbk, b / 16);
+    const int cc = b % 16;
+    for (int lr = 0; lr < 16; ++lr) blk[((cc % 4) * 16 + lr) * 4 + cc / 4] = lr == 0 ? val : 0.0;
+    return;
+  }
+  if (blockIdx.x > blockIdx.y) return;
+  double gsum[kRowsPer];
+  long long goff[kRowsPer];
+#pragma unroll
+  for (int q = 0; q < kRowsPer; ++q) {
+    const int a = blockIdx.y * kT + r0 + kRowStep * q;
+    const int hi = a / kGemmT >= b / kGemmT ? a : b, lo = a / kGemmT >= b / kGemmT ? b : a;
+    goff[q] = (a < nn && b < nn) ? (long long)hi * ncols + lo : -1;
+    gsum[q] = 0.0;
+  }
+  for (int sl = 0; sl < nslab; sl += 8) {
+    double t[8][kRowsPer];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int q = 0; q < kRowsPer; ++q) t[u][q] = (sl + u < nslab && goff[q] >= 0) ? Gp[(sl + u) * stride + goff[q]] : 0.0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int q = 0; q < kRowsPer; ++q) gsum[q] += t[u][q];
+  }
+#pragma unroll
+  for (int q = 0; q < kRowsPer; ++q) {
+    const int a = blockIdx.y * kT + r0 + kRowStep * q;
+    if (a >= npad || b >= npad || a / 16 < b / 16) continue;
+    double v = a == b ? 1.0 : 0.0;
+    if (a < nn && b < nn) {
+      v = -gsum[q];
+      if (a / ne.B == b / ne.B) {
+        const int cam = a / ne.B;
+        double h = ne.A[((long long)cam * ne.B + a % ne.B) * ne.B + b % ne.B];
+        if (a == b) h += lambda * (h > 0.0 ? h : 1.0);
+        v += h;
+      }
+    }
+    const int cc = b % 16;
+    rv.Simg[rcs_blk(a / 16, b / 16) + ((cc % 4) * 16 + a % 16) * 4 + cc / 4] = v;
+  }
+}
+
+// the pivot wavefront of k_rcs_factor (its own function: the register allocation of the 16-column chain is then independent of the
+// row-owning wavefronts' 18 resident blocks)
+__device__ __forceinline__ void rcs_pivot_role(RcsView rv, int c0, int nc, int* __restrict__ fail, double* __restrict__ Dm,
+                                                         double* __restrict__ Xb, double* __restrict__ rdb) {
+  const int lane = threadIdx.x & 63;
+  for (int k = 0; k < nc; ++k) {
+    if (k == 0) lds_barrier();                                     // B0: block (0, 0) staged
+    double a[16], x[16], rd[16];
+    // (the row index is made opaque per step: otherwise the sixteen identity values and the row's LDS addresses are hoisted out of the
+    // loop and live -- or spilled -- across the whole chain.  The entries of a above the diagonal are never read by the lower ones.)
+    int lr = lane & 15;
+    asm volatile("" : "+v"(lr));
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      a[j] = Dm[lr * 17 + j];
+      x[j] = j == lr ? 1.0 : 0.0;
+    }
+    rcs_ldl16(a, x, rd, lane, fail);
+    if (lane < 16) {                                               // lane c holds column c of X = L^-1: img(X^T)[(lr', lk')][s] = X[lr'][lk' + 4s]
+#pragma unroll
+      for (int j = 0; j < 16; ++j) Xb[((lane & 3) * 16 + j) * 4 + (lane >> 2)] = x[j];
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) rdb[j] = rd[j];
+    }
+    lds_barrier();                                                 // b1: X_k, 1/d_k
+    // (off the chain) the factor of this block for the kernels that follow
+    rcs_store(rv.Simg + rcs_blk(c0 + k, c0 + k) + lane * 4, rcs_load(Xb + lane * 4));
+    if (lane < 16) rv.Tsc[rcs_blk(c0 + k, c0 + k) + lane] = rdb[lane];
+    lds_barrier();                                                 // b2: panel k
+    if (k + 1 < nc) lds_barrier();                                 // b3: block (k + 1, k + 1)
+  }
+}
+
+// One super-panel: block columns c0 .. c0 + nc - 1 of the diagonal super-block and of the right-hand-side row.
+// Wavefront w < 10 owns the local block row w (row nc = the right-hand side) -- its <= 9 blocks stay in registers from the load to the
+// last update; wavefront 10 factorises the diagonal blocks (the pivot chain) and is handed block (k + 1, k + 1) as soon as its owner has
+// applied panel k to it: the other updates of panel k run beside the chain.  Eleven wavefronts = three per SIMD, <= 168 registers each
+// (with two row blocks per wavefront and 256 registers the compiler's scheduler let the pivot chain's pressure grow until it spilled).
+__global__ __launch_bounds__(kRcsFactorThreads) void k_rcs_factor(RcsView rv, int c0, int* __restrict__ fail) {
+  __shared__ double Dm[16 * 17];
+  __shared__ __attribute__((aligned(32))) double Xb[256];
+  __shared__ double rdb[16];
+  __shared__ __attribute__((aligned(32))) double panel[(kRcsSP + 1) * 256];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lr = lane & 15, lk = lane >> 4;
+  const int nc = min(kRcsSP, rv.nbk - c0), R = rv.nbk;
+  if (wave == kRcsSP + 1) {
+    rcs_pivot_role(rv, c0, nc, fail, Dm, Xb, rdb);
+    return;
+  }
+  const int il = wave;                                               // local block row; il == nc: the right-hand side
+  const bool has = il <= nc, isR = il == nc;
+  const int gi = isR ? R : c0 + il;
+  bcr_d4 sl[kRcsSP];
+  const bcr_d4 zero{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int jl = 0; jl < kRcsSP; ++jl) sl[jl] = (has && jl < nc && (isR || jl <= il)) ? rcs_load(rv.Simg + rcs_blk(gi, c0 + jl) + lane * 4) : zero;
+  if (wave == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Dm[(lk + 4 * r) * 17 + lr] = sl[0][r];
+  }
+  lds_barrier();                                                     // B0
+#pragma unroll
+  for (int k = 0; k < kRcsSP; ++k) {
+    if (k < nc) {
+      lds_barrier();                                                 // b1
+      const bool act = has && il > k;                                // (the right-hand side: il = nc > k)
+      bcr_d4 sc = zero;
+      if (act) {
+        const bcr_d4 xi = rcs_load(Xb + lane * 4);
+        const bcr_d4 t = rcs_mma(xi, sl[k], zero);
+        sl[k] = t;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sc[r] = -rdb[lk + 4 * r] * t[r];
+        rcs_store(panel + il * 256 + lane * 4, t);
+        rcs_store(rv.Simg + rcs_blk(gi, c0 + k) + lane * 4, t);
+        rcs_store(rv.Tsc + rcs_blk(gi, c0 + k) + lane * 4, sc);
+      }
+      lds_barrier();                                                 // b2
+      const int kn = k + 1 < kRcsSP ? k + 1 : 0;                     // (k + 1 < nc <= kRcsSP when used; the clamp keeps the unrolled index static)
+      const bool owner = act && il == k + 1 && !isR;                 // this row's diagonal block is the next pivot block
+      if (k + 1 < nc) {
+        if (owner) {
+          sl[kn] = rcs_mma(sl[k], sc, sl[kn]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) Dm[(lk + 4 * r) * 17 + lr] = sl[kn][r];
+        }
+        lds_barrier();                                               // b3
+      }
+#pragma unroll
+      for (int jl = k + 1; jl < kRcsSP; ++jl) {
+        if (jl >= nc) continue;
+        if (act && (isR || jl <= il) && !(owner && jl == k + 1)) sl[jl] = rcs_mma(rcs_load(panel + jl * 256 + lane * 4), sc, sl[jl]);
+      }
+    }
+  }
+}
+
+// LDS staging of one factorised diagonal super-block for the kernels that apply it: img(X_k^T) (nc blocks), 1/d (nc x 16), the
+// raw images T_jk, j > k (nc (nc - 1) / 2 blocks at tri(j, k)).  Every wavefront copies whole blocks, 32 bytes per lane.
+__host__ __device__ inline int rcs_stage_doubles(int nc) { return nc * 256 + nc * 16 + nc * (nc - 1) / 2 * 256; }
+__device__ __forceinline__ int rcs_tri(int j, int k) { return j * (j - 1) / 2 + k; }
+__device__ __forceinline__ void rcs_stage(const RcsView& rv, int c0, int nc, double* __restrict__ st, int lane, int wave, int nwaves) {
+  double* rds = st + nc * 256;
+  double* ts = rds + nc * 16;
+  const int nblk = nc + nc * (nc - 1) / 2;
+  for (int t = wave; t < nblk; t += nwaves) {
+    if (t < nc) {
+      rcs_store(st + t * 256 + lane * 4, rcs_load(rv.Simg + rcs_blk(c0 + t, c0 + t) + lane * 4));
+      if (lane < 16) rds[t * 16 + lane] = rv.Tsc[rcs_blk(c0 + t, c0 + t) + lane];
+    } else {
+      const int e = t - nc;
+      int j = 1;
+      while (j * (j + 1) / 2 <= e) ++j;
+      const int k = e - j * (j - 1) / 2;
+      rcs_store(ts + e * 256 + lane * 4, rcs_load(rv.Simg + rcs_blk(c0 + j, c0 + k) + lane * 4));
+    }
+  }
+}
+
+// block rows below the diagonal super-block: T_ik = X_k (U_ik - sum_{k' < k} ...) -- one wavefront per row, nine blocks in registers
+__global__ __launch_bounds__(64 * kRcsTrsmRows) void k_rcs_trsm(RcsView rv, int c0) {
+  extern __shared__ __attribute__((aligned(32))) double rcs_lds[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lk = lane >> 4;
+  const int nc = min(kRcsSP, rv.nbk - c0), c1 = c0 + nc;
+  rcs_stage(rv, c0, nc, rcs_lds, lane, wave, kRcsTrsmRows);
+  const double* rds = rcs_lds + nc * 256;
+  const double* ts = rds + nc * 16;
+  const int gi = c1 + blockIdx.x * kRcsTrsmRows + wave;
+  const bool act = gi < rv.nbk;
+  bcr_d4 s[kRcsSP];
+  const bcr_d4 zero{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int jl = 0; jl < kRcsSP; ++jl) s[jl] = (act && jl < nc) ? rcs_load(rv.Simg + rcs_blk(gi, c0 + jl) + lane * 4) : zero;
+  lds_barrier();
+  if (!act) return;
+#pragma unroll
+  for (int k = 0; k < kRcsSP; ++k) {
+    if (k >= nc) continue;
+    const bcr_d4 t = rcs_mma(rcs_load(rcs_lds + k * 256 + lane * 4), s[k], zero);
+    bcr_d4 sc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sc[r] = -rds[k * 16 + lk + 4 * r] * t[r];
+    rcs_store(rv.Simg + rcs_blk(gi, c0 + k) + lane * 4, t);
+    rcs_store(rv.Tsc + rcs_blk(gi, c0 + k) + lane * 4, sc);
+#pragma unroll
+    for (int jl = k + 1; jl < kRcsSP; ++jl)
+      if (jl < nc) s[jl] = rcs_mma(rcs_load(ts + rcs_tri(jl, k) * 256 + lane * 4), sc, s[jl]);
+  }
+}
+
+// trailing blocks (i, j), c1 <= j <= i <= nbk (i = nbk: the right-hand side): U_ij -= sum_k T_jk^T Delta_k^-1 T_ik, one wavefront each
+__global__ __launch_bounds__(256) void k_rcs_syrk(RcsView rv, int c0) {
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nc = min(kRcsSP, rv.nbk - c0), c1 = c0 + nc, m = rv.nbk - c1;
+  const int t = blockIdx.x * 4 + wave, ntri = m * (m + 1) / 2;
+  if (t >= ntri + m) return;
+  int il, jl;
+  if (t < ntri) {
+    il = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+    while ((il + 1) * (il + 2) / 2 <= t) ++il;
+    while (il * (il + 1) / 2 > t) --il;
+    jl = t - il * (il + 1) / 2;
+  } else { il = m; jl = t - ntri; }
+  const int gi = c1 + il, gj = c1 + jl;                              // (c1 + m = nbk: the right-hand-side row)
+  double* blk = rv.Simg + rcs_blk(gi, gj) + lane * 4;
+  bcr_d4 acc = rcs_load(blk);
+  bcr_d4 pj[kRcsSP], qi[kRcsSP];
+#pragma unroll
+  for (int k = 0; k < kRcsSP; ++k) {
+    if (k >= nc) continue;
+    pj[k] = rcs_load(rv.Simg + rcs_blk(gj, c0 + k) + lane * 4);
+    qi[k] = rcs_load(rv.Tsc + rcs_blk(gi, c0 + k) + lane * 4);
+  }
+#pragma unroll
+  for (int k = 0; k < kRcsSP; ++k)
+    if (k < nc) acc = rcs_mma(pj[k], qi[k], acc);
+  rcs_store(blk, acc);
+}
+
+// x = L^-T Delta^-1 t, super-panels descending, ONE workgroup; pc = -x.  Dynamic LDS: x (npad) | u (9 x 16) | partial sums of the four
+// wavefronts (4 x 9 x 16) | the staged factor of the current super-panel (rcs_stage_doubles(9)).
+__host__ __device__ inline int rcs_backsub_doubles(int nbk) { return nbk * 16 + 5 * kRcsSP * 16 + rcs_stage_doubles(kRcsSP); }
+__global__ __launch_bounds__(256) void k_rcs_backsub(RcsView rv, double* __restrict__ pc) {
+  extern __shared__ __attribute__((aligned(32))) double rcs_lds[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lr = lane & 15, lk = lane >> 4;
+  const int nbk = rv.nbk, R = nbk;
+  double* xs = rcs_lds;
+  double* u = xs + nbk * 16;
+  double* up = u + kRcsSP * 16;
+  double* st = up + 4 * kRcsSP * 16;
+  const int nsp = (nbk + kRcsSP - 1) / kRcsSP;
+  for (int K = nsp - 1; K >= 0; --K) {
+    const int c0 = K * kRcsSP, nc = min(kRcsSP, nbk - c0), c1 = c0 + nc;
+    lds_barrier();                                                   // (the previous super-panel's readers of st are done)
+    rcs_stage(rv, c0, nc, st, lane, wave, 4);
+    const double* rds = st + nc * 256;
+    const double* ts = rds + nc * 16;
+    for (int e = lane; e < nc * 16; e += 64) up[wave * kRcsSP * 16 + e] = 0.0;
+    lds_wave_sync();
+    // blocks below the super-panel: u_jl -= T_{i, c0 + jl} x_i, every wavefront its share, partial sums per wavefront
+    const int nitem = (nbk - c1) * nc;
+    for (int it = wave; it < nitem; it += 4) {
+      const int i = c1 + it / nc, jl = it % nc;
+      const bcr_d4 y = rcs_matvec(rcs_load(rv.Simg + rcs_blk(i, c0 + jl) + lane * 4), xs[i * 16 + lr]);
+      if (lr == 15) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) up[wave * kRcsSP * 16 + jl * 16 + lk + 4 * r] += y[r];
+      }
+    }
+    lds_barrier();
+    if (threadIdx.x < nc * 16) {
+      const int jl = threadIdx.x / 16, row = threadIdx.x % 16;
+      double v = rv.Simg[rcs_blk(R, c0 + jl) + ((row & 3) * 16) * 4 + (row >> 2)];          // column 0 of T_R,jl
+#pragma unroll
+      for (int w = 0; w < 4; ++w) v -= up[w * kRcsSP * 16 + threadIdx.x];
+      u[threadIdx.x] = v;
+    }
+    lds_barrier();
+    for (int k = nc - 1; k >= 0; --k) {
+      if (wave == 0) {
+        const bcr_d4 y = rcs_matvec(rcs_load(st + k * 256 + lane * 4), rds[k * 16 + lr] * u[k * 16 + lr]);
+        if (lr == 15) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) xs[(c0 + k) * 16 + lk + 4 * r] = y[r];
+        }
+      }
+      lds_barrier();
+      for (int jl = wave; jl < k; jl += 4) {
+        const bcr_d4 y = rcs_matvec(rcs_load(ts + rcs_tri(k, jl) * 256 + lane * 4), xs[(c0 + k) * 16 + lr]);
+        if (lr == 15) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) u[jl * 16 + lk + 4 * r] -= y[r];
+        }
+      }
+      lds_barrier();
+    }
+  }
+  for (int a = threadIdx.x; a < rv.nn; a += 256) pc[a] = -xs[a];
+}
+
+}  // namespace mvus

@@ -112,8 +112,6 @@ __global__ __launch_bounds__(kGaThreads) void k_assemble_spans(DevProblem dp, co
   const long long i0 = dp.chunk_start[chunk] + half * kGaObs;
   const long long a0 = dp.det_off[c], Mc = dp.det_off[c + 1] - a0;
   const int tid = threadIdx.x;
-#define MVUS_TP() ((void)0)
-  MVUS_TP();
   if (tid == 0) { any_s = 0; sort_s = 0; nr_s = 0; }
   const int t = tid & (kGaObs - 1);                    // detection handled while staging
   constexpr int kRowsPer = (2 * NS + 2 + 3) / 4;
@@ -160,7 +158,6 @@ __global__ __launch_bounds__(kGaThreads) void k_assemble_spans(DevProblem dp, co
   }
   lds_barrier();
   if (FUSED) kt = key[t];                                // the key of column t, for the threads that did not evaluate it
-  MVUS_TP();   // 1: staged
   if (tid < kGaObs) {
     if (g >= 0) any_s = 1;
     if (tid > 0 && kt < key[tid - 1]) sort_s = 1;
@@ -256,7 +253,6 @@ __global__ __launch_bounds__(kGaThreads) void k_assemble_spans(DevProblem dp, co
           mine[ra * (ra + 1) / 2 + rb] = cacc[i][j][r];              // plain stores: no contention on the camera's few lines
         }
   }
-  MVUS_TP();   // 2: ranges (+ camera block on the last wavefront)
   const bool fast = nr <= kGaMaxR;                        // uniform
   // one register file for both roles -- E role: EA(q, k) cross block + gradient (k = B) of (range, d);
   // C role: CA(qa, w, d2) band blocks (w = qb - qa), row coordinate d
@@ -334,9 +330,7 @@ __global__ __launch_bounds__(kGaThreads) void k_assemble_spans(DevProblem dp, co
     }
   }
   if (!fast) return;
-  MVUS_TP();   // 3: accumulated
   lds_barrier();                                        // every thread holds its partials in registers: Js is dead
-  MVUS_TP();   // 4: everybody accumulated
   // ---- owner tables of ALL flush rounds, built once ----------------------------------------------------------------
   // A round covers kRb consecutive ranges (as many per-range partial blocks as fit the dead staging LDS).  Inside a round a
   // control point is owned by the first range that reaches it: range t owns its last min(4, rg[t] - rg[t-1]) points (all four
@@ -409,7 +403,6 @@ __global__ __launch_bounds__(kGaThreads) void k_assemble_spans(DevProblem dp, co
     }
     lds_barrier();
   }
-  MVUS_TP();   // 5: cross block flushed
   // ---- flush of the spline band: Cp[rl][pair (qa, w)][3][3], pair = 4 qa - qa (qa - 1) / 2 + w ----
   for (int r0 = 0, rho = 0; r0 < nr; r0 += kRb, ++rho) {
     const int nb = min(kRb, nr - r0);
@@ -442,7 +435,6 @@ __global__ __launch_bounds__(kGaThreads) void k_assemble_spans(DevProblem dp, co
   }
 #undef EA
 #undef CA
-  MVUS_TP();   // 6: band flushed
 }
 
 __device__ __forceinline__ void lds_wave_sync() {      // orders the LDS traffic of ONE wavefront (writes of some lanes read by others)
@@ -2221,6 +2213,10 @@ __global__ __launch_bounds__(kGjThreads) void k_gj_step(int nn, int kb, const do
   if (threadIdx.x < 64) pivot_inverse_wave(Ai, &Q[0][0], Pinv + (long long)(base / kNB) * kNB * kNB, fail);
 }
 
+}  // namespace mvus
+#include "ba_rcs.hip.h"
+namespace mvus {
+
 // p (x order) from p_c and p_s = -(z_g + Z_E p_c)
 __global__ __launch_bounds__(kThreads) void k_back_substitute(DevProblem dp, NEView ne, int ncols, int row_lo, int row_hi, int cams,
                                                               const double* __restrict__ Z, const double* __restrict__ pc, double* __restrict__ px,
@@ -2252,6 +2248,8 @@ struct HipSchur {
   double *Erm = nullptr;
   double *NE = nullptr, *Lb = nullptr, *Z = nullptr, *G = nullptr, *G0 = nullptr, *S = nullptr, *S2 = nullptr, *Linv = nullptr, *rhs = nullptr, *pc = nullptr,
          *DG = nullptr, *D = nullptr, *gx = nullptr, *px = nullptr, *sepbuf = nullptr;
+  RcsView rcs{};            // reduced camera system in block-image form (ba_rcs.hip.h)
+  bool use_rcs = true;      // MVUS_RCS=gj: the block Gauss-Jordan of rounds 1-4 (A/B)
   int* fail = nullptr;      // [0] numerical failure of a solve, [1] a row reached outside the slice (assembly)
   int* fail_host = nullptr;
   int* fail_map = nullptr;  // device address of fail_host (mapped pinned)
@@ -2355,6 +2353,11 @@ struct HipSchur {
     rhs = be.alloc(ne.CB); pc = be.alloc(ne.CB);
     S2 = be.alloc((size_t)(ne.CB + 1) * ne.CB);
     Linv = be.alloc((size_t)((ne.CB + kNB - 1) / kNB) * kNB * kNB);
+    rcs.nn = ne.CB; rcs.nbk = (ne.CB + 15) / 16;
+    rcs.Simg = be.alloc(rcs_doubles(ne.CB)); rcs.Tsc = be.alloc(rcs_doubles(ne.CB));
+    { const char* e = std::getenv("MVUS_RCS"); use_rcs = !(e && std::strcmp(e, "gj") == 0); }
+    MVUS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rcs_trsm), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(rcs_stage_doubles(kRcsSP) * sizeof(double))));
+    MVUS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rcs_backsub), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(rcs_backsub_doubles(rcs.nbk) * sizeof(double))));
     if (shard) { DG = nullptr; D = NE + nAg + halo_count; gx = D + hp.n; }
     else { DG = be.alloc(2 * (size_t)hp.n); D = DG; gx = DG + hp.n; }
     px = be.alloc(hp.n + 2);                         // + the two failure flags of a time shard
@@ -2503,7 +2506,7 @@ struct HipSchur {
     else MVUS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_assemble_windows<9>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)win_lds));
   }
   ~HipSchur() {
-    for (double* p : {Erm, NE, Lb, Z, G, G0, S, S2, Linv, rhs, pc, DG, px, pv.VW, sepbuf, pv.U2, pv.Ha, pv.Hc, wv.Apart}) if (p) be.release(p);
+    for (double* p : {Erm, NE, Lb, Z, G, G0, S, S2, Linv, rhs, pc, DG, px, pv.VW, sepbuf, pv.U2, pv.Ha, pv.Hc, wv.Apart, rcs.Simg, rcs.Tsc}) if (p) be.release(p);
     if (win_tables) (void)hipFree(win_tables);
     if (part_tables) (void)hipFree(part_tables);
     if (halo_tables) (void)hipFree(halo_tables);
@@ -2698,15 +2701,30 @@ struct HipSchur {
       hipLaunchKernelGGL(k_schur_gemm, dim3(8 * (nbk * (nbk + 1) / 2 + nbk) * ((nslab + 7) / 8)), dim3(256), 0, be.stream, ne, ncols, row_lo, row_hi, nslab, Erm, Z, G);
     }
     const int ntile = (ne.CB + kNB - 1) / kNB;
+    const double* Gsum = G;
+    int nsl = nslab;
     if (shard) {
       const long long cnt = (long long)ne.CB * ncols;
       hipLaunchKernelGGL(k_sum_slabs, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, be.stream, cnt, nslab, G, G0);
       be.reduce(G0, (size_t)cnt);                   // the Schur complement contributions of all time slices
-      hipLaunchKernelGGL(k_schur_finish, dim3(ntile, ntile), dim3(kFinThreads), 0, be.stream, ne, ncols, 1, lambda, G0, S, Linv, fail);
-    } else {
-      hipLaunchKernelGGL(k_schur_finish, dim3(ntile, ntile), dim3(kFinThreads), 0, be.stream, ne, ncols, nslab, lambda, G, S, Linv, fail);
+      Gsum = G0; nsl = 1;
     }
-    {
+    if (use_rcs) {
+      // blocked L D L^T in block-image form (ba_rcs.hip.h): per super-panel of 144 unknowns one factor launch (one workgroup, the pivot
+      // chain inside one CU), the rows below, the trailing blocks; one descending substitution at the end
+      const int nbk = rcs.nbk, nt = (16 * nbk + 31) / 32;
+      hipLaunchKernelGGL(k_rcs_finish, dim3(nt, nt + 1), dim3(256), 0, be.stream, ne, ncols, nsl, lambda, Gsum, rcs);
+      for (int c0 = 0; c0 < nbk; c0 += kRcsSP) {
+        const int nc = std::min(kRcsSP, nbk - c0), c1 = c0 + nc, m = nbk - c1;
+        hipLaunchKernelGGL(k_rcs_factor, dim3(1), dim3(kRcsFactorThreads), 0, be.stream, rcs, c0, fail);
+        if (m > 0) {
+          hipLaunchKernelGGL(k_rcs_trsm, dim3((m + kRcsTrsmRows - 1) / kRcsTrsmRows), dim3(64 * kRcsTrsmRows), rcs_stage_doubles(nc) * sizeof(double), be.stream, rcs, c0);
+          hipLaunchKernelGGL(k_rcs_syrk, dim3((m * (m + 1) / 2 + m + 3) / 4), dim3(256), 0, be.stream, rcs, c0);
+        }
+      }
+      hipLaunchKernelGGL(k_rcs_backsub, dim3(1), dim3(256), rcs_backsub_doubles(nbk) * sizeof(double), be.stream, rcs, pc);
+    } else {
+      hipLaunchKernelGGL(k_schur_finish, dim3(ntile, ntile), dim3(kFinThreads), 0, be.stream, ne, ncols, nsl, lambda, Gsum, S, Linv, fail);
       const int nn = ne.CB;
       double* a = S;
       double* b = S2;
