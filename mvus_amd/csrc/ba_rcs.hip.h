@@ -29,11 +29,12 @@ namespace mvus {
 
 constexpr int kRcsSP = 9;                   // 16-column blocks per super-panel
 constexpr int kRcsFactorThreads = 64 * (kRcsSP + 2);      // ten row-owning wavefronts (nine block rows + the right-hand side) + the pivot wavefront
-constexpr int kRcsTrsmRows = 4;             // block rows (wavefronts) per workgroup of k_rcs_trsm
+constexpr int kRcsTrsmWaves = 4;            // wavefronts per block row (= workgroup) of k_rcs_trsm
 
 struct RcsView {
   double* Simg;      // block images: U_ij, overwritten by T_ik (i > k) and by img(X_k^T) on the diagonal
   double* Tsc;       // -Delta_k^-1 T_ik images; diagonal block (k, k): 1/d of the 16 pivots in its first 16 doubles
+  double* x;         // the solution, 16 nbk doubles (padding rows: 0)
   int nn, nbk;       // unknowns, 16-blocks (the right-hand side is block row nbk)
 };
 
@@ -46,6 +47,18 @@ __device__ __forceinline__ bcr_d4 rcs_mma(bcr_d4 p, bcr_d4 q, bcr_d4 acc) {
 #pragma unroll
   for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(p[s], q[s], acc, 0, 0, 0);
   return acc;
+}
+// the same product as FOUR independent matrix-core instructions and three vector adds.  A v_mfma_f64_16x16x4 that accumulates
+// into the result of the previous one waits for it: measured on this part ~250 cycles per link of such a chain (the trsm kernel's
+// nine steps of 2 + 4 dependent instructions took 32 k cycles), against ~110 cycles of issue for independent ones.  Every product on
+// a critical path is therefore formed this way; the order of the four partial sums differs from rcs_mma's.
+__device__ __forceinline__ bcr_d4 rcs_mma4(bcr_d4 p, bcr_d4 q, bcr_d4 acc) {
+  const bcr_d4 zero{0.0, 0.0, 0.0, 0.0};
+  const bcr_d4 a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(p[0], q[0], acc, 0, 0, 0);
+  const bcr_d4 a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(p[1], q[1], zero, 0, 0, 0);
+  const bcr_d4 a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(p[2], q[2], zero, 0, 0, 0);
+  const bcr_d4 a3 = __builtin_amdgcn_mfma_f64_16x16x4f64(p[3], q[3], zero, 0, 0, 0);
+  return (a0 + a1) + (a2 + a3);
 }
 // y = M w from img(M) and w[lr] (the value of this lane's column): the sums over the 16 lanes of a row by DPP row shifts;
 // lane lr == 15 of row lk ends with y[lk + 4r] in out[r]
@@ -72,8 +85,15 @@ __device__ __forceinline__ bcr_d4 rcs_matvec(bcr_d4 img, double w) {
 // columns, postpones the x updates, and spills the multipliers it keeps for them (256 registers and 300 - 700 bytes of scratch per
 // lane inside the chain).
 struct RcsPivotChain { double d, r, e; bool bad; };
+// lane J's value to every lane of the 16-lane row, as two v_mov_b32_dpp with an UNDEFINED old value (llvm.amdgcn.mov.dpp): the 64-bit
+// form the generic builtin produces (v_mov_b64_dpp, tied to its old operand) costs a register copy and two wait states per broadcast
+template <int J> __device__ __forceinline__ double rcs_bcast(double v) {
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x150 + J, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x150 + J, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
 template <int STAGE, int J> __device__ __forceinline__ void rcs_chain_stage(RcsPivotChain& c, const double (&a)[16]) {
-  if constexpr (STAGE == 0) { double d = row_bcast<J>(a[J]); c.bad |= !(d > 0.0); c.d = d > 0.0 ? d : 1.0; }
+  if constexpr (STAGE == 0) { double d = rcs_bcast<J>(a[J]); c.bad |= !(d > 0.0); c.d = d > 0.0 ? d : 1.0; }
   else if constexpr (STAGE == 1) c.r = __builtin_amdgcn_rcp(c.d);
   else if constexpr (STAGE == 2 || STAGE == 4) c.e = 2.0 - c.d * c.r;
   else if constexpr (STAGE == 3 || STAGE == 5) c.r = c.r * c.e;
@@ -84,17 +104,20 @@ template <int FROM, int KN> struct RcsChainRest {      // the stages that found 
   }
 };
 template <int K, int J> struct RcsColOps {
-  static __device__ __forceinline__ void run(double (&a)[16], double (&x)[16], double ta, double tx, RcsPivotChain& c) {
+  // m: the multiplier of THIS pair, broadcast while the previous pair's FMAs were issued (a dependent VALU instruction waits for
+  // its operand: with the two DPP moves directly in front of the FMAs that use them every pair cost ~32 cycles instead of ~16)
+  static __device__ __forceinline__ void run(double (&a)[16], double (&x)[16], double ta, double tx, double m, RcsPivotChain& c) {
     if constexpr (J < 16) {
-      const double m = row_bcast<J>(a[K]);
+      double mn = 0.0;
+      if constexpr (J + 1 < 16) mn = rcs_bcast<J + 1>(a[K]);
       a[J] -= ta * m;
       x[J] -= tx * m;
       rcs_chain_stage<J - (K + 1), K + 1>(c, a);
       // (scheduling barriers order machine instructions only; the empty asm makes the pair's results exist HERE in the instruction
       // selector's order too -- without it the x updates sink to the end of the block and their multipliers go to scratch)
-      asm volatile("" : "+v"(a[J]), "+v"(x[J]), "+v"(c.d), "+v"(c.r), "+v"(c.e));
+      asm volatile("" : "+v"(a[J]), "+v"(x[J]), "+v"(c.d), "+v"(c.r), "+v"(c.e), "+v"(mn));
       __builtin_amdgcn_sched_barrier(0);
-      RcsColOps<K, J + 1>::run(a, x, ta, tx, c);
+      RcsColOps<K, J + 1>::run(a, x, ta, tx, mn, c);
     }
   }
 };
@@ -103,8 +126,9 @@ template <int K> struct RcsCols {
     const double r = c.r;
     rd[K] = r;
     if constexpr (K + 1 < 16) {
+      const double m0 = rcs_bcast<K + 1>(a[K]);
       const double ta = a[K] * r, tx = x[K] * r;
-      RcsColOps<K, K + 1>::run(a, x, ta, tx, c);
+      RcsColOps<K, K + 1>::run(a, x, ta, tx, m0, c);
       RcsChainRest<(15 - K < 6 ? 15 - K : 6), K + 1>::run(c, a);
       __builtin_amdgcn_sched_barrier(0);
       RcsCols<K + 1>::run(a, x, rd, c);
@@ -185,11 +209,36 @@ __global__ __launch_bounds__(256) void k_rcs_finish(NEView ne, int ncols, int ns
   }
 }
 
-// the pivot wavefront of k_rcs_factor (its own function: the register allocation of the 16-column chain is then independent of the
-// row-owning wavefronts' 18 resident blocks)
-__device__ __forceinline__ void rcs_pivot_role(RcsView rv, int c0, int nc, int* __restrict__ fail, double* __restrict__ Dm,
-                                                         double* __restrict__ Xb, double* __restrict__ rdb) {
+// x_i[c] = sum_j X[j][c] w[j] for lane c of a 16-lane row (col: the lane's column of X, 16 contiguous doubles in LDS; w: this lane's
+// entry of w, handed round by DPP row broadcasts)
+template <int J> struct RcsXtTimes {
+  static __device__ __forceinline__ double run(const double* __restrict__ col, double w, double acc) {
+    if constexpr (J < 16) return RcsXtTimes<J + 1>::run(col, w, acc + col[J] * rcs_bcast<J>(w));
+    else return acc;
+  }
+};
+__device__ __forceinline__ double rcs_xt_times(const double* __restrict__ col, double w) { return RcsXtTimes<0>::run(col, w, 0.0); }
+// part = T_ik x_i for the block k of a row's register-resident blocks (k is wavefront-uniform but not a compile-time constant: the
+// nine-way selection is a scalar branch)
+__device__ __forceinline__ void rcs_part_product(const bcr_d4 (&sl)[kRcsSP], int k, const double* __restrict__ xi, double* __restrict__ out, int lr, int lk) {
+  const double xv = xi[lr];
+#pragma unroll
+  for (int kk = 0; kk < kRcsSP; ++kk) {
+    if (kk != k) continue;
+    const bcr_d4 y = rcs_matvec(sl[kk], xv);
+    if (lr == 15) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) out[lk + 4 * r] = y[r];
+    }
+  }
+}
+
+// the pivot wavefront of k_rcs_factor.  Nothing but LDS traffic inside the chain: img(X_k^T) and 1/d_k of every step stay in LDS
+// (Xb, rdb: one copy per step) and go to global memory after the last step -- a vector-memory store inside the loop costs every later
+// s_waitcnt vmcnt a store acknowledgement (stores and loads share the counter on this part).
+__device__ __forceinline__ void rcs_pivot_role(int nc, int* __restrict__ fail, double* __restrict__ Dm, double* __restrict__ Xb, double* __restrict__ rdb) {
   const int lane = threadIdx.x & 63;
+  __builtin_amdgcn_s_setprio(3);                                   // the chain's instructions go first on this SIMD
   for (int k = 0; k < nc; ++k) {
     if (k == 0) lds_barrier();                                     // B0: block (0, 0) staged
     double a[16], x[16], rd[16];
@@ -203,20 +252,18 @@ __device__ __forceinline__ void rcs_pivot_role(RcsView rv, int c0, int nc, int* 
       x[j] = j == lr ? 1.0 : 0.0;
     }
     rcs_ldl16(a, x, rd, lane, fail);
-    if (lane < 16) {                                               // lane c holds column c of X = L^-1: img(X^T)[(lr', lk')][s] = X[lr'][lk' + 4s]
+    // lane c holds column c of X = L^-1 (x[j] = X[j][c]) and all sixteen 1/d: Xb[k] is X column-major (Xb[c * 16 + j] = X[j][c]) --
+    // four 32-byte stores per lane of the first row instead of sixteen scattered 8-byte ones
+    if (lane < 16) {
 #pragma unroll
-      for (int j = 0; j < 16; ++j) Xb[((lane & 3) * 16 + j) * 4 + (lane >> 2)] = x[j];
+      for (int q = 0; q < 4; ++q) rcs_store(Xb + k * 256 + lane * 16 + 4 * q, bcr_d4{x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]});
     }
     if (lane == 0) {
 #pragma unroll
-      for (int j = 0; j < 16; ++j) rdb[j] = rd[j];
+      for (int q = 0; q < 4; ++q) rcs_store(rdb + k * 16 + 4 * q, bcr_d4{rd[4 * q], rd[4 * q + 1], rd[4 * q + 2], rd[4 * q + 3]});
     }
     lds_barrier();                                                 // b1: X_k, 1/d_k
-    // (off the chain) the factor of this block for the kernels that follow
-    rcs_store(rv.Simg + rcs_blk(c0 + k, c0 + k) + lane * 4, rcs_load(Xb + lane * 4));
-    if (lane < 16) rv.Tsc[rcs_blk(c0 + k, c0 + k) + lane] = rdb[lane];
-    lds_barrier();                                                 // b2: panel k
-    if (k + 1 < nc) lds_barrier();                                 // b3: block (k + 1, k + 1)
+    lds_barrier();                                                 // b2: panel k and block (k + 1, k + 1)
   }
 }
 
@@ -225,15 +272,50 @@ __device__ __forceinline__ void rcs_pivot_role(RcsView rv, int c0, int nc, int* 
 // last update; wavefront 10 factorises the diagonal blocks (the pivot chain) and is handed block (k + 1, k + 1) as soon as its owner has
 // applied panel k to it: the other updates of panel k run beside the chain.  Eleven wavefronts = three per SIMD, <= 168 registers each
 // (with two row blocks per wavefront and 256 registers the compiler's scheduler let the pivot chain's pressure grow until it spilled).
-__global__ __launch_bounds__(kRcsFactorThreads) void k_rcs_factor(RcsView rv, int c0, int* __restrict__ fail) {
+__global__ __launch_bounds__(kRcsFactorThreads) void k_rcs_factor(RcsView rv, int c0, int* __restrict__ fail, int last, double* __restrict__ pc) {
   __shared__ double Dm[16 * 17];
-  __shared__ __attribute__((aligned(32))) double Xb[256];
-  __shared__ double rdb[16];
+  __shared__ __attribute__((aligned(32))) double Xb[kRcsSP * 256];
+  __shared__ __attribute__((aligned(32))) double rdb[kRcsSP * 16];
   __shared__ __attribute__((aligned(32))) double panel[(kRcsSP + 1) * 256];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lr = lane & 15, lk = lane >> 4;
   const int nc = min(kRcsSP, rv.nbk - c0), R = rv.nbk;
+  __shared__ double u0[kRcsSP * 16];                                 // t_k = column 0 of T_R,k
+  __shared__ double part[kRcsSP * kRcsSP * 16];                      // part[i][k] = T_ik x_i
+  __shared__ double xs[kRcsSP * 16];
   if (wave == kRcsSP + 1) {
-    rcs_pivot_role(rv, c0, nc, fail, Dm, Xb, rdb);
+    rcs_pivot_role(nc, fail, Dm, Xb, rdb);
+    // the factors of the diagonal blocks, for the kernels that follow
+    if (!last || c0 > 0)
+      for (int k = 0; k < nc; ++k) {
+        bcr_d4 xi;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xi[r] = Xb[k * 256 + (lk + 4 * r) * 16 + lr];
+        rcs_store(rv.Simg + rcs_blk(c0 + k, c0 + k) + lane * 4, xi);
+        if (lane < 16) rv.Tsc[rcs_blk(c0 + k, c0 + k) + lane] = rdb[k * 16 + lane];
+      }
+    if (!last) return;
+    __builtin_amdgcn_s_setprio(0);
+    // ---- back substitution of this (the last) super-panel, pivot wavefront's part: x_i = X_i^T Delta_i^-1 (t_i - sum_{i' > i} T_i'i x_i')
+    lds_barrier();                                                   // S0: t in u0
+    for (int i = nc - 1; i >= 0; --i) {
+      double xi = 0.0;
+      if (lane < 16) {
+        double w = u0[i * 16 + lane];
+        for (int ip = i + 1; ip < nc; ++ip) w -= part[(ip * kRcsSP + i) * 16 + lane];      // fixed order: the same bits every run
+        w *= rdb[i * 16 + lane];
+        xi = rcs_xt_times(Xb + i * 256 + lane * 16, w);
+        xs[i * 16 + lane] = xi;
+      }
+      lds_barrier();                                                 // A_i: x_i
+      lds_barrier();                                                 // B_i: part[i][i - 1] (and the deferred products of the rows above)
+    }
+    if (lane < 16)
+      for (int k = 0; k < nc; ++k) {
+        const int a = (c0 + k) * 16 + lane;
+        const double v = xs[k * 16 + lane];
+        rv.x[a] = v;
+        if (a < rv.nn) pc[a] = -v;
+      }
     return;
   }
   const int il = wave;                                               // local block row; il == nc: the right-hand side
@@ -253,34 +335,80 @@ __global__ __launch_bounds__(kRcsFactorThreads) void k_rcs_factor(RcsView rv, in
     if (k < nc) {
       lds_barrier();                                                 // b1
       const bool act = has && il > k;                                // (the right-hand side: il = nc > k)
+      const bool owner = act && il == k + 1 && !isR && k + 1 < nc;   // this row's diagonal block is the next pivot block
+      if (owner) __builtin_amdgcn_s_setprio(2);                      // its two products are the chain: ahead of the other rows' on this SIMD
       bcr_d4 sc = zero;
       if (act) {
-        const bcr_d4 xi = rcs_load(Xb + lane * 4);
-        const bcr_d4 t = rcs_mma(xi, sl[k], zero);
+        bcr_d4 xi;                                                   // img(X_k^T)[lane][s] = X_k[lr][lk + 4s]; Xb holds X column-major
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xi[r] = Xb[k * 256 + (lk + 4 * r) * 16 + lr];
+        const bcr_d4 t = rcs_mma4(xi, sl[k], zero);
         sl[k] = t;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) sc[r] = -rdb[lk + 4 * r] * t[r];
+        for (int r = 0; r < 4; ++r) sc[r] = -rdb[k * 16 + lk + 4 * r] * t[r];
         rcs_store(panel + il * 256 + lane * 4, t);
-        rcs_store(rv.Simg + rcs_blk(gi, c0 + k) + lane * 4, t);
-        rcs_store(rv.Tsc + rcs_blk(gi, c0 + k) + lane * 4, sc);
       }
-      lds_barrier();                                                 // b2
+      // the row whose diagonal block is the next pivot block applies panel k to it at once (its own T_k+1,k is in registers) and
+      // stages it for the pivot wavefront: ONE barrier then publishes both the panel and the next pivot block
       const int kn = k + 1 < kRcsSP ? k + 1 : 0;                     // (k + 1 < nc <= kRcsSP when used; the clamp keeps the unrolled index static)
-      const bool owner = act && il == k + 1 && !isR;                 // this row's diagonal block is the next pivot block
-      if (k + 1 < nc) {
-        if (owner) {
-          sl[kn] = rcs_mma(sl[k], sc, sl[kn]);
+      if (owner) {
+        sl[kn] = rcs_mma4(sl[k], sc, sl[kn]);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) Dm[(lk + 4 * r) * 17 + lr] = sl[kn][r];
-        }
-        lds_barrier();                                               // b3
+        for (int r = 0; r < 4; ++r) Dm[(lk + 4 * r) * 17 + lr] = sl[kn][r];
+        __builtin_amdgcn_s_setprio(0);
       }
+      lds_barrier();                                                 // b2: panel k, block (k + 1, k + 1)
+      {                                                              // the row's remaining blocks: K-slices outer, blocks inner
+        bcr_d4 tj[kRcsSP];
+        bool up[kRcsSP];
 #pragma unroll
-      for (int jl = k + 1; jl < kRcsSP; ++jl) {
-        if (jl >= nc) continue;
-        if (act && (isR || jl <= il) && !(owner && jl == k + 1)) sl[jl] = rcs_mma(rcs_load(panel + jl * 256 + lane * 4), sc, sl[jl]);
+        for (int jl = k + 1; jl < kRcsSP; ++jl) {
+          up[jl] = jl < nc && act && (isR || jl <= il) && !(owner && jl == k + 1);
+          tj[jl] = up[jl] ? rcs_load(panel + jl * 256 + lane * 4) : zero;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int jl = k + 1; jl < kRcsSP; ++jl)
+            if (up[jl]) sl[jl] = __builtin_amdgcn_mfma_f64_16x16x4f64(tj[jl][q], sc[q], sl[jl], 0, 0, 0);
       }
     }
+  }
+  // the row's panel blocks T_il,k (k < il) and their scaled images: stored once, after the chain (a last super-panel that is also the
+  // first has no reader: the substitution below works from the registers)
+  if (has && (!last || c0 > 0)) {
+#pragma unroll
+  for (int k = 0; k < kRcsSP; ++k) {
+    if (k < nc && il > k) {
+      bcr_d4 sc;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sc[r] = -rdb[k * 16 + lk + 4 * r] * sl[k][r];
+      rcs_store(rv.Simg + rcs_blk(gi, c0 + k) + lane * 4, sl[k]);
+      rcs_store(rv.Tsc + rcs_blk(gi, c0 + k) + lane * 4, sc);
+    }
+  }
+  }
+  if (!last) return;
+  // ---- back substitution, the row-owning wavefronts' part.  Row i hands T_ik x_i (k < i) to the pivot wavefront through part[i][k]:
+  // the product for k = i - 1 -- the one the next x needs -- between the two barriers of its own step, the others one per barrier
+  // interval afterwards (k = 2 i' - i in the first interval of step i' < i, k = 2 i' - i - 1 in the second: always a full step before
+  // x_k is formed), so that no interval holds more than one product per wavefront and a step of the chain is two short intervals.
+  if (has && isR && lr == 0) {
+#pragma unroll
+    for (int k = 0; k < kRcsSP; ++k)
+      if (k < nc)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) u0[k * 16 + lk + 4 * r] = sl[k][r];
+  }
+  lds_barrier();                                                     // S0
+  for (int i = nc - 1; i >= 0; --i) {
+    const bool mine = has && !isR && il > i;                         // a row above the current one: deferred products
+    int kd = mine ? 2 * i - il : -1;
+    if (kd >= 0) rcs_part_product(sl, kd, xs + il * 16, part + (il * kRcsSP + kd) * 16, lr, lk);
+    lds_barrier();                                                   // A_i
+    kd = (has && !isR && il == i) ? i - 1 : (mine ? 2 * i - il - 1 : -1);
+    if (kd >= 0) rcs_part_product(sl, kd, xs + il * 16, part + (il * kRcsSP + kd) * 16, lr, lk);
+    lds_barrier();                                                   // B_i
   }
 }
 
@@ -288,52 +416,102 @@ __global__ __launch_bounds__(kRcsFactorThreads) void k_rcs_factor(RcsView rv, in
 // raw images T_jk, j > k (nc (nc - 1) / 2 blocks at tri(j, k)).  Every wavefront copies whole blocks, 32 bytes per lane.
 __host__ __device__ inline int rcs_stage_doubles(int nc) { return nc * 256 + nc * 16 + nc * (nc - 1) / 2 * 256; }
 __device__ __forceinline__ int rcs_tri(int j, int k) { return j * (j - 1) / 2 + k; }
-__device__ __forceinline__ void rcs_stage(const RcsView& rv, int c0, int nc, double* __restrict__ st, int lane, int wave, int nwaves) {
+// (all loads of a wavefront are issued before the first LDS store: one memory round trip, not one per block)
+template <int NWAVES>
+__device__ __forceinline__ void rcs_stage(const RcsView& rv, int c0, int nc, double* __restrict__ st, int lane, int wave) {
+  constexpr int kMaxBlk = kRcsSP + kRcsSP * (kRcsSP - 1) / 2, kPer = (kMaxBlk + NWAVES - 1) / NWAVES;
   double* rds = st + nc * 256;
   double* ts = rds + nc * 16;
   const int nblk = nc + nc * (nc - 1) / 2;
-  for (int t = wave; t < nblk; t += nwaves) {
+  bcr_d4 v[kPer];
+  double rdv[kPer];
+  int dst[kPer];
+#pragma unroll
+  for (int u = 0; u < kPer; ++u) {
+    const int t = wave + NWAVES * u;
+    dst[u] = -1; rdv[u] = 0.0;
     if (t < nc) {
-      rcs_store(st + t * 256 + lane * 4, rcs_load(rv.Simg + rcs_blk(c0 + t, c0 + t) + lane * 4));
-      if (lane < 16) rds[t * 16 + lane] = rv.Tsc[rcs_blk(c0 + t, c0 + t) + lane];
-    } else {
+      v[u] = rcs_load(rv.Simg + rcs_blk(c0 + t, c0 + t) + lane * 4);
+      if (lane < 16) rdv[u] = rv.Tsc[rcs_blk(c0 + t, c0 + t) + lane];
+      dst[u] = t * 256;
+    } else if (t < nblk) {
       const int e = t - nc;
-      int j = 1;
+      int j = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)e)) * 0.5f);
+      while (j * (j - 1) / 2 > e) --j;
       while (j * (j + 1) / 2 <= e) ++j;
       const int k = e - j * (j - 1) / 2;
-      rcs_store(ts + e * 256 + lane * 4, rcs_load(rv.Simg + rcs_blk(c0 + j, c0 + k) + lane * 4));
+      v[u] = rcs_load(rv.Simg + rcs_blk(c0 + j, c0 + k) + lane * 4);
+      dst[u] = (int)(ts - st) + e * 256;
     }
+  }
+#pragma unroll
+  for (int u = 0; u < kPer; ++u) {
+    const int t = wave + NWAVES * u;
+    if (dst[u] >= 0) rcs_store(st + dst[u] + lane * 4, v[u]);
+    if (t < nc && lane < 16) rds[t * 16 + lane] = rdv[u];
   }
 }
 
-// block rows below the diagonal super-block: T_ik = X_k (U_ik - sum_{k' < k} ...) -- one wavefront per row, nine blocks in registers
-__global__ __launch_bounds__(64 * kRcsTrsmRows) void k_rcs_trsm(RcsView rv, int c0) {
+// block rows below the diagonal super-block: T_ik = X_k (U_ik - sum_{k' < k} T_kk'^T Delta_k'^-1 T_ik'), k ascending.  ONE block row per
+// workgroup, four wavefronts = four SIMDs: wavefront w holds the row's blocks of the columns jl = w, w + 4, w + 8.  Step k: the
+// wavefront that holds column k forms T_ik and hands its scaled image to the others through LDS (two buffers, one barrier per step),
+// every wavefront then updates the blocks it holds -- the matrix-core instructions of different blocks interleaved, because a
+// dependent v_mfma_f64_16x16x4 waits ~130 cycles for its accumulator.
+__global__ __launch_bounds__(64 * kRcsTrsmWaves) void k_rcs_trsm(RcsView rv, int c0) {
   extern __shared__ __attribute__((aligned(32))) double rcs_lds[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lk = lane >> 4;
   const int nc = min(kRcsSP, rv.nbk - c0), c1 = c0 + nc;
-  rcs_stage(rv, c0, nc, rcs_lds, lane, wave, kRcsTrsmRows);
+  rcs_stage<kRcsTrsmWaves>(rv, c0, nc, rcs_lds, lane, wave);
   const double* rds = rcs_lds + nc * 256;
   const double* ts = rds + nc * 16;
-  const int gi = c1 + blockIdx.x * kRcsTrsmRows + wave;
-  const bool act = gi < rv.nbk;
-  bcr_d4 s[kRcsSP];
+  double* xch = rcs_lds + rcs_stage_doubles(nc);                     // 2 x 256 doubles
+  const int gi = c1 + blockIdx.x;
+  constexpr int kSlots = (kRcsSP + kRcsTrsmWaves - 1) / kRcsTrsmWaves;
+  bcr_d4 s[kSlots];
   const bcr_d4 zero{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-  for (int jl = 0; jl < kRcsSP; ++jl) s[jl] = (act && jl < nc) ? rcs_load(rv.Simg + rcs_blk(gi, c0 + jl) + lane * 4) : zero;
+  for (int u = 0; u < kSlots; ++u) {
+    const int jl = wave + kRcsTrsmWaves * u;
+    s[u] = jl < nc ? rcs_load(rv.Simg + rcs_blk(gi, c0 + jl) + lane * 4) : zero;
+  }
   lds_barrier();
-  if (!act) return;
 #pragma unroll
   for (int k = 0; k < kRcsSP; ++k) {
     if (k >= nc) continue;
-    const bcr_d4 t = rcs_mma(rcs_load(rcs_lds + k * 256 + lane * 4), s[k], zero);
+    if (wave == k % kRcsTrsmWaves) {
+      const bcr_d4 t = rcs_mma4(rcs_load(rcs_lds + k * 256 + lane * 4), s[k / kRcsTrsmWaves], zero);
+      s[k / kRcsTrsmWaves] = t;
+      bcr_d4 sc;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sc[r] = -rds[k * 16 + lk + 4 * r] * t[r];
+      rcs_store(xch + (k & 1) * 256 + lane * 4, sc);
+    }
+    lds_barrier();
+    if (k + 1 >= nc) continue;
+    const bcr_d4 sc = rcs_load(xch + (k & 1) * 256 + lane * 4);
+    bcr_d4 tj[kSlots];
+    bool up[kSlots];
+#pragma unroll
+    for (int u = 0; u < kSlots; ++u) {
+      const int jl = wave + kRcsTrsmWaves * u;
+      up[u] = jl > k && jl < nc;
+      tj[u] = up[u] ? rcs_load(ts + rcs_tri(jl, k) * 256 + lane * 4) : zero;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int u = 0; u < kSlots; ++u)
+        if (up[u]) s[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(tj[u][q], sc[q], s[u], 0, 0, 0);
+  }
+#pragma unroll
+  for (int u = 0; u < kSlots; ++u) {                                 // (stores after the chain: see rcs_pivot_role)
+    const int jl = wave + kRcsTrsmWaves * u;
+    if (jl >= nc) continue;
     bcr_d4 sc;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) sc[r] = -rds[k * 16 + lk + 4 * r] * t[r];
-    rcs_store(rv.Simg + rcs_blk(gi, c0 + k) + lane * 4, t);
-    rcs_store(rv.Tsc + rcs_blk(gi, c0 + k) + lane * 4, sc);
-#pragma unroll
-    for (int jl = k + 1; jl < kRcsSP; ++jl)
-      if (jl < nc) s[jl] = rcs_mma(rcs_load(ts + rcs_tri(jl, k) * 256 + lane * 4), sc, s[jl]);
+    for (int r = 0; r < 4; ++r) sc[r] = -rds[jl * 16 + lk + 4 * r] * s[u][r];
+    rcs_store(rv.Simg + rcs_blk(gi, c0 + jl) + lane * 4, s[u]);
+    rcs_store(rv.Tsc + rcs_blk(gi, c0 + jl) + lane * 4, sc);
   }
 }
 
@@ -360,48 +538,115 @@ __global__ __launch_bounds__(256) void k_rcs_syrk(RcsView rv, int c0) {
     pj[k] = rcs_load(rv.Simg + rcs_blk(gj, c0 + k) + lane * 4);
     qi[k] = rcs_load(rv.Tsc + rcs_blk(gi, c0 + k) + lane * 4);
   }
+  // sixteen independent accumulation chains would be ideal; four (one per K-slice of the 16 x 16 x 16 products) keep the dependent
+  // links at nine instead of thirty-six
+  const bcr_d4 zero{0.0, 0.0, 0.0, 0.0};
+  bcr_d4 a1 = zero, a2 = zero, a3 = zero;
 #pragma unroll
-  for (int k = 0; k < kRcsSP; ++k)
-    if (k < nc) acc = rcs_mma(pj[k], qi[k], acc);
-  rcs_store(blk, acc);
+  for (int k = 0; k < kRcsSP; ++k) {
+    if (k >= nc) continue;
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pj[k][0], qi[k][0], acc, 0, 0, 0);
+    a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(pj[k][1], qi[k][1], a1, 0, 0, 0);
+    a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(pj[k][2], qi[k][2], a2, 0, 0, 0);
+    a3 = __builtin_amdgcn_mfma_f64_16x16x4f64(pj[k][3], qi[k][3], a3, 0, 0, 0);
+  }
+  rcs_store(blk, (acc + a1) + (a2 + a3));
 }
 
-// x = L^-T Delta^-1 t, super-panels descending, ONE workgroup; pc = -x.  Dynamic LDS: x (npad) | u (9 x 16) | partial sums of the four
-// wavefronts (4 x 9 x 16) | the staged factor of the current super-panel (rcs_stage_doubles(9)).
-__host__ __device__ inline int rcs_backsub_doubles(int nbk) { return nbk * 16 + 5 * kRcsSP * 16 + rcs_stage_doubles(kRcsSP); }
-__global__ __launch_bounds__(256) void k_rcs_backsub(RcsView rv, double* __restrict__ pc) {
+// x = L^-T Delta^-1 t for the super-panels Kfirst .. 0 (the last one is solved inside its k_rcs_factor launch, its x is in rv.x),
+// ONE workgroup of sixteen wavefronts; pc = -x.  Per super-panel: the staged factor of its diagonal super-block, the products
+// T_i,jl x_i of the block rows below (x of the later super-panels) -- all loads of these three groups are issued before the first is
+// waited for: one memory round trip --, then the chain  x_k = X_k^T Delta_k^-1 u_k;  u_jl -= T_k,jl x_k  (one wavefront per jl).
+// Dynamic LDS: x (npad) | u (9 x 16) | partial sums per wavefront (16 x 9 x 16) | the staged factor (rcs_stage_doubles(9)).
+constexpr int kRcsBackWaves = 16;
+__host__ __device__ inline int rcs_backsub_doubles(int nbk) { return nbk * 16 + (1 + kRcsBackWaves) * kRcsSP * 16 + rcs_stage_doubles(kRcsSP); }
+__global__ __launch_bounds__(64 * kRcsBackWaves) void k_rcs_backsub(RcsView rv, double* __restrict__ pc, int Kfirst) {
   extern __shared__ __attribute__((aligned(32))) double rcs_lds[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lr = lane & 15, lk = lane >> 4;
   const int nbk = rv.nbk, R = nbk;
   double* xs = rcs_lds;
   double* u = xs + nbk * 16;
   double* up = u + kRcsSP * 16;
-  double* st = up + 4 * kRcsSP * 16;
-  const int nsp = (nbk + kRcsSP - 1) / kRcsSP;
-  for (int K = nsp - 1; K >= 0; --K) {
+  double* st = up + kRcsBackWaves * kRcsSP * 16;
+  for (int a = (Kfirst + 1) * kRcsSP * 16 + threadIdx.x; a < nbk * 16; a += 64 * kRcsBackWaves) xs[a] = rv.x[a];
+  constexpr int kBatch = 4;
+  for (int K = Kfirst; K >= 0; --K) {
     const int c0 = K * kRcsSP, nc = min(kRcsSP, nbk - c0), c1 = c0 + nc;
-    lds_barrier();                                                   // (the previous super-panel's readers of st are done)
-    rcs_stage(rv, c0, nc, st, lane, wave, 4);
-    const double* rds = st + nc * 256;
-    const double* ts = rds + nc * 16;
+    lds_barrier();                                                   // (the previous super-panel's readers of st are done; xs is complete)
+    // ---- issue: the staged factor (three blocks per wavefront), column 0 of T_R, the first batch of blocks below
+    double* rds = st + nc * 256;
+    double* ts = rds + nc * 16;
+    const int nblk = nc + nc * (nc - 1) / 2;
+    constexpr int kPer = (kRcsSP + kRcsSP * (kRcsSP - 1) / 2 + kRcsBackWaves - 1) / kRcsBackWaves;
+    bcr_d4 sv[kPer];
+    double srd[kPer];
+    int sdst[kPer];
+#pragma unroll
+    for (int q = 0; q < kPer; ++q) {
+      const int t = wave + kRcsBackWaves * q;
+      sdst[q] = -1; srd[q] = 0.0;
+      if (t < nc) {
+        sv[q] = rcs_load(rv.Simg + rcs_blk(c0 + t, c0 + t) + lane * 4);
+        if (lane < 16) srd[q] = rv.Tsc[rcs_blk(c0 + t, c0 + t) + lane];
+        sdst[q] = t * 256;
+      } else if (t < nblk) {
+        const int e = t - nc;
+        int j = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)e)) * 0.5f);
+        while (j * (j - 1) / 2 > e) --j;
+        while (j * (j + 1) / 2 <= e) ++j;
+        sv[q] = rcs_load(rv.Simg + rcs_blk(c0 + j, c0 + e - j * (j - 1) / 2) + lane * 4);
+        sdst[q] = (int)(ts - st) + e * 256;
+      }
+    }
+    double tR = 0.0;
+    if (threadIdx.x < nc * 16) {
+      const int jl = threadIdx.x / 16, row = threadIdx.x % 16;
+      tR = rv.Simg[rcs_blk(R, c0 + jl) + ((row & 3) * 16) * 4 + (row >> 2)];            // column 0 of T_R,jl
+    }
+    const int nitem = (nbk - c1) * nc;
+    bcr_d4 img[kBatch];
+    double xv[kBatch];
+#pragma unroll
+    for (int q = 0; q < kBatch; ++q) {
+      const int it = min(wave + kRcsBackWaves * q, max(nitem - 1, 0)), i = c1 + it / nc, jl = it % nc;
+      img[q] = nitem > 0 ? rcs_load(rv.Simg + rcs_blk(i, c0 + jl) + lane * 4) : bcr_d4{0.0, 0.0, 0.0, 0.0};
+      xv[q] = nitem > 0 ? xs[i * 16 + lr] : 0.0;
+    }
+    // ---- commit the stage, then the products of the rows below (partial sums per wavefront, added in wavefront order below)
+#pragma unroll
+    for (int q = 0; q < kPer; ++q) {
+      const int t = wave + kRcsBackWaves * q;
+      if (sdst[q] >= 0) rcs_store(st + sdst[q] + lane * 4, sv[q]);
+      if (t < nc && lane < 16) rds[t * 16 + lane] = srd[q];
+    }
     for (int e = lane; e < nc * 16; e += 64) up[wave * kRcsSP * 16 + e] = 0.0;
     lds_wave_sync();
-    // blocks below the super-panel: u_jl -= T_{i, c0 + jl} x_i, every wavefront its share, partial sums per wavefront
-    const int nitem = (nbk - c1) * nc;
-    for (int it = wave; it < nitem; it += 4) {
-      const int i = c1 + it / nc, jl = it % nc;
-      const bcr_d4 y = rcs_matvec(rcs_load(rv.Simg + rcs_blk(i, c0 + jl) + lane * 4), xs[i * 16 + lr]);
-      if (lr == 15) {
+    for (int it0 = wave; it0 < nitem; it0 += kRcsBackWaves * kBatch) {
+      if (it0 != wave) {                                             // (the first batch is in flight already)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) up[wave * kRcsSP * 16 + jl * 16 + lk + 4 * r] += y[r];
+        for (int q = 0; q < kBatch; ++q) {
+          const int it = min(it0 + kRcsBackWaves * q, nitem - 1), i = c1 + it / nc, jl = it % nc;
+          img[q] = rcs_load(rv.Simg + rcs_blk(i, c0 + jl) + lane * 4);
+          xv[q] = xs[i * 16 + lr];
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < kBatch; ++q) {
+        const int it = it0 + kRcsBackWaves * q;
+        if (it >= nitem) continue;
+        const int jl = it % nc;
+        const bcr_d4 y = rcs_matvec(img[q], xv[q]);
+        if (lr == 15) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) up[wave * kRcsSP * 16 + jl * 16 + lk + 4 * r] += y[r];
+        }
       }
     }
     lds_barrier();
     if (threadIdx.x < nc * 16) {
-      const int jl = threadIdx.x / 16, row = threadIdx.x % 16;
-      double v = rv.Simg[rcs_blk(R, c0 + jl) + ((row & 3) * 16) * 4 + (row >> 2)];          // column 0 of T_R,jl
+      double v = tR;
 #pragma unroll
-      for (int w = 0; w < 4; ++w) v -= up[w * kRcsSP * 16 + threadIdx.x];
+      for (int w = 0; w < kRcsBackWaves; ++w) v -= up[w * kRcsSP * 16 + threadIdx.x];
       u[threadIdx.x] = v;
     }
     lds_barrier();
@@ -414,17 +659,18 @@ __global__ __launch_bounds__(256) void k_rcs_backsub(RcsView rv, double* __restr
         }
       }
       lds_barrier();
-      for (int jl = wave; jl < k; jl += 4) {
-        const bcr_d4 y = rcs_matvec(rcs_load(ts + rcs_tri(k, jl) * 256 + lane * 4), xs[(c0 + k) * 16 + lr]);
+      if (wave < k) {                                                // jl = wave
+        const bcr_d4 y = rcs_matvec(rcs_load(ts + rcs_tri(k, wave) * 256 + lane * 4), xs[(c0 + k) * 16 + lr]);
         if (lr == 15) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) u[jl * 16 + lk + 4 * r] -= y[r];
+          for (int r = 0; r < 4; ++r) u[wave * 16 + lk + 4 * r] -= y[r];
         }
       }
       lds_barrier();
     }
   }
-  for (int a = threadIdx.x; a < rv.nn; a += 256) pc[a] = -xs[a];
+  const int top = min((Kfirst + 1) * kRcsSP * 16, rv.nn);
+  for (int a = threadIdx.x; a < top; a += 64 * kRcsBackWaves) pc[a] = -xs[a];
 }
 
 }  // namespace mvus

@@ -2052,6 +2052,10 @@ __device__ __forceinline__ void ldl_inv16(double (&a)[16], double (&x)[16], doub
   if (bad && lane == 0) fail[0] = 2;
 }
 
+}  // namespace mvus
+#include "ba_rcs.hip.h"
+namespace mvus {
+
 // acc += op(A) op(B) for 16x16 blocks in LDS (stride lda / ldb), K = 16: ta: A is read transposed, tb: B is.
 __device__ __forceinline__ bcr_d4 mma16(const double* __restrict__ A, int lda, bool ta, const double* __restrict__ B, int ldb, bool tb, bcr_d4 acc) {
   const int lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
@@ -2089,7 +2093,7 @@ __device__ __forceinline__ void pivot_inverse_wave(double (*Dm)[kNB + 1], double
     a[k] = k <= row ? t : 0.0;
     x[k] = k == row ? 1.0 : 0.0;
   }
-  ldl_inv16(a, x, rd, lane, fail);
+  rcs_ldl16(a, x, rd, lane, fail);
   if (lane < 32) {                        // lanes 0..15 store X, lanes 16..31 (the same values) D^-1 X
     double* dst = (lane < 16 ? M1 : M2) + row;
 #pragma unroll
@@ -2112,7 +2116,7 @@ __device__ __forceinline__ void pivot_inverse_wave(double (*Dm)[kNB + 1], double
     a[k] = k <= row ? t : 0.0;
     x[k] = k == row ? 1.0 : 0.0;
   }
-  ldl_inv16(a, x, rd, lane, fail);
+  rcs_ldl16(a, x, rd, lane, fail);
   if (lane < 32) {
     double* dst = (lane < 16 ? M1 : M2) + row;
 #pragma unroll
@@ -2212,10 +2216,6 @@ __global__ __launch_bounds__(kGjThreads) void k_gj_step(int nn, int kb, const do
   static_assert(kPivScratch <= 2 * kNB * (kNB + 1), "pivot scratch must fit Q and Bk");
   if (threadIdx.x < 64) pivot_inverse_wave(Ai, &Q[0][0], Pinv + (long long)(base / kNB) * kNB * kNB, fail);
 }
-
-}  // namespace mvus
-#include "ba_rcs.hip.h"
-namespace mvus {
 
 // p (x order) from p_c and p_s = -(z_g + Z_E p_c)
 __global__ __launch_bounds__(kThreads) void k_back_substitute(DevProblem dp, NEView ne, int ncols, int row_lo, int row_hi, int cams,
@@ -2354,9 +2354,13 @@ struct HipSchur {
     S2 = be.alloc((size_t)(ne.CB + 1) * ne.CB);
     Linv = be.alloc((size_t)((ne.CB + kNB - 1) / kNB) * kNB * kNB);
     rcs.nn = ne.CB; rcs.nbk = (ne.CB + 15) / 16;
-    rcs.Simg = be.alloc(rcs_doubles(ne.CB)); rcs.Tsc = be.alloc(rcs_doubles(ne.CB));
-    { const char* e = std::getenv("MVUS_RCS"); use_rcs = !(e && std::strcmp(e, "gj") == 0); }
-    MVUS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rcs_trsm), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(rcs_stage_doubles(kRcsSP) * sizeof(double))));
+    rcs.Simg = be.alloc(rcs_doubles(ne.CB)); rcs.Tsc = be.alloc(rcs_doubles(ne.CB)); rcs.x = be.alloc((size_t)rcs.nbk * 16);
+    // which solver of the reduced camera system: the blocked L D L^T of ba_rcs.hip.h wins while the system is ONE super-panel (<= 144
+    // unknowns: one launch, the whole chain inside one CU -- 16 + 8 us against 32 at 63 unknowns); beyond that its rows-below /
+    // trailing / substitution launches cost more than the block Gauss-Jordan's tile updates spread over the chip (measured at 288:
+    // 113 us against 95).  MVUS_RCS=ldl / gj forces one of them (tests, A/B).
+    { const char* e = std::getenv("MVUS_RCS"); use_rcs = e && std::strcmp(e, "ldl") == 0 ? true : (e && std::strcmp(e, "gj") == 0 ? false : rcs.nbk <= kRcsSP); }
+    MVUS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rcs_trsm), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((rcs_stage_doubles(kRcsSP) + 512) * sizeof(double))));
     MVUS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rcs_backsub), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(rcs_backsub_doubles(rcs.nbk) * sizeof(double))));
     if (shard) { DG = nullptr; D = NE + nAg + halo_count; gx = D + hp.n; }
     else { DG = be.alloc(2 * (size_t)hp.n); D = DG; gx = DG + hp.n; }
@@ -2506,7 +2510,7 @@ struct HipSchur {
     else MVUS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_assemble_windows<9>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)win_lds));
   }
   ~HipSchur() {
-    for (double* p : {Erm, NE, Lb, Z, G, G0, S, S2, Linv, rhs, pc, DG, px, pv.VW, sepbuf, pv.U2, pv.Ha, pv.Hc, wv.Apart, rcs.Simg, rcs.Tsc}) if (p) be.release(p);
+    for (double* p : {Erm, NE, Lb, Z, G, G0, S, S2, Linv, rhs, pc, DG, px, pv.VW, sepbuf, pv.U2, pv.Ha, pv.Hc, wv.Apart, rcs.Simg, rcs.Tsc, rcs.x}) if (p) be.release(p);
     if (win_tables) (void)hipFree(win_tables);
     if (part_tables) (void)hipFree(part_tables);
     if (halo_tables) (void)hipFree(halo_tables);
@@ -2716,13 +2720,14 @@ struct HipSchur {
       hipLaunchKernelGGL(k_rcs_finish, dim3(nt, nt + 1), dim3(256), 0, be.stream, ne, ncols, nsl, lambda, Gsum, rcs);
       for (int c0 = 0; c0 < nbk; c0 += kRcsSP) {
         const int nc = std::min(kRcsSP, nbk - c0), c1 = c0 + nc, m = nbk - c1;
-        hipLaunchKernelGGL(k_rcs_factor, dim3(1), dim3(kRcsFactorThreads), 0, be.stream, rcs, c0, fail);
+        hipLaunchKernelGGL(k_rcs_factor, dim3(1), dim3(kRcsFactorThreads), 0, be.stream, rcs, c0, fail, (int)(m == 0), pc);
         if (m > 0) {
-          hipLaunchKernelGGL(k_rcs_trsm, dim3((m + kRcsTrsmRows - 1) / kRcsTrsmRows), dim3(64 * kRcsTrsmRows), rcs_stage_doubles(nc) * sizeof(double), be.stream, rcs, c0);
+          hipLaunchKernelGGL(k_rcs_trsm, dim3(m), dim3(64 * kRcsTrsmWaves), (rcs_stage_doubles(nc) + 512) * sizeof(double), be.stream, rcs, c0);
           hipLaunchKernelGGL(k_rcs_syrk, dim3((m * (m + 1) / 2 + m + 3) / 4), dim3(256), 0, be.stream, rcs, c0);
         }
       }
-      hipLaunchKernelGGL(k_rcs_backsub, dim3(1), dim3(256), rcs_backsub_doubles(nbk) * sizeof(double), be.stream, rcs, pc);
+      const int nsp = (nbk + kRcsSP - 1) / kRcsSP;                       // (the last super-panel is solved inside its factor launch)
+      if (nsp > 1) hipLaunchKernelGGL(k_rcs_backsub, dim3(1), dim3(64 * kRcsBackWaves), rcs_backsub_doubles(nbk) * sizeof(double), be.stream, rcs, pc, nsp - 2);
     } else {
       hipLaunchKernelGGL(k_schur_finish, dim3(ntile, ntile), dim3(kFinThreads), 0, be.stream, ne, ncols, nsl, lambda, Gsum, S, Linv, fail);
       const int nn = ne.CB;
