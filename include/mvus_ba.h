@@ -109,6 +109,12 @@ typedef struct mvus_solve_opts {
                            following the noise -- the effect the reference gets from LSMR's truncated solves (common.py:670).
                            Problems whose motion rows reach over more than six control points (knots less than a frame apart: more
                            control points than detections) use at least 0.3 */
+  double lm_trust_radius; /* MVUS_SOLVER_LM_SCHUR: the reference's trust region on top of the damping.  scipy's TRF (common.py:670,
+                           x_scale = 1) bounds the Euclidean length of a step by Delta: Delta_0 = |x0|, Delta = 0.25 |step| after a
+                           step whose actual / predicted reduction is below 0.25, Delta *= 2 after one above 0.75 that reached the
+                           bound (scipy/optimize/_lsq/common.py update_tr_radius).  Here a damped step longer than Delta is cut back
+                           to Delta along its direction and the damping is raised in proportion for the next solve.
+                           0: Delta_0 = |x0| as scipy; > 0: this Delta_0; < 0: no trust region (damping only, rounds 2-4) */
 } mvus_solve_opts;
 
 /* scipy.optimize.OptimizeResult fields Scene.BA returns (common.py:670,697) */

@@ -41,6 +41,7 @@ class MvusSolveOpts(ctypes.Structure):
         ('ftol', ctypes.c_double), ('xtol', ctypes.c_double), ('gtol', ctypes.c_double),
         ('lsmr_atol', ctypes.c_double), ('lsmr_btol', ctypes.c_double), ('lsmr_conlim', ctypes.c_double),
         ('lsmr_maxiter', ctypes.c_int32), ('verbose', ctypes.c_int32), ('lm_lambda_min', ctypes.c_double),
+        ('lm_trust_radius', ctypes.c_double),
     ]
 
 
@@ -183,4 +184,5 @@ def default_opts(solver=SOLVER_TRF_LSMR, jac_mode=JAC_PATTERN, max_nfev=10):
     o.lsmr_atol, o.lsmr_btol, o.lsmr_conlim, o.lsmr_maxiter = 1e-6, 1e-6, 1e8, 0
     o.verbose = 0
     o.lm_lambda_min = 3e-3
+    o.lm_trust_radius = -1.0
     return o

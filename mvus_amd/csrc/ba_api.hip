@@ -259,6 +259,7 @@ struct HipBackend {
   // device-resident LM driver (ba_schur.h)
   std::vector<double> lb_host, ub_host;
   double *lb_dev = nullptr, *ub_dev = nullptr;
+  double* tr_pn2 = nullptr;         // |p|^2 of the damped step (trust region of the LM driver)
   unsigned* lm_counter = nullptr;   // ticket counter of the last-block reductions (k_lm_gnorm / k_lm_trial), kept at 0 between launches
   void set_bounds(const std::vector<double>& lb, const std::vector<double>& ub) {
     if (!lb_dev) {
@@ -307,18 +308,21 @@ struct HipBackend {
     std::swap(f_dev, f_new);
   }
   void lm_trial(const double* x, const double* p, const double* lb, const double* ub, const double* g, const double* D,
-                const int* fail, double* x_new, double* out, double* gnorm_out, double* x_mirror) {
+                const int* fail, double* x_new, double* out, double* gnorm_out, double* x_mirror, double* pn2 = nullptr, double delta = 0.0) {
     touch(x_new);
+    // trust region: |p|^2 first (two small launches), the trial kernel then cuts the step back to delta along its direction
+    double* pn2_dev = nullptr;
+    if (pn2) { if (!tr_pn2) tr_pn2 = dalloc<double>(1); pn2_dev = tr_pn2; dot_into(p, p, hp.n, pn2_dev); }
     // one workgroup is limited by what one CU can load (six n-vectors: 18 us at n = 15k); a few workgroups and a second, tiny
     // launch for their partials take 10 us.  Beyond 128k parameters: the one-launch form with the last-workgroup hand-over.
     const unsigned g2 = hp.n > 2048 && hp.n <= (1 << 17) ? (unsigned)std::min<int64_t>(32, (hp.n + 1023) / 1024) : 0u;
     if (g2 > 1) {
-      hipLaunchKernelGGL(k_lm_trial, dim3(g2), dim3(1024), 0, stream, (int)hp.n, x, p, lb, ub, g, D, fail, x_new, out, gnorm_out, partials, (unsigned*)nullptr, x_mirror);
+      hipLaunchKernelGGL(k_lm_trial, dim3(g2), dim3(1024), 0, stream, (int)hp.n, x, p, lb, ub, g, D, fail, x_new, out, gnorm_out, partials, (unsigned*)nullptr, x_mirror, (const double*)pn2_dev, delta);
       hipLaunchKernelGGL(k_lm_trial_sum, dim3(1), dim3(64), 0, stream, (int)g2, partials, out, gnorm_out, dp, (const double*)x_new, cams);
       cams_for = x_new;                      // decoded by that launch: the trial residual needs no k_cam_states
       return;
     }
-    hipLaunchKernelGGL(k_lm_trial, dim3(lm_grid()), dim3(1024), 0, stream, (int)hp.n, x, p, lb, ub, g, D, fail, x_new, out, gnorm_out, partials, lm_counter, x_mirror);
+    hipLaunchKernelGGL(k_lm_trial, dim3(lm_grid()), dim3(1024), 0, stream, (int)hp.n, x, p, lb, ub, g, D, fail, x_new, out, gnorm_out, partials, lm_counter, x_mirror, (const double*)pn2_dev, delta);
   }
   void fetch(const double* src, int k, double* host) {       // src inside scal_out(): the pinned mirror itself, or staged through it
     const int64_t off = src - scal_out();
@@ -733,7 +737,7 @@ void mvus_default_opts(mvus_solve_opts* o) {
   if (!o) return;
   o->solver = MVUS_SOLVER_TRF_LSMR; o->jac_mode = MVUS_JAC_PATTERN; o->max_nfev = 10;
   o->ftol = 1e-8; o->xtol = 1e-12; o->gtol = 1e-8;
-  o->lsmr_atol = 1e-6; o->lsmr_btol = 1e-6; o->lsmr_conlim = 1e8; o->lsmr_maxiter = 0; o->verbose = 0; o->lm_lambda_min = 3e-3;
+  o->lsmr_atol = 1e-6; o->lsmr_btol = 1e-6; o->lsmr_conlim = 1e8; o->lsmr_maxiter = 0; o->verbose = 0; o->lm_lambda_min = 3e-3; o->lm_trust_radius = -1.0;
 }
 
 int mvus_ba_create(const mvus_problem* p, mvus_ba** out) {
@@ -1071,6 +1075,7 @@ int mvus_ba_solve(mvus_ba* h, double* x, const mvus_solve_opts* opts, mvus_resul
     so.jac_mode = opts->jac_mode; so.max_nfev = opts->max_nfev; so.ftol = opts->ftol; so.xtol = opts->xtol; so.gtol = opts->gtol;
     so.lsmr_atol = opts->lsmr_atol; so.lsmr_btol = opts->lsmr_btol; so.lsmr_conlim = opts->lsmr_conlim;
     so.lsmr_maxiter = opts->lsmr_maxiter; so.verbose = opts->verbose; so.lm_lambda_min = opts->lm_lambda_min >= 0 ? opts->lm_lambda_min : 0.0;
+    so.lm_trust_radius = opts->lm_trust_radius;
     if (so.jac_mode == MVUS_JAC_PATTERN && !be.pattern_uploaded) {
       be.upload(be.x_cur, xv.data(), n);
       be.set_pattern(be.x_cur);
@@ -1090,7 +1095,7 @@ int mvus_ba_solve(mvus_ba* h, double* x, const mvus_solve_opts* opts, mvus_resul
       // noise along those directions (the incremental loop then ends 3 m off; with 0.3 it ends where TRF + LSMR ends:
       // profiles/r04_loop_lm_wide_band_damping.txt).  The floor of such problems is at least kLambdaMinWide.
       constexpr double kLambdaMinWide = 0.3;
-      if (h->schur->wide) so.lm_lambda_min = std::max(so.lm_lambda_min, kLambdaMinWide);
+      if (h->schur->wide && so.lm_trust_radius < 0) so.lm_lambda_min = std::max(so.lm_lambda_min, kLambdaMinWide);      // (a trust region bounds those steps itself)
       sr = lm_schur(be, *h->schur, xv, lb, ub, so, be.f_cur);
       if (!sr.error) { be.lm_lambda = std::min(std::max(sr.lm_lambda, 1e-12), 1e6); be.lm_nu = std::min(sr.lm_nu, 1024.0); }
       if (sr.jac_stale) be.has_jacobian = false;      // mvus_ba_jv / jtu / lm_step must not pair J(x_old) with f(x_new)

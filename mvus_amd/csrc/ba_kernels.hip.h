@@ -967,7 +967,11 @@ __global__ __launch_bounds__(1024) void k_lm_gnorm(int n, const double* __restri
 __global__ __launch_bounds__(1024) void k_lm_trial(int n, const double* __restrict__ x, const double* __restrict__ p, const double* __restrict__ lb,
                                                    const double* __restrict__ ub, const double* __restrict__ g, const double* __restrict__ D,
                                                    const int* __restrict__ fail, double* __restrict__ x_new, double* __restrict__ out,
-                                                   double* __restrict__ gnorm_out, double* part, unsigned* counter, double* __restrict__ x_mirror) {
+                                                   double* __restrict__ gnorm_out, double* part, unsigned* counter, double* __restrict__ x_mirror,
+                                                   const double* __restrict__ pn2 = nullptr, double delta = 0.0) {
+  // trust region (mvus_solve_opts.lm_trust_radius): a step longer than delta is cut back to delta along its direction
+  const double cut = (pn2 != nullptr && delta > 0.0 && *pn2 > delta * delta) ? delta / sqrt(*pn2) : 1.0;
+  if (pn2 != nullptr && blockIdx.x == 0 && threadIdx.x == 0) out[5] = *pn2;      // slot 7 of the driver's scalars
   // also delivers the projected gradient norm of k_lm_gnorm (x, g and the bounds are read here anyway): slot 4 = max
   __shared__ double red[5][16];
   const bool dead = fail[0] != 0;
@@ -987,7 +991,7 @@ __global__ __launch_bounds__(1024) void k_lm_trial(int n, const double* __restri
       if (i >= n) break;
       const double xi = xv[u], pi = pv[u], gi = gv[u];
       const bool ok = isfinite(pi);
-      const double xn = (dead || !ok) ? xi : fmin(fmax(xi + pi, lo[u]), hi[u]);
+      const double xn = (dead || !ok) ? xi : fmin(fmax(xi + cut * pi, lo[u]), hi[u]);
       const double st = xn - xi;
       x_new[i] = xn;
       if (x_mirror) x_mirror[i] = xn;                    // mapped pinned host memory: the accepted point needs no download

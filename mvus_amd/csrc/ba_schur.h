@@ -54,12 +54,12 @@ inline double lm_gnorm_host(int64_t n, const double* x, const double* lb, const 
 // trial point x_new = P(x + p) (projection onto the rs box) and out = [g.step, step^T D step, |step|^2, |x|^2];
 // a failed or non-finite solve gives step 0 and out[0] = NaN
 inline void lm_trial_host(int64_t n, const double* x, const double* p, const double* lb, const double* ub, const double* g,
-                          const double* D, int fail, double* x_new, double* out, double* gnorm_out) {
+                          const double* D, int fail, double* x_new, double* out, double* gnorm_out, double cut = 1.0) {
   double gp = 0, pDp = 0, s2 = 0, x2 = 0;
   bool bad = fail != 0;
   for (int64_t i = 0; i < n && !bad; ++i) bad = !std::isfinite(p[i]);
   for (int64_t i = 0; i < n; ++i) {
-    const double xn = bad ? x[i] : std::min(std::max(x[i] + p[i], lb[i]), ub[i]);
+    const double xn = bad ? x[i] : std::min(std::max(x[i] + cut * p[i], lb[i]), ub[i]);
     const double st = xn - x[i];
     x_new[i] = xn;
     gp += g[i] * st; pDp += st * D[i] * st; s2 += st * st; x2 += x[i] * x[i];
@@ -84,7 +84,7 @@ SolveResult lm_schur(B& be, Schur& sc, std::vector<double>& x, const std::vector
   const double* lbp = be.lb_ptr();
   const double* ubp = be.ub_ptr();
   double* S = be.lm_scalars();   // [0] |f|^2 at x0, [1] projected |g|_inf, [2..5] trial scalars, [6] |f(x_trial)|^2
-  double hs[7] = {0, 0, 0, 0, 0, 0, 0};
+  double hs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
   be.upload(x_dev, x.data(), n);
   // (the first linearisation follows at once: its storage is zeroed beside this evaluation where the backend can do that)
@@ -99,11 +99,22 @@ SolveResult lm_schur(B& be, Schur& sc, std::vector<double>& x, const std::vector
     else be.copy(f_dev, f_new, m);
   };
   int mir_cur = -1, mir_trial = 0;      // host mirrors of the accepted / the trial point (backend permitting)
+  // Trust region in the reference's metric (mvus_solve_opts.lm_trust_radius): scipy's TRF with x_scale = 1 bounds |step|_2 by Delta
+  // (scipy/optimize/_lsq/trf.py: Delta_0 = |x0|, or 1 when that is 0) and updates it with update_tr_radius (_lsq/common.py).  The
+  // damped step p(lambda) is cut back to Delta along its direction by the trial kernel; S[7] brings |p|^2 back.
+  const bool tr = opt.lm_trust_radius >= 0;
+  double Delta = 0;
+  if (tr) {
+    Delta = opt.lm_trust_radius;
+    if (!(Delta > 0)) { double s2 = 0; for (int64_t i = 0; i < n; ++i) s2 += x[i] * x[i]; Delta = s2 > 0 ? std::sqrt(s2) : 1.0; }
+  }
   auto launch_trial = [&](double lambda) {
     sc.solve_async(lambda);
-    be.lm_trial(x_dev, sc.step_ptr(), lbp, ubp, sc.grad_ptr(), sc.diag_ptr(), sc.fail_ptr(), xt_dev, S + 2, S + 1, be.mirror_dev(mir_trial));
+    be.lm_trial(x_dev, sc.step_ptr(), lbp, ubp, sc.grad_ptr(), sc.diag_ptr(), sc.fail_ptr(), xt_dev, S + 2, S + 1, be.mirror_dev(mir_trial),
+                tr ? S + 7 : nullptr, Delta);
     be.residual_sq(xt_dev, f_new, S + 6);
   };
+  const int nfetch = tr ? 8 : 7;
 
   double lambda = std::max(opt.lm_lambda0 > 0 ? opt.lm_lambda0 : 1e-4, opt.lm_lambda_min), nu = opt.lm_nu0 > 0 ? opt.lm_nu0 : 2.0;
   const double lambda_min = opt.lm_lambda_min;
@@ -115,7 +126,7 @@ SolveResult lm_schur(B& be, Schur& sc, std::vector<double>& x, const std::vector
     const bool can_try = res.nfev < opt.max_nfev;
     if (can_try) launch_trial(lambda);             // speculative: dropped if the gradient test below ends the solve
     else be.lm_gnorm(x_dev, lbp, ubp, sc.grad_ptr(), S + 1);
-    be.fetch(S, can_try ? 7 : 2, hs);
+    be.fetch(S, can_try ? nfetch : 2, hs);
     if (!cost_known) {
       cost = 0.5 * hs[0];
       if (!std::isfinite(cost)) { res.error = -3; cleanup(); return res; }
@@ -129,7 +140,7 @@ SolveResult lm_schur(B& be, Schur& sc, std::vector<double>& x, const std::vector
     double actual_reduction = -1, cost_new = cost;
     bool have_trial = true;
     while (actual_reduction <= 0 && res.nfev < opt.max_nfev) {
-      if (!have_trial) { launch_trial(lambda); be.fetch(S + 2, 5, hs + 2); }
+      if (!have_trial) { launch_trial(lambda); be.fetch(S + 2, nfetch - 2, hs + 2); }
       have_trial = false;
       if (!sc.solve_ok() || !std::isfinite(hs[2]) || !std::isfinite(hs[3])) {   // not positive definite at this damping: raise it
         lambda *= 10.0;
@@ -138,7 +149,9 @@ SolveResult lm_schur(B& be, Schur& sc, std::vector<double>& x, const std::vector
       }
       ++res.lin_iters;
       // predicted reduction of the quadratic model: -(g.p + 0.5 p^T H p) = 0.5 (lambda p^T D p - g.p)
-      const double predicted = 0.5 * (lambda * hs[3] - hs[2]);
+      // (a step cut back to the trust region, st = cut p: -g.st - st^T H st / 2 with p^T H p = -g.p - lambda p^T D p)
+      const double cut = (tr && hs[7] > Delta * Delta) ? Delta / std::sqrt(hs[7]) : 1.0;
+      const double predicted = cut < 1.0 ? 0.5 * lambda * hs[3] - (1.0 - 0.5 * cut) * hs[2] : 0.5 * (lambda * hs[3] - hs[2]);
       ++res.nfev;
       cost_new = 0.5 * hs[6];
       if (!std::isfinite(cost_new)) { lambda *= nu; nu *= 2.0; continue; }
@@ -148,6 +161,7 @@ SolveResult lm_schur(B& be, Schur& sc, std::vector<double>& x, const std::vector
       const int term = check_termination(actual_reduction, cost, step_norm, std::sqrt(hs[5]), ratio, opt.ftol, opt.xtol);
       if (opt.verbose >= 2)
         std::fprintf(stderr, "lm: nfev=%d cost=%.10e -> %.10e lambda=%.3e ratio=%.3f |step|=%.3e\n", res.nfev, cost, cost_new, lambda, ratio, step_norm);
+      const double lambda_used = lambda;
       if (actual_reduction > 0) {
         const double t = 2.0 * ratio - 1.0;
         lambda *= std::max(1.0 / 3.0, 1.0 - t * t * t);                 // Nielsen's update
@@ -155,6 +169,15 @@ SolveResult lm_schur(B& be, Schur& sc, std::vector<double>& x, const std::vector
         nu = 2.0;
       } else {
         lambda *= nu; nu *= 2.0;
+      }
+      if (tr) {                                                          // scipy's update_tr_radius
+        const bool bound_hit = step_norm > 0.95 * Delta;
+        if (ratio < 0.25) Delta = 0.25 * step_norm;
+        else if (ratio > 0.75 && bound_hit) Delta *= 2.0;
+        // a step that had to be cut to less than half: the next damped step should come out near the radius by itself (its
+        // direction then turns from Gauss-Newton's towards the scaled gradient, as the exact trust-region step does)
+        if (cut < 0.5) lambda = std::max(lambda, std::min(lambda_used * 0.5 / cut, lambda_used * 10.0));
+        if (opt.verbose >= 2) std::fprintf(stderr, "lm:   trust region: |p|=%.3e cut=%.3f Delta -> %.3e\n", std::sqrt(hs[7]), cut, Delta);
       }
       if (term != -1) { status = term; break; }
     }

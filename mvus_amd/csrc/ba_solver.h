@@ -45,6 +45,7 @@ struct SolveOptions {
   int lsmr_maxiter = 0;
   int verbose = 0;
   double lm_lambda_min = 3e-3;   // floor of the LM damping (see mvus_solve_opts)
+  double lm_trust_radius = -1;   // < 0: none; 0: Delta_0 = |x0| (scipy); > 0: Delta_0 (see mvus_solve_opts)
   double lm_lambda0 = 0;   // > 0: initial LM damping (a handle carries it over from its previous solve)
   double lm_nu0 = 0;       // > 0: initial damping growth factor (carried with it, so that a run of one-trial solves
                            // escalates the damping like one long solve does)

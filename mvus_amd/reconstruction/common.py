@@ -413,6 +413,7 @@ class Scene:
         h = self._resident_handle(prob, cams)      # stays resident for remove_outliers and the next BA
         opts = _ba._lib.default_opts(solver, jac_mode, max_iter)
         opts.lm_lambda_min = float(st.get('ba_lambda_min', opts.lm_lambda_min))
+        opts.lm_trust_radius = float(st.get('ba_trust_radius', opts.lm_trust_radius))
         try:
             if solver == _ba.SOLVER_LM_SCHUR and st.get('ba_lm_wide_band', 'trf') != 'lm' and self._motion_band_width(prob) > 6:
                 # POLICY, not a limit of the library (it solves bands of up to sixteen control points, tests/test_gpu_schur.py): knots less

@@ -62,7 +62,11 @@ struct HostBackend {
   bool residual_sq(const double* x, double* f, double* out, double* = nullptr, int64_t = 0) { residual(x, f); dot_m_into(f, f, out); return false; }
   void lm_gnorm(const double* x, const double* lb, const double* ub, const double* g, double* out) { *out = mvus::lm_gnorm_host(hp.n, x, lb, ub, g); }
   void lm_trial(const double* x, const double* p, const double* lb, const double* ub, const double* g, const double* D,
-                const int* fail, double* x_new, double* out, double* gn, double*) { mvus::lm_trial_host(hp.n, x, p, lb, ub, g, D, *fail, x_new, out, gn); }
+                const int* fail, double* x_new, double* out, double* gn, double*, double* pn2 = nullptr, double delta = 0.0) {
+    double cut = 1.0;
+    if (pn2) { double s = 0; for (int64_t i = 0; i < hp.n; ++i) s += p[i] * p[i]; *pn2 = s; if (delta > 0 && s > delta * delta) cut = delta / std::sqrt(s); }
+    mvus::lm_trial_host(hp.n, x, p, lb, ub, g, D, *fail, x_new, out, gn, cut);
+  }
   static constexpr bool kSwapResiduals = false;
   static constexpr bool kDeviceLsmr = false;
   double* mirror_dev(int) { return nullptr; }
@@ -381,7 +385,7 @@ int hostcheck_solve(void* h, double* x, const mvus_solve_opts* o, mvus_result* r
   if (be->hp.rs_bounds) for (int c = 0; c < be->hp.C; ++c) { lb[2 * be->hp.C + c] = 0.0; ub[2 * be->hp.C + c] = 1.0; }
   SolveOptions so;
   so.jac_mode = o->jac_mode; so.max_nfev = o->max_nfev; so.ftol = o->ftol; so.xtol = o->xtol; so.gtol = o->gtol;
-  so.lsmr_atol = o->lsmr_atol; so.lsmr_btol = o->lsmr_btol; so.lsmr_conlim = o->lsmr_conlim; so.lsmr_maxiter = o->lsmr_maxiter; so.verbose = o->verbose; so.lm_lambda_min = o->lm_lambda_min;
+  so.lsmr_atol = o->lsmr_atol; so.lsmr_btol = o->lsmr_btol; so.lsmr_conlim = o->lsmr_conlim; so.lsmr_maxiter = o->lsmr_maxiter; so.verbose = o->verbose; so.lm_lambda_min = o->lm_lambda_min; so.lm_trust_radius = o->lm_trust_radius;
   if (so.jac_mode == MVUS_JAC_PATTERN && !be->pattern_uploaded) be->set_pattern(x);
   std::vector<double> f(be->hp.m);
   SolveResult sr;

@@ -28,7 +28,7 @@ def test_header_and_binding_agree(lib):
 
 def test_struct_sizes_match_header(lib):
     # natural alignment of the C structs (see include/mvus_ba.h)
-    assert ctypes.sizeof(_lib.MvusSolveOpts) == 80
+    assert ctypes.sizeof(_lib.MvusSolveOpts) == 88
     assert ctypes.sizeof(_lib.MvusResult) == 48
     assert ctypes.sizeof(_lib.MvusProblem) == 144
 

@@ -410,3 +410,25 @@ def test_schur_product_slab_plans(slabs, monkeypatch):
     d = np.diag(H).copy()
     p_ref = np.linalg.solve(H + 0.05 * np.diag(np.where(d > 0, d, 1.0)), -g)
     assert float(np.abs(p - p_ref).max() / np.abs(p_ref).max()) < 1e-8
+
+
+def test_lm_trust_region_gpu_matches_host_driver():
+    """mvus_solve_opts.lm_trust_radius on the GPU (|p|^2 by two small launches, the cut applied by the trial kernel) against the host
+    build of the same driver: a radius that binds on the first steps and is widened / narrowed by scipy's rule afterwards."""
+    from mvus_amd.ba import BAHandle
+    scene, g = load_case('rs_F_2int_3cam')
+    prob, x0 = mp.problem_from_scene(scene)
+    radius = 1e-4 * float(np.linalg.norm(g['x0']))
+    opts = _lib.default_opts(_lib.SOLVER_LM_SCHUR, _lib.JAC_ANALYTIC, 8)
+    opts.lm_trust_radius = radius
+    one = _lib.default_opts(_lib.SOLVER_LM_SCHUR, _lib.JAC_ANALYTIC, 2)
+    one.lm_trust_radius = radius
+    with BAHandle(prob) as h:
+        r1 = h.solve(g['x0'], opts=one)
+    np.testing.assert_allclose(np.linalg.norm(r1.x - g['x0']), radius, rtol=1e-9)
+    with BAHandle(prob) as h:                                  # (fresh handle: the damping carried over from a previous solve starts equal)
+        r = h.solve(g['x0'], opts=opts)
+    xh, rh, _ = _host(prob).solve(g['x0'], opts)
+    assert (r.nfev, r.status) == (rh.nfev, rh.status)
+    np.testing.assert_allclose(r.cost, rh.cost, rtol=1e-7)
+    np.testing.assert_allclose(r.x, xh, rtol=0, atol=1e-6 * max(1.0, np.abs(xh).max()))

@@ -142,3 +142,31 @@ def test_trf_lsmr_vs_reference_result(name):
     keep = np.concatenate(orc.outlier_keep_mask(oprob, x, float(g['thres_outlier'])))
     agree = np.mean(keep.astype(np.uint8) == g['outlier_keep'])
     assert agree > 0.95
+
+
+def test_lm_trust_region_bounds_the_step_host():
+    """mvus_solve_opts.lm_trust_radius (the host build of the LM driver, dense normal equations): one trial with a radius far below the
+    damped step's length moves x by exactly that radius (the step is cut back along its direction)."""
+    from hostcheck_util import HostHandle
+    from mvus_amd import problem as mp
+    scene, g = load_case('rs_F_2int_3cam')
+    prob, x0 = mp.problem_from_scene(scene)
+
+    def run(radius, nfev):
+        o = _lib.default_opts(_lib.SOLVER_LM_SCHUR, _lib.JAC_ANALYTIC, nfev)
+        o.lm_trust_radius = radius
+        x, res, _ = HostHandle(prob).solve(g['x0'], o)      # (a fresh handle: the damping a handle carries from solve to solve starts equal)
+        return x, res
+
+    x_free, r_free = run(-1.0, 8)
+    assert r_free.cost < r_free.initial_cost
+    radius = 1e-4 * float(np.linalg.norm(g['x0']))            # far below the first damped step's length
+    x_cut, r_cut = run(radius, 2)
+    np.testing.assert_allclose(np.linalg.norm(x_cut - g['x0']), radius, rtol=1e-9)
+    assert r_cut.cost < r_cut.initial_cost
+    # scipy's rule shrinks the radius to a quarter of the step after any step with actual / predicted < 0.25, whatever it was before:
+    # a radius no step reaches at first and scipy's own Delta_0 = |x0| therefore give the same iterates (not those of "no trust region")
+    x_big, r_big = run(1e6 * float(np.linalg.norm(g['x0'])), 8)
+    x_sci, r_sci = run(0.0, 8)
+    assert np.array_equal(x_sci, x_big) and r_sci.nfev == r_big.nfev
+    assert r_sci.cost < r_sci.initial_cost

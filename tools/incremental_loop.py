@@ -33,6 +33,7 @@ def main():
     ap.add_argument('--cpu-all', action='store_true', help="time the oracle (scipy least_squares, one core) on EVERY BA of the loop, on the state the GPU BA starts from -- use a down-scaled flight (--obs 20000)")
     ap.add_argument('--seed', type=int, default=None)
     ap.add_argument('--lambda-min', type=float, default=None, help="settings['ba_lambda_min'] (floor of the LM damping)")
+    ap.add_argument('--trust-radius', type=float, default=None, help="settings['ba_trust_radius']: 0 = scipy's Delta_0 = |x0|, > 0 that radius, < 0 none")
     ap.add_argument('--lm-wide', choices=['lm', 'trf'], default=None, help="settings['ba_lm_wide_band']: what ba_solver=lm does when the motion rows reach over more than six control points")
     args = ap.parse_args()
     from mvus_amd import pipeline, synth
@@ -45,6 +46,7 @@ def main():
     st_extra = {'ba_solver': args.solver}
     if args.lambda_min is not None: st_extra['ba_lambda_min'] = args.lambda_min
     if args.lm_wide is not None: st_extra['ba_lm_wide_band'] = args.lm_wide
+    if args.trust_radius is not None: st_extra['ba_trust_radius'] = args.trust_radius
     flight, sc = pipeline.staged_scene(nc, nobs, seed=seed, settings=st_extra, perturb=0.3, **kw)
     print('scene: %d cameras, %d detections (%s), start trajectory %.0f..%.0f of 0..%.0f, %d control points; set-up %.2f s'
           % (nc, sum(d.shape[1] for d in flight.detections), [d.shape[1] for d in flight.detections], flight.spline['int'][0, 0],
