@@ -97,6 +97,7 @@ def main():
     ap.add_argument('--solver', choices=['trf', 'lm'], default=os.environ.get('MVUS_BENCH_SOLVER', 'lm'))
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-parity-solver', action='store_true', help='skip the extra timing of the scipy-TRF+LSMR restatement')
+    ap.add_argument('--no-strong-config3', action='store_true', help='N>1: skip the strong-scaling sub-record on BASELINE configs[3]')
     ap.add_argument('--obs', type=int, default=None, help='override the detection count of the config (kernel studies at other sizes; the workload string says so)')
     ap.add_argument('--shard', choices=['time', 'obs'], default=None, help='N>1: how observations are cut over the ranks (default: time for lm, obs for trf)')
     ap.add_argument('--collective', choices=['rccl', 'torch', 'auto'], default=None,
@@ -230,6 +231,36 @@ def main():
         key = 'config%d_calib%d' % (args.config, int(prob.opt_calib))
         traffic = json.load(open(tpath)).get(key, {}).get('bytes_per_launch')
 
+    # N > 1 on a weak-scaling default: the node's strong-scaling figure on BASELINE configs[3] (64 cams x 2M obs cut over the ranks) as a
+    # sub-record of the same line, so that a scaling run lands on a configuration BASELINE.json lists whichever default it was started with
+    strong3 = None
+    if world > 1 and not strong and args.solver == 'lm' and not args.no_strong_config3:
+        kw3 = dict(synth.BASELINE_CONFIGS[3])
+        scene3 = synth.make_scene(**kw3)
+        prob3, x03 = mp.problem_from_scene(scene3)
+        h3, _ = sharded_handle(prob3, rank, world, local_rank, time_x=x03 if shard_mode == 'time' else None, collective=collective)
+        x3 = x03.copy()
+        for _ in range(2):
+            x3 = h3.solve(x3, solver=solver, jac_mode=jac_mode, max_nfev=2, return_fun=False, ties='canonical').x
+        barrier()
+        t3 = time.perf_counter()
+        n3 = 5
+        c3 = None
+        for _ in range(n3):
+            r3 = h3.solve(x3, solver=solver, jac_mode=jac_mode, max_nfev=2, return_fun=False, ties='canonical')
+            x3 = r3.x
+            c3 = r3.initial_cost if c3 is None else c3
+        barrier()
+        dt3 = time.perf_counter() - t3
+        tm3 = torch.tensor([dt3], dtype=torch.float64, device='cuda')
+        dist.all_reduce(tm3, op=dist.ReduceOp.MAX)
+        dt3 = float(tm3.item())
+        strong3 = {'workload': 'BASELINE configs[3]: %d cams x %d obs cut over %d ranks (%s shards), strong scaling' % (prob3.C, prob3.M, world, shard_mode),
+                   'n_gpus': world, 'steps': n3, 'ms_per_step': 1e3 * dt3 / n3, 'residuals_per_sec': prob3.M * n3 / dt3,
+                   'ba_iters_per_sec': n3 / dt3, 'collective': getattr(h3, 'collective_used', None), 'cost_first': c3, 'cost_last': r3.cost,
+                   'one_gpu_ms_per_step': 'profiles/: bench.py --config 3 on one GPU'}
+        h3.close()
+
     if rank == 0:
         M_total = prob.M
         out = {
@@ -256,6 +287,7 @@ def main():
                          'one_buffer': {'avg_launch_ms': t_rj_one, 'achieved': bytes_launch / (t_rj_one * 1e-3) / 1e9,
                                         'frac': bytes_launch / (t_rj_one * 1e-3) / 1e9 / HBM_PEAK_GBS}},
             'parity_solver': parity,
+            'strong_config3': strong3,
             'kernels_ms': {'residual': t_r, 'residual_jacobian': t_rj, 'jv': t_jv, 'jtu': t_jtu, 'normal_eq_assembly_from_J': t_asm,
                            'fused_jacobian_normal_eq_assembly': t_fused},
         }

@@ -58,3 +58,8 @@ def test_two_rank_bench_weak_scaling_default_config():
     assert 'configs[2]' in out['config']['workload'] and out['config']['parallelism'] == 'time-shard x2'
     assert out['config']['cost_last'] < out['config']['cost_first']
     assert abs(out['value'] * out['ms_per_step'] * 1e-3 - 1_000_000) < 50_000      # ~500k per rank, summed over the ranks
+    # ... and the same line carries the node's STRONG-scaling figure on the configuration BASELINE.json lists for it (configs[3])
+    s3 = out['strong_config3']
+    assert s3['n_gpus'] == 2 and 'configs[3]' in s3['workload'] and '64 cams' in s3['workload']
+    assert s3['ms_per_step'] > 0 and abs(s3['residuals_per_sec'] * s3['ms_per_step'] * 1e-3 - 2_000_000) < 50_000
+    assert s3['cost_last'] <= s3['cost_first']
