@@ -220,10 +220,19 @@ def main():
         fd = timed(ba.JAC_FD, prep_fd)
         fd.update({'solver': 'trf_lsmr, jac = scipy 2-point finite differences with column groups (the DEFAULT of Scene.BA; common.py:670)',
                    'column_groups': ngroups[0]})
+        # the same default with ONE pass over J per LSMR iteration (MVUS_LSMR_ONE_PASS=1: u kept unnormalised, J v and J^T u from one read
+        # of J; opt-in because the unconverged 10-evaluation iterate of one parity fixture leaves its bar -- DESIGN section 7)
+        os.environ['MVUS_LSMR_ONE_PASS'] = '1'
+        try:
+            fd1 = timed(ba.JAC_FD, prep_fd)
+        finally:
+            del os.environ['MVUS_LSMR_ONE_PASS']
+        fd1['solver'] = 'as default_fd, MVUS_LSMR_ONE_PASS=1'
         pat = timed(ba.JAC_PATTERN, lambda xs: handle.prepare_pattern(xs, ties='canonical'))
         pat['solver'] = 'trf_lsmr (scipy restatement, analytic J masked to the reference pattern)'
         parity = dict(pat)
         parity['default_fd'] = fd
+        parity['default_fd_one_pass'] = fd1
 
     traffic = None
     tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')

@@ -547,7 +547,7 @@ struct HipBackend {
   // z_is_zero: the caller guarantees z == 0 on entry (the device-resident LSMR loop clears it while consuming it);
   // reuse_index: zfill of the previous call is still valid (same Jacobian, hence the same window starts)
   int32_t* jt_first = nullptr;            // [N][C] first covering chunk per (control point, camera): valid while reuse_index calls follow one another
-  void jtu_local(const double* u, double* z, bool z_is_zero = false, bool reuse_index = false, bool build_first = false) {
+  void jtu_buffers() {
     if (!zc) {
       const size_t nc = std::max<size_t>(hp.chunks.size(), 1);
       zc = dalloc<double>(nc * (size_t)(hp.NS - 12)); zs = dalloc<double>(nc * 3 * (size_t)kJtWin); zg0 = dalloc<int32_t>(nc); zfill = dalloc<int32_t>(nc);
@@ -555,6 +555,9 @@ struct HipBackend {
       jt_nondet = dalloc<int>(1);
       MVUS_HIP(hipMemsetAsync(jt_nondet, 0, sizeof(int), stream));
     }
+  }
+  void jtu_local(const double* u, double* z, bool z_is_zero = false, bool reuse_index = false, bool build_first = false) {
+    jtu_buffers();
     if (!z_is_zero) MVUS_HIP(hipMemsetAsync(z, 0, sizeof(double) * hp.n, stream));
     if (!reuse_index) MVUS_HIP(hipMemsetAsync(jt_bounds, 0, 2 * sizeof(int), stream));
     const dim3 g2(hp.C + (hp.N + kThreads / 64 - 1) / (kThreads / 64)), b(kThreads);
@@ -584,6 +587,8 @@ struct HipBackend {
   LsmrScalars* lsmr_state = nullptr;       // [2] device
   LsmrScalars* lsmr_host = nullptr;        // pinned
   double* lsmr_part = nullptr;             // [3][2048] partial sums (u.u, v.v, x.x) + beta
+  double* lsmr_pu = nullptr;               // per-workgroup partials of |u'|^2 of the one-pass form (k_jvjtu)
+  size_t lsmr_pu_cap = 0;
   bool lsmr_on_device() const { return !allreduce && std::getenv("MVUS_LSMR_HOST") == nullptr; }
   void lsmr_iterations(LsmrScalars& sc, double* ut, double* tm, double* v, double* tn, double* h, double* hbar, double* x) {
     if (!lsmr_state) {
@@ -600,15 +605,39 @@ struct HipBackend {
     const int batch = 8;
     long long launched = 0;
     MVUS_HIP(hipMemsetAsync(tn, 0, sizeof(double) * n, stream));        // J^T u adds into a zeroed vector; k_lsmr_v clears it again while reading it
+    // MVUS_LSMR_ONE_PASS=1: one pass over J per iteration (k_jvjtu: u kept unnormalised, its norm in *ubeta).  Opt-in: the converged
+    // answers stay inside the parity bars either way, but the unconverged 10-evaluation iterate of one fixture (dist_fixed_2cam) moves
+    // outside the bars measured with the two-pass arithmetic
+    const bool one_pass = dp.n_chunks > 0 && std::getenv("MVUS_LSMR_ONE_PASS") != nullptr;
+    const unsigned gj = (unsigned)(xcd_grid(dp.n_chunks) + (hp.T > 0 ? (hp.T + kThreads - 1) / kThreads : 0));
+    double* ubeta = beta_dev + 1;
+    if (one_pass) {
+      if (lsmr_pu_cap < (size_t)gj) { lsmr_pu = dalloc<double>(gj); lsmr_pu_cap = gj; }
+      jtu_buffers();
+      const double one = 1.0;
+      MVUS_HIP(hipMemcpyAsync(ubeta, &one, sizeof(double), hipMemcpyHostToDevice, stream));       // (ut arrives normalised)
+      MVUS_HIP(hipMemsetAsync(jt_bounds, 0, 2 * sizeof(int), stream));
+    }
     while (true) {
       for (int b = 0; b < batch && launched < sc.maxiter; ++b, ++launched) {
         const LsmrScalars* c = lsmr_state + cur;
         LsmrScalars* nx = lsmr_state + (cur ^ 1);
+        if (one_pass) {
+          const dim3 g2(hp.C + (hp.N + kThreads / 64 - 1) / (kThreads / 64)), bt(kThreads);
+          const int motion = hp.T > 0 ? 1 : 0;
+          if (hp.calib) hipLaunchKernelGGL(k_jvjtu<30>, dim3(gj), bt, 0, stream, dp, J, span, v, ut, c, ubeta, lsmr_pu, tn, zc, zs, zg0, jt_nondet, zext, mJ, mctrl);
+          else hipLaunchKernelGGL(k_jvjtu<21>, dim3(gj), bt, 0, stream, dp, J, span, v, ut, c, ubeta, lsmr_pu, tn, zc, zs, zg0, jt_nondet, zext, mJ, mctrl);
+          if (launched == 0) { hipLaunchKernelGGL(k_jtu_index, dim3(hp.C), dim3(64), 0, stream, dp, zg0, zfill, zext, jt_bounds); build_jt_first(); }
+          if (hp.calib) hipLaunchKernelGGL(k_jtu_reduce<30>, g2, bt, 0, stream, dp, zc, zs, zg0, zfill, mJ, mctrl, ut + 2 * hp.M, motion, tn, jt_first, jt_bounds);
+          else hipLaunchKernelGGL(k_jtu_reduce<21>, g2, bt, 0, stream, dp, zc, zs, zg0, zfill, mJ, mctrl, ut + 2 * hp.M, motion, tn, jt_first, jt_bounds);
+          hipLaunchKernelGGL(k_lsmr_v1, dim3(gn), dim3(kThreads), 0, stream, n, tn, v, c, (int)gj, lsmr_pu, beta_dev, ubeta, pv);
+        } else {
         jv(v, tm);
         hipLaunchKernelGGL(k_lsmr_u, dim3(gm), dim3(kThreads), 0, stream, m, tm, ut, c, pu);
         hipLaunchKernelGGL(k_lsmr_unorm, dim3(gm), dim3(kThreads), 0, stream, m, ut, gm, pu, c, beta_dev);
         jtu_local(ut, tn, true, launched > 0, launched == 0);
         hipLaunchKernelGGL(k_lsmr_v, dim3(gn), dim3(kThreads), 0, stream, n, tn, v, c, beta_dev, pv);
+        }
         hipLaunchKernelGGL(k_lsmr_update, dim3(gn), dim3(kThreads), 0, stream, n, v, h, hbar, x, gn, pv, c, beta_dev, nx, px);
         hipLaunchKernelGGL(k_lsmr_test, dim3(1), dim3(kThreads), 0, stream, gn, px, c, nx);
         cur ^= 1;

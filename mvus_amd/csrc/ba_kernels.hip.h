@@ -828,6 +828,170 @@ __device__ __forceinline__ void dot_partial_store(double s, double* __restrict__
     partials[blockIdx.x] = t;
   }
 }
+// ---- ONE pass over J per LSMR iteration (round 5): u' = J v - alpha u and the first pass of z = J^T u' in the same kernel -------------
+// The Golub-Kahan step of LSMR is  u <- (J v - alpha u) / beta,  v <- J^T u - beta v  -- two passes over J (k_jv, k_jtu_partial) with
+// the normalisation of u between them.  Here u is kept UNNORMALISED (ut holds u' = beta u, *ubeta its norm): a row's slots are read
+// once, give the row's entry of u' = J v - (alpha / ubeta_old) u'_old, which is stored, squared into the workgroup's partial of
+// |u'|^2 and multiplied straight back into the row for the per-chunk sums of J^T u' (k_jtu_partial's second half, unchanged);
+// k_lsmr_v1 then forms beta = |u'| and v <- (J^T u') / beta - beta v.  J is read once per iteration (183 MB at configs[2]) and three
+// launches go (k_jv, k_lsmr_u, k_lsmr_unorm).  The iterates differ from the two-pass form's in the last bits ((J^T u') / beta against
+// J^T (u' / beta)), so the form is opt-in: MVUS_LSMR_ONE_PASS=1.  Workgroups past xcd_grid(n_chunks): the motion rows of u'.
+template <int NS>
+__global__ __launch_bounds__(kThreads) void k_jvjtu(DevProblem dp, const double* __restrict__ J, const int32_t* __restrict__ span,
+                                                    const double* __restrict__ v, double* __restrict__ ut, const LsmrScalars* __restrict__ cur,
+                                                    const double* __restrict__ ubeta, double* __restrict__ pu, double* __restrict__ z,
+                                                    double* __restrict__ zc, double* __restrict__ zs, int32_t* __restrict__ zg0,
+                                                    int* __restrict__ nondet, int32_t* __restrict__ zext, const double* __restrict__ mJ,
+                                                    const int32_t* __restrict__ mctrl) {
+  constexpr int B = NS - 12;
+  constexpr int PS = kThreads + 1;
+  __shared__ double part[kThreads / 64][B];
+  __shared__ double prod[12 * PS];
+  __shared__ int lo[kJtWin], hi[kJtWin], skey[kThreads];
+  __shared__ int gmin_s[kThreads / 64];
+  __shared__ int bad_s, wide_s, lmax_s;
+  __shared__ double vc[B];
+  if (cur->istop != 0) return;
+  const double cu = -cur->alpha / *ubeta;
+  if ((int)blockIdx.x >= xcd_grid(dp.n_chunks)) {                    // motion rows
+    const int j = ((int)blockIdx.x - xcd_grid(dp.n_chunks)) * kThreads + threadIdx.x;
+    double w = 0.0;
+    if (j < dp.T) {
+      double* um = ut + 2 * (long long)dp.M;
+      w = motion_row_times(dp, mJ, mctrl, v, j) + cu * um[j];
+      um[j] = w;
+    }
+    dot_partial_store(w * w, pu);
+    return;
+  }
+  const int chunk = xcd_tile(dp.n_chunks);
+  if (chunk >= dp.n_chunks) { dot_partial_store(0.0, pu); return; }
+  const ChunkInfo ci = dp.chunks[chunk];
+  const bool active = (int)threadIdx.x < ci.count;
+  const long long i = ci.start + (active ? threadIdx.x : 0);
+  const long long a = ci.cam_start, Mc = ci.cam_count;
+  const int g = active ? span[i] : -1;
+  const double* __restrict__ Jc = J + j_chunk_offset<NS>(chunk) + (active ? threadIdx.x : 0);
+  if (threadIdx.x < B) vc[threadIdx.x] = v[cam_col(dp.C, dp.P, dp.chunk_cam[chunk], threadIdx.x)];
+  __syncthreads();
+  double ux = 0.0, uy = 0.0;
+  {
+    double sx = 0.0, sy = 0.0;
+    if (g >= 0) {
+#pragma unroll
+      for (int k = 0; k < B; ++k) {
+        sx += Jc[k * kThreads] * vc[k];
+        sy += Jc[(NS + k) * kThreads] * vc[k];
+      }
+      const int x0 = dp.mv.ctrl_x0[g], st = dp.mv.ctrl_stride[g];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          const double vv = v[x0 + q + d * st];
+          sx += Jc[(B + 3 * q + d) * kThreads] * vv;
+          sy += Jc[(NS + B + 3 * q + d) * kThreads] * vv;
+        }
+    }
+    if (active) {
+      ux = sx + cu * ut[2 * a + (i - a)];
+      uy = sy + cu * ut[2 * a + Mc + (i - a)];
+      ut[2 * a + (i - a)] = ux;
+      ut[2 * a + Mc + (i - a)] = uy;
+    }
+    dot_partial_store(ux * ux + uy * uy, pu);
+    if (g < 0) { ux = 0.0; uy = 0.0; }                               // (rows without a visible span have no Jacobian entries)
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int k = threadIdx.x; k < kJtWin; k += kThreads) { lo[k] = 0x7fffffff; hi[k] = 0; }
+  if (threadIdx.x == 0) { bad_s = 0; wide_s = 0; lmax_s = -1; }
+  skey[threadIdx.x] = g;
+  int gm = g >= 0 ? g : 0x7fffffff;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) gm = min(gm, __shfl_xor(gm, off, 64));
+  if (lane == 0) gmin_s[wave] = gm;
+#pragma unroll
+  for (int k = 0; k < B; ++k) {
+    double val = 0.0;
+    if (g >= 0) val = Jc[k * kThreads] * ux + Jc[(NS + k) * kThreads] * uy;
+    val = wave_sum_lane0(val);
+    if (lane == 0) part[wave][k] = val;
+  }
+  __syncthreads();
+  int g0 = gmin_s[0];
+#pragma unroll
+  for (int w = 1; w < kThreads / 64; ++w) g0 = min(g0, gmin_s[w]);
+  if (threadIdx.x < B) {
+    double sacc = 0.0;
+#pragma unroll
+    for (int w = 0; w < kThreads / 64; ++w) sacc += part[w][threadIdx.x];
+    zc[(long long)chunk * B + threadIdx.x] = sacc;
+  }
+  if (threadIdx.x == 0) { zg0[chunk] = g0; if (zext != nullptr && g0 == 0x7fffffff) zext[chunk] = 0; }
+  double* zw = zs + (long long)chunk * (3 * kJtWin);
+  if (g0 == 0x7fffffff) return;                       // nothing visible (uniform): pass 2 skips the chunk
+  const int l = g - g0;
+  double pv[12];
+#pragma unroll
+  for (int e = 0; e < 12; ++e) {
+    pv[e] = g >= 0 ? Jc[(B + e) * kThreads] * ux + Jc[(NS + B + e) * kThreads] * uy : 0.0;
+    prod[e * PS + threadIdx.x] = pv[e];
+  }
+  if (g >= 0) {
+    if (l + 3 >= kJtWin) atomicOr(&wide_s, 1);
+    else {
+      // only the ends of a run of equal span can set the minimum / maximum of their span's index range (LDS atomics serialise
+      // per address: a run of r detections cost 2 r of them, now 2)
+      const int tid = threadIdx.x;
+      if (tid == 0 || skey[tid - 1] != g) atomicMin(&lo[l], tid);
+      if (tid == kThreads - 1 || skey[tid + 1] != g) { atomicMax(&hi[l], tid + 1); atomicMax(&lmax_s, l); }
+    }
+  }
+  __syncthreads();
+  // do the index ranges of consecutive non-empty spans overlap (detections not in span order)?  Each non-empty span looks for the
+  // next one -- up to the last span in use only: scanning the empty tail of the 144-wide window took the last span's thread
+  // ~60 dependent LDS reads, 15 of the kernel's 49 us
+  if (threadIdx.x < kJtWin && hi[threadIdx.x] > 0) {
+    const int last = lmax_s;
+    for (int t = threadIdx.x + 1; t <= last; ++t)
+      if (hi[t] > 0) { if (lo[t] < hi[threadIdx.x]) atomicOr(&bad_s, 1); break; }
+  }
+  __syncthreads();
+  // how many control points of the window this chunk really reaches (k_jtu_index takes the maximum over the chunks: pass 2 then
+  // looks only at chunks that can cover its control point instead of at all whose 144-wide window does)
+  if (threadIdx.x == 0 && zext != nullptr) zext[chunk] = wide_s ? 0 : lmax_s + 4;
+  if (wide_s) {                                        // detections spread over more control points than the window holds
+    if (threadIdx.x == 0) { zg0[chunk] = 0x7fffffff; atomicAdd(nondet, 1); }
+    if (g >= 0) {
+      const int x0 = dp.mv.ctrl_x0[g], st = dp.mv.ctrl_stride[g];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) unsafeAtomicAdd(&z[x0 + q + d * st], pv[3 * q + d]);
+    }
+    return;
+  }
+  for (int o = threadIdx.x; o < 3 * kJtWin; o += kThreads) {
+    const int lc = o / 3, d = o % 3;
+    double acc = 0.0;
+    if (!bad_s) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int sidx = lc - q;
+        if (sidx < 0) continue;
+        const int b = lo[sidx], e = hi[sidx];
+        for (int t = b; t < e; ++t) acc += prod[(3 * q + d) * PS + t];
+      }
+    } else {                                           // interleaved spans: every detection, in index order
+      for (int t = 0; t < ci.count; ++t) {
+        const int q = lc - (skey[t] - g0);
+        if (skey[t] >= 0 && q >= 0 && q < 4) acc += prod[(3 * q + d) * PS + t];
+      }
+    }
+    zw[o] = acc;
+  }
+}
+
 // u = A v - alpha u (A v is in tm), partial sums of u.u
 __global__ __launch_bounds__(kThreads) void k_lsmr_u(long long m, const double* __restrict__ tm, double* __restrict__ ut,
                                                      const LsmrScalars* __restrict__ cur, double* __restrict__ partials) {
@@ -863,6 +1027,31 @@ __global__ __launch_bounds__(kThreads) void k_lsmr_v(long long n, double* __rest
     return;
   }
   const double a = cur->one, b = -beta;
+  double s = 0.0;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const double w = a * tn[i] + b * v[i];
+    tn[i] = 0.0;
+    v[i] = w;
+    s += w * w;
+  }
+  dot_partial_store(s, partials);
+}
+// one-pass form: beta = |u'| from the partials of k_jvjtu (every workgroup sums them itself: same tree, same bits; workgroup 0
+// records beta and the new norm of ut), then v = (J^T u') / beta - beta v and the partial sums of v.v
+__global__ __launch_bounds__(kThreads) void k_lsmr_v1(long long n, double* __restrict__ tn, double* __restrict__ v, const LsmrScalars* __restrict__ cur,
+                                                      int nbu, const double* __restrict__ pu, double* __restrict__ beta_out, double* __restrict__ ubeta,
+                                                      double* __restrict__ partials) {
+  double beta = 0.0;
+  if (cur->istop == 0) {
+    beta = sqrt(dot_final_block(nbu, pu));
+    if (blockIdx.x == 0 && threadIdx.x == 0) { *beta_out = beta; if (beta > 0) *ubeta = beta; }
+  }
+  if (cur->istop != 0 || !(beta > 0)) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) tn[i] = 0.0;
+    if (cur->istop == 0 && threadIdx.x == 0) partials[blockIdx.x] = 0.0;
+    return;
+  }
+  const double a = 1.0 / beta, b = -beta;
   double s = 0.0;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
     const double w = a * tn[i] + b * v[i];

@@ -369,15 +369,22 @@ def test_fd_mode_ba_vs_reference_result(BAHandle, name):
     assert flips <= flip_tol, flips
 
 
+@pytest.mark.parametrize('passes', ['two', 'one'])
 @pytest.mark.parametrize('name', CONVERGED_CASES)
-def test_converged_second_ba_fd_mode(BAHandle, name):
+def test_converged_second_ba_fd_mode(BAHandle, name, passes, monkeypatch):
     """North-star parity at the one point where it is decidable: the reference's second BA (main.py:59) run with max_iter=200
     (status 3 on the four small scenes; the well-posed calibration scene uses all 200 evaluations, status 0).  The reference's
     algorithm on the GPU -- TRF + LSMR + grouped forward differences over the reference's matrix -- from the reference's
     start.  Compared with the reference's result: same status, the ANSWER ITSELF (res.x is all the caller reads,
     common.py:672-695) in gauge-invariant terms -- trajectory at the detection time stamps and camera centres / orientations
     after the best similarity, beta differences, alpha ratios, rs, and K, d with opt_calib (tests/gauge.py) -- and the final
-    RMSE, each within SPREAD_FACTOR x the reference's own reproducibility; inlier mask at that point identical."""
+    RMSE, each within SPREAD_FACTOR x the reference's own reproducibility; inlier mask at that point identical.
+    passes = 'one': the LSMR iteration with ONE pass over J (MVUS_LSMR_ONE_PASS=1, round 5) -- another order of the same sums; the
+    converged answer must sit inside the same bars."""
+    if passes == 'one':
+        monkeypatch.setenv('MVUS_LSMR_ONE_PASS', '1')
+    else:
+        monkeypatch.delenv('MVUS_LSMR_ONE_PASS', raising=False)
     scene, g = filtered_case(name)
     prob, _ = mp.problem_from_scene(scene)
     oprob, _ = orc.problem_from_scene(scene)
@@ -387,8 +394,8 @@ def test_converged_second_ba_fd_mode(BAHandle, name):
     spread = reference_spread(oprob, name, g['ba2_200_x'])
     c = gauge.compare(oprob, g['ba2_200_x'], r.x)
     d_rmse = c['rmse_b'] - float(g['ba2_200_rmse'])
-    print('converged FD %s: rmse %+.2e px (spread %.1e), cost %.9g vs %.9g, nfev %d vs %d, status %d; x vs reference / spread: %s'
-          % (name, d_rmse, spread['rmse'], r.cost, float(g['ba2_200_cost']), r.nfev, int(g['ba2_200_nfev']), r.status,
+    print('converged FD (%s-pass LSMR) %s: rmse %+.2e px (spread %.1e), cost %.9g vs %.9g, nfev %d vs %d, status %d; x vs reference / spread: %s'
+          % (passes, name, d_rmse, spread['rmse'], r.cost, float(g['ba2_200_cost']), r.nfev, int(g['ba2_200_nfev']), r.status,
              ' '.join('%s %.1e/%.1e' % (k, c[k], spread[k]) for k in spread if k != 'rmse')))
     assert r.status == int(g['ba2_200_status'])
     assert abs(r.nfev - int(g['ba2_200_nfev'])) <= 6
