@@ -22,6 +22,14 @@ _ERRORS = {_lib.MVUS_E_INVALID: ValueError, _lib.MVUS_E_NUMERIC: ValueError, _li
            _lib.MVUS_E_COMM: RuntimeError, _lib.MVUS_E_UNSUPPORTED: UnsupportedBySolver}
 
 
+class _Result(SimpleNamespace):
+    """OptimizeResult-like; ``active_mask`` (all zeros: the rs box is handled by projection) is built on first use."""
+
+    @property
+    def active_mask(self):
+        return np.zeros(self.x.shape[0])
+
+
 class BAHandle:
     def __init__(self, prob, device=0, stream=None):
         self.lib = _lib.load()
@@ -219,10 +227,9 @@ class BAHandle:
         f = np.empty(self.m) if return_fun else None
         self._check(self.lib.mvus_ba_solve(self.h, _lib.dptr(x), ctypes.byref(o), ctypes.byref(res),
                                            _lib.dptr(f) if return_fun else None), 'mvus_ba_solve')
-        return SimpleNamespace(x=x, cost=res.cost, fun=f, nfev=res.nfev, njev=res.njev, status=res.status,
-                               optimality=res.optimality, lin_iters=res.lin_iters, solve_ms=res.solve_ms,
-                               initial_cost=res.initial_cost, success=res.status > 0,
-                               active_mask=np.zeros(self.n), grad=None, jac=None)
+        return _Result(x=x, cost=res.cost, fun=f, nfev=res.nfev, njev=res.njev, status=res.status,
+                       optimality=res.optimality, lin_iters=res.lin_iters, solve_ms=res.solve_ms,
+                       initial_cost=res.initial_cost, success=res.status > 0, grad=None, jac=None)
 
     def outlier_mask(self, x, thres):
         """Per-detection ``error < thres`` (camera-segmented order), dtype bool."""

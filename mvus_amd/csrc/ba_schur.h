@@ -76,8 +76,14 @@ SolveResult lm_schur(B& be, Schur& sc, std::vector<double>& x, const std::vector
   const int64_t n = be.n(), m = be.m_local();
   if (!in_bounds(x, lb, ub)) { res.error = -3; return res; }
   PoolGuard<B> pool(be);             // returned on every exit, exceptions included (a time shard can throw out of solve_ok)
-  double* x_dev = pool.get(n);
-  double* xt_dev = pool.get(n);
+  // the current and the trial point live in two buffers the backend keeps from solve to solve: a caller that continues from the point
+  // the previous solve returned (an outer loop of short solves -- bench.py's steps, Scene.BA after remove_outliers) finds it on the
+  // device already (lm_resume: bitwise comparison with the host copy of that point) and x does not cross PCIe again
+  int xcur = be.lm_resume(x.data());
+  const bool resumed = xcur >= 0;
+  if (!resumed) xcur = 0;
+  double* x_dev = be.lm_xbuf(xcur);
+  double* xt_dev = be.lm_xbuf(xcur ^ 1);
   double* f_new = pool.get(m);
   auto cleanup = [] {};
   be.set_bounds(lb, ub);
@@ -86,7 +92,7 @@ SolveResult lm_schur(B& be, Schur& sc, std::vector<double>& x, const std::vector
   double* S = be.lm_scalars();   // [0] |f|^2 at x0, [1] projected |g|_inf, [2..5] trial scalars, [6] |f(x_trial)|^2
   double hs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
-  be.upload(x_dev, x.data(), n);
+  if (!resumed) be.upload(x_dev, x.data(), n);
   // (the first linearisation follows at once: its storage is zeroed beside this evaluation where the backend can do that)
   if (be.residual_sq(x_dev, f_dev, S, sc.clear_ptr(), sc.clear_len())) sc.mark_cleared();
   res.nfev = 1; res.njev = 1;
@@ -207,6 +213,7 @@ SolveResult lm_schur(B& be, Schur& sc, std::vector<double>& x, const std::vector
   if (mir_cur < 0) { /* no step was accepted: x is the caller's x0 */ }
   else if (be.mirror_host(mir_cur)) std::copy(be.mirror_host(mir_cur), be.mirror_host(mir_cur) + n, x.begin());   // written by the accepted trial's kernel, fetched since
   else be.download(x.data(), x_dev, n);
+  be.lm_remember(x_dev, x.data());
   res.status = status;
   res.cost = cost;
   res.optimality = g_norm;

@@ -69,6 +69,10 @@ struct HostBackend {
   }
   static constexpr bool kSwapResiduals = false;
   static constexpr bool kDeviceLsmr = false;
+  std::vector<double> lm_x[2];
+  double* lm_xbuf(int k) { lm_x[k].resize((size_t)hp.n); return lm_x[k].data(); }
+  int lm_resume(const double*) { return -1; }
+  void lm_remember(const double*, const double*) {}
   double* mirror_dev(int) { return nullptr; }
   const double* mirror_host(int) const { return nullptr; }
   void adopt_residual(double*&, double*&) {}
