@@ -48,18 +48,6 @@ __device__ __forceinline__ bcr_d4 rcs_mma(bcr_d4 p, bcr_d4 q, bcr_d4 acc) {
   for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(p[s], q[s], acc, 0, 0, 0);
   return acc;
 }
-// the same product as FOUR independent matrix-core instructions and three vector adds.  A v_mfma_f64_16x16x4 that accumulates
-// into the result of the previous one waits for it: measured on this part ~250 cycles per link of such a chain (the trsm kernel's
-// nine steps of 2 + 4 dependent instructions took 32 k cycles), against ~110 cycles of issue for independent ones.  Every product on
-// a critical path is therefore formed this way; the order of the four partial sums differs from rcs_mma's.
-__device__ __forceinline__ bcr_d4 rcs_mma4(bcr_d4 p, bcr_d4 q, bcr_d4 acc) {
-  const bcr_d4 zero{0.0, 0.0, 0.0, 0.0};
-  const bcr_d4 a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(p[0], q[0], acc, 0, 0, 0);
-  const bcr_d4 a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(p[1], q[1], zero, 0, 0, 0);
-  const bcr_d4 a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(p[2], q[2], zero, 0, 0, 0);
-  const bcr_d4 a3 = __builtin_amdgcn_mfma_f64_16x16x4f64(p[3], q[3], zero, 0, 0, 0);
-  return (a0 + a1) + (a2 + a3);
-}
 // y = M w from img(M) and w[lr] (the value of this lane's column): the sums over the 16 lanes of a row by DPP row shifts;
 // lane lr == 15 of row lk ends with y[lk + 4r] in out[r]
 __device__ __forceinline__ bcr_d4 rcs_matvec(bcr_d4 img, double w) {
@@ -342,7 +330,7 @@ __global__ __launch_bounds__(kRcsFactorThreads) void k_rcs_factor(RcsView rv, in
         bcr_d4 xi;                                                   // img(X_k^T)[lane][s] = X_k[lr][lk + 4s]; Xb holds X column-major
 #pragma unroll
         for (int r = 0; r < 4; ++r) xi[r] = Xb[k * 256 + (lk + 4 * r) * 16 + lr];
-        const bcr_d4 t = rcs_mma4(xi, sl[k], zero);
+        const bcr_d4 t = rcs_mma(xi, sl[k], zero);
         sl[k] = t;
 #pragma unroll
         for (int r = 0; r < 4; ++r) sc[r] = -rdb[k * 16 + lk + 4 * r] * t[r];
@@ -352,7 +340,7 @@ __global__ __launch_bounds__(kRcsFactorThreads) void k_rcs_factor(RcsView rv, in
       // stages it for the pivot wavefront: ONE barrier then publishes both the panel and the next pivot block
       const int kn = k + 1 < kRcsSP ? k + 1 : 0;                     // (k + 1 < nc <= kRcsSP when used; the clamp keeps the unrolled index static)
       if (owner) {
-        sl[kn] = rcs_mma4(sl[k], sc, sl[kn]);
+        sl[kn] = rcs_mma(sl[k], sc, sl[kn]);
 #pragma unroll
         for (int r = 0; r < 4; ++r) Dm[(lk + 4 * r) * 17 + lr] = sl[kn][r];
         __builtin_amdgcn_s_setprio(0);
@@ -455,8 +443,8 @@ __device__ __forceinline__ void rcs_stage(const RcsView& rv, int c0, int nc, dou
 // block rows below the diagonal super-block: T_ik = X_k (U_ik - sum_{k' < k} T_kk'^T Delta_k'^-1 T_ik'), k ascending.  ONE block row per
 // workgroup, four wavefronts = four SIMDs: wavefront w holds the row's blocks of the columns jl = w, w + 4, w + 8.  Step k: the
 // wavefront that holds column k forms T_ik and hands its scaled image to the others through LDS (two buffers, one barrier per step),
-// every wavefront then updates the blocks it holds -- the matrix-core instructions of different blocks interleaved, because a
-// dependent v_mfma_f64_16x16x4 waits ~130 cycles for its accumulator.
+// every wavefront then updates the blocks it holds.  (v_mfma_f64_16x16x4 issues in 64 cycles whether or not it accumulates into the
+// previous result -- profiles/r05_fp64_issue_rates.txt -- so the order of the matrix-core instructions does not matter.)
 __global__ __launch_bounds__(64 * kRcsTrsmWaves) void k_rcs_trsm(RcsView rv, int c0) {
   extern __shared__ __attribute__((aligned(32))) double rcs_lds[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lk = lane >> 4;
@@ -479,7 +467,7 @@ __global__ __launch_bounds__(64 * kRcsTrsmWaves) void k_rcs_trsm(RcsView rv, int
   for (int k = 0; k < kRcsSP; ++k) {
     if (k >= nc) continue;
     if (wave == k % kRcsTrsmWaves) {
-      const bcr_d4 t = rcs_mma4(rcs_load(rcs_lds + k * 256 + lane * 4), s[k / kRcsTrsmWaves], zero);
+      const bcr_d4 t = rcs_mma(rcs_load(rcs_lds + k * 256 + lane * 4), s[k / kRcsTrsmWaves], zero);
       s[k / kRcsTrsmWaves] = t;
       bcr_d4 sc;
 #pragma unroll
@@ -538,19 +526,10 @@ __global__ __launch_bounds__(256) void k_rcs_syrk(RcsView rv, int c0) {
     pj[k] = rcs_load(rv.Simg + rcs_blk(gj, c0 + k) + lane * 4);
     qi[k] = rcs_load(rv.Tsc + rcs_blk(gi, c0 + k) + lane * 4);
   }
-  // sixteen independent accumulation chains would be ideal; four (one per K-slice of the 16 x 16 x 16 products) keep the dependent
-  // links at nine instead of thirty-six
-  const bcr_d4 zero{0.0, 0.0, 0.0, 0.0};
-  bcr_d4 a1 = zero, a2 = zero, a3 = zero;
 #pragma unroll
-  for (int k = 0; k < kRcsSP; ++k) {
-    if (k >= nc) continue;
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pj[k][0], qi[k][0], acc, 0, 0, 0);
-    a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(pj[k][1], qi[k][1], a1, 0, 0, 0);
-    a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(pj[k][2], qi[k][2], a2, 0, 0, 0);
-    a3 = __builtin_amdgcn_mfma_f64_16x16x4f64(pj[k][3], qi[k][3], a3, 0, 0, 0);
-  }
-  rcs_store(blk, (acc + a1) + (a2 + a3));
+  for (int k = 0; k < kRcsSP; ++k)
+    if (k < nc) acc = rcs_mma(pj[k], qi[k], acc);
+  rcs_store(blk, acc);
 }
 
 // x = L^-T Delta^-1 t for the super-panels Kfirst .. 0 (the last one is solved inside its k_rcs_factor launch, its x is in rv.x),

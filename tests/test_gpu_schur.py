@@ -432,3 +432,23 @@ def test_lm_trust_region_gpu_matches_host_driver():
     assert (r.nfev, r.status) == (rh.nfev, rh.status)
     np.testing.assert_allclose(r.cost, rh.cost, rtol=1e-7)
     np.testing.assert_allclose(r.x, xh, rtol=0, atol=1e-6 * max(1.0, np.abs(xh).max()))
+
+
+def test_lm_resumes_from_the_point_it_returned_without_an_upload():
+    """The LM driver keeps its current / trial point on the device from solve to solve: a caller that continues from the x the previous
+    solve returned finds it there (bitwise comparison with the host copy) and x is not uploaded again.  The continued solve must give
+    the same bits as one that had to upload the same point (here: after an intervening one-evaluation solve from another point)."""
+    from mvus_amd.ba import BAHandle
+    scene, g = load_case('rs_F_2int_3cam')
+    prob, x0 = mp.problem_from_scene(scene)
+    kw = dict(solver=_lib.SOLVER_LM_SCHUR, jac_mode=_lib.JAC_ANALYTIC)
+    with BAHandle(prob) as h:
+        r1 = h.solve(g['x0'], max_nfev=8, **kw)
+        r2 = h.solve(r1.x.copy(), max_nfev=8, **kw)                      # resumed: the point is on the device
+    with BAHandle(prob) as h:
+        q1 = h.solve(g['x0'], max_nfev=8, **kw)
+        h.solve(g['x0'], max_nfev=1, **kw)                                # no trial, no change of the damping; the remembered point is x0 now
+        q2 = h.solve(q1.x.copy(), max_nfev=8, **kw)                      # uploaded
+    assert np.array_equal(r1.x, q1.x) and r1.cost == q1.cost
+    assert np.array_equal(r2.x, q2.x) and r2.cost == q2.cost and r2.nfev == q2.nfev
+    assert r2.cost < r1.cost
