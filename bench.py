@@ -45,7 +45,7 @@ def algorithmic_bytes(prob):
     return per_obs, once
 
 
-def cpu_baseline(config_index, full_scene=None):
+def cpu_baseline(config_index, full_scene=None, full_ba=False):
     """The reference's CPU path restated (oracle: numpy residual + scipy least_squares with the sparsity
     pattern, exactly the call of common.py:670), single core, on a 1/32-scale sample of the workload; plus -- the anchor for that
     sample -- ONE evaluation of the oracle's residual (error_BA) on the full-size workload."""
@@ -75,7 +75,17 @@ def cpu_baseline(config_index, full_scene=None):
             orc.residual(fprob, fx0)
             dtf = time.perf_counter() - t1
         Mf = sum(d.shape[1] for d in fprob.detections)
-        full = {'value': Mf / dtf, 'unit': 'residuals/s', 'seconds_per_evaluation': dtf, 'obs': Mf,
+        full_ba_rec = None
+        if full_ba:                                       # --cpu-full: the reference's BA on the FULL workload, 10 evaluations, one core (minutes)
+            with threadpool_limits(limits=1):
+                t2 = time.perf_counter()
+                rfull = orc.solve(fprob, fx0, max_iter=10)
+                dtb = time.perf_counter() - t2
+            itb = max(rfull.nfev - 1, 1)
+            full_ba_rec = {'value': Mf * itb / dtb, 'unit': 'residuals/s', 'ba_iters_per_s': itb / dtb, 'seconds': dtb, 'nfev': int(rfull.nfev),
+                           'cost_last': float(rfull.cost),
+                           'what': 'oracle restatement of Scene.BA (scipy least_squares, jac_sparsity, lsmr, 2-point FD) on the full-size workload, max_nfev = 10, 1 core'}
+        full = {'value': Mf / dtf, 'unit': 'residuals/s', 'seconds_per_evaluation': dtf, 'obs': Mf, 'full_size_ba': full_ba_rec,
                 'what': 'one evaluation of the oracle residual (error_BA restated, numpy, 1 core) on the FULL workload; a BA iteration of '
                         'the reference costs (column groups + 1) such evaluations for its 2-point Jacobian plus the LSMR solve'}
     import numpy, scipy
@@ -96,6 +106,7 @@ def main():
     ap.add_argument('--config', type=int, default=2, help='index into BASELINE.json configs (2 = 32 cams x 500k obs)')
     ap.add_argument('--solver', choices=['trf', 'lm'], default=os.environ.get('MVUS_BENCH_SOLVER', 'lm'))
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-full', action='store_true', help='N=1: also time a full-size 10-evaluation BA of the oracle (scipy path, one core; minutes) -> cpu_baseline.residual_only_full_size.full_size_ba')
     ap.add_argument('--no-parity-solver', action='store_true', help='skip the extra timing of the scipy-TRF+LSMR restatement')
     ap.add_argument('--no-strong-config3', action='store_true', help='N>1: skip the strong-scaling sub-record on BASELINE configs[3]')
     ap.add_argument('--obs', type=int, default=None, help='override the detection count of the config (kernel studies at other sizes; the workload string says so)')
@@ -301,7 +312,7 @@ def main():
                            'fused_jacobian_normal_eq_assembly': t_fused},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(args.config, scene)
+            out['cpu_baseline'] = cpu_baseline(args.config, scene, args.cpu_full)
         print(json.dumps(out))
     handle.close()
     if world > 1:
