@@ -43,6 +43,12 @@ extern "C" {
 #define MVUS_E_UNSUPPORTED (-5)  /* the problem is outside what this solver handles (MVUS_SOLVER_LM_SCHUR: motion rows that couple control
                                  * points more than 16 apart, or more than 6 apart on a time shard): the other solver has no such limit */
 
+#define MVUS_E_RESHARD (-6)  /* time shard (mvus_ba_set_time_shard): at the point the solver has reached, a detection or motion row touches
+                              * control points outside this rank's slice +- halo (the time stamps drifted since the cuts were made).
+                              * mvus_ba_solve then RETURNS that point in x (and nfev / cost so far in res): the caller re-cuts there
+                              * and continues (mvus_amd.dist.solve_time_sharded).  Raised on every rank of the job together.
+                              * The reference re-evaluates visibility at every call: common.py:317, tools/util.py:90-116 */
+
 #define MVUS_MOTION_F 0  /* constant-force prior       common.py:984-998 */
 #define MVUS_MOTION_KE 1 /* constant-kinetic-energy    common.py:976-981 */
 

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('MVUS_LIB_PATH') or os.path.join(_HERE, 'csrc', 'libmvusba.so')   # override: kernel experiments
 
 MVUS_OK = 0
-MVUS_E_INVALID, MVUS_E_HIP, MVUS_E_NUMERIC, MVUS_E_COMM, MVUS_E_UNSUPPORTED = -1, -2, -3, -4, -5
+MVUS_E_INVALID, MVUS_E_HIP, MVUS_E_NUMERIC, MVUS_E_COMM, MVUS_E_UNSUPPORTED, MVUS_E_RESHARD = -1, -2, -3, -4, -5, -6
 JAC_ANALYTIC, JAC_PATTERN, JAC_FD = 0, 1, 2
 PAT_SHIFT, PAT_TIE = 25, 1 << 30          # pattern codes of mvus_ba_set_pattern (include/mvus_ba.h)
 SOLVER_TRF_LSMR, SOLVER_LM_SCHUR = 0, 1

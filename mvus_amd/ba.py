@@ -18,6 +18,13 @@ class UnsupportedBySolver(RuntimeError):
     """MVUS_E_UNSUPPORTED: the problem is outside what the chosen solver handles (see include/mvus_ba.h); the other solver has no such limit."""
 
 
+class ReshardNeeded(RuntimeError):
+    """MVUS_E_RESHARD: on a time shard the time stamps have drifted until a row reaches control points outside the slice.  ``x`` is the
+    point the solver had reached, ``nfev`` the evaluations it used: re-cut there and continue (mvus_amd.dist.solve_time_sharded)."""
+    x = None
+    nfev = 0
+
+
 _ERRORS = {_lib.MVUS_E_INVALID: ValueError, _lib.MVUS_E_NUMERIC: ValueError, _lib.MVUS_E_HIP: RuntimeError,
            _lib.MVUS_E_COMM: RuntimeError, _lib.MVUS_E_UNSUPPORTED: UnsupportedBySolver}
 
@@ -225,8 +232,12 @@ class BAHandle:
             self.set_pattern(x, download=False)      # canonical codes stay on the GPU: no host round trip (clears an uploaded pattern)
         res = _lib.MvusResult()
         f = np.empty(self.m) if return_fun else None
-        self._check(self.lib.mvus_ba_solve(self.h, _lib.dptr(x), ctypes.byref(o), ctypes.byref(res),
-                                           _lib.dptr(f) if return_fun else None), 'mvus_ba_solve')
+        rc = self.lib.mvus_ba_solve(self.h, _lib.dptr(x), ctypes.byref(o), ctypes.byref(res), _lib.dptr(f) if return_fun else None)
+        if rc == _lib.MVUS_E_RESHARD:
+            e = ReshardNeeded('mvus_ba_solve: %s' % self.lib.mvus_last_error(self.h).decode())
+            e.x, e.nfev, e.cost = x, int(res.nfev), float(res.cost)
+            raise e
+        self._check(rc, 'mvus_ba_solve')
         return _Result(x=x, cost=res.cost, fun=f, nfev=res.nfev, njev=res.njev, status=res.status,
                        optimality=res.optimality, lin_iters=res.lin_iters, solve_ms=res.solve_ms,
                        initial_cost=res.initial_cost, success=res.status > 0, grad=None, jac=None)

@@ -261,6 +261,8 @@ struct HipBackend {
   bool fixed_bounds_on_device = false;
   double *lb_dev = nullptr, *ub_dev = nullptr;
   double* tr_pn2 = nullptr;         // |p|^2 of the damped step (trust region of the LM driver)
+  bool reshard_flag = false;        // set by HipSchur::solve_ok when a row left the time slice
+  bool reshard_pending() { const bool r = reshard_flag; reshard_flag = false; return r; }
   // current / trial point of the LM driver, kept from solve to solve (ba_schur.h: lm_resume)
   double* lm_x[2] = {nullptr, nullptr};
   std::vector<double> lm_last_host;
@@ -1152,6 +1154,15 @@ int mvus_ba_solve(mvus_ba* h, double* x, const mvus_solve_opts* opts, mvus_resul
       if (sr.jac_stale) be.has_jacobian = false;      // mvus_ba_jv / jtu / lm_step must not pair J(x_old) with f(x_new)
     }
     else sr = trf_lsmr(be, xv, lb, ub, so, be.f_cur);
+    if (sr.error == -4) {            // a row left the time slice: the point reached so far goes back to the caller, who re-cuts there
+      std::memcpy(x, xv.data(), sizeof(double) * n);
+      MVUS_HIP(hipStreamSynchronize(be.stream));
+      h->schur.reset();              // (the device flag is raised: the next solve on this handle starts from fresh storage)
+      res->cost = sr.cost; res->optimality = 0; res->nfev = sr.nfev; res->njev = sr.njev; res->status = 0; res->lin_iters = sr.lin_iters;
+      res->initial_cost = sr.initial_cost; res->solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      be.err = "time shard: a detection or motion row reaches control points outside this rank's slice +- halo (the time stamps have drifted since the cuts were made): re-cut at the returned point";
+      return MVUS_E_RESHARD;
+    }
     if (sr.error) { be.err = "residuals are not finite in the initial point, or x0 is outside of the bounds"; return MVUS_E_NUMERIC; }
     std::memcpy(x, xv.data(), sizeof(double) * n);
     if (f_out) be.download(f_out, be.f_cur, be.hp.m);

@@ -105,6 +105,8 @@ SolveResult lm_schur(B& be, Schur& sc, std::vector<double>& x, const std::vector
     else be.copy(f_dev, f_new, m);
   };
   int mir_cur = -1, mir_trial = 0;      // host mirrors of the accepted / the trial point (backend permitting)
+  double cost = 0;
+  try {
   // Trust region in the reference's metric (mvus_solve_opts.lm_trust_radius): scipy's TRF with x_scale = 1 bounds |step|_2 by Delta
   // (scipy/optimize/_lsq/trf.py: Delta_0 = |x0|, or 1 when that is 0) and updates it with update_tr_radius (_lsq/common.py).  The
   // damped step p(lambda) is cut back to Delta along its direction by the trial kernel; S[7] brings |p|^2 back.
@@ -124,7 +126,6 @@ SolveResult lm_schur(B& be, Schur& sc, std::vector<double>& x, const std::vector
 
   double lambda = std::max(opt.lm_lambda0 > 0 ? opt.lm_lambda0 : 1e-4, opt.lm_lambda_min), nu = opt.lm_nu0 > 0 ? opt.lm_nu0 : 2.0;
   const double lambda_min = opt.lm_lambda_min;
-  double cost = 0;
   bool cost_known = false;
   int status = -1;
   double g_norm = 0;
@@ -210,15 +211,21 @@ SolveResult lm_schur(B& be, Schur& sc, std::vector<double>& x, const std::vector
     }
   }
   if (status == -1) status = 0;
+  res.status = status;
+  res.optimality = g_norm;
+  res.lm_lambda = lambda;
+  res.lm_nu = nu;
+  } catch (...) {
+    // a time shard whose rows have left the slice (backend: reshard_pending): not an error of the solve -- the point reached so far
+    // goes back to the caller (error -4 -> MVUS_E_RESHARD), who re-cuts the timeline there and continues
+    if (!be.reshard_pending()) throw;
+    res.error = -4;
+  }
   if (mir_cur < 0) { /* no step was accepted: x is the caller's x0 */ }
   else if (be.mirror_host(mir_cur)) std::copy(be.mirror_host(mir_cur), be.mirror_host(mir_cur) + n, x.begin());   // written by the accepted trial's kernel, fetched since
   else be.download(x.data(), x_dev, n);
   be.lm_remember(x_dev, x.data());
-  res.status = status;
   res.cost = cost;
-  res.optimality = g_norm;
-  res.lm_lambda = lambda;
-  res.lm_nu = nu;
   cleanup();
   return res;
 }

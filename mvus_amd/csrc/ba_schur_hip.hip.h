@@ -2638,7 +2638,10 @@ struct HipSchur {
   const int* fail_ptr() const { return fail; }
   bool solve_ok() const {                 // valid after the stream has been synchronised (the driver's fetch)
     if (fail_host[1] & 2) throw HipError{"fused assembly: the span table does not belong to the point being linearised (internal error)"};
-    if (fail_host[1] != 0) throw HipError{"time shard: a detection or motion row reaches control points outside this rank's slice (halo too small for the time-stamp drift)"};
+    if (fail_host[1] != 0) {
+      be.reshard_flag = true;        // (the LM driver hands the point it has reached back to the caller: MVUS_E_RESHARD)
+      throw HipError{"time shard: a detection or motion row reaches control points outside this rank's slice +- halo (the time stamps have drifted since the cuts were made): re-cut at the returned point", MVUS_E_RESHARD};
+    }
     if (fail_host[0] != 0 && std::getenv("MVUS_DEBUG")) std::fprintf(stderr, "schur solve: fail code %d\n", fail_host[0]);
     return fail_host[0] == 0;
   }

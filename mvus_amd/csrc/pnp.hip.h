@@ -63,41 +63,73 @@ MVUS_HD void inv_transpose3(const double* A, double det, double* out) {       //
 // Pose from six 3-D points Xs[6][3] and their normalised, undistorted image coordinates xn[6][2] by the direct linear
 // transform: P (3x4, up to scale) = the eigenvector of the smallest eigenvalue of A^T A (12x12; two rows per point),
 // found by inverse iteration; then P = s [R | t] with R the rotation nearest to the left 3x3 block.  false: degenerate sample.
+// (The 12x12 matrix is kept as its packed lower triangle, 78 doubles, and every loop over it is unrolled: all indices are compile-time
+// constants, so on the GPU the triangle lives in registers -- as a [12][12] array indexed by loop variables it was 1 216 bytes of
+// scratch per lane, rounds 2 - 4.)
+#define MVUS_TRI(a, b) ((a) * ((a) + 1) / 2 + (b))
 MVUS_HD bool pnp_dlt6(const double (*Xs)[3], const double (*xn)[2], double* R, double* t) {
-  double M[12][12];
-  for (int a = 0; a < 12; ++a) for (int b = 0; b < 12; ++b) M[a][b] = 0.0;
+  double M[78];
+#pragma unroll
+  for (int e = 0; e < 78; ++e) M[e] = 0.0;
+#pragma unroll
   for (int p = 0; p < 6; ++p) {
     const double X = Xs[p][0], Y = Xs[p][1], Z = Xs[p][2], x = xn[p][0], y = xn[p][1];
     const double r1[12] = {X, Y, Z, 1.0, 0.0, 0.0, 0.0, 0.0, -x * X, -x * Y, -x * Z, -x};
     const double r2[12] = {0.0, 0.0, 0.0, 0.0, X, Y, Z, 1.0, -y * X, -y * Y, -y * Z, -y};
-    for (int a = 0; a < 12; ++a) for (int b = 0; b <= a; ++b) M[a][b] += r1[a] * r1[b] + r2[a] * r2[b];
+#pragma unroll
+    for (int a = 0; a < 12; ++a)
+#pragma unroll
+      for (int b = 0; b <= a; ++b) M[MVUS_TRI(a, b)] += r1[a] * r1[b] + r2[a] * r2[b];
   }
   double tr = 0.0;
-  for (int a = 0; a < 12; ++a) tr += M[a][a];
+#pragma unroll
+  for (int a = 0; a < 12; ++a) tr += M[MVUS_TRI(a, a)];
   if (!(tr > 0.0)) return false;
   const double mu = 1e-13 * tr;
-  for (int a = 0; a < 12; ++a) M[a][a] += mu;
+#pragma unroll
+  for (int a = 0; a < 12; ++a) M[MVUS_TRI(a, a)] += mu;
+  bool bad = false;
+#pragma unroll
   for (int j = 0; j < 12; ++j) {                                            // Cholesky, lower triangle in place
-    double dsum = M[j][j];
-    for (int k = 0; k < j; ++k) dsum -= M[j][k] * M[j][k];
-    if (!(dsum > 0.0)) return false;
-    const double l = sqrt(dsum);
-    M[j][j] = l;
+    double dsum = M[MVUS_TRI(j, j)];
+#pragma unroll
+    for (int k = 0; k < j; ++k) dsum -= M[MVUS_TRI(j, k)] * M[MVUS_TRI(j, k)];
+    bad |= !(dsum > 0.0);
+    const double l = sqrt(dsum > 0.0 ? dsum : 1.0);
+    M[MVUS_TRI(j, j)] = l;
+#pragma unroll
     for (int i = j + 1; i < 12; ++i) {
-      double s = M[i][j];
-      for (int k = 0; k < j; ++k) s -= M[i][k] * M[j][k];
-      M[i][j] = s / l;
+      double sacc = M[MVUS_TRI(i, j)];
+#pragma unroll
+      for (int k = 0; k < j; ++k) sacc -= M[MVUS_TRI(i, k)] * M[MVUS_TRI(j, k)];
+      M[MVUS_TRI(i, j)] = sacc / l;
     }
   }
+  if (bad) return false;
   double v[12];
+#pragma unroll
   for (int a = 0; a < 12; ++a) v[a] = 1.0 + 0.37 * a - 0.11 * a * a;          // a fixed start that is not an eigenvector of anything in particular
   for (int it = 0; it < 6; ++it) {
-    for (int i = 0; i < 12; ++i) { double s = v[i]; for (int k = 0; k < i; ++k) s -= M[i][k] * v[k]; v[i] = s / M[i][i]; }
-    for (int i = 11; i >= 0; --i) { double s = v[i]; for (int k = i + 1; k < 12; ++k) s -= M[k][i] * v[k]; v[i] = s / M[i][i]; }
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      double sacc = v[i];
+#pragma unroll
+      for (int k = 0; k < i; ++k) sacc -= M[MVUS_TRI(i, k)] * v[k];
+      v[i] = sacc / M[MVUS_TRI(i, i)];
+    }
+#pragma unroll
+    for (int i = 11; i >= 0; --i) {
+      double sacc = v[i];
+#pragma unroll
+      for (int k = i + 1; k < 12; ++k) sacc -= M[MVUS_TRI(k, i)] * v[k];
+      v[i] = sacc / M[MVUS_TRI(i, i)];
+    }
     double nn = 0.0;
+#pragma unroll
     for (int a = 0; a < 12; ++a) nn += v[a] * v[a];
     if (!(nn > 0.0) || !(nn < 1e300)) return false;
     nn = 1.0 / sqrt(nn);
+#pragma unroll
     for (int a = 0; a < 12; ++a) v[a] *= nn;
   }
   double A[9] = {v[0], v[1], v[2], v[4], v[5], v[6], v[8], v[9], v[10]};

@@ -143,6 +143,33 @@ def sharded_handle(prob, rank, world, device_index, group=None, time_x=None, hal
     return h, keep
 
 
+def solve_time_sharded(make_handle, x0, max_nfev=10, max_recuts=4, **solve_kw):
+    """LM on time shards that survives drifting time stamps.  ``make_handle(x)`` returns this rank's handle with the timeline cut at x
+    (``sharded_handle(prob, rank, world, device, time_x=x, ...)[0]``, or a test's own construction); when the solver reports that a
+    row has left its slice (``ReshardNeeded``: raised on every rank together, carrying the point reached so far) the timeline is cut
+    again at that point and the solve continues with the evaluations that are left -- the reference re-evaluates visibility at every
+    call (common.py:317, tools/util.py:90-116); here that costs one shard_time + handle per re-cut, counted in ``result.recuts``."""
+    from .ba import ReshardNeeded
+    x = np.array(x0, dtype=np.float64)
+    left, recuts, used = int(max_nfev), 0, 0
+    while True:
+        h = make_handle(x)
+        try:
+            r = h.solve(x, max_nfev=max(left, 1), **solve_kw)
+            r.recuts, r.nfev_total = recuts, used + r.nfev
+            return r
+        except ReshardNeeded as e:
+            recuts += 1
+            if recuts > max_recuts:
+                raise
+            x = np.array(e.x)
+            # (the evaluation at the start of the next solve repeats the last one of this solve: it is not charged twice)
+            used += max(e.nfev - 1, 0)
+            left = max(int(max_nfev) - used, 2)
+        finally:
+            h.close()
+
+
 def shard_sizes(prob, world):
     return [sum(sharding.shard_offsets(int(prob.det_offsets[c + 1] - prob.det_offsets[c]), r, world)[1]
                 - sharding.shard_offsets(int(prob.det_offsets[c + 1] - prob.det_offsets[c]), r, world)[0]

@@ -72,6 +72,7 @@ struct HostBackend {
   std::vector<double> lm_x[2];
   double* lm_xbuf(int k) { lm_x[k].resize((size_t)hp.n); return lm_x[k].data(); }
   int lm_resume(const double*) { return -1; }
+  bool reshard_pending() { return false; }
   void lm_remember(const double*, const double*) {}
   double* mirror_dev(int) { return nullptr; }
   const double* mirror_host(int) const { return nullptr; }

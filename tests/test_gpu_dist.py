@@ -446,3 +446,67 @@ def test_ba_outliers_ba_on_time_shards():
         np.testing.assert_allclose(r2.cost, ref2.cost, rtol=1e-9)
         np.testing.assert_allclose(r2.x, ref2.x, rtol=0, atol=1e-7 * max(1.0, np.abs(ref2.x).max()))
     np.testing.assert_array_equal(keep_all, keep_ref)
+
+
+def test_time_shards_are_cut_again_when_the_time_stamps_drift():
+    """The 60-frame shift of the test above, through mvus_amd.dist.solve_time_sharded: MVUS_E_RESHARD hands the point reached so far
+    back on both ranks, the timeline is cut again THERE, and the sharded solve ends where the unsharded solve from the same start ends
+    (the reference re-evaluates visibility at every call: common.py:317, tools/util.py:90-116)."""
+    import threading
+    import torch
+    from mvus_amd import synth
+    from mvus_amd.ba import BAHandle
+    from mvus_amd.dist import _DeviceDoubles, solve_time_sharded
+    sc = synth.make_scene(3, 6000, seed=41, rolling_shutter=True, num_knots=300)
+    prob, x0 = mp.problem_from_scene(sc)
+    x_bad = x0.copy()
+    x_bad[prob.C:2 * prob.C] += 60.0
+    kw = dict(solver=_lib.SOLVER_LM_SCHUR, jac_mode=_lib.JAC_ANALYTIC)
+    with BAHandle(prob) as h:
+        ref = h.solve(x_bad, max_nfev=8, **kw)
+    world = 2
+    barrier = threading.Barrier(world)
+    bufs, total, errors, out = [None] * world, [None], [], [None] * world
+
+    def make_cb(rank):
+        def cb(ptr, count, stream):
+            t = torch.as_tensor(_DeviceDoubles(ptr, count), device='cuda:0')
+            torch.cuda.synchronize()
+            bufs[rank] = t
+            barrier.wait(30)
+            if rank == 0:
+                total[0] = bufs[0] + bufs[1]
+                torch.cuda.synchronize()
+            barrier.wait(30)
+            t.copy_(total[0])
+            torch.cuda.synchronize()
+            barrier.wait(30)
+        return cb
+
+    def run(rank):
+        try:
+            first = [True]
+
+            def make_handle(x):
+                # the FIRST cuts are made at x0 (where the time stamps were when the job was set up), later ones at the point handed back
+                shard, keep, cuts = prob.shard_time(rank, world, x0 if first[0] else x)
+                first[0] = False
+                h = BAHandle(shard, device=0)
+                h.set_time_shard(rank, world, cuts)
+                h.set_allreduce(make_cb(rank), is_root=(rank == 0))
+                return h
+            out[rank] = solve_time_sharded(make_handle, x_bad, max_nfev=8, **kw)
+        except Exception as e:
+            import traceback
+            errors.append(traceback.format_exc())
+            barrier.abort()
+
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in ts: t.start()
+    for t in ts: t.join(180)
+    assert not errors, errors[0]
+    r0, r1 = out
+    assert r0.recuts == r1.recuts == 1                                            # cut once more, at the start point
+    assert np.array_equal(r0.x, r1.x)
+    np.testing.assert_allclose(r0.cost, ref.cost, rtol=1e-9)
+    np.testing.assert_allclose(r0.x, ref.x, rtol=0, atol=1e-6 * max(1.0, np.abs(ref.x).max()))
