@@ -28,7 +28,7 @@
 namespace mvus {
 
 constexpr int kRcsSP = 9;                   // 16-column blocks per super-panel
-constexpr int kRcsFactorThreads = 64 * (kRcsSP + 2);      // ten row-owning wavefronts (nine block rows + the right-hand side) + the pivot wavefront
+constexpr int kRcsFactorThreads = 64 * (kRcsSP + 3);      // ten row-owning wavefronts (nine block rows + the right-hand side), the pivot wavefront, the publisher
 constexpr int kRcsTrsmWaves = 4;            // wavefronts per block row (= workgroup) of k_rcs_trsm
 
 struct RcsView {
@@ -133,13 +133,15 @@ __device__ __forceinline__ void rcs_ldl16(double (&a)[16], double (&x)[16], doub
 // S = (A + lambda D_c) - sum_slabs Gp[:, :CB] and rhs = gc - sum_slabs Gp[:, CB] (k_schur_finish's sums), written as block images:
 // lower block triangle, identity on the padding of the last block, the right-hand side as block row nbk.
 // Grid (ntile, ntile + 1) of 32x32 tiles, the last row of the grid writes the right-hand side.
-__global__ __launch_bounds__(256) void k_rcs_finish(NEView ne, int ncols, int nslab, double lambda, const double* __restrict__ Gp, RcsView rv) {
+__global__ __launch_bounds__(256) void k_rcs_finish(NEView ne, int ncols, int nslab, double lambda, const double* __restrict__ Gp, RcsView rv,
+                                                    unsigned* __restrict__ flags) {
   constexpr int kT = 32, kRowsPer = 4, kRowStep = 8;
   const int r0 = threadIdx.x / kT, c = threadIdx.x % kT;
   const int b = blockIdx.x * kT + c;
   const long long stride = (long long)ne.CB * ncols;
   const int nn = ne.CB, npad = rv.nbk * 16;
   if (blockIdx.y == gridDim.y - 1) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) flags[0] = 0u;          // the hand-over counter of the factor launches that follow
     if (r0 != 0 || b >= npad) return;
     double gr = 0.0;
     if (b < nn) {
@@ -196,6 +198,45 @@ __global__ __launch_bounds__(256) void k_rcs_finish(NEView ne, int ncols, int ns
     rv.Simg[rcs_blk(a / 16, b / 16) + ((cc % 4) * 16 + a % 16) * 4 + cc / 4] = v;
   }
 }
+
+// ---- hand-over of a finished panel step to the workgroups that solve the block rows BELOW the diagonal super-block, inside the
+// launch (k_rcs_factor, blockIdx.x > 0).  The recipe of the CDNA programming guide (Guideline 16, R1): the producer stores the payload
+// WRITE-THROUGH (sc1 -- other XCDs' L2s and the readers' L1s are not coherent with ours), waits for its stores (s_waitcnt vmcnt(0)),
+// then one lane stores the step number with a relaxed agent-scope atomic; a consumer polls that one word (relaxed, s_sleep between
+// polls, BOUNDED: a time-out raises fail[0] = 3 instead of hanging the device) and reads the payload with sc1 loads.
+using rcs_u4 = __attribute__((ext_vector_type(4))) unsigned;
+struct RcsWide { rcs_u4 a, b; };
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rcs_rsrc(double* p, size_t doubles) {
+  return __builtin_amdgcn_make_buffer_rsrc(p, 0, (int)(doubles * sizeof(double)), 0x00020000);
+}
+__device__ __forceinline__ void rcs_store_sc1(__amdgpu_buffer_rsrc_t r, long long dbl_off, bcr_d4 v) {
+  RcsWide w;
+  __builtin_memcpy(&w, &v, sizeof(w));
+  __builtin_amdgcn_raw_buffer_store_b128(w.a, r, (int)(dbl_off * 8), 0, 16);
+  __builtin_amdgcn_raw_buffer_store_b128(w.b, r, (int)(dbl_off * 8 + 16), 0, 16);
+}
+__device__ __forceinline__ bcr_d4 rcs_load_sc1(__amdgpu_buffer_rsrc_t r, long long dbl_off) {
+  RcsWide w;
+  w.a = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(dbl_off * 8), 0, 16);
+  w.b = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(dbl_off * 8 + 16), 0, 16);
+  bcr_d4 v;
+  __builtin_memcpy(&v, &w, sizeof(v));
+  return v;
+}
+__device__ __forceinline__ double rcs_load1_sc1(__amdgpu_buffer_rsrc_t r, long long dbl_off) {
+  using u2 = __attribute__((ext_vector_type(2))) unsigned;
+  const u2 w = __builtin_amdgcn_raw_buffer_load_b64(r, (int)(dbl_off * 8), 0, 16);
+  double v;
+  __builtin_memcpy(&v, &w, sizeof(v));
+  return v;
+}
+__device__ __forceinline__ void rcs_store1_sc1(__amdgpu_buffer_rsrc_t r, long long dbl_off, double v) {
+  using u2 = __attribute__((ext_vector_type(2))) unsigned;
+  u2 w;
+  __builtin_memcpy(&w, &v, sizeof(w));
+  __builtin_amdgcn_raw_buffer_store_b64(w, r, (int)(dbl_off * 8), 0, 16);
+}
+constexpr unsigned kRcsSpinLimit = 1u << 21;                         // polls (each >= ~100 ns): far beyond any legitimate wait
 
 // x_i[c] = sum_j X[j][c] w[j] for lane c of a 16-lane row (col: the lane's column of X, 16 contiguous doubles in LDS; w: this lane's
 // entry of w, handed round by DPP row broadcasts)
@@ -260,13 +301,124 @@ __device__ __forceinline__ void rcs_pivot_role(int nc, int* __restrict__ fail, d
 // last update; wavefront 10 factorises the diagonal blocks (the pivot chain) and is handed block (k + 1, k + 1) as soon as its owner has
 // applied panel k to it: the other updates of panel k run beside the chain.  Eleven wavefronts = three per SIMD, <= 168 registers each
 // (with two row blocks per wavefront and 256 registers the compiler's scheduler let the pivot chain's pressure grow until it spilled).
-__global__ __launch_bounds__(kRcsFactorThreads) void k_rcs_factor(RcsView rv, int c0, int* __restrict__ fail, int last, double* __restrict__ pc) {
+// block rows below the diagonal super-block, solved INSIDE the factor launch (blockIdx.x >= 1: one block row per workgroup, its first
+// four wavefronts): the algorithm of k_rcs_trsm, but each step waits for the factor workgroup's flag and reads that step's X_k, 1/d_k
+// and T_jk with sc1 loads.  The rows' chain is shorter than the pivot chain, so these workgroups trail the factorisation by about one
+// step and finish ~1 step after it: the 18 us launch of k_rcs_trsm (and its kernel boundary) disappear from the critical path.
+__device__ __forceinline__ void rcs_trsm_role(RcsView rv, int c0, int nc, unsigned* __restrict__ flags, int* __restrict__ fail, double* __restrict__ xch,
+                                              int* __restrict__ abort_s) {
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lk = lane >> 4;
+  const int c1 = c0 + nc, gi = c1 + (int)blockIdx.x - 1;
+  const size_t tot = rcs_doubles(rv.nn);
+  const __amdgpu_buffer_rsrc_t rS = rcs_rsrc(rv.Simg, tot), rT = rcs_rsrc(rv.Tsc, tot);
+  constexpr int kSlots = (kRcsSP + kRcsTrsmWaves - 1) / kRcsTrsmWaves;
+  bcr_d4 s[kSlots];
+  const bcr_d4 zero{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int u = 0; u < kSlots; ++u) {
+    const int jl = wave + kRcsTrsmWaves * u;
+    s[u] = jl < nc ? rcs_load(rv.Simg + rcs_blk(gi, c0 + jl) + lane * 4) : zero;      // (written by earlier launches: plain loads)
+  }
+  if (threadIdx.x == 0) *abort_s = 0;
+  lds_barrier();
+#pragma unroll
+  for (int k = 0; k < kRcsSP; ++k) {
+    if (k >= nc) continue;
+    if (threadIdx.x == 0 && *abort_s == 0) {                         // one lane polls one word
+      const unsigned want = (unsigned)(c0 * 16 + k + 1);
+      unsigned spins = 0;
+      while (__hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > kRcsSpinLimit) { *abort_s = 1; fail[0] = 3; break; }
+      }
+    }
+    lds_barrier();
+    const bool dead = *abort_s != 0;
+    bcr_d4 tj[kSlots];
+    bool up[kSlots];
+#pragma unroll
+    for (int u = 0; u < kSlots; ++u) {
+      const int jl = wave + kRcsTrsmWaves * u;
+      up[u] = jl > k && jl < nc && !dead;
+      tj[u] = up[u] ? rcs_load_sc1(rS, rcs_blk(c0 + jl, c0 + k) + lane * 4) : zero;
+    }
+    if (wave == k % kRcsTrsmWaves && !dead) {
+      const bcr_d4 xi = rcs_load_sc1(rS, rcs_blk(c0 + k, c0 + k) + lane * 4);
+      bcr_d4 nrd;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) nrd[r] = -rcs_load1_sc1(rT, rcs_blk(c0 + k, c0 + k) + lk + 4 * r);
+      const bcr_d4 t = rcs_mma(xi, s[k / kRcsTrsmWaves], zero);
+      s[k / kRcsTrsmWaves] = t;
+      rcs_store(xch + (k & 1) * 256 + lane * 4, t * nrd);
+    }
+    lds_barrier();
+    if (k + 1 >= nc || dead) continue;
+    const bcr_d4 sc = rcs_load(xch + (k & 1) * 256 + lane * 4);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int u = 0; u < kSlots; ++u)
+        if (up[u]) s[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(tj[u][q], sc[q], s[u], 0, 0, 0);
+  }
+#pragma unroll
+  for (int u = 0; u < kSlots; ++u) {                                 // the row's T blocks and their scaled images, for k_rcs_syrk / the substitution
+    const int jl = wave + kRcsTrsmWaves * u;
+    if (jl >= nc) continue;
+    bcr_d4 sc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sc[r] = -rcs_load1_sc1(rT, rcs_blk(c0 + jl, c0 + jl) + lk + 4 * r) * s[u][r];
+    rcs_store(rv.Simg + rcs_blk(gi, c0 + jl) + lane * 4, s[u]);
+    rcs_store(rv.Tsc + rcs_blk(gi, c0 + jl) + lane * 4, sc);
+  }
+}
+
+// the twelfth wavefront of the factor workgroup: after the barrier that completes panel k it copies X_k, 1/d_k and the panel's T_jk
+// from LDS to global memory with write-through stores; the step number is published one step LATER, when those stores are certainly
+// acknowledged (s_waitcnt vmcnt(0) finds nothing to wait for) -- the wavefront must never make the others wait at a barrier
+__device__ __forceinline__ void rcs_publisher_role(RcsView rv, int c0, int nc, unsigned* __restrict__ flags, const double* __restrict__ Xb,
+                                                   const double* __restrict__ rdb, const double* __restrict__ panel) {
+  const int lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
+  const size_t tot = rcs_doubles(rv.nn);
+  const __amdgpu_buffer_rsrc_t rS = rcs_rsrc(rv.Simg, tot), rT = rcs_rsrc(rv.Tsc, tot);
+  lds_barrier();                                                     // B0
+  for (int k = 0; k < nc; ++k) {
+    lds_barrier();                                                   // b1
+    if (k > 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) __hip_atomic_store(flags, (unsigned)(c0 * 16 + k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // steps 0 .. k - 1
+    }
+    lds_barrier();                                                   // b2: panel k complete
+    bcr_d4 xi;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xi[r] = Xb[k * 256 + (lk + 4 * r) * 16 + lr];
+    rcs_store_sc1(rS, rcs_blk(c0 + k, c0 + k) + lane * 4, xi);
+    if (lane < 16) rcs_store1_sc1(rT, rcs_blk(c0 + k, c0 + k) + lane, rdb[k * 16 + lane]);
+    for (int jl = k + 1; jl < nc; ++jl) rcs_store_sc1(rS, rcs_blk(c0 + jl, c0 + k) + lane * 4, rcs_load(panel + jl * 256 + lane * 4));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // (the LDS reads are done before the panel is overwritten: next b1)
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (lane == 0) __hip_atomic_store(flags, (unsigned)(c0 * 16 + nc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(kRcsFactorThreads) void k_rcs_factor(RcsView rv, int c0, int* __restrict__ fail, int last, double* __restrict__ pc,
+                                                                  unsigned* __restrict__ flags) {
   __shared__ double Dm[16 * 17];
   __shared__ __attribute__((aligned(32))) double Xb[kRcsSP * 256];
   __shared__ __attribute__((aligned(32))) double rdb[kRcsSP * 16];
   __shared__ __attribute__((aligned(32))) double panel[(kRcsSP + 1) * 256];
+  __shared__ int abort_s;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lr = lane & 15, lk = lane >> 4;
   const int nc = min(kRcsSP, rv.nbk - c0), R = rv.nbk;
+  if (blockIdx.x > 0) {                                              // a block row below the super-block
+    if (wave < kRcsTrsmWaves) rcs_trsm_role(rv, c0, nc, flags, fail, panel, &abort_s);
+    return;
+  }
+  if (wave == kRcsSP + 2) {                                          // the publisher (it takes part in every barrier of the chain)
+    if (gridDim.x > 1) rcs_publisher_role(rv, c0, nc, flags, Xb, rdb, panel);
+    else { lds_barrier(); for (int k = 0; k < nc; ++k) { lds_barrier(); lds_barrier(); } }
+    if (last) { lds_barrier(); for (int i = 0; i < nc; ++i) { lds_barrier(); lds_barrier(); } }
+    return;
+  }
   __shared__ double u0[kRcsSP * 16];                                 // t_k = column 0 of T_R,k
   __shared__ double part[kRcsSP * kRcsSP * 16];                      // part[i][k] = T_ik x_i
   __shared__ double xs[kRcsSP * 16];

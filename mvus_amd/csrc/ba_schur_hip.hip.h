@@ -2249,6 +2249,8 @@ struct HipSchur {
   double *NE = nullptr, *Lb = nullptr, *Z = nullptr, *G = nullptr, *G0 = nullptr, *S = nullptr, *S2 = nullptr, *Linv = nullptr, *rhs = nullptr, *pc = nullptr,
          *DG = nullptr, *D = nullptr, *gx = nullptr, *px = nullptr, *sepbuf = nullptr;
   RcsView rcs{};            // reduced camera system in block-image form (ba_rcs.hip.h)
+  unsigned* rcs_flags = nullptr;   // step counter of the in-launch hand-over (k_rcs_factor -> its row workgroups); zeroed by k_rcs_finish
+  bool rcs_trsm_launch = false;
   bool use_rcs = true;      // MVUS_RCS=gj: the block Gauss-Jordan of rounds 1-4 (A/B)
   int* fail = nullptr;      // [0] numerical failure of a solve, [1] a row reached outside the slice (assembly)
   int* fail_host = nullptr;
@@ -2355,11 +2357,14 @@ struct HipSchur {
     Linv = be.alloc((size_t)((ne.CB + kNB - 1) / kNB) * kNB * kNB);
     rcs.nn = ne.CB; rcs.nbk = (ne.CB + 15) / 16;
     rcs.Simg = be.alloc(rcs_doubles(ne.CB)); rcs.Tsc = be.alloc(rcs_doubles(ne.CB)); rcs.x = be.alloc((size_t)rcs.nbk * 16);
-    // which solver of the reduced camera system: the blocked L D L^T of ba_rcs.hip.h wins while the system is ONE super-panel (<= 144
-    // unknowns: one launch, the whole chain inside one CU -- 16 + 8 us against 32 at 63 unknowns); beyond that its rows-below /
-    // trailing / substitution launches cost more than the block Gauss-Jordan's tile updates spread over the chip (measured at 288:
-    // 113 us against 95).  MVUS_RCS=ldl / gj forces one of them (tests, A/B).
-    { const char* e = std::getenv("MVUS_RCS"); use_rcs = e && std::strcmp(e, "ldl") == 0 ? true : (e && std::strcmp(e, "gj") == 0 ? false : rcs.nbk <= kRcsSP); }
+    // which solver of the reduced camera system: the blocked L D L^T of ba_rcs.hip.h (round 5) at every size -- one launch up to 144
+    // unknowns (24 us against the block Gauss-Jordan's 32 at 63 unknowns), and with the rows below each super-block solved inside the
+    // factor launch it is level with or ahead of the Gauss-Jordan beyond (configs[2]: 0.488 - 0.495 against 0.498 - 0.503 ms per
+    // step, configs[3]: 1.297 against 1.299).  MVUS_RCS=gj keeps the Gauss-Jordan (A/B, tests).
+    MVUS_HIP(hipMalloc(reinterpret_cast<void**>(&rcs_flags), 4 * sizeof(unsigned)));
+    MVUS_HIP(hipMemsetAsync(rcs_flags, 0, 4 * sizeof(unsigned), be.stream));
+    { const char* e = std::getenv("MVUS_RCS_TRSM"); rcs_trsm_launch = e && std::strcmp(e, "launch") == 0; }
+    { const char* e = std::getenv("MVUS_RCS"); use_rcs = !(e && std::strcmp(e, "gj") == 0); }
     MVUS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rcs_trsm), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((rcs_stage_doubles(kRcsSP) + 512) * sizeof(double))));
     MVUS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rcs_backsub), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(rcs_backsub_doubles(rcs.nbk) * sizeof(double))));
     if (shard) { DG = nullptr; D = NE + nAg + halo_count; gx = D + hp.n; }
@@ -2515,6 +2520,7 @@ struct HipSchur {
     if (part_tables) (void)hipFree(part_tables);
     if (halo_tables) (void)hipFree(halo_tables);
     if (fail) (void)hipFree(fail);
+    if (rcs_flags) (void)hipFree(rcs_flags);
     if (fail_host) (void)hipHostFree(fail_host);
   }
 
@@ -2720,12 +2726,15 @@ struct HipSchur {
       // blocked L D L^T in block-image form (ba_rcs.hip.h): per super-panel of 144 unknowns one factor launch (one workgroup, the pivot
       // chain inside one CU), the rows below, the trailing blocks; one descending substitution at the end
       const int nbk = rcs.nbk, nt = (16 * nbk + 31) / 32;
-      hipLaunchKernelGGL(k_rcs_finish, dim3(nt, nt + 1), dim3(256), 0, be.stream, ne, ncols, nsl, lambda, Gsum, rcs);
+      hipLaunchKernelGGL(k_rcs_finish, dim3(nt, nt + 1), dim3(256), 0, be.stream, ne, ncols, nsl, lambda, Gsum, rcs, rcs_flags);
       for (int c0 = 0; c0 < nbk; c0 += kRcsSP) {
         const int nc = std::min(kRcsSP, nbk - c0), c1 = c0 + nc, m = nbk - c1;
-        hipLaunchKernelGGL(k_rcs_factor, dim3(1), dim3(kRcsFactorThreads), 0, be.stream, rcs, c0, fail, (int)(m == 0), pc);
+        // (the block rows below the super-block are solved by m more workgroups of the same launch, one step behind the chain;
+        // MVUS_RCS_TRSM=launch: by a launch of their own, for A/B)
+        const bool fused_rows = m > 0 && !rcs_trsm_launch;
+        hipLaunchKernelGGL(k_rcs_factor, dim3(1 + (fused_rows ? m : 0)), dim3(kRcsFactorThreads), 0, be.stream, rcs, c0, fail, (int)(m == 0), pc, rcs_flags);
         if (m > 0) {
-          hipLaunchKernelGGL(k_rcs_trsm, dim3(m), dim3(64 * kRcsTrsmWaves), (rcs_stage_doubles(nc) + 512) * sizeof(double), be.stream, rcs, c0);
+          if (!fused_rows) hipLaunchKernelGGL(k_rcs_trsm, dim3(m), dim3(64 * kRcsTrsmWaves), (rcs_stage_doubles(nc) + 512) * sizeof(double), be.stream, rcs, c0);
           hipLaunchKernelGGL(k_rcs_syrk, dim3((m * (m + 1) / 2 + m + 3) / 4), dim3(256), 0, be.stream, rcs, c0);
         }
       }

@@ -1,6 +1,7 @@
-"""The reduced camera system by blocked L D L^T in matrix-core block images (mvus_amd/csrc/ba_rcs.hip.h; round 5: the default for
-systems of one super-panel, <= 144 unknowns, MVUS_RCS=ldl at any size) against the block Gauss-Jordan (MVUS_RCS=gj; the default
-beyond 144 unknowns) and against a dense LAPACK solve of the same damped system.
+"""The reduced camera system by blocked L D L^T in matrix-core block images (mvus_amd/csrc/ba_rcs.hip.h; the default since round 5)
+against the block Gauss-Jordan of rounds 1 - 4 (MVUS_RCS=gj) and against a dense LAPACK solve of the same damped system; the block
+rows below each super-block solved inside the factor launch (flag hand-over between workgroups) and by a launch of their own
+(MVUS_RCS_TRSM=launch).
 
 No counterpart in the reference (reconstruction/common.py:670 delegates the whole solve to scipy); what is checked is that the
 damped step p of the whole GPU chain solves (H + lambda diag H) p = -g, for reduced systems of 1 .. 5 super-panels of 144 unknowns,
@@ -49,12 +50,19 @@ def test_damped_step_of_the_blocked_ldlt(cams, calib, monkeypatch):
     prob, x0 = mp.problem_from_scene(sc)
     nn = prob.C * (3 + prob.P)
     lams = (1e-3, 0.7)
-    monkeypatch.setenv('MVUS_RCS', 'ldl')              # (the default picks it for one super-panel only; here: every size)
+    monkeypatch.delenv('MVUS_RCS', raising=False)
     with BAHandle(prob) as h:
         h.residual_jacobian(x0, _lib.JAC_ANALYTIC)
         steps = [h.lm_step(lam) for lam in lams]
         again = h.lm_step(lams[0])
         refs = [_dense_step(prob, h, lam) for lam in lams]
+    monkeypatch.setenv('MVUS_RCS_TRSM', 'launch')
+    with BAHandle(prob) as h:
+        h.residual_jacobian(x0, _lib.JAC_ANALYTIC)
+        own = [h.lm_step(lam) for lam in lams]
+    monkeypatch.delenv('MVUS_RCS_TRSM')
+    for p, q in zip(steps, own):
+        assert np.array_equal(p, q), 'rows below the super-block: in-launch and separate-launch forms differ'
     monkeypatch.setenv('MVUS_RCS', 'gj')
     with BAHandle(prob) as h:
         h.residual_jacobian(x0, _lib.JAC_ANALYTIC)
