@@ -1146,7 +1146,7 @@ int mvus_ba_solve(mvus_ba* h, double* x, const mvus_solve_opts* opts, mvus_resul
       // knots closer than a frame (band wider than six control points): more control points than detections -- the spline is
       // held by the motion regulariser alone between the data, and a converging LM whose damping falls to 3e-3 diag(H) follows
       // noise along those directions (the incremental loop then ends 3 m off; with 0.3 it ends where TRF + LSMR ends:
-      // profiles/r04_loop_lm_wide_band_damping.txt).  The floor of such problems is at least kLambdaMinWide.
+      // profiles/round4/r04_loop_lm_wide_band_damping.txt).  The floor of such problems is at least kLambdaMinWide.
       constexpr double kLambdaMinWide = 0.3;
       if (h->schur->wide && so.lm_trust_radius < 0) so.lm_lambda_min = std::max(so.lm_lambda_min, kLambdaMinWide);      // (a trust region bounds those steps itself)
       sr = lm_schur(be, *h->schur, xv, lb, ub, so, be.f_cur);

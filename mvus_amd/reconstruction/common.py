@@ -65,7 +65,7 @@ def _undistort_normalized(points, K, d):
 # regulariser that is not scale invariant -- slope towards a smaller scene; a nearly undamped Newton step (the library's floor, 3e-3,
 # chosen for single large BAs) follows that slope where the reference's ten truncated LSMR solves barely move.  Eleven seeds of the
 # loop: with 0.3 every seed ends 0.21 - 0.43 m from the truth (the reference's algorithm: 0.23 - 0.51 m), with 3e-3 one seed in
-# three ends metres away (profiles/r04_loop_lm_damping_floors.txt).  A single Scene.BA keeps the library's floor: with 0.3 its last
+# three ends metres away (profiles/round4/r04_loop_lm_damping_floors.txt).  A single Scene.BA keeps the library's floor: with 0.3 its last
 # steps get short enough for xtol to end a 200-evaluation solve above the minimum (dist_fixed_2cam: cost 252.9 against 238.0).
 LOOP_LM_LAMBDA_MIN = 0.3
 
@@ -420,7 +420,7 @@ class Scene:
                 # than a frame apart mean more control points than detections -- what traj_to_spline returns after a dense triangulate
                 # inside the incremental loop -- and there an exact Newton-type step follows the regulariser-only directions: three
                 # seeds of the loop end 2.6 - 8 m from the truth with LM on those problems, 0.2 - 0.35 m with the truncated solver
-                # (profiles/r04_loop_lm_wide_band.txt).  settings['ba_lm_wide_band'] = 'lm' keeps LM (damping floor 0.3).
+                # (profiles/round4/r04_loop_lm_wide_band.txt).  settings['ba_lm_wide_band'] = 'lm' keeps LM (damping floor 0.3).
                 raise _ba.UnsupportedBySolver("settings['ba_lm_wide_band'] = 'trf': the motion rows reach over more than six control points (knots less than a frame apart)")
             res = h.solve(model, opts=opts, ties=st.get('ba_pattern_ties', 'numpy'), matrix=jac_sparsity)
             res.solver_used = 'lm' if solver == _ba.SOLVER_LM_SCHUR else 'trf'

@@ -58,7 +58,7 @@ def test_loop_with_lm_on_the_seeds_that_used_to_fail(seed):
     """ba_solver = 'lm' through the whole loop on the flights where it ended metres away with the library's damping floor (scale
     collapsing to 0.0 - 0.3: the staged two- and three-camera BAs are free in their similarity gauge and the motion regulariser rewards
     a smaller scene).  incremental_reconstruction sets the loop's floor (LOOP_LM_LAMBDA_MIN) and hands wide-band BAs to the parity
-    solver; measured over eleven seeds: 0.21 - 0.43 m from the truth, scale within 0.4 % (profiles/r04_loop_lm_damping_floors.txt)."""
+    solver; measured over eleven seeds: 0.21 - 0.43 m from the truth, scale within 0.4 % (profiles/round4/r04_loop_lm_damping_floors.txt)."""
     from mvus_amd import pipeline, synth
     kw = dict(synth.BASELINE_CONFIGS[1])
     kw.pop('seed'); kw.pop('num_cam'); kw.pop('total_obs'); kw.pop('num_intervals', None)

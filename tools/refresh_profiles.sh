@@ -5,7 +5,7 @@
 # the program after `--` is python3 itself (no wrapper that re-execs).
 set -x
 export TMPDIR=/tmp
-R=${1:-r04}
+R=${1:-r05}
 O=gpurun_out/refresh; mkdir -p $O
 python bench.py --steps 20 --warmup 5 > $O/${R}_bench_config2_lm.json 2> $O/bench_config2_lm.err
 python bench.py --solver trf --steps 5 --warmup 1 --no-cpu-baseline --no-parity-solver > $O/${R}_bench_config2_trf.json 2>> $O/bench.err
@@ -54,5 +54,10 @@ bash tools/micro/pmc_gemm.sh 2 > $O/${R}_schur_gemm_counters_config2.txt 2>&1
 python3 tools/incremental_loop.py --solver trf --obs 20000 --cpu-all 2>&1 | grep -v "^Number\|^Doing\|^$\|amdgpu" > $O/${R}_loop_oracle_clock_every_ba.txt
 python3 tools/incremental_loop.py --solver trf --obs 20000 --cpu-all --motion-weights 1e4 2>&1 | grep -v "^Number\|^Doing\|^$\|amdgpu" > $O/${R}_loop_oracle_clock_every_ba_mw1e4.txt
 for seed in 1 2 3; do echo "== seed $seed trf motion_weights 1e4"; python3 tools/incremental_loop.py --solver trf --motion-weights 1e4 --seed $seed 2>&1 | grep -v "^Number\|^Doing\|^$\|amdgpu" | tail -9; done > $O/${R}_loop_motion_weights_1e4.txt 2>&1
+# round 5: fp64 issue rates, the reduced solve per configuration (step timeline at configs[1] and [3]), A/B of the two reduced solvers
+/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -o /tmp/fp64_rates tools/micro/fp64_rates.hip 2>/dev/null && /tmp/fp64_rates > $O/${R}_fp64_issue_rates_raw.txt 2>&1
+bash tools/step_timeline.sh 3 > $O/${R}_step_timeline_config3.txt 2>&1
+bash tools/step_timeline.sh 1 > $O/${R}_step_timeline_config1.txt 2>&1
+for c in 1 2 3 4; do for m in ldl gj; do echo "configs[$c] MVUS_RCS=$m: $(MVUS_RCS=$m python3 tools/step_breakdown.py $c 2>&1 | tail -1)"; done; done > $O/${R}_reduced_solver_ab.txt 2>&1
 rm -rf $O/stats_lm $O/stats_trf $O/stats_c3 $O/pmc_fetch* $O/pmc_write* $O/pmc_traffic_c2.json $O/pmc_traffic_c23.json
 ls -la $O
