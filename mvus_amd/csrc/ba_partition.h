@@ -12,18 +12,19 @@ namespace mvus {
 constexpr int kPartL = MVUS_PART_L;                  // control points per interior
 constexpr int kPartRowsMax = 3 * (kPartL + 6);       // scalar rows of the longest interior (merged tails included)
 
-// Partition of a chain of `n` control points starting at local control point `c0`: interiors of kPartL control points
+// Partition of a chain of `n` control points starting at local control point `c0`: interiors of `len` (<= kPartL) control points
 // separated by separators of sctrl (every interior BETWEEN two separators is at least sctrl long, so that separators
 // never couple directly); `close` = the chain must END with a separator (the cut towards the next time shard),
 // otherwise a tail too short for another interior is merged into the last one.
 struct ChainPart { std::vector<int> i0, i1, sep; };     // scalar rows; sep[k] = separator right of interior k
-inline ChainPart partition_chain(int c0, int n, int sctrl, bool close) {
+inline ChainPart partition_chain(int c0, int n, int sctrl, bool close, int len = kPartL) {
+  len = std::max(2 * sctrl, std::min(len, kPartL));       // the kernels' arrays are sized for kPartL
   ChainPart cp;
   const int end = c0 + n;
   for (int g = c0; g < end;) {
-    int e = std::min(g + kPartL, end);
+    int e = std::min(g + len, end);
     if (close) {
-      e = std::min(g + kPartL, end - sctrl);
+      e = std::min(g + len, end - sctrl);
       // control points between this interior and the closing separator: none, or a separator plus an interior of at
       // least sctrl control points -- a shorter interior would let its two separators couple directly through the band,
       // which the reduced (block tridiagonal) separator system cannot express.  Shorten this interior to leave exactly that.

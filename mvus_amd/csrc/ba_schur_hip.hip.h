@@ -2251,6 +2251,7 @@ struct HipSchur {
   RcsView rcs{};            // reduced camera system in block-image form (ba_rcs.hip.h)
   unsigned* rcs_flags = nullptr;   // step counter of the in-launch hand-over (k_rcs_factor -> its row workgroups); zeroed by k_rcs_finish
   bool rcs_trsm_launch = false;
+  int part_len = kPartL;    // control points per interior of the band solver (<= kPartL)
   bool use_rcs = true;      // MVUS_RCS=gj: the block Gauss-Jordan of rounds 1-4 (A/B)
   int* fail = nullptr;      // [0] numerical failure of a solve, [1] a row reached outside the slice (assembly)
   int* fail_host = nullptr;
@@ -2379,13 +2380,19 @@ struct HipSchur {
     // partition of the owned chain; the separators are numbered along the chain of ALL ranks (each rank can compute
     // every other rank's count from the cuts)
     const bool close = shard && ts.rank + 1 < ts.world;
-    const ChainPart cp = partition_chain(own_lo, own_hi - own_lo, sctrl, close);
+    // Interior length: the factorisation of an interior is one dependent chain of its rows (0.3 us a row), the separator system one of
+    // log2(separators) levels whose cost grows with the number of right-hand-side columns.  Few columns (<= 128: configs[1], [4]):
+    // half-length interiors -- measured 0.333 -> 0.309 ms and 0.390 -> 0.362 ms a step; 289 columns: no difference; 577: 1.283 -> 1.363.
+    // (Every rank of a sharded solve computes the same value: CB is global.)
+    part_len = ne.CB <= 128 ? kPartL / 2 : kPartL;
+    if (const char* e = std::getenv("MVUS_PART_LEN")) part_len = std::atoi(e);
+    const ChainPart cp = partition_chain(own_lo, own_hi - own_lo, sctrl, close, part_len);
     pv.P = (int)cp.i0.size(); pv.s3 = 3 * sctrl;
     pv.q_off = 0; pv.m = (int)cp.sep.size();
     if (shard) {
       pv.m = 0;
       for (int r = 0; r < ts.world; ++r) {
-        const ChainPart o = partition_chain(0, ts.cuts[r + 1] - ts.cuts[r], sctrl, r + 1 < ts.world);
+        const ChainPart o = partition_chain(0, ts.cuts[r + 1] - ts.cuts[r], sctrl, r + 1 < ts.world, part_len);
         if (r == ts.rank) pv.q_off = pv.m;
         pv.m += (int)o.sep.size();
       }

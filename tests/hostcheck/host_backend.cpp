@@ -419,8 +419,8 @@ extern "C" int hostcheck_lsmr(void* h, const double* b, double damp, double atol
 
 // partition of a control-point chain (ba_partition.h): returns the number of interiors, fills i0/i1 (scalar rows) and the
 // separators' first rows; *nsep receives their count
-extern "C" int hostcheck_partition(int c0, int n, int sctrl, int close, int* i0, int* i1, int* sep, int* nsep) {
-  const mvus::ChainPart cp = mvus::partition_chain(c0, n, sctrl, close != 0);
+extern "C" int hostcheck_partition(int c0, int n, int sctrl, int close, int len, int* i0, int* i1, int* sep, int* nsep) {
+  const mvus::ChainPart cp = mvus::partition_chain(c0, n, sctrl, close != 0, len);
   for (size_t k = 0; k < cp.i0.size(); ++k) { i0[k] = cp.i0[k]; i1[k] = cp.i1[k]; }
   for (size_t k = 0; k < cp.sep.size(); ++k) sep[k] = cp.sep[k];
   *nsep = (int)cp.sep.size();

@@ -223,25 +223,26 @@ def test_time_cuts_refuse_too_few_control_points():
 def test_band_solver_partition_invariants():
     """ba_partition.h: for every chain length, separator width and both chain kinds -- interiors and separators tile the chain in
     order, separators have the band half-width, NO interior between two separators is shorter than that (its separators
-    would couple directly, outside the block-tridiagonal separator system), interiors fit the kernels' row limit, and a
-    closed chain (a time shard that is not the last) ends with a separator."""
+    would couple directly, outside the block-tridiagonal separator system), interiors fit the kernels' row limit (and that of the
+    interior length asked for: HipSchur takes half-length interiors when the reduced system has few columns), and a closed chain (a
+    time shard that is not the last) ends with a separator."""
     import ctypes
     import hostcheck_util
     lib = hostcheck_util.load()
     I = ctypes.c_int * 512
     lib.hostcheck_partition.restype = ctypes.c_int
     rows_max = 3 * (32 + 6)
-    for sctrl in (3, 5):
-        for close in (0, 1):
+    for sctrl, close, length in [(s_, c_, l_) for s_ in (3, 5) for c_ in (0, 1) for l_ in (32, 16)]:
+        if True:
             for n in range(2 * 8 + sctrl + 1, 400):
                 for c0 in (0, 11):
                     i0, i1, sep, nsep = I(), I(), I(), ctypes.c_int(0)
-                    P = lib.hostcheck_partition(c0, n, sctrl, close, i0, i1, sep, ctypes.byref(nsep))
+                    P = lib.hostcheck_partition(c0, n, sctrl, close, length, i0, i1, sep, ctypes.byref(nsep))
                     ns = nsep.value
                     assert P >= 1 and ns == (P if close else P - 1), (n, sctrl, close)
                     pos = 3 * c0
                     for k in range(P):
-                        assert i0[k] == pos and i1[k] > i0[k] and i1[k] - i0[k] <= rows_max, (n, sctrl, close, k)
+                        assert i0[k] == pos and i1[k] > i0[k] and i1[k] - i0[k] <= 3 * (length + 6) <= rows_max, (n, sctrl, close, k)
                         if 0 < k and k < ns:                      # an interior with a separator on both sides
                             assert i1[k] - i0[k] >= 3 * sctrl, (n, sctrl, close, k, i1[k] - i0[k])
                         pos = i1[k]
