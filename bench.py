@@ -20,7 +20,8 @@ cuts every camera's detections into N pieces instead, with one all-reduce per J^
 
 The JSON line also carries the roofline of the dominant kernel (residual+Jacobian), measured with
 HIP events on the kernel's own stream, and a CPU baseline (the oracle's restatement of the scipy path,
-one core) on a bounded sample, on rank 0 at N=1 only.
+one core) on a bounded sample, on rank 0 at N=1 only.  ``long_solve`` (LM): the same number of trials inside ONE call, measured after
+the timed region -- what an iteration costs inside a long Scene.BA (no residual at the start of each call, no Python between trials).
 """
 import argparse
 import json
@@ -103,6 +104,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--no-long-solve', action='store_true', help='skip the one-call leg (long_solve in the JSON line)')
     ap.add_argument('--config', type=int, default=2, help='index into BASELINE.json configs (2 = 32 cams x 500k obs)')
     ap.add_argument('--solver', choices=['trf', 'lm'], default=os.environ.get('MVUS_BENCH_SOLVER', 'lm'))
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -189,6 +191,24 @@ def main():
         tmax = torch.tensor([dt], dtype=torch.float64, device='cuda')
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+
+    # The same number of trials inside ONE call (what an iteration costs in a Scene.BA of many evaluations: no residual at the start of
+    # every call -- the accepted trial's residual is the next iteration's -- and no return to Python between trials).  Reported beside
+    # the headline, never as it; outside the timed region.
+    long_solve = None
+    if args.solver == 'lm' and not args.no_long_solve:
+        barrier()
+        tl = time.perf_counter()
+        rl = handle.solve(x, solver=solver, jac_mode=jac_mode, max_nfev=args.steps + 1, return_fun=False, ties='canonical')
+        barrier()
+        dtl = time.perf_counter() - tl
+        if world > 1:
+            tmax = torch.tensor([dtl], dtype=torch.float64, device='cuda')
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dtl = float(tmax.item())
+        long_solve = {'ms_per_trial': 1e3 * dtl / max(rl.nfev - 1, 1), 'trials': rl.nfev - 1, 'linearisations': rl.njev, 'status': rl.status,
+                      'what': 'one mvus_ba_solve with max_nfev = steps + 1 continuing from the timed steps; a rejected trial is not followed by a '
+                              'linearisation (trials > linearisations - 1 then)'}
 
     # roofline of the dominant kernel: residual + Jacobian, HIP events on the kernel's own stream
     handle.set_x(x)
@@ -308,6 +328,7 @@ def main():
                                         'frac': bytes_launch / (t_rj_one * 1e-3) / 1e9 / HBM_PEAK_GBS}},
             'parity_solver': parity,
             'strong_config3': strong3,
+            'long_solve': long_solve,
             'kernels_ms': {'residual': t_r, 'residual_jacobian': t_rj, 'jv': t_jv, 'jtu': t_jtu, 'normal_eq_assembly_from_J': t_asm,
                            'fused_jacobian_normal_eq_assembly': t_fused},
         }

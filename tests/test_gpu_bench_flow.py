@@ -63,3 +63,5 @@ def test_two_rank_bench_weak_scaling_default_config():
     assert s3['n_gpus'] == 2 and 'configs[3]' in s3['workload'] and '64 cams' in s3['workload']
     assert s3['ms_per_step'] > 0 and abs(s3['residuals_per_sec'] * s3['ms_per_step'] * 1e-3 - 2_000_000) < 50_000
     assert s3['cost_last'] <= s3['cost_first']
+    ls = out['long_solve']                                                        # the same trials inside one call, beside the headline
+    assert ls['trials'] >= 1 and ls['ms_per_trial'] > 0 and ls['linearisations'] <= ls['trials'] + 1
