@@ -74,13 +74,15 @@ SolveResult lm_schur(B& be, Schur& sc, std::vector<double>& x, const std::vector
   using namespace detail;
   SolveResult res;
   const int64_t n = be.n(), m = be.m_local();
-  if (!in_bounds(x, lb, ub)) { res.error = -3; return res; }
   PoolGuard<B> pool(be);             // returned on every exit, exceptions included (a time shard can throw out of solve_ok)
   // the current and the trial point live in two buffers the backend keeps from solve to solve: a caller that continues from the point
   // the previous solve returned (an outer loop of short solves -- bench.py's steps, Scene.BA after remove_outliers) finds it on the
   // device already (lm_resume: bitwise comparison with the host copy of that point) and x does not cross PCIe again
   int xcur = be.lm_resume(x.data());
   const bool resumed = xcur >= 0;
+  // (a resumed point is one this driver returned: the caller's x0 of that solve, checked then, or a trial point, projected onto the
+  // box by the trial kernel -- and the box is the handle's; the O(n) check would only delay the first launch)
+  if (!resumed && !in_bounds(x, lb, ub)) { res.error = -3; return res; }
   if (!resumed) xcur = 0;
   double* x_dev = be.lm_xbuf(xcur);
   double* xt_dev = be.lm_xbuf(xcur ^ 1);

@@ -58,6 +58,6 @@ for seed in 1 2 3; do echo "== seed $seed trf motion_weights 1e4"; python3 tools
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -o /tmp/fp64_rates tools/micro/fp64_rates.hip 2>/dev/null && /tmp/fp64_rates > $O/${R}_fp64_issue_rates_raw.txt 2>&1
 bash tools/step_timeline.sh 3 > $O/${R}_step_timeline_config3.txt 2>&1
 bash tools/step_timeline.sh 1 > $O/${R}_step_timeline_config1.txt 2>&1
-for c in 1 2 3 4; do for m in ldl gj; do echo "configs[$c] MVUS_RCS=$m: $(MVUS_RCS=$m python3 tools/step_breakdown.py $c 2>&1 | tail -1)"; done; done > $O/${R}_reduced_solver_ab.txt 2>&1
+for c in 1 2 3 4; do for m in ldl gj; do echo "configs[$c] MVUS_RCS=$m: $(MVUS_RCS=$m python3 tools/step_breakdown.py $c 2>&1 | tail -1)"; done; done 2>/dev/null | grep "^configs" > $O/${R}_reduced_solver_ab.txt
 rm -rf $O/stats_lm $O/stats_trf $O/stats_c3 $O/pmc_fetch* $O/pmc_write* $O/pmc_traffic_c2.json $O/pmc_traffic_c23.json
 ls -la $O
