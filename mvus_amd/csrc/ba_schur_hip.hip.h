@@ -1726,10 +1726,12 @@ __global__ __launch_bounds__(64) void k_part_back(PartView pv, int ncols, double
   }
 }
 
-// Z[3N][ncols] = [E^T | gs] and Erm[3N][CB] = E^T (row-major copies of the camera-major cross block)
+// Z[3N][ncols] = [E^T | gs]: the row-major copy of the camera-major cross block that the interior solves work on.  (Until round 5 a
+// second copy, Erm[3N][CB], was written here as the Schur product's first operand: the product now reads the camera-major block
+// itself -- 34 MB less written at configs[2], 138 MB at configs[3]: k_cholesky_and_rhs 69 -> 55 us there.)
 // The same launch also packs the damped band (band_pack_entry: the two are independent element-wise passes over the assembled
 // blocks, and every launch costs ~4.7 us before it does anything).
-__global__ void k_build_rhs(NEView ne, int ncols, double* __restrict__ Z, double* __restrict__ Erm, double lambda, int BW, double* __restrict__ Lb,
+__global__ void k_build_rhs(NEView ne, int ncols, double* __restrict__ Z, double lambda, int BW, double* __restrict__ Lb,
                             int* __restrict__ fail, DevProblem dp, int with_diag, double* __restrict__ D, double* __restrict__ gx, int tiles) {
   const long long idx = xcd_tile(tiles) * (long long)blockDim.x + threadIdx.x;      // XCD-aware order: 31.5 -> 25 us (see xcd_tile)
   band_pack_entry(ne, lambda, BW, Lb, fail, dp, with_diag, D, gx, idx);
@@ -1737,9 +1739,7 @@ __global__ void k_build_rhs(NEView ne, int ncols, double* __restrict__ Z, double
   const int r = (int)(idx / ncols), cidx = (int)(idx % ncols);
   if (cidx < ne.CB) {
     const int c = cidx / ne.B, k = cidx % ne.B;
-    const double v = ne.Et[((long long)c * ne.N3 + r) * ne.B + k];
-    Z[idx] = v;
-    Erm[(long long)r * ne.CB + cidx] = v;
+    Z[idx] = ne.Et[((long long)c * ne.N3 + r) * ne.B + k];
   } else {
     Z[idx] = ne.gs[r];
   }
@@ -1755,7 +1755,7 @@ __global__ void k_band_pack(NEView ne, double lambda, int BW, double* __restrict
 }
 template <int BW>
 __global__ __launch_bounds__(256) void k_cholesky_and_rhs(PartView pv, double* __restrict__ Lb, int* __restrict__ fail, int chol_blocks,
-                                                          NEView ne, int ncols, double* __restrict__ Z, double* __restrict__ Erm, int tiles) {
+                                                          NEView ne, int ncols, double* __restrict__ Z, int tiles) {
   __shared__ double T[(kPartRowsMax + 1) * (BW + 1)];
   if ((int)blockIdx.x < chol_blocks) {                    // chol_blocks is a multiple of 8: the copy tiles keep their XCD mapping
     if ((int)blockIdx.x < pv.P && threadIdx.x < 64) part_cholesky_body<BW>(pv, Lb, fail, T, (int)blockIdx.x, (int)threadIdx.x);
@@ -1769,16 +1769,14 @@ __global__ __launch_bounds__(256) void k_cholesky_and_rhs(PartView pv, double* _
   const int r = (int)(idx / ncols), cidx = (int)(idx % ncols);
   if (cidx < ne.CB) {
     const int c = cidx / ne.B, k = cidx % ne.B;
-    const double v = ne.Et[((long long)c * ne.N3 + r) * ne.B + k];
-    Z[idx] = v;
-    Erm[(long long)r * ne.CB + cidx] = v;
+    Z[idx] = ne.Et[((long long)c * ne.N3 + r) * ne.B + k];        // (the product's first operand is read where the assembly left it)
   } else {
     Z[idx] = ne.gs[r];
   }
 }
 
 // Gp[slab][CB][ncols] = Et^T Z over one K-slab: the one dense contraction of the solve (2 * CB^2 * 3N flops), on the
-// fp64 matrix cores (v_mfma_f64_16x16x4_f64).  Both operands are stored K-major ([3N][CB] and [3N][ncols]), which is
+// fp64 matrix cores (v_mfma_f64_16x16x4_f64).  Both operands are K-major (the cross block camera-major, [C][3N][B]: row stride B and a per-lane column offset; Z [3N][ncols]), which is
 // exactly the MFMA operand layout (lane l: A[l&15][k = l>>4], B[k = l>>4][l&15]; every 16-lane group reads 128
 // contiguous bytes), so fragments go from global memory straight to registers -- no LDS staging.  One wavefront owns a
 // 48x48 output tile (3x3 MFMA tiles, 36 accumulator registers) over wave_k rows of K; the four wavefronts of a
@@ -1836,7 +1834,7 @@ struct GemmSet {
 // The product's rows [row_lo, row_hi) are cut into sets of 16; wavefront g of nslab * 4 takes sets [g q + min(g, r), ...) with
 // q, r = nsets / nwaves, nsets % nwaves -- every wavefront within one set of the others; only the very last set can be partial.
 template <int NJ>   // NJ = 3: 48x48 tile of the symmetric part, NJ = 1: 48x16 tile holding the rhs column
-__device__ __forceinline__ void schur_gemm_tile(const NEView& ne, int ncols, const double* __restrict__ Erm, const double* __restrict__ Z,
+__device__ __forceinline__ void schur_gemm_tile(const NEView& ne, int ncols, const double* __restrict__ Ecm, const double* __restrict__ Z,
                                                 double* __restrict__ Gp, int a0, int b0, int row_lo, int row_hi, int slab, int nslab, double* red) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int lr = lane & 15, lk = lane >> 4;
@@ -1847,7 +1845,10 @@ __device__ __forceinline__ void schur_gemm_tile(const NEView& ne, int ncols, con
     for (int j = 0; j < NJ; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
   int ao[3], bo[NJ];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) ao[i] = min(a0 + 16 * i + lr, ne.CB - 1);
+  for (int i = 0; i < 3; ++i) {                                // A = the cross block where the assembly left it (camera-major [C][3N][B]):
+    const int col = min(a0 + 16 * i + lr, ne.CB - 1);          // column (c, k) of row r is Et[(c N3 + r) B + k] -- row stride B, per-lane offset
+    ao[i] = (col / ne.B) * ne.N3 * ne.B + col % ne.B;
+  }
 #pragma unroll
   for (int j = 0; j < NJ; ++j) bo[j] = NJ == 3 ? min(b0 + 16 * j + lr, ne.CB - 1) : ne.CB;
   const int nsets = (row_hi - row_lo + kGemmSetRows - 1) / kGemmSetRows, nwaves = nslab * 4, g = slab * 4 + wave;
@@ -1855,9 +1856,9 @@ __device__ __forceinline__ void schur_gemm_tile(const NEView& ne, int ncols, con
   const int s_lo = g * q + min(g, r), s_hi = s_lo + q + (g < r ? 1 : 0);
   const bool tail = s_hi == nsets && s_hi > s_lo && (row_hi - row_lo) % kGemmSetRows != 0;
   const int nfull = s_hi - s_lo - (tail ? 1 : 0);
-  const long long lda = ne.CB, ldb = ncols;
+  const long long lda = ne.B, ldb = ncols;
   const int k0 = row_lo + s_lo * kGemmSetRows;
-  const double* ap = Erm + (long long)(k0 + lk) * lda;
+  const double* ap = Ecm + (long long)(k0 + lk) * lda;
   const double* bp = Z + (long long)(k0 + lk) * ldb;
   const long long sa = kGemmSetRows * lda, sb = kGemmSetRows * ldb;
   GemmSet<NJ> s0, s1;
@@ -1880,7 +1881,7 @@ __device__ __forceinline__ void schur_gemm_tile(const NEView& ne, int ncols, con
     }
   }
   if (tail) {
-    s0.load_tail(Erm, Z, lda, ldb, ao, bo, row_lo + (s_hi - 1) * kGemmSetRows, row_hi, lk);
+    s0.load_tail(Ecm, Z, lda, ldb, ao, bo, row_lo + (s_hi - 1) * kGemmSetRows, row_hi, lk);
     s0.multiply(acc);
   }
   // sum the four wavefronts through LDS, then store: element (i, j, reg) of lane l is row 16i + (l>>4) + 4 reg, col 16j + (l&15)
@@ -1911,7 +1912,7 @@ __device__ __forceinline__ void schur_gemm_tile(const NEView& ne, int ncols, con
 // 154 - 308 MB for 55 MB of operands, and the kernel ran at the fabric's rate, not the matrix cores').  Grid: 8 * tiles *
 // ceil(nslab / 8) workgroups; the slab count is chosen by the host (HipSchur::plan_gemm) to fill whole rounds of the XCD's slots.
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void k_schur_gemm(NEView ne, int ncols, int row_lo, int row_hi, int nslab, const double* __restrict__ Erm, const double* __restrict__ Z, double* __restrict__ Gp) {
+void k_schur_gemm(NEView ne, int ncols, int row_lo, int row_hi, int nslab, const double* __restrict__ Ecm, const double* __restrict__ Z, double* __restrict__ Gp) {
   __shared__ double red[9 * 4 * 64];
   const int nbk = (ne.CB + kGemmT - 1) / kGemmT, nsym = nbk * (nbk + 1) / 2, tiles = nsym + nbk;
   const int L = blockIdx.x, j = L >> 3;
@@ -1923,9 +1924,9 @@ void k_schur_gemm(NEView ne, int ncols, int row_lo, int row_hi, int nslab, const
     while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
     while (bi * (bi + 1) / 2 > t) --bi;
     const int bj = t - bi * (bi + 1) / 2;
-    schur_gemm_tile<3>(ne, ncols, Erm, Z, G, bi * kGemmT, bj * kGemmT, row_lo, row_hi, slab, nslab, red);
+    schur_gemm_tile<3>(ne, ncols, Ecm, Z, G, bi * kGemmT, bj * kGemmT, row_lo, row_hi, slab, nslab, red);
   } else {
-    schur_gemm_tile<1>(ne, ncols, Erm, Z, G, (t - nsym) * kGemmT, ne.CB, row_lo, row_hi, slab, nslab, red);
+    schur_gemm_tile<1>(ne, ncols, Ecm, Z, G, (t - nsym) * kGemmT, ne.CB, row_lo, row_hi, slab, nslab, red);
   }
 }
 
@@ -2245,7 +2246,6 @@ struct HipSchur {
   NEView ne{};
   int ncols = 0, BW = 0;
   size_t ne_count = 0;
-  double *Erm = nullptr;
   double *NE = nullptr, *Lb = nullptr, *Z = nullptr, *G = nullptr, *G0 = nullptr, *S = nullptr, *S2 = nullptr, *Linv = nullptr, *rhs = nullptr, *pc = nullptr,
          *DG = nullptr, *D = nullptr, *gx = nullptr, *px = nullptr, *sepbuf = nullptr;
   RcsView rcs{};            // reduced camera system in block-image form (ba_rcs.hip.h)
@@ -2348,7 +2348,6 @@ struct HipSchur {
     ne.A = NE; ne.gc = ne.A + nA; ne.Cb = ne.gc + ngc + halo_count + ndg; ne.gs = ne.Cb + nCb; ne.Et = ne.gs + ngs; ne.Apart = ne.Et + nEt;
     Lb = be.alloc((size_t)ne.N3 * (BW + 1));
     Z = be.alloc((size_t)ne.N3 * ncols);
-    Erm = be.alloc((size_t)ne.N3 * ne.CB);
     plan_gemm(3 * (own_hi - own_lo));
     G = be.alloc((size_t)nslab * ne.CB * ncols);
     G0 = be.alloc((size_t)ne.CB * ncols);
@@ -2522,7 +2521,7 @@ struct HipSchur {
     else MVUS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_assemble_windows<9>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)win_lds));
   }
   ~HipSchur() {
-    for (double* p : {Erm, NE, Lb, Z, G, G0, S, S2, Linv, rhs, pc, DG, px, pv.VW, sepbuf, pv.U2, pv.Ha, pv.Hc, wv.Apart, rcs.Simg, rcs.Tsc, rcs.x}) if (p) be.release(p);
+    for (double* p : {NE, Lb, Z, G, G0, S, S2, Linv, rhs, pc, DG, px, pv.VW, sepbuf, pv.U2, pv.Ha, pv.Hc, wv.Apart, rcs.Simg, rcs.Tsc, rcs.x}) if (p) be.release(p);
     if (win_tables) (void)hipFree(win_tables);
     if (part_tables) (void)hipFree(part_tables);
     if (halo_tables) (void)hipFree(halo_tables);
@@ -2664,7 +2663,7 @@ struct HipSchur {
     const dim3 gsolve(pv.P, (ncols + 63) / 64 + 1);      // + one block row for the coupling columns
     if (overlap_chol) {
       const int cb = (pv.P + 7) / 8 * 8;
-      hipLaunchKernelGGL(k_cholesky_and_rhs<BWT>, dim3((unsigned)(cb + xcd_grid(rhs_tiles_z))), dim3(256), 0, be.stream, pv, Lb, fail, cb, ne, ncols, Z, Erm, rhs_tiles_z);
+      hipLaunchKernelGGL(k_cholesky_and_rhs<BWT>, dim3((unsigned)(cb + xcd_grid(rhs_tiles_z))), dim3(256), 0, be.stream, pv, Lb, fail, cb, ne, ncols, Z, rhs_tiles_z);
     } else {
       hipLaunchKernelGGL(k_part_cholesky<BWT>, dim3(pv.P), dim3(64), 0, be.stream, pv, Lb, fail);
     }
@@ -2706,7 +2705,7 @@ struct HipSchur {
       hipLaunchKernelGGL(k_band_pack, dim3((unsigned)((nband + 255) / 256)), dim3(256), 0, be.stream, ne, lambda, BW, Lb, fail, be.dp, (int)diag_pending, D, gx);
       rhs_tiles_z = (int)((nZ + 255) / 256);
     } else {
-      hipLaunchKernelGGL(k_build_rhs, dim3((unsigned)xcd_grid(rhs_tiles)), dim3(256), 0, be.stream, ne, ncols, Z, Erm, lambda, BW, Lb, fail, be.dp,
+      hipLaunchKernelGGL(k_build_rhs, dim3((unsigned)xcd_grid(rhs_tiles)), dim3(256), 0, be.stream, ne, ncols, Z, lambda, BW, Lb, fail, be.dp,
                          (int)diag_pending, D, gx, rhs_tiles);
     }
     diag_pending = false;
@@ -2718,7 +2717,7 @@ struct HipSchur {
     const int row_lo = 3 * own_lo, row_hi = 3 * own_hi;
     {
       const int nbk = (ne.CB + kGemmT - 1) / kGemmT;
-      hipLaunchKernelGGL(k_schur_gemm, dim3(8 * (nbk * (nbk + 1) / 2 + nbk) * ((nslab + 7) / 8)), dim3(256), 0, be.stream, ne, ncols, row_lo, row_hi, nslab, Erm, Z, G);
+      hipLaunchKernelGGL(k_schur_gemm, dim3(8 * (nbk * (nbk + 1) / 2 + nbk) * ((nslab + 7) / 8)), dim3(256), 0, be.stream, ne, ncols, row_lo, row_hi, nslab, ne.Et, Z, G);
     }
     const int ntile = (ne.CB + kNB - 1) / kNB;
     const double* Gsum = G;
