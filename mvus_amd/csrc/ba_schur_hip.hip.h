@@ -893,6 +893,11 @@ struct PartView {
   int nt;
   const int *tc0, *tpl, *tpr, *tgq, *town;
   double* VW;            // [P][kPartRowsMax][2*s3]
+  // one rank, round 5 (no back-correction of the interiors' columns, see HipSchur::band_chain):
+  double* Dl;            // [m][s3][CB] reduced minus original right-hand sides of the separators, R_S - E_S (nullptr: not kept)
+  double* Zs;            // the separator solutions X_S also go into the separators' own rows of Z (nullptr: not)
+  const int* qrow;       // [m] first scalar row of separator q
+  int CB;
   double* T;             // [m][s3][s3] diagonal blocks of the separator system
   double* U;             // [m][s3][s3] U[q] = T(q, q+1)
   double *U2, *Ha, *Hc;  // [m][s3][s3] each: cyclic-reduction workspace (k_sep_bcr_*)
@@ -1194,6 +1199,7 @@ __device__ __forceinline__ void part_reduce_rhs(const PartView& pv, int ncols, c
       for (int jj = 0; jj < BW; ++jj) r -= (b0 + jj < b1) ? f[jj] * z[jj] : 0.0;
     }
     pv.R[((long long)gq * s3 + a) * ncols + col] = r;
+    if (pv.Dl != nullptr && col < pv.CB) pv.Dl[((long long)gq * s3 + a) * pv.CB + col] = r - (own ? Z[(long long)(c0 + a) * ncols + col] : 0.0);
   }
 }
 // what: 1 = the matrix blocks T, U (workgroups with blockIdx.y == 0), 2 = the right-hand sides, 3 = both
@@ -1382,6 +1388,10 @@ __global__ __launch_bounds__(64) void k_sep_rhs(PartView pv, int ncols) {
     }
 #pragma unroll
     for (int a = 0; a < S3; ++a) { prev[a] = rv[a]; Rr[((long long)(q) * S3 + a) * ncols + col] = rv[a]; }
+    if (pv.Zs != nullptr) {                                // the solution also into the separator's own rows of Z
+#pragma unroll
+      for (int a = 0; a < S3; ++a) pv.Zs[(long long)(pv.qrow[q] + a) * ncols + col] = rv[a];
+    }
   }
 }
 
@@ -1674,7 +1684,10 @@ __global__ __launch_bounds__(256) void k_sep_bcr_rhs(PartView pv, int ncols) {
   }
   for (int e = tid; e < m * S3 * TC; e += 256) {
     const int c = e % TC, a = (e / TC) % S3, q = e / (TC * S3);
-    if (col0 + c < ncols) Rr[((long long)q * S3 + a) * ncols + col0 + c] = xs[e];
+    if (col0 + c < ncols) {
+      Rr[((long long)q * S3 + a) * ncols + col0 + c] = xs[e];
+      if (pv.Zs != nullptr) pv.Zs[(long long)(pv.qrow[q] + a) * ncols + col0 + c] = xs[e];       // ... and into the separator's own rows of Z
+    }
   }
 }
 
@@ -1831,35 +1844,18 @@ struct GemmSet {
   }
 };
 
-// The product's rows [row_lo, row_hi) are cut into sets of 16; wavefront g of nslab * 4 takes sets [g q + min(g, r), ...) with
-// q, r = nsets / nwaves, nsets % nwaves -- every wavefront within one set of the others; only the very last set can be partial.
-template <int NJ>   // NJ = 3: 48x48 tile of the symmetric part, NJ = 1: 48x16 tile holding the rhs column
-__device__ __forceinline__ void schur_gemm_tile(const NEView& ne, int ncols, const double* __restrict__ Ecm, const double* __restrict__ Z,
-                                                double* __restrict__ Gp, int a0, int b0, int row_lo, int row_hi, int slab, int nslab, double* red) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int lr = lane & 15, lk = lane >> 4;
-  d4 acc[3][NJ];
-#pragma unroll
-  for (int i = 0; i < 3; ++i)
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
-  int ao[3], bo[NJ];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {                                // A = the cross block where the assembly left it (camera-major [C][3N][B]):
-    const int col = min(a0 + 16 * i + lr, ne.CB - 1);          // column (c, k) of row r is Et[(c N3 + r) B + k] -- row stride B, per-lane offset
-    ao[i] = (col / ne.B) * ne.N3 * ne.B + col % ne.B;
-  }
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) bo[j] = NJ == 3 ? min(b0 + 16 * j + lr, ne.CB - 1) : ne.CB;
-  const int nsets = (row_hi - row_lo + kGemmSetRows - 1) / kGemmSetRows, nwaves = nslab * 4, g = slab * 4 + wave;
-  const int q = nsets / nwaves, r = nsets % nwaves;
-  const int s_lo = g * q + min(g, r), s_hi = s_lo + q + (g < r ? 1 : 0);
-  const bool tail = s_hi == nsets && s_hi > s_lo && (row_hi - row_lo) % kGemmSetRows != 0;
+// sets [s_lo, s_hi) of 16 rows of ONE operand pair (A row stride lda with per-lane offsets ao, B row stride ldb with bo), rows
+// [row_lo, row_hi): only the pair's very last set can be partial
+template <int NJ>
+__device__ __forceinline__ void schur_gemm_sets(d4 (&acc)[3][NJ], const double* __restrict__ A, const double* __restrict__ Bm, long long lda, long long ldb,
+                                                const int (&ao)[3], const int (&bo)[NJ], int row_lo, int row_hi, int s_lo, int s_hi, int lk) {
+  if (s_hi <= s_lo) return;
+  const int nsets = (row_hi - row_lo + kGemmSetRows - 1) / kGemmSetRows;
+  const bool tail = s_hi == nsets && (row_hi - row_lo) % kGemmSetRows != 0;
   const int nfull = s_hi - s_lo - (tail ? 1 : 0);
-  const long long lda = ne.B, ldb = ncols;
   const int k0 = row_lo + s_lo * kGemmSetRows;
-  const double* ap = Ecm + (long long)(k0 + lk) * lda;
-  const double* bp = Z + (long long)(k0 + lk) * ldb;
+  const double* ap = A + (long long)(k0 + lk) * lda;
+  const double* bp = Bm + (long long)(k0 + lk) * ldb;
   const long long sa = kGemmSetRows * lda, sb = kGemmSetRows * ldb;
   GemmSet<NJ> s0, s1;
   if (nfull > 0) {
@@ -1881,9 +1877,39 @@ __device__ __forceinline__ void schur_gemm_tile(const NEView& ne, int ncols, con
     }
   }
   if (tail) {
-    s0.load_tail(Ecm, Z, lda, ldb, ao, bo, row_lo + (s_hi - 1) * kGemmSetRows, row_hi, lk);
+    s0.load_tail(A, Bm, lda, ldb, ao, bo, row_lo + (s_hi - 1) * kGemmSetRows, row_hi, lk);
     s0.multiply(acc);
   }
+}
+// The product's K range is the rows [row_lo, row_hi) of (Ecm, Z) followed by the rows [0, sep_rows) of the compact pair (Dl, Xs) -- the
+// separators' correction term (one rank, round 5; sep_rows = 0: none) --, cut into sets of 16; wavefront g of nslab * 4 takes sets
+// [g q + min(g, r), ...) with q, r = nsets / nwaves, nsets % nwaves of the WHOLE range: every wavefront within one set of the others.
+template <int NJ>   // NJ = 3: 48x48 tile of the symmetric part, NJ = 1: 48x16 tile holding the rhs column
+__device__ __forceinline__ void schur_gemm_tile(const NEView& ne, int ncols, const double* __restrict__ Ecm, const double* __restrict__ Z,
+                                                double* __restrict__ Gp, int a0, int b0, int row_lo, int row_hi, int slab, int nslab, double* red,
+                                                const double* __restrict__ Dl, const double* __restrict__ Xs, int sep_rows) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lr = lane & 15, lk = lane >> 4;
+  d4 acc[3][NJ];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+  int ao[3], ac[3], bo[NJ];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {                                // A = the cross block where the assembly left it (camera-major [C][3N][B]):
+    const int col = min(a0 + 16 * i + lr, ne.CB - 1);          // column (c, k) of row r is Et[(c N3 + r) B + k] -- row stride B, per-lane offset
+    ao[i] = (col / ne.B) * ne.N3 * ne.B + col % ne.B;
+    ac[i] = col;                                               // (the compact pair is row-major [rows][CB])
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) bo[j] = NJ == 3 ? min(b0 + 16 * j + lr, ne.CB - 1) : ne.CB;
+  const int nmain = (row_hi - row_lo + kGemmSetRows - 1) / kGemmSetRows, ncorr = (sep_rows + kGemmSetRows - 1) / kGemmSetRows;
+  const int nsets = nmain + ncorr, nwaves = nslab * 4, g = slab * 4 + wave;
+  const int q = nsets / nwaves, r = nsets % nwaves;
+  const int s_lo = g * q + min(g, r), s_hi = s_lo + q + (g < r ? 1 : 0);
+  schur_gemm_sets<NJ>(acc, Ecm, Z, ne.B, ncols, ao, bo, row_lo, row_hi, min(s_lo, nmain), min(s_hi, nmain), lk);
+  if (ncorr > 0) schur_gemm_sets<NJ>(acc, Dl, Xs, ne.CB, ncols, ac, bo, 0, sep_rows, max(s_lo, nmain) - nmain, max(s_hi, nmain) - nmain, lk);
   // sum the four wavefronts through LDS, then store: element (i, j, reg) of lane l is row 16i + (l>>4) + 4 reg, col 16j + (l&15)
   for (int w = 0; w < 4; ++w) {
     if (wave == w) {
@@ -1912,21 +1938,24 @@ __device__ __forceinline__ void schur_gemm_tile(const NEView& ne, int ncols, con
 // 154 - 308 MB for 55 MB of operands, and the kernel ran at the fabric's rate, not the matrix cores').  Grid: 8 * tiles *
 // ceil(nslab / 8) workgroups; the slab count is chosen by the host (HipSchur::plan_gemm) to fill whole rounds of the XCD's slots.
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void k_schur_gemm(NEView ne, int ncols, int row_lo, int row_hi, int nslab, const double* __restrict__ Ecm, const double* __restrict__ Z, double* __restrict__ Gp) {
+void k_schur_gemm(NEView ne, int ncols, int row_lo, int row_hi, int nslab, const double* __restrict__ Ecm, const double* __restrict__ Z, double* __restrict__ Gp,
+                  const double* __restrict__ Dl = nullptr, const double* __restrict__ Xs = nullptr, int sep_rows = 0) {
   __shared__ double red[9 * 4 * 64];
   const int nbk = (ne.CB + kGemmT - 1) / kGemmT, nsym = nbk * (nbk + 1) / 2, tiles = nsym + nbk;
   const int L = blockIdx.x, j = L >> 3;
   const int slab = (L & 7) + 8 * (j / tiles), t = j % tiles;
   if (slab >= nslab) return;
   double* G = Gp + (long long)slab * ne.CB * ncols;
+  // (Dl, Xs, sep_rows: one rank, round 5 -- the separators' share of E^T C^-1 E that is not in E_S^T X_S, (R_S - E_S)^T X_S over the compact
+  // separator arrays, as further rows of K; with it the product may read the interiors' UNCORRECTED solutions: HipSchur, where ncorr is set)
   if (t < nsym) {
     int bi = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
     while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
     while (bi * (bi + 1) / 2 > t) --bi;
     const int bj = t - bi * (bi + 1) / 2;
-    schur_gemm_tile<3>(ne, ncols, Ecm, Z, G, bi * kGemmT, bj * kGemmT, row_lo, row_hi, slab, nslab, red);
+    schur_gemm_tile<3>(ne, ncols, Ecm, Z, G, bi * kGemmT, bj * kGemmT, row_lo, row_hi, slab, nslab, red, Dl, Xs, sep_rows);
   } else {
-    schur_gemm_tile<1>(ne, ncols, Ecm, Z, G, (t - nsym) * kGemmT, ne.CB, row_lo, row_hi, slab, nslab, red);
+    schur_gemm_tile<1>(ne, ncols, Ecm, Z, G, (t - nsym) * kGemmT, ne.CB, row_lo, row_hi, slab, nslab, red, Dl, Xs, sep_rows);
   }
 }
 
@@ -2240,6 +2269,41 @@ __global__ __launch_bounds__(kThreads) void k_back_substitute(DevProblem dp, NEV
   }
 }
 
+// One rank, round 5: the interiors' rows of the step from k_back_substitute's UNCORRECTED values.  The interiors' columns of Z are no
+// longer corrected for the separators (k_part_back: a read-modify-write of all of Z); for the one vector that needs it,
+//   p_i = -(Z_i p_c + z_g,i) + sum_a VW[i][a] s[a],   s = X_S p_c + x_S,g = -(the separator's entries of p, which k_back_substitute
+// has just written from the separators' rows of Z),
+// so one thread per interior row subtracts 2 s3 products of the step's own separator entries.
+template <int S3>
+__global__ __launch_bounds__(128) void k_back_correct(DevProblem dp, NEView ne, PartView pv, double* __restrict__ px) {
+  const int p = blockIdx.x, i = threadIdx.x;
+  constexpr int st = 2 * S3;
+  const int r0 = pv.i0[p], nr = pv.i1[p] - r0;
+  const int sl = pv.sl[p], sr = pv.sr[p];
+  __shared__ double sx[st];
+  if (i < st) {
+    const int base = i < S3 ? sl : sr, a = i < S3 ? i : i - S3;
+    double v = 0.0;
+    if (base >= 0) { const int r = base + a, g = r / 3 + ne.row0; v = px[dp.mv.ctrl_x0[g] + (r % 3) * dp.mv.ctrl_stride[g]]; }
+    sx[i] = v;
+  }
+  __syncthreads();
+  if (i >= nr) return;
+  const double* __restrict__ vw = pv.VW + ((long long)p * kPartRowsMax + i) * st;
+  double acc = 0.0;
+  if (sl >= 0) {
+#pragma unroll
+    for (int a = 0; a < S3; ++a) acc += vw[a] * sx[a];
+  }
+  if (sr >= 0) {
+#pragma unroll
+    for (int a = 0; a < S3; ++a) acc += vw[S3 + a] * sx[S3 + a];
+  }
+  const int r = r0 + i, g = r / 3 + ne.row0;
+  px[dp.mv.ctrl_x0[g] + (r % 3) * dp.mv.ctrl_stride[g]] -= acc;
+}
+static_assert(kPartRowsMax <= 128, "k_back_correct: one thread per row of an interior");
+
 template <class BE>
 struct HipSchur {
   BE& be;
@@ -2259,6 +2323,8 @@ struct HipSchur {
   PartView pv{};
   int* part_tables = nullptr;
   int nslab = 1;            // K-slabs of the Schur product (partial sums in G): HipSchur::plan_gemm
+  int ncorr = 0;            // 1: the product carries the separators' correction term and the interiors are NOT back-corrected (one rank)
+  double* Dl = nullptr;
   int bcr_cols = kBcrCols;
   size_t bcr_lds = 0;       // dynamic LDS of k_sep_bcr_rhs; the sequential separator kernels remain for chains too long for it
   bool use_bcr = false;
@@ -2412,11 +2478,18 @@ struct HipSchur {
     pv.nt = (int)tc0.size();
     std::vector<int> tab;
     for (const std::vector<int>* v : std::initializer_list<const std::vector<int>*>{&cp.i0, &cp.i1, &sl, &sr, &tc0, &tpl, &tpr, &tgq, &town}) tab.insert(tab.end(), v->begin(), v->end());
+    const size_t qrow_at = tab.size();
+    {
+      std::vector<int> qrow((size_t)std::max(pv.m, 1), 0);          // separator (global number) -> its first scalar row here, when owned
+      for (size_t t = 0; t < tc0.size(); ++t) if (town[t]) qrow[(size_t)tgq[t]] = tc0[t];
+      tab.insert(tab.end(), qrow.begin(), qrow.end());
+    }
     tab.push_back(0);
     MVUS_HIP(hipMalloc(reinterpret_cast<void**>(&part_tables), tab.size() * sizeof(int)));
     MVUS_HIP(hipMemcpyAsync(part_tables, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice, be.stream));
     pv.i0 = part_tables; pv.i1 = pv.i0 + pv.P; pv.sl = pv.i1 + pv.P; pv.sr = pv.sl + pv.P;
     pv.tc0 = pv.sr + pv.P; pv.tpl = pv.tc0 + pv.nt; pv.tpr = pv.tpl + pv.nt; pv.tgq = pv.tpr + pv.nt; pv.town = pv.tgq + pv.nt;
+    pv.qrow = part_tables + qrow_at; pv.CB = ne.CB; pv.Dl = nullptr; pv.Zs = nullptr;
     if (nbound > 0) {
       std::vector<int> hb;
       if (ts.rank > 0) hb.push_back(ts.cuts[ts.rank]);
@@ -2428,6 +2501,19 @@ struct HipSchur {
     }
     MVUS_HIP(hipStreamSynchronize(be.stream));
     pv.VW = be.alloc((size_t)pv.P * kPartRowsMax * 2 * pv.s3);
+    // One rank: the interiors' columns of Z are NOT corrected for the separators after the separator solve (k_part_back: a
+    // read-modify-write of all of Z, 20 us at configs[2], 41 at configs[3]).  Block elimination gives
+    //   E^T C^-1 E = E_I^T (B^-1 E_I) + R_S^T X_S,   R_S = E_S - H_SI B^-1 E_I  (the separators' reduced right-hand sides),
+    // so the Schur product may pair the cross block with the UNCORRECTED interior solutions if the separator rows contribute R_S^T X_S:
+    // X_S goes into the separators' rows of Z (k_sep_bcr_rhs), where it meets E_S, and (R_S - E_S)^T X_S is added as further rows of the
+    // product's K range, over the compact arrays pv.Dl, pv.R (dealt to the same wavefronts: schur_gemm_tile).  The step's own back-substitution is corrected for ONE vector
+    // (k_back_correct).  Time shards keep the back-correction: their separator sums run over the ranks.
+    ncorr = 0;
+    if (!shard && !wide && pv.m > 0 && std::getenv("MVUS_PART_BACK") == nullptr) {
+      ncorr = 1;
+      Dl = be.alloc((size_t)pv.m * pv.s3 * ne.CB);
+      pv.Dl = Dl; pv.Zs = Z;
+    }
     const size_t mm = (size_t)std::max(pv.m, 1), ss = (size_t)pv.s3 * pv.s3;
     sep_count = mm * (2 * ss + (size_t)pv.s3 * ncols);
     sepbuf = be.alloc(sep_count);                    // [T | U | R]: one sum over the ranks
@@ -2521,7 +2607,7 @@ struct HipSchur {
     else MVUS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_assemble_windows<9>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)win_lds));
   }
   ~HipSchur() {
-    for (double* p : {NE, Lb, Z, G, G0, S, S2, Linv, rhs, pc, DG, px, pv.VW, sepbuf, pv.U2, pv.Ha, pv.Hc, wv.Apart, rcs.Simg, rcs.Tsc, rcs.x}) if (p) be.release(p);
+    for (double* p : {Dl, NE, Lb, Z, G, G0, S, S2, Linv, rhs, pc, DG, px, pv.VW, sepbuf, pv.U2, pv.Ha, pv.Hc, wv.Apart, rcs.Simg, rcs.Tsc, rcs.x}) if (p) be.release(p);
     if (win_tables) (void)hipFree(win_tables);
     if (part_tables) (void)hipFree(part_tables);
     if (halo_tables) (void)hipFree(halo_tables);
@@ -2688,9 +2774,11 @@ struct HipSchur {
         hipLaunchKernelGGL(k_sep_factor<S3T>, dim3(1), dim3(64), 0, be.stream, pv, fail);
         hipLaunchKernelGGL(k_sep_rhs<S3T>, dim3((ncols + 63) / 64), dim3(64), 0, be.stream, pv, ncols);
       }
-      const int gy = (ncols + 63) / 64, gz = (kPartRowsMax + kBackRows - 1) / kBackRows;
-      const dim3 gback(xcd_grid(pv.P * gy * gz));
-      hipLaunchKernelGGL(k_part_back<S3T>, gback, dim3(64), 0, be.stream, pv, ncols, Z, gy, gz);
+      if (ncorr == 0) {                                   // (one rank: no back-correction -- see where ncorr is set)
+        const int gy = (ncols + 63) / 64, gz = (kPartRowsMax + kBackRows - 1) / kBackRows;
+        const dim3 gback(xcd_grid(pv.P * gy * gz));
+        hipLaunchKernelGGL(k_part_back<S3T>, gback, dim3(64), 0, be.stream, pv, ncols, Z, gy, gz);
+      }
     }
   }
 
@@ -2717,7 +2805,9 @@ struct HipSchur {
     const int row_lo = 3 * own_lo, row_hi = 3 * own_hi;
     {
       const int nbk = (ne.CB + kGemmT - 1) / kGemmT;
-      hipLaunchKernelGGL(k_schur_gemm, dim3(8 * (nbk * (nbk + 1) / 2 + nbk) * ((nslab + 7) / 8)), dim3(256), 0, be.stream, ne, ncols, row_lo, row_hi, nslab, ne.Et, Z, G);
+      const bool corr = !wide && ncorr > 0;
+      hipLaunchKernelGGL(k_schur_gemm, dim3(8 * (nbk * (nbk + 1) / 2 + nbk) * ((nslab + 7) / 8)), dim3(256), 0, be.stream, ne, ncols, row_lo, row_hi, nslab, ne.Et, Z, G,
+                         corr ? (const double*)pv.Dl : (const double*)nullptr, (const double*)pv.R, corr ? pv.m * pv.s3 : 0);
     }
     const int ntile = (ne.CB + kNB - 1) / kNB;
     const double* Gsum = G;
@@ -2763,6 +2853,10 @@ struct HipSchur {
     const int nrows = row_hi - row_lo, per = kThreads / 64;
     hipLaunchKernelGGL(k_back_substitute, dim3((unsigned)std::max(1, (nrows + per - 1) / per)), dim3(kThreads), 0, be.stream, be.dp, ne, ncols,
                        row_lo, row_hi, (int)(!shard || be.tshard.rank == 0), Z, pc, px, fail, (!shard && be.scal_direct()) ? fail_map : (int*)nullptr);
+    if (!wide && ncorr > 0) {                          // the interiors' rows were computed from uncorrected columns: one vector is corrected here
+      if (BW == 11) hipLaunchKernelGGL(k_back_correct<9>, dim3(pv.P), dim3(128), 0, be.stream, be.dp, ne, pv, px);
+      else hipLaunchKernelGGL(k_back_correct<15>, dim3(pv.P), dim3(128), 0, be.stream, be.dp, ne, pv, px);
+    }
     if (shard) {
       hipLaunchKernelGGL(k_fail_pack, dim3(1), dim3(64), 0, be.stream, fail, px + be.hp.n);
       be.reduce(px, (size_t)be.hp.n + 2);             // every rank's part of the step (+ failure flags)
