@@ -894,10 +894,11 @@ struct PartView {
   const int *tc0, *tpl, *tpr, *tgq, *town;
   double* VW;            // [P][kPartRowsMax][2*s3]
   // one rank, round 5 (no back-correction of the interiors' columns, see HipSchur::band_chain):
-  double* Dl;            // [m][s3][CB] reduced minus original right-hand sides of the separators, R_S - E_S (nullptr: not kept)
-  double* Zs;            // the separator solutions X_S also go into the separators' own rows of Z (nullptr: not)
-  const int* qrow;       // [m] first scalar row of separator q
-  int CB;
+  double* Dl;            // [m][s3][CB] a copy of the separators' reduced right-hand sides R_S (pv.R is solved in place); nullptr: not kept
+  const double* Et;      // with Dl: the separators' rows of Z are ZERO and their own right-hand sides are read from the assembled blocks:
+  const double* gs;      //   the camera-major cross block [C][N3][B] and the spline gradient [N3]
+  const unsigned char* seprow;   // [N3] 1 = the row belongs to a separator
+  int CB, B, N3;
   double* T;             // [m][s3][s3] diagonal blocks of the separator system
   double* U;             // [m][s3][s3] U[q] = T(q, q+1)
   double *U2, *Ha, *Hc;  // [m][s3][s3] each: cyclic-reduction workspace (k_sep_bcr_*)
@@ -1175,7 +1176,11 @@ __device__ __forceinline__ void part_reduce_rhs(const PartView& pv, int ncols, c
   const int b0 = pr >= 0 ? pv.i0[pr] : 0, b1 = pr >= 0 ? pv.i1[pr] : 0;
   for (int e = e0; e < s3 * ncols; e += estride) {
     const int a = e / ncols, col = e % ncols;
-    double r = own ? Z[(long long)(c0 + a) * ncols + col] : 0.0;
+    double r = 0.0;
+    if (own) {
+      if (pv.Dl == nullptr) r = Z[(long long)(c0 + a) * ncols + col];
+      else r = col < pv.CB ? pv.Et[((long long)(col / pv.B) * pv.N3 + (c0 + a)) * pv.B + col % pv.B] : pv.gs[c0 + a];    // (its rows of Z hold zeros)
+    }
     if (pl >= 0) {                                       // (clamped rows, dropped products: every load unconditional, as in k_part_reduce)
       double f[BW], z[BW];
 #pragma unroll
@@ -1199,7 +1204,7 @@ __device__ __forceinline__ void part_reduce_rhs(const PartView& pv, int ncols, c
       for (int jj = 0; jj < BW; ++jj) r -= (b0 + jj < b1) ? f[jj] * z[jj] : 0.0;
     }
     pv.R[((long long)gq * s3 + a) * ncols + col] = r;
-    if (pv.Dl != nullptr && col < pv.CB) pv.Dl[((long long)gq * s3 + a) * pv.CB + col] = r - (own ? Z[(long long)(c0 + a) * ncols + col] : 0.0);
+    if (pv.Dl != nullptr && col < pv.CB) pv.Dl[((long long)gq * s3 + a) * pv.CB + col] = r;
   }
 }
 // what: 1 = the matrix blocks T, U (workgroups with blockIdx.y == 0), 2 = the right-hand sides, 3 = both
@@ -1388,10 +1393,6 @@ __global__ __launch_bounds__(64) void k_sep_rhs(PartView pv, int ncols) {
     }
 #pragma unroll
     for (int a = 0; a < S3; ++a) { prev[a] = rv[a]; Rr[((long long)(q) * S3 + a) * ncols + col] = rv[a]; }
-    if (pv.Zs != nullptr) {                                // the solution also into the separator's own rows of Z
-#pragma unroll
-      for (int a = 0; a < S3; ++a) pv.Zs[(long long)(pv.qrow[q] + a) * ncols + col] = rv[a];
-    }
   }
 }
 
@@ -1684,10 +1685,7 @@ __global__ __launch_bounds__(256) void k_sep_bcr_rhs(PartView pv, int ncols) {
   }
   for (int e = tid; e < m * S3 * TC; e += 256) {
     const int c = e % TC, a = (e / TC) % S3, q = e / (TC * S3);
-    if (col0 + c < ncols) {
-      Rr[((long long)q * S3 + a) * ncols + col0 + c] = xs[e];
-      if (pv.Zs != nullptr) pv.Zs[(long long)(pv.qrow[q] + a) * ncols + col0 + c] = xs[e];       // ... and into the separator's own rows of Z
-    }
+    if (col0 + c < ncols) Rr[((long long)q * S3 + a) * ncols + col0 + c] = xs[e];
   }
 }
 
@@ -1744,13 +1742,14 @@ __global__ __launch_bounds__(64) void k_part_back(PartView pv, int ncols, double
 // itself -- 34 MB less written at configs[2], 138 MB at configs[3]: k_cholesky_and_rhs 69 -> 55 us there.)
 // The same launch also packs the damped band (band_pack_entry: the two are independent element-wise passes over the assembled
 // blocks, and every launch costs ~4.7 us before it does anything).
-__global__ void k_build_rhs(NEView ne, int ncols, double* __restrict__ Z, double lambda, int BW, double* __restrict__ Lb,
+__global__ void k_build_rhs(NEView ne, int ncols, double* __restrict__ Z, const unsigned char* __restrict__ seprow, double lambda, int BW, double* __restrict__ Lb,
                             int* __restrict__ fail, DevProblem dp, int with_diag, double* __restrict__ D, double* __restrict__ gx, int tiles) {
   const long long idx = xcd_tile(tiles) * (long long)blockDim.x + threadIdx.x;      // XCD-aware order: 31.5 -> 25 us (see xcd_tile)
   band_pack_entry(ne, lambda, BW, Lb, fail, dp, with_diag, D, gx, idx);
   if (idx >= (long long)ne.N3 * ncols) return;
   const int r = (int)(idx / ncols), cidx = (int)(idx % ncols);
-  if (cidx < ne.CB) {
+  if (seprow != nullptr && seprow[r]) Z[idx] = 0.0;            // (one rank: the separators' rows take no part in the product's main range)
+  else if (cidx < ne.CB) {
     const int c = cidx / ne.B, k = cidx % ne.B;
     Z[idx] = ne.Et[((long long)c * ne.N3 + r) * ne.B + k];
   } else {
@@ -1768,7 +1767,7 @@ __global__ void k_band_pack(NEView ne, double lambda, int BW, double* __restrict
 }
 template <int BW>
 __global__ __launch_bounds__(256) void k_cholesky_and_rhs(PartView pv, double* __restrict__ Lb, int* __restrict__ fail, int chol_blocks,
-                                                          NEView ne, int ncols, double* __restrict__ Z, int tiles) {
+                                                          NEView ne, int ncols, double* __restrict__ Z, int tiles, const unsigned char* __restrict__ seprow) {
   __shared__ double T[(kPartRowsMax + 1) * (BW + 1)];
   if ((int)blockIdx.x < chol_blocks) {                    // chol_blocks is a multiple of 8: the copy tiles keep their XCD mapping
     if ((int)blockIdx.x < pv.P && threadIdx.x < 64) part_cholesky_body<BW>(pv, Lb, fail, T, (int)blockIdx.x, (int)threadIdx.x);
@@ -1780,7 +1779,8 @@ __global__ __launch_bounds__(256) void k_cholesky_and_rhs(PartView pv, double* _
   const long long idx = (long long)(((qq / run) * 8 + xcd) * run + qq % run) * blockDim.x + threadIdx.x;     // xcd_tile for the shifted index
   if (idx >= (long long)ne.N3 * ncols) return;
   const int r = (int)(idx / ncols), cidx = (int)(idx % ncols);
-  if (cidx < ne.CB) {
+  if (seprow != nullptr && seprow[r]) Z[idx] = 0.0;            // (one rank: the separators' rows take no part in the product's main range)
+  else if (cidx < ne.CB) {
     const int c = cidx / ne.B, k = cidx % ne.B;
     Z[idx] = ne.Et[((long long)c * ne.N3 + r) * ne.B + k];        // (the product's first operand is read where the assembly left it)
   } else {
@@ -2269,25 +2269,52 @@ __global__ __launch_bounds__(kThreads) void k_back_substitute(DevProblem dp, NEV
   }
 }
 
-// One rank, round 5: the interiors' rows of the step from k_back_substitute's UNCORRECTED values.  The interiors' columns of Z are no
-// longer corrected for the separators (k_part_back: a read-modify-write of all of Z); for the one vector that needs it,
-//   p_i = -(Z_i p_c + z_g,i) + sum_a VW[i][a] s[a],   s = X_S p_c + x_S,g = -(the separator's entries of p, which k_back_substitute
-// has just written from the separators' rows of Z),
-// so one thread per interior row subtracts 2 s3 products of the step's own separator entries.
+// One rank, round 5: the step's spline rows when the interiors' columns of Z were NOT corrected for the separators (k_part_back: a
+// read-modify-write of all of Z) and the separators' rows of Z hold zeros.  k_back_substitute has written -(Z_i p_c + z_g,i) for the
+// interiors' rows (and zeros for the separators'); one workgroup per interior finishes them:
+//   s = X_S p_c + x_S,g  for the separators either side (rows of pv.R: 2 s3 dot products),
+//   p_i += sum_a VW[i][a] s[a]  for its rows,   p_S = -s  for the separator after it.
 template <int S3>
-__global__ __launch_bounds__(128) void k_back_correct(DevProblem dp, NEView ne, PartView pv, double* __restrict__ px) {
+__global__ __launch_bounds__(128) void k_back_correct(DevProblem dp, NEView ne, PartView pv, int ncols, const double* __restrict__ pc, double* __restrict__ px) {
   const int p = blockIdx.x, i = threadIdx.x;
   constexpr int st = 2 * S3;
   const int r0 = pv.i0[p], nr = pv.i1[p] - r0;
   const int sl = pv.sl[p], sr = pv.sr[p];
+  __shared__ double part[st][128];
   __shared__ double sx[st];
-  if (i < st) {
-    const int base = i < S3 ? sl : sr, a = i < S3 ? i : i - S3;
-    double v = 0.0;
-    if (base >= 0) { const int r = base + a, g = r / 3 + ne.row0; v = px[dp.mv.ctrl_x0[g] + (r % 3) * dp.mv.ctrl_stride[g]]; }
-    sx[i] = v;
+  {
+    const double* xr[st];
+    bool on[st];
+#pragma unroll
+    for (int a = 0; a < st; ++a) {
+      on[a] = (a < S3 ? sl : sr) >= 0;
+      const long long gq = (long long)pv.q_off + p - (a < S3 ? 1 : 0);
+      xr[a] = pv.R + ((on[a] ? gq : 0) * S3 + (a % S3)) * ncols;
+    }
+    double acc[st];
+#pragma unroll
+    for (int a = 0; a < st; ++a) acc[a] = 0.0;
+    for (int k = i; k < ne.CB; k += 128) {
+      const double pk = pc[k];
+#pragma unroll
+      for (int a = 0; a < st; ++a) acc[a] += xr[a][k] * pk;
+    }
+#pragma unroll
+    for (int a = 0; a < st; ++a) part[a][i] = on[a] ? acc[a] : 0.0;
+    __syncthreads();
+    if (i < st) {
+      double t = 0.0;
+      for (int w = 0; w < 128; ++w) t += part[i][w];
+      const bool o = (i < S3 ? sl : sr) >= 0;
+      const long long gq = (long long)pv.q_off + p - (i < S3 ? 1 : 0);
+      sx[i] = o ? t + pv.R[(gq * S3 + (i % S3)) * ncols + ne.CB] : 0.0;
+    }
+    __syncthreads();
   }
-  __syncthreads();
+  if (sr >= 0 && i < S3) {
+    const int r = sr + i, g = r / 3 + ne.row0;
+    px[dp.mv.ctrl_x0[g] + (r % 3) * dp.mv.ctrl_stride[g]] = -sx[S3 + i];
+  }
   if (i >= nr) return;
   const double* __restrict__ vw = pv.VW + ((long long)p * kPartRowsMax + i) * st;
   double acc = 0.0;
@@ -2300,7 +2327,7 @@ __global__ __launch_bounds__(128) void k_back_correct(DevProblem dp, NEView ne, 
     for (int a = 0; a < S3; ++a) acc += vw[S3 + a] * sx[S3 + a];
   }
   const int r = r0 + i, g = r / 3 + ne.row0;
-  px[dp.mv.ctrl_x0[g] + (r % 3) * dp.mv.ctrl_stride[g]] -= acc;
+  px[dp.mv.ctrl_x0[g] + (r % 3) * dp.mv.ctrl_stride[g]] += acc;
 }
 static_assert(kPartRowsMax <= 128, "k_back_correct: one thread per row of an interior");
 
@@ -2478,18 +2505,20 @@ struct HipSchur {
     pv.nt = (int)tc0.size();
     std::vector<int> tab;
     for (const std::vector<int>* v : std::initializer_list<const std::vector<int>*>{&cp.i0, &cp.i1, &sl, &sr, &tc0, &tpl, &tpr, &tgq, &town}) tab.insert(tab.end(), v->begin(), v->end());
-    const size_t qrow_at = tab.size();
+    const size_t seprow_at = tab.size();
     {
-      std::vector<int> qrow((size_t)std::max(pv.m, 1), 0);          // separator (global number) -> its first scalar row here, when owned
-      for (size_t t = 0; t < tc0.size(); ++t) if (town[t]) qrow[(size_t)tgq[t]] = tc0[t];
-      tab.insert(tab.end(), qrow.begin(), qrow.end());
+      std::vector<unsigned char> srow((size_t)(ne.N3 + 3) / 4 * 4, 0);      // 1 = the row belongs to a separator (bytes, packed into the int table)
+      for (int k = 0; k < (int)cp.sep.size(); ++k) for (int a = 0; a < pv.s3; ++a) { const int r = cp.sep[k] + a; if (r >= 0 && r < ne.N3) srow[(size_t)r] = 1; }     // (rows as the tasks' tc0: local to the slice)
+      tab.resize(tab.size() + srow.size() / 4);
+      std::memcpy(tab.data() + seprow_at, srow.data(), srow.size());
     }
     tab.push_back(0);
     MVUS_HIP(hipMalloc(reinterpret_cast<void**>(&part_tables), tab.size() * sizeof(int)));
     MVUS_HIP(hipMemcpyAsync(part_tables, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice, be.stream));
     pv.i0 = part_tables; pv.i1 = pv.i0 + pv.P; pv.sl = pv.i1 + pv.P; pv.sr = pv.sl + pv.P;
     pv.tc0 = pv.sr + pv.P; pv.tpl = pv.tc0 + pv.nt; pv.tpr = pv.tpl + pv.nt; pv.tgq = pv.tpr + pv.nt; pv.town = pv.tgq + pv.nt;
-    pv.qrow = part_tables + qrow_at; pv.CB = ne.CB; pv.Dl = nullptr; pv.Zs = nullptr;
+    pv.seprow = reinterpret_cast<const unsigned char*>(part_tables + seprow_at); pv.CB = ne.CB; pv.B = ne.B; pv.N3 = ne.N3; pv.Dl = nullptr;
+    pv.Et = ne.Et; pv.gs = ne.gs;
     if (nbound > 0) {
       std::vector<int> hb;
       if (ts.rank > 0) hb.push_back(ts.cuts[ts.rank]);
@@ -2504,15 +2533,15 @@ struct HipSchur {
     // One rank: the interiors' columns of Z are NOT corrected for the separators after the separator solve (k_part_back: a
     // read-modify-write of all of Z, 20 us at configs[2], 41 at configs[3]).  Block elimination gives
     //   E^T C^-1 E = E_I^T (B^-1 E_I) + R_S^T X_S,   R_S = E_S - H_SI B^-1 E_I  (the separators' reduced right-hand sides),
-    // so the Schur product may pair the cross block with the UNCORRECTED interior solutions if the separator rows contribute R_S^T X_S:
-    // X_S goes into the separators' rows of Z (k_sep_bcr_rhs), where it meets E_S, and (R_S - E_S)^T X_S is added as further rows of the
-    // product's K range, over the compact arrays pv.Dl, pv.R (dealt to the same wavefronts: schur_gemm_tile).  The step's own back-substitution is corrected for ONE vector
-    // (k_back_correct).  Time shards keep the back-correction: their separator sums run over the ranks.
+    // so the Schur product may pair the cross block with the UNCORRECTED interior solutions if the separators contribute R_S^T X_S: their
+    // rows of Z are written as ZEROS by the right-hand-side copy (nothing from the main K range), R_S is kept beside the in-place solve
+    // (pv.Dl) and R_S^T X_S runs as further rows of the product's K range over the compact arrays pv.Dl, pv.R (dealt to the same
+    // wavefronts: schur_gemm_tile).  The step's own back-substitution is corrected for ONE vector (k_back_correct).  Time shards keep the back-correction: their separator sums run over the ranks.
     ncorr = 0;
     if (!shard && !wide && pv.m > 0 && std::getenv("MVUS_PART_BACK") == nullptr) {
       ncorr = 1;
       Dl = be.alloc((size_t)pv.m * pv.s3 * ne.CB);
-      pv.Dl = Dl; pv.Zs = Z;
+      pv.Dl = Dl;
     }
     const size_t mm = (size_t)std::max(pv.m, 1), ss = (size_t)pv.s3 * pv.s3;
     sep_count = mm * (2 * ss + (size_t)pv.s3 * ncols);
@@ -2749,7 +2778,7 @@ struct HipSchur {
     const dim3 gsolve(pv.P, (ncols + 63) / 64 + 1);      // + one block row for the coupling columns
     if (overlap_chol) {
       const int cb = (pv.P + 7) / 8 * 8;
-      hipLaunchKernelGGL(k_cholesky_and_rhs<BWT>, dim3((unsigned)(cb + xcd_grid(rhs_tiles_z))), dim3(256), 0, be.stream, pv, Lb, fail, cb, ne, ncols, Z, rhs_tiles_z);
+      hipLaunchKernelGGL(k_cholesky_and_rhs<BWT>, dim3((unsigned)(cb + xcd_grid(rhs_tiles_z))), dim3(256), 0, be.stream, pv, Lb, fail, cb, ne, ncols, Z, rhs_tiles_z, pv.Dl ? pv.seprow : (const unsigned char*)nullptr);
     } else {
       hipLaunchKernelGGL(k_part_cholesky<BWT>, dim3(pv.P), dim3(64), 0, be.stream, pv, Lb, fail);
     }
@@ -2793,7 +2822,7 @@ struct HipSchur {
       hipLaunchKernelGGL(k_band_pack, dim3((unsigned)((nband + 255) / 256)), dim3(256), 0, be.stream, ne, lambda, BW, Lb, fail, be.dp, (int)diag_pending, D, gx);
       rhs_tiles_z = (int)((nZ + 255) / 256);
     } else {
-      hipLaunchKernelGGL(k_build_rhs, dim3((unsigned)xcd_grid(rhs_tiles)), dim3(256), 0, be.stream, ne, ncols, Z, lambda, BW, Lb, fail, be.dp,
+      hipLaunchKernelGGL(k_build_rhs, dim3((unsigned)xcd_grid(rhs_tiles)), dim3(256), 0, be.stream, ne, ncols, Z, (!wide && pv.Dl) ? pv.seprow : (const unsigned char*)nullptr, lambda, BW, Lb, fail, be.dp,
                          (int)diag_pending, D, gx, rhs_tiles);
     }
     diag_pending = false;
@@ -2854,8 +2883,8 @@ struct HipSchur {
     hipLaunchKernelGGL(k_back_substitute, dim3((unsigned)std::max(1, (nrows + per - 1) / per)), dim3(kThreads), 0, be.stream, be.dp, ne, ncols,
                        row_lo, row_hi, (int)(!shard || be.tshard.rank == 0), Z, pc, px, fail, (!shard && be.scal_direct()) ? fail_map : (int*)nullptr);
     if (!wide && ncorr > 0) {                          // the interiors' rows were computed from uncorrected columns: one vector is corrected here
-      if (BW == 11) hipLaunchKernelGGL(k_back_correct<9>, dim3(pv.P), dim3(128), 0, be.stream, be.dp, ne, pv, px);
-      else hipLaunchKernelGGL(k_back_correct<15>, dim3(pv.P), dim3(128), 0, be.stream, be.dp, ne, pv, px);
+      if (BW == 11) hipLaunchKernelGGL(k_back_correct<9>, dim3(pv.P), dim3(128), 0, be.stream, be.dp, ne, pv, ncols, (const double*)pc, px);
+      else hipLaunchKernelGGL(k_back_correct<15>, dim3(pv.P), dim3(128), 0, be.stream, be.dp, ne, pv, ncols, (const double*)pc, px);
     }
     if (shard) {
       hipLaunchKernelGGL(k_fail_pack, dim3(1), dim3(64), 0, be.stream, fail, px + be.hp.n);
