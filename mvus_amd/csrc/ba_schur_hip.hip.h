@@ -899,6 +899,7 @@ struct PartView {
   const double* gs;      //   the camera-major cross block [C][N3][B] and the spline gradient [N3]
   const unsigned char* seprow;   // [N3] 1 = the row belongs to a separator
   int CB, B, N3;
+  int direct;            // 1: no right-hand-side copy -- the interior solves read the assembled blocks (part_solve_block), Z's separator rows stay zero
   double* T;             // [m][s3][s3] diagonal blocks of the separator system
   double* U;             // [m][s3][s3] U[q] = T(q, q+1)
   double *U2, *Ha, *Hc;  // [m][s3][s3] each: cyclic-reduction workspace (k_sep_bcr_*)
@@ -1053,6 +1054,16 @@ __device__ __forceinline__ void part_solve_block(const PartView& pv, int ncols, 
   if (!live) return;                                         // no barrier below
   double* out = COUPLING ? pv.VW + ((long long)p * kPartRowsMax) * (2 * s3) + tid : Z + (long long)r0 * ncols + by * 64 + tid;
   const long long ostride = COUPLING ? 2 * s3 : ncols;
+  // where the forward pass reads its right-hand side: the column's rows of Z (written by the right-hand-side copy), or -- pv.direct, one rank,
+  // many columns -- the assembled blocks themselves: column (c, k) of the camera-major cross block, the spline gradient for the last
+  // column.  The copy (a pass over all of E and Z) is then not launched at all.
+  const double* src = out;
+  long long sstride = ostride;
+  if (!COUPLING && pv.direct) {
+    const int col = min((int)(by * 64 + tid), ncols - 1);
+    if (col < pv.CB) { src = pv.Et + ((long long)(col / pv.B) * pv.N3 + r0) * pv.B + col % pv.B; sstride = pv.B; }
+    else { src = pv.gs + r0; sstride = 1; }
+  }
   // Batches of kPf rows.  A FULL batch (all its rows inside the interior) is loaded, solved and stored without a single condition:
   // with a condition per row (`i < nr ? load : 0`) every load and store sat in its own scalar branch and the compiler closed each
   // batch of prefetches with s_waitcnt vmcnt(0) -- the wavefront then waited out the memory latency once per batch in both passes
@@ -1063,8 +1074,8 @@ __device__ __forceinline__ void part_solve_block(const PartView& pv, int ncols, 
 #pragma unroll
     for (int k = 0; k < kPf; ++k) {
       const int i = ib + k;
-      if constexpr (decltype(full)::value) dst[k] = COUPLING ? band_entry_nc<BW>(Lb, r0 + i, ccol) : out[(long long)i * ostride];
-      else dst[k] = i < nr ? (COUPLING ? band_entry<BW>(Lb, r0 + i, ccol) : out[(long long)i * ostride]) : 0.0;
+      if constexpr (decltype(full)::value) dst[k] = COUPLING ? band_entry_nc<BW>(Lb, r0 + i, ccol) : src[(long long)i * sstride];
+      else dst[k] = i < nr ? (COUPLING ? band_entry<BW>(Lb, r0 + i, ccol) : src[(long long)i * sstride]) : 0.0;
     }
   };
   auto load_y = [&](auto full, double (&dst)[kPf], int ib) {
@@ -2517,7 +2528,7 @@ struct HipSchur {
     MVUS_HIP(hipMemcpyAsync(part_tables, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice, be.stream));
     pv.i0 = part_tables; pv.i1 = pv.i0 + pv.P; pv.sl = pv.i1 + pv.P; pv.sr = pv.sl + pv.P;
     pv.tc0 = pv.sr + pv.P; pv.tpl = pv.tc0 + pv.nt; pv.tpr = pv.tpl + pv.nt; pv.tgq = pv.tpr + pv.nt; pv.town = pv.tgq + pv.nt;
-    pv.seprow = reinterpret_cast<const unsigned char*>(part_tables + seprow_at); pv.CB = ne.CB; pv.B = ne.B; pv.N3 = ne.N3; pv.Dl = nullptr;
+    pv.seprow = reinterpret_cast<const unsigned char*>(part_tables + seprow_at); pv.CB = ne.CB; pv.B = ne.B; pv.N3 = ne.N3; pv.Dl = nullptr; pv.direct = 0;
     pv.Et = ne.Et; pv.gs = ne.gs;
     if (nbound > 0) {
       std::vector<int> hb;
@@ -2542,6 +2553,12 @@ struct HipSchur {
       ncorr = 1;
       Dl = be.alloc((size_t)pv.m * pv.s3 * ne.CB);
       pv.Dl = Dl;
+      // ... and the right-hand-side copy (Z = row-major E: a pass over both, the longer half of k_cholesky_and_rhs at configs[3]) is not
+      // made at all: the interior solves' forward pass reads the assembled blocks (part_solve_block).  Z's separator rows are then
+      // written by nobody: zeroed once, here.  (configs[3] 1.245 -> 1.218 ms, configs[2] 0.468 -> 0.460, configs[1] level.)
+      pv.direct = 1;
+      if (const char* e = std::getenv("MVUS_DIRECT_RHS")) pv.direct = std::atoi(e) != 0;
+      if (pv.direct) MVUS_HIP(hipMemsetAsync(Z, 0, (size_t)ne.N3 * ncols * sizeof(double), be.stream));
     }
     const size_t mm = (size_t)std::max(pv.m, 1), ss = (size_t)pv.s3 * pv.s3;
     sep_count = mm * (2 * ss + (size_t)pv.s3 * ncols);
@@ -2776,7 +2793,7 @@ struct HipSchur {
   template <int BWT, int S3T>
   void band_chain() {
     const dim3 gsolve(pv.P, (ncols + 63) / 64 + 1);      // + one block row for the coupling columns
-    if (overlap_chol) {
+    if (overlap_chol && !pv.direct) {
       const int cb = (pv.P + 7) / 8 * 8;
       hipLaunchKernelGGL(k_cholesky_and_rhs<BWT>, dim3((unsigned)(cb + xcd_grid(rhs_tiles_z))), dim3(256), 0, be.stream, pv, Lb, fail, cb, ne, ncols, Z, rhs_tiles_z, pv.Dl ? pv.seprow : (const unsigned char*)nullptr);
     } else {
