@@ -5,7 +5,8 @@ rows below each super-block solved inside the factor launch (flag hand-over betw
 
 No counterpart in the reference (reconstruction/common.py:670 delegates the whole solve to scipy); what is checked is that the
 damped step p of the whole GPU chain solves (H + lambda diag H) p = -g, for reduced systems of 1 .. 5 super-panels of 144 unknowns,
-sizes that are not multiples of 16 (identity padding), and P = 6 and 15 camera parameters."""
+sizes that are not multiples of 16 (identity padding), and P = 6 and 15 camera parameters.  Also here: the band solver's one-rank path
+of round 5 (no right-hand-side copy, no back-correction) against the path time shards still run and against the dense solve."""
 import numpy as np
 import pytest
 
@@ -86,3 +87,40 @@ def test_non_positive_pivot_raises_the_flag_and_lm_recovers():
     with BAHandle(prob) as h:
         r = h.solve(x0, solver=_lib.SOLVER_LM_SCHUR, jac_mode=_lib.JAC_ANALYTIC, max_nfev=8)
         assert np.isfinite(r.cost) and r.cost < r.initial_cost
+
+
+# the band solver's one-rank path of round 5 (no right-hand-side copy, no back-correction of the interiors' columns: the separators'
+# share of E^T C^-1 E as further rows of the Schur product, the step corrected for one vector) against the path of rounds 2-4
+# (MVUS_PART_BACK=1, still what time shards run) and against the dense solve; interiors of 16 and of 32 control points
+@pytest.mark.parametrize('cams,calib,knots', [(7, False, 40), (5, True, 64), (20, False, 150), (33, False, 90)])
+def test_band_solver_without_back_correction(cams, calib, knots, monkeypatch):
+    from mvus_amd import synth
+    from mvus_amd.ba import BAHandle
+    sc = synth.make_scene(cams, 120 * cams + 600, seed=300 + cams, rolling_shutter=True, num_knots=knots, opt_calib=calib)
+    prob, x0 = mp.problem_from_scene(sc)
+    lams = (1e-3, 0.7)
+
+    def steps(env):
+        for k in ('MVUS_PART_BACK', 'MVUS_DIRECT_RHS', 'MVUS_PART_LEN'):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with BAHandle(prob) as h:
+            h.residual_jacobian(x0, _lib.JAC_ANALYTIC)
+            out = [h.lm_step(lam) for lam in lams]
+            ref = [_dense_step(prob, h, lam) for lam in lams] if not env else None
+        return out, ref
+
+    new, refs = steps({})
+    again, _ = steps({})
+    old, _ = steps({'MVUS_PART_BACK': '1'})
+    copy, _ = steps({'MVUS_DIRECT_RHS': '0'})
+    other_len, _ = steps({'MVUS_PART_LEN': '32' if prob.C * (3 + prob.P) <= 128 else '16'})
+    for lam, p, a, o, c, l, r in zip(lams, new, again, old, copy, other_len, refs):
+        scale = np.abs(r).max()
+        assert np.array_equal(p, a), 'the solve is not reproducible run to run'
+        print('lambda = %g: |p - dense| = %.2e, |p - back-corrected| = %.2e, |p - with the copy| = %.2e, |p - other interior length| = %.2e (relative)'
+              % (lam, np.abs(p - r).max() / scale, np.abs(p - o).max() / scale, np.abs(p - c).max() / scale, np.abs(p - l).max() / scale))
+        np.testing.assert_allclose(p, r, rtol=0, atol=1e-7 * scale)
+        for q in (o, c, l):
+            np.testing.assert_allclose(p, q, rtol=0, atol=1e-8 * scale)
