@@ -2286,61 +2286,70 @@ __global__ __launch_bounds__(kThreads) void k_back_substitute(DevProblem dp, NEV
 //   s = X_S p_c + x_S,g  for the separators either side (rows of pv.R: 2 s3 dot products),
 //   p_i += sum_a VW[i][a] s[a]  for its rows,   p_S = -s  for the separator after it.
 template <int S3>
-__global__ __launch_bounds__(128) void k_back_correct(DevProblem dp, NEView ne, PartView pv, int ncols, const double* __restrict__ pc, double* __restrict__ px) {
+__global__ __launch_bounds__(256) void k_back_correct(DevProblem dp, NEView ne, PartView pv, int ncols, const double* __restrict__ pc, double* __restrict__ px) {
   const int p = blockIdx.x, i = threadIdx.x;
   constexpr int st = 2 * S3;
   const int r0 = pv.i0[p], nr = pv.i1[p] - r0;
   const int sl = pv.sl[p], sr = pv.sr[p];
-  __shared__ double part[st][128];
+  constexpr int nch = 256 / st;                               // threads per separator value: thread (a, ch) takes columns ch, ch + nch, ...
+  __shared__ double part[st][nch];
   __shared__ double sx[st];
+  // (everything the row needs at the end -- its coupling entries, its place in x, the value k_back_substitute left there -- is requested
+  // before the dot products: the kernel is a chain of memory round trips)
+  double vwv[st];
+  const int ic = min(i, max(nr - 1, 0));
   {
-    const double* xr[st];
-    bool on[st];
+    const double* __restrict__ vw = pv.VW + ((long long)p * kPartRowsMax + ic) * st;
 #pragma unroll
-    for (int a = 0; a < st; ++a) {
-      on[a] = (a < S3 ? sl : sr) >= 0;
+    for (int a = 0; a < st; ++a) vwv[a] = vw[a];
+  }
+  const int rrow = r0 + ic, grow = rrow / 3 + ne.row0;
+  const int xrow = dp.mv.ctrl_x0[grow] + (rrow % 3) * dp.mv.ctrl_stride[grow];
+  const double pold = px[xrow];
+  int xsep = 0;
+  if (sr >= 0 && i < S3) { const int r = sr + i, g = r / 3 + ne.row0; xsep = dp.mv.ctrl_x0[g] + (r % 3) * dp.mv.ctrl_stride[g]; }
+  {
+    const int a = i / nch, ch = i - a * nch;
+    if (a < st) {
+      const bool on = (a < S3 ? sl : sr) >= 0;
       const long long gq = (long long)pv.q_off + p - (a < S3 ? 1 : 0);
-      xr[a] = pv.R + ((on[a] ? gq : 0) * S3 + (a % S3)) * ncols;
+      const double* __restrict__ xr = pv.R + ((on ? gq : 0) * S3 + (a % S3)) * ncols;
+      double acc = 0.0;
+      constexpr int kU = 12;
+      for (int k0 = ch; k0 < ne.CB; k0 += nch * kU) {          // twelve products in flight per thread
+        double xv[kU], pk[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) { const int k = min(k0 + nch * u, ne.CB - 1); xv[u] = xr[k]; pk[u] = pc[k]; }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) acc += k0 + nch * u < ne.CB ? xv[u] * pk[u] : 0.0;
+      }
+      part[a][ch] = on ? acc : 0.0;
     }
-    double acc[st];
-#pragma unroll
-    for (int a = 0; a < st; ++a) acc[a] = 0.0;
-    for (int k = i; k < ne.CB; k += 128) {
-      const double pk = pc[k];
-#pragma unroll
-      for (int a = 0; a < st; ++a) acc[a] += xr[a][k] * pk;
-    }
-#pragma unroll
-    for (int a = 0; a < st; ++a) part[a][i] = on[a] ? acc[a] : 0.0;
     __syncthreads();
     if (i < st) {
       double t = 0.0;
-      for (int w = 0; w < 128; ++w) t += part[i][w];
+#pragma unroll
+      for (int w = 0; w < nch; ++w) t += part[i][w];
       const bool o = (i < S3 ? sl : sr) >= 0;
       const long long gq = (long long)pv.q_off + p - (i < S3 ? 1 : 0);
       sx[i] = o ? t + pv.R[(gq * S3 + (i % S3)) * ncols + ne.CB] : 0.0;
     }
     __syncthreads();
   }
-  if (sr >= 0 && i < S3) {
-    const int r = sr + i, g = r / 3 + ne.row0;
-    px[dp.mv.ctrl_x0[g] + (r % 3) * dp.mv.ctrl_stride[g]] = -sx[S3 + i];
-  }
+  if (sr >= 0 && i < S3) px[xsep] = -sx[S3 + i];
   if (i >= nr) return;
-  const double* __restrict__ vw = pv.VW + ((long long)p * kPartRowsMax + i) * st;
   double acc = 0.0;
   if (sl >= 0) {
 #pragma unroll
-    for (int a = 0; a < S3; ++a) acc += vw[a] * sx[a];
+    for (int a = 0; a < S3; ++a) acc += vwv[a] * sx[a];
   }
   if (sr >= 0) {
 #pragma unroll
-    for (int a = 0; a < S3; ++a) acc += vw[S3 + a] * sx[S3 + a];
+    for (int a = 0; a < S3; ++a) acc += vwv[S3 + a] * sx[S3 + a];
   }
-  const int r = r0 + i, g = r / 3 + ne.row0;
-  px[dp.mv.ctrl_x0[g] + (r % 3) * dp.mv.ctrl_stride[g]] += acc;
+  px[xrow] = pold + acc;
 }
-static_assert(kPartRowsMax <= 128, "k_back_correct: one thread per row of an interior");
+static_assert(kPartRowsMax <= 256, "k_back_correct: one thread per row of an interior");
 
 template <class BE>
 struct HipSchur {
@@ -2900,8 +2909,8 @@ struct HipSchur {
     hipLaunchKernelGGL(k_back_substitute, dim3((unsigned)std::max(1, (nrows + per - 1) / per)), dim3(kThreads), 0, be.stream, be.dp, ne, ncols,
                        row_lo, row_hi, (int)(!shard || be.tshard.rank == 0), Z, pc, px, fail, (!shard && be.scal_direct()) ? fail_map : (int*)nullptr);
     if (!wide && ncorr > 0) {                          // the interiors' rows were computed from uncorrected columns: one vector is corrected here
-      if (BW == 11) hipLaunchKernelGGL(k_back_correct<9>, dim3(pv.P), dim3(128), 0, be.stream, be.dp, ne, pv, ncols, (const double*)pc, px);
-      else hipLaunchKernelGGL(k_back_correct<15>, dim3(pv.P), dim3(128), 0, be.stream, be.dp, ne, pv, ncols, (const double*)pc, px);
+      if (BW == 11) hipLaunchKernelGGL(k_back_correct<9>, dim3(pv.P), dim3(256), 0, be.stream, be.dp, ne, pv, ncols, (const double*)pc, px);
+      else hipLaunchKernelGGL(k_back_correct<15>, dim3(pv.P), dim3(256), 0, be.stream, be.dp, ne, pv, ncols, (const double*)pc, px);
     }
     if (shard) {
       hipLaunchKernelGGL(k_fail_pack, dim3(1), dim3(64), 0, be.stream, fail, px + be.hp.n);
