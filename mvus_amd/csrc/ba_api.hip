@@ -266,15 +266,21 @@ struct HipBackend {
   // current / trial point of the LM driver, kept from solve to solve (ba_schur.h: lm_resume)
   double* lm_x[2] = {nullptr, nullptr};
   std::vector<double> lm_last_host;
+  const double* lm_last_ptr = nullptr;   // host copy of the point the last solve returned: the pinned mirror the trial kernel wrote (no copy), else lm_last_host
   int lm_last = -1;
   double* lm_xbuf(int k) { if (!lm_x[k]) lm_x[k] = dalloc<double>(std::max<int64_t>(hp.n, 1)); return lm_x[k]; }
   int lm_resume(const double* x_host) {
-    if (lm_last < 0 || (int64_t)lm_last_host.size() != hp.n || allreduce) return -1;
-    return std::memcmp(lm_last_host.data(), x_host, sizeof(double) * hp.n) == 0 ? lm_last : -1;
+    if (lm_last < 0 || lm_last_ptr == nullptr || allreduce) return -1;
+    return std::memcmp(lm_last_ptr, x_host, sizeof(double) * hp.n) == 0 ? lm_last : -1;
   }
-  void lm_remember(const double* x_dev, const double* x_host) {
+  // mirror: the pinned host buffer that holds the returned point already (written by the accepted trial's kernel; the next solve's first
+  // trial goes to the OTHER mirror, and the comparison happens before any trial of that solve) -- else the point is copied
+  void lm_remember(const double* x_dev, const double* x_host, const double* mirror) {
     lm_last = x_dev == lm_x[0] ? 0 : (x_dev == lm_x[1] ? 1 : -1);
-    if (lm_last >= 0) lm_last_host.assign(x_host, x_host + hp.n);
+    lm_last_ptr = nullptr;
+    if (lm_last < 0) return;
+    if (mirror != nullptr) lm_last_ptr = mirror;
+    else { lm_last_host.assign(x_host, x_host + hp.n); lm_last_ptr = lm_last_host.data(); }
   }
   unsigned* lm_counter = nullptr;   // ticket counter of the last-block reductions (k_lm_gnorm / k_lm_trial), kept at 0 between launches
   void set_bounds(const std::vector<double>& lb, const std::vector<double>& ub) {
@@ -1118,7 +1124,8 @@ int mvus_ba_solve(mvus_ba* h, double* x, const mvus_solve_opts* opts, mvus_resul
     if (!x || !opts || !res) { be.err = "NULL argument"; return MVUS_E_INVALID; }
     const auto t0 = std::chrono::steady_clock::now();
     const int64_t n = be.hp.n;
-    std::vector<double> xv(x, x + n);
+    std::vector<double> xv;                          // (the TRF path works on a vector; the LM driver on the caller's buffer itself)
+    if (opts->solver != MVUS_SOLVER_LM_SCHUR || opts->jac_mode == MVUS_JAC_PATTERN) xv.assign(x, x + n);
     if ((int64_t)be.lb_fixed.size() != n) {          // the box of the rs block (common.py:652-668): fixed for the handle, built once
       be.lb_fixed.assign(n, -INFINITY); be.ub_fixed.assign(n, INFINITY);
       if (be.hp.rs_bounds) for (int c = 0; c < be.hp.C; ++c) { be.lb_fixed[2 * be.hp.C + c] = 0.0; be.ub_fixed[2 * be.hp.C + c] = 1.0; }
@@ -1149,13 +1156,13 @@ int mvus_ba_solve(mvus_ba* h, double* x, const mvus_solve_opts* opts, mvus_resul
       // profiles/round4/r04_loop_lm_wide_band_damping.txt).  The floor of such problems is at least kLambdaMinWide.
       constexpr double kLambdaMinWide = 0.3;
       if (h->schur->wide && so.lm_trust_radius < 0) so.lm_lambda_min = std::max(so.lm_lambda_min, kLambdaMinWide);      // (a trust region bounds those steps itself)
-      sr = lm_schur(be, *h->schur, xv, lb, ub, so, be.f_cur);
+      sr = lm_schur(be, *h->schur, x, lb, ub, so, be.f_cur);
       if (!sr.error) { be.lm_lambda = std::min(std::max(sr.lm_lambda, 1e-12), 1e6); be.lm_nu = std::min(sr.lm_nu, 1024.0); }
       if (sr.jac_stale) be.has_jacobian = false;      // mvus_ba_jv / jtu / lm_step must not pair J(x_old) with f(x_new)
     }
     else sr = trf_lsmr(be, xv, lb, ub, so, be.f_cur);
-    if (sr.error == -4) {            // a row left the time slice: the point reached so far goes back to the caller, who re-cuts there
-      std::memcpy(x, xv.data(), sizeof(double) * n);
+    const bool lm = opts->solver == MVUS_SOLVER_LM_SCHUR;
+    if (sr.error == -4) {            // a row left the time slice: the point reached so far goes back to the caller, who re-cuts there (already in x)
       MVUS_HIP(hipStreamSynchronize(be.stream));
       h->schur.reset();              // (the device flag is raised: the next solve on this handle starts from fresh storage)
       res->cost = sr.cost; res->optimality = 0; res->nfev = sr.nfev; res->njev = sr.njev; res->status = 0; res->lin_iters = sr.lin_iters;
@@ -1164,7 +1171,7 @@ int mvus_ba_solve(mvus_ba* h, double* x, const mvus_solve_opts* opts, mvus_resul
       return MVUS_E_RESHARD;
     }
     if (sr.error) { be.err = "residuals are not finite in the initial point, or x0 is outside of the bounds"; return MVUS_E_NUMERIC; }
-    std::memcpy(x, xv.data(), sizeof(double) * n);
+    if (!lm) std::memcpy(x, xv.data(), sizeof(double) * n);
     if (f_out) be.download(f_out, be.f_cur, be.hp.m);
     MVUS_HIP(hipStreamSynchronize(be.stream));
     res->cost = sr.cost; res->optimality = sr.optimality; res->nfev = sr.nfev; res->njev = sr.njev; res->status = sr.status;

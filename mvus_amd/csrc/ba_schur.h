@@ -69,8 +69,11 @@ inline void lm_trial_host(int64_t n, const double* x, const double* p, const dou
 }
 
 template <class B, class Schur>
-SolveResult lm_schur(B& be, Schur& sc, std::vector<double>& x, const std::vector<double>& lb, const std::vector<double>& ub,
+SolveResult lm_schur(B& be, Schur& sc, double* x, const std::vector<double>& lb, const std::vector<double>& ub,
                      const SolveOptions& opt, double* f_dev) {          // f_dev: the backend's residual buffer (f(x) on return)
+  // x: the caller's buffer, n values, in and out -- read at the start, written once at the end (a vector in between was two 122 KB
+  // copies and an allocation per call at configs[2], with the GPU idle: every microsecond of host work before the first launch and
+  // after the last fetch is a microsecond of the step)
   using namespace detail;
   SolveResult res;
   const int64_t n = be.n(), m = be.m_local();
@@ -78,11 +81,11 @@ SolveResult lm_schur(B& be, Schur& sc, std::vector<double>& x, const std::vector
   // the current and the trial point live in two buffers the backend keeps from solve to solve: a caller that continues from the point
   // the previous solve returned (an outer loop of short solves -- bench.py's steps, Scene.BA after remove_outliers) finds it on the
   // device already (lm_resume: bitwise comparison with the host copy of that point) and x does not cross PCIe again
-  int xcur = be.lm_resume(x.data());
+  int xcur = be.lm_resume(x);
   const bool resumed = xcur >= 0;
   // (a resumed point is one this driver returned: the caller's x0 of that solve, checked then, or a trial point, projected onto the
   // box by the trial kernel -- and the box is the handle's; the O(n) check would only delay the first launch)
-  if (!resumed && !in_bounds(x, lb, ub)) { res.error = -3; return res; }
+  if (!resumed) for (int64_t i = 0; i < n; ++i) if (!(x[i] >= lb[i] && x[i] <= ub[i])) { res.error = -3; return res; }
   if (!resumed) xcur = 0;
   double* x_dev = be.lm_xbuf(xcur);
   double* xt_dev = be.lm_xbuf(xcur ^ 1);
@@ -94,7 +97,7 @@ SolveResult lm_schur(B& be, Schur& sc, std::vector<double>& x, const std::vector
   double* S = be.lm_scalars();   // [0] |f|^2 at x0, [1] projected |g|_inf, [2..5] trial scalars, [6] |f(x_trial)|^2
   double hs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
-  if (!resumed) be.upload(x_dev, x.data(), n);
+  if (!resumed) be.upload(x_dev, x, n);
   // (the first linearisation follows at once: its storage is zeroed beside this evaluation where the backend can do that)
   if (be.residual_sq(x_dev, f_dev, S, sc.clear_ptr(), sc.clear_len())) sc.mark_cleared();
   res.nfev = 1; res.njev = 1;
@@ -224,9 +227,9 @@ SolveResult lm_schur(B& be, Schur& sc, std::vector<double>& x, const std::vector
     res.error = -4;
   }
   if (mir_cur < 0) { /* no step was accepted: x is the caller's x0 */ }
-  else if (be.mirror_host(mir_cur)) std::copy(be.mirror_host(mir_cur), be.mirror_host(mir_cur) + n, x.begin());   // written by the accepted trial's kernel, fetched since
-  else be.download(x.data(), x_dev, n);
-  be.lm_remember(x_dev, x.data());
+  else if (be.mirror_host(mir_cur)) std::copy(be.mirror_host(mir_cur), be.mirror_host(mir_cur) + n, x);   // written by the accepted trial's kernel, fetched since
+  else be.download(x, x_dev, n);
+  be.lm_remember(x_dev, x, mir_cur >= 0 ? be.mirror_host(mir_cur) : nullptr);
   res.cost = cost;
   cleanup();
   return res;

@@ -73,7 +73,7 @@ struct HostBackend {
   double* lm_xbuf(int k) { lm_x[k].resize((size_t)hp.n); return lm_x[k].data(); }
   int lm_resume(const double*) { return -1; }
   bool reshard_pending() { return false; }
-  void lm_remember(const double*, const double*) {}
+  void lm_remember(const double*, const double*, const double*) {}
   double* mirror_dev(int) { return nullptr; }
   const double* mirror_host(int) const { return nullptr; }
   void adopt_residual(double*&, double*&) {}
@@ -395,7 +395,7 @@ int hostcheck_solve(void* h, double* x, const mvus_solve_opts* o, mvus_result* r
   std::vector<double> f(be->hp.m);
   SolveResult sr;
 #ifdef MVUS_WITH_SCHUR
-  if (o->solver == MVUS_SOLVER_LM_SCHUR) { HostSchur sc; sr = lm_schur(*be, sc, xv, lb, ub, so, f.data()); }
+  if (o->solver == MVUS_SOLVER_LM_SCHUR) { HostSchur sc; sr = lm_schur(*be, sc, xv.data(), lb, ub, so, f.data()); }
   else
 #endif
     sr = trf_lsmr(*be, xv, lb, ub, so, f.data());
