@@ -61,3 +61,5 @@ bash tools/step_timeline.sh 1 > $O/${R}_step_timeline_config1.txt 2>&1
 for c in 1 2 3 4; do for m in ldl gj; do echo "configs[$c] MVUS_RCS=$m: $(MVUS_RCS=$m python3 tools/step_breakdown.py $c 2>&1 | tail -1)"; done; done 2>/dev/null | grep "^configs" > $O/${R}_reduced_solver_ab.txt
 rm -rf $O/stats_lm $O/stats_trf $O/stats_c3 $O/pmc_fetch* $O/pmc_write* $O/pmc_traffic_c2.json $O/pmc_traffic_c23.json
 ls -la $O
+# round 5: the band solver's one-rank path against its parts switched off (same box, three repetitions, ms per step: python wall / C++ solve)
+bash tools/band_solver_ab.sh > $O/${R}_band_solver_ab.txt 2>/dev/null
