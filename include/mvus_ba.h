@@ -139,7 +139,17 @@ typedef struct mvus_result {
  * Called by the solver once per normal-equation assembly / J^T u product when observations are sharded. */
 typedef int (*mvus_allreduce_fn)(void* user, void* buf_dev, size_t count, void* stream);
 
+/* Always start from mvus_default_opts: a zero-filled mvus_solve_opts is NOT the default (lm_trust_radius = 0 means "scipy's
+ * Delta_0", i.e. ON; the defaults are listed in INTEGRATION.md). */
 void mvus_default_opts(mvus_solve_opts* opts);
+
+/* Layout check for bindings in other languages (ctypes / cgo / JNI stubs that restate the structs): writes sizeof(mvus_solve_opts),
+ * sizeof(mvus_result), sizeof(mvus_problem) as this library was compiled (any pointer may be NULL) and returns MVUS_ABI_VERSION.  A
+ * binding asserts these against its own struct definitions at load time -- mvus_solve_opts has grown over the rounds (lm_lambda_min,
+ * lm_trust_radius) and a stale stub would otherwise hand the library a short buffer.  The version is raised whenever a struct or a
+ * prototype of this header changes.  Stateless, no device is touched.  No reference counterpart (the reference has no FFI). */
+#define MVUS_ABI_VERSION 6
+int32_t mvus_abi_sizes(int32_t* solve_opts_size, int32_t* result_size, int32_t* problem_size);
 
 /* Copies the problem to the GPU, undistorts observations once when calibration is fixed
  * (detection_to_global, common.py:126).  */

@@ -58,6 +58,7 @@ ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, 
 # every symbol include/mvus_ba.h declares: (name, restype, argtypes)
 API = [
     ('mvus_default_opts', None, [ctypes.POINTER(MvusSolveOpts)]),
+    ('mvus_abi_sizes', ctypes.c_int32, [c_int32_p, c_int32_p, c_int32_p]),
     ('mvus_ba_create', ctypes.c_int, [ctypes.POINTER(MvusProblem), ctypes.POINTER(ctypes.c_void_p)]),
     ('mvus_ba_destroy', None, [ctypes.c_void_p]),
     ('mvus_last_error', ctypes.c_char_p, [ctypes.c_void_p]),
@@ -129,9 +130,23 @@ def load(path=None):
         fn = getattr(lib, name)          # AttributeError here = header/library mismatch
         fn.restype = restype
         fn.argtypes = argtypes
+    check_abi(lib)
     if path is None:
         _lib = lib
     return lib
+
+
+ABI_VERSION = 6
+
+
+def check_abi(lib):
+    """The struct layouts of this binding against the library's own sizeof (mvus_abi_sizes): a stale binding fails at load."""
+    so, sr, sp = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+    ver = lib.mvus_abi_sizes(ctypes.byref(so), ctypes.byref(sr), ctypes.byref(sp))
+    mine = (ctypes.sizeof(MvusSolveOpts), ctypes.sizeof(MvusResult), ctypes.sizeof(MvusProblem))
+    if ver != ABI_VERSION or (so.value, sr.value, sp.value) != mine:
+        raise RuntimeError('libmvusba.so ABI %d with struct sizes %s does not match this binding (ABI %d, %s): rebuild the library'
+                           % (ver, (so.value, sr.value, sp.value), ABI_VERSION, mine))
 
 
 def dptr(a):

@@ -269,12 +269,18 @@ struct HipBackend {
   const double* lm_last_ptr = nullptr;   // host copy of the point the last solve returned: the pinned mirror the trial kernel wrote (no copy), else lm_last_host
   int lm_last = -1;
   double* lm_xbuf(int k) { if (!lm_x[k]) lm_x[k] = dalloc<double>(std::max<int64_t>(hp.n, 1)); return lm_x[k]; }
+  // Consulting the remembered point DISARMS it: from here on the solve writes into both buffers (upload, trial points), so only a solve
+  // that reaches lm_remember -- a normal or a reshard exit -- re-arms it.  A solve that leaves early (non-finite cost at x0, an exception)
+  // therefore cannot leave a stale "buffer k holds the point I returned" behind for a caller that retries from the last good point.
   int lm_resume(const double* x_host) {
-    if (lm_last < 0 || lm_last_ptr == nullptr || allreduce) return -1;
-    return std::memcmp(lm_last_ptr, x_host, sizeof(double) * hp.n) == 0 ? lm_last : -1;
+    int r = -1;
+    if (lm_last >= 0 && lm_last_ptr != nullptr && !allreduce && std::memcmp(lm_last_ptr, x_host, sizeof(double) * hp.n) == 0) r = lm_last;
+    lm_last = -1; lm_last_ptr = nullptr;
+    return r;
   }
-  // mirror: the pinned host buffer that holds the returned point already (written by the accepted trial's kernel; the next solve's first
-  // trial goes to the OTHER mirror, and the comparison happens before any trial of that solve) -- else the point is copied
+  // mirror: the pinned host buffer that holds the returned point already (written by the accepted trial's kernel).  Every solve starts its
+  // trials at mirror 0 again: the comparison in lm_resume happens before any trial of that solve is launched, and a resumed solve that
+  // accepts no step re-remembers through the caller's x (mirror == nullptr) -- else the point is copied
   void lm_remember(const double* x_dev, const double* x_host, const double* mirror) {
     lm_last = x_dev == lm_x[0] ? 0 : (x_dev == lm_x[1] ? 1 : -1);
     lm_last_ptr = nullptr;
@@ -795,6 +801,13 @@ void mvus_default_opts(mvus_solve_opts* o) {
   o->lsmr_atol = 1e-6; o->lsmr_btol = 1e-6; o->lsmr_conlim = 1e8; o->lsmr_maxiter = 0; o->verbose = 0; o->lm_lambda_min = 3e-3; o->lm_trust_radius = -1.0;
 }
 
+int32_t mvus_abi_sizes(int32_t* solve_opts_size, int32_t* result_size, int32_t* problem_size) {
+  if (solve_opts_size) *solve_opts_size = (int32_t)sizeof(mvus_solve_opts);
+  if (result_size) *result_size = (int32_t)sizeof(mvus_result);
+  if (problem_size) *problem_size = (int32_t)sizeof(mvus_problem);
+  return MVUS_ABI_VERSION;
+}
+
 int mvus_ba_create(const mvus_problem* p, mvus_ba** out) {
   if (!out) return MVUS_E_INVALID;
   *out = nullptr;
@@ -1113,6 +1126,7 @@ int mvus_ba_lm_step(mvus_ba* h, double lambda, double* p_out) {
     sc.assemble_held(be);
     sc.solve_async(lambda);
     be.download(p_out, sc.step_ptr(), be.hp.n);          // synchronises
+    if (!sc.solve_ok() && sc.retry_same()) { sc.solve_async(lambda); be.download(p_out, sc.step_ptr(), be.hp.n); }
     if (!sc.solve_ok()) { be.err = "lm_step: the damped normal equations are not positive definite at this lambda"; return MVUS_E_NUMERIC; }
     return MVUS_OK;
   });

@@ -25,7 +25,7 @@
 //                  E[q][k]  += h_q (gu_d Jx_k + gv_d Jy_k)          cross block rows (g + q, d), this camera's B columns
 //                  gq[q]    += h_q (gu_d fx + gv_d fy)              spline gradient
 //                  C[qa][w] += h_qa h_{qa+w} (gu_d gu + gv_d gv)    band block (g + qa, g + qa + w), row d
-//              -- 106 multiply-adds for 30 LDS reads per detection and lane; band and gradient accumulators live across the whole
+//              -- 44 multiply-adds for 30 LDS reads per detection and lane (round 6: the band row through the 1 x 3 row of its point block); band and gradient accumulators live across the whole
 //              camera walk, the cross-block accumulators across the batches of one camera.
 //   flush E    the <= 4 spans that reach a control point are added in span order through the (now dead) staging region and the
 //              camera's Wn x 3 x B block of Et leaves as one contiguous, coalesced run of plain stores.
@@ -183,10 +183,17 @@ void k_assemble_windows(DevProblem dp, NEView ne, WinView wv, const CamState* __
       p0 = wv.flut[cw.lut_off + (int)kl];
       p1 = wv.flut[cw.lut_off + (int)kh];
     }
-    p0v = p0; p1v = max(p0, p1);
+    // ABSOLUTE detection indices (the host takes this path only with M < 2^31 and < 2^24 detections per camera: HipSchur::win_prepare)
+    // and the camera's index in the top byte of the count: the camera loop below needs no load of cam_perm / det_off -- at the loop
+    // head those were VECTOR loads (the loop stores, so the compiler cannot use the scalar cache) followed by s_waitcnt vmcnt(0): one
+    // wait for the previous camera's stores to be acknowledged and one more for det_off[next camera] in front of every camera's first
+    // prefetch, two dependent memory round trips per camera (found in the ISA, round 6)
+    p0v = (int)dp.det_off[c] + p0; p1v = (c << 24) | (max(p0, p1) - p0);
   }
-  auto cam_range = [&](int i, int& p0, int& p1) {           // (i wave-uniform)
-    p0 = __builtin_amdgcn_readlane(p0v, i); p1 = __builtin_amdgcn_readlane(p1v, i);
+  auto cam_range = [&](int i, int& c, int& p0, int& p1) {   // (i wave-uniform)
+    p0 = __builtin_amdgcn_readlane(p0v, i);
+    const int pc = __builtin_amdgcn_readlane(p1v, i);
+    c = (int)((unsigned)pc >> 24); p1 = p0 + (pc & 0xffffff);
   };
 
   // this lane's row of the band (blocks (pl, pl + w), w = 0..3, row d) and of the gradient: across the whole camera walk
@@ -198,10 +205,10 @@ void k_assemble_windows(DevProblem dp, NEView ne, WinView wv, const CamState* __
 
   // inputs of one batch (lane = detection), fetched one batch ahead: the detection and its first control point from the span table
   struct Inputs { double fr, vr, p, q; int g; };
-  auto fetch = [&](long long a0, int pos, int p1) {
+  auto fetch = [&](int pos, int p1) {
     Inputs in{0.0, 0.0, 0.0, 0.0, -1};
     if (pos < p1) {                                         // (five independent loads: nothing here waits for the span)
-      const long long i = a0 + pos;
+      const long long i = pos;
       in.g = wv.span[i];
       in.fr = dp.frame[i]; in.vr = dp.v_raw[i];
       in.p = CALIB ? dp.u_raw[i] : dp.u_obs[i];
@@ -218,17 +225,14 @@ void k_assemble_windows(DevProblem dp, NEView ne, WinView wv, const CamState* __
   };
 
 #define MVUS_WTP(i) ((void)0)
-  int p0 = 0, p1 = 0;
-  if (ncam > 0) cam_range(0, p0, p1);
-  int cnext = ncam > 0 ? wv.cam_perm[wave] : 0;
-  Inputs cur = ncam > 0 ? fetch(dp.det_off[cnext], p0 + lane, p1) : Inputs{0.0, 0.0, 0.0, 0.0, -1};
+  int p0 = 0, p1 = 0, cnext = 0;                            // (p0, p1: absolute detection indices)
+  if (ncam > 0) cam_range(0, cnext, p0, p1);
+  Inputs cur = ncam > 0 ? fetch(p0 + lane, p1) : Inputs{0.0, 0.0, 0.0, 0.0, -1};
   for (int ci = 0; ci < ncam; ++ci) {
     const int c = cnext;
-    if (ci + 1 < ncam) cnext = wv.cam_perm[wave + kWinWaves * (ci + 1)];
     const CamState& cam = cams[c];                          // wave-uniform: scalar loads
-    const long long a0 = dp.det_off[c];
     int np0 = 0, np1 = 0;                                   // the next camera's range
-    if (ci + 1 < ncam) cam_range(ci + 1, np0, np1);
+    if (ci + 1 < ncam) cam_range(ci + 1, cnext, np0, np1);
     d4v cacc[2][TI][TI];
 #pragma unroll
     for (int h2 = 0; h2 < 2; ++h2)
@@ -239,14 +243,14 @@ void k_assemble_windows(DevProblem dp, NEView ne, WinView wv, const CamState* __
     double E[B];                                            // this lane's row (pl, d) of the camera's block of Et: across the camera's batches
 #pragma unroll
     for (int k = 0; k < B; ++k) E[k] = 0.0;
-    if (!(p0 < p1)) cur = (ci + 1 < ncam) ? fetch(dp.det_off[cnext], np0 + lane, np1) : Inputs{0.0, 0.0, 0.0, 0.0, -1};   // (no batch: nothing was fetched ahead)
+    if (!(p0 < p1)) cur = (ci + 1 < ncam) ? fetch(np0 + lane, np1) : Inputs{0.0, 0.0, 0.0, 0.0, -1};   // (no batch: nothing was fetched ahead)
 
     for (int base = p0; base < p1; base += 64) {
       const bool last = base + 64 >= p1;
       // the next batch's inputs (this camera's, else the first of the next camera): in flight over this batch's arithmetic
       Inputs nxt;
-      if (!last) nxt = fetch(a0, base + 64 + lane, p1);
-      else if (ci + 1 < ncam) nxt = fetch(dp.det_off[cnext], np0 + lane, np1);
+      if (!last) nxt = fetch(base + 64 + lane, p1);
+      else if (ci + 1 < ncam) nxt = fetch(np0 + lane, np1);
       else nxt = Inputs{0.0, 0.0, 0.0, 0.0, -1};
       MVUS_WTP(0);     // camera set-up / previous batch's tail
       // ---- stage: lane = detection; knot span known (span table), its knots and coefficients from LDS ----
@@ -374,9 +378,13 @@ void k_assemble_windows(DevProblem dp, NEView ne, WinView wv, const CamState* __
           const double hu_ = P##hb[0] * gud_, hv_ = P##hb[0] * gvd_;      /* this control point's spline slot (x row, y row) */ \
           _Pragma("unroll") for (int k = 0; k < B; ++k) E[k] += hu_ * P##jx[k] + hv_ * P##jy[k];                           \
           gacc += hu_ * P##fx + hv_ * P##fy;                                                                               \
+          /* band row: h_q h_{q+w} (gu_d gu + gv_d gv) -- the 1 x 3 row m of the point block once per detection, then one  \
+             product and three multiply-adds per block (22 operations instead of the 32 of (h_q g)(h_{q+w} g) per block) */ \
+          double m_[3];                                                                                                    \
+          _Pragma("unroll") for (int d2 = 0; d2 < 3; ++d2) m_[d2] = gud_ * P##gu[d2] + gvd_ * P##gv[d2];                   \
           _Pragma("unroll") for (int w = 0; w < 4; ++w) {                                                                  \
-            const double bu_ = hu_ * P##hb[w], bv_ = hv_ * P##hb[w];                                                       \
-            _Pragma("unroll") for (int d2 = 0; d2 < 3; ++d2) Cw[w][d2] += bu_ * P##gu[d2] + bv_ * P##gv[d2];               \
+            const double hh_ = P##hb[0] * P##hb[w];                                                                        \
+            _Pragma("unroll") for (int d2 = 0; d2 < 3; ++d2) Cw[w][d2] += hh_ * m_[d2];                                    \
           }                                                                                                                \
         } while (0)
         if (mall != 0ull) {                                 // two value sets in turn: the reads of one are in flight over the adds of the other
@@ -416,7 +424,12 @@ void k_assemble_windows(DevProblem dp, NEView ne, WinView wv, const CamState* __
         }
       }
       if (role && s == 0) {
-        double* row = er + (pl * 3 + d) * B;
+        // (the row's offset is recomputed here, from a lane index the optimiser cannot see through: hoisted out of the camera loop, the
+        // 64-bit offsets of this block's and the next block's stores are loop invariants that cost ten registers the loop does not have --
+        // they were spilled to scratch, and a scratch reload in front of the stores waits for every store before it)
+        int lh = lane;
+        asm volatile("" : "+v"(lh));
+        double* row = er + (lh / SP) * B;                   // lane / SP = pl * 3 + d
 #pragma unroll
         for (int k = 0; k < B; ++k) row[k] = E[k];
       }
@@ -424,7 +437,9 @@ void k_assemble_windows(DevProblem dp, NEView ne, WinView wv, const CamState* __
     // the camera block's partial (C/D layout of the 16x16 tile: row = (lane >> 4) + 4 reg, column = lane & 15)
     {
       double* mine = wv.Apart + ((long long)win * dp.C + c) * PSZ;
-      const int lr = lane & 15, lk = lane >> 4;
+      int lh = lane;
+      asm volatile("" : "+v"(lh));                          // (as above: the entries' offsets are not to live across the loop)
+      const int lr = lh & 15, lk = lh >> 4;
 #pragma unroll
       for (int i = 0; i < TI; ++i)
 #pragma unroll

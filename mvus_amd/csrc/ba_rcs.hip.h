@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void k_rcs_finish(NEView ne, int ncols, int ns
   const long long stride = (long long)ne.CB * ncols;
   const int nn = ne.CB, npad = rv.nbk * 16;
   if (blockIdx.y == gridDim.y - 1) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) flags[0] = 0u;          // the hand-over counter of the factor launches that follow
+    if (blockIdx.x == 0 && threadIdx.x == 0) { flags[0] = 0u; flags[1] = 0u; }   // the hand-over counter of the factor launches that follow, and their time-out mark
     if (r0 != 0 || b >= npad) return;
     double gr = 0.0;
     if (b < nn) {
@@ -203,7 +203,8 @@ __global__ __launch_bounds__(256) void k_rcs_finish(NEView ne, int ncols, int ns
 // launch (k_rcs_factor, blockIdx.x > 0).  The recipe of the CDNA programming guide (Guideline 16, R1): the producer stores the payload
 // WRITE-THROUGH (sc1 -- other XCDs' L2s and the readers' L1s are not coherent with ours), waits for its stores (s_waitcnt vmcnt(0)),
 // then one lane stores the step number with a relaxed agent-scope atomic; a consumer polls that one word (relaxed, s_sleep between
-// polls, BOUNDED: a time-out raises fail[0] = 3 instead of hanging the device) and reads the payload with sc1 loads.
+// polls, BOUNDED: a time-out raises fail[0] = kFailHandover -- a code of its own, NOT the 'not positive definite' of the pivots: the host
+// then repeats the solve with the rows in a launch of their own instead of raising the damping) and reads the payload with sc1 loads.
 using rcs_u4 = __attribute__((ext_vector_type(4))) unsigned;
 struct RcsWide { rcs_u4 a, b; };
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t rcs_rsrc(double* p, size_t doubles) {
@@ -237,6 +238,7 @@ __device__ __forceinline__ void rcs_store1_sc1(__amdgpu_buffer_rsrc_t r, long lo
   __builtin_amdgcn_raw_buffer_store_b64(w, r, (int)(dbl_off * 8), 0, 16);
 }
 constexpr unsigned kRcsSpinLimit = 1u << 21;                         // polls (each >= ~100 ns): far beyond any legitimate wait
+constexpr int kFailHandover = kFailHandoverCode;                     // fail[0]: a consumer workgroup gave up waiting for the factor workgroup's flag
 
 // x_i[c] = sum_j X[j][c] w[j] for lane c of a 16-lane row (col: the lane's column of X, 16 contiguous doubles in LDS; w: this lane's
 // entry of w, handed round by DPP row broadcasts)
@@ -306,7 +308,7 @@ __device__ __forceinline__ void rcs_pivot_role(int nc, int* __restrict__ fail, d
 // and T_jk with sc1 loads.  The rows' chain is shorter than the pivot chain, so these workgroups trail the factorisation by about one
 // step and finish ~1 step after it: the 18 us launch of k_rcs_trsm (and its kernel boundary) disappear from the critical path.
 __device__ __forceinline__ void rcs_trsm_role(RcsView rv, int c0, int nc, unsigned* __restrict__ flags, int* __restrict__ fail, double* __restrict__ xch,
-                                              int* __restrict__ abort_s) {
+                                              int* __restrict__ abort_s, unsigned spin_limit) {
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lk = lane >> 4;
   const int c1 = c0 + nc, gi = c1 + (int)blockIdx.x - 1;
   const size_t tot = rcs_doubles(rv.nn);
@@ -329,7 +331,7 @@ __device__ __forceinline__ void rcs_trsm_role(RcsView rv, int c0, int nc, unsign
       unsigned spins = 0;
       while (__hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
         __builtin_amdgcn_s_sleep(8);
-        if (++spins > kRcsSpinLimit) { *abort_s = 1; fail[0] = 3; break; }
+        if (++spins > spin_limit) { *abort_s = 1; fail[0] = kFailHandover; flags[1] = 1u; break; }     // (flags[1]: sticky for this solve -- a later kernel that meets the unfinished rows may overwrite fail[0])
       }
     }
     lds_barrier();
@@ -401,7 +403,7 @@ __device__ __forceinline__ void rcs_publisher_role(RcsView rv, int c0, int nc, u
 }
 
 __global__ __launch_bounds__(kRcsFactorThreads) void k_rcs_factor(RcsView rv, int c0, int* __restrict__ fail, int last, double* __restrict__ pc,
-                                                                  unsigned* __restrict__ flags) {
+                                                                  unsigned* __restrict__ flags, unsigned spin_limit) {
   __shared__ double Dm[16 * 17];
   __shared__ __attribute__((aligned(32))) double Xb[kRcsSP * 256];
   __shared__ __attribute__((aligned(32))) double rdb[kRcsSP * 16];
@@ -410,7 +412,7 @@ __global__ __launch_bounds__(kRcsFactorThreads) void k_rcs_factor(RcsView rv, in
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lr = lane & 15, lk = lane >> 4;
   const int nc = min(kRcsSP, rv.nbk - c0), R = rv.nbk;
   if (blockIdx.x > 0) {                                              // a block row below the super-block
-    if (wave < kRcsTrsmWaves) rcs_trsm_role(rv, c0, nc, flags, fail, panel, &abort_s);
+    if (wave < kRcsTrsmWaves) rcs_trsm_role(rv, c0, nc, flags, fail, panel, &abort_s, spin_limit);
     return;
   }
   if (wave == kRcsSP + 2) {                                          // the publisher (it takes part in every barrier of the chain)

@@ -27,6 +27,7 @@
 //                   const double* grad_ptr(), diag_ptr();          g = J^T f and D = diag(H) (1 where zero), x order
 //                   void solve_async(double lambda);               p = -(H + lambda D)^-1 g -> step_ptr()
 //                   const double* step_ptr(); const int* fail_ptr();  bool solve_ok();   (solve_ok after a fetch)
+//                   bool retry_same();   after a failed solve: true = not a numerical failure, repeat it at the same lambda
 // Backend additions: set_bounds(lb, ub) -> lb_ptr()/ub_ptr(); lm_scalars() (>= 8 doubles); dot_m_into(a, b, out);
 //                   lm_gnorm(x, lb, ub, g, out); lm_trial(x, p, lb, ub, g, D, fail, x_new, out4, gnorm_out) (the trial
 //                   kernel reads x, g and the bounds anyway, so it also delivers the gradient norm); fetch(src, k, host).
@@ -155,6 +156,7 @@ SolveResult lm_schur(B& be, Schur& sc, double* x, const std::vector<double>& lb,
       if (!have_trial) { launch_trial(lambda); be.fetch(S + 2, nfetch - 2, hs + 2); }
       have_trial = false;
       if (!sc.solve_ok() || !std::isfinite(hs[2]) || !std::isfinite(hs[3])) {   // not positive definite at this damping: raise it
+        if (sc.retry_same()) continue;      // (not a numerical failure -- an in-launch hand-over timed out: the same solve again, other route)
         lambda *= 10.0;
         if (lambda > 1e12) { status = 0; break; }
         continue;
@@ -273,6 +275,7 @@ struct HostSchur {
   const double* step_ptr() const { return pstep.data(); }
   const int* fail_ptr() const { return &fail; }
   bool solve_ok() const { return fail == 0; }
+  bool retry_same() { return false; }
   void solve_async(double lambda) { fail = solve(lambda, pstep) ? 0 : 1; if (fail) pstep.assign(n, 0.0); }
   static double damp_scale(double hii) { return hii > 0 ? hii : 1.0; }
   bool solve(double lambda, std::vector<double>& p) {

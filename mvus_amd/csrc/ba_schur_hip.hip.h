@@ -833,8 +833,16 @@ __global__ void k_halo_copy(NEView ne, int halo, int nb, const int* __restrict__
 }
 // time shards: the two failure flags travel with the step (px[n], px[n+1]) through its sum over the ranks, so that every
 // rank takes the same decision (a rank whose own interiors factorise fine must still see its neighbour's failure)
-__global__ void k_fail_pack(const int* __restrict__ fail, double* __restrict__ tail) { if (threadIdx.x < 2) tail[threadIdx.x] = (double)fail[threadIdx.x]; }
+// A hand-over time-out of the reduced solve (fail[0] = kFailHandoverCode, ba_rcs.hip.h) is not a numerical failure: it travels as a
+// value no sum of the other codes (<= 8 each, <= 64 ranks) can reach, and EVERY rank then reports the time-out -- all of them repeat
+// the solve on the separate-launch route together (HipSchur::retry_same), none raises the damping alone.
+constexpr int kFailHandoverCode = 4;
+constexpr double kFailHandoverSum = 1048576.0;
+__global__ void k_fail_pack(const int* __restrict__ fail, double* __restrict__ tail) {
+  if (threadIdx.x < 2) tail[threadIdx.x] = (threadIdx.x == 0 && fail[0] == kFailHandoverCode) ? kFailHandoverSum : (double)fail[threadIdx.x];
+}
 __global__ void k_fail_unpack(const double* __restrict__ tail, int* __restrict__ fail) {
+  if (threadIdx.x == 0 && tail[0] >= kFailHandoverSum) { fail[0] = kFailHandoverCode; return; }
   if (threadIdx.x < 2 && tail[threadIdx.x] != 0.0 && fail[threadIdx.x] == 0) fail[threadIdx.x] = threadIdx.x == 0 ? 8 : 1;
 }
 __global__ void k_sum_slabs(long long count, int nslab, const double* __restrict__ Gp, double* __restrict__ G0) {
@@ -2261,11 +2269,17 @@ __global__ __launch_bounds__(kGjThreads) void k_gj_step(int nn, int kb, const do
 // p (x order) from p_c and p_s = -(z_g + Z_E p_c)
 __global__ __launch_bounds__(kThreads) void k_back_substitute(DevProblem dp, NEView ne, int ncols, int row_lo, int row_hi, int cams,
                                                               const double* __restrict__ Z, const double* __restrict__ pc, double* __restrict__ px,
-                                                              const int* __restrict__ fail = nullptr, int* __restrict__ fail_mirror = nullptr) {
+                                                              int* __restrict__ fail = nullptr, int* __restrict__ fail_mirror = nullptr, const unsigned* __restrict__ handover = nullptr) {
   // one wavefront per owned spline row: lanes stride over the row of Z (coalesced), then a shuffle reduction
   const int lane = threadIdx.x & 63;
   // last kernel of a solve: the two failure flags go to the host's mapped copy here (a device-to-host copy of 8 bytes is a launch)
-  if (fail_mirror != nullptr && blockIdx.x == 0 && threadIdx.x < 2) fail_mirror[threadIdx.x] = fail[threadIdx.x];
+  // (a hand-over time-out inside the reduced solve -- flags[1] of k_rcs_factor's row workgroups -- outranks whatever a later kernel made of the
+  // unfinished rows: it is reported as its own code, HipSchur::retry_same)
+  if (fail != nullptr && blockIdx.x == 0 && threadIdx.x < 2) {
+    int v = fail[threadIdx.x];
+    if (threadIdx.x == 0 && handover != nullptr && handover[1] != 0u) { v = kFailHandoverCode; fail[0] = v; }
+    if (fail_mirror != nullptr) fail_mirror[threadIdx.x] = v;
+  }
   const int r = row_lo + blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
   if (blockIdx.x == 0 && cams)
     for (int idx = threadIdx.x; idx < ne.CB; idx += kThreads) px[cam_col(dp.C, dp.P, idx / ne.B, idx % ne.B)] = pc[idx];
@@ -2362,6 +2376,8 @@ struct HipSchur {
   RcsView rcs{};            // reduced camera system in block-image form (ba_rcs.hip.h)
   unsigned* rcs_flags = nullptr;   // step counter of the in-launch hand-over (k_rcs_factor -> its row workgroups); zeroed by k_rcs_finish
   bool rcs_trsm_launch = false;
+  unsigned rcs_spin_limit = kRcsSpinLimit;   // MVUS_RCS_SPIN_LIMIT: test hook (0 = the first poll that finds the flag behind gives up)
+  int handover_timeouts = 0;                 // solves repeated because a consumer workgroup of k_rcs_factor timed out (retry_same)
   int part_len = kPartL;    // control points per interior of the band solver (<= kPartL)
   bool use_rcs = true;      // MVUS_RCS=gj: the block Gauss-Jordan of rounds 1-4 (A/B)
   int* fail = nullptr;      // [0] numerical failure of a solve, [1] a row reached outside the slice (assembly)
@@ -2477,6 +2493,7 @@ struct HipSchur {
     MVUS_HIP(hipMalloc(reinterpret_cast<void**>(&rcs_flags), 4 * sizeof(unsigned)));
     MVUS_HIP(hipMemsetAsync(rcs_flags, 0, 4 * sizeof(unsigned), be.stream));
     { const char* e = std::getenv("MVUS_RCS_TRSM"); rcs_trsm_launch = e && std::strcmp(e, "launch") == 0; }
+    { const char* e = std::getenv("MVUS_RCS_SPIN_LIMIT"); if (e) rcs_spin_limit = (unsigned)std::strtoul(e, nullptr, 10); }
     { const char* e = std::getenv("MVUS_RCS"); use_rcs = !(e && std::strcmp(e, "gj") == 0); }
     MVUS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rcs_trsm), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((rcs_stage_doubles(kRcsSP) + 512) * sizeof(double))));
     MVUS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rcs_backsub), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(rcs_backsub_doubles(rcs.nbk) * sizeof(double))));
@@ -2588,6 +2605,9 @@ struct HipSchur {
   void win_prepare() {
     const HostProblem& hp = be.hp;
     use_win = hp.frames_sorted && hp.M > 0 && ne.N > 0 && hp.C <= 64 * kWinWaves && !std::getenv("MVUS_ASM_ATOMIC");
+    // (the kernel keeps absolute detection indices in 32 bits and a camera's range length in 24: k_assemble_windows, cam_range)
+    if (hp.M >= (int64_t)1 << 31) use_win = false;
+    for (int c = 0; c < hp.C && use_win; ++c) if (hp.det_off[c + 1] - hp.det_off[c] >= (1 << 24)) use_win = false;
     if (!use_win) return;
     // Window length.  A (window, camera) pair costs its batches of 64 staged detections -- (Wn + 3) spans reach a window, so camera
     // c brings n_c = (Wn + 3) rho_c + 3 of them, rho_c = detections per knot span -- a fixed part per batch (evaluation, matrix-core
@@ -2798,6 +2818,18 @@ struct HipSchur {
     if (fail_host[0] != 0 && std::getenv("MVUS_DEBUG")) std::fprintf(stderr, "schur solve: fail code %d\n", fail_host[0]);
     return fail_host[0] == 0;
   }
+  // A failed solve that is NOT a numerical failure: a workgroup of k_rcs_factor gave up waiting for the factor workgroup's hand-over
+  // flag (a GPU shared with other processes or streams may not schedule workgroup 0 of a launch before the others: forward progress
+  // between the workgroups of one launch is assumed there, not guaranteed).  The handle then takes the separate-launch route for the
+  // rows below a super-block (MVUS_RCS_TRSM=launch: bit-identical results, no spinning) for the rest of its life and the caller
+  // repeats the solve at the SAME damping -- raising lambda, the answer to a lost pivot, would silently change the iterates.
+  bool retry_same() {
+    if (fail_host[0] != kFailHandover || rcs_trsm_launch) return false;
+    rcs_trsm_launch = true;
+    ++handover_timeouts;
+    if (std::getenv("MVUS_DEBUG")) std::fprintf(stderr, "schur solve: hand-over time-out in k_rcs_factor -> rows below the super-block in a launch of their own from now on\n");
+    return true;
+  }
 
   template <int BWT, int S3T>
   void band_chain() {
@@ -2883,7 +2915,7 @@ struct HipSchur {
         // (the block rows below the super-block are solved by m more workgroups of the same launch, one step behind the chain;
         // MVUS_RCS_TRSM=launch: by a launch of their own, for A/B)
         const bool fused_rows = m > 0 && !rcs_trsm_launch;
-        hipLaunchKernelGGL(k_rcs_factor, dim3(1 + (fused_rows ? m : 0)), dim3(kRcsFactorThreads), 0, be.stream, rcs, c0, fail, (int)(m == 0), pc, rcs_flags);
+        hipLaunchKernelGGL(k_rcs_factor, dim3(1 + (fused_rows ? m : 0)), dim3(kRcsFactorThreads), 0, be.stream, rcs, c0, fail, (int)(m == 0), pc, rcs_flags, rcs_spin_limit);
         if (m > 0) {
           if (!fused_rows) hipLaunchKernelGGL(k_rcs_trsm, dim3(m), dim3(64 * kRcsTrsmWaves), (rcs_stage_doubles(nc) + 512) * sizeof(double), be.stream, rcs, c0);
           hipLaunchKernelGGL(k_rcs_syrk, dim3((m * (m + 1) / 2 + m + 3) / 4), dim3(256), 0, be.stream, rcs, c0);
@@ -2907,7 +2939,7 @@ struct HipSchur {
     if (shard) MVUS_HIP(hipMemsetAsync(px, 0, be.hp.n * sizeof(double), be.stream));
     const int nrows = row_hi - row_lo, per = kThreads / 64;
     hipLaunchKernelGGL(k_back_substitute, dim3((unsigned)std::max(1, (nrows + per - 1) / per)), dim3(kThreads), 0, be.stream, be.dp, ne, ncols,
-                       row_lo, row_hi, (int)(!shard || be.tshard.rank == 0), Z, pc, px, fail, (!shard && be.scal_direct()) ? fail_map : (int*)nullptr);
+                       row_lo, row_hi, (int)(!shard || be.tshard.rank == 0), Z, pc, px, fail, (!shard && be.scal_direct()) ? fail_map : (int*)nullptr, (const unsigned*)(use_rcs ? rcs_flags : nullptr));
     if (!wide && ncorr > 0) {                          // the interiors' rows were computed from uncorrected columns: one vector is corrected here
       if (BW == 11) hipLaunchKernelGGL(k_back_correct<9>, dim3(pv.P), dim3(256), 0, be.stream, be.dp, ne, pv, ncols, (const double*)pc, px);
       else hipLaunchKernelGGL(k_back_correct<15>, dim3(pv.P), dim3(256), 0, be.stream, be.dp, ne, pv, ncols, (const double*)pc, px);

@@ -62,14 +62,17 @@ def test_config3_on_one_gpu(BAHandle):
     rng = np.random.default_rng(1)
     with BAHandle(prob) as h:
         f1 = h.residual(x0)
-        # a slice of the detections against the oracle (the oracle evaluates whole cameras: use camera 0 and 63)
-        for c in (0, prob.C - 1):
+        # the detections against the oracle (the oracle evaluates whole cameras): every 8th camera and the last one, residual and
+        # the integer outlier test of Scene.remove_outliers (common.py:709-713) on the same rows
+        oprob = orc.problem_from_scene(sc)[0]
+        alpha, beta, rs, cams, tck = orc.unpack_x(oprob, x0)
+        keep_all = h.outlier_mask(x0, 10.0)
+        for c in sorted(set(range(0, prob.C, 8)) | {prob.C - 1}):
             a, b = int(prob.det_offsets[c]), int(prob.det_offsets[c + 1])
-            alpha, beta, rs, cams, tck = orc.unpack_x(orc.problem_from_scene(sc)[0], x0)
-            oprob = orc.problem_from_scene(sc)[0]
             fo = orc.error_cam_each(oprob, c, alpha, beta, rs, cams[c], tck)
             assert np.max(np.abs(f1[2 * a:2 * b] - fo) / np.maximum(1.0, np.abs(fo))) < 1e-9
             assert np.array_equal(f1[2 * a:2 * b] == 0, fo == 0)
+            assert np.array_equal(keep_all[a:b], np.sqrt(fo[:b - a] ** 2 + fo[b - a:] ** 2) < 10.0)
         v, u = rng.normal(size=h.n), rng.normal(size=h.m)
         f2, J, ctrl = h.residual_jacobian(x0, _lib.JAC_ANALYTIC)
         del J

@@ -272,8 +272,22 @@ def test_full_size_properties(BAHandle):
     prob, x0 = mp.problem_from_scene(sc)
     assert prob.C == 32 and abs(prob.M - 500_000) < 25_000
     rng = np.random.default_rng(0)
+    oprob, ox0 = orc.problem_from_scene(sc)
+    np.testing.assert_array_equal(x0, ox0)
     with BAHandle(prob) as h:
         f1 = h.residual(x0)
+        # the headline workload against the oracle, all 32 cameras x 504k detections: residual (zero pattern exact) and the integer
+        # outlier mask (bit-exact), at x0 and at the point a short LM solve reaches, whose cost the oracle re-evaluates
+        fo = orc.residual(oprob, x0)
+        assert f1.shape == fo.shape and np.array_equal(f1 == 0, fo == 0)
+        assert np.max(np.abs(f1 - fo) / np.maximum(1.0, np.abs(fo))) < 1e-9
+        assert np.array_equal(h.outlier_mask(x0, 10.0), np.concatenate(orc.outlier_keep_mask(oprob, x0, 10.0)))
+        r = h.solve(x0, solver=_lib.SOLVER_LM_SCHUR, jac_mode=_lib.JAC_ANALYTIC, max_nfev=6)
+        fo2 = orc.residual(oprob, r.x)
+        assert r.cost < r.initial_cost and abs(0.5 * float(fo2 @ fo2) - r.cost) <= 1e-9 * r.cost
+        assert np.max(np.abs(r.fun - fo2) / np.maximum(1.0, np.abs(fo2))) < 1e-9
+        assert np.array_equal(h.outlier_mask(r.x, 10.0), np.concatenate(orc.outlier_keep_mask(oprob, r.x, 10.0)))
+        del fo, fo2, r
         f2, J, ctrl = h.residual_jacobian(x0, _lib.JAC_ANALYTIC)
         assert np.array_equal(f1, f2)                              # idempotent, and both kernels agree bit for bit
         assert (ctrl >= 0).mean() > 0.9

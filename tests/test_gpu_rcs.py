@@ -89,6 +89,37 @@ def test_non_positive_pivot_raises_the_flag_and_lm_recovers():
         assert np.isfinite(r.cost) and r.cost < r.initial_cost
 
 
+def test_handover_timeout_repeats_the_solve_on_the_other_route(monkeypatch, capfd):
+    """The workgroups of k_rcs_factor that solve the rows below a super-block wait for the factor workgroup's flag with a BOUNDED spin.
+    A time-out (a GPU shared with other processes: forward progress between workgroups of one launch is not guaranteed) is not a lost
+    pivot: the driver must repeat the SAME solve through the separate-launch route, not raise the damping.  MVUS_RCS_SPIN_LIMIT=0 makes
+    the first poll give up; the iterates must be those of an undisturbed handle, bit for bit."""
+    from mvus_amd import synth
+    from mvus_amd.ba import BAHandle
+    sc = synth.make_scene(17, 17 * 150 + 400, seed=117, rolling_shutter=True, num_knots=24)       # 153 unknowns: one block row below the first super-panel
+    prob, x0 = mp.problem_from_scene(sc)
+    kw = dict(solver=_lib.SOLVER_LM_SCHUR, jac_mode=_lib.JAC_ANALYTIC, max_nfev=6)
+    for k in ('MVUS_RCS', 'MVUS_RCS_TRSM', 'MVUS_RCS_SPIN_LIMIT', 'MVUS_DEBUG'):
+        monkeypatch.delenv(k, raising=False)
+    with BAHandle(prob) as h:
+        ref = h.solve(x0, **kw)
+        h.residual_jacobian(x0, _lib.JAC_ANALYTIC)
+        p_ref = h.lm_step(1e-3)
+    capfd.readouterr()
+    monkeypatch.setenv('MVUS_RCS_SPIN_LIMIT', '0')
+    monkeypatch.setenv('MVUS_DEBUG', '1')
+    with BAHandle(prob) as h:
+        r = h.solve(x0, **kw)
+    err = capfd.readouterr().err
+    with BAHandle(prob) as h:
+        h.residual_jacobian(x0, _lib.JAC_ANALYTIC)
+        p = h.lm_step(1e-3)                                # the inspection hook repeats the solve as well
+    err2 = capfd.readouterr().err
+    assert err.count('hand-over time-out') == 1 and err2.count('hand-over time-out') == 1, (err, err2)   # once per handle: the route is switched for good
+    assert np.array_equal(r.x, ref.x) and (r.nfev, r.status, r.cost) == (ref.nfev, ref.status, ref.cost)
+    assert np.array_equal(p, p_ref)
+
+
 # the band solver's one-rank path of round 5 (no right-hand-side copy, no back-correction of the interiors' columns: the separators'
 # share of E^T C^-1 E as further rows of the Schur product, the step corrected for one vector) against the path of rounds 2-4
 # (MVUS_PART_BACK=1, still what time shards run) and against the dense solve; interiors of 16 and of 32 control points

@@ -452,3 +452,27 @@ def test_lm_resumes_from_the_point_it_returned_without_an_upload():
     assert np.array_equal(r1.x, q1.x) and r1.cost == q1.cost
     assert np.array_equal(r2.x, q2.x) and r2.cost == q2.cost and r2.nfev == q2.nfev
     assert r2.cost < r1.cost
+
+
+def test_a_failed_solve_leaves_no_stale_resume_point():
+    """The remembered point is disarmed as soon as it has been consulted (HipBackend::lm_resume): a solve that leaves early -- a
+    non-finite cost at its x0, after that x0 went into the driver's buffer -- must not leave 'buffer k holds the point I returned'
+    behind.  solve OK, solve from a point with an infinite cost (ValueError, as scipy raises), solve from the FIRST result again: the
+    same bits as on a handle that never saw the failure."""
+    from mvus_amd.ba import BAHandle
+    scene, g = load_case('rs_F_2int_3cam')
+    prob, x0 = mp.problem_from_scene(scene)
+    kw = dict(solver=_lib.SOLVER_LM_SCHUR, jac_mode=_lib.JAC_ANALYTIC)
+    bad = g['x0'].copy()
+    bad[-1] = 1e200                                    # a control point far away: finite x, |f|^2 overflows
+    with BAHandle(prob) as h:
+        q1 = h.solve(g['x0'], max_nfev=8, **kw)
+        q2 = h.solve(q1.x.copy(), max_nfev=8, **kw)
+    for x_fail in (bad, np.where(np.arange(bad.size) == bad.size - 1, np.nan, g['x0'])):
+        with BAHandle(prob) as h:
+            r1 = h.solve(g['x0'], max_nfev=8, **kw)
+            with pytest.raises(ValueError):
+                h.solve(x_fail, max_nfev=8, **kw)
+            r2 = h.solve(r1.x.copy(), max_nfev=8, **kw)
+        assert np.array_equal(r1.x, q1.x)
+        assert np.array_equal(r2.x, q2.x) and r2.cost == q2.cost and r2.nfev == q2.nfev
