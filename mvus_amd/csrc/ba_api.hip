@@ -148,6 +148,7 @@ struct HipBackend {
     for (void* p : owned) (void)hipFree(p);
     for (auto& kv : pool_size) (void)hipFree(kv.first);
     if (scal_host) (void)hipHostFree(scal_host);
+    if (fetch_ev) (void)hipEventDestroy(fetch_ev);
     if (lsmr_host) (void)hipHostFree(lsmr_host);
     for (int i = 0; i < 2; ++i) if (xmir_host[i]) (void)hipHostFree(xmir_host[i]);
     for (int i = 0; i < kStageSlots; ++i) {
@@ -288,6 +289,32 @@ struct HipBackend {
     if (mirror != nullptr) lm_last_ptr = mirror;
     else { lm_last_host.assign(x_host, x_host + hp.n); lm_last_ptr = lm_last_host.data(); }
   }
+  // What the last LM solve left for the point it returned (ba_schur.h: LmCarry).  Valid for the NEXT call on the handle only: every entry
+  // point bumps api_seq (guarded), so any call in between -- a residual, a pattern, an outlier removal -- disarms it; consulting it
+  // disarms it as well (a solve that fails early must not leave it behind).
+  uint64_t api_seq = 0, carry_seq = 0;
+  LmCarry carry{};
+  int carry_jac_mode = -1;
+  LmCarry lm_carry(int jac_mode) {
+    LmCarry c{};
+    if (carry.f_valid && carry_seq + 1 == api_seq && !allreduce && !std::getenv("MVUS_LM_NO_CARRY")) {
+      c = carry;
+      if (carry_jac_mode != jac_mode) c.lin_valid = false;
+    }
+    carry = LmCarry{};
+    return c;
+  }
+  void lm_keep(const LmCarry& c, int jac_mode) { carry = c; carry_seq = api_seq; carry_jac_mode = jac_mode; }
+  // fetch_mark: the next fetch waits for the work enqueued so far only (an event), not for what is enqueued after the mark -- the
+  // speculative linearisation of the LM driver.  Needs the scalars written straight into mapped memory (one rank).
+  hipEvent_t fetch_ev = nullptr;
+  bool fetch_marked = false;
+  void fetch_mark() {
+    if (!scal_direct()) return;
+    if (!fetch_ev) MVUS_HIP(hipEventCreateWithFlags(&fetch_ev, hipEventDisableTiming));
+    MVUS_HIP(hipEventRecord(fetch_ev, stream));
+    fetch_marked = true;
+  }
   unsigned* lm_counter = nullptr;   // ticket counter of the last-block reductions (k_lm_gnorm / k_lm_trial), kept at 0 between launches
   void set_bounds(const std::vector<double>& lb, const std::vector<double>& ub) {
     if (!lb_dev) {
@@ -359,7 +386,9 @@ struct HipBackend {
   void fetch(const double* src, int k, double* host) {       // src inside scal_out(): the pinned mirror itself, or staged through it
     const int64_t off = src - scal_out();
     if (!scal_direct()) MVUS_HIP(hipMemcpyAsync(scal_host + off, src, sizeof(double) * k, hipMemcpyDeviceToHost, stream));
-    MVUS_HIP(hipStreamSynchronize(stream));
+    if (fetch_marked && scal_direct()) MVUS_HIP(hipEventSynchronize(fetch_ev));
+    else MVUS_HIP(hipStreamSynchronize(stream));
+    fetch_marked = false;
     for (int i = 0; i < k; ++i) host[i] = scal_host[off + i];
   }
   double dot_n(const double* a, const double* b, int64_t len) { dot_to_slot(a, b, len, 0); return read_slot(0); }
@@ -782,6 +811,7 @@ static int guarded(mvus_ba* h, F&& fn) {
   if (!h) return MVUS_E_INVALID;
   try {
     (void)hipSetDevice(h->be.device);
+    ++h->be.api_seq;                 // (what an LM solve carries over to the next call is valid for the very next call only: HipBackend::lm_carry)
     return fn();
   } catch (const HipError& e) {
     h->be.err = e.msg;
@@ -1187,7 +1217,9 @@ int mvus_ba_solve(mvus_ba* h, double* x, const mvus_solve_opts* opts, mvus_resul
     if (sr.error) { be.err = "residuals are not finite in the initial point, or x0 is outside of the bounds"; return MVUS_E_NUMERIC; }
     if (!lm) std::memcpy(x, xv.data(), sizeof(double) * n);
     if (f_out) be.download(f_out, be.f_cur, be.hp.m);
-    MVUS_HIP(hipStreamSynchronize(be.stream));
+    // (an LM solve that ends on its evaluation budget may leave the linearisation at the returned point running: x and the scalars are
+    // on the host already -- mapped memory, fetched behind an event -- and whatever reads those blocks is a later call on this stream)
+    if (!(lm && sr.async_tail && !f_out)) MVUS_HIP(hipStreamSynchronize(be.stream));
     res->cost = sr.cost; res->optimality = sr.optimality; res->nfev = sr.nfev; res->njev = sr.njev; res->status = sr.status;
     res->lin_iters = sr.lin_iters; res->initial_cost = sr.initial_cost;
     res->solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

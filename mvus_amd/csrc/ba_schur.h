@@ -28,6 +28,8 @@
 //                   void solve_async(double lambda);               p = -(H + lambda D)^-1 g -> step_ptr()
 //                   const double* step_ptr(); const int* fail_ptr();  bool solve_ok();   (solve_ok after a fetch)
 //                   bool retry_same();   after a failed solve: true = not a numerical failure, repeat it at the same lambda
+//                   bool spec_ok(jac_mode); void linearize_spec(B&, x, f, jac_mode); void adopt_spec();   the linearisation at a TRIAL point,
+//                                        enqueued into a second set of blocks before the host knows whether the trial is accepted
 // Backend additions: set_bounds(lb, ub) -> lb_ptr()/ub_ptr(); lm_scalars() (>= 8 doubles); dot_m_into(a, b, out);
 //                   lm_gnorm(x, lb, ub, g, out); lm_trial(x, p, lb, ub, g, D, fail, x_new, out4, gnorm_out) (the trial
 //                   kernel reads x, g and the bounds anyway, so it also delivers the gradient norm); fetch(src, k, host).
@@ -99,10 +101,18 @@ SolveResult lm_schur(B& be, Schur& sc, double* x, const std::vector<double>& lb,
   double hs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
   if (!resumed) be.upload(x_dev, x, n);
+  // A resumed point may come with more than its coordinates: the previous solve left f(x) in the residual buffer (its last accepted
+  // trial's, or the start's) and, if its last act was a linearisation at x, the normal equations -- nothing else has touched the handle
+  // since (lm_carry checks that and disarms itself).  The evaluation and the linearisation below are then the values already there.
+  const LmCarry carry = resumed ? be.lm_carry(opt.jac_mode) : LmCarry{};
+  double cost = 0;
+  bool cost_known = false;
   // (the first linearisation follows at once: its storage is zeroed beside this evaluation where the backend can do that)
-  if (be.residual_sq(x_dev, f_dev, S, sc.clear_ptr(), sc.clear_len())) sc.mark_cleared();
+  if (carry.f_valid) { cost = carry.cost; res.initial_cost = cost; cost_known = true; }
+  else if (be.residual_sq(x_dev, f_dev, S, sc.clear_ptr(), sc.clear_len())) sc.mark_cleared();
   res.nfev = 1; res.njev = 1;
-  sc.linearize(be, x_dev, f_dev, opt.jac_mode, true);
+  if (!(carry.f_valid && carry.lin_valid)) sc.linearize(be, x_dev, f_dev, opt.jac_mode, true);
+  bool lin_at_x = true;                 // the blocks the solver holds are those of x_dev
 
   // f(x_new) becomes f(x): the two buffers change roles where the backend allows it (the HIP backend's are pool buffers of
   // one size), else a copy
@@ -111,7 +121,7 @@ SolveResult lm_schur(B& be, Schur& sc, double* x, const std::vector<double>& lb,
     else be.copy(f_dev, f_new, m);
   };
   int mir_cur = -1, mir_trial = 0;      // host mirrors of the accepted / the trial point (backend permitting)
-  double cost = 0;
+  bool spec_live = false;               // the current trial's linearisation is enqueued (sc.linearize_spec)
   try {
   // Trust region in the reference's metric (mvus_solve_opts.lm_trust_radius): scipy's TRF with x_scale = 1 bounds |step|_2 by Delta
   // (scipy/optimize/_lsq/trf.py: Delta_0 = |x0|, or 1 when that is 0) and updates it with update_tr_radius (_lsq/common.py).  The
@@ -127,12 +137,17 @@ SolveResult lm_schur(B& be, Schur& sc, double* x, const std::vector<double>& lb,
     be.lm_trial(x_dev, sc.step_ptr(), lbp, ubp, sc.grad_ptr(), sc.diag_ptr(), sc.fail_ptr(), xt_dev, S + 2, S + 1, be.mirror_dev(mir_trial),
                 tr ? S + 7 : nullptr, Delta);
     be.residual_sq(xt_dev, f_new, S + 6);
+    // Most trials are accepted, and an accepted trial is followed by the linearisation at its point: that linearisation is enqueued NOW,
+    // into the solver's second set of blocks, behind a marker the fetch below waits for instead of the whole stream -- the GPU works on
+    // it while the host wakes up, decides and enqueues the next solve (20 - 60 us of idle device per iteration otherwise).  A rejected
+    // trial leaves the blocks of x untouched (the next solve reads those) and the speculative set is simply written again.
+    spec_live = false;
+    if (sc.spec_ok(opt.jac_mode)) { be.fetch_mark(); sc.linearize_spec(be, xt_dev, f_new, opt.jac_mode); spec_live = true; }
   };
   const int nfetch = tr ? 8 : 7;
 
   double lambda = std::max(opt.lm_lambda0 > 0 ? opt.lm_lambda0 : 1e-4, opt.lm_lambda_min), nu = opt.lm_nu0 > 0 ? opt.lm_nu0 : 2.0;
   const double lambda_min = opt.lm_lambda_min;
-  bool cost_known = false;
   int status = -1;
   double g_norm = 0;
   while (true) {
@@ -201,14 +216,18 @@ SolveResult lm_schur(B& be, Schur& sc, double* x, const std::vector<double>& lb,
       cost = cost_new;
       if (status == -1 && res.nfev >= opt.max_nfev) {
         // evaluation budget spent: no further step will be taken, so the accepted point is not re-linearised (one
-        // Jacobian + assembly saved per call); the reported optimality is then that of the last linearisation
+        // Jacobian + assembly saved per call); the reported optimality is then that of the last linearisation.
+        // (With a speculative linearisation in flight the blocks of the accepted point exist anyway: they are kept for a caller that
+        // continues from here -- lm_keep below -- and nobody waits for them now.)
         accept_residual();
-        res.jac_stale = true;             // J, span and the assembled blocks still belong to the previous point
+        if (spec_live) { sc.adopt_spec(); res.async_tail = true; }
+        else { lin_at_x = false; res.jac_stale = true; }   // J, span and the assembled blocks still belong to the previous point
         break;
       }
       accept_residual();                        // f at the accepted point is the trial residual: not evaluated again
       ++res.njev;
-      sc.linearize(be, x_dev, f_dev, opt.jac_mode, true);
+      if (spec_live) sc.adopt_spec();           // (enqueued before the fetch that decided: see launch_trial)
+      else sc.linearize(be, x_dev, f_dev, opt.jac_mode, true);
     }
     if (status != -1) {                 // converged / gave up: report the gradient norm of the final linearisation
       be.lm_gnorm(x_dev, lbp, ubp, sc.grad_ptr(), S + 1);
@@ -232,6 +251,7 @@ SolveResult lm_schur(B& be, Schur& sc, double* x, const std::vector<double>& lb,
   else if (be.mirror_host(mir_cur)) std::copy(be.mirror_host(mir_cur), be.mirror_host(mir_cur) + n, x);   // written by the accepted trial's kernel, fetched since
   else be.download(x, x_dev, n);
   be.lm_remember(x_dev, x, mir_cur >= 0 ? be.mirror_host(mir_cur) : nullptr);
+  if (!res.error) be.lm_keep(LmCarry{true, lin_at_x, cost}, opt.jac_mode);      // f_dev holds f(x_dev) on every regular exit
   res.cost = cost;
   cleanup();
   return res;
@@ -276,6 +296,9 @@ struct HostSchur {
   const int* fail_ptr() const { return &fail; }
   bool solve_ok() const { return fail == 0; }
   bool retry_same() { return false; }
+  bool spec_ok(int) const { return false; }
+  template <class B> void linearize_spec(B&, const double*, double*, int) {}
+  void adopt_spec() {}
   void solve_async(double lambda) { fail = solve(lambda, pstep) ? 0 : 1; if (fail) pstep.assign(n, 0.0); }
   static double damp_scale(double hii) { return hii > 0 ? hii : 1.0; }
   bool solve(double lambda, std::vector<double>& p) {

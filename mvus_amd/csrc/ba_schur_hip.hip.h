@@ -2371,6 +2371,9 @@ struct HipSchur {
   NEView ne{};
   int ncols = 0, BW = 0;
   size_t ne_count = 0;
+  double* NEset[2] = {nullptr, nullptr};   // two sets of normal-equation blocks: the solver reads NEset[ne_cur]; the other one takes the speculative linearisation (linearize_spec)
+  int ne_cur = 0;
+  size_t off_gc = 0, off_Cb = 0, off_gs = 0, off_Et = 0, off_Apart = 0;
   double *NE = nullptr, *Lb = nullptr, *Z = nullptr, *G = nullptr, *G0 = nullptr, *S = nullptr, *S2 = nullptr, *Linv = nullptr, *rhs = nullptr, *pc = nullptr,
          *DG = nullptr, *D = nullptr, *gx = nullptr, *px = nullptr, *sepbuf = nullptr;
   RcsView rcs{};            // reduced camera system in block-image form (ba_rcs.hip.h)
@@ -2473,8 +2476,9 @@ struct HipSchur {
     ne_count = nA + ngc + halo_count + ndg + nCb + ngs + nEt;
     // + the per-workgroup camera-block partials of the assembly, behind the blocks (cleared with them, never summed over ranks)
     n_apart = (size_t)kGaParts * (kGaThreads / 64) * std::max<size_t>(hp.chunks.size(), 1) * (size_t)((ne.B + 1) * (ne.B + 2) / 2);
-    NE = be.alloc(ne_count + n_apart);
-    ne.A = NE; ne.gc = ne.A + nA; ne.Cb = ne.gc + ngc + halo_count + ndg; ne.gs = ne.Cb + nCb; ne.Et = ne.gs + ngs; ne.Apart = ne.Et + nEt;
+    NEset[0] = be.alloc(ne_count + n_apart);
+    off_gc = nA; off_Cb = nA + ngc + halo_count + ndg; off_gs = off_Cb + nCb; off_Et = off_gs + ngs; off_Apart = off_Et + nEt;
+    bind_ne(0);
     Lb = be.alloc((size_t)ne.N3 * (BW + 1));
     Z = be.alloc((size_t)ne.N3 * ncols);
     plan_gemm(3 * (own_hi - own_lo));
@@ -2556,6 +2560,7 @@ struct HipSchur {
     pv.tc0 = pv.sr + pv.P; pv.tpl = pv.tc0 + pv.nt; pv.tpr = pv.tpl + pv.nt; pv.tgq = pv.tpr + pv.nt; pv.town = pv.tgq + pv.nt;
     pv.seprow = reinterpret_cast<const unsigned char*>(part_tables + seprow_at); pv.CB = ne.CB; pv.B = ne.B; pv.N3 = ne.N3; pv.Dl = nullptr; pv.direct = 0;
     pv.Et = ne.Et; pv.gs = ne.gs;
+    pv_ready = true;
     if (nbound > 0) {
       std::vector<int> hb;
       if (ts.rank > 0) hb.push_back(ts.cuts[ts.rank]);
@@ -2682,7 +2687,7 @@ struct HipSchur {
     else MVUS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_assemble_windows<9>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)win_lds));
   }
   ~HipSchur() {
-    for (double* p : {Dl, NE, Lb, Z, G, G0, S, S2, Linv, rhs, pc, DG, px, pv.VW, sepbuf, pv.U2, pv.Ha, pv.Hc, wv.Apart, rcs.Simg, rcs.Tsc, rcs.x}) if (p) be.release(p);
+    for (double* p : {Dl, NEset[0], NEset[1], Lb, Z, G, G0, S, S2, Linv, rhs, pc, DG, px, pv.VW, sepbuf, pv.U2, pv.Ha, pv.Hc, wv.Apart, rcs.Simg, rcs.Tsc, rcs.x}) if (p) be.release(p);
     if (win_tables) (void)hipFree(win_tables);
     if (part_tables) (void)hipFree(part_tables);
     if (halo_tables) (void)hipFree(halo_tables);
@@ -2690,6 +2695,30 @@ struct HipSchur {
     if (rcs_flags) (void)hipFree(rcs_flags);
     if (fail_host) (void)hipHostFree(fail_host);
   }
+
+  // ---- two sets of blocks ----
+  bool pv_ready = false;
+  void bind_ne(int k) {
+    NE = NEset[k];
+    ne.A = NE; ne.gc = NE + off_gc; ne.Cb = NE + off_Cb; ne.gs = NE + off_gs; ne.Et = NE + off_Et; ne.Apart = NE + off_Apart;
+    if (pv_ready) { pv.Et = ne.Et; pv.gs = ne.gs; }
+  }
+  // Speculative linearisation (ba_schur.h, launch_trial): one rank, the fused window-major assembly (every entry written by one plain
+  // store: the second set needs no clearing), scalars fetched behind an event.  MVUS_NO_SPEC=1 keeps the sequential form for an A/B.
+  bool spec_ok(int jac_mode) {
+    if (shard || !use_win || !be.scal_direct() || jac_mode != MVUS_JAC_ANALYTIC) return false;
+    if (std::getenv("MVUS_NO_SPEC") || std::getenv("MVUS_LM_MATERIALIZE_J")) return false;
+    if (!NEset[1]) NEset[1] = be.alloc(ne_count + n_apart);
+    return true;
+  }
+  void linearize_spec(BE&, const double* x_dev, double* f_dev, int jac_mode) {
+    const bool pending = diag_pending;      // D and g in x order belong to the set the solver reads: untouched until adopt_spec
+    bind_ne(ne_cur ^ 1);
+    linearize(be, x_dev, f_dev, jac_mode, true);
+    bind_ne(ne_cur);
+    diag_pending = pending;
+  }
+  void adopt_spec() { ne_cur ^= 1; bind_ne(ne_cur); diag_pending = true; }
 
   // x_fused != nullptr: the detection rows' Jacobian is evaluated inside the assembly kernel at x_fused (no J in memory);
   // the motion rows (O(T), tiny) still go through k_motion

@@ -58,6 +58,15 @@ struct SolveResult {
   double lm_lambda = 0;  // final LM damping
   double lm_nu = 2;      // final growth factor of the damping
   bool jac_stale = false;  // the Jacobian held by the backend belongs to an earlier point than the returned x
+  bool async_tail = false; // LM_SCHUR: a speculative linearisation at the returned point may still be running on the stream (its results
+                           // are only ever read by later work on the same stream: the caller need not wait for it)
+};
+
+// What an LM solve leaves behind for the point it returned, for a caller that continues from exactly that point (ba_schur.h):
+// f(x) in the backend's residual buffer with its cost, and -- when the solve's last act was a linearisation there -- the normal equations.
+struct LmCarry {
+  bool f_valid = false, lin_valid = false;
+  double cost = 0;
 };
 
 // returns the pooled work vectors of a solve when the driver leaves, by return or by exception

@@ -74,6 +74,9 @@ struct HostBackend {
   int lm_resume(const double*) { return -1; }
   bool reshard_pending() { return false; }
   void lm_remember(const double*, const double*, const double*) {}
+  mvus::LmCarry lm_carry(int) { return {}; }
+  void lm_keep(const mvus::LmCarry&, int) {}
+  void fetch_mark() {}
   double* mirror_dev(int) { return nullptr; }
   const double* mirror_host(int) const { return nullptr; }
   void adopt_residual(double*&, double*&) {}

@@ -476,3 +476,47 @@ def test_a_failed_solve_leaves_no_stale_resume_point():
             r2 = h.solve(r1.x.copy(), max_nfev=8, **kw)
         assert np.array_equal(r1.x, q1.x)
         assert np.array_equal(r2.x, q2.x) and r2.cost == q2.cost and r2.nfev == q2.nfev
+
+
+@pytest.mark.parametrize('name', ['rs_F_2int_3cam', 'c1_pinhole_2cam', 'calib_KE_bounds_3cam'])
+def test_speculative_linearisation_and_carry_over_change_no_bit(name, monkeypatch):
+    """Round 6: (a) the linearisation at a trial point is enqueued into a second set of blocks before the host knows whether the trial
+    is accepted (HipSchur::linearize_spec), the fetch waits behind an event; (b) a caller that continues from the returned point finds
+    f(x), its cost and -- after a solve that ended on its budget with an accepted trial -- the normal equations on the device
+    (HipBackend::lm_carry).  Both change WHEN work is done, never a value: one long solve and a chain of two-evaluation calls (bench.py's
+    steps) give the same bits as the sequential driver (MVUS_NO_SPEC=1, MVUS_LM_NO_CARRY=1), accepted and rejected trials alike."""
+    from mvus_amd.ba import BAHandle
+    scene, g = load_case(name)
+    prob, _ = mp.problem_from_scene(scene)
+    kw = dict(solver=_lib.SOLVER_LM_SCHUR, jac_mode=_lib.JAC_ANALYTIC)
+
+    def run():
+        out = []
+        with BAHandle(prob) as h:
+            o = _lib.default_opts(_lib.SOLVER_LM_SCHUR, _lib.JAC_ANALYTIC, 14)
+            o.lm_lambda_min = 0.0                            # (no floor: the damping falls until trials are rejected)
+            r = h.solve(g['x0'], opts=o)
+            out.append((r.x.copy(), r.cost, r.nfev, r.njev, r.status))
+        with BAHandle(prob) as h:
+            x = g['x0'].copy()
+            for k in range(7):
+                r = h.solve(x, max_nfev=2 if k != 3 else 3, **kw)
+                out.append((r.x.copy(), r.cost, r.nfev, r.njev, r.status))
+                x = r.x
+            f = h.residual(x)                                # (another call in between: what the solve left behind must not be used)
+            r = h.solve(x, max_nfev=3, **kw)
+            out.append((r.x.copy(), r.cost, r.nfev, r.njev, r.status, 0.5 * float(f @ f)))
+        return out
+
+    for k in ('MVUS_NO_SPEC', 'MVUS_LM_NO_CARRY'):
+        monkeypatch.delenv(k, raising=False)
+    new = run()
+    again = run()
+    monkeypatch.setenv('MVUS_NO_SPEC', '1')
+    monkeypatch.setenv('MVUS_LM_NO_CARRY', '1')
+    old = run()
+    for a, b, c in zip(new, old, again):
+        assert np.array_equal(a[0], b[0]) and a[1:] == b[1:], (a[1:], b[1:])
+        assert np.array_equal(a[0], c[0]) and a[1:] == c[1:]
+    assert new[0][2] - 1 > new[0][3] - 1 or name != 'rs_F_2int_3cam', 'the long solve was meant to contain a rejected trial'
+    assert new[-1][1] <= new[-1][5]                           # the last solve started from the cost the residual call saw
