@@ -243,7 +243,10 @@ int mvus_ba_normal_equations(mvus_ba* h, double* g, double* JtJ_cam, double* ban
 int mvus_ba_lm_step(mvus_ba* h, double lambda, double* p_out);
 
 /* The least_squares call of Scene.BA (common.py:670) -- x is read and overwritten with res.x.
- * lb/ub come from opts of the problem (rs_bounds).  f_out[m] may be NULL.  Synchronises before returning.
+ * lb/ub come from opts of the problem (rs_bounds).  f_out[m] may be NULL.  x, res and f_out are complete on return.  MVUS_SOLVER_LM_SCHUR
+ * with f_out == NULL may return while device work for the NEXT call is still running on the handle's stream (the linearisation at the
+ * returned point, enqueued before the accept / reject decision was known); every later call on the handle is ordered behind it, and a
+ * solve that continues from the returned x reuses it together with f(x) and the cost instead of evaluating them again.
  * Termination tests, nfev/njev counting and status codes follow scipy for both solvers (max_nfev = the reference's
  * max_iter); MVUS_SOLVER_LM_SCHUR does not re-linearise the accepted point when max_nfev stops it. */
 int mvus_ba_solve(mvus_ba* h, double* x, const mvus_solve_opts* opts, mvus_result* res, double* f_out);

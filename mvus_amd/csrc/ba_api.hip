@@ -3,6 +3,7 @@
 // launches HIP kernels, and mvus_ba_create fails with MVUS_E_HIP when no device is usable.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <chrono>
 #include <cstring>
 #include <dlfcn.h>
@@ -119,8 +120,8 @@ struct HipBackend {
     mJ = dalloc<double>((size_t)36 * hp.T); mctrl = dalloc<int32_t>((size_t)3 * hp.T);
     x_cur = dalloc<double>(hp.n); f_cur = alloc(hp.m);      // (from the pool: an LM solve swaps it with its trial buffer)
     partials = dalloc<double>(2048); scal_dev = dalloc<double>(16);
-    MVUS_HIP(hipHostMalloc(reinterpret_cast<void**>(&scal_host), 16 * sizeof(double), hipHostMallocMapped));
-    for (int i = 0; i < 16; ++i) scal_host[i] = 0.0;
+    MVUS_HIP(hipHostMalloc(reinterpret_cast<void**>(&scal_host), 32 * sizeof(double), hipHostMallocMapped));      // [16]: the start mark of fetch_poll_begin
+    for (int i = 0; i < 32; ++i) scal_host[i] = 0.0;
     if (hipHostGetDevicePointer(reinterpret_cast<void**>(&scal_map), scal_host, 0) != hipSuccess) scal_map = nullptr;
     stage_cap = std::max<int64_t>(hp.n, 1024);
     for (int i = 0; i < kStageSlots; ++i) {
@@ -149,6 +150,7 @@ struct HipBackend {
     for (auto& kv : pool_size) (void)hipFree(kv.first);
     if (scal_host) (void)hipHostFree(scal_host);
     if (fetch_ev) (void)hipEventDestroy(fetch_ev);
+    for (double* p : sqh_host) if (p) (void)hipHostFree(p);
     if (lsmr_host) (void)hipHostFree(lsmr_host);
     for (int i = 0; i < 2; ++i) if (xmir_host[i]) (void)hipHostFree(xmir_host[i]);
     for (int i = 0; i < kStageSlots; ++i) {
@@ -307,6 +309,19 @@ struct HipBackend {
   void lm_keep(const LmCarry& c, int jac_mode) { carry = c; carry_seq = api_seq; carry_jac_mode = jac_mode; }
   // fetch_mark: the next fetch waits for the work enqueued so far only (an event), not for what is enqueued after the mark -- the
   // speculative linearisation of the LM driver.  Needs the scalars written straight into mapped memory (one rank).
+  // fetch_poll_begin: the same without an event (hipEventRecord costs a 6 us bubble between the two kernels it separates): the FIRST
+  // kernel enqueued after the point writes *mark = value when it starts -- it cannot start before everything in front of it has
+  // finished and released its writes -- and the fetch spins on that word in mapped memory.
+  static constexpr int kMarkSlot = 16;
+  double fetch_seq = 0.0;
+  bool fetch_polled = false;
+  bool fetch_poll_begin(double** mark, double* value) {
+    if (!scal_direct() || std::getenv("MVUS_FETCH_EVENT")) return false;
+    fetch_seq += 1.0;
+    *mark = scal_map + kMarkSlot; *value = fetch_seq;
+    fetch_polled = true;
+    return true;
+  }
   hipEvent_t fetch_ev = nullptr;
   bool fetch_marked = false;
   void fetch_mark() {
@@ -386,9 +401,20 @@ struct HipBackend {
   void fetch(const double* src, int k, double* host) {       // src inside scal_out(): the pinned mirror itself, or staged through it
     const int64_t off = src - scal_out();
     if (!scal_direct()) MVUS_HIP(hipMemcpyAsync(scal_host + off, src, sizeof(double) * k, hipMemcpyDeviceToHost, stream));
-    if (fetch_marked && scal_direct()) MVUS_HIP(hipEventSynchronize(fetch_ev));
+    if (fetch_polled && scal_direct()) {
+      const volatile double* m = scal_host + kMarkSlot;
+      const auto t0 = std::chrono::steady_clock::now();
+      unsigned spins = 0;
+      while (*m != fetch_seq) {
+        if ((++spins & 0xfff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) { MVUS_HIP(hipStreamSynchronize(stream)); break; }   // (never seen; the stream then tells)
+        __builtin_ia32_pause();
+      }
+      std::atomic_thread_fence(std::memory_order_acquire);
+    } else if (fetch_marked && scal_direct()) MVUS_HIP(hipEventSynchronize(fetch_ev));
     else MVUS_HIP(hipStreamSynchronize(stream));
-    fetch_marked = false;
+    fetch_marked = false; fetch_polled = false;
+    for (SqPending& sp : sq_pend)                         // sums of squares left as per-workgroup partials in mapped memory (residual_sq)
+      if (sp.slot >= off && sp.slot < off + k) { scal_host[sp.slot] = sq_host_sum(sqh_host[&sp - sq_pend], sp.n); sp.slot = -1; }
     for (int i = 0; i < k; ++i) host[i] = scal_host[off + i];
   }
   double dot_n(const double* a, const double* b, int64_t len) { dot_to_slot(a, b, len, 0); return read_slot(0); }
@@ -432,13 +458,51 @@ struct HipBackend {
   // behind and one small launch adds them -- no separate pass over f
   double* sq_part = nullptr;
   size_t sq_cap = 0;
+  // One rank (scalars in mapped memory): the workgroups' partial sums go to mapped pinned HOST memory and the host adds them after
+  // the fetch's wait, in k_dot_final's own tree (sq_host_sum: the same bits) -- the 4.4 - 5 us launch of k_dot_final behind every
+  // residual evaluation of the LM driver is gone.  Two sets: the start's |f|^2 and the first trial's are both outstanding at the
+  // first fetch of a solve.  MVUS_SQ_DEVICE_SUM=1 keeps the launch (A/B).
+  double* sqh_host[2] = {nullptr, nullptr};
+  double* sqh_dev[2] = {nullptr, nullptr};
+  size_t sqh_cap = 0;
+  struct SqPending { int64_t slot = -1; int n = 0; } sq_pend[2];
+  static double sq_host_sum(const double* part, int nb) {
+    double red[kThreads / 64];
+    for (int w = 0; w < kThreads / 64; ++w) {
+      double lane[64];
+      for (int l = 0; l < 64; ++l) {                       // k_dot_final: thread t adds partials t, t + kThreads, ...
+        double a = 0.0;
+        for (int i = w * 64 + l; i < nb; i += kThreads) a += part[i];
+        lane[l] = a;
+      }
+      for (int off = 32; off > 0; off >>= 1)                // wave_sum as lane 0 sees it
+        for (int l = 0; l < off; ++l) lane[l] += lane[l + off];
+      red[w] = lane[0];
+    }
+    double t = 0.0;
+    for (int w = 0; w < kThreads / 64; ++w) t += red[w];
+    return t;
+  }
   // clr / clr_len: storage to zero beside the evaluation (HipSchur's normal-equation blocks); returns false if it was not done
   bool residual_sq(const double* x, double* f, double* out, double* clr = nullptr, int64_t clr_len = 0) {
     if (allreduce) { residual(x, f); dot_m_into(f, f, out); return false; }
     RoctxRange range("mvus residual");
     const int mb = hp.T > 0 ? (int)((hp.T + kThreads - 1) / kThreads) : 0;
     const size_t need = (size_t)dp.n_chunks + mb + 1;
-    if (need > sq_cap) { sq_part = dalloc<double>(need); sq_cap = need; }
+    const bool host_sum = scal_direct() && out >= scal_out() && out < scal_out() + 16 && !std::getenv("MVUS_SQ_DEVICE_SUM");
+    const int set = (out == lm_scalars()) ? 0 : 1;
+    double* sq_part = this->sq_part;
+    if (host_sum) {
+      if (need > sqh_cap) {
+        for (int i = 0; i < 2; ++i) {
+          if (sqh_host[i]) (void)hipHostFree(sqh_host[i]);
+          MVUS_HIP(hipHostMalloc(reinterpret_cast<void**>(&sqh_host[i]), need * sizeof(double), hipHostMallocMapped));
+          MVUS_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&sqh_dev[i]), sqh_host[i], 0));
+        }
+        sqh_cap = need;
+      }
+      sq_part = sqh_dev[set];
+    } else if (need > sq_cap) { this->sq_part = dalloc<double>(need); sq_cap = need; sq_part = this->sq_part; }
     ensure_cams(x);
     bool cleared = false;
     if (dp.n_chunks > 0) {
@@ -451,7 +515,8 @@ struct HipBackend {
       cleared = fb > 0;
     }
     if (mb > 0) hipLaunchKernelGGL(k_motion<false>, dim3(mb), dim3(kThreads), 0, stream, dp, x, f + 2 * hp.M, mJ, mctrl, 0, sq_part + dp.n_chunks);
-    if (dp.n_chunks + mb > 0) hipLaunchKernelGGL(k_dot_final, dim3(1), dim3(kThreads), 0, stream, dp.n_chunks + mb, sq_part, out);
+    if (host_sum) { sq_pend[set].slot = out - scal_out(); sq_pend[set].n = dp.n_chunks + mb; }      // added up by fetch()
+    else if (dp.n_chunks + mb > 0) hipLaunchKernelGGL(k_dot_final, dim3(1), dim3(kThreads), 0, stream, dp.n_chunks + mb, sq_part, out);
     else MVUS_HIP(hipMemsetAsync(out, 0, sizeof(double), stream));
     MVUS_HIP(hipGetLastError());
     return cleared;

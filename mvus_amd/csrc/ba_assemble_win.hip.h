@@ -54,6 +54,8 @@ struct WinView {
                              //        (stride between coordinates), index of knot t[l-2] of its span, 1: first span | 2: last span of the interval}
   int Wn, nwin;
   int Ntot;                  // control points of the whole problem (a time shard's slice is shorter)
+  double* mark;              // non-null: workgroup 0 writes mark_val there when it starts (mapped host memory: the host's fetch spins on it --
+  double mark_val;           //           this launch cannot start before everything enqueued in front of it has finished; HipBackend::fetch_poll_begin)
 };
 
 constexpr __host__ __device__ int win_region_doubles(int B) {       // LDS doubles per wavefront: staging, reused by the flushes
@@ -128,6 +130,7 @@ void k_assemble_windows(DevProblem dp, NEView ne, WinView wv, const CamState* __
   constexpr int REG = win_region_doubles(B), WAVE = win_wave_doubles(B);
   static_assert(NV * kWinStr <= REG, "staging fits the region");
   extern __shared__ double win_lds[];                       // per wavefront: [REG] staging / flush region, [32] masks; then the window's span records
+  if (wv.mark != nullptr && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(wv.mark, wv.mark_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   using d4v = __attribute__((ext_vector_type(4))) double;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));

@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void k_rcs_finish(NEView ne, int ncols, int ns
   const long long stride = (long long)ne.CB * ncols;
   const int nn = ne.CB, npad = rv.nbk * 16;
   if (blockIdx.y == gridDim.y - 1) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) { flags[0] = 0u; flags[1] = 0u; }   // the hand-over counter of the factor launches that follow, and their time-out mark
+    if (blockIdx.x == 0 && threadIdx.x == 0) flags[0] = 0u;          // the hand-over counter of the factor launches that follow
     if (r0 != 0 || b >= npad) return;
     double gr = 0.0;
     if (b < nn) {
@@ -331,7 +331,7 @@ __device__ __forceinline__ void rcs_trsm_role(RcsView rv, int c0, int nc, unsign
       unsigned spins = 0;
       while (__hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
         __builtin_amdgcn_s_sleep(8);
-        if (++spins > spin_limit) { *abort_s = 1; fail[0] = kFailHandover; flags[1] = 1u; break; }     // (flags[1]: sticky for this solve -- a later kernel that meets the unfinished rows may overwrite fail[0])
+        if (++spins > spin_limit) { *abort_s = 1; fail[0] = kFailHandover; fail[2] = 1; break; }     // (fail[2]: sticky for this solve -- a later kernel that meets the unfinished rows may overwrite fail[0])
       }
     }
     lds_barrier();

@@ -142,7 +142,7 @@ SolveResult lm_schur(B& be, Schur& sc, double* x, const std::vector<double>& lb,
     // it while the host wakes up, decides and enqueues the next solve (20 - 60 us of idle device per iteration otherwise).  A rejected
     // trial leaves the blocks of x untouched (the next solve reads those) and the speculative set is simply written again.
     spec_live = false;
-    if (sc.spec_ok(opt.jac_mode)) { be.fetch_mark(); sc.linearize_spec(be, xt_dev, f_new, opt.jac_mode); spec_live = true; }
+    if (sc.spec_ok(opt.jac_mode)) { sc.linearize_spec(be, xt_dev, f_new, opt.jac_mode); spec_live = true; }      // (marks where the fetch stops waiting)
   };
   const int nfetch = tr ? 8 : 7;
 

@@ -859,7 +859,7 @@ __device__ __forceinline__ void ne_diag_grad_entry(const DevProblem& dp, const N
 // linearisation; the first solve after an assembly carries it)
 __device__ __forceinline__ void band_pack_entry(const NEView& ne, double lambda, int BW, double* __restrict__ Lb, int* __restrict__ fail, const DevProblem& dp,
                                                 int with_diag, double* __restrict__ D, double* __restrict__ gx, long long idx) {
-  if (idx == 0) fail[0] = 0;              // first kernel of a solve: clears the failure flag the later ones may raise
+  if (idx == 0) { fail[0] = 0; fail[2] = 0; }   // first kernel of a solve: clears the failure flag the later ones may raise, and the sticky hand-over mark
   if (with_diag && idx < ne.CB + ne.N3) ne_diag_grad_entry(dp, ne, 0, (int)idx, D, gx);
   const long long total = (long long)ne.N3 * (BW + 1);
   if (idx >= total) return;
@@ -1501,7 +1501,7 @@ struct BcrGaussJordan {
 template <int S3>
 struct BcrGaussJordan<S3, S3> { static __device__ __forceinline__ void run(double (&)[S3], int, bool&) {} };
 
-template <int S3>
+template <int S3, bool WT = false>      // WT: T_i and C_i leave as agent-scope write-through stores (readers in other workgroups of the SAME launch: k_sep_bcr_levels)
 __device__ __forceinline__ void bcr_survivor(const PartView& pv, int h, int s, double* __restrict__ w, int* __restrict__ fail) {
   constexpr int SS = S3 * S3, KS = (S3 + 3) / 4;
   const int m = pv.m, lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
@@ -1593,8 +1593,13 @@ __device__ __forceinline__ void bcr_survivor(const PartView& pv, int h, int s, d
   for (int r = 0; r < 4; ++r) {
     const int rw = lk + 4 * r;
     if (rw < S3 && lr < S3) {
-      pv.T[(long long)i * SS + rw * S3 + lr] = ti[r] - dacc[r];
-      Cc[(long long)i * SS + rw * S3 + lr] = 0.0 - cacc[r];
+      if constexpr (WT) {
+        __hip_atomic_store(pv.T + (long long)i * SS + rw * S3 + lr, ti[r] - dacc[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(Cc + (long long)i * SS + rw * S3 + lr, 0.0 - cacc[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        pv.T[(long long)i * SS + rw * S3 + lr] = ti[r] - dacc[r];
+        Cc[(long long)i * SS + rw * S3 + lr] = 0.0 - cacc[r];
+      }
     }
   }
 }
@@ -1604,6 +1609,40 @@ template <int S3>
 __global__ __launch_bounds__(64) void k_sep_bcr_level(PartView pv, int h, int* __restrict__ fail) {
   __shared__ double w[3 * S3 * S3];
   bcr_survivor<S3>(pv, h, blockIdx.x, w, fail);
+}
+// ALL the wide levels in ONE launch (round 6): workgroup b is survivor s of level L (levels in launch order: the first ones have the
+// lowest block indices), and a survivor of level L >= 1 waits until the three nodes it reads -- itself and its two neighbours, all
+// survivors of level L - 1 -- carry the mark of that level.  Hand-over as in k_rcs_factor (the CDNA guide's Guideline 16): the
+// producer's T_i and C_i go out as agent-scope (sc1, write-through) stores, s_waitcnt vmcnt(0), then ONE lane stores done[i] = epoch + L
+// + 1 with a relaxed agent-scope atomic; the consumer polls with relaxed agent-scope loads (s_sleep, BOUNDED: a time-out raises
+// fail[0] = kFailHandoverCode and the sticky fail[2], the host then repeats the solve with a launch per level) and reads the blocks with
+// agent-scope loads (bcr_ld).  `epoch` grows by 8 per solve: the marks are never reset.  Three launches of ~5 us (a ramp and two or
+// three memory round trips each) become one of ~7.
+struct BcrLevels { int nlev; int first[4]; int h[4]; };      // first[l]: block index of level l's survivor 0
+template <int S3>
+__global__ __launch_bounds__(64) void k_sep_bcr_levels(PartView pv, BcrLevels lv, unsigned* __restrict__ done, unsigned epoch, unsigned spin_limit, int* __restrict__ fail) {
+  __shared__ double w[3 * S3 * S3];
+  int L = 0;
+#pragma unroll
+  for (int l = 1; l < 4; ++l) if (l < lv.nlev && (int)blockIdx.x >= lv.first[l]) L = l;
+  const int h = lv.h[L], s = (int)blockIdx.x - lv.first[L];
+  const int i = 2 * h * (s + 1) - 1, jL = i - h, jR = i + h;
+  if (L > 0 && threadIdx.x == 0) {
+    const unsigned want = epoch + (unsigned)L;
+    unsigned spins = 0;
+    while (true) {
+      const unsigned a = __hip_atomic_load(done + jL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned b = i < pv.m ? __hip_atomic_load(done + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : want;
+      const unsigned c = jR < pv.m ? __hip_atomic_load(done + jR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : want;
+      if ((int)(a - want) >= 0 && (int)(b - want) >= 0 && (int)(c - want) >= 0) break;
+      __builtin_amdgcn_s_sleep(4);
+      if (++spins > spin_limit) { fail[0] = kFailHandoverCode; fail[2] = 1; break; }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  bcr_survivor<S3, true>(pv, h, s, w, fail);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (threadIdx.x == 0 && i < pv.m) __hip_atomic_store(done + i, epoch + (unsigned)L + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // the remaining levels from stride h0 on, one workgroup: a wavefront per survivor, one barrier per level
 constexpr int bcr_tail_waves(int s3) { return s3 > 9 ? kBcrWaves / 2 : kBcrWaves; }
@@ -2269,15 +2308,15 @@ __global__ __launch_bounds__(kGjThreads) void k_gj_step(int nn, int kb, const do
 // p (x order) from p_c and p_s = -(z_g + Z_E p_c)
 __global__ __launch_bounds__(kThreads) void k_back_substitute(DevProblem dp, NEView ne, int ncols, int row_lo, int row_hi, int cams,
                                                               const double* __restrict__ Z, const double* __restrict__ pc, double* __restrict__ px,
-                                                              int* __restrict__ fail = nullptr, int* __restrict__ fail_mirror = nullptr, const unsigned* __restrict__ handover = nullptr) {
+                                                              int* __restrict__ fail = nullptr, int* __restrict__ fail_mirror = nullptr) {
   // one wavefront per owned spline row: lanes stride over the row of Z (coalesced), then a shuffle reduction
   const int lane = threadIdx.x & 63;
   // last kernel of a solve: the two failure flags go to the host's mapped copy here (a device-to-host copy of 8 bytes is a launch)
-  // (a hand-over time-out inside the reduced solve -- flags[1] of k_rcs_factor's row workgroups -- outranks whatever a later kernel made of the
-  // unfinished rows: it is reported as its own code, HipSchur::retry_same)
+  // (a hand-over time-out inside the solve -- fail[2], raised by a workgroup that gave up waiting for another one of its launch: k_rcs_factor's
+  // rows, k_sep_bcr_levels -- outranks whatever a later kernel made of the unfinished data: it is reported as its own code, HipSchur::retry_same)
   if (fail != nullptr && blockIdx.x == 0 && threadIdx.x < 2) {
     int v = fail[threadIdx.x];
-    if (threadIdx.x == 0 && handover != nullptr && handover[1] != 0u) { v = kFailHandoverCode; fail[0] = v; }
+    if (threadIdx.x == 0 && fail[2] != 0) { v = kFailHandoverCode; fail[0] = v; }
     if (fail_mirror != nullptr) fail_mirror[threadIdx.x] = v;
   }
   const int r = row_lo + blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
@@ -2379,6 +2418,9 @@ struct HipSchur {
   RcsView rcs{};            // reduced camera system in block-image form (ba_rcs.hip.h)
   unsigned* rcs_flags = nullptr;   // step counter of the in-launch hand-over (k_rcs_factor -> its row workgroups); zeroed by k_rcs_finish
   bool rcs_trsm_launch = false;
+  bool bcr_fused = true;                     // the wide cyclic-reduction levels in one launch (k_sep_bcr_levels); MVUS_BCR_FUSED=0: a launch per level
+  unsigned* bcr_done = nullptr;              // [m] per separator: the level mark of the hand-over
+  unsigned bcr_epoch = 0;
   unsigned rcs_spin_limit = kRcsSpinLimit;   // MVUS_RCS_SPIN_LIMIT: test hook (0 = the first poll that finds the flag behind gives up)
   int handover_timeouts = 0;                 // solves repeated because a consumer workgroup of k_rcs_factor timed out (retry_same)
   int part_len = kPartL;    // control points per interior of the band solver (<= kPartL)
@@ -2499,13 +2541,14 @@ struct HipSchur {
     { const char* e = std::getenv("MVUS_RCS_TRSM"); rcs_trsm_launch = e && std::strcmp(e, "launch") == 0; }
     { const char* e = std::getenv("MVUS_RCS_SPIN_LIMIT"); if (e) rcs_spin_limit = (unsigned)std::strtoul(e, nullptr, 10); }
     { const char* e = std::getenv("MVUS_RCS"); use_rcs = !(e && std::strcmp(e, "gj") == 0); }
+    { const char* e = std::getenv("MVUS_BCR_FUSED"); if (e) bcr_fused = std::atoi(e) != 0; }
     MVUS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rcs_trsm), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((rcs_stage_doubles(kRcsSP) + 512) * sizeof(double))));
     MVUS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rcs_backsub), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(rcs_backsub_doubles(rcs.nbk) * sizeof(double))));
     if (shard) { DG = nullptr; D = NE + nAg + halo_count; gx = D + hp.n; }
     else { DG = be.alloc(2 * (size_t)hp.n); D = DG; gx = DG + hp.n; }
     px = be.alloc(hp.n + 2);                         // + the two failure flags of a time shard
-    MVUS_HIP(hipMalloc(reinterpret_cast<void**>(&fail), 2 * sizeof(int)));
-    MVUS_HIP(hipMemsetAsync(fail, 0, 2 * sizeof(int), be.stream));
+    MVUS_HIP(hipMalloc(reinterpret_cast<void**>(&fail), 4 * sizeof(int)));      // [2]: sticky hand-over time-out mark of the running solve
+    MVUS_HIP(hipMemsetAsync(fail, 0, 4 * sizeof(int), be.stream));
     MVUS_HIP(hipHostMalloc(reinterpret_cast<void**>(&fail_host), 2 * sizeof(int), hipHostMallocMapped));
     fail_host[0] = fail_host[1] = 0;
     if (hipHostGetDevicePointer(reinterpret_cast<void**>(&fail_map), fail_host, 0) != hipSuccess) fail_map = nullptr;
@@ -2602,6 +2645,8 @@ struct HipSchur {
     bcr_lds = (size_t)2 * mm * pv.s3 * bcr_cols * sizeof(double);
     if (bcr_lds > 64 * 1024) { bcr_cols = 1; bcr_lds /= kBcrCols; }
     use_bcr = bcr_lds <= 64 * 1024 && !std::getenv("MVUS_SEP_SEQUENTIAL");
+    MVUS_HIP(hipMalloc(reinterpret_cast<void**>(&bcr_done), mm * sizeof(unsigned)));
+    MVUS_HIP(hipMemsetAsync(bcr_done, 0, mm * sizeof(unsigned), be.stream));
     win_prepare();
   }
   // Window-major assembly: needs every camera's frames in non-decreasing order (HostProblem::frames_sorted; anything else keeps the
@@ -2693,6 +2738,7 @@ struct HipSchur {
     if (halo_tables) (void)hipFree(halo_tables);
     if (fail) (void)hipFree(fail);
     if (rcs_flags) (void)hipFree(rcs_flags);
+    if (bcr_done) (void)hipFree(bcr_done);
     if (fail_host) (void)hipHostFree(fail_host);
   }
 
@@ -2713,9 +2759,12 @@ struct HipSchur {
   }
   void linearize_spec(BE&, const double* x_dev, double* f_dev, int jac_mode) {
     const bool pending = diag_pending;      // D and g in x order belong to the set the solver reads: untouched until adopt_spec
+    // where the fetch that follows stops waiting: the start of the assembly kernel (a word in mapped memory), else an event in front of it
+    if (!be.fetch_poll_begin(&wv.mark, &wv.mark_val)) { wv.mark = nullptr; be.fetch_mark(); }
     bind_ne(ne_cur ^ 1);
     linearize(be, x_dev, f_dev, jac_mode, true);
     bind_ne(ne_cur);
+    wv.mark = nullptr;
     diag_pending = pending;
   }
   void adopt_spec() { ne_cur ^= 1; bind_ne(ne_cur); diag_pending = true; }
@@ -2853,10 +2902,10 @@ struct HipSchur {
   // rows below a super-block (MVUS_RCS_TRSM=launch: bit-identical results, no spinning) for the rest of its life and the caller
   // repeats the solve at the SAME damping -- raising lambda, the answer to a lost pivot, would silently change the iterates.
   bool retry_same() {
-    if (fail_host[0] != kFailHandover || rcs_trsm_launch) return false;
-    rcs_trsm_launch = true;
+    if (fail_host[0] != kFailHandover || (rcs_trsm_launch && !bcr_fused)) return false;
+    rcs_trsm_launch = true; bcr_fused = false;
     ++handover_timeouts;
-    if (std::getenv("MVUS_DEBUG")) std::fprintf(stderr, "schur solve: hand-over time-out in k_rcs_factor -> rows below the super-block in a launch of their own from now on\n");
+    if (std::getenv("MVUS_DEBUG")) std::fprintf(stderr, "schur solve: hand-over time-out in k_rcs_factor / k_sep_bcr_levels -> a launch per stage from now on\n");
     return true;
   }
 
@@ -2877,7 +2926,17 @@ struct HipSchur {
       if (pv.nt > 0) hipLaunchKernelGGL(k_part_reduce<BWT>, dim3(pv.nt, split ? 1 : (pv.s3 * ncols + 255) / 256), dim3(256), 0, be.stream, pv, ncols, Lb, Z, split ? 1 : 3);
       if (shard) be.reduce(sepbuf, sep_count);        // every rank now holds the whole separator system
       if (use_bcr) {
-        int h = 1;                                        // wide levels: a launch each; the rest in one workgroup
+        int h = 1;                                        // wide levels: one launch for all of them (or a launch each); the rest in one workgroup
+        {
+          BcrLevels lv{};
+          int total = 0, hh = 1;
+          for (; hh <= pv.m && pv.m / (2 * hh) > kBcrTailNs && lv.nlev < 4; hh <<= 1) { lv.first[lv.nlev] = total; lv.h[lv.nlev] = hh; total += pv.m / (2 * hh); ++lv.nlev; }
+          if (bcr_fused && !shard && lv.nlev >= 2 && !(hh <= pv.m && pv.m / (2 * hh) > kBcrTailNs)) {
+            bcr_epoch += 8;
+            hipLaunchKernelGGL(k_sep_bcr_levels<S3T>, dim3(total), dim3(64), 0, be.stream, pv, lv, bcr_done, bcr_epoch, rcs_spin_limit, fail);
+            h = hh;
+          }
+        }
         for (; h <= pv.m && pv.m / (2 * h) > kBcrTailNs; h <<= 1)
           hipLaunchKernelGGL(k_sep_bcr_level<S3T>, dim3(pv.m / (2 * h)), dim3(64), 0, be.stream, pv, h, fail);
         if (split) {
@@ -2968,7 +3027,7 @@ struct HipSchur {
     if (shard) MVUS_HIP(hipMemsetAsync(px, 0, be.hp.n * sizeof(double), be.stream));
     const int nrows = row_hi - row_lo, per = kThreads / 64;
     hipLaunchKernelGGL(k_back_substitute, dim3((unsigned)std::max(1, (nrows + per - 1) / per)), dim3(kThreads), 0, be.stream, be.dp, ne, ncols,
-                       row_lo, row_hi, (int)(!shard || be.tshard.rank == 0), Z, pc, px, fail, (!shard && be.scal_direct()) ? fail_map : (int*)nullptr, (const unsigned*)(use_rcs ? rcs_flags : nullptr));
+                       row_lo, row_hi, (int)(!shard || be.tshard.rank == 0), Z, pc, px, fail, (!shard && be.scal_direct()) ? fail_map : (int*)nullptr);
     if (!wide && ncorr > 0) {                          // the interiors' rows were computed from uncorrected columns: one vector is corrected here
       if (BW == 11) hipLaunchKernelGGL(k_back_correct<9>, dim3(pv.P), dim3(256), 0, be.stream, be.dp, ne, pv, ncols, (const double*)pc, px);
       else hipLaunchKernelGGL(k_back_correct<15>, dim3(pv.P), dim3(256), 0, be.stream, be.dp, ne, pv, ncols, (const double*)pc, px);

@@ -520,3 +520,35 @@ def test_speculative_linearisation_and_carry_over_change_no_bit(name, monkeypatc
         assert np.array_equal(a[0], c[0]) and a[1:] == c[1:]
     assert new[0][2] - 1 > new[0][3] - 1 or name != 'rs_F_2int_3cam', 'the long solve was meant to contain a rejected trial'
     assert new[-1][1] <= new[-1][5]                           # the last solve started from the cost the residual call saw
+
+
+@pytest.mark.parametrize('cams,knots', [(3, 2400), (20, 5000)])
+def test_wide_cyclic_reduction_levels_in_one_launch(cams, knots, monkeypatch, capfd):
+    """Round 6: the wide levels of the separators' cyclic reduction run in ONE launch (k_sep_bcr_levels: a survivor waits for the marks
+    of the three nodes it reads, write-through stores, agent-scope loads) instead of a launch per level.  Same bits as the launch-per-level
+    form (MVUS_BCR_FUSED=0); and a hand-over time-out (MVUS_RCS_SPIN_LIMIT=0: the first poll gives up) repeats the solve on the
+    launch-per-level route instead of failing it numerically -- again the same bits."""
+    from mvus_amd import synth
+    from mvus_amd.ba import BAHandle
+    sc = synth.make_scene(cams, 4000 * cams, seed=50 + cams, rolling_shutter=True, num_knots=knots)
+    prob, x0 = mp.problem_from_scene(sc)
+    lams = (1e-3, 0.5)
+
+    def steps(env):
+        for k in ('MVUS_BCR_FUSED', 'MVUS_RCS_SPIN_LIMIT', 'MVUS_DEBUG'):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with BAHandle(prob) as h:
+            h.residual_jacobian(x0, _lib.JAC_ANALYTIC)
+            return [h.lm_step(lam) for lam in lams] + [h.lm_step(lams[0])]
+
+    fused = steps({})
+    per_level = steps({'MVUS_BCR_FUSED': '0'})
+    capfd.readouterr()
+    timed_out = steps({'MVUS_RCS_SPIN_LIMIT': '0', 'MVUS_DEBUG': '1'})
+    err = capfd.readouterr().err
+    assert err.count('hand-over time-out') == 1, err
+    for a, b, c in zip(fused, per_level, timed_out):
+        assert np.isfinite(a).all() and np.array_equal(a, b) and np.array_equal(a, c)
+    assert np.array_equal(fused[0], fused[2])
