@@ -1026,7 +1026,10 @@ __global__ __launch_bounds__(64) void k_part_cholesky(PartView pv, double* __res
 // substitution loops are branch free) and read as broadcasts, rows are addressed by pointer increments, and the rows of
 // the right-hand side are fetched one batch of kPf rows ahead (they are ncols*8 bytes apart: every row is a fresh
 // cache line, ~1-2 us away).
-constexpr int kPsPf = 16;
+#ifndef MVUS_PS_PF
+#define MVUS_PS_PF 16
+#endif
+constexpr int kPsPf = MVUS_PS_PF;       // rows of right-hand side in flight per lane (a batch)
 template <int BW, bool COUPLING>
 __device__ __forceinline__ void part_solve_block(const PartView& pv, int ncols, const double* __restrict__ Lb, double* __restrict__ Z, double* Ls, int p, int by) {
   constexpr int R = BW + 1, kPf = kPsPf;
@@ -2431,7 +2434,8 @@ struct HipSchur {
   PartView pv{};
   int* part_tables = nullptr;
   int nslab = 1;            // K-slabs of the Schur product (partial sums in G): HipSchur::plan_gemm
-  int ncorr = 0;            // 1: the product carries the separators' correction term and the interiors are NOT back-corrected (one rank)
+  int ncorr = 0;            // 1: the product carries the separators' correction term and the interiors are NOT back-corrected
+  int n_own_sep = 0;        // separators of this slice (a time shard adds the correction rows of ITS separators: every separator once over the ranks)
   double* Dl = nullptr;
   int bcr_cols = kBcrCols;
   size_t bcr_lds = 0;       // dynamic LDS of k_sep_bcr_rhs; the sequential separator kernels remain for chains too long for it
@@ -2623,7 +2627,8 @@ struct HipSchur {
     // (pv.Dl) and R_S^T X_S runs as further rows of the product's K range over the compact arrays pv.Dl, pv.R (dealt to the same
     // wavefronts: schur_gemm_tile).  The step's own back-substitution is corrected for ONE vector (k_back_correct).  Time shards keep the back-correction: their separator sums run over the ranks.
     ncorr = 0;
-    if (!shard && !wide && pv.m > 0 && std::getenv("MVUS_PART_BACK") == nullptr) {
+    n_own_sep = (int)cp.sep.size();
+    if (!wide && pv.m > 0 && std::getenv("MVUS_PART_BACK") == nullptr) {      // (round 6: time shards too -- R_S is the SUMMED reduced right-hand side there, copied beside the in-place solve after the ranks' sum)
       ncorr = 1;
       Dl = be.alloc((size_t)pv.m * pv.s3 * ne.CB);
       pv.Dl = Dl;
@@ -2924,7 +2929,13 @@ struct HipSchur {
       // one rank, cyclic reduction: only the matrix blocks first; the right-hand sides ride beside the one-workgroup tail
       const bool split = overlap_chol && !shard && use_bcr && pv.nt > 0;
       if (pv.nt > 0) hipLaunchKernelGGL(k_part_reduce<BWT>, dim3(pv.nt, split ? 1 : (pv.s3 * ncols + 255) / 256), dim3(256), 0, be.stream, pv, ncols, Lb, Z, split ? 1 : 3);
-      if (shard) be.reduce(sepbuf, sep_count);        // every rank now holds the whole separator system
+      if (shard) {
+        be.reduce(sepbuf, sep_count);        // every rank now holds the whole separator system
+        // (no back-correction: the Schur product needs the reduced right-hand sides R_S as they are BEFORE the in-place solve -- on one rank
+        // part_reduce_rhs writes them to pv.Dl as it forms them, here they exist only after the sum)
+        if (ncorr > 0) MVUS_HIP(hipMemcpy2DAsync(pv.Dl, (size_t)ne.CB * sizeof(double), pv.R, (size_t)ncols * sizeof(double), (size_t)ne.CB * sizeof(double),
+                                                 (size_t)pv.m * pv.s3, hipMemcpyDeviceToDevice, be.stream));
+      }
       if (use_bcr) {
         int h = 1;                                        // wide levels: one launch for all of them (or a launch each); the rest in one workgroup
         {
@@ -2981,8 +2992,11 @@ struct HipSchur {
     {
       const int nbk = (ne.CB + kGemmT - 1) / kGemmT;
       const bool corr = !wide && ncorr > 0;
+      // the separators whose R_S^T X_S this rank adds: all of them, or -- time shard -- its own (global numbers q_off ...)
+      const int cq0 = shard ? pv.q_off : 0, cqn = shard ? n_own_sep : pv.m;
       hipLaunchKernelGGL(k_schur_gemm, dim3(8 * (nbk * (nbk + 1) / 2 + nbk) * ((nslab + 7) / 8)), dim3(256), 0, be.stream, ne, ncols, row_lo, row_hi, nslab, ne.Et, Z, G,
-                         corr ? (const double*)pv.Dl : (const double*)nullptr, (const double*)pv.R, corr ? pv.m * pv.s3 : 0);
+                         corr ? (const double*)(pv.Dl + (size_t)cq0 * pv.s3 * ne.CB) : (const double*)nullptr, (const double*)(pv.R + (size_t)cq0 * pv.s3 * ncols),
+                         corr ? cqn * pv.s3 : 0);
     }
     const int ntile = (ne.CB + kNB - 1) / kNB;
     const double* Gsum = G;

@@ -65,3 +65,12 @@ def ground_truth_x(oprob, name):
     from oracle import ba_oracle as orc
     tr = golden_cases.make(name).truth
     return orc.pack_x(oprob, tr['alpha'], tr['beta'], tr['rs'], tr['cameras'], [t[1] for t in tr['tck']])
+
+
+def reference_spread_10(name):
+    """The REAL reference's own spread of its unconverged 10-evaluation BAs under last-place noise on the residuals
+    (tests/golden/make_golden_ensemble10.py): relative cost, RMSE [px] and inlier-mask flips of the first BA (`ba10`), relative cost and
+    RMSE of the second (`ba2_10`)."""
+    e = dict(np.load(os.path.join(GOLDEN_DIR, 'ens10_' + name + '.npz'), allow_pickle=False))
+    return {'ba10': dict(cost=float(e['ba10_spread_cost_rel']), rmse=float(e['ba10_spread_rmse']), flips=int(e['ba10_spread_flips'])),
+            'ba2_10': dict(cost=float(e['ba2_10_spread_cost_rel']), rmse=float(e['ba2_10_spread_rmse']))}

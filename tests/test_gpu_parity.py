@@ -353,9 +353,21 @@ def test_fd_jacobian_gpu_vs_host_and_scipy(BAHandle, name):
     assert not D[A.toarray() == 0].any()                      # nothing outside the reference pattern
 
 
+@pytest.mark.parametrize('passes', ['two', 'one'])
 @pytest.mark.parametrize('name', CASES)
-def test_fd_mode_ba_vs_reference_result(BAHandle, name):
-    """The reference's own algorithm end to end on the GPU (scipy TRF + LSMR + grouped 2-point differences)."""
+def test_fd_mode_ba_vs_reference_result(BAHandle, name, passes, monkeypatch):
+    """The reference's own algorithm end to end on the GPU (scipy TRF + LSMR + grouped 2-point differences), at the point every real
+    call returns: max_iter = 10 (Scene.BA's default, common.py:441; main.py:49).  The unconverged iterate is chaotic in the last bits
+    of LSMR's sums, for the reference as for anybody else -- so the bars are THE REFERENCE'S OWN: its 10-evaluation BA re-run with one
+    unit in the last place of noise on the residuals (tests/golden/ens10_<case>.npz, 16 members) moves by `spread` in cost, RMSE and
+    inlier-mask flips, and the GPU is held to SPREAD_FACTOR x that (round 6; rounds 1-5 used multiples of the GPU's own deviations).
+    passes = 'one': LSMR with ONE pass over J per iteration (MVUS_LSMR_ONE_PASS=1) -- inside the bars on three scenes, outside on
+    dist_fixed_2cam (cost 3.1e-3 against 3 x 4.8e-4, 14 flips against 3 x 1): that is why it is opt-in, and this test keeps the verdict."""
+    from golden_util import reference_spread_10
+    if passes == 'one':
+        monkeypatch.setenv('MVUS_LSMR_ONE_PASS', '1')
+    else:
+        monkeypatch.delenv('MVUS_LSMR_ONE_PASS', raising=False)
     scene, g = load_case(name)
     prob, _ = mp.problem_from_scene(scene)
     oprob, _ = orc.problem_from_scene(scene)
@@ -363,24 +375,21 @@ def test_fd_mode_ba_vs_reference_result(BAHandle, name):
         r = h.solve(g['x0'], solver=_lib.SOLVER_TRF_LSMR, jac_mode=_lib.JAC_FD, max_nfev=10, matrix=golden_matrix(g))
         keep = h.outlier_mask(r.x, float(g['thres_outlier']))
     assert r.nfev == int(g['ba10_nfev'])
-    # same algorithm, same matrix: what is left is the rounding order of LSMR's products (tests/test_fd_mode_host.py has
-    # the host-build numbers; the calib+KE+bounds iterate is the one the reference itself does not reproduce)
-    loose = name == 'calib_KE_bounds_3cam'
+    sp = reference_spread_10(name)['ba10']
     d_cost = abs(r.cost - float(g['ba10_cost'])) / float(g['ba10_cost'])
     d_rmse = abs(orc.reprojection_rmse(oprob, r.x) - float(g['ba10_rmse']))
     flips = int(np.sum(keep.astype(np.uint8) != g['outlier_keep']))
-    print('FD 10 evaluations %s: cost rel %.2e, rmse %.2e px, %d mask flips' % (name, d_cost, d_rmse, flips))
-    # The unconverged 10-evaluation iterate is chaotic in the last bits of LSMR's sums (run to run it is reproducible here:
-    # J^T u is summed in a fixed order, k_jtu_partial / k_jtu_reduce).  Measured on MI355X: cost 2e-5 / 1e-5 / 1.5e-3 / 4e-4
-    # relative, RMSE 2e-4 / 2e-5 / 9e-3 / 1e-2 px, 13 / 0 / 29 / 1 mask flips of 1000-2200 detections; with atomics in
-    # J^T u (round 1) the same quantities moved by that much from run to run.  The decidable comparison is the converged one.
-    # bars = those measured values x ~3 (the iterate is deterministic on the GPU; the margin is for changes of summation order)
-    cost_tol = {'c1_pinhole_2cam': 1e-4, 'rs_F_2int_3cam': 5e-5, 'calib_KE_bounds_3cam': 5e-3, 'dist_fixed_2cam': 1.5e-3}[name]
-    rmse_tol = {'c1_pinhole_2cam': 1e-3, 'rs_F_2int_3cam': 1e-4, 'calib_KE_bounds_3cam': 3e-2, 'dist_fixed_2cam': 3e-2}[name]
-    flip_tol = {'c1_pinhole_2cam': 30, 'rs_F_2int_3cam': 2, 'calib_KE_bounds_3cam': 60, 'dist_fixed_2cam': 4}[name]
-    assert d_cost < cost_tol
-    assert d_rmse < rmse_tol
-    assert flips <= flip_tol, flips
+    print('FD 10 evaluations (%s-pass LSMR) %s: cost rel %.2e (reference spread %.2e), rmse %.2e px (%.2e), %d mask flips (%d)'
+          % (passes, name, d_cost, sp['cost'], d_rmse, sp['rmse'], flips, sp['flips']))
+    inside = d_cost <= SPREAD_FACTOR * sp['cost'] and d_rmse <= SPREAD_FACTOR * sp['rmse'] and flips <= SPREAD_FACTOR * sp['flips']
+    if passes == 'one' and name == 'dist_fixed_2cam':
+        # the one place the one-pass arithmetic leaves the reference's own bars: recorded, not hidden (and the reason it is opt-in);
+        # should a change of the kernels bring it inside, this assertion says so and the default can be reconsidered
+        assert not inside, 'one-pass LSMR is now inside the reference-derived bars on every fixture: reconsider the default'
+        return
+    assert d_cost <= SPREAD_FACTOR * sp['cost']
+    assert d_rmse <= SPREAD_FACTOR * sp['rmse']
+    assert flips <= SPREAD_FACTOR * sp['flips'], flips
 
 
 @pytest.mark.parametrize('passes', ['two', 'one'])

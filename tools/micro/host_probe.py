@@ -1,5 +1,5 @@
 import os, sys, time
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, '' + os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))) + '')
 import torch, numpy as np
 from mvus_amd import ba, problem as mp, synth, _lib
 sc = synth.baseline_scene(2)
