@@ -716,15 +716,21 @@ struct HipBackend {
   double* lsmr_pu = nullptr;               // per-workgroup partials of |u'|^2 of the one-pass form (k_jvjtu)
   size_t lsmr_pu_cap = 0;
   bool lsmr_on_device() const { return !allreduce && std::getenv("MVUS_LSMR_HOST") == nullptr; }
-  void lsmr_iterations(LsmrScalars& sc, double* ut, double* tm, double* v, double* tn, double* h, double* hbar, double* x) {
+  bool lsmr_scaled_on_device() const { return std::getenv("MVUS_LSMR_BOUNDED_HOST") == nullptr; }      // (A/B: the bounded problem on the host-driven loop, rounds 3-5)
+  // D, E: the column scaling and the extra diagonal rows of the bounded problem (trf_bounds), device n-vectors or null; ub: the n extra rows of u
+  void lsmr_iterations(LsmrScalars& sc, double* ut, double* tm, double* v, double* tn, double* h, double* hbar, double* x,
+                       const double* D = nullptr, const double* E = nullptr, double* ub = nullptr) {
     if (!lsmr_state) {
       lsmr_state = dalloc<LsmrScalars>(2);
-      lsmr_part = dalloc<double>(3 * 2048 + 8);
+      lsmr_part = dalloc<double>(4 * 2048 + 8);      // u.u, v.v, x.x, (ub.ub) partials + beta
       MVUS_HIP(hipHostMalloc(reinterpret_cast<void**>(&lsmr_host), sizeof(LsmrScalars), hipHostMallocDefault));
     }
     const long long n = hp.n, m = hp.m;
     const int gm = grid_for(m), gn = grid_for(n);
-    double *pu = lsmr_part, *pv = lsmr_part + 2048, *px = lsmr_part + 4096, *beta_dev = lsmr_part + 6144;
+    double *pu = lsmr_part, *pv = lsmr_part + 2048, *px = lsmr_part + 4096, *pub = lsmr_part + 6144, *beta_dev = lsmr_part + 8192;
+    const bool scaled = D != nullptr || E != nullptr;
+    double* dv = nullptr;                                   // D v (the scaled problem's argument of J)
+    if (D) dv = alloc(n);
     *lsmr_host = sc;
     MVUS_HIP(hipMemcpyAsync(lsmr_state, lsmr_host, sizeof(LsmrScalars), hipMemcpyHostToDevice, stream));
     int cur = 0;
@@ -734,7 +740,7 @@ struct HipBackend {
     // MVUS_LSMR_ONE_PASS=1: one pass over J per iteration (k_jvjtu: u kept unnormalised, its norm in *ubeta).  Opt-in: the converged
     // answers stay inside the parity bars either way, but the unconverged 10-evaluation iterate of one fixture (dist_fixed_2cam) moves
     // outside the bars measured with the two-pass arithmetic
-    const bool one_pass = dp.n_chunks > 0 && std::getenv("MVUS_LSMR_ONE_PASS") != nullptr;
+    const bool one_pass = dp.n_chunks > 0 && !scaled && std::getenv("MVUS_LSMR_ONE_PASS") != nullptr;
     const unsigned gj = (unsigned)(xcd_grid(dp.n_chunks) + (hp.T > 0 ? (hp.T + kThreads - 1) / kThreads : 0));
     double* ubeta = beta_dev + 1;
     if (one_pass) {
@@ -757,6 +763,18 @@ struct HipBackend {
           if (hp.calib) hipLaunchKernelGGL(k_jtu_reduce<30>, g2, bt, 0, stream, dp, zc, zs, zg0, zfill, mJ, mctrl, ut + 2 * hp.M, motion, tn, jt_first, jt_bounds);
           else hipLaunchKernelGGL(k_jtu_reduce<21>, g2, bt, 0, stream, dp, zc, zs, zg0, zfill, mJ, mctrl, ut + 2 * hp.M, motion, tn, jt_first, jt_bounds);
           hipLaunchKernelGGL(k_lsmr_v1, dim3(gn), dim3(kThreads), 0, stream, n, tn, v, c, (int)gj, lsmr_pu, beta_dev, ubeta, pv);
+        } else if (scaled) {
+        // the bounded problem: A = [J diag(D); diag(E)] -- the host-driven loop's operations (Lsmr::run), launch for launch without its
+        // three synchronisations per iteration
+        if (D) { hipLaunchKernelGGL(k_lsmr_scale, dim3(gn), dim3(kThreads), 0, stream, n, D, (const double*)v, dv, c); jv(dv, tm); }
+        else jv(v, tm);
+        hipLaunchKernelGGL(k_lsmr_u, dim3(gm), dim3(kThreads), 0, stream, m, tm, ut, c, pu);
+        if (E) {
+          hipLaunchKernelGGL(k_lsmr_ub, dim3(gn), dim3(kThreads), 0, stream, n, E, (const double*)v, ub, c, pub);
+          hipLaunchKernelGGL(k_lsmr_unorm2, dim3(gm), dim3(kThreads), 0, stream, m, ut, gm, pu, n, ub, gn, pub, c, beta_dev);
+        } else hipLaunchKernelGGL(k_lsmr_unorm, dim3(gm), dim3(kThreads), 0, stream, m, ut, gm, pu, c, beta_dev);
+        jtu_local(ut, tn, true, launched > 0, launched == 0);
+        hipLaunchKernelGGL(k_lsmr_v_de, dim3(gn), dim3(kThreads), 0, stream, n, tn, v, D, E, (const double*)ub, c, beta_dev, pv);
         } else {
         jv(v, tm);
         hipLaunchKernelGGL(k_lsmr_u, dim3(gm), dim3(kThreads), 0, stream, m, tm, ut, c, pu);
@@ -774,6 +792,7 @@ struct HipBackend {
       if (lsmr_host->istop != 0 || launched >= sc.maxiter) break;
     }
     sc = *lsmr_host;
+    if (dv) release(dv);
     touch(v); touch(x); touch(h); touch(hbar);
   }
 };

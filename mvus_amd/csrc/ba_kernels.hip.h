@@ -1016,6 +1016,68 @@ __global__ __launch_bounds__(kThreads) void k_lsmr_unorm(long long m, double* __
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < m; i += (long long)gridDim.x * blockDim.x)
     ut[i] = a * ut[i] + b * ut[i];
 }
+// ---- the bounded problem (trf_bounds: A = [J diag(D); diag(E)], ba_solver.h Lsmr::run) on the device-resident iteration, round 6.  Each
+// kernel evaluates the host-driven loop's elementwise operations in the same order and with the same roundings (mul: one product;
+// axpby: a x + b y), so the iterates are that loop's bits.
+// out = D v  (the argument of J in A v = J (D v))
+__global__ __launch_bounds__(kThreads) void k_lsmr_scale(long long n, const double* __restrict__ D, const double* __restrict__ v, double* __restrict__ out,
+                                                         const LsmrScalars* __restrict__ cur) {
+  if (cur->istop != 0) return;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) out[i] = D[i] * v[i];
+}
+// the n extra rows of u: ub = E v - alpha ub, partial sums of ub.ub (k_dot_partial's tree over grid_for(n) workgroups)
+__global__ __launch_bounds__(kThreads) void k_lsmr_ub(long long n, const double* __restrict__ E, const double* __restrict__ v, double* __restrict__ ub,
+                                                      const LsmrScalars* __restrict__ cur, double* __restrict__ partials) {
+  if (cur->istop != 0) return;
+  const double a = cur->one, b = -cur->alpha;
+  double s = 0.0;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const double t = E[i] * v[i];
+    const double u = a * t + b * ub[i];
+    ub[i] = u;
+    s += u * u;
+  }
+  dot_partial_store(s, partials);
+}
+// beta = sqrt(|u_top|^2 + |u_bottom|^2); both parts divided by it
+__global__ __launch_bounds__(kThreads) void k_lsmr_unorm2(long long m, double* __restrict__ ut, int nb, const double* __restrict__ partials, long long n,
+                                                          double* __restrict__ ub, int nb2, const double* __restrict__ partials2,
+                                                          const LsmrScalars* __restrict__ cur, double* __restrict__ beta_out) {
+  if (cur->istop != 0) return;
+  double bsq = dot_final_block(nb, partials);
+  bsq += dot_final_block(nb2, partials2);
+  const double beta = sqrt(bsq);
+  if (blockIdx.x == 0 && threadIdx.x == 0) *beta_out = beta;
+  if (!(beta > 0)) return;
+  const double a = 1.0 / beta, b = cur->zero;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < m; i += (long long)gridDim.x * blockDim.x)
+    ut[i] = a * ut[i] + b * ut[i];
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    ub[i] = a * ub[i] + b * ub[i];
+}
+// v = D (J^T u_top) - beta v + E u_bottom, partial sums of v.v; tn is cleared as it is consumed (D / E / ub may be null: factor 1 / no rows)
+__global__ __launch_bounds__(kThreads) void k_lsmr_v_de(long long n, double* __restrict__ tn, double* __restrict__ v, const double* __restrict__ D,
+                                                        const double* __restrict__ E, const double* __restrict__ ub, const LsmrScalars* __restrict__ cur,
+                                                        const double* __restrict__ beta_in, double* __restrict__ partials) {
+  const double beta = *beta_in;
+  if (cur->istop != 0 || !(beta > 0)) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) tn[i] = 0.0;
+    if (cur->istop == 0 && threadIdx.x == 0) partials[blockIdx.x] = 0.0;
+    return;
+  }
+  const double a = cur->one, b = -beta;
+  double s = 0.0;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    double t = tn[i];
+    if (D != nullptr) t = D[i] * t;
+    double w = a * t + b * v[i];
+    if (E != nullptr) { const double e = E[i] * ub[i]; w = a * w + a * e; }
+    tn[i] = 0.0;
+    v[i] = w;
+    s += w * w;
+  }
+  dot_partial_store(s, partials);
+}
 // v = A^T u - beta v (A^T u is in tn), partial sums of v.v
 // (tn is cleared as it is consumed: the next J^T u adds into it without a memset of its own)
 __global__ __launch_bounds__(kThreads) void k_lsmr_v(long long n, double* __restrict__ tn, double* __restrict__ v,

@@ -425,8 +425,8 @@ struct Lsmr {
     if constexpr (B::kDeviceLsmr) {
       // the HIP backend keeps the scalars on the device and runs batches of iterations without a host round trip
       // (three synchronisations and ~17 launches per iteration otherwise); same kernels' arithmetic, same bits
-      if (!D && !E && !trace && be.lsmr_on_device()) {
-        be.lsmr_iterations(sc, ut, tm, v, tn, h, hbar, x);
+      if (!trace && be.lsmr_on_device() && (!(D || E) || be.lsmr_scaled_on_device())) {
+        be.lsmr_iterations(sc, ut, tm, v, tn, h, hbar, x, D, E, ub);
         if (itn_out) *itn_out = (int)sc.itn;
         return sc.istop;
       }

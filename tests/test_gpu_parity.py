@@ -577,3 +577,28 @@ def test_chunk_orders_cover_every_chunk(BAHandle, total_obs):
             np.testing.assert_allclose(JTu, D_ref.T @ u, rtol=1e-10, atol=1e-10 * np.abs(JTu).max())
         r = h.solve(x0, solver=_lib.SOLVER_LM_SCHUR, jac_mode=_lib.JAC_ANALYTIC, max_nfev=4)
         assert r.cost < r.initial_cost
+
+
+@pytest.mark.parametrize('name,jac', [('calib_KE_bounds_3cam', 'fd'), ('calib_KE_bounds_3cam', 'pattern'), (CALIB_WP, 'pattern')])
+def test_bounded_lsmr_on_the_device_is_the_host_driven_loop(BAHandle, name, jac, monkeypatch):
+    """Round 6: the LSMR iteration of the BOUNDED problem (rs_bounds: scipy's trf_bounds works on A = [J diag(D); diag(E)], common.py:654-670)
+    runs device resident like the unbounded one -- column scaling, the n extra rows of u and the scalar recurrences in kernels, batches
+    of eight iterations without a host round trip -- instead of three synchronisations and ~17 launches per iteration.  Same operations
+    in the same order: the iterates are the host-driven loop's (MVUS_LSMR_BOUNDED_HOST=1) bit for bit."""
+    scene, g = load_case(name)
+    prob, _ = mp.problem_from_scene(scene)
+    assert prob.rs_bounds
+    jm = _lib.JAC_FD if jac == 'fd' else _lib.JAC_PATTERN
+
+    def run():
+        with BAHandle(prob) as h:
+            return h.solve(g['x0'], solver=_lib.SOLVER_TRF_LSMR, jac_mode=jm, max_nfev=8, matrix=golden_matrix(g))
+
+    monkeypatch.delenv('MVUS_LSMR_BOUNDED_HOST', raising=False)
+    dev = run()
+    monkeypatch.setenv('MVUS_LSMR_BOUNDED_HOST', '1')
+    host = run()
+    print('%s %s: %d LSMR iterations in %d evaluations, %.1f ms (device) against %.1f ms (host-driven)' % (name, jac, dev.lin_iters, dev.nfev, dev.solve_ms, host.solve_ms))
+    assert (dev.nfev, dev.status, dev.lin_iters) == (host.nfev, host.status, host.lin_iters)
+    assert dev.cost == host.cost and np.array_equal(dev.x, host.x)
+    assert dev.cost < dev.initial_cost

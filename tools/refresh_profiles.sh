@@ -5,7 +5,7 @@
 # the program after `--` is python3 itself (no wrapper that re-execs).
 set -x
 export TMPDIR=/tmp
-R=${1:-r05}
+R=${1:-r06}
 O=gpurun_out/refresh; mkdir -p $O
 python bench.py --steps 20 --warmup 5 > $O/${R}_bench_config2_lm.json 2> $O/bench_config2_lm.err
 python bench.py --solver trf --steps 5 --warmup 1 --no-cpu-baseline --no-parity-solver > $O/${R}_bench_config2_trf.json 2>> $O/bench.err
@@ -54,8 +54,8 @@ bash tools/micro/pmc_gemm.sh 2 > $O/${R}_schur_gemm_counters_config2.txt 2>&1
 python3 tools/incremental_loop.py --solver trf --obs 20000 --cpu-all 2>&1 | grep -v "^Number\|^Doing\|^$\|amdgpu" > $O/${R}_loop_oracle_clock_every_ba.txt
 python3 tools/incremental_loop.py --solver trf --obs 20000 --cpu-all --motion-weights 1e4 2>&1 | grep -v "^Number\|^Doing\|^$\|amdgpu" > $O/${R}_loop_oracle_clock_every_ba_mw1e4.txt
 for seed in 1 2 3; do echo "== seed $seed trf motion_weights 1e4"; python3 tools/incremental_loop.py --solver trf --motion-weights 1e4 --seed $seed 2>&1 | grep -v "^Number\|^Doing\|^$\|amdgpu" | tail -9; done > $O/${R}_loop_motion_weights_1e4.txt 2>&1
-# round 5: fp64 issue rates, the reduced solve per configuration (step timeline at configs[1] and [3]), A/B of the two reduced solvers
-/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -o /tmp/fp64_rates tools/micro/fp64_rates.hip 2>/dev/null && /tmp/fp64_rates > $O/${R}_fp64_issue_rates_raw.txt 2>&1
+# round 5/6: fp64 vector / matrix issue and co-issue (aggregate per SIMD), the reduced solve per configuration (step timeline at configs[1] and [3]), A/B of the two reduced solvers
+/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -o /tmp/fp64_coissue tools/micro/fp64_coissue.hip 2>/dev/null && /tmp/fp64_coissue > $O/${R}_fp64_coissue.txt 2>&1
 bash tools/step_timeline.sh 3 > $O/${R}_step_timeline_config3.txt 2>&1
 bash tools/step_timeline.sh 1 > $O/${R}_step_timeline_config1.txt 2>&1
 for c in 1 2 3 4; do for m in ldl gj; do echo "configs[$c] MVUS_RCS=$m: $(MVUS_RCS=$m python3 tools/step_breakdown.py $c 2>&1 | tail -1)"; done; done 2>/dev/null | grep "^configs" > $O/${R}_reduced_solver_ab.txt
@@ -63,3 +63,7 @@ rm -rf $O/stats_lm $O/stats_trf $O/stats_c3 $O/pmc_fetch* $O/pmc_write* $O/pmc_t
 ls -la $O
 # round 5: the band solver's one-rank path against its parts switched off (same box, three repetitions, ms per step: python wall / C++ solve)
 bash tools/band_solver_ab.sh > $O/${R}_band_solver_ab.txt 2>/dev/null
+# round 6: the default solver on BASELINE configs[4] (opt_calib + rs_bounds + KE: the bounded TRF), the LM driver with and without the
+# speculative linearisation / carry-over (python wall, C++ wall, long solve), LM at configs[4] with the sequential driver for reference
+python bench.py --config 4 --solver trf --steps 3 --warmup 1 --no-cpu-baseline --no-parity-solver > $O/${R}_bench_config4_calib_trf.json 2>> $O/bench.err
+( python3 tools/micro/host_probe.py; echo "--- MVUS_NO_SPEC=1 MVUS_LM_NO_CARRY=1 (the sequential driver of rounds 2-5)"; MVUS_NO_SPEC=1 MVUS_LM_NO_CARRY=1 python3 tools/micro/host_probe.py ) 2>&1 | grep -v amdgpu > $O/${R}_lm_driver_spec_ab.txt
