@@ -11,7 +11,7 @@ import json
 d = json.load(open('gpurun_out/quick/bench.json'))
 print('ms/step %.4f  frac %.3f  cost_last %r' % (d['ms_per_step'], d['roofline']['frac'], d.get('cost_last')))
 PY
-rocprofv3 --kernel-trace --stats -d $O/stats -o r -- python3 tools/micro/gj_probe.py > $O/stats.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/stats -o r -- python3 tools/micro/host_probe.py > $O/stats.log 2>&1
 python3 tools/rocprof_summary.py stats $O/stats/r_results.db | cut -c1-70,111-160 > $O/kernel_stats.txt
 rm -rf $O/stats
 head -40 $O/kernel_stats.txt
