@@ -148,7 +148,7 @@ void mvus_default_opts(mvus_solve_opts* opts);
  * binding asserts these against its own struct definitions at load time -- mvus_solve_opts has grown over the rounds (lm_lambda_min,
  * lm_trust_radius) and a stale stub would otherwise hand the library a short buffer.  The version is raised whenever a struct or a
  * prototype of this header changes.  Stateless, no device is touched.  No reference counterpart (the reference has no FFI). */
-#define MVUS_ABI_VERSION 6
+#define MVUS_ABI_VERSION 7
 int32_t mvus_abi_sizes(int32_t* solve_opts_size, int32_t* result_size, int32_t* problem_size);
 
 /* Copies the problem to the GPU, undistorts observations once when calibration is fixed
@@ -272,6 +272,11 @@ int mvus_ba_set_allreduce(mvus_ba* h, mvus_allreduce_fn fn, void* user, int32_t 
  * handle's device.  librccl.so.1 is opened at run time (the copy the process already holds -- e.g. PyTorch's -- else the loader's):
  * the library has no link-time dependency on it and MVUS_E_COMM reports its absence.  Replaces a callback set earlier; is_root as
  * above.  The sums of a given topology are RCCL's: the same bits on every run.  SURVEY 8e's collective; no reference counterpart. */
+/* mvus_rccl_available: MVUS_OK when librccl.so.1 can be opened and its entry points resolved in this process, else MVUS_E_COMM (message:
+ * mvus_last_error(NULL)).  It touches no device and no communicator: a job asks it on EVERY rank and exchanges the answers before any
+ * rank calls mvus_ba_set_rccl -- ncclCommInitRank is itself a blocking collective, and a rank that cannot open RCCL would otherwise
+ * leave the others waiting inside it (mvus_amd/dist.py::agree_on_rccl). */
+int mvus_rccl_available(void);
 int mvus_rccl_unique_id(uint8_t id_out[128]);
 int mvus_ba_set_rccl(mvus_ba* h, const uint8_t id[128], int32_t rank, int32_t world, int32_t is_root);
 /* Measurement hook: `reps` back-to-back sums of `count` doubles (a scratch buffer) through the route installed on the handle (the

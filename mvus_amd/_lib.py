@@ -85,6 +85,7 @@ API = [
     ('mvus_ba_outlier_mask', ctypes.c_int, [ctypes.c_void_p, c_double_p, ctypes.c_double, c_uint8_p]),
     ('mvus_ba_remove_outliers', ctypes.c_int, [ctypes.c_void_p, c_double_p, ctypes.c_double, c_uint8_p, c_int64_p]),
     ('mvus_ba_set_allreduce', ctypes.c_int, [ctypes.c_void_p, ALLREDUCE_FN, ctypes.c_void_p, ctypes.c_int32]),
+    ('mvus_rccl_available', ctypes.c_int, []),
     ('mvus_rccl_unique_id', ctypes.c_int, [c_uint8_p]),
     ('mvus_ba_set_rccl', ctypes.c_int, [ctypes.c_void_p, c_uint8_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
     ('mvus_ba_time_allreduce', ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, c_double_p]),
@@ -136,7 +137,7 @@ def load(path=None):
     return lib
 
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 def check_abi(lib):
@@ -151,6 +152,15 @@ def check_abi(lib):
 
 def dptr(a):
     return a.ctypes.data_as(c_double_p)
+
+
+def rccl_available():
+    """True when the library can open RCCL in this process (mvus_rccl_available: no device, no communicator touched); else raises."""
+    lib = load()
+    rc = lib.mvus_rccl_available()
+    if rc != MVUS_OK:
+        raise RuntimeError('mvus_rccl_available (%d): %s' % (rc, lib.mvus_last_error(None).decode()))
+    return True
 
 
 def rccl_unique_id():

@@ -235,7 +235,7 @@ class BAHandle:
         rc = self.lib.mvus_ba_solve(self.h, _lib.dptr(x), ctypes.byref(o), ctypes.byref(res), _lib.dptr(f) if return_fun else None)
         if rc == _lib.MVUS_E_RESHARD:
             e = ReshardNeeded('mvus_ba_solve: %s' % self.lib.mvus_last_error(self.h).decode())
-            e.x, e.nfev, e.cost = x, int(res.nfev), float(res.cost)
+            e.x, e.nfev, e.cost, e.initial_cost = x, int(res.nfev), float(res.cost), float(res.initial_cost)
             raise e
         self._check(rc, 'mvus_ba_solve')
         return _Result(x=x, cost=res.cost, fun=f, nfev=res.nfev, njev=res.njev, status=res.status,

@@ -1407,6 +1407,12 @@ mvus_ba::~mvus_ba() {
 }
 extern "C" {
 
+int mvus_rccl_available(void) {
+  std::lock_guard<std::mutex> lock(g_rccl_mutex);
+  if (!g_rccl.load()) { g_create_error = g_rccl.err; return MVUS_E_COMM; }
+  return MVUS_OK;
+}
+
 int mvus_rccl_unique_id(uint8_t id_out[128]) {
   if (!id_out) return MVUS_E_INVALID;
   std::lock_guard<std::mutex> lock(g_rccl_mutex);

@@ -49,8 +49,12 @@ def make_gpu_allreduce(device_index, group=None):
     return fn
 
 
-def agree_on_rccl(rank, world, group, get_id, join, leave):
+def agree_on_rccl(rank, world, group, get_id, join, leave, probe=None):
     """The route of the sums is a COLLECTIVE decision: every rank returns the same (ok, reason).
+
+    ``probe()`` (every rank; raises when this rank cannot open RCCL at all) is asked FIRST and the answers are exchanged: ``join`` is
+    ncclCommInitRank, itself a blocking collective -- a rank that cannot even load the library must be found out before anybody
+    enters it, or the others wait there for ever.
 
     ``get_id()`` (rank 0 only) returns the 128-byte RCCL id or raises; ``join(id)`` makes this rank join the library's communicator
     or raises; ``leave()`` tears down a communicator that did initialise.  Protocol, every step a collective of ``group`` that all
@@ -59,6 +63,20 @@ def agree_on_rccl(rank, world, group, get_id, join, leave):
     the ranks that did join leave again and everyone reports failure.  No rank can end up in the native route while another one is
     in the callback route (mismatched collectives = a hang)."""
     import torch.distributed as dist
+    if probe is not None:
+        perr = None
+        try:
+            probe()
+        except Exception as e:
+            perr = '%s: %s' % (type(e).__name__, e)
+        answers = [None] * world
+        if world > 1:
+            dist.all_gather_object(answers, perr, group=group)
+        else:
+            answers[0] = perr
+        missing = [(r, o) for r, o in enumerate(answers) if o is not None]
+        if missing:
+            return False, '; '.join('rank %d cannot open RCCL (%s)' % f for f in missing)
     box = [None]
     if rank == 0:
         try:
@@ -97,7 +115,7 @@ def join_rccl(handle, rank, world, group=None, is_root=None):
     root = (rank == 0) if is_root is None else is_root
     return agree_on_rccl(rank, world, group, _lib.rccl_unique_id,
                          lambda uid: handle.set_rccl(uid, rank, world, is_root=root),
-                         lambda: handle.set_allreduce(None, is_root=root))
+                         lambda: handle.set_allreduce(None, is_root=root), probe=_lib.rccl_available)
 
 
 def sharded_handle(prob, rank, world, device_index, group=None, time_x=None, halo=8, collective='torch'):
@@ -150,22 +168,35 @@ def solve_time_sharded(make_handle, x0, max_nfev=10, max_recuts=4, **solve_kw):
     again at that point and the solve continues with the evaluations that are left -- the reference re-evaluates visibility at every
     call (common.py:317, tools/util.py:90-116); here that costs one shard_time + handle per re-cut, counted in ``result.recuts``."""
     from .ba import ReshardNeeded
+    from .ba import _Result
     x = np.array(x0, dtype=np.float64)
-    left, recuts, used = int(max_nfev), 0, 0
+    left, recuts, used, first_cost = int(max_nfev), 0, 0, None
     while True:
         h = make_handle(x)
         try:
             r = h.solve(x, max_nfev=max(left, 1), **solve_kw)
             r.recuts, r.nfev_total = recuts, used + r.nfev
+            # the caller's view is ONE solve: evaluations over all segments, the cost it started from
+            r.nfev = r.nfev_total
+            if first_cost is not None:
+                r.initial_cost = first_cost
             return r
         except ReshardNeeded as e:
             recuts += 1
             if recuts > max_recuts:
                 raise
             x = np.array(e.x)
+            if first_cost is None:
+                first_cost = getattr(e, 'initial_cost', None)
             # (the evaluation at the start of the next solve repeats the last one of this solve: it is not charged twice)
             used += max(e.nfev - 1, 0)
-            left = max(int(max_nfev) - used, 2)
+            left = int(max_nfev) - used
+            if left < 2:
+                # the evaluation budget is spent: the point reached so far is the answer (status 0, as scipy reports max_nfev) -- no
+                # further segment is forced onto the caller's budget
+                return _Result(x=x, cost=float(e.cost), fun=None, nfev=used + 1, njev=0, status=0, optimality=float('nan'), lin_iters=0,
+                               solve_ms=0.0, initial_cost=first_cost if first_cost is not None else float(e.cost), success=False,
+                               grad=None, jac=None, recuts=recuts, nfev_total=used + 1)
         finally:
             h.close()
 

@@ -206,7 +206,11 @@ def _route_worker(rank, world, port, fail_at, out_dir):
         def leave():
             state['left'] = True
 
-        ok, why = agree_on_rccl(rank, world, None, get_id, join, leave)
+        def probe():                                   # (mvus_rccl_available: this rank cannot even open the library)
+            if fail_at == 'probe%d' % rank:
+                raise OSError('librccl.so.1 cannot be opened on this rank (injected)')
+
+        ok, why = agree_on_rccl(rank, world, None, get_id, join, leave, probe=probe)
         total = _sum(np.array([1.0 + rank]))          # the route both ranks fell back to: must not hang
         np.save(os.path.join(out_dir, 'route%d.npy' % rank),
                 np.array([float(ok), float(state['joined']), float(state['left']), float(total[0])]))
@@ -217,7 +221,7 @@ def _route_worker(rank, world, port, fail_at, out_dir):
 
 
 @pytest.mark.timeout(120)
-@pytest.mark.parametrize('fail_at', ['none', 'id', 'join0', 'join1'])
+@pytest.mark.parametrize('fail_at', ['none', 'id', 'join0', 'join1', 'probe1'])
 def test_rccl_route_is_a_collective_decision(tmp_path, fail_at):
     """collective='auto' (mvus_amd/dist.py): a librccl the library cannot open on rank 0 only, or a communicator that fails to
     initialise on one rank only, must send BOTH ranks to the callback route -- not one rank into its first all_reduce while the
@@ -235,6 +239,9 @@ def test_rccl_route_is_a_collective_decision(tmp_path, fail_at):
             assert joined == 1.0 and left == 0.0
         elif fail_at == 'id':
             assert joined == 0.0 and left == 0.0 and 'rank 0 could not get an RCCL id' in why[k]
+        elif fail_at.startswith('probe'):
+            # a rank that cannot open RCCL at all is found out BEFORE anybody enters the (blocking, collective) join: nobody joined
+            assert joined == 0.0 and left == 0.0 and 'rank 1 cannot open RCCL' in why[k]
         else:
             failing = int(fail_at[-1])
             assert joined == (0.0 if k == failing else 1.0) and left == joined        # who joined has left again
