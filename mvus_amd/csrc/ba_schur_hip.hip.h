@@ -1750,6 +1750,109 @@ __global__ __launch_bounds__(256) void k_sep_bcr_rhs(PartView pv, int ncols) {
   }
 }
 
+// ---- time shards, round 6: TWO-LEVEL elimination of the separators ------------------------------------------------------------------
+// Rank r's chain of separators is  [ghost G = the cut closing rank r-1]  s_1 .. s_k  [cut K closing rank r]  (global numbers q0-1, q0 ..
+// q0+k-1, q0+k; no ghost on the first rank, no cut on the last).  k_part_reduce has left every block of it in the globally numbered
+// [T | U | R]: T_q, U_q = T(q, q+1), the reduced right-hand sides R_q -- of G only the part interior 0 contributes, of K only the part
+// the last interior contributes.  Rounds 3-5 summed the WHOLE system over the ranks (3.4 MB at configs[3]) and every rank solved all m
+// separators.  Here the local separators L = {s_1 .. s_k} are a second-level interior:
+//     L [Y | V | W] = [R_L | C_LG | C_LK]      the rank's own block-tridiagonal system, solved by the cyclic reduction as it is, on a
+//                                               right-hand side with 2 s3 extra columns (C_LG = U_G^T in s_1's rows, C_LK = U_{s_k} in s_k's)
+//     T'_G += T_G - U_G V_1      U'_G (= T'(G,K)) += -U_G W_1      R'_G += R_G - U_G Y_1            (subscript: the node's rows of Y, V, W)
+//     T'_K += T_K - U_{s_k}^T W_k                                  R'_K += R_K - U_{s_k}^T Y_k
+// the (world - 1)-node cut system [T' | U' | R'] is what the ranks sum (0.3 MB), every rank solves it (k_sep_factor, k_sep_rhs), and
+//     X_L = Y - V X_G - W X_K
+// goes into the globally numbered R beside X_G and X_K: k_back_correct, k_part_back and the Schur product's correction rows read it there
+// as before.  The correction term of a cut separator splits by itself: rank r adds (its part of R_K)^T X_K, rank r+1 (its part)^T X_K.
+template <int S3>
+__global__ __launch_bounds__(256) void k_sep2_build(PartView pv, int q0, int k, int has_ghost, int has_cut, int ncols, double* __restrict__ Rloc,
+                                                    double* __restrict__ CG, double* __restrict__ CK) {
+  constexpr int SS = S3 * S3;
+  const int nc2 = ncols + 2 * S3;
+  const long long total = (long long)k * S3 * nc2;
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total + 2 * SS; e += (long long)gridDim.x * blockDim.x) {
+    if (e >= total) {                                   // the two coupling blocks, saved: the cyclic reduction overwrites U of its last node
+      const int t = (int)(e - total), which = t / SS, idx = t % SS;
+      if (which == 0) CG[idx] = has_ghost ? pv.U[(long long)(q0 - 1) * SS + idx] : 0.0;
+      else CK[idx] = (has_cut && k > 0) ? pv.U[(long long)(q0 + k - 1) * SS + idx] : 0.0;
+      continue;
+    }
+    const int col = (int)(e % nc2), a = (int)((e / nc2) % S3), j = (int)(e / ((long long)nc2 * S3));
+    double v = 0.0;
+    if (col < ncols) v = pv.R[((long long)(q0 + j) * S3 + a) * ncols + col];
+    else if (col < ncols + S3) { if (j == 0 && has_ghost) v = pv.U[(long long)(q0 - 1) * SS + (col - ncols) * S3 + a]; }            // U_G^T
+    else if (j == k - 1 && has_cut) v = pv.U[(long long)(q0 + k - 1) * SS + a * S3 + (col - ncols - S3)];                          // U_{s_k}
+    Rloc[e] = v;
+  }
+}
+// the rank's contribution to the cut system (cut node c closes rank c: G = node rank - 1, K = node rank); cutbuf = [T' | U' | R'] zeroed
+template <int S3>
+__global__ __launch_bounds__(256) void k_sep2_reduce(PartView pv, int q0, int k, int has_ghost, int has_cut, int rank, int ncut, int ncols,
+                                                     const double* __restrict__ Rloc, const double* __restrict__ CG, const double* __restrict__ CK,
+                                                     double* __restrict__ cutbuf) {
+  constexpr int SS = S3 * S3;
+  const int nc2 = ncols + 2 * S3;
+  double* T2 = cutbuf;
+  double* U2 = cutbuf + (long long)ncut * SS;
+  double* R2 = cutbuf + 2LL * ncut * SS;
+  const int per = 2 * SS + S3 * ncols;                  // outputs of one side: T' (SS), U' (SS, ghost side only), R' (S3 ncols)
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < 2 * per; e += gridDim.x * blockDim.x) {
+    const int side = e / per, o = e % per;              // 0: the ghost G, 1: the cut K
+    if (side == 0 ? !has_ghost : !has_cut) continue;
+    const int node = side == 0 ? rank - 1 : rank;
+    const long long gq = side == 0 ? q0 - 1 : q0 + k;
+    if (o < SS) {                                       // T'
+      const int a = o / S3, b = o % S3;
+      double v = pv.T[gq * SS + o];
+      if (k > 0) {
+        if (side == 0) { for (int c = 0; c < S3; ++c) v -= CG[a * S3 + c] * Rloc[((long long)(0) * S3 + c) * nc2 + ncols + b]; }                   // U_G V_1
+        else { for (int c = 0; c < S3; ++c) v -= CK[c * S3 + a] * Rloc[((long long)(k - 1) * S3 + c) * nc2 + ncols + S3 + b]; }                    // U_{s_k}^T W_k
+      }
+      T2[(long long)node * SS + o] = v;
+    } else if (o < 2 * SS) {                            // U' = T'(G, K): through the local chain, or -- no local separator -- the direct coupling
+      if (side != 0 || !has_cut) continue;
+      const int oo = o - SS, a = oo / S3, b = oo % S3;
+      double v = 0.0;
+      if (k > 0) { for (int c = 0; c < S3; ++c) v -= CG[a * S3 + c] * Rloc[((long long)(0) * S3 + c) * nc2 + ncols + S3 + b]; }                    // -U_G W_1
+      else v = pv.U[gq * SS + oo];
+      U2[(long long)node * SS + oo] = v;
+    } else {                                            // R'
+      const int oo = o - 2 * SS, a = oo / ncols, col = oo % ncols;
+      double v = pv.R[(gq * S3 + a) * ncols + col];
+      if (k > 0) {
+        if (side == 0) { for (int c = 0; c < S3; ++c) v -= CG[a * S3 + c] * Rloc[((long long)(0) * S3 + c) * nc2 + col]; }
+        else { for (int c = 0; c < S3; ++c) v -= CK[c * S3 + a] * Rloc[((long long)(k - 1) * S3 + c) * nc2 + col]; }
+      }
+      R2[((long long)node * S3 + a) * ncols + col] = v;
+    }
+  }
+}
+// X_L = Y - V X_G - W X_K and the two cut solutions, into the globally numbered R
+template <int S3>
+__global__ __launch_bounds__(256) void k_sep2_finish(PartView pv, int q0, int k, int has_ghost, int has_cut, int rank, int ncut, int ncols,
+                                                     const double* __restrict__ Rloc, const double* __restrict__ cutbuf) {
+  constexpr int SS = S3 * S3;
+  const int nc2 = ncols + 2 * S3;
+  const double* X2 = cutbuf + 2LL * ncut * SS;          // the solved cut system
+  const long long total = (long long)(k + 2) * S3 * ncols;
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const int col = (int)(e % ncols), a = (int)((e / ncols) % S3), j = (int)(e / ((long long)ncols * S3));
+    if (j >= k) {                                       // j = k: X_G, j = k + 1: X_K
+      const bool g = j == k;
+      if (g ? !has_ghost : !has_cut) continue;
+      const int node = g ? rank - 1 : rank;
+      const long long gq = g ? q0 - 1 : q0 + k;
+      pv.R[(gq * S3 + a) * ncols + col] = X2[((long long)node * S3 + a) * ncols + col];
+      continue;
+    }
+    const double* row = Rloc + ((long long)j * S3 + a) * nc2;
+    double v = row[col];
+    if (has_ghost) for (int b = 0; b < S3; ++b) v -= row[ncols + b] * X2[((long long)(rank - 1) * S3 + b) * ncols + col];
+    if (has_cut) for (int b = 0; b < S3; ++b) v -= row[ncols + S3 + b] * X2[((long long)rank * S3 + b) * ncols + col];
+    pv.R[((long long)(q0 + j) * S3 + a) * ncols + col] = v;
+  }
+}
+
 // interiors: X = Y - V X_{S_{p-1}} - W X_{S_p}.  One thread per right-hand-side column: the 2*S3 separator values of
 // its column stay in registers, the rows of V|W are the same for every lane (scalar loads), so each interior entry
 // costs one coalesced load, 2*S3 FMAs and one store.
@@ -2436,6 +2539,12 @@ struct HipSchur {
   int nslab = 1;            // K-slabs of the Schur product (partial sums in G): HipSchur::plan_gemm
   int ncorr = 0;            // 1: the product carries the separators' correction term and the interiors are NOT back-corrected
   int n_own_sep = 0;        // separators of this slice (a time shard adds the correction rows of ITS separators: every separator once over the ranks)
+  // time shards, round 6: two-level elimination of the separators (k_sep2_*): the local ones by this rank alone, the world - 1 cut separators summed
+  bool two_level = false;
+  int k_loc = 0, has_ghost = 0, has_cut = 0, ncut = 0;
+  double *Rloc = nullptr, *CGK = nullptr, *cutbuf = nullptr;
+  size_t cut_count = 0, bcr_lds_loc = 0;
+  int bcr_cols_loc = kBcrCols;
   double* Dl = nullptr;
   int bcr_cols = kBcrCols;
   size_t bcr_lds = 0;       // dynamic LDS of k_sep_bcr_rhs; the sequential separator kernels remain for chains too long for it
@@ -2652,6 +2761,22 @@ struct HipSchur {
     use_bcr = bcr_lds <= 64 * 1024 && !std::getenv("MVUS_SEP_SEQUENTIAL");
     MVUS_HIP(hipMalloc(reinterpret_cast<void**>(&bcr_done), mm * sizeof(unsigned)));
     MVUS_HIP(hipMemsetAsync(bcr_done, 0, mm * sizeof(unsigned), be.stream));
+    if (shard && use_bcr && !wide) {
+      const char* e = std::getenv("MVUS_SEP_TWO_LEVEL");
+      two_level = !(e && std::atoi(e) == 0);
+    }
+    if (two_level) {
+      has_ghost = ts.rank > 0; has_cut = ts.rank + 1 < ts.world; ncut = ts.world - 1;
+      k_loc = n_own_sep - has_cut;
+      const size_t nc2 = (size_t)ncols + 2 * pv.s3;
+      Rloc = be.alloc((size_t)std::max(k_loc, 1) * pv.s3 * nc2);
+      CGK = be.alloc(2 * ss);
+      cut_count = (size_t)ncut * (2 * ss + (size_t)pv.s3 * ncols);
+      cutbuf = be.alloc(cut_count);
+      bcr_cols_loc = kBcrCols;
+      bcr_lds_loc = (size_t)2 * std::max(k_loc, 1) * pv.s3 * bcr_cols_loc * sizeof(double);
+      if (bcr_lds_loc > 64 * 1024) { bcr_cols_loc = 1; bcr_lds_loc /= kBcrCols; }
+    }
     win_prepare();
   }
   // Window-major assembly: needs every camera's frames in non-decreasing order (HostProblem::frames_sorted; anything else keeps the
@@ -2737,7 +2862,7 @@ struct HipSchur {
     else MVUS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_assemble_windows<9>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)win_lds));
   }
   ~HipSchur() {
-    for (double* p : {Dl, NEset[0], NEset[1], Lb, Z, G, G0, S, S2, Linv, rhs, pc, DG, px, pv.VW, sepbuf, pv.U2, pv.Ha, pv.Hc, wv.Apart, rcs.Simg, rcs.Tsc, rcs.x}) if (p) be.release(p);
+    for (double* p : {Rloc, CGK, cutbuf, Dl, NEset[0], NEset[1], Lb, Z, G, G0, S, S2, Linv, rhs, pc, DG, px, pv.VW, sepbuf, pv.U2, pv.Ha, pv.Hc, wv.Apart, rcs.Simg, rcs.Tsc, rcs.x}) if (p) be.release(p);
     if (win_tables) (void)hipFree(win_tables);
     if (part_tables) (void)hipFree(part_tables);
     if (halo_tables) (void)hipFree(halo_tables);
@@ -2929,6 +3054,46 @@ struct HipSchur {
       // one rank, cyclic reduction: only the matrix blocks first; the right-hand sides ride beside the one-workgroup tail
       const bool split = overlap_chol && !shard && use_bcr && pv.nt > 0;
       if (pv.nt > 0) hipLaunchKernelGGL(k_part_reduce<BWT>, dim3(pv.nt, split ? 1 : (pv.s3 * ncols + 255) / 256), dim3(256), 0, be.stream, pv, ncols, Lb, Z, split ? 1 : 3);
+      if (shard && two_level) {
+        // round 6: the local separators are eliminated by this rank alone; only the world - 1 cut separators are summed (k_sep2_* above)
+        const int q0 = pv.q_off, cq0 = q0 - has_ghost, cqn = n_own_sep + has_ghost;
+        // (no back-correction: the correction rows of the Schur product need this rank's parts of the reduced right-hand sides R_S as
+        // they are before the solve overwrites them)
+        if (ncorr > 0) MVUS_HIP(hipMemcpy2DAsync(pv.Dl + (size_t)cq0 * pv.s3 * ne.CB, (size_t)ne.CB * sizeof(double), pv.R + (size_t)cq0 * pv.s3 * ncols,
+                                                 (size_t)ncols * sizeof(double), (size_t)ne.CB * sizeof(double), (size_t)cqn * pv.s3, hipMemcpyDeviceToDevice, be.stream));
+        const int nc2 = ncols + 2 * S3T;
+        double *CG = CGK, *CK = CGK + (size_t)S3T * S3T;
+        {
+          const long long tot = (long long)k_loc * S3T * nc2 + 2 * S3T * S3T;
+          hipLaunchKernelGGL(k_sep2_build<S3T>, dim3((unsigned)std::min<long long>(2048, (tot + 255) / 256)), dim3(256), 0, be.stream, pv, q0, k_loc, has_ghost, has_cut, ncols, Rloc, CG, CK);
+        }
+        if (k_loc > 0) {
+          PartView pl = pv;                  // the local chain: nodes q0 .. q0 + k - 1 of the global arrays, renumbered from 0
+          const size_t ssz = (size_t)S3T * S3T;
+          pl.m = k_loc; pl.T = pv.T + q0 * ssz; pl.U = pv.U + q0 * ssz; pl.U2 = pv.U2 + q0 * ssz; pl.Ha = pv.Ha + q0 * ssz; pl.Hc = pv.Hc + q0 * ssz; pl.R = Rloc;
+          int h = 1;
+          for (; h <= pl.m && pl.m / (2 * h) > kBcrTailNs; h <<= 1)
+            hipLaunchKernelGGL(k_sep_bcr_level<S3T>, dim3(pl.m / (2 * h)), dim3(64), 0, be.stream, pl, h, fail);
+          if (h <= pl.m) hipLaunchKernelGGL(k_sep_bcr_tail<S3T>, dim3(1), dim3(bcr_tail_waves(S3T) * 64), 0, be.stream, pl, h, fail);
+          if (bcr_cols_loc == kBcrCols) hipLaunchKernelGGL((k_sep_bcr_rhs<S3T, kBcrCols>), dim3((nc2 + kBcrCols - 1) / kBcrCols), dim3(256), bcr_lds_loc, be.stream, pl, nc2);
+          else hipLaunchKernelGGL((k_sep_bcr_rhs<S3T, 1>), dim3(nc2), dim3(256), bcr_lds_loc, be.stream, pl, nc2);
+        }
+        MVUS_HIP(hipMemsetAsync(cutbuf, 0, cut_count * sizeof(double), be.stream));
+        hipLaunchKernelGGL(k_sep2_reduce<S3T>, dim3((unsigned)((2 * (2 * S3T * S3T + S3T * ncols) + 255) / 256)), dim3(256), 0, be.stream, pv, q0, k_loc, has_ghost, has_cut,
+                           be.tshard.rank, ncut, ncols, (const double*)Rloc, (const double*)CG, (const double*)CK, cutbuf);
+        be.reduce(cutbuf, cut_count);        // every rank now holds the cut system
+        {
+          PartView pc = pv;
+          pc.m = ncut; pc.T = cutbuf; pc.U = cutbuf + (size_t)ncut * S3T * S3T; pc.R = cutbuf + 2 * (size_t)ncut * S3T * S3T;
+          hipLaunchKernelGGL(k_sep_factor<S3T>, dim3(1), dim3(64), 0, be.stream, pc, fail);
+          hipLaunchKernelGGL(k_sep_rhs<S3T>, dim3((ncols + 63) / 64), dim3(64), 0, be.stream, pc, ncols);
+        }
+        {
+          const long long tot = (long long)(k_loc + 2) * S3T * ncols;
+          hipLaunchKernelGGL(k_sep2_finish<S3T>, dim3((unsigned)std::min<long long>(2048, (tot + 255) / 256)), dim3(256), 0, be.stream, pv, q0, k_loc, has_ghost, has_cut,
+                             be.tshard.rank, ncut, ncols, (const double*)Rloc, (const double*)cutbuf);
+        }
+      } else {
       if (shard) {
         be.reduce(sepbuf, sep_count);        // every rank now holds the whole separator system
         // (no back-correction: the Schur product needs the reduced right-hand sides R_S as they are BEFORE the in-place solve -- on one rank
@@ -2960,6 +3125,7 @@ struct HipSchur {
         hipLaunchKernelGGL(k_sep_factor<S3T>, dim3(1), dim3(64), 0, be.stream, pv, fail);
         hipLaunchKernelGGL(k_sep_rhs<S3T>, dim3((ncols + 63) / 64), dim3(64), 0, be.stream, pv, ncols);
       }
+      }      // (one level: the whole separator system on every rank)
       if (ncorr == 0) {                                   // (one rank: no back-correction -- see where ncorr is set)
         const int gy = (ncols + 63) / 64, gz = (kPartRowsMax + kBackRows - 1) / kBackRows;
         const dim3 gback(xcd_grid(pv.P * gy * gz));
@@ -2993,7 +3159,8 @@ struct HipSchur {
       const int nbk = (ne.CB + kGemmT - 1) / kGemmT;
       const bool corr = !wide && ncorr > 0;
       // the separators whose R_S^T X_S this rank adds: all of them, or -- time shard -- its own (global numbers q_off ...)
-      const int cq0 = shard ? pv.q_off : 0, cqn = shard ? n_own_sep : pv.m;
+      // (two levels: plus the ghost -- the cut separator's correction term splits into the two neighbours' own parts of R_S)
+      const int cq0 = shard ? pv.q_off - (two_level ? has_ghost : 0) : 0, cqn = shard ? n_own_sep + (two_level ? has_ghost : 0) : pv.m;
       hipLaunchKernelGGL(k_schur_gemm, dim3(8 * (nbk * (nbk + 1) / 2 + nbk) * ((nslab + 7) / 8)), dim3(256), 0, be.stream, ne, ncols, row_lo, row_hi, nslab, ne.Et, Z, G,
                          corr ? (const double*)(pv.Dl + (size_t)cq0 * pv.s3 * ne.CB) : (const double*)nullptr, (const double*)(pv.R + (size_t)cq0 * pv.s3 * ncols),
                          corr ? cqn * pv.s3 : 0);
