@@ -201,6 +201,83 @@ def test_time_shards_on_one_gpu_match_unsharded(world, motion):
         assert nbytes[0] / max(1, ref.njev + ref.nfev) < 40 * cross_bytes    # small scene: separator rhs dominates
 
 
+@pytest.mark.parametrize('world,motion', [(3, False), (4, True)])
+def test_two_level_separator_elimination_sums_the_cut_separators_only(world, motion, monkeypatch):
+    """Round 6: on time shards every rank eliminates its LOCAL separators itself (cyclic reduction on its own sub-chain with the two
+    coupling blocks as extra right-hand-side columns) and only the world - 1 cut separators are summed and solved redundantly
+    (k_sep2_build / k_sep2_reduce / k_sep2_finish).  Against the one-level form of rounds 3-5 (MVUS_SEP_TWO_LEVEL=0: the WHOLE separator
+    system summed, every rank solving all of it): the same solve (cost 1e-10, x 1e-8 -- another elimination order of the same system),
+    ranks in lockstep bit for bit, and far fewer bytes through the collective."""
+    import threading
+    import torch
+    from mvus_amd import synth
+    from mvus_amd.ba import BAHandle
+    from mvus_amd.dist import _DeviceDoubles
+    sc = synth.make_scene(3, 9000, seed=43, rolling_shutter=True, num_knots=900, motion_reg=bool(motion), motion_type='F', motion_weights=50.0)
+    prob, x0 = mp.problem_from_scene(sc)
+    opts = _lib.default_opts(_lib.SOLVER_LM_SCHUR, _lib.JAC_ANALYTIC, 5)
+    with BAHandle(prob) as h0:
+        ref = h0.solve(x0, opts=opts)
+
+    def run_world(levels):
+        monkeypatch.setenv('MVUS_SEP_TWO_LEVEL', '1' if levels == 2 else '0')
+        barrier = threading.Barrier(world)
+        bufs, total, results, errors, sizes = [None] * world, [None], [None] * world, [], []
+
+        def make_cb(rank):
+            def cb(ptr, count, stream):
+                t = torch.as_tensor(_DeviceDoubles(ptr, count), device='cuda:0')
+                torch.cuda.synchronize()
+                bufs[rank] = t
+                barrier.wait(60)
+                if rank == 0:
+                    total[0] = torch.stack(bufs).sum(0)
+                    sizes.append(count)
+                    torch.cuda.synchronize()
+                barrier.wait(60)
+                t.copy_(total[0])
+                torch.cuda.synchronize()
+                barrier.wait(60)
+            return cb
+
+        def run(rank):
+            try:
+                shard, keep, cuts = prob.shard_time(rank, world, x0)
+                h = BAHandle(shard, device=0)
+                h.set_time_shard(rank, world, cuts)
+                h.set_allreduce(make_cb(rank), is_root=(rank == 0))
+                results[rank] = h.solve(x0, opts=opts)
+                h.close()
+            except Exception as e:                      # pragma: no cover
+                errors.append(e)
+                barrier.abort()
+
+        threads = [threading.Thread(target=run, args=(r,), daemon=True) for r in range(world)]
+        [t.start() for t in threads]
+        [t.join(180) for t in threads]
+        assert not errors, errors
+        for r in range(1, world):
+            np.testing.assert_array_equal(results[0].x, results[r].x)
+        return results[0], sizes
+
+    two, sizes2 = run_world(2)
+    one, sizes1 = run_world(1)
+    for res in (two, one):
+        assert (res.nfev, res.njev, res.status) == (ref.nfev, ref.njev, ref.status)
+        np.testing.assert_allclose(res.cost, ref.cost, rtol=1e-9)
+        np.testing.assert_allclose(res.x, ref.x, rtol=0, atol=1e-7 * max(1.0, np.abs(ref.x).max()))
+    np.testing.assert_allclose(two.cost, one.cost, rtol=1e-10)
+    np.testing.assert_allclose(two.x, one.x, rtol=0, atol=1e-8 * max(1.0, np.abs(one.x).max()))
+    # the separator sum is the largest collective of an iteration in the one-level form; with two levels it carries world - 1 separators
+    s3 = 3 * (5 if motion else 3)
+    ncols = prob.C * (3 + prob.P) + 1
+    cut = (world - 1) * (2 * s3 * s3 + s3 * ncols)
+    assert cut in sizes2 and cut not in sizes1
+    assert max(sizes2) < max(sizes1) and sum(sizes2) < 0.6 * sum(sizes1), (sum(sizes2), sum(sizes1))
+    print('world %d: doubles through the collective per solve: two-level %d, one-level %d (largest buffer %d against %d)'
+          % (world, sum(sizes2), sum(sizes1), max(sizes2), max(sizes1)))
+
+
 def test_time_shard_reports_detections_that_leave_its_slice():
     """Cuts made at x0, solve started from time shifts 60 frames away: rank 0's detections now reach control points its
     slice does not hold -- the solve must fail loudly (no silent dropping of rows)."""
