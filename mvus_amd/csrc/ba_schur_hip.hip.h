@@ -2542,7 +2542,7 @@ struct HipSchur {
   // time shards, round 6: two-level elimination of the separators (k_sep2_*): the local ones by this rank alone, the world - 1 cut separators summed
   bool two_level = false;
   int k_loc = 0, has_ghost = 0, has_cut = 0, ncut = 0;
-  double *Rloc = nullptr, *CGK = nullptr, *cutbuf = nullptr;
+  double *Rloc = nullptr, *CGK = nullptr, *cutbuf = nullptr, *cutws = nullptr;
   size_t cut_count = 0, bcr_lds_loc = 0;
   int bcr_cols_loc = kBcrCols;
   double* Dl = nullptr;
@@ -2773,6 +2773,7 @@ struct HipSchur {
       CGK = be.alloc(2 * ss);
       cut_count = (size_t)ncut * (2 * ss + (size_t)pv.s3 * ncols);
       cutbuf = be.alloc(cut_count);
+      cutws = be.alloc(3 * (size_t)std::max(ncut, 1) * ss);
       bcr_cols_loc = kBcrCols;
       bcr_lds_loc = (size_t)2 * std::max(k_loc, 1) * pv.s3 * bcr_cols_loc * sizeof(double);
       if (bcr_lds_loc > 64 * 1024) { bcr_cols_loc = 1; bcr_lds_loc /= kBcrCols; }
@@ -2862,7 +2863,7 @@ struct HipSchur {
     else MVUS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_assemble_windows<9>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)win_lds));
   }
   ~HipSchur() {
-    for (double* p : {Rloc, CGK, cutbuf, Dl, NEset[0], NEset[1], Lb, Z, G, G0, S, S2, Linv, rhs, pc, DG, px, pv.VW, sepbuf, pv.U2, pv.Ha, pv.Hc, wv.Apart, rcs.Simg, rcs.Tsc, rcs.x}) if (p) be.release(p);
+    for (double* p : {Rloc, CGK, cutbuf, cutws, Dl, NEset[0], NEset[1], Lb, Z, G, G0, S, S2, Linv, rhs, pc, DG, px, pv.VW, sepbuf, pv.U2, pv.Ha, pv.Hc, wv.Apart, rcs.Simg, rcs.Tsc, rcs.x}) if (p) be.release(p);
     if (win_tables) (void)hipFree(win_tables);
     if (part_tables) (void)hipFree(part_tables);
     if (halo_tables) (void)hipFree(halo_tables);
@@ -3085,8 +3086,17 @@ struct HipSchur {
         {
           PartView pc = pv;
           pc.m = ncut; pc.T = cutbuf; pc.U = cutbuf + (size_t)ncut * S3T * S3T; pc.R = cutbuf + 2 * (size_t)ncut * S3T * S3T;
-          hipLaunchKernelGGL(k_sep_factor<S3T>, dim3(1), dim3(64), 0, be.stream, pc, fail);
-          hipLaunchKernelGGL(k_sep_rhs<S3T>, dim3((ncols + 63) / 64), dim3(64), 0, be.stream, pc, ncols);
+          // (the cyclic reduction again, not the sequential block-tridiagonal kernels: 7 nodes are three levels in one workgroup -- 63 us of
+          // k_sep_factor + k_sep_rhs measured at world 8, configs[3], against ~25)
+          pc.U2 = cutws; pc.Ha = cutws + (size_t)ncut * S3T * S3T; pc.Hc = cutws + 2 * (size_t)ncut * S3T * S3T;
+          if (ncut > 2 * kBcrTailNs + 1) {                 // (more than 33 ranks: the general kernels)
+            hipLaunchKernelGGL(k_sep_factor<S3T>, dim3(1), dim3(64), 0, be.stream, pc, fail);
+            hipLaunchKernelGGL(k_sep_rhs<S3T>, dim3((ncols + 63) / 64), dim3(64), 0, be.stream, pc, ncols);
+          } else {
+            hipLaunchKernelGGL(k_sep_bcr_tail<S3T>, dim3(1), dim3(bcr_tail_waves(S3T) * 64), 0, be.stream, pc, 1, fail);
+            const size_t lds = (size_t)2 * ncut * S3T * kBcrCols * sizeof(double);
+            hipLaunchKernelGGL((k_sep_bcr_rhs<S3T, kBcrCols>), dim3((ncols + kBcrCols - 1) / kBcrCols), dim3(256), lds, be.stream, pc, ncols);
+          }
         }
         {
           const long long tot = (long long)(k_loc + 2) * S3T * ncols;
