@@ -3051,7 +3051,8 @@ struct HipSchur {
     }
     hipLaunchKernelGGL(k_part_solve<BWT>, dim3(xcd_grid(pv.P * (int)gsolve.y)), dim3(64), 0, be.stream, pv, ncols, Lb, Z, (int)gsolve.y);
     if (pv.m > 0) {
-      if (shard) MVUS_HIP(hipMemsetAsync(sepbuf, 0, sep_count * sizeof(double), be.stream));      // other ranks' separators: zero here
+      // other ranks' separators: zero here (one level: the whole system is summed; two levels: k_part_reduce writes every block this rank reads)
+      if (shard && !two_level) MVUS_HIP(hipMemsetAsync(sepbuf, 0, sep_count * sizeof(double), be.stream));
       // one rank, cyclic reduction: only the matrix blocks first; the right-hand sides ride beside the one-workgroup tail
       const bool split = overlap_chol && !shard && use_bcr && pv.nt > 0;
       if (pv.nt > 0) hipLaunchKernelGGL(k_part_reduce<BWT>, dim3(pv.nt, split ? 1 : (pv.s3 * ncols + 255) / 256), dim3(256), 0, be.stream, pv, ncols, Lb, Z, split ? 1 : 3);

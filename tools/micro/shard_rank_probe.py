@@ -1,13 +1,15 @@
 """What ONE rank of a time-sharded run computes per LM step: rank R of WORLD on BASELINE configs[CFG], alone on the GPU, with an all-reduce
 callback that leaves the buffers as they are (the sums are wrong, the kernels and their sizes are the real ones).  Under
 `rocprofv3 --kernel-trace --stats` this gives the per-kernel times behind the multi-GPU time model of DESIGN section 6 -- measured for
-the rank's slice instead of scaled from the one-GPU run.  usage: shard_rank_probe.py [cfg=3] [world=8] [rank=3] [steps=8]"""
+the rank's slice instead of scaled from the one-GPU run.  usage: shard_rank_probe.py [cfg=3] [world=8] [rank=3] [steps=8] [obs multiplier=1]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch, numpy as np
 from mvus_amd import ba, problem as mp, synth
-cfg, world, rank, steps = [int(a) for a in (sys.argv[1:] + ['3', '8', '3', '8'][len(sys.argv) - 1:])][:4]
-prob, x0 = mp.problem_from_scene(synth.make_scene(**dict(synth.BASELINE_CONFIGS[cfg])))
+cfg, world, rank, steps, mult = [int(a) for a in (sys.argv[1:] + ['3', '8', '3', '8', '1'][len(sys.argv) - 1:])][:5]
+kw = dict(synth.BASELINE_CONFIGS[cfg])
+kw['total_obs'] *= mult              # (bench.py's weak scaling: the configuration's detections PER GPU)
+prob, x0 = mp.problem_from_scene(synth.make_scene(**kw))
 shard, keep, cuts = prob.shard_time(rank, world, x0)
 calls = []
 with ba.BAHandle(shard, device=0) as h:
