@@ -316,16 +316,26 @@ struct HipBackend {
   double fetch_seq = 0.0;
   bool fetch_polled = false;
   bool fetch_poll_begin(double** mark, double* value) {
-    if (!scal_direct() || std::getenv("MVUS_FETCH_EVENT")) return false;
+    if (scal_map == nullptr || std::getenv("MVUS_FETCH_EVENT")) return false;      // (the mark itself is always written through mapped memory)
     fetch_seq += 1.0;
     *mark = scal_map + kMarkSlot; *value = fetch_seq;
     fetch_polled = true;
     return true;
   }
+  // sharded handles (scalars in device memory, copied out): the copy a later fetch() reads is enqueued NOW, in front of speculative work
+  bool fetch_queued = false;
+  int64_t fq_off = 0;
+  int fq_k = 0;
+  void fetch_enqueue(const double* src, int k) {
+    if (scal_direct()) return;
+    fq_off = src - scal_out(); fq_k = k;
+    MVUS_HIP(hipMemcpyAsync(scal_host + fq_off, src, sizeof(double) * k, hipMemcpyDeviceToHost, stream));
+    fetch_queued = true;
+  }
+  bool spec_on_shards() const { return scal_map != nullptr && std::getenv("MVUS_NO_SPEC_SHARDS") == nullptr; }
   hipEvent_t fetch_ev = nullptr;
   bool fetch_marked = false;
   void fetch_mark() {
-    if (!scal_direct()) return;
     if (!fetch_ev) MVUS_HIP(hipEventCreateWithFlags(&fetch_ev, hipEventDisableTiming));
     MVUS_HIP(hipEventRecord(fetch_ev, stream));
     fetch_marked = true;
@@ -400,8 +410,10 @@ struct HipBackend {
   // step, three A/B pairs on one box -- the runtime's own wait already spins; not kept)
   void fetch(const double* src, int k, double* host) {       // src inside scal_out(): the pinned mirror itself, or staged through it
     const int64_t off = src - scal_out();
-    if (!scal_direct()) MVUS_HIP(hipMemcpyAsync(scal_host + off, src, sizeof(double) * k, hipMemcpyDeviceToHost, stream));
-    if (fetch_polled && scal_direct()) {
+    const bool queued = fetch_queued && off >= fq_off && off + k <= fq_off + fq_k;
+    if (!scal_direct() && !queued) MVUS_HIP(hipMemcpyAsync(scal_host + off, src, sizeof(double) * k, hipMemcpyDeviceToHost, stream));
+    fetch_queued = false;
+    if (fetch_polled && (scal_direct() || queued)) {
       const volatile double* m = scal_host + kMarkSlot;
       const auto t0 = std::chrono::steady_clock::now();
       unsigned spins = 0;
@@ -410,7 +422,7 @@ struct HipBackend {
         __builtin_ia32_pause();
       }
       std::atomic_thread_fence(std::memory_order_acquire);
-    } else if (fetch_marked && scal_direct()) MVUS_HIP(hipEventSynchronize(fetch_ev));
+    } else if (fetch_marked && (scal_direct() || queued)) MVUS_HIP(hipEventSynchronize(fetch_ev));
     else MVUS_HIP(hipStreamSynchronize(stream));
     fetch_marked = false; fetch_polled = false;
     for (SqPending& sp : sq_pend)                         // sums of squares left as per-workgroup partials in mapped memory (residual_sq)

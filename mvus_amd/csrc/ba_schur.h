@@ -28,7 +28,7 @@
 //                   void solve_async(double lambda);               p = -(H + lambda D)^-1 g -> step_ptr()
 //                   const double* step_ptr(); const int* fail_ptr();  bool solve_ok();   (solve_ok after a fetch)
 //                   bool retry_same();   after a failed solve: true = not a numerical failure, repeat it at the same lambda
-//                   bool spec_ok(jac_mode); void linearize_spec(B&, x, f, jac_mode); void adopt_spec();   the linearisation at a TRIAL point,
+//                   bool spec_ok(jac_mode); void linearize_spec(B&, x, f, jac_mode); void adopt_spec(); void drop_spec();   the linearisation at a TRIAL point,
 //                                        enqueued into a second set of blocks before the host knows whether the trial is accepted
 // Backend additions: set_bounds(lb, ub) -> lb_ptr()/ub_ptr(); lm_scalars() (>= 8 doubles); dot_m_into(a, b, out);
 //                   lm_gnorm(x, lb, ub, g, out); lm_trial(x, p, lb, ub, g, D, fail, x_new, out4, gnorm_out) (the trial
@@ -132,6 +132,7 @@ SolveResult lm_schur(B& be, Schur& sc, double* x, const std::vector<double>& lb,
     Delta = opt.lm_trust_radius;
     if (!(Delta > 0)) { double s2 = 0; for (int64_t i = 0; i < n; ++i) s2 += x[i] * x[i]; Delta = s2 > 0 ? std::sqrt(s2) : 1.0; }
   }
+  const int nfetch_all = tr ? 8 : 7;
   auto launch_trial = [&](double lambda) {
     sc.solve_async(lambda);
     be.lm_trial(x_dev, sc.step_ptr(), lbp, ubp, sc.grad_ptr(), sc.diag_ptr(), sc.fail_ptr(), xt_dev, S + 2, S + 1, be.mirror_dev(mir_trial),
@@ -142,7 +143,7 @@ SolveResult lm_schur(B& be, Schur& sc, double* x, const std::vector<double>& lb,
     // it while the host wakes up, decides and enqueues the next solve (20 - 60 us of idle device per iteration otherwise).  A rejected
     // trial leaves the blocks of x untouched (the next solve reads those) and the speculative set is simply written again.
     spec_live = false;
-    if (sc.spec_ok(opt.jac_mode)) { sc.linearize_spec(be, xt_dev, f_new, opt.jac_mode); spec_live = true; }      // (marks where the fetch stops waiting)
+    if (sc.spec_ok(opt.jac_mode)) { be.fetch_enqueue(S, nfetch_all); sc.linearize_spec(be, xt_dev, f_new, opt.jac_mode); spec_live = true; }      // (marks where the fetch stops waiting)
   };
   const int nfetch = tr ? 8 : 7;
 
@@ -171,6 +172,7 @@ SolveResult lm_schur(B& be, Schur& sc, double* x, const std::vector<double>& lb,
       if (!have_trial) { launch_trial(lambda); be.fetch(S + 2, nfetch - 2, hs + 2); }
       have_trial = false;
       if (!sc.solve_ok() || !std::isfinite(hs[2]) || !std::isfinite(hs[3])) {   // not positive definite at this damping: raise it
+        if (spec_live) { sc.drop_spec(); spec_live = false; }
         if (sc.retry_same()) continue;      // (not a numerical failure -- an in-launch hand-over timed out: the same solve again, other route)
         lambda *= 10.0;
         if (lambda > 1e12) { status = 0; break; }
@@ -183,7 +185,7 @@ SolveResult lm_schur(B& be, Schur& sc, double* x, const std::vector<double>& lb,
       const double predicted = cut < 1.0 ? 0.5 * lambda * hs[3] - (1.0 - 0.5 * cut) * hs[2] : 0.5 * (lambda * hs[3] - hs[2]);
       ++res.nfev;
       cost_new = 0.5 * hs[6];
-      if (!std::isfinite(cost_new)) { lambda *= nu; nu *= 2.0; continue; }
+      if (!std::isfinite(cost_new)) { if (spec_live) { sc.drop_spec(); spec_live = false; } lambda *= nu; nu *= 2.0; continue; }
       actual_reduction = cost - cost_new;
       const double ratio = predicted > 0 ? actual_reduction / predicted : (actual_reduction > 0 ? 1.0 : 0.0);
       const double step_norm = std::sqrt(hs[4]);
@@ -198,6 +200,7 @@ SolveResult lm_schur(B& be, Schur& sc, double* x, const std::vector<double>& lb,
         nu = 2.0;
       } else {
         lambda *= nu; nu *= 2.0;
+        if (spec_live) { sc.drop_spec(); spec_live = false; }
       }
       if (tr) {                                                          // scipy's update_tr_radius
         const bool bound_hit = step_norm > 0.95 * Delta;
@@ -299,6 +302,7 @@ struct HostSchur {
   bool spec_ok(int) const { return false; }
   template <class B> void linearize_spec(B&, const double*, double*, int) {}
   void adopt_spec() {}
+  void drop_spec() {}
   void solve_async(double lambda) { fail = solve(lambda, pstep) ? 0 : 1; if (fail) pstep.assign(n, 0.0); }
   static double damp_scale(double hii) { return hii > 0 ? hii : 1.0; }
   bool solve(double lambda, std::vector<double>& p) {

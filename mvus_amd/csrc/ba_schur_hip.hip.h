@@ -2879,11 +2879,15 @@ struct HipSchur {
     NE = NEset[k];
     ne.A = NE; ne.gc = NE + off_gc; ne.Cb = NE + off_Cb; ne.gs = NE + off_gs; ne.Et = NE + off_Et; ne.Apart = NE + off_Apart;
     if (pv_ready) { pv.Et = ne.Et; pv.gs = ne.gs; }
+    if (shard) { D = NE + nAg + halo_count; gx = D + be.hp.n; }      // (a time shard's diag(H) and g ride inside the summed head of the set)
   }
   // Speculative linearisation (ba_schur.h, launch_trial): one rank, the fused window-major assembly (every entry written by one plain
   // store: the second set needs no clearing), scalars fetched behind an event.  MVUS_NO_SPEC=1 keeps the sequential form for an A/B.
+  // Time shards (round 6): the speculative assembly carries its collective with it -- every rank takes the same decision from the same
+  // summed scalars, so every rank enqueues the same sequence; the scalars' copy to the host is enqueued in front of it (fetch_enqueue).
   bool spec_ok(int jac_mode) {
-    if (shard || !use_win || !be.scal_direct() || jac_mode != MVUS_JAC_ANALYTIC) return false;
+    if (!use_win || jac_mode != MVUS_JAC_ANALYTIC) return false;
+    if (shard ? !be.spec_on_shards() : !be.scal_direct()) return false;
     if (std::getenv("MVUS_NO_SPEC") || std::getenv("MVUS_LM_MATERIALIZE_J")) return false;
     if (!NEset[1]) NEset[1] = be.alloc(ne_count + n_apart);
     return true;
@@ -2898,7 +2902,10 @@ struct HipSchur {
     wv.mark = nullptr;
     diag_pending = pending;
   }
-  void adopt_spec() { ne_cur ^= 1; bind_ne(ne_cur); diag_pending = true; }
+  void adopt_spec() { ne_cur ^= 1; bind_ne(ne_cur); diag_pending = !shard; }
+  // a rejected trial's speculative assembly may have raised the "row left the slice" flag for a point nobody keeps: forget it (a flag
+  // raised by the CURRENT point's assembly has been acted on before any trial)
+  void drop_spec() { if (shard) MVUS_HIP(hipMemsetAsync(fail + 1, 0, sizeof(int), be.stream)); }
 
   // x_fused != nullptr: the detection rows' Jacobian is evaluated inside the assembly kernel at x_fused (no J in memory);
   // the motion rows (O(T), tiny) still go through k_motion

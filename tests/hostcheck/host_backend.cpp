@@ -77,6 +77,7 @@ struct HostBackend {
   mvus::LmCarry lm_carry(int) { return {}; }
   void lm_keep(const mvus::LmCarry&, int) {}
   void fetch_mark() {}
+  void fetch_enqueue(const double*, int) {}
   double* mirror_dev(int) { return nullptr; }
   const double* mirror_host(int) const { return nullptr; }
   void adopt_residual(double*&, double*&) {}

@@ -260,8 +260,20 @@ def test_two_level_separator_elimination_sums_the_cut_separators_only(world, mot
             np.testing.assert_array_equal(results[0].x, results[r].x)
         return results[0], sizes
 
+    monkeypatch.delenv('MVUS_NO_SPEC_SHARDS', raising=False)
     two, sizes2 = run_world(2)
     one, sizes1 = run_world(1)
+    # the linearisation at the trial point is enqueued speculatively on shards too (its collective with it): no value may change
+    monkeypatch.setenv('MVUS_NO_SPEC_SHARDS', '1')
+    seq, sizes_seq = run_world(2)
+    monkeypatch.delenv('MVUS_NO_SPEC_SHARDS')
+    assert (two.nfev, two.njev) == (seq.nfev, seq.njev)
+    if motion:      # (time shards add the motion rows with fp64 atomics -- k_assemble_motion: last-bit differences from run to run)
+        np.testing.assert_allclose(two.cost, seq.cost, rtol=1e-11)
+        np.testing.assert_allclose(two.x, seq.x, rtol=0, atol=1e-9 * max(1.0, np.abs(seq.x).max()))
+    else:
+        assert np.array_equal(two.x, seq.x) and two.cost == seq.cost
+    assert len(sizes2) >= len(sizes_seq)          # (a speculative assembly after the last trial, or after a rejected one, is an extra sum)
     for res in (two, one):
         assert (res.nfev, res.njev, res.status) == (ref.nfev, ref.njev, ref.status)
         np.testing.assert_allclose(res.cost, ref.cost, rtol=1e-9)
