@@ -54,6 +54,9 @@ struct WinView {
                              //        (stride between coordinates), index of knot t[l-2] of its span, 1: first span | 2: last span of the interval}
   int Wn, nwin;
   int Ntot;                  // control points of the whole problem (a time shard's slice is shorter)
+  int G;                     // camera groups (round 6): the grid is nwin x G workgroups, group g walks the cameras perm[g * 4 + v + 4 G i] -- when the windows
+                             // alone cannot fill the device (a time shard's slice, a few hundred control points) the cameras are dealt over more workgroups
+  double* band_part;         // G > 1: [G][N * (3 + W * 9)] the groups' partial band rows and gradients (gs then Cb), summed in group order by k_cam_block_sum
   double* mark;              // non-null: workgroup 0 writes mark_val there when it starts (mapped host memory: the host's fetch spins on it --
   double mark_val;           //           this launch cannot start before everything enqueued in front of it has finished; HipBackend::fetch_poll_begin)
 };
@@ -137,7 +140,8 @@ void k_assemble_windows(DevProblem dp, NEView ne, WinView wv, const CamState* __
   double* S = win_lds + wave * WAVE;
   unsigned long long* mk = reinterpret_cast<unsigned long long*>(S + REG);
   double* spl = win_lds + kWinWaves * WAVE;                 // [NJ][18]: knots t[l-2 .. l+3] and coefficients (x, y, z) x 4 of every span of the window
-  const int win = blockIdx.x;
+  const int win = (int)blockIdx.x % wv.nwin, grp = (int)blockIdx.x / wv.nwin;       // (consecutive workgroups: consecutive windows of one camera group)
+  const int slot = grp * kWinWaves + wave, nslot = wv.G * kWinWaves;                 // this wavefront's place among the G x 4 that share the cameras
   const int a = win * wv.Wn;                                // first owned control point (local to the handle's slice)
   const int nown = min(wv.Wn, ne.N - a), NJ = nown + 3;     // spans a - 3 .. a + nown - 1 reach the window
   const int SP = win_pieces(wv.Wn);                         // lane = (control point pl, coordinate d, piece s): an output ROW and a share of its detections (SP <= 5)
@@ -169,10 +173,10 @@ void k_assemble_windows(DevProblem dp, NEView ne, WinView wv, const CamState* __
 
   // ---- detection range of every camera of this wavefront, all at once (lane i: camera wave + 4 i): frames that can carry a time
   //      stamp in [T0, T1), tau = alpha (frame + rs v / H) + beta with v in [vmin, vmax], looked up in the camera's frame grid ----
-  const int ncam = (dp.C - wave + kWinWaves - 1) / kWinWaves;       // cameras of this wavefront: <= 64 (the reduced camera system limits C * B to 1152)
+  const int ncam = slot < dp.C ? (dp.C - slot + nslot - 1) / nslot : 0;       // cameras of this wavefront: <= 64 (the reduced camera system limits C * B to 1152)
   int p0v = 0, p1v = 0;
   if (lane < ncam) {
-    const int c = wv.cam_perm[wave + kWinWaves * lane];
+    const int c = wv.cam_perm[slot + nslot * lane];
     const CamState* cs = cams + c;
     const CamWin cw = wv.cw[c];
     const double alpha = cs->alpha, beta = cs->beta, rs = cs->rs, H = cs->H;
@@ -484,17 +488,21 @@ void k_assemble_windows(DevProblem dp, NEView ne, WinView wv, const CamState* __
   }
   __syncthreads();
   const int per = 3 + ne.W * 9;
+  // (several camera groups: the group's partial rows go to its slice of band_part -- gs then Cb, the layout of the blocks themselves --
+  // and k_cam_block_sum adds the groups in order)
+  double* gs_out = wv.G > 1 ? wv.band_part + (long long)grp * ((long long)ne.N * per) : ne.gs;
+  double* Cb_out = wv.G > 1 ? gs_out + 3LL * ne.N : ne.Cb;
   for (int e = threadIdx.x; e < nown * per; e += kWinThreads) {
     const int p = e / per, r = e - p * per;
     double acc = 0.0;
     if (r < 3) {
       for (int v = 0; v < kWinWaves; ++v) acc += win_lds[v * WAVE + (p * 3 + r) * kRow + 12];
-      ne.gs[3 * (a + p) + r] = acc;
+      gs_out[3 * (a + p) + r] = acc;
     } else {
       const int w = (r - 3) / 9, dd = (r - 3) - 9 * w;        // block (p, p + w), entry (row dd / 3, column dd % 3)
       if (w < 4)
         for (int v = 0; v < kWinWaves; ++v) acc += win_lds[v * WAVE + (p * 3 + dd / 3) * kRow + w * 3 + dd % 3];
-      ne.Cb[((long long)(a + p) * ne.W) * 9 + (r - 3)] = acc;       // (w >= 4: the motion rows' blocks start from zero)
+      Cb_out[((long long)(a + p) * ne.W) * 9 + (r - 3)] = acc;       // (w >= 4: the motion rows' blocks start from zero)
     }
   }
 }
@@ -502,9 +510,19 @@ void k_assemble_windows(DevProblem dp, NEView ne, WinView wv, const CamState* __
 // A[c] (both triangles) and gc[c] from the per-(window, camera) partial blocks: one workgroup per camera, the windows added in
 // index order (four interleaved chains per entry and group, the groups combined in order) -- plain stores, nothing to clear.
 template <int B>
-__global__ __launch_bounds__(1024) void k_cam_block_sum(int C, int nwin, const double* __restrict__ Apart, NEView ne) {
+__global__ __launch_bounds__(1024) void k_cam_block_sum(int C, int nwin, const double* __restrict__ Apart, NEView ne, int G = 1,
+                                                        const double* __restrict__ band_part = nullptr) {
   constexpr int PSZ = (B + 1) * (B + 2) / 2, kLanes = PSZ <= 64 ? 64 : 256, kGroups = 1024 / kLanes;
   __shared__ double part[kGroups][kLanes];
+  if ((int)blockIdx.x >= C) {                               // workgroups past the cameras (G > 1): the camera groups' band rows and gradients, added in group order
+    const long long len = (long long)ne.N * (3 + ne.W * 9), i = ((long long)blockIdx.x - C) * 1024 + threadIdx.x;
+    if (i < len) {
+      double t = band_part[i];
+      for (int g = 1; g < G; ++g) t += band_part[(long long)g * len + i];
+      if (i < 3LL * ne.N) ne.gs[i] = t; else ne.Cb[i - 3LL * ne.N] = t;
+    }
+    return;
+  }
   const int c = blockIdx.x;
   const int k = threadIdx.x % kLanes, grp = threadIdx.x / kLanes;
   double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;

@@ -2790,30 +2790,55 @@ struct HipSchur {
     if (hp.M >= (int64_t)1 << 31) use_win = false;
     for (int c = 0; c < hp.C && use_win; ++c) if (hp.det_off[c + 1] - hp.det_off[c] >= (1 << 24)) use_win = false;
     if (!use_win) return;
-    // Window length.  A (window, camera) pair costs its batches of 64 staged detections -- (Wn + 3) spans reach a window, so camera
-    // c brings n_c = (Wn + 3) rho_c + 3 of them, rho_c = detections per knot span -- a fixed part per batch (evaluation, matrix-core
-    // pass) and a part per detection (accumulation); the windows run two workgroups per CU at a time.  Short windows repeat more
-    // evaluations (the three spans below a window) but fill the machine; the model picks the cheapest length, MVUS_WIN overrides.
-    int Wn = 8;
+    // Window length AND camera groups, from one cost model.  A (window, camera) pair costs its batches of 64 staged detections -- (Wn + 3)
+    // spans reach a window, so camera c brings n_c = (Wn + 3) rho_c + 3 of them, rho_c = detections per knot span -- a fixed part per
+    // batch (evaluation, matrix-core pass) and a part per detection (accumulation); a workgroup walks the cameras of its group (C / G of
+    // them, dealt over its four wavefronts) and pays a prologue of its own (the window's spline records); the grid of nwin x G workgroups
+    // runs two per CU at a time.  Short windows repeat more evaluations (the three spans below a window) but fill the machine; camera
+    // groups (round 6) fill it when the windows alone cannot -- a time shard's slice, few control points -- as long as a wavefront still
+    // walks more than one camera.  MVUS_WIN / MVUS_WIN_GROUPS override.
+    int Wn = 8, G = 1;
     {
       int ncu = 256;
       hipDeviceProp_t prop;
       if (hipGetDeviceProperties(&prop, be.device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
       const double slots = 2.0 * ncu;
-      double best = 1e300;
-      for (int w = 3; w <= kWinMaxW; ++w) {
+      const double nspan = shard ? std::max(1, own_hi - own_lo) : std::max(1, hp.N);      // control points the held detections spread over
+      auto wg_cost = [&](int w) {
         double wg = 0.0;
         for (int c = 0; c < hp.C; ++c) {
-          const double nc = (w + 3) * (double)(hp.det_off[c + 1] - hp.det_off[c]) / std::max(1, hp.N) + 3.0;
+          const double nc = (w + 3) * (double)(hp.det_off[c + 1] - hp.det_off[c]) / nspan + 3.0;
           wg += 0.45 * std::ceil(nc / 64.0) + 0.55 * nc / 64.0 + 0.15;      // + the camera's own set-up and stores
         }
-        const double nwin = std::ceil((double)ne.N / w);
-        const double t = std::max(1.0, nwin / slots) * wg;
+        return wg;
+      };
+      // one group: the model of round 4 (measured optima 10 / 3 / 8 / 3 at configs[2] / [1] / [3] / [4], picks within 6 %)
+      double best = 1e300;
+      for (int w = 3; w <= kWinMaxW; ++w) {
+        const double t = std::max(1.0, std::ceil((double)ne.N / w) / slots) * wg_cost(w);
         if (t < best * 0.999) { best = t; Wn = w; }
+      }
+      // camera groups only where that choice leaves a quarter or more of the workgroup slots empty, and only in ONE round of workgroups
+      // (measured, `tools/micro/win_group_sweep.sh`: with the slots full, groups + longer windows are level at configs[2] -- 95-97 us against
+      // 91-93 -- and the model cannot tell 13 x 4 (114 us) from 21 x 4 (97 us) there)
+      if (std::ceil((double)ne.N / Wn) <= 0.75 * slots) {
+        double bt = wg_cost(Wn) + 0.5;
+        for (int g = 2; g <= 4; g *= 2) {
+          if (hp.C <= kWinWaves * (g / 2)) break;
+          for (int w = 3; w <= kWinMaxW; ++w) {
+            if (std::ceil((double)ne.N / w) * g > 1.03 * slots) continue;      // (a handful of late workgroups is no second round)
+            const double t = wg_cost(w) / g + 0.5;
+            if (t < bt * 0.999) { bt = t; Wn = w; G = g; }
+          }
+        }
       }
     }
     if (const char* e = std::getenv("MVUS_WIN")) { if (std::atoi(e) > 0) Wn = std::min(kWinMaxW, std::atoi(e)); }
+    if (const char* e = std::getenv("MVUS_WIN_GROUPS")) { if (std::atoi(e) > 0) G = std::min(8, std::atoi(e)); }
     wv.Wn = Wn; wv.nwin = (ne.N + Wn - 1) / Wn; wv.Ntot = hp.N;
+    wv.G = G;
+    if (std::getenv("MVUS_DEBUG")) std::fprintf(stderr, "window-major assembly: %d control points per window, %d windows x %d camera group(s)\n", Wn, wv.nwin, G);
+    wv.band_part = G > 1 ? be.alloc((size_t)G * ne.N * (3 + ne.W * 9)) : nullptr;
     const size_t psz = (size_t)(ne.B + 1) * (ne.B + 2) / 2;
     wv.Apart = be.alloc((size_t)wv.nwin * ne.C * psz);
     const size_t bytes_cw = sizeof(CamWin) * (size_t)hp.C, bytes_t = sizeof(double) * ((size_t)hp.N + 1), bytes_l = sizeof(int32_t) * (((size_t)hp.flut_len + 3) & ~(size_t)3);
@@ -2826,15 +2851,16 @@ struct HipSchur {
       std::vector<int32_t> byc((size_t)hp.C);
       for (int c = 0; c < hp.C; ++c) byc[c] = c;
       std::stable_sort(byc.begin(), byc.end(), [&](int32_t u, int32_t v) { return hp.det_off[u + 1] - hp.det_off[u] > hp.det_off[v + 1] - hp.det_off[v]; });
-      std::vector<std::vector<int32_t>> of(kWinWaves);
-      for (int i = 0; i < hp.C; ++i) { const int r = i % (2 * kWinWaves); of[r < kWinWaves ? r : 2 * kWinWaves - 1 - r].push_back(byc[i]); }
-      // wavefront v walks perm[v], perm[v + 4], ...: it takes ceil((C - v) / 4) cameras, the first waves one more than the last ones
+      const int ns = kWinWaves * wv.G;                       // wavefront slots that share the cameras of a window (G workgroups of four)
+      std::vector<std::vector<int32_t>> of(ns);
+      for (int i = 0; i < hp.C; ++i) { const int r = i % (2 * ns); of[r < ns ? r : 2 * ns - 1 - r].push_back(byc[i]); }
+      // slot u walks perm[u], perm[u + ns], ...: it takes ceil((C - u) / ns) cameras, the first slots one more than the last ones
       std::vector<int32_t> flat;
-      for (int v = 0; v < kWinWaves; ++v) flat.insert(flat.end(), of[v].begin(), of[v].end());
-      std::vector<size_t> take(kWinWaves);
-      for (int v = 0; v < kWinWaves; ++v) take[v] = (size_t)(hp.C - v + kWinWaves - 1) / kWinWaves;
+      for (int v = 0; v < ns; ++v) flat.insert(flat.end(), of[v].begin(), of[v].end());
+      std::vector<size_t> take(ns);
+      for (int v = 0; v < ns; ++v) take[v] = v < hp.C ? (size_t)(hp.C - v + ns - 1) / ns : 0;
       size_t pos = 0;
-      for (int v = 0; v < kWinWaves; ++v) for (size_t i = 0; i < take[v]; ++i) perm[(size_t)v + kWinWaves * i] = flat[pos++];
+      for (int v = 0; v < ns; ++v) for (size_t i = 0; i < take[v]; ++i) perm[(size_t)v + ns * i] = flat[pos++];
     }
     std::vector<int4> crec((size_t)std::max(1, hp.N), int4{0, 0, 0, 0});
     for (int sI = 0; sI < hp.S; ++sI) {
@@ -2863,7 +2889,7 @@ struct HipSchur {
     else MVUS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_assemble_windows<9>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)win_lds));
   }
   ~HipSchur() {
-    for (double* p : {Rloc, CGK, cutbuf, cutws, Dl, NEset[0], NEset[1], Lb, Z, G, G0, S, S2, Linv, rhs, pc, DG, px, pv.VW, sepbuf, pv.U2, pv.Ha, pv.Hc, wv.Apart, rcs.Simg, rcs.Tsc, rcs.x}) if (p) be.release(p);
+    for (double* p : {wv.band_part, Rloc, CGK, cutbuf, cutws, Dl, NEset[0], NEset[1], Lb, Z, G, G0, S, S2, Linv, rhs, pc, DG, px, pv.VW, sepbuf, pv.U2, pv.Ha, pv.Hc, wv.Apart, rcs.Simg, rcs.Tsc, rcs.x}) if (p) be.release(p);
     if (win_tables) (void)hipFree(win_tables);
     if (part_tables) (void)hipFree(part_tables);
     if (halo_tables) (void)hipFree(halo_tables);
@@ -2943,11 +2969,13 @@ struct HipSchur {
       }
       be.ensure_cams(x_fused);
       if (be.hp.calib) {
-        hipLaunchKernelGGL(k_assemble_windows<18>, dim3(wv.nwin), dim3(kWinThreads), win_lds, be.stream, be.dp, ne, wv, be.cams, x_fused);
-        hipLaunchKernelGGL(k_cam_block_sum<18>, dim3(be.hp.C), dim3(1024), 0, be.stream, be.hp.C, wv.nwin, wv.Apart, ne);
+        const unsigned sumg = (unsigned)be.hp.C + (wv.G > 1 ? (unsigned)(((long long)ne.N * (3 + ne.W * 9) + 1023) / 1024) : 0u);
+        hipLaunchKernelGGL(k_assemble_windows<18>, dim3(wv.nwin * wv.G), dim3(kWinThreads), win_lds, be.stream, be.dp, ne, wv, be.cams, x_fused);
+        hipLaunchKernelGGL(k_cam_block_sum<18>, dim3(sumg), dim3(1024), 0, be.stream, be.hp.C, wv.nwin, wv.Apart, ne, wv.G, (const double*)wv.band_part);
       } else {
-        hipLaunchKernelGGL(k_assemble_windows<9>, dim3(wv.nwin), dim3(kWinThreads), win_lds, be.stream, be.dp, ne, wv, be.cams, x_fused);
-        hipLaunchKernelGGL(k_cam_block_sum<9>, dim3(be.hp.C), dim3(1024), 0, be.stream, be.hp.C, wv.nwin, wv.Apart, ne);
+        const unsigned sumg = (unsigned)be.hp.C + (wv.G > 1 ? (unsigned)(((long long)ne.N * (3 + ne.W * 9) + 1023) / 1024) : 0u);
+        hipLaunchKernelGGL(k_assemble_windows<9>, dim3(wv.nwin * wv.G), dim3(kWinThreads), win_lds, be.stream, be.dp, ne, wv, be.cams, x_fused);
+        hipLaunchKernelGGL(k_cam_block_sum<9>, dim3(sumg), dim3(1024), 0, be.stream, be.hp.C, wv.nwin, wv.Apart, ne, wv.G, (const double*)wv.band_part);
       }
       motion_rows(f_dev);
       MVUS_HIP(hipGetLastError());
