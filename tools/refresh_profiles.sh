@@ -67,3 +67,7 @@ bash tools/band_solver_ab.sh > $O/${R}_band_solver_ab.txt 2>/dev/null
 # speculative linearisation / carry-over (python wall, C++ wall, long solve), LM at configs[4] with the sequential driver for reference
 python bench.py --config 4 --solver trf --steps 3 --warmup 1 --no-cpu-baseline --no-parity-solver > $O/${R}_bench_config4_calib_trf.json 2>> $O/bench.err
 ( python3 tools/micro/host_probe.py; echo "--- MVUS_NO_SPEC=1 MVUS_LM_NO_CARRY=1 (the sequential driver of rounds 2-5)"; MVUS_NO_SPEC=1 MVUS_LM_NO_CARRY=1 python3 tools/micro/host_probe.py ) 2>&1 | grep -v amdgpu > $O/${R}_lm_driver_spec_ab.txt
+# round 6: one rank of an 8-rank time-sharded run, alone on the GPU (per-kernel times behind the multi-GPU model of DESIGN section 6);
+# (window length, camera groups) sweep of the window-major assembly
+bash tools/micro/shard_rank_probe.sh 2>&1 | grep -v amdgpu > $O/${R}_shard_rank_probe_world8.txt
+bash tools/micro/win_group_sweep.sh 2>&1 | grep -v amdgpu > $O/${R}_window_groups_sweep.txt
