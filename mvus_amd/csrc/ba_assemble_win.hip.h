@@ -231,7 +231,6 @@ void k_assemble_windows(DevProblem dp, NEView ne, WinView wv, const CamState* __
     return (kk >= 0 && kk < NJ) ? kk : -1;
   };
 
-#define MVUS_WTP(i) ((void)0)
   int p0 = 0, p1 = 0, cnext = 0;                            // (p0, p1: absolute detection indices)
   if (ncam > 0) cam_range(0, cnext, p0, p1);
   Inputs cur = ncam > 0 ? fetch(p0 + lane, p1) : Inputs{0.0, 0.0, 0.0, 0.0, -1};
@@ -259,7 +258,6 @@ void k_assemble_windows(DevProblem dp, NEView ne, WinView wv, const CamState* __
       if (!last) nxt = fetch(base + 64 + lane, p1);
       else if (ci + 1 < ncam) nxt = fetch(np0 + lane, np1);
       else nxt = Inputs{0.0, 0.0, 0.0, 0.0, -1};
-      MVUS_WTP(0);     // camera set-up / previous batch's tail
       // ---- stage: lane = detection; knot span known (span table), its knots and coefficients from LDS ----
       const int key = span_key(cur.g);
       // staged column of a detection: its rank among the lanes that hold one of this window's (lane order kept) -- the columns in
@@ -300,21 +298,12 @@ void k_assemble_windows(DevProblem dp, NEView ne, WinView wv, const CamState* __
         }
       }
       win_wave_sync();
-      MVUS_WTP(1);     // evaluation + staging
       // the masks of the four spans that reach this lane's control point (its piece of each): span pl + 3 - q touches it as ITS control point q
       unsigned long long mq[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) mq[q] = role ? mk[(pl + 3 - q) * SP + s] : 0ull;
-#if defined(MVUS_WIN_STOP) && MVUS_WIN_STOP == 1
-#pragma unroll
-      for (int q = 0; q < 4; ++q) mq[q] = 0ull;             // timing probe: evaluation + staging only
-#endif
       // ---- camera block of the owned detections on the matrix cores: two independent accumulation chains (x rows, y rows) ----
-#if defined(MVUS_WIN_STOP) && (MVUS_WIN_STOP == 1 || MVUS_WIN_STOP == 3)
-      if (false) {
-#else
       if (own != 0ull) {
-#endif
         const int lr = lane & 15, lk = lane >> 4;
         int srcs[2][TI];
         bool rowok[TI];
@@ -353,16 +342,11 @@ void k_assemble_windows(DevProblem dp, NEView ne, WinView wv, const CamState* __
               for (int jj = 0; jj <= i; ++jj) cacc[xy][i][jj] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[xy][i], av[xy][jj], cacc[xy][i][jj], 0, 0, 0);
         }
       }
-      MVUS_WTP(2);     // camera block on the matrix cores
       // ---- accumulate: lane = (control point pl, coordinate d, piece s).  The lane walks the staged detections of the four spans
       //      that reach its control point (its piece of them, in column = time order); a detection of span pl + 3 - q has the
       //      control point as ITS q-th, so the lane's spline slot is h[q] (gu_d, gv_d) and the band blocks (pl, pl + w) take
       //      h[q] h[q + w] (zero rows stand in for q + w > 3).  The sums of an output row never leave the lane: nothing to
       //      exchange, nothing to flush.  The values of the next detection are in flight while this one is added ----
-#if defined(MVUS_WIN_STOP) && MVUS_WIN_STOP == 2
-#pragma unroll
-      for (int q = 0; q < 4; ++q) mq[q] = 0ull;             // timing probe: no accumulation
-#endif
       {
         unsigned long long mall = mq[0] | mq[1] | mq[2] | mq[3];
         // (two sets of plain locals and macros: value sets passed by reference end up in scratch memory)
@@ -414,7 +398,6 @@ void k_assemble_windows(DevProblem dp, NEView ne, WinView wv, const CamState* __
       }
       win_wave_sync();                                      // the staging region is rewritten by the next batch
       if (lane < 32) mk[lane] = 0ull;
-      MVUS_WTP(3);     // accumulation
       cur = nxt;
     }
 
@@ -458,11 +441,9 @@ void k_assemble_windows(DevProblem dp, NEView ne, WinView wv, const CamState* __
             mine[ra * (ra + 1) / 2 + rb] = cacc[0][i][jj][r] + cacc[1][i][jj][r];
           }
     }
-    MVUS_WTP(4);     // the camera's stores
     p0 = np0; p1 = np1;
   }
 
-  MVUS_WTP(5);
   // ---- band and gradient: the rows' pieces, then the four wavefronts, added in order; every entry stored once ----
   if (SP > 1) {
 #pragma unroll

@@ -188,9 +188,6 @@ __device__ __forceinline__ int xcd_tile(int tiles) {
 #ifndef MVUS_JAC_WAVES_CALIB
 #define MVUS_JAC_WAVES_CALIB 3        // opt_calib (2 x 30 slots + the K, d tangents): at 4 wavefronts per SIMD (128 VGPRs) it spills 40 B per lane
 #endif
-#if !defined(MVUS_JAC_ARRAY) && !defined(MVUS_JAC_DIRECT)
-#define MVUS_JAC_DIRECT 1        // default: values go to memory as they are produced (98 VGPRs; the array form needs 128 + scratch)
-#endif
 // Chunk-major Jacobian: the 2*NS slot rows of one <=256-detection chunk are adjacent in memory,
 //     J[(chunk * 2*NS + r) * kThreads + lane],   r = k (x row of slot k) or NS + k (y row),
 // so a workgroup writes (and J v / J^T u / the assembly read) ONE contiguous 2*NS*2 KB block instead of 2*NS pieces M*8 bytes
@@ -202,14 +199,9 @@ inline size_t j_doubles(int NS, int n_chunks) { return (size_t)2 * NS * kThreads
 
 // The Jacobian is written once and read by other kernels later: non-temporal stores.  With the chunk-major layout they take the
 // kernel from 39.4 to 35.2 us when the outputs go to HBM (with the slot-major layout they cost +4 us, with plain stores into a
-// cache-resident buffer they are 1 us slower): measured, tools/micro/ab_kernel.sh.  MVUS_JAC_PLAIN / MVUS_JAC_SC1: the variants.
-#if defined(MVUS_JAC_PLAIN)
-#define MVUS_JSTORE(ptr, val) (*(ptr) = (val))
-#elif defined(MVUS_JAC_SC1)
-#define MVUS_JSTORE(ptr, val) __hip_atomic_store((ptr), (val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#else
+// cache-resident buffer they are 1 us slower; write-through sc1 stores were slower still): measured in rounds 2-3 with build variants
+// (docs/NOTEBOOK.md section G); the shipped form is the only one in the source.
 #define MVUS_JSTORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
-#endif
 // Sink of eval_observation_to that stores each value of the 2 x NS block straight to the chunk-major Jacobian
 // (masked: spline slots outside the pattern become zeros; an all-zero pattern row stores nothing).
 struct JStoreSink {
@@ -291,7 +283,6 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(JAC ? 
   const long long a = ci.cam_start, Mc = ci.cam_count;
   const double uo = CALIB ? 0.0 : dp.u_obs[i], vo = CALIB ? 0.0 : dp.v_obs[i];
   const double ur = CALIB ? dp.u_raw[i] : 0.0;
-#ifdef MVUS_JAC_DIRECT
   // every Jacobian value goes to memory as soon as it exists: the row never sits in registers as a whole
   double* __restrict__ Jc = J + j_chunk_offset<NS>(chunk);          // wave-uniform
   JStoreSink sink{Jc, Jc + NS * kThreads, kThreads, (JAC && masked) ? pat0[i] : 0, NS - 12, JAC && masked != 0, true, -1, threadIdx.x};
@@ -300,29 +291,6 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(JAC ? 
   f[2 * a + Mc + (i - a)] = r.ey;
   if (JAC) span[i] = (r.ctrl >= 0 && sink.live) ? r.ctrl : -1;
   else if (span != nullptr) span[i] = r.ctrl;
-#else
-  double jx[NS], jy[NS];
-  ObsResult r = eval_observation<CALIB, JAC>(cam, dp.sp, x, dp.undist != 0, dp.rs_free != 0, dp.sync_free != 0, dp.frame[i], ur, dp.v_raw[i],
-                                             uo, vo, jx, jy);
-  f[2 * a + (i - a)] = r.ex;
-  f[2 * a + Mc + (i - a)] = r.ey;
-  if (JAC) {
-    int32_t ctrl = r.ctrl;
-    if (masked && ctrl >= 0) {
-      const int32_t p = pat0[i];
-      if (p < 0) ctrl = -1;
-      else mask_to_pattern(jx, jy, NS - 12, ctrl, p);
-    }
-    span[i] = ctrl;
-    if (ctrl >= 0) {
-#pragma unroll
-      for (int k = 0; k < NS; ++k) {
-        MVUS_JSTORE(&(J + j_chunk_offset<NS>(chunk) + k * kThreads)[threadIdx.x], jx[k]);
-        MVUS_JSTORE(&(J + j_chunk_offset<NS>(chunk) + (NS + k) * kThreads)[threadIdx.x], jy[k]);
-      }
-    }
-  }
-#endif
 }
 
 // Reference sparsity pattern of the detection rows at x0 (jac_BA + compute_visibility).
