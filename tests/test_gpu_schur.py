@@ -508,12 +508,13 @@ def test_speculative_linearisation_and_carry_over_change_no_bit(name, monkeypatc
             out.append((r.x.copy(), r.cost, r.nfev, r.njev, r.status, 0.5 * float(f @ f)))
         return out
 
-    for k in ('MVUS_NO_SPEC', 'MVUS_LM_NO_CARRY'):
+    for k in ('MVUS_NO_SPEC', 'MVUS_LM_NO_CARRY', 'MVUS_SQ_DEVICE_SUM', 'MVUS_FETCH_EVENT'):
         monkeypatch.delenv(k, raising=False)
     new = run()
     again = run()
     monkeypatch.setenv('MVUS_NO_SPEC', '1')
     monkeypatch.setenv('MVUS_LM_NO_CARRY', '1')
+    monkeypatch.setenv('MVUS_SQ_DEVICE_SUM', '1')          # |f|^2 by k_dot_final instead of the host-side sum of the partials
     old = run()
     for a, b, c in zip(new, old, again):
         assert np.array_equal(a[0], b[0]) and a[1:] == b[1:], (a[1:], b[1:])
