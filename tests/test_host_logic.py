@@ -312,3 +312,94 @@ def test_group_columns_rejects_bad_input_and_matches_scipy_on_a_random_pattern()
     assert run(rows, cols, bad)[0] == _lib.MVUS_E_INVALID and b'permutation' in lib.mvus_last_error(None)
     r2 = rows.copy(); r2[7] = m
     assert run(r2, cols, order)[0] == _lib.MVUS_E_INVALID and b'outside' in lib.mvus_last_error(None)
+
+
+def test_two_level_separator_elimination_algebra():
+    """The algebra behind the time shards' two-level elimination of the separators (mvus_amd/csrc/ba_schur_hip.hip.h: k_sep2_build /
+    k_sep2_reduce / k_sep2_finish), in numpy on a random SPD block-tridiagonal system: every "rank" solves its LOCAL separators with the
+    two coupling blocks as extra right-hand-side columns, contributes T'_G, U'_G, R'_G, T'_K, R'_K to the (world - 1)-node cut system,
+    the cut system is solved once, and X_L = Y - V X_G - W X_K.  Must equal the direct solve -- including ranks without local separators
+    (the cuts couple directly), the first rank (no ghost) and the last (no cut)."""
+    rng = np.random.default_rng(5)
+    s3, ncols = 9, 7
+    for sizes in ([3, 2, 4], [2, 0, 3, 1], [1, 1], [0, 2, 0], [5]):          # local separators per rank; ranks 0 .. W-2 are followed by a cut
+        W = len(sizes)
+        kinds = []                                                  # chain order: rank r's local nodes, then its cut (except the last rank)
+        for r, k in enumerate(sizes):
+            kinds += [('L', r)] * k + ([('K', r)] if r + 1 < W else [])
+        m = len(kinds)
+        if m == 0:
+            continue
+        U = [rng.normal(size=(s3, s3)) * 0.3 for _ in range(m - 1)]          # U[q] = T(q, q + 1)
+        T = [np.eye(s3) * 4 + (lambda a: a @ a.T * 0.1)(rng.normal(size=(s3, s3))) for _ in range(m)]
+        R = [rng.normal(size=(s3, ncols)) for _ in range(m)]
+        A = np.zeros((m * s3, m * s3))
+        for q in range(m):
+            A[q * s3:(q + 1) * s3, q * s3:(q + 1) * s3] = T[q]
+            if q + 1 < m:
+                A[q * s3:(q + 1) * s3, (q + 1) * s3:(q + 2) * s3] = U[q]
+                A[(q + 1) * s3:(q + 2) * s3, q * s3:(q + 1) * s3] = U[q].T
+        X_direct = np.linalg.solve(A, np.vstack(R))
+        # the cut system, summed over the "ranks"
+        ncut = W - 1
+        T2 = [np.zeros((s3, s3)) for _ in range(ncut)]
+        U2 = [np.zeros((s3, s3)) for _ in range(ncut)]
+        R2 = [np.zeros((s3, ncols)) for _ in range(ncut)]
+        idx = {kind: q for q, kind in enumerate(kinds) if kind[0] == 'K'}
+        local = {}
+        for r, k in enumerate(sizes):
+            g = idx.get(('K', r - 1))                                # the ghost: the cut closing rank r - 1
+            c = idx.get(('K', r))                                    # this rank's own cut
+            q0 = (g + 1) if g is not None else 0
+            # a cut separator's T and R are the sum of what its two neighbouring ranks contribute (here: half each, any split works)
+            if k == 0:
+                if g is not None:
+                    T2[r - 1] += 0.5 * T[g]; R2[r - 1] += 0.5 * R[g]
+                    if c is not None:
+                        U2[r - 1] += U[g]                            # no local separator: the two cuts couple directly
+                if c is not None:
+                    T2[r] += 0.5 * T[c]; R2[r] += 0.5 * R[c]
+                continue
+            L = np.zeros((k * s3, k * s3))
+            for j in range(k):
+                L[j * s3:(j + 1) * s3, j * s3:(j + 1) * s3] = T[q0 + j]
+                if j + 1 < k:
+                    L[j * s3:(j + 1) * s3, (j + 1) * s3:(j + 2) * s3] = U[q0 + j]
+                    L[(j + 1) * s3:(j + 2) * s3, j * s3:(j + 1) * s3] = U[q0 + j].T
+            rhs = np.zeros((k * s3, ncols + 2 * s3))
+            rhs[:, :ncols] = np.vstack(R[q0:q0 + k])
+            if g is not None:
+                rhs[:s3, ncols:ncols + s3] = U[g].T                  # C_LG: T(s_1, G) = U_G^T in s_1's rows
+            if c is not None:
+                rhs[-s3:, ncols + s3:] = U[q0 + k - 1]               # C_LK: T(s_k, K) = U_{s_k} in s_k's rows
+            YVW = np.linalg.solve(L, rhs)
+            local[r] = (q0, k, YVW)
+            Y1, V1, W1 = YVW[:s3, :ncols], YVW[:s3, ncols:ncols + s3], YVW[:s3, ncols + s3:]
+            Yk, Wk = YVW[-s3:, :ncols], YVW[-s3:, ncols + s3:]
+            if g is not None:
+                T2[r - 1] += 0.5 * T[g] - U[g] @ V1
+                R2[r - 1] += 0.5 * R[g] - U[g] @ Y1
+                if c is not None:
+                    U2[r - 1] += -U[g] @ W1
+            if c is not None:
+                T2[r] += 0.5 * T[c] - U[q0 + k - 1].T @ Wk
+                R2[r] += 0.5 * R[c] - U[q0 + k - 1].T @ Yk
+        X = np.zeros_like(X_direct)
+        if ncut:
+            C = np.zeros((ncut * s3, ncut * s3))
+            for q in range(ncut):
+                C[q * s3:(q + 1) * s3, q * s3:(q + 1) * s3] = T2[q]
+                if q + 1 < ncut:
+                    C[q * s3:(q + 1) * s3, (q + 1) * s3:(q + 2) * s3] = U2[q]
+                    C[(q + 1) * s3:(q + 2) * s3, q * s3:(q + 1) * s3] = U2[q].T
+            Xc = np.linalg.solve(C, np.vstack(R2))
+            for r in range(ncut):
+                X[idx[('K', r)] * s3:(idx[('K', r)] + 1) * s3] = Xc[r * s3:(r + 1) * s3]
+        for r, (q0, k, YVW) in local.items():
+            XL = YVW[:, :ncols].copy()
+            if ('K', r - 1) in idx:
+                XL -= YVW[:, ncols:ncols + s3] @ X[idx[('K', r - 1)] * s3:(idx[('K', r - 1)] + 1) * s3]
+            if ('K', r) in idx:
+                XL -= YVW[:, ncols + s3:] @ X[idx[('K', r)] * s3:(idx[('K', r)] + 1) * s3]
+            X[q0 * s3:(q0 + k) * s3] = XL
+        np.testing.assert_allclose(X, X_direct, rtol=0, atol=1e-11 * np.abs(X_direct).max())
