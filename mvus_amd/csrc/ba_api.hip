@@ -119,8 +119,8 @@ struct HipBackend {
     span = dalloc<int32_t>(hp.M); pat0 = dalloc<int32_t>(hp.M); rspan = dalloc<int32_t>(hp.M);
     mJ = dalloc<double>((size_t)36 * hp.T); mctrl = dalloc<int32_t>((size_t)3 * hp.T);
     x_cur = dalloc<double>(hp.n); f_cur = alloc(hp.m);      // (from the pool: an LM solve swaps it with its trial buffer)
-    partials = dalloc<double>(2048); scal_dev = dalloc<double>(16);
-    MVUS_HIP(hipHostMalloc(reinterpret_cast<void**>(&scal_host), 32 * sizeof(double), hipHostMallocMapped));      // [16]: the start mark of fetch_poll_begin
+    partials = dalloc<double>(2048); scal_dev = dalloc<double>(32);
+    MVUS_HIP(hipHostMalloc(reinterpret_cast<void**>(&scal_host), 32 * sizeof(double), hipHostMallocMapped));      // [kMarkSlot]: the start mark of fetch_poll_begin
     for (int i = 0; i < 32; ++i) scal_host[i] = 0.0;
     if (hipHostGetDevicePointer(reinterpret_cast<void**>(&scal_map), scal_host, 0) != hipSuccess) scal_map = nullptr;
     stage_cap = std::max<int64_t>(hp.n, 1024);
@@ -312,7 +312,8 @@ struct HipBackend {
   // fetch_poll_begin: the same without an event (hipEventRecord costs a 6 us bubble between the two kernels it separates): the FIRST
   // kernel enqueued after the point writes *mark = value when it starts -- it cannot start before everything in front of it has
   // finished and released its writes -- and the fetch spins on that word in mapped memory.
-  static constexpr int kMarkSlot = 16;
+  static constexpr int kMarkSlot = 24;
+  static constexpr int kFailSumSlot = 16;  // [16], [17]: a time shard's failure flags summed over the ranks (= lm_scalars() + 8: fetched with the trial's scalars)
   double fetch_seq = 0.0;
   bool fetch_polled = false;
   bool fetch_poll_begin(double** mark, double* value) {
@@ -390,8 +391,10 @@ struct HipBackend {
     std::swap(f_dev, f_new);
   }
   void lm_trial(const double* x, const double* p, const double* lb, const double* ub, const double* g, const double* D,
-                const int* fail, double* x_new, double* out, double* gnorm_out, double* x_mirror, double* pn2 = nullptr, double delta = 0.0) {
+                const int* fail, double* x_new, double* out, double* gnorm_out, double* x_mirror, double* pn2 = nullptr, double delta = 0.0,
+                const double* fail_sum = nullptr) {
     touch(x_new);
+    double* const fail_out = scal_out() + kFailSumSlot;
     // trust region: |p|^2 first (two small launches), the trial kernel then cuts the step back to delta along its direction
     double* pn2_dev = nullptr;
     if (pn2) { if (!tr_pn2) tr_pn2 = dalloc<double>(1); pn2_dev = tr_pn2; dot_into(p, p, hp.n, pn2_dev); }
@@ -399,12 +402,12 @@ struct HipBackend {
     // launch for their partials take 10 us.  Beyond 128k parameters: the one-launch form with the last-workgroup hand-over.
     const unsigned g2 = hp.n > 2048 && hp.n <= (1 << 17) ? (unsigned)std::min<int64_t>(32, (hp.n + 1023) / 1024) : 0u;
     if (g2 > 1) {
-      hipLaunchKernelGGL(k_lm_trial, dim3(g2), dim3(1024), 0, stream, (int)hp.n, x, p, lb, ub, g, D, fail, x_new, out, gnorm_out, partials, (unsigned*)nullptr, x_mirror, (const double*)pn2_dev, delta);
+      hipLaunchKernelGGL(k_lm_trial, dim3(g2), dim3(1024), 0, stream, (int)hp.n, x, p, lb, ub, g, D, fail, x_new, out, gnorm_out, partials, (unsigned*)nullptr, x_mirror, (const double*)pn2_dev, delta, fail_sum, fail_out);
       hipLaunchKernelGGL(k_lm_trial_sum, dim3(1), dim3(64), 0, stream, (int)g2, partials, out, gnorm_out, dp, (const double*)x_new, cams);
       cams_for = x_new;                      // decoded by that launch: the trial residual needs no k_cam_states
       return;
     }
-    hipLaunchKernelGGL(k_lm_trial, dim3(lm_grid()), dim3(1024), 0, stream, (int)hp.n, x, p, lb, ub, g, D, fail, x_new, out, gnorm_out, partials, lm_counter, x_mirror, (const double*)pn2_dev, delta);
+    hipLaunchKernelGGL(k_lm_trial, dim3(lm_grid()), dim3(1024), 0, stream, (int)hp.n, x, p, lb, ub, g, D, fail, x_new, out, gnorm_out, partials, lm_counter, x_mirror, (const double*)pn2_dev, delta, fail_sum, fail_out);
   }
   // (spinning on a sentinel in the mapped scalars instead of hipStreamSynchronize was measured in round 5: 0.509 against 0.509 ms per
   // step, three A/B pairs on one box -- the runtime's own wait already spins; not kept)
@@ -497,7 +500,8 @@ struct HipBackend {
   }
   // clr / clr_len: storage to zero beside the evaluation (HipSchur's normal-equation blocks); returns false if it was not done
   bool residual_sq(const double* x, double* f, double* out, double* clr = nullptr, int64_t clr_len = 0) {
-    if (allreduce) { residual(x, f); dot_m_into(f, f, out); return false; }
+    // (observation shards off the root rank: the replicated motion rows are rows of zeros there -- the general path)
+    if (allreduce && hp.T > 0 && !(is_root || tshard.on)) { residual(x, f); dot_m_into(f, f, out); return false; }
     RoctxRange range("mvus residual");
     const int mb = hp.T > 0 ? (int)((hp.T + kThreads - 1) / kThreads) : 0;
     const size_t need = (size_t)dp.n_chunks + mb + 1;
@@ -530,6 +534,7 @@ struct HipBackend {
     if (host_sum) { sq_pend[set].slot = out - scal_out(); sq_pend[set].n = dp.n_chunks + mb; }      // added up by fetch()
     else if (dp.n_chunks + mb > 0) hipLaunchKernelGGL(k_dot_final, dim3(1), dim3(kThreads), 0, stream, dp.n_chunks + mb, sq_part, out);
     else MVUS_HIP(hipMemsetAsync(out, 0, sizeof(double), stream));
+    reduce(out, 1);                  // (sharded: the workgroups' partial sums replace a pass of k_dot_partial over f; the ranks' sums are added here)
     MVUS_HIP(hipGetLastError());
     return cleared;
   }

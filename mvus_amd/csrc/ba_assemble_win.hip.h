@@ -492,9 +492,13 @@ void k_assemble_windows(DevProblem dp, NEView ne, WinView wv, const CamState* __
 // index order (four interleaved chains per entry and group, the groups combined in order) -- plain stores, nothing to clear.
 template <int B>
 __global__ __launch_bounds__(1024) void k_cam_block_sum(int C, int nwin, const double* __restrict__ Apart, NEView ne, int G = 1,
-                                                        const double* __restrict__ band_part = nullptr) {
+                                                        const double* __restrict__ band_part = nullptr, double* __restrict__ zero = nullptr,
+                                                        long long zero_len = 0) {
   constexpr int PSZ = (B + 1) * (B + 2) / 2, kLanes = PSZ <= 64 ? 64 : 256, kGroups = 1024 / kLanes;
   __shared__ double part[kGroups][kLanes];
+  // (a time shard: the part of the packed head that is SUMMED over the ranks without being written in full by this rank -- the other
+  // cuts' halo blocks, diag(H) and g of the columns outside the slice -- starts from zero; cleared here instead of by a launch of its own)
+  for (long long i = blockIdx.x * 1024LL + threadIdx.x; i < zero_len; i += gridDim.x * 1024LL) zero[i] = 0.0;
   if ((int)blockIdx.x >= C) {                               // workgroups past the cameras (G > 1): the camera groups' band rows and gradients, added in group order
     const long long len = (long long)ne.N * (3 + ne.W * 9), i = ((long long)blockIdx.x - C) * 1024 + threadIdx.x;
     if (i < len) {

@@ -1187,13 +1187,17 @@ __global__ __launch_bounds__(1024) void k_lm_trial(int n, const double* __restri
                                                    const double* __restrict__ ub, const double* __restrict__ g, const double* __restrict__ D,
                                                    const int* __restrict__ fail, double* __restrict__ x_new, double* __restrict__ out,
                                                    double* __restrict__ gnorm_out, double* part, unsigned* counter, double* __restrict__ x_mirror,
-                                                   const double* __restrict__ pn2 = nullptr, double delta = 0.0) {
+                                                   const double* __restrict__ pn2 = nullptr, double delta = 0.0,
+                                                   const double* __restrict__ fail_sum = nullptr, double* __restrict__ fail_out = nullptr) {
   // trust region (mvus_solve_opts.lm_trust_radius): a step longer than delta is cut back to delta along its direction
   const double cut = (pn2 != nullptr && delta > 0.0 && *pn2 > delta * delta) ? delta / sqrt(*pn2) : 1.0;
   if (pn2 != nullptr && blockIdx.x == 0 && threadIdx.x == 0) out[5] = *pn2;      // slot 7 of the driver's scalars
   // also delivers the projected gradient norm of k_lm_gnorm (x, g and the bounds are read here anyway): slot 4 = max
   __shared__ double red[5][16];
-  const bool dead = fail[0] != 0;
+  // (time shards: fail_sum = the two failure flags of the solve SUMMED over the ranks -- they travelled with the step; any rank's failure
+  // stops every rank's step, and the sums go on to the host with the trial's scalars)
+  const bool dead = fail[0] != 0 || (fail_sum != nullptr && fail_sum[0] != 0.0);
+  if (fail_sum != nullptr && blockIdx.x == 0 && threadIdx.x < 2) fail_out[threadIdx.x] = fail_sum[threadIdx.x];
   double s[5] = {dead ? __longlong_as_double(0x7ff8000000000000LL) : 0.0, 0.0, 0.0, 0.0, 0.0};
   for (int i0 = blockIdx.x * 1024 + threadIdx.x; i0 < n; i0 += gridDim.x * 1024 * 4) {      // batches of 4: loads first, see k_lm_gnorm
     double xv[4], pv[4], gv[4], lo[4], hi[4], dv[4];

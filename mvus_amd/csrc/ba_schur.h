@@ -98,7 +98,7 @@ SolveResult lm_schur(B& be, Schur& sc, double* x, const std::vector<double>& lb,
   const double* lbp = be.lb_ptr();
   const double* ubp = be.ub_ptr();
   double* S = be.lm_scalars();   // [0] |f|^2 at x0, [1] projected |g|_inf, [2..5] trial scalars, [6] |f(x_trial)|^2
-  double hs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  double hs[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
   if (!resumed) be.upload(x_dev, x, n);
   // A resumed point may come with more than its coordinates: the previous solve left f(x) in the residual buffer (its last accepted
@@ -132,11 +132,11 @@ SolveResult lm_schur(B& be, Schur& sc, double* x, const std::vector<double>& lb,
     Delta = opt.lm_trust_radius;
     if (!(Delta > 0)) { double s2 = 0; for (int64_t i = 0; i < n; ++i) s2 += x[i] * x[i]; Delta = s2 > 0 ? std::sqrt(s2) : 1.0; }
   }
-  const int nfetch_all = tr ? 8 : 7;
+  const int nfetch_all = sc.fail_in_scalars() ? 10 : (tr ? 8 : 7);      // (time shards: + the solve's failure flags, summed over the ranks)
   auto launch_trial = [&](double lambda) {
-    sc.solve_async(lambda);
+    sc.solve_async(lambda, true);
     be.lm_trial(x_dev, sc.step_ptr(), lbp, ubp, sc.grad_ptr(), sc.diag_ptr(), sc.fail_ptr(), xt_dev, S + 2, S + 1, be.mirror_dev(mir_trial),
-                tr ? S + 7 : nullptr, Delta);
+                tr ? S + 7 : nullptr, Delta, sc.fail_sum_ptr());
     be.residual_sq(xt_dev, f_new, S + 6);
     // Most trials are accepted, and an accepted trial is followed by the linearisation at its point: that linearisation is enqueued NOW,
     // into the solver's second set of blocks, behind a marker the fetch below waits for instead of the whole stream -- the GPU works on
@@ -145,7 +145,7 @@ SolveResult lm_schur(B& be, Schur& sc, double* x, const std::vector<double>& lb,
     spec_live = false;
     if (sc.spec_ok(opt.jac_mode)) { be.fetch_enqueue(S, nfetch_all); sc.linearize_spec(be, xt_dev, f_new, opt.jac_mode); spec_live = true; }      // (marks where the fetch stops waiting)
   };
-  const int nfetch = tr ? 8 : 7;
+  const int nfetch = nfetch_all;
 
   double lambda = std::max(opt.lm_lambda0 > 0 ? opt.lm_lambda0 : 1e-4, opt.lm_lambda_min), nu = opt.lm_nu0 > 0 ? opt.lm_nu0 : 2.0;
   const double lambda_min = opt.lm_lambda_min;
@@ -303,7 +303,9 @@ struct HostSchur {
   template <class B> void linearize_spec(B&, const double*, double*, int) {}
   void adopt_spec() {}
   void drop_spec() {}
-  void solve_async(double lambda) { fail = solve(lambda, pstep) ? 0 : 1; if (fail) pstep.assign(n, 0.0); }
+  void solve_async(double lambda, bool = false) { fail = solve(lambda, pstep) ? 0 : 1; if (fail) pstep.assign(n, 0.0); }
+  bool fail_in_scalars() const { return false; }
+  const double* fail_sum_ptr() const { return nullptr; }
   static double damp_scale(double hii) { return hii > 0 ? hii : 1.0; }
   bool solve(double lambda, std::vector<double>& p) {
     std::vector<double> L(H);

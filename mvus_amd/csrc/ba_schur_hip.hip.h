@@ -784,7 +784,7 @@ __global__ __launch_bounds__(64) void k_band_solve_generic(int n, int BW, int nc
 
 // D = diag(H) in x order (0 -> 1 so that unused columns stay put), and g in x order
 __device__ __forceinline__ void ne_diag_grad_entry(const DevProblem& dp, const NEView& ne, int raw, int idx, double* __restrict__ D, double* __restrict__ gx) {
-  // raw (time shards): this rank's PARTIAL diagonal, to be summed over the ranks before k_diag_fix replaces zeros by 1
+  // raw (time shards): this rank's PARTIAL diagonal, to be summed over the ranks before the unpacking k_halo_copy replaces zeros by 1
   if (idx < ne.CB) {
     const int c = idx / ne.B, k = idx % ne.B;
     const double h = ne.A[((long long)c * ne.B + k) * ne.B + k];
@@ -803,19 +803,24 @@ __device__ __forceinline__ void ne_diag_grad_entry(const DevProblem& dp, const N
 __global__ void k_ne_diag_grad(DevProblem dp, NEView ne, int raw, double* __restrict__ D, double* __restrict__ gx) {
   ne_diag_grad_entry(dp, ne, raw, blockIdx.x * blockDim.x + threadIdx.x, D, gx);
 }
-__global__ void k_diag_fix(long long n, double* __restrict__ D) {
-  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-  if (i < n && !(D[i] > 0.0)) D[i] = 1.0;
-}
 
 // ---- time shards: the blocks of the control points within `halo` of a cut receive rows from both neighbours --------
 // Packed exchange buffer: [boundary b = 1 .. world-1][2*halo control points from cut_b - halo][3*CB cross | W*9 band | 3 grad].
 // pack: this rank's partial blocks of its (<= 2) boundaries, everything else stays zero; after the sum over the ranks
 // unpack overwrites the local blocks with the totals.
+// (round 6: the launch also carries what used to be two launches of their own either side of the sum -- pack: this rank's PARTIAL
+// diag(H) and g in x order (k_ne_diag_grad, raw); unpack: zeros of the summed diagonal -> 1)
 __global__ void k_halo_copy(NEView ne, int halo, int nb, const int* __restrict__ bcut, const int* __restrict__ bidx, int Ntot,
-                            double* __restrict__ buf, int unpack) {
+                            double* __restrict__ buf, int unpack, DevProblem dp, double* __restrict__ D, double* __restrict__ gx, long long n) {
   const int per = 3 * ne.CB + ne.W * 9 + 3;
   const long long total = (long long)nb * 2 * halo * per;
+  if (!unpack) {
+    for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < ne.CB + ne.N3; e += (long long)gridDim.x * blockDim.x)
+      ne_diag_grad_entry(dp, ne, 1, (int)e, D, gx);
+  } else {
+    for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x)
+      if (!(D[e] > 0.0)) D[e] = 1.0;
+  }
   for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
     const int f = (int)(e % per);
     const int ci = (int)((e / per) % (2 * halo)), b = (int)(e / ((long long)per * 2 * halo));
@@ -836,17 +841,17 @@ __global__ void k_halo_copy(NEView ne, int halo, int nb, const int* __restrict__
 // A hand-over time-out of the reduced solve (fail[0] = kFailHandoverCode, ba_rcs.hip.h) is not a numerical failure: it travels as a
 // value no sum of the other codes (<= 8 each, <= 64 ranks) can reach, and EVERY rank then reports the time-out -- all of them repeat
 // the solve on the separate-launch route together (HipSchur::retry_same), none raises the damping alone.
+// (round 6: packed by the last kernel of the solve, k_back_substitute; the sum is read where it lands -- by the trial kernel, which takes
+// no step when any rank failed, and by the host through the driver's scalars: no pack / unpack launches, no copy of its own)
 constexpr int kFailHandoverCode = 4;
 constexpr double kFailHandoverSum = 1048576.0;
-__global__ void k_fail_pack(const int* __restrict__ fail, double* __restrict__ tail) {
-  if (threadIdx.x < 2) tail[threadIdx.x] = (threadIdx.x == 0 && fail[0] == kFailHandoverCode) ? kFailHandoverSum : (double)fail[threadIdx.x];
-}
-__global__ void k_fail_unpack(const double* __restrict__ tail, int* __restrict__ fail) {
-  if (threadIdx.x == 0 && tail[0] >= kFailHandoverSum) { fail[0] = kFailHandoverCode; return; }
-  if (threadIdx.x < 2 && tail[threadIdx.x] != 0.0 && fail[threadIdx.x] == 0) fail[threadIdx.x] = threadIdx.x == 0 ? 8 : 1;
-}
-__global__ void k_sum_slabs(long long count, int nslab, const double* __restrict__ Gp, double* __restrict__ G0) {
+constexpr double kFailSpanSum = 4096.0;                 // flag bit 2 (a span table that does not belong to the point) in the sum of the second flags
+inline int fail_sum_code(double t0) { return t0 >= kFailHandoverSum ? kFailHandoverCode : (t0 != 0.0 ? 8 : 0); }
+inline int fail_sum_flag(double t1) { return (t1 >= kFailSpanSum ? 2 : 0) | (std::fmod(t1, kFailSpanSum) != 0.0 ? 1 : 0); }
+// (zero / nzero: the step vector every rank then writes its rows of, before it is summed -- cleared here, not by a launch of its own)
+__global__ void k_sum_slabs(long long count, int nslab, const double* __restrict__ Gp, double* __restrict__ G0, double* __restrict__ zero, long long nzero) {
   const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i < nzero) zero[i] = 0.0;
   if (i >= count) return;
   double t = 0.0;
   for (int sl = 0; sl < nslab; ++sl) t += Gp[sl * count + i];
@@ -1766,10 +1771,16 @@ __global__ __launch_bounds__(256) void k_sep_bcr_rhs(PartView pv, int ncols) {
 // as before.  The correction term of a cut separator splits by itself: rank r adds (its part of R_K)^T X_K, rank r+1 (its part)^T X_K.
 template <int S3>
 __global__ __launch_bounds__(256) void k_sep2_build(PartView pv, int q0, int k, int has_ghost, int has_cut, int ncols, double* __restrict__ Rloc,
-                                                    double* __restrict__ CG, double* __restrict__ CK) {
+                                                    double* __restrict__ CG, double* __restrict__ CK, int corr_q0 = 0, int corr_rows = 0, int CB = 0) {
   constexpr int SS = S3 * S3;
   const int nc2 = ncols + 2 * S3;
   const long long total = (long long)k * S3 * nc2;
+  // (the correction rows of the Schur product need this rank's parts of the reduced right-hand sides R_S as they are BEFORE the solve
+  // overwrites them: their camera columns go to pv.Dl here -- a rectangle copy of its own until round 6)
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < (long long)corr_rows * CB; e += (long long)gridDim.x * blockDim.x) {
+    const long long r = (long long)corr_q0 * S3 + e / CB;
+    pv.Dl[r * CB + e % CB] = pv.R[r * ncols + e % CB];
+  }
   for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total + 2 * SS; e += (long long)gridDim.x * blockDim.x) {
     if (e >= total) {                                   // the two coupling blocks, saved: the cyclic reduction overwrites U of its last node
       const int t = (int)(e - total), which = t / SS, idx = t % SS;
@@ -1785,46 +1796,46 @@ __global__ __launch_bounds__(256) void k_sep2_build(PartView pv, int q0, int k, 
     Rloc[e] = v;
   }
 }
-// the rank's contribution to the cut system (cut node c closes rank c: G = node rank - 1, K = node rank); cutbuf = [T' | U' | R'] zeroed
+// the rank's contribution to the cut system (cut node c closes rank c: G = node rank - 1, K = node rank); EVERY entry of
+// cutbuf = [T' | U' | R'] is written -- zeros for the nodes of other ranks (a memset of its own until round 6)
 template <int S3>
 __global__ __launch_bounds__(256) void k_sep2_reduce(PartView pv, int q0, int k, int has_ghost, int has_cut, int rank, int ncut, int ncols,
                                                      const double* __restrict__ Rloc, const double* __restrict__ CG, const double* __restrict__ CK,
                                                      double* __restrict__ cutbuf) {
   constexpr int SS = S3 * S3;
   const int nc2 = ncols + 2 * S3;
-  double* T2 = cutbuf;
-  double* U2 = cutbuf + (long long)ncut * SS;
-  double* R2 = cutbuf + 2LL * ncut * SS;
-  const int per = 2 * SS + S3 * ncols;                  // outputs of one side: T' (SS), U' (SS, ghost side only), R' (S3 ncols)
-  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < 2 * per; e += gridDim.x * blockDim.x) {
-    const int side = e / per, o = e % per;              // 0: the ghost G, 1: the cut K
-    if (side == 0 ? !has_ghost : !has_cut) continue;
-    const int node = side == 0 ? rank - 1 : rank;
-    const long long gq = side == 0 ? q0 - 1 : q0 + k;
-    if (o < SS) {                                       // T'
-      const int a = o / S3, b = o % S3;
-      double v = pv.T[gq * SS + o];
-      if (k > 0) {
-        if (side == 0) { for (int c = 0; c < S3; ++c) v -= CG[a * S3 + c] * Rloc[((long long)(0) * S3 + c) * nc2 + ncols + b]; }                   // U_G V_1
-        else { for (int c = 0; c < S3; ++c) v -= CK[c * S3 + a] * Rloc[((long long)(k - 1) * S3 + c) * nc2 + ncols + S3 + b]; }                    // U_{s_k}^T W_k
+  const long long nT = (long long)ncut * SS, total = 2 * nT + (long long)ncut * S3 * ncols;
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const int sec = e < nT ? 0 : (e < 2 * nT ? 1 : 2);                         // T', U', R'
+    const long long w = e - (sec == 0 ? 0 : (sec == 1 ? nT : 2 * nT));
+    const int node = (int)(w / (sec == 2 ? S3 * ncols : SS)), o = (int)(w % (sec == 2 ? S3 * ncols : SS));
+    const int side = (has_ghost && node == rank - 1) ? 0 : ((has_cut && node == rank) ? 1 : -1);      // 0: the ghost G, 1: the cut K
+    double v = 0.0;
+    if (side >= 0) {
+      const long long gq = side == 0 ? q0 - 1 : q0 + k;
+      if (sec == 0) {                                   // T'
+        const int a = o / S3, b = o % S3;
+        v = pv.T[gq * SS + o];
+        if (k > 0) {
+          if (side == 0) { for (int c = 0; c < S3; ++c) v -= CG[a * S3 + c] * Rloc[((long long)(0) * S3 + c) * nc2 + ncols + b]; }                   // U_G V_1
+          else { for (int c = 0; c < S3; ++c) v -= CK[c * S3 + a] * Rloc[((long long)(k - 1) * S3 + c) * nc2 + ncols + S3 + b]; }                    // U_{s_k}^T W_k
+        }
+      } else if (sec == 1) {                            // U' = T'(G, K): through the local chain, or -- no local separator -- the direct coupling
+        if (side == 0 && has_cut) {
+          const int a = o / S3, b = o % S3;
+          if (k > 0) { for (int c = 0; c < S3; ++c) v -= CG[a * S3 + c] * Rloc[((long long)(0) * S3 + c) * nc2 + ncols + S3 + b]; }                  // -U_G W_1
+          else v = pv.U[gq * SS + o];
+        }
+      } else {                                          // R'
+        const int a = o / ncols, col = o % ncols;
+        v = pv.R[(gq * S3 + a) * ncols + col];
+        if (k > 0) {
+          if (side == 0) { for (int c = 0; c < S3; ++c) v -= CG[a * S3 + c] * Rloc[((long long)(0) * S3 + c) * nc2 + col]; }
+          else { for (int c = 0; c < S3; ++c) v -= CK[c * S3 + a] * Rloc[((long long)(k - 1) * S3 + c) * nc2 + col]; }
+        }
       }
-      T2[(long long)node * SS + o] = v;
-    } else if (o < 2 * SS) {                            // U' = T'(G, K): through the local chain, or -- no local separator -- the direct coupling
-      if (side != 0 || !has_cut) continue;
-      const int oo = o - SS, a = oo / S3, b = oo % S3;
-      double v = 0.0;
-      if (k > 0) { for (int c = 0; c < S3; ++c) v -= CG[a * S3 + c] * Rloc[((long long)(0) * S3 + c) * nc2 + ncols + S3 + b]; }                    // -U_G W_1
-      else v = pv.U[gq * SS + oo];
-      U2[(long long)node * SS + oo] = v;
-    } else {                                            // R'
-      const int oo = o - 2 * SS, a = oo / ncols, col = oo % ncols;
-      double v = pv.R[(gq * S3 + a) * ncols + col];
-      if (k > 0) {
-        if (side == 0) { for (int c = 0; c < S3; ++c) v -= CG[a * S3 + c] * Rloc[((long long)(0) * S3 + c) * nc2 + col]; }
-        else { for (int c = 0; c < S3; ++c) v -= CK[c * S3 + a] * Rloc[((long long)(k - 1) * S3 + c) * nc2 + col]; }
-      }
-      R2[((long long)node * S3 + a) * ncols + col] = v;
     }
+    cutbuf[e] = v;
   }
 }
 // X_L = Y - V X_G - W X_K and the two cut solutions, into the globally numbered R
@@ -2414,7 +2425,8 @@ __global__ __launch_bounds__(kGjThreads) void k_gj_step(int nn, int kb, const do
 // p (x order) from p_c and p_s = -(z_g + Z_E p_c)
 __global__ __launch_bounds__(kThreads) void k_back_substitute(DevProblem dp, NEView ne, int ncols, int row_lo, int row_hi, int cams,
                                                               const double* __restrict__ Z, const double* __restrict__ pc, double* __restrict__ px,
-                                                              int* __restrict__ fail = nullptr, int* __restrict__ fail_mirror = nullptr) {
+                                                              int* __restrict__ fail = nullptr, int* __restrict__ fail_mirror = nullptr,
+                                                              double* __restrict__ fail_tail = nullptr) {
   // one wavefront per owned spline row: lanes stride over the row of Z (coalesced), then a shuffle reduction
   const int lane = threadIdx.x & 63;
   // last kernel of a solve: the two failure flags go to the host's mapped copy here (a device-to-host copy of 8 bytes is a launch)
@@ -2424,6 +2436,9 @@ __global__ __launch_bounds__(kThreads) void k_back_substitute(DevProblem dp, NEV
     int v = fail[threadIdx.x];
     if (threadIdx.x == 0 && fail[2] != 0) { v = kFailHandoverCode; fail[0] = v; }
     if (fail_mirror != nullptr) fail_mirror[threadIdx.x] = v;
+    // time shards: the flags travel with the step through its sum over the ranks (fail_tail = px + n; decoded by fail_sum_code / fail_sum_flag)
+    if (fail_tail != nullptr) fail_tail[threadIdx.x] = threadIdx.x == 0 ? (v == kFailHandoverCode ? kFailHandoverSum : (double)v)
+                                                                        : (double)(v & 1) + ((v & 2) ? kFailSpanSum : 0.0);
   }
   const int r = row_lo + blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
   if (blockIdx.x == 0 && cams)
@@ -2961,7 +2976,8 @@ struct HipSchur {
       ne_cleared = false; last_atomic = false;
       // (a time shard: the part of the packed head that is SUMMED over the ranks without being written in full here -- the halo exchange
       // buffer of the other ranks' cuts, diag(H) and g of the columns outside this slice -- starts from zero: ~1 MB, not the 36 MB of blocks)
-      if (shard) be.fill(NE + nAg, 0.0, (int64_t)(halo_count + 2 * (size_t)be.hp.n));
+      double* const zr = shard ? NE + nAg : (double*)nullptr;               // (cleared by k_cam_block_sum below: no launch of its own)
+      const long long zn = shard ? (long long)(halo_count + 2 * (size_t)be.hp.n) : 0;
       if (span_held) wv.span = span_held;
       else {
         if (be.rspan_for != x_fused) be.residual(x_fused, const_cast<double*>(f_dev));      // (f_dev holds f(x) already: the same values again)
@@ -2971,11 +2987,11 @@ struct HipSchur {
       if (be.hp.calib) {
         const unsigned sumg = (unsigned)be.hp.C + (wv.G > 1 ? (unsigned)(((long long)ne.N * (3 + ne.W * 9) + 1023) / 1024) : 0u);
         hipLaunchKernelGGL(k_assemble_windows<18>, dim3(wv.nwin * wv.G), dim3(kWinThreads), win_lds, be.stream, be.dp, ne, wv, be.cams, x_fused);
-        hipLaunchKernelGGL(k_cam_block_sum<18>, dim3(sumg), dim3(1024), 0, be.stream, be.hp.C, wv.nwin, wv.Apart, ne, wv.G, (const double*)wv.band_part);
+        hipLaunchKernelGGL(k_cam_block_sum<18>, dim3(sumg), dim3(1024), 0, be.stream, be.hp.C, wv.nwin, wv.Apart, ne, wv.G, (const double*)wv.band_part, zr, zn);
       } else {
         const unsigned sumg = (unsigned)be.hp.C + (wv.G > 1 ? (unsigned)(((long long)ne.N * (3 + ne.W * 9) + 1023) / 1024) : 0u);
         hipLaunchKernelGGL(k_assemble_windows<9>, dim3(wv.nwin * wv.G), dim3(kWinThreads), win_lds, be.stream, be.dp, ne, wv, be.cams, x_fused);
-        hipLaunchKernelGGL(k_cam_block_sum<9>, dim3(sumg), dim3(1024), 0, be.stream, be.hp.C, wv.nwin, wv.Apart, ne, wv.G, (const double*)wv.band_part);
+        hipLaunchKernelGGL(k_cam_block_sum<9>, dim3(sumg), dim3(1024), 0, be.stream, be.hp.C, wv.nwin, wv.Apart, ne, wv.G, (const double*)wv.band_part, zr, zn);
       }
       motion_rows(f_dev);
       MVUS_HIP(hipGetLastError());
@@ -3023,11 +3039,10 @@ struct HipSchur {
       // ranks), so they go into the same all-reduce, before the halo blocks are completed
       double* hb = NE + nAg;
       const int halo = be.tshard.halo;
-      if (nbound > 0) hipLaunchKernelGGL(k_halo_copy, dim3(256), dim3(256), 0, be.stream, ne, halo, nbound, halo_tables, halo_tables + nbound, Ntot, hb, 0);
-      hipLaunchKernelGGL(k_ne_diag_grad, dim3((tot + 255) / 256), dim3(256), 0, be.stream, be.dp, ne, 1, D, gx);
+      (void)tot;
+      hipLaunchKernelGGL(k_halo_copy, dim3(256), dim3(256), 0, be.stream, ne, halo, nbound, halo_tables, halo_tables + nbound, Ntot, hb, 0, be.dp, D, gx, (long long)be.hp.n);
       be.reduce(NE, nAg + halo_count + 2 * (size_t)be.hp.n);
-      if (nbound > 0) hipLaunchKernelGGL(k_halo_copy, dim3(256), dim3(256), 0, be.stream, ne, halo, nbound, halo_tables, halo_tables + nbound, Ntot, hb, 1);
-      hipLaunchKernelGGL(k_diag_fix, dim3((unsigned)((be.hp.n + 255) / 256)), dim3(256), 0, be.stream, (long long)be.hp.n, D);
+      hipLaunchKernelGGL(k_halo_copy, dim3(256), dim3(256), 0, be.stream, ne, halo, nbound, halo_tables, halo_tables + nbound, Ntot, hb, 1, be.dp, D, gx, (long long)be.hp.n);
     } else {
       be.reduce(NE, ne_count);          // observation shards: one sum-all-reduce of the packed normal-equation blocks per iteration
       diag_pending = true;              // D and g (x order) are written by the next solve's first kernel, or by flush_diag()
@@ -3054,6 +3069,7 @@ struct HipSchur {
   const double* step_ptr() const { return px; }
   const int* fail_ptr() const { return fail; }
   bool solve_ok() const {                 // valid after the stream has been synchronised (the driver's fetch)
+    if (shard) { fail_host[0] = fail_sum_code(be.scal_host[be.kFailSumSlot]); fail_host[1] = fail_sum_flag(be.scal_host[be.kFailSumSlot + 1]); }
     if (fail_host[1] & 2) throw HipError{"fused assembly: the span table does not belong to the point being linearised (internal error)"};
     if (fail_host[1] != 0) {
       be.reshard_flag = true;        // (the LM driver hands the point it has reached back to the caller: MVUS_E_RESHARD)
@@ -3096,13 +3112,12 @@ struct HipSchur {
         const int q0 = pv.q_off, cq0 = q0 - has_ghost, cqn = n_own_sep + has_ghost;
         // (no back-correction: the correction rows of the Schur product need this rank's parts of the reduced right-hand sides R_S as
         // they are before the solve overwrites them)
-        if (ncorr > 0) MVUS_HIP(hipMemcpy2DAsync(pv.Dl + (size_t)cq0 * pv.s3 * ne.CB, (size_t)ne.CB * sizeof(double), pv.R + (size_t)cq0 * pv.s3 * ncols,
-                                                 (size_t)ncols * sizeof(double), (size_t)ne.CB * sizeof(double), (size_t)cqn * pv.s3, hipMemcpyDeviceToDevice, be.stream));
         const int nc2 = ncols + 2 * S3T;
         double *CG = CGK, *CK = CGK + (size_t)S3T * S3T;
         {
-          const long long tot = (long long)k_loc * S3T * nc2 + 2 * S3T * S3T;
-          hipLaunchKernelGGL(k_sep2_build<S3T>, dim3((unsigned)std::min<long long>(2048, (tot + 255) / 256)), dim3(256), 0, be.stream, pv, q0, k_loc, has_ghost, has_cut, ncols, Rloc, CG, CK);
+          const long long tot = std::max((long long)k_loc * S3T * nc2 + 2 * S3T * S3T, ncorr > 0 ? (long long)cqn * S3T * ne.CB : 0LL);
+          hipLaunchKernelGGL(k_sep2_build<S3T>, dim3((unsigned)std::min<long long>(2048, (tot + 255) / 256)), dim3(256), 0, be.stream, pv, q0, k_loc, has_ghost, has_cut, ncols, Rloc, CG, CK,
+                             cq0, ncorr > 0 ? cqn * S3T : 0, ne.CB);
         }
         if (k_loc > 0) {
           PartView pl = pv;                  // the local chain: nodes q0 .. q0 + k - 1 of the global arrays, renumbered from 0
@@ -3115,8 +3130,7 @@ struct HipSchur {
           if (bcr_cols_loc == kBcrCols) hipLaunchKernelGGL((k_sep_bcr_rhs<S3T, kBcrCols>), dim3((nc2 + kBcrCols - 1) / kBcrCols), dim3(256), bcr_lds_loc, be.stream, pl, nc2);
           else hipLaunchKernelGGL((k_sep_bcr_rhs<S3T, 1>), dim3(nc2), dim3(256), bcr_lds_loc, be.stream, pl, nc2);
         }
-        MVUS_HIP(hipMemsetAsync(cutbuf, 0, cut_count * sizeof(double), be.stream));
-        hipLaunchKernelGGL(k_sep2_reduce<S3T>, dim3((unsigned)((2 * (2 * S3T * S3T + S3T * ncols) + 255) / 256)), dim3(256), 0, be.stream, pv, q0, k_loc, has_ghost, has_cut,
+        hipLaunchKernelGGL(k_sep2_reduce<S3T>, dim3((unsigned)((cut_count + 255) / 256)), dim3(256), 0, be.stream, pv, q0, k_loc, has_ghost, has_cut,
                            be.tshard.rank, ncut, ncols, (const double*)Rloc, (const double*)CG, (const double*)CK, cutbuf);
         be.reduce(cutbuf, cut_count);        // every rank now holds the cut system
         {
@@ -3180,7 +3194,11 @@ struct HipSchur {
     }
   }
 
-  void solve_async(double lambda) {
+  // time shards: the failure flags of a solve are SUMMED with the step (px[n], px[n + 1]); the LM driver's trial kernel forwards the sums
+  // to the scalars its fetch brings to the host (trial_follows), any other caller gets them by a copy to the same two slots
+  bool fail_in_scalars() const { return shard; }
+  const double* fail_sum_ptr() const { return shard ? px + be.hp.n : (const double*)nullptr; }
+  void solve_async(double lambda, bool trial_follows = false) {
     RoctxRange range("mvus schur solve");
     const long long nLb = (long long)ne.N3 * (BW + 1);
     const long long nZ = (long long)ne.N3 * ncols;          // >= nLb: one launch covers both passes
@@ -3216,7 +3234,7 @@ struct HipSchur {
     int nsl = nslab;
     if (shard) {
       const long long cnt = (long long)ne.CB * ncols;
-      hipLaunchKernelGGL(k_sum_slabs, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, be.stream, cnt, nslab, G, G0);
+      hipLaunchKernelGGL(k_sum_slabs, dim3((unsigned)((std::max<long long>(cnt, be.hp.n) + 255) / 256)), dim3(256), 0, be.stream, cnt, nslab, G, G0, px, (long long)be.hp.n);
       be.reduce(G0, (size_t)cnt);                   // the Schur complement contributions of all time slices
       Gsum = G0; nsl = 1;
     }
@@ -3251,21 +3269,19 @@ struct HipSchur {
         std::swap(a, b);
       }
     }
-    if (shard) MVUS_HIP(hipMemsetAsync(px, 0, be.hp.n * sizeof(double), be.stream));
     const int nrows = row_hi - row_lo, per = kThreads / 64;
     hipLaunchKernelGGL(k_back_substitute, dim3((unsigned)std::max(1, (nrows + per - 1) / per)), dim3(kThreads), 0, be.stream, be.dp, ne, ncols,
-                       row_lo, row_hi, (int)(!shard || be.tshard.rank == 0), Z, pc, px, fail, (!shard && be.scal_direct()) ? fail_map : (int*)nullptr);
+                       row_lo, row_hi, (int)(!shard || be.tshard.rank == 0), Z, pc, px, fail, (!shard && be.scal_direct()) ? fail_map : (int*)nullptr,
+                       shard ? px + be.hp.n : (double*)nullptr);
     if (!wide && ncorr > 0) {                          // the interiors' rows were computed from uncorrected columns: one vector is corrected here
       if (BW == 11) hipLaunchKernelGGL(k_back_correct<9>, dim3(pv.P), dim3(256), 0, be.stream, be.dp, ne, pv, ncols, (const double*)pc, px);
       else hipLaunchKernelGGL(k_back_correct<15>, dim3(pv.P), dim3(256), 0, be.stream, be.dp, ne, pv, ncols, (const double*)pc, px);
     }
-    if (shard) {
-      hipLaunchKernelGGL(k_fail_pack, dim3(1), dim3(64), 0, be.stream, fail, px + be.hp.n);
-      be.reduce(px, (size_t)be.hp.n + 2);             // every rank's part of the step (+ failure flags)
-      hipLaunchKernelGGL(k_fail_unpack, dim3(1), dim3(64), 0, be.stream, px + be.hp.n, fail);
-    }
+    if (shard) be.reduce(px, (size_t)be.hp.n + 2);             // every rank's part of the step (+ failure flags, packed by k_back_substitute)
     MVUS_HIP(hipGetLastError());
-    if (shard || !be.scal_direct() || !fail_map) MVUS_HIP(hipMemcpyAsync(fail_host, fail, 2 * sizeof(int), hipMemcpyDeviceToHost, be.stream));
+    if (shard) {
+      if (!trial_follows) MVUS_HIP(hipMemcpyAsync(be.scal_host + be.kFailSumSlot, px + be.hp.n, 2 * sizeof(double), hipMemcpyDeviceToHost, be.stream));
+    } else if (!be.scal_direct() || !fail_map) MVUS_HIP(hipMemcpyAsync(fail_host, fail, 2 * sizeof(int), hipMemcpyDeviceToHost, be.stream));
   }
 };
 

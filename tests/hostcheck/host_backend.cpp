@@ -62,7 +62,7 @@ struct HostBackend {
   bool residual_sq(const double* x, double* f, double* out, double* = nullptr, int64_t = 0) { residual(x, f); dot_m_into(f, f, out); return false; }
   void lm_gnorm(const double* x, const double* lb, const double* ub, const double* g, double* out) { *out = mvus::lm_gnorm_host(hp.n, x, lb, ub, g); }
   void lm_trial(const double* x, const double* p, const double* lb, const double* ub, const double* g, const double* D,
-                const int* fail, double* x_new, double* out, double* gn, double*, double* pn2 = nullptr, double delta = 0.0) {
+                const int* fail, double* x_new, double* out, double* gn, double*, double* pn2 = nullptr, double delta = 0.0, const double* = nullptr) {
     double cut = 1.0;
     if (pn2) { double s = 0; for (int64_t i = 0; i < hp.n; ++i) s += p[i] * p[i]; *pn2 = s; if (delta > 0 && s > delta * delta) cut = delta / std::sqrt(s); }
     mvus::lm_trial_host(hp.n, x, p, lb, ub, g, D, *fail, x_new, out, gn, cut);
