@@ -70,4 +70,8 @@ python bench.py --config 4 --solver trf --steps 3 --warmup 1 --no-cpu-baseline -
 # round 6: one rank of an 8-rank time-sharded run, alone on the GPU (per-kernel times behind the multi-GPU model of DESIGN section 6);
 # (window length, camera groups) sweep of the window-major assembly
 bash tools/micro/shard_rank_probe.sh 2>&1 | grep -v amdgpu > $O/${R}_shard_rank_probe_world8.txt
+{ echo; echo "== one iteration of the rank in launch order: configs[3] cut over 8, rank 3 (the last fill is the probe's rejected trial, not part of an accepted iteration)"; bash tools/micro/shard_rank_timeline.sh 3 1;
+  echo; echo "== the same for the weak-scaled default"; bash tools/micro/shard_rank_timeline.sh 2 8; } 2>&1 | grep -v amdgpu >> $O/${R}_shard_rank_probe_world8.txt
+/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -w -o /tmp/fp64_clock tools/micro/fp64_clock.hip 2>/dev/null && /tmp/fp64_clock > $O/${R}_fp64_clock.txt 2>&1
+/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -w -o /tmp/bcr_rhs_probe tools/micro/bcr_rhs_probe.hip 2>/dev/null && /tmp/bcr_rhs_probe > $O/${R}_bcr_rhs_probe.txt 2>&1
 bash tools/micro/win_group_sweep.sh 2>&1 | grep -v amdgpu > $O/${R}_window_groups_sweep.txt
