@@ -3032,14 +3032,12 @@ struct HipSchur {
   }
   void assemble(BE&, const double* f_dev, const double* x_fused = nullptr, const int32_t* span_held = nullptr) {
     assemble_local(f_dev, x_fused, span_held);
-    const int tot = ne.CB + ne.N3;          // every entry of x is a camera column or a control-point coordinate
     if (shard) {
       // time shard: sum the camera blocks and the blocks of the control points near a cut; the cross block never moves
       // ... and diag(H), g in x order: every rank adds its PARTIAL sums (rows of a control point near a cut sit on two
       // ranks), so they go into the same all-reduce, before the halo blocks are completed
       double* hb = NE + nAg;
       const int halo = be.tshard.halo;
-      (void)tot;
       hipLaunchKernelGGL(k_halo_copy, dim3(256), dim3(256), 0, be.stream, ne, halo, nbound, halo_tables, halo_tables + nbound, Ntot, hb, 0, be.dp, D, gx, (long long)be.hp.n);
       be.reduce(NE, nAg + halo_count + 2 * (size_t)be.hp.n);
       hipLaunchKernelGGL(k_halo_copy, dim3(256), dim3(256), 0, be.stream, ne, halo, nbound, halo_tables, halo_tables + nbound, Ntot, hb, 1, be.dp, D, gx, (long long)be.hp.n);
