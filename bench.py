@@ -179,6 +179,11 @@ def main():
     for _ in range(args.warmup):
         r = handle.solve(x, solver=solver, jac_mode=jac_mode, max_nfev=2, return_fun=False, ties='canonical')
         x = r.x
+    # (like timeit: no garbage-collector pass inside the timed regions -- a generation-2 collection of the interpreter's heap is milliseconds,
+    # twenty steps are eight)
+    import gc
+    gc.collect()
+    gc.disable()
     barrier()
     t0 = time.perf_counter()
     cost0 = None
@@ -212,6 +217,7 @@ def main():
                       'what': 'one mvus_ba_solve with max_nfev = steps + 1 continuing from the timed steps; a rejected trial is not followed by a '
                               'linearisation (trials > linearisations - 1 then)'}
 
+    gc.enable()
     # roofline of the dominant kernel: residual + Jacobian, HIP events on the kernel's own stream
     handle.set_x(x)
     t_rj = handle.time_kernel(ba.KERNEL_RESIDUAL_JACOBIAN, 100)          # outputs rotate over >= 1 GiB: every launch goes to HBM
