@@ -601,12 +601,14 @@ def test_time_shards_are_cut_again_when_the_time_stamps_drift():
     np.testing.assert_allclose(r0.x, ref.x, rtol=0, atol=1e-6 * max(1.0, np.abs(ref.x).max()))
 
 
-@pytest.mark.parametrize('what', ['pivot', 'reshard', 'span'])
+@pytest.mark.parametrize('what', ['pivot', 'handover', 'reshard', 'span'])
 def test_failure_flags_of_one_rank_reach_every_rank_with_the_step(what):
     """The two failure flags of a solve travel behind the step through its sum over the ranks (packed by k_back_substitute, read where the
     sum lands by the trial kernel and -- with the trial's scalars -- by the host; round 6: no pack / unpack launches).  A flag raised on ONE
     rank must be every rank's: here the sum of the first solve's step buffer gets a flag added as if rank 1 had raised it
       pivot   (slot 0): a lost pivot -> both ranks take no step, raise the damping together and go on in lockstep, bit for bit;
+      handover (slot 0, travels as 2^20): a hand-over time-out inside the reduced solve -> both ranks repeat the solve at the SAME damping on
+              the separate-launch route, whose results are the in-launch route's bits: the solve ends where an undisturbed one ends;
       reshard (slot 1, bit 1): both ranks hand the point back with MVUS_E_RESHARD;
       span    (slot 1, bit 2 travels as 4096): both ranks report the internal error -- none waits for the other in the next collective."""
     import threading
@@ -619,49 +621,57 @@ def test_failure_flags_of_one_rank_reach_every_rank_with_the_step(what):
     prob, x0 = mp.problem_from_scene(sc)
     opts = _lib.default_opts(_lib.SOLVER_LM_SCHUR, _lib.JAC_ANALYTIC, 5)
     n = prob.n_params
-    slot, value = {'pivot': (0, 1.0), 'reshard': (1, 1.0), 'span': (1, 4096.0)}[what]
-    barrier = threading.Barrier(world)
-    bufs, total, results, errors, injected, steps = [None] * world, [None], [None] * world, [None] * world, [0], [0]
+    slot, value = {'pivot': (0, 1.0), 'handover': (0, 1048576.0), 'reshard': (1, 1.0), 'span': (1, 4096.0)}[what]
 
-    def make_cb(rank):
-        def cb(ptr, count, stream):
-            t = torch.as_tensor(_DeviceDoubles(ptr, count), device='cuda:0')
-            torch.cuda.synchronize()
-            bufs[rank] = t
-            barrier.wait(60)
-            if rank == 0:
-                total[0] = torch.stack(bufs).sum(0)
-                if count == n + 2:
-                    steps[0] += 1
-                    if not injected[0]:
-                        total[0][n + slot] += value
-                        injected[0] = 1
+    def sharded_run(inject):
+        barrier = threading.Barrier(world)
+        bufs, total, results, errors, injected, steps = [None] * world, [None], [None] * world, [None] * world, [0 if inject else 1], [0]
+        return _flag_run(barrier, bufs, total, results, errors, injected, steps)
+
+    def _flag_run(barrier, bufs, total, results, errors, injected, steps):
+
+        def make_cb(rank):
+            def cb(ptr, count, stream):
+                t = torch.as_tensor(_DeviceDoubles(ptr, count), device='cuda:0')
                 torch.cuda.synchronize()
-            barrier.wait(60)
-            t.copy_(total[0])
-            torch.cuda.synchronize()
-            barrier.wait(60)
-        return cb
+                bufs[rank] = t
+                barrier.wait(60)
+                if rank == 0:
+                    total[0] = torch.stack(bufs).sum(0)
+                    if count == n + 2:
+                        steps[0] += 1
+                        if not injected[0]:
+                            total[0][n + slot] += value
+                            injected[0] = 1
+                    torch.cuda.synchronize()
+                barrier.wait(60)
+                t.copy_(total[0])
+                torch.cuda.synchronize()
+                barrier.wait(60)
+            return cb
 
-    def run(rank):
-        try:
-            shard, keep, cuts = prob.shard_time(rank, world, x0)
-            h = BAHandle(shard, device=0)
-            h.set_time_shard(rank, world, cuts)
-            h.set_allreduce(make_cb(rank), is_root=(rank == 0))
+        def run(rank):
             try:
-                results[rank] = h.solve(x0, opts=opts)
-            except Exception as e:
+                shard, keep, cuts = prob.shard_time(rank, world, x0)
+                h = BAHandle(shard, device=0)
+                h.set_time_shard(rank, world, cuts)
+                h.set_allreduce(make_cb(rank), is_root=(rank == 0))
+                try:
+                    results[rank] = h.solve(x0, opts=opts)
+                except Exception as e:
+                    errors[rank] = e
+                h.close()
+            except Exception as e:                      # pragma: no cover
                 errors[rank] = e
-            h.close()
-        except Exception as e:                      # pragma: no cover
-            errors[rank] = e
-            barrier.abort()
+                barrier.abort()
 
-    threads = [threading.Thread(target=run, args=(r,), daemon=True) for r in range(world)]
-    [t.start() for t in threads]
-    [t.join(180) for t in threads]
-    assert not any(t.is_alive() for t in threads)          # nobody is left waiting in a collective
+        threads = [threading.Thread(target=run, args=(r,), daemon=True) for r in range(world)]
+        [t.start() for t in threads]
+        [t.join(180) for t in threads]
+        assert not any(t.is_alive() for t in threads)          # nobody is left waiting in a collective
+        return results, errors, injected, steps
+
+    results, errors, injected, steps = sharded_run(True)
     assert injected[0] == 1
     if what == 'pivot':
         assert errors == [None, None], errors
@@ -672,6 +682,14 @@ def test_failure_flags_of_one_rank_reach_every_rank_with_the_step(what):
         with BAHandle(prob) as h0:
             ref = h0.solve(x0, opts=opts)
         assert a.cost < ref.initial_cost and abs(a.cost - ref.cost) < 0.05 * ref.cost      # (another damping sequence, the same basin)
+    elif what == 'handover':
+        assert errors == [None, None], errors
+        plain, perr, _, psteps = sharded_run(False)
+        assert perr == [None, None], perr
+        for r in range(world):
+            np.testing.assert_array_equal(results[r].x, plain[r].x)
+            assert (results[r].nfev, results[r].njev, results[r].cost) == (plain[r].nfev, plain[r].njev, plain[r].cost)
+        assert steps[0] == psteps[0] + 1                   # one solve was repeated, nothing else changed
     elif what == 'reshard':
         assert all(isinstance(e, ReshardNeeded) for e in errors), errors
     else:
